@@ -1,0 +1,308 @@
+"""Host-side mirror of the reference's operator interface for the feature hot path, on top of the C ABI
+(include/d2fe.h, libd2fe_hip.so).
+
+Mirrors (names / argument meaning / error behaviour):
+  * SuperPointConfig + SuperPoint.build()/infer()   d2frontend/include/d2frontend/CNN/superpoint_tensorrt.h:17-48
+  * matchKNN(desc_a, desc_b, knn_match_ratio, pts_a, pts_b, search_local_dist)   d2frontend/include/d2frontend/feature_matcher.h:6-11
+  * cv::BFMatcher(NORM_L2, crossCheck=True).match    loop_cam.cpp:167-170
+  * getFeatureHalfImg                                d2frontend/src/d2featuretracker.cpp:1051-1075
+
+There is NO CPU fallback: if libd2fe_hip.so is missing or no GPU is visible these calls raise.
+"""
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from .weights import SP_LAYERS
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libd2fe_hip.so")
+
+POSTPROC_B, POSTPROC_A = 0, 1
+PREC_F32, PREC_F16X2 = 0, 1
+
+
+class D2FEError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("d2fe error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Config(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device_id", C.c_int32), ("max_width", C.c_int32),
+                ("max_height", C.c_int32), ("max_batch", C.c_int32), ("max_keypoints", C.c_int32),
+                ("remove_borders", C.c_int32), ("keypoint_threshold", C.c_float), ("postproc", C.c_int32),
+                ("nms_dist", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
+class _ConvParams(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32),
+                ("ksize", C.c_int32)]
+
+
+class _SPWeights(C.Structure):
+    _fields_ = [("layer", _ConvParams * 12)]
+
+
+class _MatchBatch(C.Structure):
+    _fields_ = [("d_a", C.c_void_p), ("d_b", C.c_void_p), ("d_pts_a", C.c_void_p), ("d_pts_b", C.c_void_p),
+                ("d_a_off", C.c_void_p), ("d_b_off", C.c_void_p), ("d_a_cnt", C.c_void_p), ("d_b_cnt", C.c_void_p),
+                ("npairs", C.c_int32), ("dim", C.c_int32), ("max_n", C.c_int32), ("mode", C.c_int32),
+                ("ratio", C.c_double), ("radius", C.c_double),
+                ("d_q_idx", C.c_void_p), ("d_t_idx", C.c_void_p), ("d_dist", C.c_void_p), ("d_n_out", C.c_void_p)]
+
+
+_lib = None
+
+EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_create", "d2fe_destroy",
+           "d2fe_load_superpoint", "d2fe_superpoint_extract", "d2fe_superpoint_extract_batch",
+           "d2fe_superpoint_extract_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device",
+           "d2fe_half_image_filter", "d2fe_debug_read", "d2fe_sync"]
+
+
+def load_library():
+    """dlopen the C-ABI library.  Raises if it has not been built (python -m d2slam_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise D2FEError(-100, "libd2fe_hip.so not built: run `python __graft_entry__.py` or d2slam_amd/build.py "
+                                  "(no CPU fallback exists)")
+        lib = C.CDLL(LIB_PATH)
+        lib.d2fe_last_error.restype = C.c_char_p
+        lib.d2fe_version.restype = C.c_char_p
+        lib.d2fe_debug_read.restype = C.c_long
+        lib.d2fe_destroy.restype = None
+        lib.d2fe_default_config.restype = None
+        lib.d2fe_superpoint_extract_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                      C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        lib.d2fe_superpoint_extract_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                       C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       C.c_int, C.c_void_p, C.c_void_p]
+        lib.d2fe_superpoint_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        lib.d2fe_match_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double,
+                                       C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p]
+        lib.d2fe_match_crosscheck.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        lib.d2fe_match_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.d2fe_half_image_filter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        lib.d2fe_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+        lib.d2fe_create.argtypes = [C.c_void_p, C.c_void_p]
+        lib.d2fe_destroy.argtypes = [C.c_void_p]
+        lib.d2fe_load_superpoint.argtypes = [C.c_void_p, C.c_void_p]
+        lib.d2fe_sync.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise D2FEError(rc, load_library().d2fe_last_error().decode())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+@dataclass
+class SuperPointConfig:
+    """Field-for-field SuperPointConfig (superpoint_tensorrt.h:17-33); TensorRT-only fields are kept for
+    source compatibility and ignored (onnx_path/engine_path/tensor names/dla_core/fp_16)."""
+    max_keypoints: int = 100
+    remove_borders: int = 1
+    dla_core: int = 0
+    fp_16: int = 0
+    input_width: int = 640
+    input_height: int = 480
+    superpoint_pca_dims: int = -1
+    keypoint_threshold: float = 0.015
+    input_tensor_names: List[str] = field(default_factory=lambda: ["input"])
+    output_tensor_names: List[str] = field(default_factory=lambda: ["scores", "descriptors"])
+    onnx_path: str = ""
+    engine_path: str = ""
+    pca_mean_path: str = ""
+    pca_comp_path: str = ""
+    enable_pca: bool = False
+    # device-side additions
+    device_id: int = 0
+    max_batch: int = 2
+    postproc: int = POSTPROC_B
+    nms_dist: int = 10
+    precision: int = PREC_F32
+
+
+class FrontEnd:
+    """One device context (== one LoopCam's networks, loop_cam.cpp:24-70)."""
+
+    def __init__(self, cfg: SuperPointConfig):
+        lib = load_library()
+        c = _Config()
+        lib.d2fe_default_config(C.byref(c))
+        c.device_id = cfg.device_id
+        c.max_width = cfg.input_width
+        c.max_height = cfg.input_height
+        c.max_batch = cfg.max_batch
+        c.max_keypoints = cfg.max_keypoints
+        c.remove_borders = cfg.remove_borders
+        c.keypoint_threshold = cfg.keypoint_threshold
+        c.postproc = cfg.postproc
+        c.nms_dist = cfg.nms_dist
+        c.precision = cfg.precision
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        _check(lib.d2fe_create(C.byref(c), C.byref(self._h)))
+        self._lib = lib
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.d2fe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def load_superpoint(self, weights):
+        """weights: {layer: (W [cout,cin,k,k], b [cout])} for the 12 layers of superpoint.ipynb:306-321."""
+        sw = _SPWeights()
+        keep = []
+        for i, name in enumerate(SP_LAYERS):
+            W, b = weights[name]
+            W = np.ascontiguousarray(W, np.float32); b = np.ascontiguousarray(b, np.float32)
+            keep += [W, b]
+            sw.layer[i].weight = W.ctypes.data
+            sw.layer[i].bias = b.ctypes.data
+            sw.layer[i].cout, sw.layer[i].cin, sw.layer[i].ksize = W.shape[0], W.shape[1], W.shape[2]
+        _check(self._lib.d2fe_load_superpoint(self._h, C.byref(sw)))
+
+    # ---- extractor ---------------------------------------------------------------------------------------------
+    def extract_batch(self, images, cap=None):
+        """images: u8 [n,H,W].  Returns list of (kps [k,2], scores [k], desc [k,256])."""
+        images = np.ascontiguousarray(images, np.uint8)
+        if images.ndim == 2:
+            images = images[None]
+        n, H, W = images.shape
+        cap = cap or self.cfg.max_keypoints
+        kps = np.zeros((n, cap, 2), np.float32); sc = np.zeros((n, cap), np.float32)
+        desc = np.zeros((n, cap, 256), np.float32); cnt = np.zeros(n, np.int32)
+        _check(self._lib.d2fe_superpoint_extract_batch(self._h, _ptr(images), n, W, H, W, H * W, _ptr(kps), _ptr(sc),
+                                                       _ptr(desc), cap, _ptr(cnt)))
+        return [(kps[i, :cnt[i]].copy(), sc[i, :cnt[i]].copy(), desc[i, :cnt[i]].copy()) for i in range(n)]
+
+    def extract_device(self, d_gray, n, W, H, d_kps, d_scores, d_desc, d_idx, cap, d_n, stream=None, stride=None,
+                       image_stride=None):
+        """Device-resident form; arguments are raw device addresses (ints)."""
+        _check(self._lib.d2fe_superpoint_extract_device(self._h, d_gray, n, W, H, stride or W, image_stride or H * W,
+                                                        d_kps, d_scores, d_desc, d_idx, cap, d_n, stream))
+
+    def debug_read(self, name, shape):
+        out = np.empty(shape, np.float32)
+        r = self._lib.d2fe_debug_read(self._h, name.encode(), _ptr(out), out.nbytes)
+        if r < 0:
+            _check(int(r))
+        if r != out.nbytes:
+            raise D2FEError(-1, "debug_read size mismatch %d vs %d" % (r, out.nbytes))
+        return out
+
+    def sync(self):
+        _check(self._lib.d2fe_sync(self._h))
+
+    # ---- matcher -------------------------------------------------------------------------------------------------
+    def match_knn(self, desc_a, desc_b, knn_match_ratio=0.8, pts_a=None, pts_b=None, search_local_dist=-1.0):
+        a = np.ascontiguousarray(desc_a, np.float32); b = np.ascontiguousarray(desc_b, np.float32)
+        na = a.shape[0] if a.ndim == 2 else 0
+        nb = b.shape[0] if b.ndim == 2 else 0
+        dim = a.shape[1] if na else (b.shape[1] if nb else 256)
+        cap = max(na, 1)
+        q = np.zeros(cap, np.int32); t = np.zeros(cap, np.int32); d = np.zeros(cap, np.float32); n = C.c_int(0)
+        pa = np.ascontiguousarray(pts_a, np.float32) if pts_a is not None and len(pts_a) else None
+        pb = np.ascontiguousarray(pts_b, np.float32) if pts_b is not None and len(pts_b) else None
+        _check(self._lib.d2fe_match_knn(self._h, _ptr(a), na, _ptr(b), nb, dim, float(knn_match_ratio), _ptr(pa), _ptr(pb),
+                                        float(search_local_dist), _ptr(q), _ptr(t), _ptr(d), cap, C.byref(n)))
+        return q[:n.value].copy(), t[:n.value].copy(), d[:n.value].copy()
+
+    def match_crosscheck(self, desc_a, desc_b):
+        a = np.ascontiguousarray(desc_a, np.float32); b = np.ascontiguousarray(desc_b, np.float32)
+        na, nb = a.shape[0], b.shape[0]
+        dim = a.shape[1]
+        cap = max(na, 1)
+        q = np.zeros(cap, np.int32); t = np.zeros(cap, np.int32); d = np.zeros(cap, np.float32); n = C.c_int(0)
+        _check(self._lib.d2fe_match_crosscheck(self._h, _ptr(a), na, _ptr(b), nb, dim, _ptr(q), _ptr(t), _ptr(d), cap,
+                                               C.byref(n)))
+        return q[:n.value].copy(), t[:n.value].copy(), d[:n.value].copy()
+
+    def match_batch_device(self, d_a, d_b, d_a_off, d_b_off, d_a_cnt, d_b_cnt, npairs, dim, max_n, d_q, d_t, d_dist,
+                           d_n, mode=0, ratio=0.8, radius=-1.0, d_pts_a=None, d_pts_b=None, stream=None):
+        mb = _MatchBatch(d_a, d_b, d_pts_a, d_pts_b, d_a_off, d_b_off, d_a_cnt, d_b_cnt, npairs, dim, max_n, mode,
+                         ratio, radius, d_q, d_t, d_dist, d_n)
+        _check(self._lib.d2fe_match_batch_device(self._h, C.byref(mb), stream))
+
+
+class SuperPoint:
+    """Mirror of class SuperPoint (superpoint_tensorrt.h:36-93): build() then infer()."""
+
+    def __init__(self, super_point_config: SuperPointConfig, weights=None):
+        self.super_point_config_ = super_point_config
+        self._weights = weights
+        self._fe: Optional[FrontEnd] = None
+
+    def build(self) -> bool:
+        """SuperPoint::build (superpoint_tensorrt.cpp:22-107): returns False instead of raising, like the reference."""
+        try:
+            self._fe = FrontEnd(self.super_point_config_)
+            if self._weights is None:
+                raise D2FEError(-3, "no weights given (the reference would fail to parse onnx_path)")
+            self._fe.load_superpoint(self._weights)
+            return True
+        except D2FEError as e:
+            self.last_error = str(e)
+            self._fe = None
+            return False
+
+    def infer(self, image):
+        """bool SuperPoint::infer(const cv::Mat&, vector<Point2f>& keypoints, vector<float>& descriptors,
+        vector<float>& scores) (superpoint_tensorrt.cpp:161-183).  Returns (ok, keypoints [k,2], descriptors
+        flat [k*256], scores [k]); on failure all three are empty, as the reference clears them."""
+        empty = (False, np.zeros((0, 2), np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32))
+        if self._fe is None:
+            return empty
+        try:
+            (kps, sc, desc), = self._fe.extract_batch(np.asarray(image)[None])
+            return True, kps, desc.reshape(-1), sc
+        except D2FEError as e:
+            self.last_error = str(e)
+            return empty
+
+    @property
+    def frontend(self):
+        return self._fe
+
+
+def matchKNN(fe: FrontEnd, desc_a, desc_b, knn_match_ratio=0.8, pts_a=None, pts_b=None, search_local_dist=-1.0):
+    """D2FrontEnd::matchKNN (feature_matcher.cpp:4-42) -> list of (queryIdx, trainIdx, distance)."""
+    q, t, d = fe.match_knn(desc_a, desc_b, knn_match_ratio, pts_a, pts_b, search_local_dist)
+    return list(zip(q.tolist(), t.tolist(), d.tolist()))
+
+
+def get_feature_half_img(pts, desc, require_left, width_undistort, undistort_fov, dims=256):
+    """getFeatureHalfImg (d2featuretracker.cpp:1051-1075): returns (desc_half, pts_new, tmp_to_idx)."""
+    lib = load_library()
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    n = pts.shape[0]
+    m = np.zeros(max(n, 1), np.int32); cnt = C.c_int(0)
+    _check(lib.d2fe_half_image_filter(_ptr(pts), n, int(require_left), int(width_undistort), float(undistort_fov),
+                                      _ptr(m), C.byref(cnt)))
+    idx = m[:cnt.value].copy()
+    desc = np.asarray(desc, np.float32).reshape(-1, dims)
+    return desc[idx].copy(), pts[idx].copy(), idx

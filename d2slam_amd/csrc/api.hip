@@ -1,0 +1,501 @@
+// api.hip -- C ABI (include/d2fe.h) of libd2fe_hip.so: context, device buffers, weight packing and the
+// launch sequence of the SuperPoint / matcher kernels.  Host code only; kernels live in conv.hip,
+// conv_f16.hip, postproc.hip and match.hip.  There is deliberately NO CPU fallback in this library.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/d2fe.h"
+#include "kernels.h"
+
+using namespace d2fe;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+  do {                                                                                                      \
+    hipError_t e_ = (expr);                                                                                 \
+    if (e_ != hipSuccess)                                                                                   \
+      return fail(D2FE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " @" + __FILE__ + ":" + \
+                                    std::to_string(__LINE__));                                              \
+  } while (0)
+
+struct Layer {
+  void* wpack = nullptr;
+  float* bias = nullptr;
+  int cout = 0, cout_pad = 0, cin = 0, ks = 0;
+};
+
+enum { L_1B = 0, L_2A, L_2B, L_3A, L_3B, L_4A, L_4B, L_PADA, L_PB, L_DB, L_COUNT };
+
+struct Tensor {
+  float* p = nullptr;
+  size_t per_img = 0;  // floats per image at max size
+};
+
+}  // namespace
+
+struct d2fe_context {
+  d2fe_config cfg;
+  hipStream_t stream = nullptr;
+  bool sp_loaded = false;
+  float* w1a = nullptr;  // [9][64]
+  float* b1a = nullptr;
+  Layer L[L_COUNT];
+  // activations (NHWC fp32), separate buffer per layer so that d2fe_debug_read can inspect any of them
+  Tensor a1a, a1b, a2a, a2b, a3a, a3b, a4a, a4b, aPD, logits, draw, semi;
+  unsigned long long* cand = nullptr;
+  int* cand_count = nullptr;
+  long cand_cap = 0;
+  // staging for the host-pointer API
+  uint8_t* s_img = nullptr;
+  float *s_kps = nullptr, *s_scores = nullptr, *s_desc = nullptr;
+  int32_t *s_idx = nullptr, *s_n = nullptr;
+  int s_cap = 0;
+  // last call geometry (for debug reads)
+  int last_w = 0, last_h = 0, last_n = 0;
+  // matcher scratch
+  std::mutex match_mu;
+  void* m_buf = nullptr;
+  size_t m_bytes = 0;
+  int32_t* m_cand4 = nullptr;
+  size_t m_cand4_bytes = 0;
+};
+
+namespace {
+
+int alloc_f(Tensor& t, size_t per_img, int batch) {
+  t.per_img = per_img;
+  HIP_TRY(hipMalloc(&t.p, per_img * batch * sizeof(float)));
+  return D2FE_OK;
+}
+
+int upload(const void* src, size_t bytes, void** dst) {
+  HIP_TRY(hipMalloc(dst, bytes));
+  HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return D2FE_OK;
+}
+
+// pack one conv (or a channel-concatenation of convs sharing the input) into the kernel's fragment order
+int pack_layer(d2fe_context* h, Layer& L, const std::vector<const d2fe_conv_params*>& parts, int cout_pad) {
+  const int cin = parts[0]->cin, ks = parts[0]->ksize;
+  int cout = 0;
+  for (auto* p : parts) cout += p->cout;
+  std::vector<float> w((size_t)cout * cin * ks * ks), b(cout_pad, 0.f);
+  size_t wo = 0;
+  int bo = 0;
+  for (auto* p : parts) {
+    const size_t n = (size_t)p->cout * cin * ks * ks;
+    memcpy(w.data() + wo, p->weight, n * sizeof(float));
+    memcpy(b.data() + bo, p->bias, p->cout * sizeof(float));
+    wo += n;
+    bo += p->cout;
+  }
+  L.cout = cout; L.cout_pad = cout_pad; L.cin = cin; L.ks = ks;
+  if (L.wpack) { hipFree(L.wpack); L.wpack = nullptr; }
+  if (L.bias) { hipFree(L.bias); L.bias = nullptr; }
+  int rc;
+  if (h->cfg.precision == D2FE_PREC_F32) {
+    std::vector<float> pk(packed_weight_floats_f32(cout_pad, cin, ks));
+    pack_weights_f32(w.data(), cout, cin, ks, cout_pad, pk.data());
+    rc = upload(pk.data(), pk.size() * sizeof(float), &L.wpack);
+  } else {
+    std::vector<uint16_t> pk(packed_weight_halfs_f16x2(cout_pad, cin, ks));
+    pack_weights_f16x2(w.data(), cout, cin, ks, cout_pad, pk.data());
+    rc = upload(pk.data(), pk.size() * sizeof(uint16_t), &L.wpack);
+  }
+  if (rc) return rc;
+  return upload(b.data(), b.size() * sizeof(float), reinterpret_cast<void**>(&L.bias));
+}
+
+int check_layer(const d2fe_conv_params& p, int cout, int cin, int ks, const char* name) {
+  if (!p.weight || !p.bias || p.cout != cout || p.cin != cin || p.ksize != ks)
+    return fail(D2FE_ERR_INVALID, std::string("superpoint layer ") + name + ": unexpected shape");
+  return D2FE_OK;
+}
+
+// the launch sequence == one TensorRT executeV2 + processOutput of the reference
+int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int stride, size_t image_stride,
+                   float* d_kps, float* d_scores, float* d_desc, int32_t* d_idx, int cap, int32_t* d_n, hipStream_t s) {
+  const int prec = h->cfg.precision;
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8;
+  HIP_TRY(launch_conv1a(d_gray, stride, (long)image_stride, H, W, n, h->w1a, h->b1a, h->a1a.p, s));
+  auto conv = [&](ConvShape shape, const Layer& L, const float* in, int ics, int ico, long iis, float* out, int ocs,
+                  long ois, int hh, int ww, bool pool, bool relu) -> hipError_t {
+    ConvArgs a;
+    a.in = in; a.in_cstride = ics; a.in_coff = ico;
+    a.out = out; a.out_cstride = ocs; a.out_coff = 0;
+    a.cout_real = L.cout; a.wpack = L.wpack; a.bias = L.bias;
+    a.H = hh; a.W = ww; a.n_img = n; a.in_img_stride = iis; a.out_img_stride = ois;
+    return launch_conv(shape, prec, pool, relu, L.cout_pad, a, s);
+  };
+  HIP_TRY(conv(CONV_64_T8x32, h->L[L_1B], h->a1a.p, 64, 0, (long)H * W * 64, h->a1b.p, 64, (long)H2 * W2 * 64, H, W, true, true));
+  HIP_TRY(conv(CONV_64_T8x32, h->L[L_2A], h->a1b.p, 64, 0, (long)H2 * W2 * 64, h->a2a.p, 64, (long)H2 * W2 * 64, H2, W2, false, true));
+  HIP_TRY(conv(CONV_64_T8x32, h->L[L_2B], h->a2a.p, 64, 0, (long)H2 * W2 * 64, h->a2b.p, 64, (long)H4 * W4 * 64, H2, W2, true, true));
+  HIP_TRY(conv(CONV_64_T8x32, h->L[L_3A], h->a2b.p, 64, 0, (long)H4 * W4 * 64, h->a3a.p, 128, (long)H4 * W4 * 128, H4, W4, false, true));
+  HIP_TRY(conv(CONV_128_T4x32, h->L[L_3B], h->a3a.p, 128, 0, (long)H4 * W4 * 128, h->a3b.p, 128, (long)Hc * Wc * 128, H4, W4, true, true));
+  HIP_TRY(conv(CONV_128_T4x16, h->L[L_4A], h->a3b.p, 128, 0, (long)Hc * Wc * 128, h->a4a.p, 128, (long)Hc * Wc * 128, Hc, Wc, false, true));
+  HIP_TRY(conv(CONV_128_T4x16, h->L[L_4B], h->a4a.p, 128, 0, (long)Hc * Wc * 128, h->a4b.p, 128, (long)Hc * Wc * 128, Hc, Wc, false, true));
+  HIP_TRY(conv(CONV_128_T4x16, h->L[L_PADA], h->a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 512, (long)Hc * Wc * 512, Hc, Wc, false, true));
+  HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_PB], h->aPD.p, 512, 0, (long)Hc * Wc * 512, h->logits.p, 65, (long)Hc * Wc * 65, Hc, Wc, false, false));
+  HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_DB], h->aPD.p, 512, 256, (long)Hc * Wc * 512, h->draw.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, false));
+  if (h->cfg.postproc != D2FE_POSTPROC_B) return fail(D2FE_ERR_UNSUPPORTED, "postproc variant A not available in this build");
+  HIP_TRY(launch_softmax_cand(h->logits.p, 65, Hc, Wc, n, h->cfg.keypoint_threshold, h->cfg.remove_borders, h->semi.p,
+                              h->cand, h->cand_count, h->cand_cap, s));
+  HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, W, h->cfg.max_keypoints, cap, d_kps, d_scores, d_idx,
+                          d_n, s));
+  HIP_TRY(launch_sample_b(h->draw.p, 256, 0, Hc, Wc, n, d_kps, d_n, cap, d_desc, s));
+  h->last_w = W; h->last_h = H; h->last_n = n;
+  return D2FE_OK;
+}
+
+int check_geometry(d2fe_context* h, int n, int W, int H, int stride, int cap) {
+  if (!h) return fail(D2FE_ERR_INVALID, "null handle");
+  if (!h->sp_loaded) return fail(D2FE_ERR_NOT_READY, "superpoint weights not loaded");
+  if (n < 1 || n > h->cfg.max_batch) return fail(D2FE_ERR_INVALID, "batch size out of range");
+  if (W < 16 || H < 16 || (W & 7) || (H & 7) || W > h->cfg.max_width || H > h->cfg.max_height || (long)W * H > (long)h->cfg.max_width * h->cfg.max_height)
+    return fail(D2FE_ERR_INVALID, "image size must be a multiple of 8 within the configured maximum");
+  if (stride < W) return fail(D2FE_ERR_INVALID, "stride < width");
+  if (cap < 1) return fail(D2FE_ERR_INVALID, "cap < 1");
+  return D2FE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* d2fe_last_error(void) { return g_err.c_str(); }
+const char* d2fe_version(void) { return "d2fe-hip 0.1 (gfx950)"; }
+
+void d2fe_default_config(d2fe_config* c) {
+  memset(c, 0, sizeof(*c));
+  c->struct_size = (int32_t)sizeof(d2fe_config);
+  c->device_id = 0;
+  c->max_width = 640;
+  c->max_height = 480;
+  c->max_batch = 2;
+  c->max_keypoints = 100;       // SuperPointConfig default, superpoint_tensorrt.h:18
+  c->remove_borders = 1;        // :19
+  c->keypoint_threshold = 0.015f;  // :24
+  c->postproc = D2FE_POSTPROC_B;
+  c->nms_dist = 10;
+  c->precision = D2FE_PREC_F32;
+}
+
+int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
+  if (!cfg || !out) return fail(D2FE_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(d2fe_config)) return fail(D2FE_ERR_INVALID, "d2fe_config size mismatch");
+  if (cfg->max_width < 16 || cfg->max_height < 16 || (cfg->max_width & 7) || (cfg->max_height & 7))
+    return fail(D2FE_ERR_INVALID, "max_width/max_height must be multiples of 8");
+  if (cfg->max_batch < 1) return fail(D2FE_ERR_INVALID, "max_batch < 1");
+  if (cfg->max_keypoints < 1 || cfg->max_keypoints > 1024) return fail(D2FE_ERR_INVALID, "max_keypoints must be in 1..1024");
+  if (cfg->precision != D2FE_PREC_F32 && cfg->precision != D2FE_PREC_F16X2) return fail(D2FE_ERR_INVALID, "bad precision");
+  if (cfg->postproc != D2FE_POSTPROC_B && cfg->postproc != D2FE_POSTPROC_A) return fail(D2FE_ERR_INVALID, "bad postproc");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail(D2FE_ERR_HIP, "no HIP device visible (this library has no CPU fallback)");
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(D2FE_ERR_INVALID, "device_id out of range");
+  HIP_TRY(hipSetDevice(cfg->device_id));
+  d2fe_context* h = new d2fe_context();
+  h->cfg = *cfg;
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const size_t H = cfg->max_height, W = cfg->max_width;
+  const int B = cfg->max_batch;
+  int rc = 0;
+  rc |= alloc_f(h->a1a, H * W * 64, B);
+  rc |= alloc_f(h->a1b, H * W * 16, B);
+  rc |= alloc_f(h->a2a, H * W * 16, B);
+  rc |= alloc_f(h->a2b, H * W * 4, B);
+  rc |= alloc_f(h->a3a, H * W * 8, B);
+  rc |= alloc_f(h->a3b, H * W * 2, B);
+  rc |= alloc_f(h->a4a, H * W * 2, B);
+  rc |= alloc_f(h->a4b, H * W * 2, B);
+  rc |= alloc_f(h->aPD, H * W * 8, B);
+  rc |= alloc_f(h->logits, (H / 8) * (W / 8) * 65, B);
+  rc |= alloc_f(h->draw, H * W * 4, B);
+  rc |= alloc_f(h->semi, H * W, B);
+  if (rc) { d2fe_destroy(h); return D2FE_ERR_HIP; }
+  h->cand_cap = (long)(H * W);
+  HIP_TRY(hipMalloc(&h->cand, sizeof(unsigned long long) * h->cand_cap * B));
+  HIP_TRY(hipMalloc(&h->cand_count, sizeof(int) * B));
+  h->s_cap = 1024;
+  HIP_TRY(hipMalloc(&h->s_img, H * W * B));
+  HIP_TRY(hipMalloc(&h->s_kps, sizeof(float) * 2 * h->s_cap * B));
+  HIP_TRY(hipMalloc(&h->s_scores, sizeof(float) * h->s_cap * B));
+  HIP_TRY(hipMalloc(&h->s_desc, sizeof(float) * 256 * h->s_cap * B));
+  HIP_TRY(hipMalloc(&h->s_idx, sizeof(int32_t) * h->s_cap * B));
+  HIP_TRY(hipMalloc(&h->s_n, sizeof(int32_t) * B));
+  *out = h;
+  return D2FE_OK;
+}
+
+void d2fe_destroy(d2fe_handle h) {
+  if (!h) return;
+  hipSetDevice(h->cfg.device_id);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (Tensor* t : {&h->a1a, &h->a1b, &h->a2a, &h->a2b, &h->a3a, &h->a3b, &h->a4a, &h->a4b, &h->aPD, &h->logits, &h->draw, &h->semi})
+    if (t->p) hipFree(t->p);
+  for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
+  for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->cand_count, (void*)h->s_img, (void*)h->s_kps,
+                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, h->m_buf, (void*)h->m_cand4})
+    if (p) hipFree(p);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int d2fe_load_superpoint(d2fe_handle h, const d2fe_superpoint_weights* w) {
+  if (!h || !w) return fail(D2FE_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  static const struct { const char* name; int cout, cin, ks; } spec[D2FE_SP_NUM_LAYERS] = {
+      {"conv1a", 64, 1, 3},    {"conv1b", 64, 64, 3},   {"conv2a", 64, 64, 3},   {"conv2b", 64, 64, 3},
+      {"conv3a", 128, 64, 3},  {"conv3b", 128, 128, 3}, {"conv4a", 128, 128, 3}, {"conv4b", 128, 128, 3},
+      {"convPa", 256, 128, 3}, {"convPb", 65, 256, 1},  {"convDa", 256, 128, 3}, {"convDb", 256, 256, 1}};
+  for (int i = 0; i < D2FE_SP_NUM_LAYERS; ++i) {
+    int rc = check_layer(w->layer[i], spec[i].cout, spec[i].cin, spec[i].ks, spec[i].name);
+    if (rc) return rc;
+  }
+  h->sp_loaded = false;
+  // conv1a: [64][1][3][3] -> [9][64]
+  {
+    std::vector<float> t(9 * 64);
+    for (int co = 0; co < 64; ++co)
+      for (int k = 0; k < 9; ++k) t[k * 64 + co] = w->layer[0].weight[co * 9 + k];
+    if (h->w1a) { hipFree(h->w1a); h->w1a = nullptr; }
+    if (h->b1a) { hipFree(h->b1a); h->b1a = nullptr; }
+    int rc = upload(t.data(), t.size() * sizeof(float), reinterpret_cast<void**>(&h->w1a));
+    if (rc) return rc;
+    rc = upload(w->layer[0].bias, 64 * sizeof(float), reinterpret_cast<void**>(&h->b1a));
+    if (rc) return rc;
+  }
+  const d2fe_conv_params* l = w->layer;
+  int rc = 0;
+  rc = rc ? rc : pack_layer(h, h->L[L_1B], {&l[1]}, 64);
+  rc = rc ? rc : pack_layer(h, h->L[L_2A], {&l[2]}, 64);
+  rc = rc ? rc : pack_layer(h, h->L[L_2B], {&l[3]}, 64);
+  rc = rc ? rc : pack_layer(h, h->L[L_3A], {&l[4]}, 128);
+  rc = rc ? rc : pack_layer(h, h->L[L_3B], {&l[5]}, 128);
+  rc = rc ? rc : pack_layer(h, h->L[L_4A], {&l[6]}, 128);
+  rc = rc ? rc : pack_layer(h, h->L[L_4B], {&l[7]}, 128);
+  rc = rc ? rc : pack_layer(h, h->L[L_PADA], {&l[8], &l[10]}, 512);  // convPa | convDa share their input
+  rc = rc ? rc : pack_layer(h, h->L[L_PB], {&l[9]}, 128);
+  rc = rc ? rc : pack_layer(h, h->L[L_DB], {&l[11]}, 256);
+  if (rc) return rc;
+  h->sp_loaded = true;
+  return D2FE_OK;
+}
+
+int d2fe_superpoint_extract_device(d2fe_handle h, const uint8_t* d_gray, int n, int width, int height, int stride,
+                                   size_t image_stride, float* d_kps_xy, float* d_scores, float* d_desc,
+                                   int32_t* d_kps_idx, int cap, int32_t* d_n_out, void* stream) {
+  int rc = check_geometry(h, n, width, height, stride, cap);
+  if (rc) return rc;
+  if (!d_gray || !d_kps_xy || !d_scores || !d_desc || !d_n_out) return fail(D2FE_ERR_INVALID, "null device pointer");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  return run_superpoint(h, d_gray, n, width, height, stride, image_stride, d_kps_xy, d_scores, d_desc, d_kps_idx, cap,
+                        d_n_out, s);
+}
+
+int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int height, int stride,
+                                  size_t image_stride, float* kps_xy, float* scores, float* desc, int cap, int* n_out) {
+  if (n_out) for (int i = 0; i < (n > 0 ? n : 0); ++i) n_out[i] = 0;
+  int rc = check_geometry(h, n, width, height, stride, cap);
+  if (rc) return rc;
+  if (!gray || !kps_xy || !scores || !desc || !n_out) return fail(D2FE_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  const int dcap = cap < h->s_cap ? cap : h->s_cap;
+  hipStream_t s = h->stream;
+  // tightly pack rows on upload (stride -> width)
+  if (image_stride == (size_t)stride * height) {
+    HIP_TRY(hipMemcpy2DAsync(h->s_img, width, gray, stride, width, (size_t)height * n, hipMemcpyHostToDevice, s));
+  } else {
+    for (int i = 0; i < n; ++i)
+      HIP_TRY(hipMemcpy2DAsync(h->s_img + (size_t)i * width * height, width, gray + i * image_stride, stride, width, height,
+                               hipMemcpyHostToDevice, s));
+  }
+  rc = run_superpoint(h, h->s_img, n, width, height, width, (size_t)width * height, h->s_kps, h->s_scores, h->s_desc,
+                      h->s_idx, dcap, h->s_n, s);
+  if (rc) return rc;
+  std::vector<int32_t> cnt(n);
+  HIP_TRY(hipMemcpyAsync(cnt.data(), h->s_n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < n; ++i) {
+    const int k = cnt[i];
+    n_out[i] = k;
+    if (k > 0) {
+      HIP_TRY(hipMemcpyAsync(kps_xy + (size_t)i * cap * 2, h->s_kps + (size_t)i * dcap * 2, sizeof(float) * 2 * k, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(scores + (size_t)i * cap, h->s_scores + (size_t)i * dcap, sizeof(float) * k, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(desc + (size_t)i * cap * 256, h->s_desc + (size_t)i * dcap * 256, sizeof(float) * 256 * k, hipMemcpyDeviceToHost, s));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  return D2FE_OK;
+}
+
+int d2fe_superpoint_extract(d2fe_handle h, const uint8_t* gray, int width, int height, int stride, float* kps_xy,
+                            float* scores, float* desc, int cap, int* n_out) {
+  return d2fe_superpoint_extract_batch(h, gray, 1, width, height, stride, (size_t)stride * height, kps_xy, scores, desc,
+                                       cap, n_out);
+}
+
+int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* stream) {
+  if (!h || !mb) return fail(D2FE_ERR_INVALID, "null argument");
+  if (mb->npairs < 1 || mb->max_n < 1 || mb->max_n > 1024) return fail(D2FE_ERR_INVALID, "npairs/max_n out of range (max_n <= 1024)");
+  if (mb->dim < 4 || mb->dim > 256 || (mb->dim & 3)) return fail(D2FE_ERR_INVALID, "dim must be a multiple of 4 in 4..256");
+  if (mb->mode != 0 && mb->mode != 1) return fail(D2FE_ERR_INVALID, "bad mode");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  std::lock_guard<std::mutex> lk(h->match_mu);
+  const size_t need = sizeof(int32_t) * 4 * 2 * (size_t)mb->max_n * mb->npairs;
+  if (need > h->m_cand4_bytes) {
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h->m_cand4) hipFree(h->m_cand4);
+    h->m_cand4 = nullptr; h->m_cand4_bytes = 0;
+    HIP_TRY(hipMalloc(&h->m_cand4, need));
+    h->m_cand4_bytes = need;
+  }
+  MatchArgs m;
+  m.a = mb->d_a; m.b = mb->d_b; m.pts_a = mb->d_pts_a; m.pts_b = mb->d_pts_b;
+  m.a_off = mb->d_a_off; m.b_off = mb->d_b_off; m.a_cnt = mb->d_a_cnt; m.b_cnt = mb->d_b_cnt;
+  m.npairs = mb->npairs; m.dim = mb->dim; m.max_n = mb->max_n; m.mode = mb->mode;
+  m.ratio = mb->ratio; m.radius = mb->radius;
+  m.q_idx = mb->d_q_idx; m.t_idx = mb->d_t_idx; m.dist = mb->d_dist; m.n_out = mb->d_n_out;
+  m.cand4 = h->m_cand4;
+  HIP_TRY(launch_match(m, s));
+  return D2FE_OK;
+}
+
+static int match_host(d2fe_handle h, int mode, const float* a, int na, const float* b, int nb, int dim, double ratio,
+                      const float* pts_a, const float* pts_b, double radius, int32_t* q_idx, int32_t* t_idx, float* dist,
+                      int cap, int* n_out) {
+  if (n_out) *n_out = 0;
+  if (!h || !n_out) return fail(D2FE_ERR_INVALID, "null argument");
+  if (na < 0 || nb < 0 || cap < 0) return fail(D2FE_ERR_INVALID, "negative size");
+  if (na == 0 || nb == 0) return D2FE_OK;
+  if (!a || !b || !q_idx || !t_idx || !dist) return fail(D2FE_ERR_INVALID, "null pointer");
+  const int max_n = na > nb ? na : nb;
+  if (max_n > 1024) return fail(D2FE_ERR_UNSUPPORTED, "more than 1024 descriptors per side");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  // private stream + scratch per call: re-entrant (the reference calls matchKNN from three threads)
+  hipStream_t s;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  const bool use_pts = mode == 0 && radius > 0 && pts_a && pts_b;
+  const size_t fa = (size_t)na * dim, fb = (size_t)nb * dim;
+  const size_t bytes = sizeof(float) * (fa + fb + 2 * (size_t)na + 2 * (size_t)nb + max_n) + sizeof(int32_t) * (2 * (size_t)max_n + 5 + 8 * (size_t)max_n);
+  char* buf = nullptr;
+  hipError_t e = hipMalloc(&buf, bytes);
+  if (e != hipSuccess) { hipStreamDestroy(s); return fail(D2FE_ERR_HIP, "hipMalloc match scratch"); }
+  float* d_a = reinterpret_cast<float*>(buf);
+  float* d_b = d_a + fa;
+  float* d_pa = d_b + fb;
+  float* d_pb = d_pa + 2 * (size_t)na;
+  float* d_dist = d_pb + 2 * (size_t)nb;
+  int32_t* d_q = reinterpret_cast<int32_t*>(d_dist + max_n);
+  int32_t* d_t = d_q + max_n;
+  int32_t* d_meta = d_t + max_n;  // a_off, b_off, a_cnt, b_cnt, n_out
+  int32_t* d_c4 = d_meta + 5;
+  const int32_t meta[5] = {0, 0, na, nb, 0};
+  int rc = D2FE_OK;
+  auto chk = [&](hipError_t er, const char* what) { if (er != hipSuccess && rc == D2FE_OK) rc = fail(D2FE_ERR_HIP, std::string(what) + ": " + hipGetErrorString(er)); };
+  chk(hipMemcpyAsync(d_a, a, sizeof(float) * fa, hipMemcpyHostToDevice, s), "H2D a");
+  chk(hipMemcpyAsync(d_b, b, sizeof(float) * fb, hipMemcpyHostToDevice, s), "H2D b");
+  if (use_pts) {
+    chk(hipMemcpyAsync(d_pa, pts_a, sizeof(float) * 2 * na, hipMemcpyHostToDevice, s), "H2D pts_a");
+    chk(hipMemcpyAsync(d_pb, pts_b, sizeof(float) * 2 * nb, hipMemcpyHostToDevice, s), "H2D pts_b");
+  }
+  chk(hipMemcpyAsync(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice, s), "H2D meta");
+  MatchArgs m;
+  m.a = d_a; m.b = d_b; m.pts_a = use_pts ? d_pa : nullptr; m.pts_b = use_pts ? d_pb : nullptr;
+  m.a_off = d_meta; m.b_off = d_meta + 1; m.a_cnt = d_meta + 2; m.b_cnt = d_meta + 3;
+  m.npairs = 1; m.dim = dim; m.max_n = max_n; m.mode = mode; m.ratio = ratio; m.radius = use_pts ? radius : -1.0;
+  m.q_idx = d_q; m.t_idx = d_t; m.dist = d_dist; m.n_out = d_meta + 4; m.cand4 = d_c4;
+  if (dim < 4 || dim > 256 || (dim & 3)) rc = fail(D2FE_ERR_INVALID, "dim must be a multiple of 4 in 4..256");
+  if (rc == D2FE_OK) chk(launch_match(m, s), "launch_match");
+  int32_t cnt = 0;
+  if (rc == D2FE_OK) chk(hipMemcpyAsync(&cnt, d_meta + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s), "D2H n");
+  if (rc == D2FE_OK) chk(hipStreamSynchronize(s), "sync");
+  if (rc == D2FE_OK) {
+    const int k = cnt < cap ? cnt : cap;
+    if (k > 0) {
+      chk(hipMemcpyAsync(q_idx, d_q, sizeof(int32_t) * k, hipMemcpyDeviceToHost, s), "D2H q");
+      chk(hipMemcpyAsync(t_idx, d_t, sizeof(int32_t) * k, hipMemcpyDeviceToHost, s), "D2H t");
+      chk(hipMemcpyAsync(dist, d_dist, sizeof(float) * k, hipMemcpyDeviceToHost, s), "D2H d");
+      chk(hipStreamSynchronize(s), "sync2");
+    }
+    *n_out = k;
+    if (rc == D2FE_OK && cnt > cap) rc = fail(D2FE_ERR_TRUNCATED, "match output capacity too small");
+  }
+  hipFree(buf);
+  hipStreamDestroy(s);
+  return rc;
+}
+
+int d2fe_match_knn(d2fe_handle h, const float* a, int na, const float* b, int nb, int dim, double ratio,
+                   const float* pts_a, const float* pts_b, double radius, int32_t* q_idx, int32_t* t_idx, float* dist,
+                   int cap, int* n_out) {
+  return match_host(h, 0, a, na, b, nb, dim, ratio, pts_a, pts_b, radius, q_idx, t_idx, dist, cap, n_out);
+}
+
+int d2fe_match_crosscheck(d2fe_handle h, const float* a, int na, const float* b, int nb, int dim, int32_t* q_idx,
+                          int32_t* t_idx, float* dist, int cap, int* n_out) {
+  return match_host(h, 1, a, na, b, nb, dim, 0.0, nullptr, nullptr, -1.0, q_idx, t_idx, dist, cap, n_out);
+}
+
+int d2fe_half_image_filter(const float* pts_xy, int n, int require_left, int width_undistort, double undistort_fov,
+                           int32_t* map, int* n_out) {
+  if (!n_out) return fail(D2FE_ERR_INVALID, "null argument");
+  *n_out = 0;
+  if (n < 0 || (n > 0 && (!pts_xy || !map))) return fail(D2FE_ERR_INVALID, "null pointer");
+  // host bookkeeping on <= N points (d2featuretracker.cpp:1058-1071); float move_cols as in the reference
+  const float move_cols = (float)((double)width_undistort * 90.0 / undistort_fov);
+  int c = 0;
+  for (int i = 0; i < n; ++i) {
+    const float x = pts_xy[2 * i];
+    if ((require_left && x < (float)width_undistort - move_cols) || (!require_left && x >= move_cols)) map[c++] = i;
+  }
+  *n_out = c;
+  return D2FE_OK;
+}
+
+long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_bytes) {
+  if (!h || !name || !dst) return fail(D2FE_ERR_INVALID, "null argument");
+  if (h->last_n == 0) return fail(D2FE_ERR_NOT_READY, "no extract call yet");
+  hipSetDevice(h->cfg.device_id);
+  const size_t H = h->last_h, W = h->last_w, n = h->last_n;
+  struct { const char* nm; Tensor* t; size_t per; } tab[] = {
+      {"conv1a", &h->a1a, H * W * 64},           {"conv1b", &h->a1b, H * W * 16},        {"conv2a", &h->a2a, H * W * 16},
+      {"conv2b", &h->a2b, H * W * 4},            {"conv3a", &h->a3a, H * W * 8},         {"conv3b", &h->a3b, H * W * 2},
+      {"conv4a", &h->a4a, H * W * 2},            {"conv4b", &h->a4b, H * W * 2},         {"convPaDa", &h->aPD, H * W * 8},
+      {"logits", &h->logits, (H / 8) * (W / 8) * 65}, {"desc_raw", &h->draw, H * W * 4}, {"semi", &h->semi, H * W}};
+  for (auto& e : tab)
+    if (!strcmp(e.nm, name)) {
+      const size_t bytes = e.per * n * sizeof(float);
+      if (bytes > max_bytes) return fail(D2FE_ERR_TRUNCATED, "destination too small");
+      if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(D2FE_ERR_HIP, "sync");
+      if (hipMemcpy(dst, e.t->p, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(D2FE_ERR_HIP, "D2H");
+      return (long)bytes;
+    }
+  return fail(D2FE_ERR_INVALID, "unknown tensor name");
+}
+
+int d2fe_sync(d2fe_handle h) {
+  if (!h) return fail(D2FE_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return D2FE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,247 @@
+// conv.hip -- SuperPoint convolution stack for gfx950 (MI355X), implicit GEMM on MFMA.
+//
+// Replaces the TensorRT engine execution at d2frontend/src/CNN/superpoint_tensorrt.cpp:150
+// (network definition: d2frontend/superpoint.ipynb:300-374).
+//
+// GEMM view: M = output pixels, N = output channels, K = (ky, kx, ci).  Activations are NHWC fp32 in HBM.
+// A block stages the (TH+2)x(TW+2)xCin input patch of its TH x TW pixel tile in LDS once (halo included,
+// zero-filled outside the image == the conv's zero padding) and then walks K with the patch as the A operand;
+// B fragments (weights) are pre-packed on the host in MFMA lane order and stream from L2 as one coalesced
+// 1 KiB load per 32-wide N tile per 8 input channels.
+//
+// Exact mode (precision 0): v_mfma_f32_32x32x2_f32.  Per output the accumulation is bit-for-bit the fp32
+// fmaf chain acc0 = bias; for ky, kx, ci ascending: acc = fmaf(x, w, acc)  -- the order the oracle uses
+// (oracle/d2fe_oracle.c orc_conv), so activations compare bitwise.
+// Fast mode (precision 1): operands split into fp16 hi + lo (x = hi + lo to ~2^-22), three
+// v_mfma_f32_32x32x16_f16 per k-step (hi*hi + hi*lo + lo*hi) into one fp32 accumulator.
+#include "conv_common.h"
+
+namespace d2fe {
+
+// =====================================================================================================
+// Exact fp32 kernel
+// =====================================================================================================
+template <int CIN, int KS, int TH, int TW, int WM, int WN, int MT, int NT, bool POOL, bool RELU>
+__global__ __launch_bounds__(WM * WN * 64) void conv_f32_kernel(ConvArgs a) {
+  constexpr int P = KS / 2;
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  constexpr int CP = CIN + 1;  // odd pixel stride: 32 pixels x same channel hit 32 distinct banks
+  constexpr int NTHREADS = WM * WN * 64;
+  constexpr int TAPS = KS * KS;
+  constexpr int C8 = CIN / 8;
+  static_assert(TH * TW == WM * MT * 32, "tile / wave mismatch");
+  extern __shared__ __attribute__((aligned(16))) float patch[];
+
+  const int tiles_x = (a.W + TW - 1) / TW;
+  const int tx0 = (blockIdx.x % tiles_x) * TW;
+  const int ty0 = (blockIdx.x / tiles_x) * TH;
+  const int img = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- stage the input patch -------------------------------------------------------------------------
+  {
+    const float* in = a.in + (size_t)img * a.in_img_stride + a.in_coff;
+    constexpr int C4 = CIN / 4;
+    constexpr int TOTAL = PH * PW * C4;
+    constexpr int ITERS = (TOTAL + NTHREADS - 1) / NTHREADS;
+    constexpr int UNR = 8;
+    for (int it0 = 0; it0 < ITERS; it0 += UNR) {
+      f32x4 v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int idx = (it0 + u) * NTHREADS + tid;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (it0 + u < ITERS && idx < TOTAL) {
+          const int pix = idx / C4, c4 = idx % C4;
+          const int gy = ty0 + pix / PW - P, gx = tx0 + pix % PW - P;
+          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            v[u] = *reinterpret_cast<const f32x4*>(in + ((size_t)gy * a.W + gx) * a.in_cstride + c4 * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int idx = (it0 + u) * NTHREADS + tid;
+        if (it0 + u < ITERS && idx < TOTAL) {
+          const int pix = idx / C4, c4 = idx % C4;
+          float* d = patch + pix * CP + c4 * 4;
+          d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- accumulators start from the bias ----------------------------------------------------------------
+  const int ntile0 = blockIdx.y * (WN * NT) + wn * NT;  // global 32-wide N tile index
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const float b = a.bias[(ntile0 + n) * 32 + (lane & 31)];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = b;
+  }
+
+  // per-lane A base offsets (floats) of this wave's m-tiles at tap (0,0), channel k-half
+  int aoff[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    int py, px;
+    mtile_pixel<TW>(wm * MT + m, lane & 31, py, px);
+    aoff[m] = (py * PW + px) * CP + (lane >> 5);
+  }
+
+  // packed weights: [ntile][tap][c8][lane] float4;  float4[q] = W[co = ntile*32 + (lane&31)][ci = c8*8 + 2q + (lane>>5)][tap]
+  const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack);
+  const f32x4* wbase[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) wbase[n] = wp + (size_t)(ntile0 + n) * TAPS * C8 * 64 + lane;
+
+  f32x4 bw[NT], bw_next[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) bw[n] = wbase[n][0];
+
+  for (int tap = 0; tap < TAPS; ++tap) {
+    const int tap_off = ((tap / KS) * PW + (tap % KS)) * CP;
+#pragma unroll 2
+    for (int c8 = 0; c8 < C8; ++c8) {
+      const int step = tap * C8 + c8;
+      // prefetch next step's B fragments (clamped on the last step)
+      const int nstep = (step + 1 < TAPS * C8) ? step + 1 : step;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bw_next[n] = wbase[n][(size_t)nstep * 64];
+      float av[MT][4];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float* ap = patch + aoff[m] + tap_off + c8 * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[m][q] = ap[2 * q];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], bw[n][q], acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bw[n] = bw_next[n];
+    }
+  }
+
+  conv_epilogue<TW, MT, NT, POOL, RELU>(a, acc, 1.0f, img, ty0, tx0, wm, ntile0, lane);
+}
+
+template <int CIN, int KS, int TH, int TW, int WM, int WN, int MT, int NT>
+static hipError_t launch_f32(bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s) {
+  constexpr int BN = WN * NT * 32;
+  constexpr size_t lds = (size_t)(TH + KS - 1) * (TW + KS - 1) * (CIN + 1) * sizeof(float);
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  dim3 grid(tiles_x * tiles_y, cout_pad / BN, a.n_img), block(WM * WN * 64);
+  if (cout_pad % BN) return hipErrorInvalidValue;
+#define D2FE_LAUNCH(PL, RL)                                                                          \
+  do {                                                                                               \
+    auto k = conv_f32_kernel<CIN, KS, TH, TW, WM, WN, MT, NT, PL, RL>;                               \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                             \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+    if (e != hipSuccess) return e;                                                                   \
+    hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                   \
+  } while (0)
+  if constexpr (MT == 2 && TW == 32) {
+    if (pool) { if (relu) D2FE_LAUNCH(true, true); else D2FE_LAUNCH(true, false); return hipGetLastError(); }
+  } else {
+    if (pool) return hipErrorInvalidValue;
+  }
+  if (relu) D2FE_LAUNCH(false, true); else D2FE_LAUNCH(false, false);
+#undef D2FE_LAUNCH
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_f16x2(ConvShape shape, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s);
+
+hipError_t launch_conv(ConvShape shape, int precision, bool pool, bool relu, int cout_pad, const ConvArgs& a,
+                       hipStream_t s) {
+  if (precision == 1) return launch_conv_f16x2(shape, pool, relu, cout_pad, a, s);
+  switch (shape) {
+    case CONV_64_T8x32:      return launch_f32<64, 3, 8, 32, 4, 1, 2, 2>(pool, relu, cout_pad, a, s);
+    case CONV_128_T4x32:     return launch_f32<128, 3, 4, 32, 2, 2, 2, 2>(pool, relu, cout_pad, a, s);
+    case CONV_128_T4x16:     return launch_f32<128, 3, 4, 16, 1, 4, 2, 1>(pool, relu, cout_pad, a, s);
+    case CONV_256_1x1_T4x16: return launch_f32<256, 1, 4, 16, 1, 4, 2, 1>(pool, relu, cout_pad, a, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// host-side weight packing (fp32 fragment order)
+// -----------------------------------------------------------------------------------------------------
+size_t packed_weight_floats_f32(int cout_pad, int cin, int ks) { return (size_t)cout_pad * cin * ks * ks; }
+
+void pack_weights_f32(const float* w, int cout, int cin, int ks, int cout_pad, float* dst) {
+  const int taps = ks * ks, c8n = cin / 8;
+  for (int nt = 0; nt < cout_pad / 32; ++nt)
+    for (int tap = 0; tap < taps; ++tap)
+      for (int c8 = 0; c8 < c8n; ++c8)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int q = 0; q < 4; ++q) {
+            const int co = nt * 32 + (lane & 31);
+            const int ci = c8 * 8 + 2 * q + (lane >> 5);
+            const float v = co < cout ? w[((size_t)co * cin + ci) * taps + tap] : 0.f;
+            dst[((((size_t)nt * taps + tap) * c8n + c8) * 64 + lane) * 4 + q] = v;
+          }
+}
+
+// =====================================================================================================
+// conv1a: 1 -> 64 channels, K = 9.  VALU kernel (K too small for MFMA to matter), fused u8 -> f32 prep
+// (SuperPoint::processInput, superpoint_tensorrt.cpp:185-198: convertTo(CV_32FC1, 1/255)).
+// Thread = (pixel, group of 16 output channels); chain order (ky,kx), acc0 = bias: bitwise == oracle.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void conv1a_kernel(const uint8_t* __restrict__ img, int stride, long img_stride,
+                                                     int H, int W, const float* __restrict__ w9x64,
+                                                     const float* __restrict__ bias, float* __restrict__ out) {
+  __shared__ float wsm[9 * 64 + 64];
+  for (int i = threadIdx.x; i < 9 * 64 + 64; i += 256) wsm[i] = i < 576 ? w9x64[i] : bias[i - 576];
+  __syncthreads();
+  const int n = blockIdx.z;
+  const int y = blockIdx.y;
+  const int x = blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int g = threadIdx.x & 3;
+  if (x >= W) return;
+  const uint8_t* ip = img + (size_t)n * img_stride;
+  const float scale = (float)(1.0 / 255.0);
+  float v[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yy = y + ky - 1, xx = x + kx - 1;
+      v[ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (float)ip[(size_t)yy * stride + xx] * scale : 0.f;
+    }
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = wsm[576 + g * 16 + c];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = __builtin_fmaf(v[t], wsm[t * 64 + g * 16 + c], acc[c]);
+  float* op = out + (((size_t)n * H + y) * W + x) * 64 + g * 16;
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) {
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float t = acc[c4 * 4 + j]; o[j] = t > 0.f ? t : 0.f; }
+    *reinterpret_cast<f32x4*>(op + c4 * 4) = o;
+  }
+}
+
+hipError_t launch_conv1a(const uint8_t* img, int stride, long img_stride_bytes, int H, int W, int n,
+                         const float* w9x64, const float* bias, float* out, hipStream_t s) {
+  dim3 grid((W + 63) / 64, H, n), block(256);
+  hipLaunchKernelGGL(conv1a_kernel, grid, block, 0, s, img, stride, img_stride_bytes, H, W, w9x64, bias, out);
+  return hipGetLastError();
+}
+
+}  // namespace d2fe

@@ -1,0 +1,208 @@
+// conv_f16.hip -- "fast" precision of the SuperPoint conv stack: fp16 hi/lo split operands on the
+// double-rate gfx950 matrix instruction v_mfma_f32_32x32x16_f16, fp32 accumulation.
+//
+// Every fp32 operand x is represented as hi + lo with hi = fp16(x), lo = fp16(x - hi)  (|x - hi - lo| <~ 2^-22 |x|);
+// a product is evaluated as hi_a*hi_b + hi_a*lo_b + lo_a*hi_b (the dropped lo*lo term is <= 2^-22 relative), i.e.
+// three MFMAs per k-step at 16x the fp32-MFMA rate => 5.3x the exact mode's throughput ceiling at ~fp32 accuracy.
+// To keep the lo parts out of fp16's subnormal range, activations are scaled by 2^SA and weights by 2^SW before
+// the split (exact power-of-two scalings); the epilogue multiplies by 2^-(SA+SW).
+//
+// Same tiling and staging as conv.hip: the (TH+2)x(TW+2)xCin patch is converted once per block while it is
+// staged (global fp32 -> LDS fp16 hi plane + lo plane), and is then read as ds_read_b128 A fragments
+// (pixel stride Cin+8 halves -> the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots).
+#include "conv_common.h"
+
+namespace d2fe {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int F16_SA = 4;   // activation scale 2^4  (|x| <= 4094 representable; clamped)
+constexpr int F16_SW = 8;   // weight scale 2^8
+
+template <int CIN, int KS, int TH, int TW, int WM, int WN, int MT, int NT, bool POOL, bool RELU>
+__global__ __launch_bounds__(WM * WN * 64) void conv_f16x2_kernel(ConvArgs a) {
+  constexpr int P = KS / 2;
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  constexpr int CPH = CIN + 8;  // halves per pixel (16-byte slots per pixel = CIN/8 + 1, odd)
+  constexpr int NPIX = PH * PW;
+  constexpr int NTHREADS = WM * WN * 64;
+  constexpr int TAPS = KS * KS;
+  constexpr int KST = CIN / 16;
+  static_assert(TH * TW == WM * MT * 32, "tile / wave mismatch");
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  _Float16* hi = lds;
+  _Float16* lo = lds + NPIX * CPH;
+
+  const int tiles_x = (a.W + TW - 1) / TW;
+  const int tx0 = (blockIdx.x % tiles_x) * TW;
+  const int ty0 = (blockIdx.x / tiles_x) * TH;
+  const int img = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- stage + split the input patch ---------------------------------------------------------------------
+  {
+    const float* in = a.in + (size_t)img * a.in_img_stride + a.in_coff;
+    constexpr int C4 = CIN / 4;
+    constexpr int TOTAL = NPIX * C4;
+    constexpr int ITERS = (TOTAL + NTHREADS - 1) / NTHREADS;
+    constexpr int UNR = 8;
+    const float sa = (float)(1 << F16_SA);
+    for (int it0 = 0; it0 < ITERS; it0 += UNR) {
+      f32x4 v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int idx = (it0 + u) * NTHREADS + tid;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (it0 + u < ITERS && idx < TOTAL) {
+          const int pix = idx / C4, c4 = idx % C4;
+          const int gy = ty0 + pix / PW - P, gx = tx0 + pix % PW - P;
+          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            v[u] = *reinterpret_cast<const f32x4*>(in + ((size_t)gy * a.W + gx) * a.in_cstride + c4 * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int idx = (it0 + u) * NTHREADS + tid;
+        if (it0 + u < ITERS && idx < TOTAL) {
+          const int pix = idx / C4, c4 = idx % C4;
+          f16x4 h4, l4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x = v[u][j] * sa;
+            x = fminf(fmaxf(x, -65000.f), 65000.f);
+            const _Float16 h = (_Float16)x;
+            h4[j] = h;
+            l4[j] = (_Float16)(x - (float)h);
+          }
+          *reinterpret_cast<f16x4*>(hi + pix * CPH + c4 * 4) = h4;
+          *reinterpret_cast<f16x4*>(lo + pix * CPH + c4 * 4) = l4;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int ntile0 = blockIdx.y * (WN * NT) + wn * NT;
+  const float bscale = (float)(1 << (F16_SA + F16_SW));
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const float b = a.bias[(ntile0 + n) * 32 + (lane & 31)] * bscale;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = b;
+  }
+
+  int aoff[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    int py, px;
+    mtile_pixel<TW>(wm * MT + m, lane & 31, py, px);
+    aoff[m] = (py * PW + px) * CPH + 8 * (lane >> 5);
+  }
+
+  // packed weights: [ntile][tap][kstep][hi|lo][lane] f16x8;  element i = W[co = ntile*32 + (lane&31)][ci = kstep*16 + 8*(lane>>5) + i][tap]
+  const f16x8* wp = reinterpret_cast<const f16x8*>(a.wpack);
+  const f16x8* wbase[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) wbase[n] = wp + (size_t)(ntile0 + n) * TAPS * KST * 128 + lane;
+
+  f16x8 bh[NT], bl[NT], bh_n[NT], bl_n[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) { bh[n] = wbase[n][0]; bl[n] = wbase[n][64]; }
+
+  for (int tap = 0; tap < TAPS; ++tap) {
+    const int tap_off = ((tap / KS) * PW + (tap % KS)) * CPH;
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks) {
+      const int step = tap * KST + ks;
+      const int nstep = (step + 1 < TAPS * KST) ? step + 1 : step;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { bh_n[n] = wbase[n][(size_t)nstep * 128]; bl_n[n] = wbase[n][(size_t)nstep * 128 + 64]; }
+      f16x8 ah[MT], al[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        ah[m] = *reinterpret_cast<const f16x8*>(hi + aoff[m] + tap_off + ks * 16);
+        al[m] = *reinterpret_cast<const f16x8*>(lo + aoff[m] + tap_off + ks * 16);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+        }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { bh[n] = bh_n[n]; bl[n] = bl_n[n]; }
+    }
+  }
+
+  conv_epilogue<TW, MT, NT, POOL, RELU>(a, acc, 1.0f / bscale, img, ty0, tx0, wm, ntile0, lane);
+}
+
+template <int CIN, int KS, int TH, int TW, int WM, int WN, int MT, int NT>
+static hipError_t launch_f16(bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s) {
+  constexpr int BN = WN * NT * 32;
+  constexpr size_t lds = (size_t)(TH + KS - 1) * (TW + KS - 1) * (CIN + 8) * sizeof(_Float16) * 2;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  dim3 grid(tiles_x * tiles_y, cout_pad / BN, a.n_img), block(WM * WN * 64);
+  if (cout_pad % BN) return hipErrorInvalidValue;
+#define D2FE_LAUNCH(PL, RL)                                                                          \
+  do {                                                                                               \
+    auto k = conv_f16x2_kernel<CIN, KS, TH, TW, WM, WN, MT, NT, PL, RL>;                             \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                             \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+    if (e != hipSuccess) return e;                                                                   \
+    hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                   \
+  } while (0)
+  if constexpr (MT == 2 && TW == 32) {
+    if (pool) { if (relu) D2FE_LAUNCH(true, true); else D2FE_LAUNCH(true, false); return hipGetLastError(); }
+  } else {
+    if (pool) return hipErrorInvalidValue;
+  }
+  if (relu) D2FE_LAUNCH(false, true); else D2FE_LAUNCH(false, false);
+#undef D2FE_LAUNCH
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_f16x2(ConvShape shape, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s) {
+  switch (shape) {
+    case CONV_64_T8x32:      return launch_f16<64, 3, 8, 32, 4, 1, 2, 2>(pool, relu, cout_pad, a, s);
+    case CONV_128_T4x32:     return launch_f16<128, 3, 4, 32, 2, 2, 2, 2>(pool, relu, cout_pad, a, s);
+    case CONV_128_T4x16:     return launch_f16<128, 3, 4, 16, 1, 4, 2, 1>(pool, relu, cout_pad, a, s);
+    case CONV_256_1x1_T4x16: return launch_f16<256, 1, 4, 16, 1, 4, 2, 1>(pool, relu, cout_pad, a, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+// host-side packing: hi/lo fp16 fragments of 2^SW * w
+size_t packed_weight_halfs_f16x2(int cout_pad, int cin, int ks) { return (size_t)cout_pad * cin * ks * ks * 2; }
+
+void pack_weights_f16x2(const float* w, int cout, int cin, int ks, int cout_pad, uint16_t* dst) {
+  const int taps = ks * ks, kst = cin / 16;
+  const float sw = (float)(1 << F16_SW);
+  _Float16* d = reinterpret_cast<_Float16*>(dst);
+  for (int nt = 0; nt < cout_pad / 32; ++nt)
+    for (int tap = 0; tap < taps; ++tap)
+      for (int k = 0; k < kst; ++k)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int i = 0; i < 8; ++i) {
+            const int co = nt * 32 + (lane & 31);
+            const int ci = k * 16 + 8 * (lane >> 5) + i;
+            float v = co < cout ? w[((size_t)co * cin + ci) * taps + tap] * sw : 0.f;
+            if (v > 65000.f) v = 65000.f;
+            if (v < -65000.f) v = -65000.f;
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)(v - (float)h);
+            const size_t base = (((size_t)nt * taps + tap) * kst + k) * 128;
+            d[(base + lane) * 8 + i] = h;
+            d[(base + 64 + lane) * 8 + i] = l;
+          }
+}
+
+}  // namespace d2fe

@@ -1,0 +1,69 @@
+// kernels.h -- launch interfaces of the gfx950 kernels behind include/d2fe.h (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace d2fe {
+
+// ---- conv stack -----------------------------------------------------------------------------------
+// Activations: NHWC fp32 in HBM, addressed as base + ((img*H + y)*W + x)*cstride + coff + c.
+struct ConvArgs {
+  const float* in;  int in_cstride;  int in_coff;
+  float* out;       int out_cstride; int out_coff;
+  int cout_real;            // channels actually stored (<= padded cout)
+  const void* wpack;        // packed weights (layout depends on kernel family)
+  const float* bias;        // padded to a multiple of 32
+  int H, W;                 // conv input == output spatial size (before the optional 2x2 pool)
+  int n_img;
+  long in_img_stride;       // floats between images
+  long out_img_stride;
+};
+
+enum ConvShape {
+  CONV_64_T8x32 = 0,    // Cin 64, 3x3, tile 8x32, BN 64           (conv1b, conv2a, conv2b, conv3a)
+  CONV_128_T4x32,       // Cin 128, 3x3, tile 4x32, BN 128          (conv3b)
+  CONV_128_T4x16,       // Cin 128, 3x3, tile 4x16, BN 128          (conv4a, conv4b, convPa|convDa)
+  CONV_256_1x1_T4x16,   // Cin 256, 1x1, tile 4x16, BN 128          (convPb, convDb)
+};
+
+// precision: 0 = fp32 exact MFMA, 1 = fp16 hi/lo split MFMA
+hipError_t launch_conv(ConvShape shape, int precision, bool pool, bool relu, int cout_pad, const ConvArgs& a,
+                       hipStream_t s);
+
+// conv1a: u8 gray [n][H][stride] -> NHWC fp32 [n][H][W][64], fused (float)u8 * (1/255), bias, ReLU.
+hipError_t launch_conv1a(const uint8_t* img, int stride, long img_stride_bytes, int H, int W, int n,
+                         const float* w9x64 /*[9][64]*/, const float* bias, float* out, hipStream_t s);
+
+// host-side packing helpers (fragment order of the kernels above)
+size_t packed_weight_floats_f32(int cout_pad, int cin, int ks);
+void pack_weights_f32(const float* w /*[cout][cin][k][k]*/, int cout, int cin, int ks, int cout_pad, float* dst);
+size_t packed_weight_halfs_f16x2(int cout_pad, int cin, int ks);
+void pack_weights_f16x2(const float* w, int cout, int cin, int ks, int cout_pad, uint16_t* dst);
+
+// ---- post-processing ------------------------------------------------------------------------------
+// softmax(65) -> drop dustbin -> 8x8 unfold; writes dense semi (optional) and appends variant-B candidates
+// (score > thr, inside borders) as u64 keys (score_bits << 32 | ~raster_idx) with one counter per image.
+hipError_t launch_softmax_cand(const float* logits, int lstride, int Hc, int Wc, int n_img, float thr, int border,
+                               float* semi /*nullable*/, unsigned long long* cand, int* cand_count, long cand_cap,
+                               hipStream_t s);
+// exact top-K (score desc, raster asc) / raster-ordered pass-through when count <= K (variant B).
+hipError_t launch_select_b(const unsigned long long* cand, const int* cand_count, long cand_cap, int n_img, int W,
+                           int max_kp, int cap, float* kps_xy, float* scores, int32_t* kps_idx, int32_t* n_out,
+                           hipStream_t s);
+// variant-B descriptor sampling (normalize_keypoints + grid_sample + normalize_descriptors).
+hipError_t launch_sample_b(const float* desc_raw, int dstride, int dcoff, int Hc, int Wc, int n_img, const float* kps_xy,
+                           const int32_t* n_kp, int cap, float* desc_out, hipStream_t s);
+
+// ---- matcher --------------------------------------------------------------------------------------
+struct MatchArgs {
+  const float* a; const float* b; const float* pts_a; const float* pts_b;
+  const int32_t* a_off; const int32_t* b_off; const int32_t* a_cnt; const int32_t* b_cnt;
+  int npairs, dim, max_n, mode;
+  double ratio, radius;
+  int32_t* q_idx; int32_t* t_idx; float* dist; int32_t* n_out;
+  // scratch: per pair, per direction, per row: 4 candidate indices
+  int32_t* cand4;   // [npairs][2][max_n][4]
+};
+hipError_t launch_match(const MatchArgs& m, hipStream_t s);
+
+}  // namespace d2fe

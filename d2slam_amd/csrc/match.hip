@@ -1,0 +1,292 @@
+// match.hip -- brute-force descriptor matching on gfx950: matchKNN and the cross-check matcher.
+//
+// Replaces D2FrontEnd::matchKNN (d2frontend/src/feature_matcher.cpp:4-42: cv::BFMatcher(NORM_L2).knnMatch
+// both ways, Lowe ratio, mutual check, optional pixel-radius gate) and cv::BFMatcher(NORM_L2, true).match
+// (loop_cam.cpp:167-170, d2featuretracker.cpp:1141-1142).
+//
+// Two kernels per batch of pairs:
+//  (1) match_prefilter: per (pair, direction, 32-query tile) the Gram tile  T . Q^T  on fp32 MFMA
+//      (v_mfma_f32_32x32x2_f32), d2 = |t|^2 + |q|^2 - 2 t.q, and a per-query top-4 of candidate train indices
+//      kept in registers (queries sit on the MFMA column axis, so the scan over a lane's 16 train rows is
+//      lane-local; halves and waves merge through shuffles / LDS).
+//  (2) match_finalize: per pair, re-evaluates the <= 4 candidates of every row of both directions with the
+//      ORACLE's arithmetic (orc_l2_dist: OpenCV normL2Sqr_ accumulation order, then sqrt), takes the exact
+//      2-NN, applies ratio / mutual / radius tests in double exactly as feature_matcher.cpp:16-37, and emits
+//      matches in ascending query order.  Indices and distances therefore equal the oracle's bit for bit
+//      unless more than four train rows lie within fp32 round-off (~1e-6) of the nearest distance.
+#include "kernels.h"
+
+namespace d2fe {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MQ = 32;         // queries per block
+constexpr int TB = 128;        // train rows per staged block (4 waves x 32)
+constexpr int KCH = 128;       // K chunk staged per pass
+constexpr int QS = 257;        // LDS row stride of the query tile (odd -> conflict-free column reads)
+constexpr int TS = KCH + 1;    // LDS row stride of the train chunk
+constexpr int MAXDIM = 256;
+
+struct Cand { float d; int i; };
+__device__ __forceinline__ bool cand_less(float d, int i, const Cand& c) { return d < c.d || (d == c.d && i < c.i); }
+__device__ __forceinline__ void cand_insert(Cand (&top)[4], float d, int i) {
+  if (!cand_less(d, i, top[3])) return;
+  top[3].d = d; top[3].i = i;
+#pragma unroll
+  for (int k = 3; k > 0; --k) {
+    if (cand_less(top[k].d, top[k].i, top[k - 1])) {
+      const Cand t = top[k]; top[k] = top[k - 1]; top[k - 1] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;                       // [MQ][QS]
+  float* Ts = Qs + MQ * QS;               // [TB][TS]
+  float* qn = Ts + TB * TS;               // [MQ]
+  float* tn = qn + MQ;                    // [TB]
+  Cand* merge = reinterpret_cast<Cand*>(tn + TB);  // [4 waves][MQ][4]
+
+  const int pair = blockIdx.z, dir = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int na = min(m.a_cnt[pair], m.max_n), nb = min(m.b_cnt[pair], m.max_n);
+  const int nq = dir == 0 ? na : nb, nt = dir == 0 ? nb : na;
+  const int q0 = blockIdx.x * MQ;
+  if (q0 >= nq || q0 >= m.max_n) return;
+  const float* Q = dir == 0 ? m.a + (size_t)m.a_off[pair] * m.dim : m.b + (size_t)m.b_off[pair] * m.dim;
+  const float* T = dir == 0 ? m.b + (size_t)m.b_off[pair] * m.dim : m.a + (size_t)m.a_off[pair] * m.dim;
+  const int dim = m.dim;
+  const int d4 = dim / 4;
+
+  // stage the query tile (zero padded), coalesced float4 reads
+  for (int i = tid; i < MQ * (MAXDIM / 4); i += 256) {
+    const int r = i / (MAXDIM / 4), c4 = i % (MAXDIM / 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q0 + r < nq && c4 < d4) v = *reinterpret_cast<const f32x4*>(Q + (size_t)(q0 + r) * dim + c4 * 4);
+    float* d = Qs + r * QS + c4 * 4;
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+  __syncthreads();
+  if (tid < MQ) {
+    float s = 0.f;
+    for (int k = 0; k < dim; ++k) s = __builtin_fmaf(Qs[tid * QS + k], Qs[tid * QS + k], s);
+    qn[tid] = s;
+  }
+
+  Cand top[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { top[k].d = __builtin_inff(); top[k].i = 0x7FFFFFFF; }
+
+  const int nkc = (dim + KCH - 1) / KCH;
+  for (int t0 = 0; t0 < nt; t0 += TB) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float tnorm = 0.f;
+    for (int kc = 0; kc < nkc; ++kc) {
+      __syncthreads();
+      for (int i = tid; i < TB * (KCH / 4); i += 256) {
+        const int r = i / (KCH / 4), c4 = i % (KCH / 4);
+        const int col = kc * KCH + c4 * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t0 + r < nt && col < dim) v = *reinterpret_cast<const f32x4*>(T + (size_t)(t0 + r) * dim + col);
+        float* d = Ts + r * TS + c4 * 4;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+      }
+      __syncthreads();
+      if (tid < TB) {
+        float s = tnorm;
+        for (int k = 0; k < KCH; ++k) s = __builtin_fmaf(Ts[tid * TS + k], Ts[tid * TS + k], s);
+        tnorm = s;
+      }
+      // A = train rows of this wave (row = lane&31), B = queries (col = lane&31); k = 2*step + (lane>>5)
+      const float* ap = Ts + (wave * 32 + (lane & 31)) * TS + (lane >> 5);
+      const float* bp = Qs + (lane & 31) * QS + kc * KCH + (lane >> 5);
+#pragma unroll 8
+      for (int ks = 0; ks < KCH / 2; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
+    }
+    if (tid < TB) tn[tid] = tnorm;
+    __syncthreads();
+    // acc[r]: train row i = (r&3) + 8*(r>>2) + 4*(lane>>5) of this wave's 32, query j = lane&31
+    const float qq = qn[lane & 31];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int li = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int gi = t0 + li;
+      if (gi < nt) {
+        const float d2 = (tn[li] + qq) - 2.0f * acc[r];
+        cand_insert(top, d2, gi);
+      }
+    }
+  }
+  // merge the two lane halves (same query, different train rows)
+  {
+    Cand other[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      other[k].d = __shfl_xor(top[k].d, 32, 64);
+      other[k].i = __shfl_xor(top[k].i, 32, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cand_insert(top, other[k].d, other[k].i);
+  }
+  __syncthreads();
+  if (lane < 32) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) merge[(wave * MQ + lane) * 4 + k] = top[k];
+  }
+  __syncthreads();
+  if (wave == 0 && lane < 32) {
+    for (int w = 1; w < 4; ++w)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const Cand c = merge[(w * MQ + lane) * 4 + k];
+        cand_insert(top, c.d, c.i);
+      }
+    if (q0 + lane < nq) {
+      int32_t* out = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + q0 + lane) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[k] = top[k].i == 0x7FFFFFFF ? -1 : top[k].i;
+    }
+  }
+}
+
+// exact distance of one (q, t) row pair with 16 lanes: lane slot s accumulates elements j = 16*i + s
+// (slot s = 4*v + l of OpenCV's four 4-lane accumulators), then the oracle's reduction order.
+__device__ __forceinline__ float exact_dist16(const float* __restrict__ q, const float* __restrict__ t, int dim, int slot,
+                                              int lane) {
+  float acc = 0.f;
+  const int nfull = dim & ~15;
+  for (int j = slot; j < nfull; j += 16) {
+    const float d = q[j] - t[j];
+    const float dd = d * d;
+    acc = acc + dd;
+  }
+  // r[l] = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l]   with slot = 4*v + l
+  const int base = lane & ~15;
+  const int l = slot & 3;
+  const float a0 = __shfl(acc, base + 0 + l, 64), a1 = __shfl(acc, base + 4 + l, 64);
+  const float a2 = __shfl(acc, base + 8 + l, 64), a3 = __shfl(acc, base + 12 + l, 64);
+  const float r = ((a0 + a1) + a2) + a3;  // valid in every lane for its l
+  const float r0 = __shfl(r, base + 0, 64), r1 = __shfl(r, base + 1, 64);
+  const float r2 = __shfl(r, base + 2, 64), r3 = __shfl(r, base + 3, 64);
+  float d = (r0 + r2) + (r1 + r3);
+  for (int j = nfull; j < dim; ++j) { const float e = q[j] - t[j]; d += e * e; }
+  return __builtin_sqrtf(d);
+}
+
+constexpr int FIN_THREADS = 1024;
+constexpr int FIN_MAXN = 1024;
+
+__global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(MatchArgs m) {
+  __shared__ int f0[FIN_MAXN];
+  __shared__ float fd0[FIN_MAXN], fd1[FIN_MAXN];
+  __shared__ int g0[FIN_MAXN];
+  __shared__ float gd0[FIN_MAXN], gd1[FIN_MAXN];
+  __shared__ int wsum[FIN_THREADS / 64];
+  const int pair = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int na = min(m.a_cnt[pair], m.max_n), nb = min(m.b_cnt[pair], m.max_n);
+  const float* A = m.a + (size_t)m.a_off[pair] * m.dim;
+  const float* B = m.b + (size_t)m.b_off[pair] * m.dim;
+  const int dim = m.dim;
+
+  // phase 1: exact 2-NN among the prefiltered candidates; one wave per row, 16 lanes per candidate
+  for (int task = wave; task < na + nb; task += FIN_THREADS / 64) {
+    const int dir = task < na ? 0 : 1;
+    const int row = dir == 0 ? task : task - na;
+    const float* q = (dir == 0 ? A : B) + (size_t)row * dim;
+    const float* Tm = dir == 0 ? B : A;
+    const int32_t* c4 = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + row) * 4;
+    const int ci = c4[lane >> 4];
+    float d = __builtin_inff();
+    // all lanes must run the shuffles: use row 0 as a dummy when the candidate is missing
+    const float* t = Tm + (size_t)(ci >= 0 ? ci : 0) * dim;
+    const float dd = exact_dist16(q, t, dim, lane & 15, lane);
+    if (ci >= 0) d = dd;
+    // gather the four (d, idx) and pick the best two: ascending distance, ties -> lower index
+    float bd0 = __builtin_inff(), bd1 = __builtin_inff();
+    int bi0 = -1, bi1 = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dk = __shfl(d, k * 16, 64);
+      const int ik = __shfl(ci, k * 16, 64);
+      if (ik < 0) continue;
+      if (dk < bd0 || (dk == bd0 && ik < bi0)) { bd1 = bd0; bi1 = bi0; bd0 = dk; bi0 = ik; }
+      else if (dk < bd1 || (dk == bd1 && ik < bi1)) { bd1 = dk; bi1 = ik; }
+    }
+    if (lane == 0) {
+      if (dir == 0) { f0[row] = bi0; fd0[row] = bd0; fd1[row] = bd1; }
+      else { g0[row] = bi0; gd0[row] = bd0; gd1[row] = bd1; }
+    }
+  }
+  __syncthreads();
+  // phase 2: inverse dictionary (feature_matcher.cpp:16-25)
+  for (int j = tid; j < nb; j += FIN_THREADS) {
+    int inv = -1;
+    if (m.mode == 0) {
+      if (na >= 2 && (double)gd0[j] < m.ratio * (double)gd1[j]) inv = g0[j];
+    } else {
+      inv = g0[j];
+    }
+    g0[j] = inv;
+  }
+  __syncthreads();
+  // phase 3: forward test + ordered compaction (ascending query index)
+  int base = 0;
+  for (int i0 = 0; i0 < na; i0 += FIN_THREADS) {
+    const int i = i0 + tid;
+    bool ok = false;
+    if (i < na) {
+      const int j = f0[i];
+      if (m.mode == 0) {
+        ok = nb >= 2 && j >= 0 && (double)fd0[i] < m.ratio * (double)fd1[i] && g0[j] == i;
+        if (ok && m.radius > 0 && m.pts_a && m.pts_b) {
+          const float* pa = m.pts_a + 2 * ((size_t)m.a_off[pair] + i);
+          const float* pb = m.pts_b + 2 * ((size_t)m.b_off[pair] + j);
+          const float dx = pa[0] - pb[0], dy = pa[1] - pb[1];
+          const double nr = __builtin_sqrt((double)dx * dx + (double)dy * dy);
+          if (nr > m.radius) ok = false;
+        }
+      } else {
+        ok = j >= 0 && g0[j] == i;
+      }
+    }
+    const unsigned long long bal = __ballot(ok);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    int total = 0;
+    for (int w = 0; w < FIN_THREADS / 64; ++w) total += wsum[w];
+    if (ok) {
+      const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+      if (pos < m.max_n) {
+        const size_t o = (size_t)pair * m.max_n + pos;
+        m.q_idx[o] = i; m.t_idx[o] = f0[i]; m.dist[o] = fd0[i];
+      }
+    }
+    base += total;
+    __syncthreads();
+  }
+  if (tid == 0) m.n_out[pair] = base < m.max_n ? base : m.max_n;
+}
+
+hipError_t launch_match(const MatchArgs& m, hipStream_t s) {
+  if (m.dim > MAXDIM || (m.dim & 3) || m.max_n > FIN_MAXN || m.max_n < 1) return hipErrorInvalidValue;
+  const size_t lds = sizeof(float) * (MQ * QS + TB * TS + MQ + TB) + sizeof(Cand) * 4 * MQ * 4;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(match_prefilter_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  dim3 grid((m.max_n + MQ - 1) / MQ, 2, m.npairs);
+  hipLaunchKernelGGL(match_prefilter_kernel, grid, dim3(256), lds, s, m);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(match_finalize_kernel, dim3(m.npairs), dim3(FIN_THREADS), 0, s, m);
+  return hipGetLastError();
+}
+
+}  // namespace d2fe

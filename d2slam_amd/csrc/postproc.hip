@@ -1,0 +1,277 @@
+// postproc.hip -- SuperPoint post-processing kept on the device (gfx950).
+//
+// Replaces the CPU code the reference runs after copying the whole score and descriptor maps back to
+// the host: SuperPoint::processOutput and helpers,
+// d2frontend/src/CNN/superpoint_tensorrt.cpp:201-350, plus the in-graph tail of the network
+// (softmax / dustbin drop / 8x8 depth-to-space, d2frontend/superpoint.ipynb:355-364).
+// All kernels here are HBM/latency bound integer+fp32 work; the arithmetic follows the oracle
+// (oracle/d2fe_oracle.c) operation by operation so that scores and indices compare exactly.
+#include "kernels.h"
+
+namespace d2fe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// fma-only expf: SAME operation sequence as orc_expf (oracle/d2fe_oracle.c) -> bitwise-equal results.
+__device__ __forceinline__ float d2fe_expf(float x) {
+  if (x < -87.0f) x = -87.0f;
+  const float t = x * 1.44269504088896341f;
+  const float n = __builtin_rintf(t);
+  float r = __builtin_fmaf(n, -0.693359375f, x);
+  r = __builtin_fmaf(n, 2.12194440e-4f, r);
+  float p = 1.9875691500E-4f;
+  p = __builtin_fmaf(p, r, 1.3981999507E-3f);
+  p = __builtin_fmaf(p, r, 8.3334519073E-3f);
+  p = __builtin_fmaf(p, r, 4.1665795894E-2f);
+  p = __builtin_fmaf(p, r, 1.6666665459E-1f);
+  p = __builtin_fmaf(p, r, 5.0000001201E-1f);
+  const float r2 = r * r;
+  const float y = __builtin_fmaf(p, r2, r) + 1.0f;
+  return __builtin_ldexpf(y, (int)n);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// softmax over 65 logits per 8x8 cell, sequential sum c = 0..64 (oracle order), scores e_c / s.
+// Block = 64 threads = 64 consecutive cells: logits are staged through LDS with coalesced loads, then
+// one thread owns one cell.  Variant-B candidates (superpoint_tensorrt.cpp:201-230: score > thr, inside
+// [border, dim-border)) are appended as keys (score_bits << 32) | (0xFFFFFFFF - raster_idx): descending
+// key order == descending score, ties by ascending raster index (the oracle's tie-break).
+// -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void softmax_cand_kernel(const float* __restrict__ logits, int lstride, int Hc, int Wc,
+                                                          float thr, int border, float* __restrict__ semi,
+                                                          unsigned long long* __restrict__ cand,
+                                                          int* __restrict__ cand_count, long cand_cap) {
+  __shared__ float sl[64 * 65];
+  const int img = blockIdx.y;
+  const int ncell = Hc * Wc;
+  const int cell0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  const float* lg = logits + ((size_t)img * ncell + cell0) * lstride;
+  const int nvalid = min(64, ncell - cell0);
+  for (int i = tid; i < nvalid * 65; i += 64) {
+    const int c = i / 65, k = i % 65;
+    sl[c * 65 + k] = lg[(size_t)c * lstride + k];
+  }
+  __syncthreads();
+  if (tid >= nvalid) return;
+  const float* l = sl + tid * 65;  // stride 65 floats: conflict-free across the wave
+  float m = l[0];
+  for (int c = 1; c < 65; ++c) m = l[c] > m ? l[c] : m;
+  float e[65];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 65; ++c) {
+    e[c] = d2fe_expf(l[c] - m);
+    s += e[c];
+  }
+  const int cell = cell0 + tid;
+  const int cy = cell / Wc, cx = cell % Wc;
+  const int W = Wc * 8, H = Hc * 8;
+  unsigned long long* cd = cand + (size_t)img * cand_cap;
+#pragma unroll
+  for (int c = 0; c < 64; ++c) {
+    const float p = e[c] / s;
+    const int y = cy * 8 + (c >> 3), x = cx * 8 + (c & 7);
+    const int idx = y * W + x;
+    if (semi) semi[(size_t)img * H * W + idx] = p;
+    if (p > thr && y >= border && y < H - border && x >= border && x < W - border) {
+      const int slot = atomicAdd(cand_count + img, 1);
+      if (slot < cand_cap)
+        cd[slot] = ((unsigned long long)__float_as_uint(p) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
+    }
+  }
+}
+
+hipError_t launch_softmax_cand(const float* logits, int lstride, int Hc, int Wc, int n_img, float thr, int border,
+                               float* semi, unsigned long long* cand, int* cand_count, long cand_cap, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(cand_count, 0, sizeof(int) * n_img, s);
+  if (e != hipSuccess) return e;
+  dim3 grid((Hc * Wc + 63) / 64, n_img), block(64);
+  hipLaunchKernelGGL(softmax_cand_kernel, grid, block, 0, s, logits, lstride, Hc, Wc, thr, border, semi, cand,
+                     cand_count, cand_cap);
+  return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Variant-B selection (topKeypoints, superpoint_tensorrt.cpp:241-253): one 1024-thread block per image.
+//   count <= K : keep all, in RASTER order (the reference does not sort in this case)
+//   count >  K : the K largest keys, in descending key order (score desc, raster asc on ties)
+// Exact selection by MSB-first radix select on the unique 64-bit keys, then an in-LDS bitonic sort.
+// -----------------------------------------------------------------------------------------------------
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_MAXK = 1024;
+
+__global__ __launch_bounds__(SEL_THREADS) void select_b_kernel(const unsigned long long* __restrict__ cand,
+                                                               const int* __restrict__ cand_count, long cand_cap,
+                                                               int W, int max_kp, int cap, float* __restrict__ kps_xy,
+                                                               float* __restrict__ scores, int32_t* __restrict__ kps_idx,
+                                                               int32_t* __restrict__ n_out) {
+  __shared__ unsigned long long keys[SEL_MAXK];
+  __shared__ int hist[256];
+  __shared__ int s_digit, s_need, s_cnt;
+  const int img = blockIdx.x;
+  const int tid = threadIdx.x;
+  const unsigned long long* c = cand + (size_t)img * cand_cap;
+  long n = cand_count[img];
+  if (n > cand_cap) n = cand_cap;
+  int K = (max_kp < 0) ? cap : min(max_kp, cap);
+  if (K > SEL_MAXK) K = SEL_MAXK;
+  const bool take_all = (n <= K);
+  // When everything is kept the output order is raster (the reference does not sort): sort on the low word
+  // (0xFFFFFFFF - idx, descending == idx ascending) and let the score bits ride along in the low half.
+  unsigned long long thresh = 0;  // keep keys >= thresh
+  int nk = (int)n;
+  if (!take_all) {
+    // radix select: find the K-th largest key
+    unsigned long long prefix = 0, mask = 0;
+    int need = K;
+    for (int pass = 7; pass >= 0; --pass) {
+      const int shift = pass * 8;
+      for (int i = tid; i < 256; i += SEL_THREADS) hist[i] = 0;
+      __syncthreads();
+      for (long i = tid; i < n; i += SEL_THREADS) {
+        const unsigned long long k = c[i];
+        if ((k & mask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 0xFF)], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int acc = 0, d = 255;
+        for (; d > 0; --d) {
+          if (acc + hist[d] >= need) break;
+          acc += hist[d];
+        }
+        s_digit = d;
+        s_need = need - acc;
+      }
+      __syncthreads();
+      prefix |= ((unsigned long long)s_digit) << shift;
+      mask |= 0xFFull << shift;
+      need = s_need;
+      __syncthreads();
+    }
+    thresh = prefix;  // exactly K keys are >= thresh (keys are unique)
+    nk = K;
+  }
+  // gather survivors into LDS
+  if (tid == 0) s_cnt = 0;
+  for (int i = tid; i < SEL_MAXK; i += SEL_THREADS) keys[i] = 0;
+  __syncthreads();
+  for (long i = tid; i < n; i += SEL_THREADS) {
+    const unsigned long long k = c[i];
+    if (k >= thresh) {
+      const int slot = atomicAdd(&s_cnt, 1);
+      if (slot < SEL_MAXK) keys[slot] = take_all ? ((k << 32) | (k >> 32)) : k;
+    }
+  }
+  __syncthreads();
+  // bitonic sort, descending, SEL_MAXK elements (zeros sink to the end)
+  for (int k2 = 2; k2 <= SEL_MAXK; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      const int i = tid, ixj = i ^ j;
+      if (ixj > i) {
+        const unsigned long long x = keys[i], y = keys[ixj];
+        const bool desc = ((i & k2) == 0);
+        if (desc ? (x < y) : (x > y)) { keys[i] = y; keys[ixj] = x; }
+      }
+      __syncthreads();
+    }
+  if (tid == 0) n_out[img] = nk;
+  if (tid < nk) {
+    unsigned long long k = keys[tid];
+    if (take_all) k = (k << 32) | (k >> 32);
+    const unsigned idx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+    const float sc = __uint_as_float((unsigned)(k >> 32));
+    const size_t o = (size_t)img * cap + tid;
+    kps_xy[2 * o] = (float)(idx % (unsigned)W);
+    kps_xy[2 * o + 1] = (float)(idx / (unsigned)W);
+    scores[o] = sc;
+    if (kps_idx) kps_idx[o] = (int32_t)idx;
+  }
+}
+
+hipError_t launch_select_b(const unsigned long long* cand, const int* cand_count, long cand_cap, int n_img, int W,
+                           int max_kp, int cap, float* kps_xy, float* scores, int32_t* kps_idx, int32_t* n_out,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(select_b_kernel, dim3(n_img), dim3(SEL_THREADS), 0, s, cand, cand_count, cand_cap, W, max_kp, cap,
+                     kps_xy, scores, kps_idx, n_out);
+  return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Variant-B descriptor sampling: normalize_keypoints (:255-265), grid_sample (:272-310) and
+// normalize_descriptors (:312-317) of superpoint_tensorrt.cpp.  One wave per keypoint, 4 channels per lane
+// (256 = 64 x 4): each corner is one coalesced 1 KiB read of the NHWC descriptor map.  The dense channel-L2
+// normalisation of the network's `desc` output (superpoint.ipynb:352-353) is applied to the four corner
+// cells on the fly, so the normalised 4.9 MB map is never written.
+// -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int clipi(int v, int mx) { return v < 0 ? 0 : (v < mx - 1 ? v : mx - 1); }
+
+__global__ __launch_bounds__(256) void sample_b_kernel(const float* __restrict__ desc_raw, int dstride, int dcoff, int Hc,
+                                                       int Wc, const float* __restrict__ kps_xy,
+                                                       const int32_t* __restrict__ n_kp, int cap,
+                                                       float* __restrict__ desc_out) {
+  const int img = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= n_kp[img] || k >= cap) return;
+  const size_t o = (size_t)img * cap + k;
+  const float x = kps_xy[2 * o], y = kps_xy[2 * o + 1];
+  const int s = 8;
+  // literal transcription of the reference's mixed float/double arithmetic (see orc_sample_b)
+  float k0 = (float)((double)(x - (float)(s / 2)) + 0.5);
+  float k1 = (float)((double)(y - (float)(s / 2)) + 0.5);
+  k0 = (float)((double)k0 / ((double)(Wc * s - s / 2) - 0.5));
+  k1 = (float)((double)k1 / ((double)(Hc * s - s / 2) - 0.5));
+  k0 = k0 * 2.0f - 1.0f;
+  k1 = k1 * 2.0f - 1.0f;
+  const float ix = ((k0 + 1.0f) / 2.0f) * (float)(Wc - 1);
+  const float iy = ((k1 + 1.0f) / 2.0f) * (float)(Hc - 1);
+  const int ix_nw = clipi((int)__builtin_floorf(ix), Wc), iy_nw = clipi((int)__builtin_floorf(iy), Hc);
+  const int ix_ne = clipi(ix_nw + 1, Wc), iy_ne = clipi(iy_nw, Hc);
+  const int ix_sw = clipi(ix_nw, Wc), iy_sw = clipi(iy_nw + 1, Hc);
+  const int ix_se = clipi(ix_nw + 1, Wc), iy_se = clipi(iy_nw + 1, Hc);
+  const float nw = ((float)ix_se - ix) * ((float)iy_se - iy);
+  const float ne = (ix - (float)ix_sw) * ((float)iy_sw - iy);
+  const float sw = ((float)ix_ne - ix) * (iy - (float)iy_ne);
+  const float se = (ix - (float)ix_nw) * (iy - (float)iy_nw);
+  const float* base = desc_raw + (size_t)img * Hc * Wc * dstride + dcoff + lane * 4;
+  const f32x4 vnw = *reinterpret_cast<const f32x4*>(base + ((size_t)iy_nw * Wc + ix_nw) * dstride);
+  const f32x4 vne = *reinterpret_cast<const f32x4*>(base + ((size_t)iy_ne * Wc + ix_ne) * dstride);
+  const f32x4 vsw = *reinterpret_cast<const f32x4*>(base + ((size_t)iy_sw * Wc + ix_sw) * dstride);
+  const f32x4 vse = *reinterpret_cast<const f32x4*>(base + ((size_t)iy_se * Wc + ix_se) * dstride);
+  auto sq = [](const f32x4& v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; };
+  const float n_nw = __builtin_sqrtf(wave_sum(sq(vnw)));
+  const float n_ne = __builtin_sqrtf(wave_sum(sq(vne)));
+  const float n_sw = __builtin_sqrtf(wave_sum(sq(vsw)));
+  const float n_se = __builtin_sqrtf(wave_sum(sq(vse)));
+  f32x4 d;
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float v = (vnw[j] / n_nw) * nw;
+    v = v + (vne[j] / n_ne) * ne;
+    v = v + (vsw[j] / n_sw) * sw;
+    v = v + (vse[j] / n_se) * se;
+    d[j] = v;
+    ss += v * v;
+  }
+  ss = wave_sum(ss);
+  const float ninv = (float)(1.0 / (double)__builtin_sqrtf(ss));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) d[j] = d[j] * ninv;
+  *reinterpret_cast<f32x4*>(desc_out + o * 256 + lane * 4) = d;
+}
+
+hipError_t launch_sample_b(const float* desc_raw, int dstride, int dcoff, int Hc, int Wc, int n_img, const float* kps_xy,
+                           const int32_t* n_kp, int cap, float* desc_out, hipStream_t s) {
+  dim3 grid((cap + 3) / 4, n_img), block(256);
+  hipLaunchKernelGGL(sample_b_kernel, grid, block, 0, s, desc_raw, dstride, dcoff, Hc, Wc, kps_xy, n_kp, cap, desc_out);
+  return hipGetLastError();
+}
+
+}  // namespace d2fe

@@ -1,0 +1,160 @@
+/*
+ * d2fe.h -- C ABI of libd2fe_hip.so: the MI355X (gfx950) implementation of D2SLAM's d2frontend
+ * feature hot path (SuperPoint extraction, NetVLAD global descriptor, brute-force descriptor matching).
+ *
+ * Every entry point below replaces one call the reference makes into TensorRT / ONNX Runtime / OpenCV;
+ * the reference interface it stands in for is cited as file:line relative to the D2SLAM tree.
+ * Conventions: plain pointers and sizes only; caller owns every buffer; nothing is retained past return;
+ * functions return 0 (D2FE_OK) or a negative d2fe_status and never throw; d2fe_last_error() describes the
+ * last failure on the calling thread.  Pointers are HOST pointers unless the parameter name starts with d_.
+ */
+#ifndef D2FE_H_
+#define D2FE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define D2FE_API __attribute__((visibility("default")))
+#else
+#define D2FE_API
+#endif
+
+typedef struct d2fe_context* d2fe_handle;
+
+typedef enum {
+  D2FE_OK = 0,
+  D2FE_ERR_INVALID = -1,     /* bad argument / size mismatch (reference: assert, superpoint_onnx.cpp:74-75) */
+  D2FE_ERR_HIP = -2,         /* HIP runtime failure (reference: infer() returns false, superpoint_tensorrt.cpp:164-170) */
+  D2FE_ERR_NOT_READY = -3,   /* weights not loaded */
+  D2FE_ERR_TRUNCATED = -4,   /* output capacity too small; n_out holds what was written */
+  D2FE_ERR_UNSUPPORTED = -5
+} d2fe_status;
+
+/* Post-processing variant. B is the live USE_CUDA path of the reference. */
+typedef enum {
+  D2FE_POSTPROC_B = 0, /* SuperPoint::processOutput, superpoint_tensorrt.cpp:327-350: threshold, borders, top-K */
+  D2FE_POSTPROC_A = 1  /* SuperPointONNX: getKeyPoints + NMS2 + grid_sampler, superpoint_common.cpp:12-177 */
+} d2fe_postproc;
+
+typedef enum {
+  D2FE_PREC_F32 = 0,   /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): bitwise equal to the oracle's fmaf chains */
+  D2FE_PREC_F16X2 = 1  /* fp16 hi/lo split operands, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate (~2^-22 rel.) */
+} d2fe_precision;
+
+/* Mirrors SuperPointConfig (d2frontend/include/d2frontend/CNN/superpoint_tensorrt.h:17-33) plus the
+ * SuperPointONNX ctor arguments (superpoint_onnx.h:17-21) and the device/batch geometry. */
+typedef struct {
+  int32_t struct_size;        /* sizeof(d2fe_config), for forward compatibility */
+  int32_t device_id;          /* HIP device ordinal */
+  int32_t max_width;          /* largest input width (multiple of 8)  -- SuperPointConfig::input_width  */
+  int32_t max_height;         /* largest input height (multiple of 8) -- SuperPointConfig::input_height */
+  int32_t max_batch;          /* images per batched call (>= 1) */
+  int32_t max_keypoints;      /* SuperPointConfig::max_keypoints (1..1024)  [params->max_superpoint_cnt] */
+  int32_t remove_borders;     /* SuperPointConfig::remove_borders (variant B), default 1 */
+  float   keypoint_threshold; /* SuperPointConfig::keypoint_threshold, default 0.015 */
+  int32_t postproc;           /* d2fe_postproc */
+  int32_t nms_dist;           /* variant A: NMS2 dist_thresh (SuperPointONNX::nms_dist) */
+  int32_t precision;          /* d2fe_precision */
+  int32_t reserved[8];
+} d2fe_config;
+
+/* One conv layer in PyTorch layout: weight [cout][cin][k][k], bias [cout]. */
+typedef struct {
+  const float* weight;
+  const float* bias;
+  int32_t cout, cin, ksize;
+} d2fe_conv_params;
+
+/* The 12 SuperPoint layers in the order of d2frontend/superpoint.ipynb:306-321:
+ * conv1a conv1b conv2a conv2b conv3a conv3b conv4a conv4b convPa convPb convDa convDb */
+#define D2FE_SP_NUM_LAYERS 12
+typedef struct {
+  d2fe_conv_params layer[D2FE_SP_NUM_LAYERS];
+} d2fe_superpoint_weights;
+
+D2FE_API const char* d2fe_last_error(void);
+D2FE_API const char* d2fe_version(void);
+D2FE_API void d2fe_default_config(d2fe_config* cfg);
+
+/* Lifecycle.  Replaces: LoopCam ctor building the networks (loop_cam.cpp:24-70),
+ * SuperPoint::SuperPoint + SuperPoint::build (superpoint_tensorrt.cpp:17-107). */
+D2FE_API int d2fe_create(const d2fe_config* cfg, d2fe_handle* out);
+D2FE_API void d2fe_destroy(d2fe_handle h);
+/* Replaces the ONNX parse / engine deserialisation (superpoint_tensorrt.cpp:109-125,376-398):
+ * weights are copied, re-packed into MFMA fragment order and cached on the device. */
+D2FE_API int d2fe_load_superpoint(d2fe_handle h, const d2fe_superpoint_weights* w);
+
+/* Extractor.  Replaces: bool SuperPoint::infer(const cv::Mat&, std::vector<cv::Point2f>&, std::vector<float>&
+ * descriptors, std::vector<float>& scores) (superpoint_tensorrt.h:47-48, .cpp:161-183), called from
+ * LoopCam::extractorImgDescDeepnet (loop_cam.cpp:609-610).
+ *   gray: u8 image, height rows of `stride` bytes.   kps_xy: cap*2 floats (x,y).   scores: cap floats.
+ *   desc: cap*256 floats keypoint-major.   *n_out = number of keypoints written (0 on failure).
+ * Order of outputs = selection order of the chosen variant (B: raster if K<=N else score-desc; A: score-desc).
+ * Not re-entrant per handle (the reference has one caller thread, d2frontend.cpp:155-169). */
+D2FE_API int d2fe_superpoint_extract(d2fe_handle h, const uint8_t* gray, int width, int height, int stride,
+                                     float* kps_xy, float* scores, float* desc, int cap, int* n_out);
+
+/* Batched form of the same call: n images of identical size, image i at gray + i*image_stride bytes;
+ * outputs of image i at kps_xy + i*cap*2, scores + i*cap, desc + i*cap*256, n_out[i]. */
+D2FE_API int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int height,
+                                           int stride, size_t image_stride, float* kps_xy, float* scores,
+                                           float* desc, int cap, int* n_out);
+
+/* Device-resident form: inputs already in HBM (d_gray) and outputs left in HBM (d_*), asynchronous on
+ * `stream` (a hipStream_t, or NULL for the handle's own stream).  d_n_out: n int32 counts.
+ * d_kps_idx (optional, may be NULL): raster indices y*W+x of the keypoints. */
+D2FE_API int d2fe_superpoint_extract_device(d2fe_handle h, const uint8_t* d_gray, int n, int width, int height,
+                                            int stride, size_t image_stride, float* d_kps_xy, float* d_scores,
+                                            float* d_desc, int32_t* d_kps_idx, int cap, int32_t* d_n_out,
+                                            void* stream);
+
+/* Matcher.  Replaces: std::vector<cv::DMatch> matchKNN(const cv::Mat& desc_a, const cv::Mat& desc_b,
+ * double knn_match_ratio, pts_a, pts_b, double search_local_dist) (feature_matcher.h:6-11,
+ * feature_matcher.cpp:4-42).  a: na x dim row-major, b: nb x dim.  pts_*: n x 2 floats or NULL.
+ * radius <= 0 disables the pixel gate.  Outputs ascending in query index; *n_out matches written.
+ * Re-entrant (the reference calls it from three threads). */
+D2FE_API int d2fe_match_knn(d2fe_handle h, const float* a, int na, const float* b, int nb, int dim, double ratio,
+                            const float* pts_a, const float* pts_b, double radius, int32_t* q_idx,
+                            int32_t* t_idx, float* dist, int cap, int* n_out);
+
+/* Replaces: cv::BFMatcher(cv::NORM_L2, true).match(desc_a, desc_b, matches)
+ * (loop_cam.cpp:167-170, d2featuretracker.cpp:1141-1142,1175-1176, loop_detector.cpp:576-577). */
+D2FE_API int d2fe_match_crosscheck(d2fe_handle h, const float* a, int na, const float* b, int nb, int dim,
+                                   int32_t* q_idx, int32_t* t_idx, float* dist, int cap, int* n_out);
+
+/* Batched, device-resident matcher: npairs problems; pair p matches rows [a_off[p], a_off[p]+a_cnt[p]) of
+ * d_a against rows [b_off[p], ...) of d_b.  Counts may live on the device (d_a_cnt/d_b_cnt, e.g. the d_n_out
+ * of an extract call) -- pass max_n as the upper bound of any count.  mode: 0 = matchKNN, 1 = cross-check.
+ * Outputs: pair p writes at most max_n matches at d_q_idx + p*max_n etc., and d_n_out[p]. */
+typedef struct {
+  const float* d_a; const float* d_b;             /* descriptor pools, row-major dim floats per row */
+  const float* d_pts_a; const float* d_pts_b;     /* optional pools of (x,y), may be NULL */
+  const int32_t* d_a_off; const int32_t* d_b_off; /* [npairs] first row of each side */
+  const int32_t* d_a_cnt; const int32_t* d_b_cnt; /* [npairs] row counts (device) */
+  int32_t npairs, dim, max_n, mode;
+  double ratio, radius;
+  int32_t* d_q_idx; int32_t* d_t_idx; float* d_dist; int32_t* d_n_out;
+} d2fe_match_batch;
+D2FE_API int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* stream);
+
+/* Half-image filter for quadcam neighbour matching.  Replaces getFeatureHalfImg
+ * (d2featuretracker.cpp:1051-1075): map[c] = source index of the c-th kept keypoint; returns count in *n_out. */
+D2FE_API int d2fe_half_image_filter(const float* pts_xy, int n, int require_left, int width_undistort,
+                                    double undistort_fov, int32_t* map, int* n_out);
+
+/* Debug/inspection: copy an internal device tensor of the last extract call to the host.
+ * names: "conv1a".."conv4b","convPaDa","logits","desc_raw","semi".  Returns bytes copied or <0. */
+D2FE_API long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_bytes);
+
+/* Synchronise the handle's stream (for timing with device-resident calls). */
+D2FE_API int d2fe_sync(d2fe_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D2FE_H_ */

@@ -1,0 +1,475 @@
+/*
+ * d2fe_oracle.c -- CPU restatement ("oracle") of the D2SLAM d2frontend feature hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  The shipped path (the HIP sources in d2slam_amd/csrc behind
+ * include/d2fe.h) never calls into this file and has no CPU fallback.
+ *
+ * PARITY STATUS: **parity unpinned**.  The reference ships no golden vectors, no
+ * assertion-based tests and no model weights for this path, and it cannot
+ * be compiled here (needs OpenCV/Eigen/TensorRT/ROS).  The oracle is
+ * therefore a line-by-line restatement of the reference sources cited on each function,
+ * cross-checked in tests/ against independent PyTorch-CPU implementations of the same ops
+ * (conv2d/max_pool2d/softmax fp32+fp64, and F.grid_sample -- the very ATen kernel the
+ * reference's variant-A path calls).
+ *
+ * Numerical definition.  Where the reference leaves floating-point evaluation order to a
+ * third-party engine (TensorRT conv kernels, OpenCV SIMD reductions, Eigen reductions) the
+ * oracle fixes one order and says so:
+ *   - convolutions: one k-ordered fp32 fmaf chain per output, k = (ky, kx, ci) ascending,
+ *     accumulator initialised with the bias.  (This is also bit-for-bit what gfx950's
+ *     v_mfma_f32_32x32x2_f32 computes, so the HIP "exact" mode can be compared bitwise.)
+ *   - softmax: max, then e = exp(x - max) with the fma-only expf below, sequential sum over
+ *     c = 0..64, IEEE division.
+ *   - unstable std::sort calls in the reference get the deterministic tie-break
+ *     "equal score -> lower raster index first" (marked there).
+ *
+ * Layouts: activations are NHWC fp32; weights are passed in PyTorch layout
+ * [cout][cin][kh][kw] (the layout of the SuperPointNet state_dict in
+ * d2frontend/superpoint.ipynb cell 1, /root/reference) and re-ordered internally.
+ *
+ * Build: see oracle/Makefile  (gcc -O2 -mavx2 -mfma -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * A1  image prep.  Reference: SuperPoint::processInput, d2frontend/src/CNN/superpoint_tensorrt.cpp:185-198
+ *     image.convertTo(mono, CV_32FC1, 1.0/255.0)  -> OpenCV cvt for 8U->32F evaluates
+ *     (float)src * (float)alpha in single precision.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_prep_u8(const uint8_t* img, int h, int w, int stride, float* out) {
+  const float a = (float)(1.0 / 255.0);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) out[(size_t)y * w + x] = (float)img[(size_t)y * stride + x] * a;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A2  SuperPoint network.  Reference: d2frontend/superpoint.ipynb:300-374 (class SuperPointNetHalf)
+ * ---------------------------------------------------------------------------------------- */
+
+/* KxK conv (K = 1 or 3), stride 1, zero pad K/2, NHWC in/out, optional ReLU.
+ * wgt: [cout][cin][K][K] (PyTorch).  One fmaf chain per output in (ky,kx,ci) order, acc0 = bias.
+ * Out-of-image taps are skipped (== fmaf(0, w, acc) up to the sign of zero). */
+ORC_API void orc_conv(const float* in, int h, int w, int cin, const float* wgt, const float* bias,
+                      int cout, int ksize, int relu, float* out) {
+  const int K = ksize, P = K / 2;
+  /* re-order weights to [ky][kx][ci][co] so the co loop vectorises */
+  float* wt = (float*)malloc(sizeof(float) * (size_t)K * K * cin * cout);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int ky = 0; ky < K; ++ky)
+        for (int kx = 0; kx < K; ++kx)
+          wt[(((size_t)ky * K + kx) * cin + ci) * cout + co] =
+              wgt[(((size_t)co * cin + ci) * K + ky) * K + kx];
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h; ++y) {
+    float* acc = (float*)malloc(sizeof(float) * cout);
+    for (int x = 0; x < w; ++x) {
+      for (int co = 0; co < cout; ++co) acc[co] = bias[co];
+      for (int ky = 0; ky < K; ++ky) {
+        const int yy = y + ky - P;
+        if (yy < 0 || yy >= h) continue;
+        for (int kx = 0; kx < K; ++kx) {
+          const int xx = x + kx - P;
+          if (xx < 0 || xx >= w) continue;
+          const float* ip = in + ((size_t)yy * w + xx) * cin;
+          const float* wp = wt + ((size_t)ky * K + kx) * cin * cout;
+          for (int ci = 0; ci < cin; ++ci) {
+            const float a = ip[ci];
+            const float* wr = wp + (size_t)ci * cout;
+            for (int co = 0; co < cout; ++co) acc[co] = fmaf(a, wr[co], acc[co]);
+          }
+        }
+      }
+      float* op = out + ((size_t)y * w + x) * cout;
+      if (relu)
+        for (int co = 0; co < cout; ++co) op[co] = acc[co] > 0.f ? acc[co] : 0.f;
+      else
+        for (int co = 0; co < cout; ++co) op[co] = acc[co];
+    }
+    free(acc);
+  }
+  free(wt);
+}
+
+/* MaxPool2d(kernel 2, stride 2), NHWC.  superpoint.ipynb:304,336,339,342 */
+ORC_API void orc_maxpool2(const float* in, int h, int w, int c, float* out) {
+  const int ho = h / 2, wo = w / 2;
+  for (int y = 0; y < ho; ++y)
+    for (int x = 0; x < wo; ++x)
+      for (int k = 0; k < c; ++k) {
+        const float a = in[((size_t)(2 * y) * w + 2 * x) * c + k];
+        const float b = in[((size_t)(2 * y) * w + 2 * x + 1) * c + k];
+        const float d = in[((size_t)(2 * y + 1) * w + 2 * x) * c + k];
+        const float e = in[((size_t)(2 * y + 1) * w + 2 * x + 1) * c + k];
+        const float m0 = a > b ? a : b, m1 = d > e ? d : e;
+        out[((size_t)y * wo + x) * c + k] = m0 > m1 ? m0 : m1;
+      }
+}
+
+/* fma-only expf, identical instruction sequence on CPU (this file) and GPU (postproc.hip):
+ * range reduction x = n ln2 + r, degree-6 polynomial (Cephes coefficients), ldexp.
+ * Max error vs libm expf: <= 2 ulp on [-87, 0] (checked in tests/test_oracle.py). */
+ORC_API float orc_expf(float x) {
+  if (x < -87.0f) x = -87.0f;
+  const float t = x * 1.44269504088896341f;
+  const float n = rintf(t);
+  float r = fmaf(n, -0.693359375f, x);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float p = 1.9875691500E-4f;
+  p = fmaf(p, r, 1.3981999507E-3f);
+  p = fmaf(p, r, 8.3334519073E-3f);
+  p = fmaf(p, r, 4.1665795894E-2f);
+  p = fmaf(p, r, 1.6666665459E-1f);
+  p = fmaf(p, r, 5.0000001201E-1f);
+  const float r2 = r * r;
+  const float y = fmaf(p, r2, r) + 1.0f;
+  return ldexpf(y, (int)n);
+}
+
+/* softmax over 65 channels, drop dustbin (ch 64), unfold 8x8 cells to [H][W].
+ * superpoint.ipynb:355-364.  logits: [hc][wc][65] (NHWC).  semi: [hc*8][wc*8]. */
+ORC_API void orc_softmax_semi(const float* logits, int hc, int wc, float* semi) {
+  const int W = wc * 8;
+  for (int cy = 0; cy < hc; ++cy)
+    for (int cx = 0; cx < wc; ++cx) {
+      const float* l = logits + ((size_t)cy * wc + cx) * 65;
+      float m = l[0];
+      for (int c = 1; c < 65; ++c) m = l[c] > m ? l[c] : m;
+      float e[65], s = 0.f;
+      for (int c = 0; c < 65; ++c) {
+        e[c] = orc_expf(l[c] - m);
+        s += e[c];
+      }
+      for (int c = 0; c < 64; ++c)
+        semi[(size_t)(cy * 8 + c / 8) * W + cx * 8 + (c % 8)] = e[c] / s;
+    }
+}
+
+/* channel L2 normalisation of the dense descriptor map, NHWC [n][c].
+ * superpoint.ipynb:352-353  (dn = norm(desc,2,dim=1); desc = desc / dn) */
+ORC_API void orc_l2norm_rows(const float* in, int n, int c, float* out) {
+  for (int i = 0; i < n; ++i) {
+    float s = 0.f;
+    for (int k = 0; k < c; ++k) s = fmaf(in[(size_t)i * c + k], in[(size_t)i * c + k], s);
+    const float nrm = sqrtf(s);
+    for (int k = 0; k < c; ++k) out[(size_t)i * c + k] = in[(size_t)i * c + k] / nrm;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A3/A4  Variant-B selection.  Reference: SuperPoint::processOutput :327-350,
+ *        findHighScoreIndex :201-212, removeBorders :215-230, sortIndexes/topKeypoints :233-253
+ *        (d2frontend/src/CNN/superpoint_tensorrt.cpp).  SURVEY.md Appendix B.1.
+ * Returns number of keypoints (<= cap); kps_xy[2*i] = x, kps_xy[2*i+1] = y; idx_out = raster index.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { float s; int idx; } orc_cand;
+static int orc_cand_cmp(const void* a, const void* b) {
+  const orc_cand* p = (const orc_cand*)a; const orc_cand* q = (const orc_cand*)b;
+  if (p->s > q->s) return -1;
+  if (p->s < q->s) return 1;
+  return p->idx < q->idx ? -1 : (p->idx > q->idx ? 1 : 0); /* deterministic tie-break */
+}
+ORC_API int orc_select_b(const float* semi, int h, int w, float thr, int border, int max_kp,
+                         float* kps_xy, float* scores, int32_t* idx_out, int cap) {
+  orc_cand* c = (orc_cand*)malloc(sizeof(orc_cand) * (size_t)h * w);
+  int n = 0;
+  for (int i = 0; i < h * w; ++i) {
+    if (!(semi[i] > thr)) continue;                /* strict >  (:205) */
+    const int x = i % w, y = i / w;
+    if (!(y >= border && y < h - border && x >= border && x < w - border)) continue; /* :221-222 */
+    c[n].s = semi[i]; c[n].idx = i; ++n;
+  }
+  if (max_kp != -1 && max_kp < n) {                /* :242  only then is anything sorted */
+    qsort(c, n, sizeof(orc_cand), orc_cand_cmp);
+    n = max_kp;
+  }
+  if (n > cap) n = cap;
+  for (int i = 0; i < n; ++i) {
+    kps_xy[2 * i] = (float)(c[i].idx % w);
+    kps_xy[2 * i + 1] = (float)(c[i].idx / w);
+    scores[i] = c[i].s;
+    if (idx_out) idx_out[i] = c[i].idx;
+  }
+  free(c);
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A5  Variant-B descriptor sampling.  Reference: normalize_keypoints :255-265, grid_sample :272-310,
+ *     normalize_descriptors :312-317 (superpoint_tensorrt.cpp).  desc_map: NHWC [hc][wc][dim],
+ *     already channel-L2-normalised (the engine's "desc" output).  s = 8.
+ *     The mixed float/double arithmetic of the C++ source is reproduced literally.
+ * ---------------------------------------------------------------------------------------- */
+static int orc_clip(int v, int mx) { if (v < 0) return 0; return v < mx - 1 ? v : mx - 1; }
+ORC_API void orc_sample_b(const float* desc_map, int hc, int wc, int dim, const float* kps_xy, int n,
+                          float* out) {
+  const int s = 8;
+  for (int i = 0; i < n; ++i) {
+    /* kp = {x - s/2 + 0.5, ...}: float - int -> float, + 0.5 (double) -> double -> stored float */
+    float k0 = (float)((double)(kps_xy[2 * i] - (float)(s / 2)) + 0.5);
+    float k1 = (float)((double)(kps_xy[2 * i + 1] - (float)(s / 2)) + 0.5);
+    k0 = (float)((double)k0 / ((double)(wc * s - s / 2) - 0.5));
+    k1 = (float)((double)k1 / ((double)(hc * s - s / 2) - 0.5));
+    k0 = k0 * 2.0f - 1.0f;
+    k1 = k1 * 2.0f - 1.0f;
+    const float ix = ((k0 + 1.0f) / 2.0f) * (float)(wc - 1);
+    const float iy = ((k1 + 1.0f) / 2.0f) * (float)(hc - 1);
+    const int ix_nw = orc_clip((int)floorf(ix), wc), iy_nw = orc_clip((int)floorf(iy), hc);
+    const int ix_ne = orc_clip(ix_nw + 1, wc), iy_ne = orc_clip(iy_nw, hc);
+    const int ix_sw = orc_clip(ix_nw, wc), iy_sw = orc_clip(iy_nw + 1, hc);
+    const int ix_se = orc_clip(ix_nw + 1, wc), iy_se = orc_clip(iy_nw + 1, hc);
+    const float nw = ((float)ix_se - ix) * ((float)iy_se - iy);
+    const float ne = (ix - (float)ix_sw) * ((float)iy_sw - iy);
+    const float sw = ((float)ix_ne - ix) * (iy - (float)iy_ne);
+    const float se = (ix - (float)ix_nw) * (iy - (float)iy_nw);
+    const float* pnw = desc_map + ((size_t)iy_nw * wc + ix_nw) * dim;
+    const float* pne = desc_map + ((size_t)iy_ne * wc + ix_ne) * dim;
+    const float* psw = desc_map + ((size_t)iy_sw * wc + ix_sw) * dim;
+    const float* pse = desc_map + ((size_t)iy_se * wc + ix_se) * dim;
+    float* d = out + (size_t)i * dim;
+    float ss = 0.f;
+    for (int k = 0; k < dim; ++k) {
+      float v = pnw[k] * nw;
+      v = v + pne[k] * ne;
+      v = v + psw[k] * sw;
+      v = v + pse[k] * se;
+      d[k] = v;
+      ss += v * v;                                   /* Eigen norm(): sqrt(sum sq) in float */
+    }
+    const float ninv = (float)(1.0 / (double)sqrtf(ss)); /* double reciprocal, float scale (:314-315) */
+    for (int k = 0; k < dim; ++k) d[k] = d[k] * ninv;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A6  Variant-A candidates + NMS2.  Reference: getKeyPoints superpoint_common.cpp:12-40,
+ *     NMS2 :107-177.  SURVEY.md Appendix B.2.  CV_16UC1 index-map wraparound reproduced.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API int orc_nms2_a(const float* prob, int h, int w, float thr, int dist_thresh, int border,
+                       int max_num, float* kps_xy, float* scores, int cap) {
+  const size_t hw = (size_t)h * w;
+  int* cand = (int*)malloc(sizeof(int) * hw);
+  uint8_t* grid = (uint8_t*)calloc(hw, 1);
+  uint16_t* inds = (uint16_t*)calloc(hw, 2);
+  float* conf = (float*)calloc(hw, 4);
+  int n = 0;
+  for (size_t i = 0; i < hw; ++i)
+    if (prob[i] > thr) cand[n++] = (int)i;           /* cv::findNonZero raster order (:17-19) */
+  for (int i = 0; i < n; ++i) {
+    grid[cand[i]] = 1; inds[cand[i]] = (uint16_t)i; conf[cand[i]] = prob[cand[i]];
+  }
+  for (int i = 0; i < n; ++i) {
+    const int uu = cand[i] % w, vv = cand[i] / w;
+    if (grid[cand[i]] != 1) continue;
+    for (int k = -dist_thresh; k < dist_thresh + 1; ++k)
+      for (int j = -dist_thresh; j < dist_thresh + 1; ++j) {
+        if (j == 0 && k == 0) continue;
+        if (uu + j < 0 || uu + j >= w || vv + k < 0 || vv + k >= h) continue;
+        if (conf[(size_t)(vv + k) * w + uu + j] < conf[cand[i]]) grid[(size_t)(vv + k) * w + uu + j] = 0;
+      }
+    grid[cand[i]] = 2;
+  }
+  orc_cand* kept = (orc_cand*)malloc(sizeof(orc_cand) * (size_t)(n > 0 ? n : 1));
+  orc_cand* dec = (orc_cand*)malloc(sizeof(orc_cand) * (size_t)(n > 0 ? n : 1));
+  int m = 0;
+  for (int v = 0; v < h; ++v)
+    for (int u = 0; u < w; ++u) {
+      if (u >= w - border || u < border || v >= h - border || v < border) continue;
+      if (grid[(size_t)v * w + u] == 2) {
+        const int sel = inds[(size_t)v * w + u];      /* u16 wrap: pts_raw[select_ind] */
+        kept[m].idx = cand[sel]; kept[m].s = conf[(size_t)v * w + u]; ++m;
+      }
+    }
+  /* std::sort by confidence desc (:172); oracle tie-break = raster-scan position (stable) */
+  for (int i = 0; i < m; ++i) { dec[i].s = kept[i].s; dec[i].idx = i; }
+  qsort(dec, m, sizeof(orc_cand), orc_cand_cmp);
+  {
+    int nout = m < max_num ? m : max_num;
+    if (nout > cap) nout = cap;
+    for (int i = 0; i < nout; ++i) {
+      const int src = kept[dec[i].idx].idx;
+      kps_xy[2 * i] = (float)(src % w);
+      kps_xy[2 * i + 1] = (float)(src / w);
+      scores[i] = dec[i].s;
+    }
+    m = nout;
+  }
+  free(dec);
+  free(kept); free(cand); free(grid); free(inds); free(conf);
+  return m;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A7  Variant-A descriptor sampling.  Reference: computeDescriptors superpoint_common.cpp:42-99.
+ *     grid = 2*x/W - 1 ; torch::grid_sampler(bilinear, zeros padding, align_corners=false)
+ *     => ix = ((g+1)*wc - 1)/2 ; L2 normalise; optional PCA (d - mean) * comp_T then row L2.
+ *     desc_map NHWC [hc][wc][dim] already channel-normalised.  pca_comp: [pca_dims][dim] (the CSV
+ *     layout, superpoint_onnx.cpp:47-53) or NULL.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_sample_a(const float* desc_map, int hc, int wc, int dim, int img_w, int img_h,
+                          const float* kps_xy, int n, const float* pca_comp, const float* pca_mean,
+                          int pca_dims, float* out) {
+  float* tmp = (float*)malloc(sizeof(float) * dim);
+  for (int i = 0; i < n; ++i) {
+    /* grid built in float tensors: 2.0 * x / width - 1 */
+    const float gx = 2.0f * kps_xy[2 * i] / (float)img_w - 1.0f;
+    const float gy = 2.0f * kps_xy[2 * i + 1] / (float)img_h - 1.0f;
+    /* ATen grid_sampler_unnormalize, align_corners=false: ((coord + 1) * size - 1) / 2 */
+    const float ix = ((gx + 1.0f) * (float)wc - 1.0f) / 2.0f;
+    const float iy = ((gy + 1.0f) * (float)hc - 1.0f) / 2.0f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    /* ATen: nw = (ix_se - ix)*(iy_se - iy) ... */
+    const float nw = ((float)x1 - ix) * ((float)y1 - iy);
+    const float ne = (ix - (float)x0) * ((float)y1 - iy);
+    const float sw = ((float)x1 - ix) * (iy - (float)y0);
+    const float se = (ix - (float)x0) * (iy - (float)y0);
+    float ss = 0.f;
+    for (int k = 0; k < dim; ++k) {
+      float v = 0.f;
+      if (y0 >= 0 && y0 < hc && x0 >= 0 && x0 < wc) v += desc_map[((size_t)y0 * wc + x0) * dim + k] * nw;
+      if (y0 >= 0 && y0 < hc && x1 >= 0 && x1 < wc) v += desc_map[((size_t)y0 * wc + x1) * dim + k] * ne;
+      if (y1 >= 0 && y1 < hc && x0 >= 0 && x0 < wc) v += desc_map[((size_t)y1 * wc + x0) * dim + k] * sw;
+      if (y1 >= 0 && y1 < hc && x1 >= 0 && x1 < wc) v += desc_map[((size_t)y1 * wc + x1) * dim + k] * se;
+      tmp[k] = v;
+      ss += v * v;
+    }
+    const float nrm = sqrtf(ss);
+    for (int k = 0; k < dim; ++k) tmp[k] = tmp[k] / nrm;   /* :68-69 (and again :87-89: idempotent) */
+    if (pca_comp) {
+      float s2 = 0.f;
+      float* o = out + (size_t)i * pca_dims;
+      for (int j = 0; j < pca_dims; ++j) {
+        float a = 0.f;
+        for (int k = 0; k < dim; ++k) a += (tmp[k] - pca_mean[k]) * pca_comp[(size_t)j * dim + k];
+        o[j] = a; s2 += a * a;
+      }
+      const float n2 = sqrtf(s2);
+      for (int j = 0; j < pca_dims; ++j) o[j] = o[j] / n2;
+    } else {
+      float s2 = 0.f;
+      for (int k = 0; k < dim; ++k) s2 += tmp[k] * tmp[k];
+      const float n2 = sqrtf(s2);
+      for (int k = 0; k < dim; ++k) out[(size_t)i * dim + k] = tmp[k] / n2;
+    }
+  }
+  free(tmp);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A10  matchKNN.  Reference: d2frontend/src/feature_matcher.cpp:4-42.   SURVEY.md Appendix B.3.
+ * Third-party arithmetic restated: OpenCV 4.10.0 (docker/Dockerfile.x86:6) cv::BFMatcher(NORM_L2)
+ * -> batchDistance -> normL2Sqr_(float) then std::sqrt.  The accumulation order fixed here is that
+ * of the x86-64 baseline (SSE2, 128-bit universal intrinsics) build of
+ * modules/core/src/norm.cpp normL2Sqr_: four 4-lane accumulators over 16-element strides,
+ * v_muladd = separate mul and add, d = reduce_sum((d0+d1)+d2)+d3), scalar tail.
+ * knn ordering: ascending distance, ties keep the lower train index (strict '<' insertion).
+ * ---------------------------------------------------------------------------------------- */
+ORC_API float orc_l2_dist(const float* a, const float* b, int n) {
+  float acc[4][4];
+  memset(acc, 0, sizeof(acc));
+  int j = 0;
+  for (; j <= n - 16; j += 16)
+    for (int v = 0; v < 4; ++v)
+      for (int l = 0; l < 4; ++l) {
+        const float t = a[j + 4 * v + l] - b[j + 4 * v + l];
+        const float tt = t * t;
+        acc[v][l] = acc[v][l] + tt;
+      }
+  float r[4];
+  for (int l = 0; l < 4; ++l) r[l] = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l];
+  /* v_reduce_sum (SSE): (r0 + r2) + (r1 + r3) */
+  float d = (r[0] + r[2]) + (r[1] + r[3]);
+  for (; j < n; ++j) { const float t = a[j] - b[j]; d += t * t; }
+  return sqrtf(d);
+}
+
+static void orc_knn2(const float* q, int nq, const float* t, int nt, int dim, int* i0, float* d0,
+                     int* i1, float* d1) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < nq; ++i) {
+    int b0 = -1, b1 = -1; float e0 = INFINITY, e1 = INFINITY;
+    for (int j = 0; j < nt; ++j) {
+      const float d = orc_l2_dist(q + (size_t)i * dim, t + (size_t)j * dim, dim);
+      if (d < e0) { e1 = e0; b1 = b0; e0 = d; b0 = j; }
+      else if (d < e1) { e1 = d; b1 = j; }
+    }
+    i0[i] = b0; d0[i] = e0; i1[i] = b1; d1[i] = e1;
+  }
+}
+
+ORC_API int orc_match_knn(const float* a, int na, const float* b, int nb, int dim, double ratio,
+                          const float* pts_a, const float* pts_b, double radius, int32_t* q_idx,
+                          int32_t* t_idx, float* dist, int cap) {
+  if (na <= 0 || nb <= 0) return 0;
+  int *f0 = (int*)malloc(sizeof(int) * na), *f1 = (int*)malloc(sizeof(int) * na);
+  float *fd0 = (float*)malloc(sizeof(float) * na), *fd1 = (float*)malloc(sizeof(float) * na);
+  int *g0 = (int*)malloc(sizeof(int) * nb), *g1 = (int*)malloc(sizeof(int) * nb);
+  float *gd0 = (float*)malloc(sizeof(float) * nb), *gd1 = (float*)malloc(sizeof(float) * nb);
+  int* inv = (int*)malloc(sizeof(int) * nb);
+  orc_knn2(a, na, b, nb, dim, f0, fd0, f1, fd1);
+  orc_knn2(b, nb, a, na, dim, g0, gd0, g1, gd1);
+  for (int j = 0; j < nb; ++j) {
+    inv[j] = -1;
+    if (na < 2) continue;                                    /* match.size() < 2 (:18-20) */
+    if ((double)gd0[j] < ratio * (double)gd1[j]) inv[j] = g0[j];   /* :21-23 */
+  }
+  int n = 0;
+  for (int i = 0; i < na; ++i) {
+    if (nb < 2) continue;                                    /* :27-29 */
+    if ((double)fd0[i] < ratio * (double)fd1[i] && inv[f0[i]] == i) {
+      if (radius > 0) {
+        /* cv::norm(Point2f) = sqrt((double)x*x + (double)y*y) */
+        const float dx = pts_a[2 * i] - pts_b[2 * f0[i]], dy = pts_a[2 * i + 1] - pts_b[2 * f0[i] + 1];
+        const double nr = sqrt((double)dx * dx + (double)dy * dy);
+        if (nr > radius) continue;
+      }
+      if (n < cap) { q_idx[n] = i; t_idx[n] = f0[i]; dist[n] = fd0[i]; }
+      ++n;
+    }
+  }
+  free(f0); free(f1); free(fd0); free(fd1); free(g0); free(g1); free(gd0); free(gd1); free(inv);
+  return n < cap ? n : cap;
+}
+
+/* A11 cross-check matcher: cv::BFMatcher(NORM_L2, true).match  (loop_cam.cpp:167-170,
+ * d2featuretracker.cpp:1141-1142).  OpenCV crossCheck semantics: knnMatch(k=1) both ways; keep (i,j)
+ * iff j = argmin_j d(i,j) and i = argmin_i d(i,j) (first minimum on ties).  Output ascending i. */
+ORC_API int orc_match_crosscheck(const float* a, int na, const float* b, int nb, int dim, int32_t* q_idx,
+                                 int32_t* t_idx, float* dist, int cap) {
+  if (na <= 0 || nb <= 0) return 0;
+  int *f0 = (int*)malloc(sizeof(int) * na), *f1 = (int*)malloc(sizeof(int) * na);
+  float *fd0 = (float*)malloc(sizeof(float) * na), *fd1 = (float*)malloc(sizeof(float) * na);
+  int *g0 = (int*)malloc(sizeof(int) * nb), *g1 = (int*)malloc(sizeof(int) * nb);
+  float *gd0 = (float*)malloc(sizeof(float) * nb), *gd1 = (float*)malloc(sizeof(float) * nb);
+  orc_knn2(a, na, b, nb, dim, f0, fd0, f1, fd1);
+  orc_knn2(b, nb, a, na, dim, g0, gd0, g1, gd1);
+  int n = 0;
+  for (int i = 0; i < na; ++i)
+    if (f0[i] >= 0 && g0[f0[i]] == i) {
+      if (n < cap) { q_idx[n] = i; t_idx[n] = f0[i]; dist[n] = fd0[i]; }
+      ++n;
+    }
+  free(f0); free(f1); free(fd0); free(fd1); free(g0); free(g1); free(gd0); free(gd1);
+  return n < cap ? n : cap;
+}
+
+/* A12 half-image filter.  Reference: getFeatureHalfImg d2featuretracker.cpp:1051-1075.
+ * move_cols = width_undistort * 90.0 / undistort_fov (float).  Returns count; map[c] = source index. */
+ORC_API int orc_half_img(const float* pts_xy, int n, int require_left, int width_undistort,
+                         double undistort_fov, int32_t* map) {
+  const float move_cols = (float)((double)width_undistort * 90.0 / undistort_fov);
+  int c = 0;
+  for (int i = 0; i < n; ++i) {
+    const float x = pts_xy[2 * i];
+    if ((require_left && x < (float)width_undistort - move_cols) || (!require_left && x >= move_cols))
+      map[c++] = i;
+  }
+  return c;
+}

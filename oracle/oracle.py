@@ -1,0 +1,208 @@
+"""ctypes front-end of the CPU oracle (oracle/d2fe_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under d2slam_amd/ imports this module.  Parity status: unpinned
+(the reference has no golden vectors for this path) -- see the header of d2fe_oracle.c.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SP_LAYERS = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b",
+             "convPa", "convPb", "convDa", "convDb"]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libd2fe_oracle.so")
+    src = os.path.join(_HERE, "d2fe_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libd2fe_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.orc_expf.restype = C.c_float
+        _LIB.orc_expf.argtypes = [C.c_float]
+        _LIB.orc_l2_dist.restype = C.c_float
+    return _LIB
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def prep_u8(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.empty((h, w), np.float32)
+    lib().orc_prep_u8(_p(img), h, w, w, _p(out))
+    return out
+
+
+def conv(x, wgt, bias, relu):
+    """x: [H,W,Cin] NHWC; wgt: [Cout,Cin,K,K]; returns [H,W,Cout]."""
+    x = _f(x); wgt = _f(wgt); bias = _f(bias)
+    h, w, cin = x.shape
+    cout, cin2, k, _ = wgt.shape
+    assert cin == cin2
+    out = np.empty((h, w, cout), np.float32)
+    lib().orc_conv(_p(x), h, w, cin, _p(wgt), _p(bias), cout, k, int(relu), _p(out))
+    return out
+
+
+def maxpool2(x):
+    x = _f(x)
+    h, w, c = x.shape
+    out = np.empty((h // 2, w // 2, c), np.float32)
+    lib().orc_maxpool2(_p(x), h, w, c, _p(out))
+    return out
+
+
+def expf(x):
+    return float(lib().orc_expf(C.c_float(float(x))))
+
+
+def softmax_semi(logits):
+    logits = _f(logits)
+    hc, wc, c = logits.shape
+    assert c == 65
+    out = np.empty((hc * 8, wc * 8), np.float32)
+    lib().orc_softmax_semi(_p(logits), hc, wc, _p(out))
+    return out
+
+
+def l2norm_rows(x):
+    x = _f(x)
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1])
+    out = np.empty_like(x2)
+    lib().orc_l2norm_rows(_p(x2), x2.shape[0], x2.shape[1], _p(out))
+    return out.reshape(shp)
+
+
+def superpoint_forward(img_u8, weights, return_trunk=False):
+    """A1+A2 (d2frontend/superpoint.ipynb:300-374). Returns semi [H,W], desc_map [H/8,W/8,256] (normalised),
+    plus raw logits / raw desc for finer-grained checks."""
+    x = prep_u8(img_u8)[:, :, None]
+    w = weights
+    x = conv(x, *w["conv1a"], True)
+    x = conv(x, *w["conv1b"], True)
+    x = maxpool2(x)
+    x = conv(x, *w["conv2a"], True)
+    x = conv(x, *w["conv2b"], True)
+    x = maxpool2(x)
+    x = conv(x, *w["conv3a"], True)
+    x = conv(x, *w["conv3b"], True)
+    x = maxpool2(x)
+    x = conv(x, *w["conv4a"], True)
+    x = conv(x, *w["conv4b"], True)
+    cpa = conv(x, *w["convPa"], True)
+    logits = conv(cpa, *w["convPb"], False)
+    cda = conv(x, *w["convDa"], True)
+    draw = conv(cda, *w["convDb"], False)
+    semi = softmax_semi(logits)
+    desc = l2norm_rows(draw)
+    out = dict(semi=semi, desc=desc, logits=logits, desc_raw=draw)
+    if return_trunk:
+        out["trunk"] = x
+    return out
+
+
+def select_b(semi, thr, border, max_kp, cap=None):
+    semi = _f(semi)
+    h, w = semi.shape
+    cap = cap or h * w
+    kps = np.empty((cap, 2), np.float32); sc = np.empty(cap, np.float32); idx = np.empty(cap, np.int32)
+    n = lib().orc_select_b(_p(semi), h, w, C.c_float(thr), border, max_kp, _p(kps), _p(sc), _p(idx), cap)
+    return kps[:n].copy(), sc[:n].copy(), idx[:n].copy()
+
+
+def sample_b(desc_map, kps):
+    desc_map = _f(desc_map); kps = _f(kps).reshape(-1, 2)
+    hc, wc, dim = desc_map.shape
+    n = kps.shape[0]
+    out = np.empty((n, dim), np.float32)
+    lib().orc_sample_b(_p(desc_map), hc, wc, dim, _p(kps), n, _p(out))
+    return out
+
+
+def nms2_a(prob, thr, dist_thresh, max_num, border=0, cap=None):
+    prob = _f(prob)
+    h, w = prob.shape
+    cap = cap or max(max_num, 1)
+    kps = np.empty((cap, 2), np.float32); sc = np.empty(cap, np.float32)
+    n = lib().orc_nms2_a(_p(prob), h, w, C.c_float(thr), dist_thresh, border, max_num, _p(kps), _p(sc), cap)
+    return kps[:n].copy(), sc[:n].copy()
+
+
+def sample_a(desc_map, kps, img_w, img_h, pca_comp=None, pca_mean=None):
+    desc_map = _f(desc_map); kps = _f(kps).reshape(-1, 2)
+    hc, wc, dim = desc_map.shape
+    n = kps.shape[0]
+    if pca_comp is not None:
+        pca_comp = _f(pca_comp); pca_mean = _f(pca_mean)
+        pd = pca_comp.shape[0]
+        out = np.empty((n, pd), np.float32)
+        lib().orc_sample_a(_p(desc_map), hc, wc, dim, img_w, img_h, _p(kps), n, _p(pca_comp), _p(pca_mean), pd, _p(out))
+    else:
+        out = np.empty((n, dim), np.float32)
+        lib().orc_sample_a(_p(desc_map), hc, wc, dim, img_w, img_h, _p(kps), n, None, None, 0, _p(out))
+    return out
+
+
+def extract_b(img_u8, weights, thr=0.015, border=1, max_kp=200):
+    """Full variant-B extractor == SuperPoint::infer (superpoint_tensorrt.cpp:161-183)."""
+    f = superpoint_forward(img_u8, weights)
+    kps, sc, idx = select_b(f["semi"], thr, border, max_kp)
+    d = sample_b(f["desc"], kps)
+    return kps, sc, d, idx, f
+
+
+def l2_dist(a, b):
+    a = _f(a); b = _f(b)
+    return float(lib().orc_l2_dist(_p(a), _p(b), a.shape[0]))
+
+
+def match_knn(a, b, ratio=0.8, pts_a=None, pts_b=None, radius=-1.0):
+    a = _f(a); b = _f(b)
+    na, dim = a.shape if a.ndim == 2 else (0, b.shape[1])
+    nb = b.shape[0]
+    cap = max(na, 1)
+    q = np.empty(cap, np.int32); t = np.empty(cap, np.int32); d = np.empty(cap, np.float32)
+    pa = _f(pts_a) if pts_a is not None else np.zeros((max(na, 1), 2), np.float32)
+    pb = _f(pts_b) if pts_b is not None else np.zeros((max(nb, 1), 2), np.float32)
+    n = lib().orc_match_knn(_p(a), na, _p(b), nb, dim, C.c_double(ratio), _p(pa), _p(pb),
+                            C.c_double(radius if pts_a is not None else -1.0), _p(q), _p(t), _p(d), cap)
+    return q[:n].copy(), t[:n].copy(), d[:n].copy()
+
+
+def match_crosscheck(a, b):
+    a = _f(a); b = _f(b)
+    na, dim = a.shape
+    nb = b.shape[0]
+    cap = max(na, 1)
+    q = np.empty(cap, np.int32); t = np.empty(cap, np.int32); d = np.empty(cap, np.float32)
+    n = lib().orc_match_crosscheck(_p(a), na, _p(b), nb, dim, _p(q), _p(t), _p(d), cap)
+    return q[:n].copy(), t[:n].copy(), d[:n].copy()
+
+
+def half_img(pts, require_left, width_undistort, undistort_fov):
+    pts = _f(pts).reshape(-1, 2)
+    m = np.empty(max(pts.shape[0], 1), np.int32)
+    n = lib().orc_half_img(_p(pts), pts.shape[0], int(require_left), width_undistort, C.c_double(undistort_fov), _p(m))
+    return m[:n].copy()
