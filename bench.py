@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json on MI355X:
+stereo frames/s for SuperPoint extraction (both images) + brute-force matching, 640x480, N<=200 keypoints.
+
+Workload (configs[1], "realsense_d435 stereo 640x480, 200 keypoints/frame, SuperPoint+match only"):
+one step = F stereo frames resident in HBM -> SuperPoint on the 2F images -> matchKNN left<->right and
+left<->previous-left for every frame (the two matchKNN calls D2FeatureTracker::trackLocalFrames makes per stereo
+frame, d2featuretracker.cpp:403-456,658-695).  With --gpus N>1 every rank runs the same per-rank workload on its own
+frames (weak scaling), all-gathers the left-image descriptor blocks over RCCL and additionally matches its frames
+against every other rank's (the cross-agent step).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel (conv1b,
+43% of the FLOPs) from HIP events on the launch stream and `cpu_baseline` = the oracle timed on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, CAP = 480, 640, 200
+CONV1B_FLOP_PER_IMG = 2.0 * H * W * 64 * 64 * 9          # 22.65 GFLOP (SURVEY.md section 8a layer table)
+SP_FLOP_PER_IMG = 52.1e9
+PEAK_TFLOPS = {"f32": 157.3, "f16x2": 2500.0}             # MI355X_MICROARCH.md: fp32 MFMA / dense f16 MFMA
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=8, help="stereo frames per step and per GPU")
+    ap.add_argument("--precision", choices=["f32", "f16x2"], default=os.environ.get("D2FE_BENCH_PRECISION", "f32"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event breakdown to stderr")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from d2slam_amd import api, swarm
+    from d2slam_amd.synth import synth_stereo
+    from d2slam_amd.weights import synthetic_superpoint_weights
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    F = args.frames
+    NI = 2 * F
+    weights = synthetic_superpoint_weights(dustbin_bias=7.5)
+    prec = api.PREC_F32 if args.precision == "f32" else api.PREC_F16X2
+    cfg = api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=NI, precision=prec,
+                               device_id=local_rank)
+    fe = api.FrontEnd(cfg)
+    fe.load_superpoint(weights)
+
+    # synthetic frames, resident in HBM before the timed region: [L0, R0, L1, R1, ...]
+    host = np.empty((NI, H, W), np.uint8)
+    for f in range(F):
+        l, r = synth_stereo(H, W, seed=rank * 1000 + f)
+        host[2 * f], host[2 * f + 1] = l, r
+    imgs = torch.from_numpy(host).to(dev)
+
+    NPOOL = swarm.pool_rows(F, world)   # current L/R | previous L | gathered remote L
+    desc = torch.zeros((NPOOL, CAP, 256), dtype=torch.float32, device=dev)
+    kps = torch.zeros((NPOOL, CAP, 2), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((NPOOL,), dtype=torch.int32, device=dev)
+    scores = torch.zeros((NI, CAP), dtype=torch.float32, device=dev)
+    kidx = torch.zeros((NI, CAP), dtype=torch.int32, device=dev)
+
+    # pairs: (L_f, R_f), (L_f, prevL_f) and, for N>1, (L_f, remote L_f of every other rank)
+    a_rows, b_rows = swarm.build_pairs(F, world)
+    NP = len(a_rows)
+    a_rows_t = torch.tensor(a_rows, dtype=torch.int64, device=dev)
+    b_rows_t = torch.tensor(b_rows, dtype=torch.int64, device=dev)
+    a_off = (a_rows_t * CAP).to(torch.int32)
+    b_off = (b_rows_t * CAP).to(torch.int32)
+    a_cnt = torch.zeros(NP, dtype=torch.int32, device=dev)
+    b_cnt = torch.zeros(NP, dtype=torch.int32, device=dev)
+    mq = torch.zeros((NP, CAP), dtype=torch.int32, device=dev)
+    mt = torch.zeros((NP, CAP), dtype=torch.int32, device=dev)
+    md = torch.zeros((NP, CAP), dtype=torch.float32, device=dev)
+    mn = torch.zeros((NP,), dtype=torch.int32, device=dev)
+    left_rows = torch.arange(0, NI, 2, device=dev)
+    if world > 1:
+        gath_desc = torch.zeros((world, F, CAP, 256), dtype=torch.float32, device=dev)
+        gath_cnt = torch.zeros((world, F), dtype=torch.int32, device=dev)
+
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        fe.extract_device(imgs.data_ptr(), NI, W, H, kps.data_ptr(), scores.data_ptr(), desc.data_ptr(), kidx.data_ptr(),
+                          CAP, cnt.data_ptr(), stream=stream)
+        if world > 1:
+            # cross-agent exchange: one all-gather of the fixed-capacity left-image blocks (RCCL over xGMI)
+            swarm.exchange_blocks(desc, cnt, F, rank, world, gath_desc, gath_cnt)
+        torch.index_select(cnt, 0, a_rows_t, out=a_cnt)
+        torch.index_select(cnt, 0, b_rows_t, out=b_cnt)
+        fe.match_batch_device(desc.data_ptr(), desc.data_ptr(), a_off.data_ptr(), b_off.data_ptr(), a_cnt.data_ptr(),
+                              b_cnt.data_ptr(), NP, 256, CAP, mq.data_ptr(), mt.data_ptr(), md.data_ptr(), mn.data_ptr(),
+                              mode=0, ratio=0.8, radius=-1.0, stream=stream)
+        # this step's left descriptors become the "previous keyframe" of the next step
+        desc[NI:NI + F].copy_(desc[left_rows])
+        cnt[NI:NI + F].copy_(cnt[left_rows])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    fe.profile_enable(1)   # HIP events around the dominant kernel only (2 event records per step)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    t1 = time.perf_counter()
+    prof = fe.profile_read()
+    fe.profile_enable(0)
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    frames_total = F * world * args.steps
+    value = frames_total / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # sanity: the step really produced keypoints and matches
+    n_kp = cnt[:NI].float().mean().item()
+    n_match = mn.float().mean().item()
+
+    breakdown = None
+    if args.breakdown and rank == 0 and world == 1:
+        fe.profile_enable(2)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize(dev)
+        breakdown = {k: round(v[0] / max(v[1], 1), 4) for k, v in fe.profile_read().items() if v[1]}
+        fe.profile_enable(0)
+        print("per-stage ms (avg of 5 steps, %d images/step): %s" % (NI, json.dumps(breakdown)), file=sys.stderr)
+
+    c1b_ms, c1b_n = prof["conv1b"]
+    avg_ms = c1b_ms / max(c1b_n, 1)
+    achieved = CONV1B_FLOP_PER_IMG * NI / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    peak = PEAK_TFLOPS[args.precision]
+    roofline = {"kernel": "conv_%s_kernel<64,3,8,32,...,POOL> (conv1b)" % ("f32" if args.precision == "f32" else "f16x2"),
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "launches": c1b_n,
+                "algorithmic_flop_per_launch": CONV1B_FLOP_PER_IMG * NI,
+                "note": "algorithmic FLOPs (2*MACs); f16x2 executes 3 MFMA FLOPs per algorithmic FLOP"}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(weights, args.cpu_seconds)
+
+    if rank == 0:
+        out = {
+            "metric": "stereo frames/sec SuperPoint+match, 640x480 stereo",
+            "value": round(value, 2), "unit": "stereo_frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16x2(hi+lo split)/f32-acc",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: realsense_d435 stereo 640x480, 200 keypoints/frame, SuperPoint (both "
+                                   "images) + matchKNN L<->R and L<->prevL" + ("; + RCCL all-gather and cross-agent matchKNN" if world > 1 else ""),
+                       "frames_per_step_per_gpu": F, "images_per_step_per_gpu": NI, "match_pairs_per_step_per_gpu": NP,
+                       "max_keypoints": CAP, "postproc": "B", "precision": args.precision,
+                       "weights": "seeded random-init SuperPoint (no checkpoint in tree)"},
+            "sp_tflops_algorithmic": round(SP_FLOP_PER_IMG * 2 * value / 1e12, 2),
+            "avg_keypoints_per_image": round(n_kp, 1), "avg_matches_per_pair": round(n_match, 1),
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        if breakdown:
+            out["stage_ms"] = breakdown
+        print(json.dumps(out), flush=True)
+    fe.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(weights, budget_s):
+    """The oracle (kind "port": a CPU restatement, the reference has no runnable CPU extractor -- SURVEY.md F2)
+    timed on this host's cores on a bounded sample of the same workload."""
+    from d2slam_amd.synth import synth_stereo
+    from oracle import oracle as orc
+    orc.build()
+    prev = None
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        l, r = synth_stereo(H, W, seed=n)
+        kl, sl, dl, _, _ = orc.extract_b(l, weights, 0.015, 1, CAP)
+        kr, sr, dr, _, _ = orc.extract_b(r, weights, 0.015, 1, CAP)
+        orc.match_knn(dl, dr, 0.8)
+        if prev is not None:
+            orc.match_knn(dl, prev, 0.8)
+        else:
+            orc.match_knn(dl, dl, 0.8)
+        prev = dl
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 16:
+            break
+    return {"value": round(n / el, 4), "unit": "stereo_frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d stereo frames 640x480 (oracle/d2fe_oracle.c, OpenMP over all host cores, fp32 fmaf chains), %.1f s" % (n, el)}
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libd2fe_hip.so")
 
 POSTPROC_B, POSTPROC_A = 0, 1
 PREC_F32, PREC_F16X2 = 0, 1
+PROF_STAGES = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPaDa",
+               "convPb", "convDb", "softmax_cand", "select", "sample", "match"]
 
 
 class D2FEError(RuntimeError):
@@ -60,7 +62,7 @@ _lib = None
 EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_create", "d2fe_destroy",
            "d2fe_load_superpoint", "d2fe_superpoint_extract", "d2fe_superpoint_extract_batch",
            "d2fe_superpoint_extract_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device",
-           "d2fe_half_image_filter", "d2fe_debug_read", "d2fe_sync"]
+           "d2fe_half_image_filter", "d2fe_debug_read", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read"]
 
 
 def load_library():
@@ -95,6 +97,8 @@ def load_library():
         lib.d2fe_destroy.argtypes = [C.c_void_p]
         lib.d2fe_load_superpoint.argtypes = [C.c_void_p, C.c_void_p]
         lib.d2fe_sync.argtypes = [C.c_void_p]
+        lib.d2fe_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        lib.d2fe_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -217,6 +221,15 @@ class FrontEnd:
 
     def sync(self):
         _check(self._lib.d2fe_sync(self._h))
+
+    def profile_enable(self, mode):
+        """0 off, 1 dominant kernel (conv1b) only, 2 every stage (HIP events on the launch stream)."""
+        _check(self._lib.d2fe_profile_enable(self._h, int(mode)))
+
+    def profile_read(self):
+        ms = np.zeros(len(PROF_STAGES), np.float32); cnt = np.zeros(len(PROF_STAGES), np.int32)
+        _check(self._lib.d2fe_profile_read(self._h, _ptr(ms), _ptr(cnt)))
+        return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(PROF_STAGES)}
 
     # ---- matcher -------------------------------------------------------------------------------------------------
     def match_knn(self, desc_a, desc_b, knn_match_ratio=0.8, pts_a=None, pts_b=None, search_local_dist=-1.0):

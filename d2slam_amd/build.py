@@ -13,7 +13,7 @@ SOURCES = ["api.hip", "conv.hip", "conv_f16.hip", "postproc.hip", "match.hip"]
 HEADERS = ["kernels.h", "conv_common.h", os.path.join("..", "..", "include", "d2fe.h")]
 # -ffp-contract=off: the post-processing arithmetic must follow the oracle operation by operation
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 
 
 def _hipcc():

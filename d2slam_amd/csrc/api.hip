@@ -72,6 +72,12 @@ struct d2fe_context {
   size_t m_bytes = 0;
   int32_t* m_cand4 = nullptr;
   size_t m_cand4_bytes = 0;
+  // profiling (HIP events on the launch stream)
+  int prof_mode = 0;
+  std::vector<hipEvent_t> prof_pool;
+  size_t prof_used = 0;
+  struct ProfRec { int stage; hipEvent_t a, b; };
+  std::vector<ProfRec> prof_recs;
 };
 
 namespace {
@@ -126,12 +132,30 @@ int check_layer(const d2fe_conv_params& p, int cout, int cin, int ks, const char
   return D2FE_OK;
 }
 
+struct ProfScope {
+  d2fe_context* h; int stage; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on = false;
+  ProfScope(d2fe_context* h_, int stage_, hipStream_t s_) : h(h_), stage(stage_), s(s_) {
+    on = h->prof_mode == 2 || (h->prof_mode == 1 && stage == D2FE_PROF_CONV1B);
+    if (!on) return;
+    if (h->prof_used + 2 > h->prof_pool.size()) {
+      for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } h->prof_pool.push_back(e); }
+    }
+    a = h->prof_pool[h->prof_used++]; b = h->prof_pool[h->prof_used++];
+    (void)hipEventRecord(a, s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(b, s);
+    h->prof_recs.push_back({stage, a, b});
+  }
+};
+
 // the launch sequence == one TensorRT executeV2 + processOutput of the reference
 int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int stride, size_t image_stride,
                    float* d_kps, float* d_scores, float* d_desc, int32_t* d_idx, int cap, int32_t* d_n, hipStream_t s) {
   const int prec = h->cfg.precision;
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8;
-  HIP_TRY(launch_conv1a(d_gray, stride, (long)image_stride, H, W, n, h->w1a, h->b1a, h->a1a.p, s));
+  { ProfScope ps(h, D2FE_PROF_CONV1A, s); HIP_TRY(launch_conv1a(d_gray, stride, (long)image_stride, H, W, n, h->w1a, h->b1a, h->a1a.p, s)); }
   auto conv = [&](ConvShape shape, const Layer& L, const float* in, int ics, int ico, long iis, float* out, int ocs,
                   long ois, int hh, int ww, bool pool, bool relu) -> hipError_t {
     ConvArgs a;
@@ -141,22 +165,24 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     a.H = hh; a.W = ww; a.n_img = n; a.in_img_stride = iis; a.out_img_stride = ois;
     return launch_conv(shape, prec, pool, relu, L.cout_pad, a, s);
   };
-  HIP_TRY(conv(CONV_64_T8x32, h->L[L_1B], h->a1a.p, 64, 0, (long)H * W * 64, h->a1b.p, 64, (long)H2 * W2 * 64, H, W, true, true));
-  HIP_TRY(conv(CONV_64_T8x32, h->L[L_2A], h->a1b.p, 64, 0, (long)H2 * W2 * 64, h->a2a.p, 64, (long)H2 * W2 * 64, H2, W2, false, true));
-  HIP_TRY(conv(CONV_64_T8x32, h->L[L_2B], h->a2a.p, 64, 0, (long)H2 * W2 * 64, h->a2b.p, 64, (long)H4 * W4 * 64, H2, W2, true, true));
-  HIP_TRY(conv(CONV_64_T8x32, h->L[L_3A], h->a2b.p, 64, 0, (long)H4 * W4 * 64, h->a3a.p, 128, (long)H4 * W4 * 128, H4, W4, false, true));
-  HIP_TRY(conv(CONV_128_T4x32, h->L[L_3B], h->a3a.p, 128, 0, (long)H4 * W4 * 128, h->a3b.p, 128, (long)Hc * Wc * 128, H4, W4, true, true));
-  HIP_TRY(conv(CONV_128_T4x16, h->L[L_4A], h->a3b.p, 128, 0, (long)Hc * Wc * 128, h->a4a.p, 128, (long)Hc * Wc * 128, Hc, Wc, false, true));
-  HIP_TRY(conv(CONV_128_T4x16, h->L[L_4B], h->a4a.p, 128, 0, (long)Hc * Wc * 128, h->a4b.p, 128, (long)Hc * Wc * 128, Hc, Wc, false, true));
-  HIP_TRY(conv(CONV_128_T4x16, h->L[L_PADA], h->a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 512, (long)Hc * Wc * 512, Hc, Wc, false, true));
-  HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_PB], h->aPD.p, 512, 0, (long)Hc * Wc * 512, h->logits.p, 65, (long)Hc * Wc * 65, Hc, Wc, false, false));
-  HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_DB], h->aPD.p, 512, 256, (long)Hc * Wc * 512, h->draw.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, false));
+  { ProfScope ps(h, D2FE_PROF_CONV1B, s); HIP_TRY(conv(CONV_64_T8x32, h->L[L_1B], h->a1a.p, 64, 0, (long)H * W * 64, h->a1b.p, 64, (long)H2 * W2 * 64, H, W, true, true)); }
+  { ProfScope ps(h, D2FE_PROF_CONV2A, s); HIP_TRY(conv(CONV_64_T8x32, h->L[L_2A], h->a1b.p, 64, 0, (long)H2 * W2 * 64, h->a2a.p, 64, (long)H2 * W2 * 64, H2, W2, false, true)); }
+  { ProfScope ps(h, D2FE_PROF_CONV2B, s); HIP_TRY(conv(CONV_64_T8x32, h->L[L_2B], h->a2a.p, 64, 0, (long)H2 * W2 * 64, h->a2b.p, 64, (long)H4 * W4 * 64, H2, W2, true, true)); }
+  { ProfScope ps(h, D2FE_PROF_CONV3A, s); HIP_TRY(conv(CONV_64_T8x32, h->L[L_3A], h->a2b.p, 64, 0, (long)H4 * W4 * 64, h->a3a.p, 128, (long)H4 * W4 * 128, H4, W4, false, true)); }
+  { ProfScope ps(h, D2FE_PROF_CONV3B, s); HIP_TRY(conv(CONV_128_T4x32, h->L[L_3B], h->a3a.p, 128, 0, (long)H4 * W4 * 128, h->a3b.p, 128, (long)Hc * Wc * 128, H4, W4, true, true)); }
+  { ProfScope ps(h, D2FE_PROF_CONV4A, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_4A], h->a3b.p, 128, 0, (long)Hc * Wc * 128, h->a4a.p, 128, (long)Hc * Wc * 128, Hc, Wc, false, true)); }
+  { ProfScope ps(h, D2FE_PROF_CONV4B, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_4B], h->a4a.p, 128, 0, (long)Hc * Wc * 128, h->a4b.p, 128, (long)Hc * Wc * 128, Hc, Wc, false, true)); }
+  { ProfScope ps(h, D2FE_PROF_CONVPADA, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_PADA], h->a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 512, (long)Hc * Wc * 512, Hc, Wc, false, true)); }
+  { ProfScope ps(h, D2FE_PROF_CONVPB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_PB], h->aPD.p, 512, 0, (long)Hc * Wc * 512, h->logits.p, 65, (long)Hc * Wc * 65, Hc, Wc, false, false)); }
+  { ProfScope ps(h, D2FE_PROF_CONVDB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_DB], h->aPD.p, 512, 256, (long)Hc * Wc * 512, h->draw.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, false)); }
   if (h->cfg.postproc != D2FE_POSTPROC_B) return fail(D2FE_ERR_UNSUPPORTED, "postproc variant A not available in this build");
+  { ProfScope ps(h, D2FE_PROF_SOFTMAX, s);
   HIP_TRY(launch_softmax_cand(h->logits.p, 65, Hc, Wc, n, h->cfg.keypoint_threshold, h->cfg.remove_borders, h->semi.p,
-                              h->cand, h->cand_count, h->cand_cap, s));
+                              h->cand, h->cand_count, h->cand_cap, s)); }
+  { ProfScope ps(h, D2FE_PROF_SELECT, s);
   HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, W, h->cfg.max_keypoints, cap, d_kps, d_scores, d_idx,
-                          d_n, s));
-  HIP_TRY(launch_sample_b(h->draw.p, 256, 0, Hc, Wc, n, d_kps, d_n, cap, d_desc, s));
+                          d_n, s)); }
+  { ProfScope ps(h, D2FE_PROF_SAMPLE, s); HIP_TRY(launch_sample_b(h->draw.p, 256, 0, Hc, Wc, n, d_kps, d_n, cap, d_desc, s)); }
   h->last_w = W; h->last_h = H; h->last_n = n;
   return D2FE_OK;
 }
@@ -252,7 +278,8 @@ void d2fe_destroy(d2fe_handle h) {
   for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->cand_count, (void*)h->s_img, (void*)h->s_kps,
                   (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, h->m_buf, (void*)h->m_cand4})
     if (p) hipFree(p);
-  if (h->stream) hipStreamDestroy(h->stream);
+  for (auto e : h->prof_pool) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
@@ -374,7 +401,7 @@ int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* str
   m.ratio = mb->ratio; m.radius = mb->radius;
   m.q_idx = mb->d_q_idx; m.t_idx = mb->d_t_idx; m.dist = mb->d_dist; m.n_out = mb->d_n_out;
   m.cand4 = h->m_cand4;
-  HIP_TRY(launch_match(m, s));
+  { ProfScope ps(h, D2FE_PROF_MATCH, s); HIP_TRY(launch_match(m, s)); }
   return D2FE_OK;
 }
 
@@ -489,6 +516,32 @@ long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_byte
       return (long)bytes;
     }
   return fail(D2FE_ERR_INVALID, "unknown tensor name");
+}
+
+int d2fe_profile_enable(d2fe_handle h, int mode) {
+  if (!h || mode < 0 || mode > 2) return fail(D2FE_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  h->prof_mode = mode;
+  h->prof_used = 0;
+  h->prof_recs.clear();
+  return D2FE_OK;
+}
+
+int d2fe_profile_read(d2fe_handle h, float* ms, int32_t* launches) {
+  if (!h || !ms || !launches) return fail(D2FE_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  for (int i = 0; i < D2FE_PROF_COUNT; ++i) { ms[i] = 0.f; launches[i] = 0; }
+  for (auto& r : h->prof_recs) {
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+    ms[r.stage] += t;
+    launches[r.stage] += 1;
+  }
+  h->prof_used = 0;
+  h->prof_recs.clear();
+  return D2FE_OK;
 }
 
 int d2fe_sync(d2fe_handle h) {

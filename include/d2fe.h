@@ -151,6 +151,18 @@ D2FE_API int d2fe_half_image_filter(const float* pts_xy, int n, int require_left
  * names: "conv1a".."conv4b","convPaDa","logits","desc_raw","semi".  Returns bytes copied or <0. */
 D2FE_API long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_bytes);
 
+/* Stage timing with HIP events recorded on the stream the kernels run on.
+ * mode 0 = off, 1 = bracket only the dominant kernel (conv1b), 2 = bracket every stage.
+ * d2fe_profile_read synchronises, returns the accumulated milliseconds and launch counts per stage since the
+ * last d2fe_profile_enable call, and clears them.  Stage order: D2FE_PROF_* below. */
+enum {
+  D2FE_PROF_CONV1A = 0, D2FE_PROF_CONV1B, D2FE_PROF_CONV2A, D2FE_PROF_CONV2B, D2FE_PROF_CONV3A, D2FE_PROF_CONV3B,
+  D2FE_PROF_CONV4A, D2FE_PROF_CONV4B, D2FE_PROF_CONVPADA, D2FE_PROF_CONVPB, D2FE_PROF_CONVDB, D2FE_PROF_SOFTMAX,
+  D2FE_PROF_SELECT, D2FE_PROF_SAMPLE, D2FE_PROF_MATCH, D2FE_PROF_COUNT
+};
+D2FE_API int d2fe_profile_enable(d2fe_handle h, int mode);
+D2FE_API int d2fe_profile_read(d2fe_handle h, float* ms /*[D2FE_PROF_COUNT]*/, int32_t* launches /*[D2FE_PROF_COUNT]*/);
+
 /* Synchronise the handle's stream (for timing with device-resident calls). */
 D2FE_API int d2fe_sync(d2fe_handle h);
 
