@@ -1,0 +1,89 @@
+"""CPU checks of the drop-in boundary: libd2fe_hip.so loads without a GPU and exports exactly what
+include/d2fe.h declares; host-side entry points behave; device entry points fail loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "d2fe.h")).read()
+    return sorted(set(re.findall(r"D2FE_API\s+[\w\s\*]+?\b(d2fe_\w+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from d2slam_amd import build
+    return C.CDLL(build.build())
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(lib, n), "missing export %s" % n
+    from d2slam_amd import api
+    assert sorted(api.EXPORTS) == names, "api.EXPORTS out of sync with include/d2fe.h"
+
+
+def test_version_and_default_config(lib):
+    from d2slam_amd.api import _Config
+    lib.d2fe_version.restype = C.c_char_p
+    assert b"gfx950" in lib.d2fe_version()
+    c = _Config()
+    lib.d2fe_default_config(C.byref(c))
+    assert c.struct_size == C.sizeof(_Config)
+    # SuperPointConfig defaults, superpoint_tensorrt.h:18-24
+    assert (c.max_keypoints, c.remove_borders) == (100, 1) and abs(c.keypoint_threshold - 0.015) < 1e-9
+
+
+def test_half_image_filter_host_logic(lib, orc):
+    rng = np.random.RandomState(0)
+    pts = rng.uniform(0, 800, size=(300, 2)).astype(np.float32)
+    from d2slam_amd.api import get_feature_half_img
+    desc = rng.randn(300, 256).astype(np.float32)
+    for left in (True, False):
+        d, p, idx = get_feature_half_img(pts, desc, left, 800, 200.0)
+        ref = orc.half_img(pts, left, 800, 200.0)
+        assert np.array_equal(idx, ref) and np.array_equal(d, desc[ref]) and np.array_equal(p, pts[ref])
+
+
+def test_invalid_arguments_do_not_crash(lib):
+    lib.d2fe_last_error.restype = C.c_char_p
+    h = C.c_void_p()
+    assert lib.d2fe_create(None, C.byref(h)) == -1
+    from d2slam_amd.api import _Config
+    c = _Config()
+    lib.d2fe_default_config(C.byref(c))
+    c.max_width = 641
+    assert lib.d2fe_create(C.byref(c), C.byref(h)) == -1 and b"multiples of 8" in lib.d2fe_last_error()
+    n = C.c_int(5)
+    assert lib.d2fe_match_knn(None, None, 3, None, 3, 256, C.c_double(0.8), None, None, C.c_double(-1.0), None, None, None,
+                              3, C.byref(n)) == -1 and n.value == 0
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path must raise, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from d2slam_amd import api
+    with pytest.raises(api.D2FEError):
+        api.FrontEnd(api.SuperPointConfig())
+    sp = api.SuperPoint(api.SuperPointConfig(), weights=None)
+    assert sp.build() is False
+    ok, k, d, s = sp.infer(np.zeros((480, 640), np.uint8))
+    assert ok is False and len(k) == 0 and len(d) == 0 and len(s) == 0      # reference clears outputs on failure
+
+
+def test_product_does_not_import_oracle():
+    pk = os.path.join(ROOT, "d2slam_amd")
+    for dp, _, fs in os.walk(pk):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                s = open(os.path.join(dp, f)).read()
+                assert "from oracle" not in s and "import oracle" not in s and "d2fe_oracle" not in s.replace("oracle/d2fe_oracle.c", ""), f

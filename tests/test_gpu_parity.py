@@ -1,0 +1,262 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the oracle on identical inputs.
+ * exact mode (fp32 MFMA): activations, scores, keypoint indices BIT-EXACT; descriptors <= 1e-6
+ * fast mode (fp16 hi/lo split): descriptors <= 1e-4 (north_star tolerance), scores <= 1e-5; indices equal except
+   at score near-ties (checked as: the symmetric difference of the keypoint sets only contains near-boundary scores)
+ * matcher: indices and distances bit-exact
+"""
+import numpy as np
+import pytest
+
+from d2slam_amd.synth import synth_descriptor_pair, synth_image, synth_stereo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from d2slam_amd import api as a
+    a.load_library()
+    return a
+
+
+def _fe(api, H, W, n, prec, max_kp=200, thr=0.015):
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=max_kp, input_width=W, input_height=H, max_batch=n, precision=prec,
+                                           keypoint_threshold=thr))
+    return fe
+
+
+LAYERS = [("conv1a", 1, 64), ("conv1b", 2, 64), ("conv2a", 2, 64), ("conv2b", 4, 64), ("conv3a", 4, 128), ("conv3b", 8, 128),
+          ("conv4a", 8, 128), ("conv4b", 8, 128)]
+
+
+def _oracle_layers(orc, img, w):
+    x = orc.prep_u8(img)[:, :, None]
+    out = {}
+    x = orc.conv(x, *w["conv1a"], True); out["conv1a"] = x
+    x = orc.maxpool2(orc.conv(x, *w["conv1b"], True)); out["conv1b"] = x
+    x = orc.conv(x, *w["conv2a"], True); out["conv2a"] = x
+    x = orc.maxpool2(orc.conv(x, *w["conv2b"], True)); out["conv2b"] = x
+    x = orc.conv(x, *w["conv3a"], True); out["conv3a"] = x
+    x = orc.maxpool2(orc.conv(x, *w["conv3b"], True)); out["conv3b"] = x
+    x = orc.conv(x, *w["conv4a"], True); out["conv4a"] = x
+    x = orc.conv(x, *w["conv4b"], True); out["conv4b"] = x
+    return out
+
+
+@pytest.mark.parametrize("H,W", [(96, 128), (104, 136), (72, 200)])
+def test_exact_mode_bitwise_every_layer(api, orc, sp_weights, H, W):
+    """fp32 MFMA conv stack == oracle fmaf chains, bit for bit, incl. ragged tiles (sizes not multiples of the tile)."""
+    n = 2
+    imgs = np.stack([synth_image(H, W, 10 + s) for s in range(n)])
+    fe = _fe(api, H, W, n, api.PREC_F32)
+    fe.load_superpoint(sp_weights)
+    res = fe.extract_batch(imgs, cap=200)
+    for i in range(n):
+        ref = _oracle_layers(orc, imgs[i], sp_weights)
+        for name, div, c in LAYERS:
+            got = fe.debug_read(name, (n, H // div, W // div, c))[i]
+            assert np.array_equal(got, ref[name]), "%s differs (max %g)" % (name, np.abs(got - ref[name]).max())
+        f = orc.superpoint_forward(imgs[i], sp_weights)
+        assert np.array_equal(fe.debug_read("logits", (n, H // 8, W // 8, 65))[i], f["logits"])
+        assert np.array_equal(fe.debug_read("desc_raw", (n, H // 8, W // 8, 256))[i], f["desc_raw"])
+        assert np.array_equal(fe.debug_read("semi", (n, H, W))[i], f["semi"])
+        rk, rs, ri = orc.select_b(f["semi"], 0.015, 1, 200)
+        kps, sc, desc = res[i]
+        assert np.array_equal(kps, rk) and np.array_equal(sc, rs)
+        assert np.abs(desc - orc.sample_b(f["desc"], rk)).max() <= 1e-6
+    fe.close()
+
+
+def test_exact_mode_full_size_stereo(api, orc, sp_weights):
+    """BASELINE config[1] size: 640x480 stereo pair, 200 keypoints: indices exact, descriptors <= 1e-6."""
+    l, r = synth_stereo(480, 640, seed=1)
+    imgs = np.stack([l, r])
+    fe = _fe(api, 480, 640, 2, api.PREC_F32)
+    fe.load_superpoint(sp_weights)
+    res = fe.extract_batch(imgs, cap=200)
+    descs = []
+    for i in range(2):
+        rk, rs, rd, ri, f = orc.extract_b(imgs[i], sp_weights, 0.015, 1, 200)
+        kps, sc, desc = res[i]
+        assert len(kps) == 200
+        assert np.array_equal(kps, rk) and np.array_equal(sc, rs)
+        assert np.abs(desc - rd).max() <= 1e-6
+        descs.append((desc, rd, kps))
+    # end to end: matches computed from the GPU descriptors equal the oracle's matches of the oracle descriptors
+    q, t, d = fe.match_knn(descs[0][0], descs[1][0], 0.8, descs[0][2], descs[1][2], 0.2 * 640)
+    rq, rt, rdist = orc.match_knn(descs[0][0], descs[1][0], 0.8, descs[0][2], descs[1][2], 0.2 * 640)
+    assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rdist)
+    fe.close()
+
+
+def test_raster_order_when_fewer_than_max(api, orc, sp_weights):
+    """K <= N: the reference does not sort (superpoint_tensorrt.cpp:242) -> raster order; also the empty case."""
+    img = synth_image(96, 128, 5)
+    f = orc.superpoint_forward(img, sp_weights)
+    thr = float(np.sort(f["semi"].reshape(-1))[-40])      # ~39 candidates above
+    fe = _fe(api, 96, 128, 1, api.PREC_F32, max_kp=200, thr=thr)
+    fe.load_superpoint(sp_weights)
+    (kps, sc, desc), = fe.extract_batch(img[None], cap=200)
+    rk, rs, ri = orc.select_b(f["semi"], thr, 1, 200)
+    assert 0 < len(rk) < 200 and np.array_equal(kps, rk) and np.array_equal(sc, rs)
+    assert np.all(np.diff(ri) > 0)
+    fe.close()
+    fe = _fe(api, 96, 128, 1, api.PREC_F32, max_kp=200, thr=0.99)
+    fe.load_superpoint(sp_weights)
+    (kps, sc, desc), = fe.extract_batch(img[None], cap=200)
+    assert len(kps) == 0 and len(sc) == 0 and desc.shape == (0, 256)
+    fe.close()
+
+
+def test_score_ties_use_raster_tiebreak(api, orc, sp_weights):
+    """A constant image makes every interior cell identical -> massive exact score ties; selection must still equal
+    the oracle's (score desc, raster asc)."""
+    img = np.full((96, 128), 127, np.uint8)
+    f = orc.superpoint_forward(img, sp_weights)
+    thr = float(np.median(f["semi"]))
+    fe = _fe(api, 96, 128, 1, api.PREC_F32, max_kp=64, thr=thr)
+    fe.load_superpoint(sp_weights)
+    (kps, sc, desc), = fe.extract_batch(img[None], cap=64)
+    rk, rs, ri = orc.select_b(f["semi"], thr, 1, 64)
+    assert len(rk) == 64 and np.array_equal(kps, rk) and np.array_equal(sc, rs)
+    fe.close()
+
+
+@pytest.mark.parametrize("H,W", [(96, 128), (480, 640)])
+def test_fast_mode_tolerances(api, orc, sp_weights, H, W):
+    imgs = np.stack(synth_stereo(H, W, seed=3))
+    fe = _fe(api, H, W, 2, api.PREC_F16X2)
+    fe.load_superpoint(sp_weights)
+    res = fe.extract_batch(imgs, cap=200)
+    for i in range(2):
+        f = orc.superpoint_forward(imgs[i], sp_weights)
+        semi = fe.debug_read("semi", (2, H, W))[i]
+        assert np.abs(semi - f["semi"]).max() <= 1e-5
+        assert np.abs(fe.debug_read("desc_raw", (2, H // 8, W // 8, 256))[i] - f["desc_raw"]).max() <= 1e-4
+        rk, rs, ri = orc.select_b(f["semi"], 0.015, 1, 200)
+        kps, sc, desc = res[i]
+        gi = (kps[:, 1] * W + kps[:, 0]).astype(np.int64)
+        common = np.intersect1d(gi, ri)
+        assert len(common) >= 195, "fast mode keypoint set diverged: %d common" % len(common)
+        # any keypoint not shared must be a near-tie at the top-K boundary
+        kth = rs[-1]
+        for j in np.setdiff1d(gi, ri):
+            assert abs(f["semi"].reshape(-1)[j] - kth) <= 2e-5 * max(kth, 1e-3)
+        # descriptors of the shared keypoints: 1e-4 (north_star), actually ~1e-6
+        rd = orc.sample_b(f["desc"], rk)
+        pos_g = {int(v): k for k, v in enumerate(gi)}
+        pos_r = {int(v): k for k, v in enumerate(ri)}
+        dg = np.stack([desc[pos_g[int(c)]] for c in common]); dr = np.stack([rd[pos_r[int(c)]] for c in common])
+        assert np.abs(dg - dr).max() <= 1e-4
+        assert np.abs(dg - dr).max() <= 5e-6
+    fe.close()
+
+
+MATCH_CASES = [(200, 200, 256, 0.8, -1.0, 0.05), (150, 97, 256, 0.7, 32.0, 0.2), (33, 200, 64, 0.9, -1.0, 0.05),
+               (100, 100, 256, 0.9, 19.2, 0.05), (200, 150, 32, 0.8, -1.0, 0.2), (257, 300, 256, 0.8, -1.0, 0.05),
+               (1, 5, 256, 0.8, -1.0, 0.05), (5, 1, 256, 0.8, -1.0, 0.05), (2, 2, 256, 0.8, -1.0, 0.05), (1024, 1000, 128, 0.8, -1.0, 0.1)]
+
+
+@pytest.mark.parametrize("na,nb,dim,ratio,radius,sigma", MATCH_CASES)
+def test_match_knn_and_crosscheck_exact(api, orc, na, nb, dim, ratio, radius, sigma):
+    fe = _fe(api, 64, 64, 1, api.PREC_F32)
+    a, b, pa, pb = synth_descriptor_pair(na, nb, dim, seed=na * 7 + nb, sigma=sigma)
+    q, t, d = fe.match_knn(a, b, ratio, pa, pb, radius)
+    rq, rt, rd = orc.match_knn(a, b, ratio, pa, pb, radius)
+    assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd)
+    q, t, d = fe.match_crosscheck(a, b)
+    rq, rt, rd = orc.match_crosscheck(a, b)
+    assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd)
+    fe.close()
+
+
+def test_match_edge_cases(api, orc):
+    fe = _fe(api, 64, 64, 1, api.PREC_F32)
+    a, b, pa, pb = synth_descriptor_pair(50, 60, 256, seed=1)
+    q, t, d = fe.match_knn(a[:0], b, 0.8)
+    assert len(q) == 0
+    q, t, d = fe.match_knn(a, b[:0], 0.8)
+    assert len(q) == 0
+    # duplicated train rows: exact distance ties -> lower index wins, ratio test d0 < r*d1 fails (d0 == d1)
+    b2 = np.concatenate([b, b[:10]])
+    q, t, d = fe.match_knn(a, b2, 0.8)
+    rq, rt, rd = orc.match_knn(a, b2, 0.8)
+    assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd)
+    # self match: identity with zero distance (size-independent property)
+    q, t, d = fe.match_knn(a, a, 0.8)
+    assert np.array_equal(q, np.arange(50)) and np.array_equal(t, np.arange(50)) and np.all(d == 0)
+    # too many rows -> loud error, not silence
+    with pytest.raises(api.D2FEError):
+        fe.match_knn(np.zeros((1025, 256), np.float32), b, 0.8)
+    fe.close()
+
+
+def test_match_batch_device_equals_host_calls(api, orc):
+    """The batched device-resident entry point (what bench.py times) == per-pair host calls == oracle."""
+    torch = pytest.importorskip("torch")
+    fe = _fe(api, 64, 64, 1, api.PREC_F32)
+    dev = torch.device("cuda", 0)
+    cap, npairs = 200, 6
+    rng = np.random.RandomState(0)
+    pool = np.zeros((2 * npairs, cap, 256), np.float32); cnts = np.zeros(2 * npairs, np.int32)
+    refs = []
+    for p in range(npairs):
+        na, nb = int(rng.randint(1, cap + 1)), int(rng.randint(1, cap + 1))
+        a, b, _, _ = synth_descriptor_pair(na, nb, 256, seed=100 + p)
+        pool[2 * p, :na] = a; pool[2 * p + 1, :nb] = b; cnts[2 * p] = na; cnts[2 * p + 1] = nb
+        refs.append(orc.match_knn(a, b, 0.8))
+    d_pool = torch.from_numpy(pool).to(dev); d_cnt = torch.from_numpy(cnts).to(dev)
+    a_off = torch.arange(0, 2 * npairs, 2, dtype=torch.int32, device=dev) * cap
+    b_off = a_off + cap
+    a_cnt = d_cnt[0::2].contiguous(); b_cnt = d_cnt[1::2].contiguous()
+    q = torch.zeros((npairs, cap), dtype=torch.int32, device=dev); t = torch.zeros_like(q)
+    d = torch.zeros((npairs, cap), dtype=torch.float32, device=dev); n = torch.zeros(npairs, dtype=torch.int32, device=dev)
+    fe.match_batch_device(d_pool.data_ptr(), d_pool.data_ptr(), a_off.data_ptr(), b_off.data_ptr(), a_cnt.data_ptr(),
+                          b_cnt.data_ptr(), npairs, 256, cap, q.data_ptr(), t.data_ptr(), d.data_ptr(), n.data_ptr(),
+                          stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for p in range(npairs):
+        k = int(n[p])
+        rq, rt, rd = refs[p]
+        assert k == len(rq)
+        assert np.array_equal(q[p, :k].cpu().numpy(), rq) and np.array_equal(t[p, :k].cpu().numpy(), rt)
+        assert np.array_equal(d[p, :k].cpu().numpy(), rd)
+    fe.close()
+
+
+def test_extract_device_equals_host_api(api, sp_weights):
+    torch = pytest.importorskip("torch")
+    H, W, n, cap = 96, 128, 4, 100
+    imgs = np.stack([synth_image(H, W, 30 + s) for s in range(n)])
+    fe = _fe(api, H, W, n, api.PREC_F32, max_kp=cap)
+    fe.load_superpoint(sp_weights)
+    host = fe.extract_batch(imgs, cap=cap)
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(imgs).to(dev)
+    kps = torch.zeros((n, cap, 2), device=dev); sc = torch.zeros((n, cap), device=dev); desc = torch.zeros((n, cap, 256), device=dev)
+    idx = torch.zeros((n, cap), dtype=torch.int32, device=dev); cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    fe.extract_device(d_img.data_ptr(), n, W, H, kps.data_ptr(), sc.data_ptr(), desc.data_ptr(), idx.data_ptr(), cap, cnt.data_ptr(),
+                      stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(n):
+        k = int(cnt[i])
+        assert k == len(host[i][0])
+        assert np.array_equal(kps[i, :k].cpu().numpy(), host[i][0]) and np.array_equal(desc[i, :k].cpu().numpy(), host[i][2])
+        assert np.array_equal(idx[i, :k].cpu().numpy(), (host[i][0][:, 1] * W + host[i][0][:, 0]).astype(np.int32))
+    fe.close()
+
+
+def test_error_behaviour(api, sp_weights):
+    fe = _fe(api, 96, 128, 1, api.PREC_F32)
+    with pytest.raises(api.D2FEError):            # weights not loaded (reference: infer() -> false)
+        fe.extract_batch(np.zeros((1, 96, 128), np.uint8))
+    fe.load_superpoint(sp_weights)
+    with pytest.raises(api.D2FEError):            # size not a multiple of 8 / larger than configured
+        fe.extract_batch(np.zeros((1, 100, 128), np.uint8))
+    with pytest.raises(api.D2FEError):
+        fe.extract_batch(np.zeros((2, 96, 128), np.uint8))   # batch > max_batch
+    fe.close()
+    sp = api.SuperPoint(api.SuperPointConfig(input_width=128, input_height=96, max_keypoints=50), weights=sp_weights)
+    assert sp.build() is True
+    ok, k, d, s = sp.infer(synth_image(96, 128, 1))
+    assert ok and k.shape == (50, 2) and d.shape == (50 * 256,) and s.shape == (50,)

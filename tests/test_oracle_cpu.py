@@ -1,0 +1,254 @@
+"""CPU tests of the oracle (oracle/d2fe_oracle.c): each restated routine is checked against an INDEPENDENT
+implementation (PyTorch fp64 / plain numpy written from SURVEY.md Appendix B) and against the committed golden
+fixtures.  The reference ships no golden vectors for this path (parity unpinned, see oracle header)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from d2slam_amd.synth import synth_descriptor_pair, synth_image
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_expf_accuracy(orc):
+    xs = np.concatenate([np.linspace(-87, 0, 20001), -np.logspace(-8, 1.9, 2000)]).astype(np.float32)
+    got = np.array([orc.expf(x) for x in xs], np.float32)
+    ref = np.exp(xs.astype(np.float64))
+    ulp = np.abs(got.astype(np.float64) - ref) / np.spacing(ref.astype(np.float32)).astype(np.float64)
+    assert ulp.max() <= 2.0, ulp.max()
+    assert orc.expf(0.0) == 1.0
+
+
+def _torch_forward(img, w, dtype=torch.float64):
+    x = torch.from_numpy(img.astype(np.float32) * np.float32(1.0 / 255.0))[None, None].to(dtype)
+
+    def cv(x, n, relu=True):
+        W, b = w[n]
+        y = F.conv2d(x, torch.from_numpy(W).to(dtype), torch.from_numpy(b).to(dtype), padding=W.shape[-1] // 2)
+        return torch.relu(y) if relu else y
+    mp = lambda t: F.max_pool2d(t, 2, 2)
+    x = cv(x, "conv1a"); x = cv(x, "conv1b"); x = mp(x); x = cv(x, "conv2a"); x = cv(x, "conv2b"); x = mp(x)
+    x = cv(x, "conv3a"); x = cv(x, "conv3b"); x = mp(x); x = cv(x, "conv4a"); x = cv(x, "conv4b")
+    semi = cv(cv(x, "convPa"), "convPb", False)
+    desc = cv(cv(x, "convDa"), "convDb", False)
+    dn = torch.norm(desc, p=2, dim=1)
+    descn = desc / dn.unsqueeze(1)
+    sm = torch.softmax(semi, 1)[:, :64].permute(0, 2, 3, 1)
+    Hc, Wc = sm.shape[1], sm.shape[2]
+    sm = sm.contiguous().view(-1, Hc, Wc, 8, 8).permute(0, 1, 3, 2, 4).contiguous().view(-1, Hc * 8, Wc * 8)
+    return semi[0].permute(1, 2, 0).numpy(), desc[0].permute(1, 2, 0).numpy(), descn[0].permute(1, 2, 0).numpy(), sm[0].numpy()
+
+
+def test_network_vs_torch_fp64(orc, sp_weights):
+    """A1+A2 against the notebook's own graph (superpoint.ipynb:300-374) evaluated by PyTorch in fp64."""
+    img = synth_image(64, 96, 3)
+    f = orc.superpoint_forward(img, sp_weights)
+    logits, draw, descn, semi = _torch_forward(img, sp_weights)
+    assert np.abs(f["logits"] - logits).max() < 5e-5
+    assert np.abs(f["desc_raw"] - draw).max() < 5e-5
+    assert np.abs(f["desc"] - descn).max() < 1e-5
+    assert np.abs(f["semi"] - semi).max() < 5e-6
+
+
+def test_conv_is_fmaf_chain(orc):
+    """The oracle conv is exactly the (ky,kx,ci) fp32 fma chain started from the bias."""
+    rng = np.random.RandomState(0)
+    x = rng.randn(5, 6, 8).astype(np.float32); w = rng.randn(4, 8, 3, 3).astype(np.float32); b = rng.randn(4).astype(np.float32)
+    got = orc.conv(x, w, b, False)
+    for (y, xx, co) in [(0, 0, 0), (2, 3, 1), (4, 5, 3)]:
+        acc = np.float32(b[co])
+        for ky in range(3):
+            for kx in range(3):
+                yy, xs = y + ky - 1, xx + kx - 1
+                if 0 <= yy < 5 and 0 <= xs < 6:
+                    for ci in range(8):
+                        acc = np.float32(np.float64(x[yy, xs, ci]) * np.float64(w[co, ci, ky, kx]) + np.float64(acc))  # fma: exact product, one rounding
+        assert got[y, xx, co] == acc
+
+
+def _select_b_numpy(semi, thr, border, max_kp):
+    h, w = semi.shape
+    idx = np.flatnonzero(semi.reshape(-1) > thr)
+    y, x = idx // w, idx % w
+    keep = (y >= border) & (y < h - border) & (x >= border) & (x < w - border)
+    idx = idx[keep]
+    s = semi.reshape(-1)[idx]
+    if max_kp != -1 and max_kp < len(idx):
+        order = np.lexsort((idx, -s.astype(np.float64)))[:max_kp]
+        idx, s = idx[order], s[order]
+    return np.stack([idx % w, idx // w], 1).astype(np.float32), s, idx
+
+
+@pytest.mark.parametrize("thr,maxkp", [(0.015, 50), (0.015, -1), (0.5, 50), (0.0, 7)])
+def test_select_b(orc, thr, maxkp):
+    rng = np.random.RandomState(1)
+    semi = (rng.rand(40, 56) ** 6 * 0.3).astype(np.float32)
+    semi[5, 5] = semi[7, 9] = semi[30, 40] = np.float32(0.29)  # exact ties -> raster tie-break
+    k, s, i = orc.select_b(semi, thr, 1, maxkp)
+    rk, rs, ri = _select_b_numpy(semi, thr, 1, maxkp)
+    assert np.array_equal(i, ri) and np.array_equal(k, rk) and np.array_equal(s, rs)
+
+
+def _sample_b_numpy(desc, kps):
+    hc, wc, dim = desc.shape
+    out = []
+    for x, y in kps.astype(np.float64):
+        gx = ((x - 3.5) / (wc * 8 - 4.5)) * 2 - 1
+        gy = ((y - 3.5) / (hc * 8 - 4.5)) * 2 - 1
+        ix = (gx + 1) / 2 * (wc - 1); iy = (gy + 1) / 2 * (hc - 1)
+        clip = lambda v, m: min(max(int(v), 0), m - 1)
+        x0 = clip(np.floor(ix), wc); y0 = clip(np.floor(iy), hc); x1 = clip(x0 + 1, wc); y1 = clip(y0 + 1, hc)
+        d = (desc[y0, x0] * (x1 - ix) * (y1 - iy) + desc[y0, x1] * (ix - x0) * (y1 - iy)
+             + desc[y1, x0] * (x1 - ix) * (iy - y0) + desc[y1, x1] * (ix - x0) * (iy - y0)).astype(np.float64)
+        out.append(d / np.linalg.norm(d))
+    return np.array(out)
+
+
+def test_sample_b(orc):
+    rng = np.random.RandomState(2)
+    desc = rng.randn(9, 12, 256).astype(np.float32)
+    desc /= np.linalg.norm(desc, axis=2, keepdims=True)
+    kps = np.stack([rng.randint(1, 95, 60), rng.randint(1, 71, 60)], 1).astype(np.float32)
+    kps[0] = (1, 1); kps[1] = (94, 70); kps[2] = (3, 4)   # border cases exercise the clipped-corner weights
+    got = orc.sample_b(desc, kps)
+    assert np.abs(got - _sample_b_numpy(desc, kps)).max() < 2e-6
+    assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-6
+
+
+def test_sample_a_vs_aten_grid_sampler(orc):
+    """Variant A calls torch::grid_sampler(bilinear, zeros, align_corners=false) (superpoint_common.cpp:64):
+    compare with the very same ATen kernel."""
+    rng = np.random.RandomState(3)
+    hc, wc = 8, 10
+    desc = rng.randn(hc, wc, 256).astype(np.float32)
+    desc /= np.linalg.norm(desc, axis=2, keepdims=True)
+    kps = np.stack([rng.randint(0, wc * 8, 50), rng.randint(0, hc * 8, 50)], 1).astype(np.float32)
+    kps[0] = (0, 0); kps[1] = (wc * 8 - 1, hc * 8 - 1)
+    got = orc.sample_a(desc, kps, wc * 8, hc * 8)
+    grid = torch.zeros(1, 1, len(kps), 2)
+    grid[0, 0, :, 0] = 2.0 * torch.from_numpy(kps[:, 0]) / (wc * 8) - 1
+    grid[0, 0, :, 1] = 2.0 * torch.from_numpy(kps[:, 1]) / (hc * 8) - 1
+    t = torch.from_numpy(desc).permute(2, 0, 1)[None]
+    ref = F.grid_sample(t, grid, mode="bilinear", padding_mode="zeros", align_corners=False)[0, :, 0].T
+    ref = ref / ref.norm(dim=1, keepdim=True)
+    assert np.abs(got - ref.numpy()).max() < 2e-6
+    # PCA branch: (d - mean) @ comp^T then row L2 (superpoint_common.cpp:76-85)
+    comp = rng.randn(64, 256).astype(np.float32); mean = rng.randn(256).astype(np.float32) * 0.01
+    gp = orc.sample_a(desc, kps, wc * 8, hc * 8, comp, mean)
+    rp = (ref.numpy().astype(np.float64) - mean) @ comp.T.astype(np.float64)
+    rp /= np.linalg.norm(rp, axis=1, keepdims=True)
+    assert np.abs(gp - rp).max() < 5e-6
+
+
+def _nms2_python(prob, thr, d, max_num):
+    """SURVEY.md Appendix B.2 written out naively."""
+    h, w = prob.shape
+    cand = [(i % w, i // w) for i in np.flatnonzero(prob.reshape(-1) > thr)]
+    grid = np.zeros((h, w), np.uint8); conf = np.zeros((h, w), np.float32)
+    for (x, y) in cand:
+        grid[y, x] = 1; conf[y, x] = prob[y, x]
+    for (x, y) in cand:
+        if grid[y, x] != 1:
+            continue
+        for k in range(-d, d + 1):
+            for j in range(-d, d + 1):
+                if (j or k) and 0 <= x + j < w and 0 <= y + k < h and conf[y + k, x + j] < conf[y, x]:
+                    grid[y + k, x + j] = 0
+        grid[y, x] = 2
+    kept = [(x, y, conf[y, x]) for y in range(h) for x in range(w) if grid[y, x] == 2]
+    order = sorted(range(len(kept)), key=lambda i: (-kept[i][2], i))[:max_num]
+    return np.array([[kept[i][0], kept[i][1]] for i in order], np.float32).reshape(-1, 2), np.array([kept[i][2] for i in order], np.float32)
+
+
+def test_nms2_a(orc):
+    rng = np.random.RandomState(4)
+    prob = (rng.rand(48, 64) ** 8).astype(np.float32)
+    for d, thr in ((4, 0.05), (10, 0.015), (1, 0.3)):
+        k, s = orc.nms2_a(prob, thr, d, 40)
+        rk, rs = _nms2_python(prob, thr, d, 40)
+        assert np.array_equal(k, rk) and np.array_equal(s, rs)
+    # raster-order dependence: C<B<A in raster order C,B,A keeps only A
+    p = np.zeros((8, 16), np.float32); p[2, 2] = 0.1; p[2, 5] = 0.2; p[2, 8] = 0.3
+    k, s = orc.nms2_a(p, 0.05, 3, 10)
+    assert k.tolist() == [[8.0, 2.0]]
+
+
+def _knn_numpy(a, b, ratio, pts_a, pts_b, radius):
+    d = np.sqrt(((a[:, None, :].astype(np.float64) - b[None].astype(np.float64)) ** 2).sum(-1))
+    out = []
+    if a.shape[0] < 2 or b.shape[0] < 2:
+        return out
+    inv = {}
+    for j in range(b.shape[0]):
+        o = np.argsort(d[:, j], kind="stable")
+        if d[o[0], j] < ratio * d[o[1], j]:
+            inv[j] = o[0]
+    for i in range(a.shape[0]):
+        o = np.argsort(d[i], kind="stable")
+        if d[i, o[0]] < ratio * d[i, o[1]] and inv.get(o[0], -1) == i:
+            if radius > 0 and np.hypot(*(pts_a[i] - pts_b[o[0]]).astype(np.float64)) > radius:
+                continue
+            out.append((i, int(o[0])))
+    return out
+
+
+@pytest.mark.parametrize("na,nb,dim,ratio,radius", [(60, 70, 256, 0.8, -1), (50, 50, 64, 0.7, 25.0), (33, 17, 256, 0.9, -1),
+                                                    (1, 9, 256, 0.8, -1), (9, 1, 256, 0.8, -1), (2, 2, 32, 0.95, -1)])
+def test_match_knn(orc, na, nb, dim, ratio, radius):
+    a, b, pa, pb = synth_descriptor_pair(na, nb, dim, seed=na + nb)
+    q, t, d = orc.match_knn(a, b, ratio, pa, pb, radius)
+    ref = _knn_numpy(a, b, ratio, pa, pb, radius)
+    assert list(zip(q.tolist(), t.tolist())) == ref
+    if len(q):
+        dd = np.sqrt(((a[q].astype(np.float64) - b[t].astype(np.float64)) ** 2).sum(-1))
+        assert np.abs(d - dd).max() < 1e-6
+        assert np.all(np.diff(q) > 0)
+
+
+def test_match_empty_and_crosscheck(orc):
+    a, b, _, _ = synth_descriptor_pair(40, 30, 256, seed=9)
+    q, t, d = orc.match_knn(a[:0], b, 0.8)
+    assert len(q) == 0
+    q, t, d = orc.match_crosscheck(a, b)
+    dm = np.sqrt(((a[:, None].astype(np.float64) - b[None].astype(np.float64)) ** 2).sum(-1))
+    ref = [(i, int(dm[i].argmin())) for i in range(40) if dm[:, dm[i].argmin()].argmin() == i]
+    assert list(zip(q.tolist(), t.tolist())) == ref
+
+
+def test_l2_dist_order_is_opencv_sse(orc):
+    """orc_l2_dist == 4x4 strided accumulators, ((d0+d1)+d2)+d3, (r0+r2)+(r1+r3), sqrt -- evaluated here in numpy f32."""
+    rng = np.random.RandomState(5)
+    a = rng.randn(256).astype(np.float32); b = rng.randn(256).astype(np.float32)
+    t = (a - b); tt = (t * t).reshape(16, 4, 4)         # [iter][v][l]
+    acc = np.zeros((4, 4), np.float32)
+    for i in range(16):
+        acc = acc + tt[i]
+    r = ((acc[0] + acc[1]) + acc[2]) + acc[3]
+    ref = np.sqrt(np.float32((r[0] + r[2]) + (r[1] + r[3])))
+    assert orc.l2_dist(a, b) == ref
+
+
+def test_half_img(orc):
+    pts = np.array([[10, 5], [399, 1], [400, 2], [600, 3], [179.9, 0], [180, 0]], np.float32)
+    # width_undistort 800, fov 200 -> move_cols = 360
+    assert orc.half_img(pts, True, 800, 200.0).tolist() == [0, 1, 2, 4, 5]   # x < 440
+    assert orc.half_img(pts, False, 800, 200.0).tolist() == [1, 2, 3]        # x >= 360
+
+
+def test_golden_fixtures(orc, sp_weights):
+    """Committed known-answer vectors (tests/golden/make_golden.py): the network outputs of the fixture were
+    produced by PyTorch fp64 (independent of the oracle); the post-processing/matching outputs pin the oracle."""
+    z = np.load(os.path.join(GOLDEN, "superpoint_64x96.npz"))
+    f = orc.superpoint_forward(z["image"], sp_weights)
+    assert np.abs(f["logits"] - z["torch_logits"]).max() < 5e-5
+    assert np.abs(f["semi"] - z["torch_semi"]).max() < 5e-6
+    assert np.abs(f["desc"] - z["torch_desc"]).max() < 1e-5
+    k, s, i = orc.select_b(f["semi"], 0.015, 1, 50)
+    assert np.array_equal(i, z["sel_idx"]) and np.array_equal(s, z["sel_scores"])
+    assert np.abs(orc.sample_b(f["desc"], k) - z["sel_desc"]).max() < 1e-6
+    m = np.load(os.path.join(GOLDEN, "match_120x90.npz"))
+    q, t, d = orc.match_knn(m["a"], m["b"], 0.8, m["pts_a"], m["pts_b"], 40.0)
+    assert np.array_equal(q, m["q"]) and np.array_equal(t, m["t"]) and np.array_equal(d, m["d"])
