@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -163,6 +164,7 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     a.out = out; a.out_cstride = ocs; a.out_coff = 0;
     a.cout_real = L.cout; a.wpack = L.wpack; a.bias = L.bias;
     a.H = hh; a.W = ww; a.n_img = n; a.in_img_stride = iis; a.out_img_stride = ois;
+    { static int ab = -1; if (ab < 0) { const char* e = getenv("D2FE_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
     return launch_conv(shape, prec, pool, relu, L.cout_pad, a, s);
   };
   { ProfScope ps(h, D2FE_PROF_CONV1B, s); HIP_TRY(conv(CONV_64_T8x32, h->L[L_1B], h->a1a.p, 64, 0, (long)H * W * 64, h->a1b.p, 64, (long)H2 * W2 * 64, H, W, true, true)); }

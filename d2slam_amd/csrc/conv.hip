@@ -21,8 +21,14 @@ namespace d2fe {
 // =====================================================================================================
 // Exact fp32 kernel
 // =====================================================================================================
+// waves/SIMD the LDS footprint allows (160 KiB per CU, 4 waves per block on 4 SIMDs): used as the register-allocation target
+constexpr int f32_min_waves(int CIN, int KS, int TH, int TW) {
+  const int lds = (TH + KS - 1) * (TW + KS - 1) * (CIN + 1) * 4;
+  return 163840 / lds >= 3 ? 3 : (163840 / lds >= 2 ? 2 : 1);
+}
+
 template <int CIN, int KS, int TH, int TW, int WM, int WN, int MT, int NT, bool POOL, bool RELU>
-__global__ __launch_bounds__(WM * WN * 64) void conv_f32_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, f32_min_waves(CIN, KS, TH, TW)) void conv_f32_kernel(ConvArgs a) {
   constexpr int P = KS / 2;
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
   constexpr int CP = CIN + 1;  // odd pixel stride: 32 pixels x same channel hit 32 distinct banks
@@ -57,7 +63,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f32_kernel(ConvArgs a) {
         if (it0 + u < ITERS && idx < TOTAL) {
           const int pix = idx / C4, c4 = idx % C4;
           const int gy = ty0 + pix / PW - P, gx = tx0 + pix % PW - P;
-          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && !(a.ablate & 1))
             v[u] = *reinterpret_cast<const f32x4*>(in + ((size_t)gy * a.W + gx) * a.in_cstride + c4 * 4);
         }
       }
@@ -101,23 +107,30 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f32_kernel(ConvArgs a) {
 #pragma unroll
   for (int n = 0; n < NT; ++n) wbase[n] = wp + (size_t)(ntile0 + n) * TAPS * C8 * 64 + lane;
 
-  f32x4 bw[NT], bw_next[NT];
+  // B fragments are double-buffered in registers in groups of G k-steps: group g+1 is requested from L2 before the
+  // MFMAs of group g start (sched_barrier keeps hipcc from sinking the loads next to their uses), so one L2 round
+  // trip is covered by G*4*MT*NT MFMAs (>= 64 x 64 cycles).
+  constexpr int G = 8;                 // k-steps (of 8 channels) per group; divides C8
+  constexpr int GPT = C8 / G;          // groups per tap
+  constexpr int NG = TAPS * GPT;
+  static_assert(C8 % G == 0, "group size must divide the steps per tap");
+  f32x4 bq[2][G][NT];
+  auto load_grp = [&](int buf, int grp) {
+    if (a.ablate & 2) grp = 0;
 #pragma unroll
-  for (int n = 0; n < NT; ++n) bw[n] = wbase[n][0];
-
-  for (int tap = 0; tap < TAPS; ++tap) {
-    const int tap_off = ((tap / KS) * PW + (tap % KS)) * CP;
-#pragma unroll 2
-    for (int c8 = 0; c8 < C8; ++c8) {
-      const int step = tap * C8 + c8;
-      // prefetch next step's B fragments (clamped on the last step)
-      const int nstep = (step + 1 < TAPS * C8) ? step + 1 : step;
+    for (int j = 0; j < G; ++j)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bw_next[n] = wbase[n][(size_t)nstep * 64];
+      for (int n = 0; n < NT; ++n) bq[buf][j][n] = wbase[n][(size_t)(grp * G + j) * 64];
+  };
+  auto compute_grp = [&](int buf, int grp) {
+    const int tap = grp / GPT, c80 = (grp % GPT) * G;
+    const int tap_off = ((tap / KS) * PW + (tap % KS)) * CP + c80 * 8;
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
       float av[MT][4];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const float* ap = patch + aoff[m] + tap_off + c8 * 8;
+        const float* ap = patch + aoff[m] + tap_off + j * 8;
 #pragma unroll
         for (int q = 0; q < 4; ++q) av[m][q] = ap[2 * q];
       }
@@ -127,11 +140,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f32_kernel(ConvArgs a) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int n = 0; n < NT; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], bw[n][q], acc[m][n], 0, 0, 0);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) bw[n] = bw_next[n];
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], bq[buf][j][n][q], acc[m][n], 0, 0, 0);
     }
+  };
+  load_grp(0, 0);
+#pragma unroll 1
+  for (int g = 0; g + 1 < NG; g += 2) {
+    load_grp(1, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_grp(0, g);
+    load_grp(0, g + 2 < NG ? g + 2 : NG - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_grp(1, g + 1);
   }
+  if constexpr (NG & 1) compute_grp(0, NG - 1);
 
   conv_epilogue<TW, MT, NT, POOL, RELU>(a, acc, 1.0f, img, ty0, tx0, wm, ntile0, lane);
 }
@@ -167,7 +189,9 @@ hipError_t launch_conv(ConvShape shape, int precision, bool pool, bool relu, int
                        hipStream_t s) {
   if (precision == 1) return launch_conv_f16x2(shape, pool, relu, cout_pad, a, s);
   switch (shape) {
-    case CONV_64_T8x32:      return launch_f32<64, 3, 8, 32, 4, 1, 2, 2>(pool, relu, cout_pad, a, s);
+    case CONV_64_T8x32:
+      if (tune_conv64() == 1) return launch_f32<64, 3, 4, 32, 2, 2, 2, 1>(pool, relu, cout_pad, a, s);
+      return launch_f32<64, 3, 8, 32, 4, 1, 2, 2>(pool, relu, cout_pad, a, s);
     case CONV_128_T4x32:     return launch_f32<128, 3, 4, 32, 2, 2, 2, 2>(pool, relu, cout_pad, a, s);
     case CONV_128_T4x16:     return launch_f32<128, 3, 4, 16, 1, 4, 2, 1>(pool, relu, cout_pad, a, s);
     case CONV_256_1x1_T4x16: return launch_f32<256, 1, 4, 16, 1, 4, 2, 1>(pool, relu, cout_pad, a, s);

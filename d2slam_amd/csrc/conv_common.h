@@ -2,7 +2,21 @@
 #pragma once
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace d2fe {
+
+// experiment knob: D2FE_CONV64_TILE: 1 (default) = 4x32-pixel tile, 2x2 waves, ~53 KB LDS, 3 blocks/CU; 0 = 8x32 tile, 4x1 waves, 1 block/CU
+static inline int tune_ablate() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("D2FE_ABLATE"); v = e ? atoi(e) : 0; }
+  return v;
+}
+static inline int tune_conv64() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("D2FE_CONV64_TILE"); v = e ? atoi(e) : 1; }
+  return v;
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -48,7 +62,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
             const int co = (ntile0 + n) * 32 + (lane & 31);
             float v = acc[m][n][r] * scale;
             if (RELU) v = v > 0.f ? v : 0.f;
-            if (co < a.cout_real) out[((size_t)oy * a.W + ox) * a.out_cstride + co] = v;
+            if (co < a.cout_real && !(a.ablate & 4)) out[((size_t)oy * a.W + ox) * a.out_cstride + co] = v;
           }
         }
       }
@@ -68,7 +82,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
           const float m1 = fmaxf(acc[1][n][r], acc[1][n][r + 1]);
           float v = fmaxf(m0, m1) * scale;
           if (RELU) v = v > 0.f ? v : 0.f;
-          if (co < a.cout_real) out[((size_t)oy * Wo + ox) * a.out_cstride + co] = v;
+          if (co < a.cout_real && !(a.ablate & 4)) out[((size_t)oy * Wo + ox) * a.out_cstride + co] = v;
         }
       }
     }

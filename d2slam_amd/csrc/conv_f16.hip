@@ -59,7 +59,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f16x2_kernel(ConvArgs a) {
         if (it0 + u < ITERS && idx < TOTAL) {
           const int pix = idx / C4, c4 = idx % C4;
           const int gy = ty0 + pix / PW - P, gx = tx0 + pix % PW - P;
-          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && !(a.ablate & 1))
             v[u] = *reinterpret_cast<const f32x4*>(in + ((size_t)gy * a.W + gx) * a.in_cstride + c4 * 4);
         }
       }
@@ -111,36 +111,55 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f16x2_kernel(ConvArgs a) {
 #pragma unroll
   for (int n = 0; n < NT; ++n) wbase[n] = wp + (size_t)(ntile0 + n) * TAPS * KST * 128 + lane;
 
-  f16x8 bh[NT], bl[NT], bh_n[NT], bl_n[NT];
+  // B fragments are double-buffered in registers in groups of G k-steps (hi and lo): group g+1 is requested from L2
+  // before the MFMAs of group g start (sched_barrier keeps hipcc from sinking the loads next to their uses).
+  constexpr int G = 4;                 // k-steps (of 16 channels) per group; divides KST
+  constexpr int GPT = KST / G;
+  constexpr int NG = TAPS * GPT;
+  static_assert(KST % G == 0, "group size must divide the steps per tap");
+  f16x8 bq[2][G][NT][2];
+  auto load_grp = [&](int buf, int grp) {
+    if (a.ablate & 2) grp = 0;
 #pragma unroll
-  for (int n = 0; n < NT; ++n) { bh[n] = wbase[n][0]; bl[n] = wbase[n][64]; }
-
-  for (int tap = 0; tap < TAPS; ++tap) {
-    const int tap_off = ((tap / KS) * PW + (tap % KS)) * CPH;
+    for (int j = 0; j < G; ++j)
 #pragma unroll
-    for (int ks = 0; ks < KST; ++ks) {
-      const int step = tap * KST + ks;
-      const int nstep = (step + 1 < TAPS * KST) ? step + 1 : step;
+      for (int n = 0; n < NT; ++n) {
+        bq[buf][j][n][0] = wbase[n][(size_t)(grp * G + j) * 128];
+        bq[buf][j][n][1] = wbase[n][(size_t)(grp * G + j) * 128 + 64];
+      }
+  };
+  auto compute_grp = [&](int buf, int grp) {
+    const int tap = grp / GPT, ks0 = (grp % GPT) * G;
+    const int tap_off = ((tap / KS) * PW + (tap % KS)) * CPH + ks0 * 16;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) { bh_n[n] = wbase[n][(size_t)nstep * 128]; bl_n[n] = wbase[n][(size_t)nstep * 128 + 64]; }
+    for (int j = 0; j < G; ++j) {
       f16x8 ah[MT], al[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        ah[m] = *reinterpret_cast<const f16x8*>(hi + aoff[m] + tap_off + ks * 16);
-        al[m] = *reinterpret_cast<const f16x8*>(lo + aoff[m] + tap_off + ks * 16);
+        ah[m] = *reinterpret_cast<const f16x8*>(hi + aoff[m] + tap_off + j * 16);
+        al[m] = *reinterpret_cast<const f16x8*>(lo + aoff[m] + tap_off + j * 16);
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bq[buf][j][n][0], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bq[buf][j][n][1], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bq[buf][j][n][0], acc[m][n], 0, 0, 0);
         }
-#pragma unroll
-      for (int n = 0; n < NT; ++n) { bh[n] = bh_n[n]; bl[n] = bl_n[n]; }
     }
+  };
+  load_grp(0, 0);
+#pragma unroll 1
+  for (int g = 0; g + 1 < NG; g += 2) {
+    load_grp(1, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_grp(0, g);
+    load_grp(0, g + 2 < NG ? g + 2 : NG - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_grp(1, g + 1);
   }
+  if constexpr (NG & 1) compute_grp(0, NG - 1);
 
   conv_epilogue<TW, MT, NT, POOL, RELU>(a, acc, 1.0f / bscale, img, ty0, tx0, wm, ntile0, lane);
 }
@@ -172,7 +191,9 @@ static hipError_t launch_f16(bool pool, bool relu, int cout_pad, const ConvArgs&
 
 hipError_t launch_conv_f16x2(ConvShape shape, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s) {
   switch (shape) {
-    case CONV_64_T8x32:      return launch_f16<64, 3, 8, 32, 4, 1, 2, 2>(pool, relu, cout_pad, a, s);
+    case CONV_64_T8x32:
+      if (tune_conv64() == 1) return launch_f16<64, 3, 4, 32, 2, 2, 2, 1>(pool, relu, cout_pad, a, s);
+      return launch_f16<64, 3, 8, 32, 4, 1, 2, 2>(pool, relu, cout_pad, a, s);
     case CONV_128_T4x32:     return launch_f16<128, 3, 4, 32, 2, 2, 2, 2>(pool, relu, cout_pad, a, s);
     case CONV_128_T4x16:     return launch_f16<128, 3, 4, 16, 1, 4, 2, 1>(pool, relu, cout_pad, a, s);
     case CONV_256_1x1_T4x16: return launch_f16<256, 1, 4, 16, 1, 4, 2, 1>(pool, relu, cout_pad, a, s);

@@ -17,6 +17,7 @@ struct ConvArgs {
   int n_img;
   long in_img_stride;       // floats between images
   long out_img_stride;
+  int ablate;               // experiment knob (D2FE_ABLATE): 1 skip patch loads, 2 skip B reloads, 4 skip stores
 };
 
 enum ConvShape {

@@ -1,0 +1,30 @@
+"""Summarise rocprofv3 output dirs produced by tools/profile.sh into a small text file for profiles/."""
+import csv, glob, os, sys
+from collections import defaultdict
+
+def short(name):
+    name = name.replace("void d2fe::", "").replace("d2fe::", "")
+    return name[:110]
+
+def main(root):
+    out = []
+    stats = glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    for f in stats:
+        out.append("== kernel stats (%s)" % os.path.relpath(f, root))
+        rows = list(csv.DictReader(open(f)))
+        for r in rows[:25]:
+            out.append("  %-112s calls=%-5s total_ms=%9.3f avg_us=%10.2f pct=%s" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_lds"):
+        fs = glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True)
+        for f in fs:
+            agg = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int)
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"]); agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+            out.append("== %s per-dispatch averages" % sub)
+            for k in sorted(agg, key=lambda k: -sum(agg[k].values()))[:14]:
+                out.append("  " + k)
+                out.append("      " + "  ".join("%s=%.4g" % (c, v / cnt[(k, c)]) for c, v in sorted(agg[k].items())))
+    print("\n".join(out))
+
+if __name__ == "__main__":
+    main(sys.argv[1])
