@@ -67,6 +67,8 @@ struct d2fe_context {
   int s_cap = 0;
   // last call geometry (for debug reads)
   int last_w = 0, last_h = 0, last_n = 0;
+  const uint8_t* last_gray = nullptr; int last_stride = 0; size_t last_istride = 0;
+  bool fuse1a = true;      // conv1a fused into conv1b's staging (D2FE_FUSE1A=0 keeps the stand-alone conv1a kernel)
   // matcher scratch
   std::mutex match_mu;
   void* m_buf = nullptr;
@@ -156,18 +158,24 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
                    float* d_kps, float* d_scores, float* d_desc, int32_t* d_idx, int cap, int32_t* d_n, hipStream_t s) {
   const int prec = h->cfg.precision;
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8;
-  { ProfScope ps(h, D2FE_PROF_CONV1A, s); HIP_TRY(launch_conv1a(d_gray, stride, (long)image_stride, H, W, n, h->w1a, h->b1a, h->a1a.p, s)); }
   auto conv = [&](ConvShape shape, const Layer& L, const float* in, int ics, int ico, long iis, float* out, int ocs,
                   long ois, int hh, int ww, bool pool, bool relu) -> hipError_t {
     ConvArgs a;
     a.in = in; a.in_cstride = ics; a.in_coff = ico;
     a.out = out; a.out_cstride = ocs; a.out_coff = 0;
     a.cout_real = L.cout; a.wpack = L.wpack; a.bias = L.bias;
+    a.img = d_gray; a.img_stride = stride; a.img_istride = (long)image_stride; a.w1a = h->w1a; a.b1a = h->b1a;
     a.H = hh; a.W = ww; a.n_img = n; a.in_img_stride = iis; a.out_img_stride = ois;
     { static int ab = -1; if (ab < 0) { const char* e = getenv("D2FE_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
     return launch_conv(shape, prec, pool, relu, L.cout_pad, a, s);
   };
-  { ProfScope ps(h, D2FE_PROF_CONV1B, s); HIP_TRY(conv(CONV_64_T8x32, h->L[L_1B], h->a1a.p, 64, 0, (long)H * W * 64, h->a1b.p, 64, (long)H2 * W2 * 64, H, W, true, true)); }
+  if (h->fuse1a) {
+    ProfScope ps(h, D2FE_PROF_CONV1B, s);
+    HIP_TRY(conv(CONV1B_FUSED, h->L[L_1B], nullptr, 64, 0, 0, h->a1b.p, 64, (long)H2 * W2 * 64, H, W, true, true));
+  } else {
+    { ProfScope ps(h, D2FE_PROF_CONV1A, s); HIP_TRY(launch_conv1a(d_gray, stride, (long)image_stride, H, W, n, h->w1a, h->b1a, h->a1a.p, s)); }
+    { ProfScope ps(h, D2FE_PROF_CONV1B, s); HIP_TRY(conv(CONV_64_T8x32, h->L[L_1B], h->a1a.p, 64, 0, (long)H * W * 64, h->a1b.p, 64, (long)H2 * W2 * 64, H, W, true, true)); }
+  }
   { ProfScope ps(h, D2FE_PROF_CONV2A, s); HIP_TRY(conv(CONV_64_T8x32, h->L[L_2A], h->a1b.p, 64, 0, (long)H2 * W2 * 64, h->a2a.p, 64, (long)H2 * W2 * 64, H2, W2, false, true)); }
   { ProfScope ps(h, D2FE_PROF_CONV2B, s); HIP_TRY(conv(CONV_64_T8x32, h->L[L_2B], h->a2a.p, 64, 0, (long)H2 * W2 * 64, h->a2b.p, 64, (long)H4 * W4 * 64, H2, W2, true, true)); }
   { ProfScope ps(h, D2FE_PROF_CONV3A, s); HIP_TRY(conv(CONV_64_T8x32, h->L[L_3A], h->a2b.p, 64, 0, (long)H4 * W4 * 64, h->a3a.p, 128, (long)H4 * W4 * 128, H4, W4, false, true)); }
@@ -186,6 +194,7 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
                           d_n, s)); }
   { ProfScope ps(h, D2FE_PROF_SAMPLE, s); HIP_TRY(launch_sample_b(h->draw.p, 256, 0, Hc, Wc, n, d_kps, d_n, cap, d_desc, s)); }
   h->last_w = W; h->last_h = H; h->last_n = n;
+  h->last_gray = d_gray; h->last_stride = stride; h->last_istride = image_stride;
   return D2FE_OK;
 }
 
@@ -239,6 +248,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   HIP_TRY(hipSetDevice(cfg->device_id));
   d2fe_context* h = new d2fe_context();
   h->cfg = *cfg;
+  { const char* e = getenv("D2FE_FUSE1A"); if (e) h->fuse1a = atoi(e) != 0; }
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   const size_t H = cfg->max_height, W = cfg->max_width;
   const int B = cfg->max_batch;
@@ -509,6 +519,11 @@ long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_byte
       {"conv2b", &h->a2b, H * W * 4},            {"conv3a", &h->a3a, H * W * 8},         {"conv3b", &h->a3b, H * W * 2},
       {"conv4a", &h->a4a, H * W * 2},            {"conv4b", &h->a4b, H * W * 2},         {"convPaDa", &h->aPD, H * W * 8},
       {"logits", &h->logits, (H / 8) * (W / 8) * 65}, {"desc_raw", &h->draw, H * W * 4}, {"semi", &h->semi, H * W}};
+  if (!strcmp(name, "conv1a") && h->fuse1a) {
+    // fused mode never materialises conv1a: evaluate it on demand from the last input frame(s)
+    if (launch_conv1a(h->last_gray, h->last_stride, (long)h->last_istride, (int)H, (int)W, (int)n, h->w1a, h->b1a, h->a1a.p, h->stream) != hipSuccess)
+      return fail(D2FE_ERR_HIP, "conv1a debug launch");
+  }
   for (auto& e : tab)
     if (!strcmp(e.nm, name)) {
       const size_t bytes = e.per * n * sizeof(float);

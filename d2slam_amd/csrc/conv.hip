@@ -27,7 +27,7 @@ constexpr int f32_min_waves(int CIN, int KS, int TH, int TW) {
   return 163840 / lds >= 3 ? 3 : (163840 / lds >= 2 ? 2 : 1);
 }
 
-template <int CIN, int KS, int TH, int TW, int WM, int WN, int MT, int NT, bool POOL, bool RELU>
+template <int CIN, int KS, int TH, int TW, int WM, int WN, int MT, int NT, bool POOL, bool RELU, bool FUSE1A = false>
 __global__ __launch_bounds__(WM * WN * 64, f32_min_waves(CIN, KS, TH, TW)) void conv_f32_kernel(ConvArgs a) {
   constexpr int P = KS / 2;
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
@@ -48,7 +48,27 @@ __global__ __launch_bounds__(WM * WN * 64, f32_min_waves(CIN, KS, TH, TW)) void 
   const int wm = wave / WN, wn = wave % WN;
 
   // ---- stage the input patch -------------------------------------------------------------------------
-  {
+  if constexpr (FUSE1A) {
+    // conv1a is evaluated on the fly for the (TH+2)x(TW+2) patch: the 78.6 MB/image conv1a activation never exists
+    static_assert(CIN == 64 && KS == 3, "fused prologue is conv1a -> conv1b");
+    const uint8_t* ip = a.img + (size_t)img * a.img_istride;
+    for (int pix = tid; pix < ((PH * PW + 63) / 64) * 64; pix += NTHREADS) {
+      const int gy = ty0 + pix / PW - P, gx = tx0 + pix % PW - P;
+      const bool inpatch = pix < PH * PW;
+      const bool valid = inpatch && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      float v[9];
+      conv1a_load_taps(ip, a.img_stride, a.H, a.W, valid ? gy : 0, valid ? gx : 0, v);
+#pragma unroll 1
+      for (int oct = 0; oct < 8; ++oct) {
+        float o[8];
+        conv1a_octet(v, a.w1a, a.b1a, oct, valid, o);
+        if (inpatch) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) patch[pix * CP + oct * 8 + c] = o[c];
+        }
+      }
+    }
+  } else {
     const float* in = a.in + (size_t)img * a.in_img_stride + a.in_coff;
     constexpr int C4 = CIN / 4;
     constexpr int TOTAL = PH * PW * C4;
@@ -183,6 +203,18 @@ static hipError_t launch_f32(bool pool, bool relu, int cout_pad, const ConvArgs&
   return hipGetLastError();
 }
 
+static hipError_t launch_f32_fused1b(int cout_pad, const ConvArgs& a, hipStream_t s) {
+  constexpr int TH = 4, TW = 32;
+  constexpr size_t lds = (size_t)(TH + 2) * (TW + 2) * 65 * sizeof(float);
+  if (cout_pad != 64) return hipErrorInvalidValue;
+  auto k = conv_f32_kernel<64, 3, TH, TW, 2, 2, 2, 1, true, true, true>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  dim3 grid(((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH), 1, a.n_img), block(256);
+  hipLaunchKernelGGL(k, grid, block, lds, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_conv_f16x2(ConvShape shape, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s);
 
 hipError_t launch_conv(ConvShape shape, int precision, bool pool, bool relu, int cout_pad, const ConvArgs& a,
@@ -195,6 +227,7 @@ hipError_t launch_conv(ConvShape shape, int precision, bool pool, bool relu, int
     case CONV_128_T4x32:     return launch_f32<128, 3, 4, 32, 2, 2, 2, 2>(pool, relu, cout_pad, a, s);
     case CONV_128_T4x16:     return launch_f32<128, 3, 4, 16, 1, 4, 2, 1>(pool, relu, cout_pad, a, s);
     case CONV_256_1x1_T4x16: return launch_f32<256, 1, 4, 16, 1, 4, 2, 1>(pool, relu, cout_pad, a, s);
+    case CONV1B_FUSED:       return launch_f32_fused1b(cout_pad, a, s);
   }
   return hipErrorInvalidValue;
 }

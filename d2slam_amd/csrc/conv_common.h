@@ -40,6 +40,32 @@ __device__ __forceinline__ void mtile_pixel(int mt, int i, int& py, int& px) {
 }
 
 
+// conv1a (1 -> 64 channels, 3x3, pad 1) + ReLU for ONE pixel, evaluated exactly as conv1a_kernel / the oracle:
+// u8 -> f32 * (1/255)  (SuperPoint::processInput, superpoint_tensorrt.cpp:185-198), chain acc0 = bias, taps in (ky,kx)
+// order.  `oct` (group of 8 output channels) is wave-uniform, so the 72 weights + 8 biases come in through scalar loads.
+__device__ __forceinline__ void conv1a_load_taps(const uint8_t* __restrict__ img, int stride, int H, int W, int gy, int gx,
+                                                 float (&v)[9]) {
+  const float scale = (float)(1.0 / 255.0);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yy = gy + ky - 1, xx = gx + kx - 1;
+      v[ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (float)img[(size_t)yy * stride + xx] * scale : 0.f;
+    }
+}
+__device__ __forceinline__ void conv1a_octet(const float (&v)[9], const float* __restrict__ w9x64,
+                                             const float* __restrict__ bias, int oct, bool valid, float (&o)[8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) o[c] = bias[oct * 8 + c];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = __builtin_fmaf(v[t], w9x64[t * 64 + oct * 8 + c], o[c]);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) o[c] = (valid && o[c] > 0.f) ? o[c] : 0.f;
+}
+
 // Epilogue: optional power-of-two rescale, ReLU, optional fused 2x2 max pool, NHWC store.
 // C layout of v_mfma_*_32x32: col = lane&31 (output channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel of the m-tile).
 // Pooling is lane-local: horizontal neighbours are registers (r, r+1), vertical neighbours are the wave's two m-tiles.

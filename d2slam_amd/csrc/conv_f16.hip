@@ -19,7 +19,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int F16_SA = 4;   // activation scale 2^4  (|x| <= 4094 representable; clamped)
 constexpr int F16_SW = 8;   // weight scale 2^8
 
-template <int CIN, int KS, int TH, int TW, int WM, int WN, int MT, int NT, bool POOL, bool RELU>
+template <int CIN, int KS, int TH, int TW, int WM, int WN, int MT, int NT, bool POOL, bool RELU, bool FUSE1A = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_f16x2_kernel(ConvArgs a) {
   constexpr int P = KS / 2;
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
@@ -43,7 +43,36 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f16x2_kernel(ConvArgs a) {
   const int wm = wave / WN, wn = wave % WN;
 
   // ---- stage + split the input patch ---------------------------------------------------------------------
-  {
+  if constexpr (FUSE1A) {
+    // conv1a evaluated on the fly (exact fp32 chain, see conv1a_octet), then scaled and split into hi/lo
+    static_assert(CIN == 64 && KS == 3, "fused prologue is conv1a -> conv1b");
+    const uint8_t* ip = a.img + (size_t)img * a.img_istride;
+    const float sa = (float)(1 << F16_SA);
+    for (int pix = tid; pix < ((NPIX + 63) / 64) * 64; pix += NTHREADS) {
+      const int gy = ty0 + pix / PW - P, gx = tx0 + pix % PW - P;
+      const bool inpatch = pix < NPIX;
+      const bool valid = inpatch && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      float v[9];
+      conv1a_load_taps(ip, a.img_stride, a.H, a.W, valid ? gy : 0, valid ? gx : 0, v);
+#pragma unroll 1
+      for (int oct = 0; oct < 8; ++oct) {
+        float o[8];
+        conv1a_octet(v, a.w1a, a.b1a, oct, valid, o);
+        f16x8 h8, l8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float x = fminf(o[c] * sa, 65000.f);
+          const _Float16 h = (_Float16)x;
+          h8[c] = h;
+          l8[c] = (_Float16)(x - (float)h);
+        }
+        if (inpatch) {
+          *reinterpret_cast<f16x8*>(hi + pix * CPH + oct * 8) = h8;
+          *reinterpret_cast<f16x8*>(lo + pix * CPH + oct * 8) = l8;
+        }
+      }
+    }
+  } else {
     const float* in = a.in + (size_t)img * a.in_img_stride + a.in_coff;
     constexpr int C4 = CIN / 4;
     constexpr int TOTAL = NPIX * C4;
@@ -189,8 +218,21 @@ static hipError_t launch_f16(bool pool, bool relu, int cout_pad, const ConvArgs&
   return hipGetLastError();
 }
 
+static hipError_t launch_f16_fused1b(int cout_pad, const ConvArgs& a, hipStream_t s) {
+  constexpr int TH = 4, TW = 32;
+  constexpr size_t lds = (size_t)(TH + 2) * (TW + 2) * 72 * sizeof(_Float16) * 2;
+  if (cout_pad != 64) return hipErrorInvalidValue;
+  auto k = conv_f16x2_kernel<64, 3, TH, TW, 2, 2, 2, 1, true, true, true>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  dim3 grid(((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH), 1, a.n_img), block(256);
+  hipLaunchKernelGGL(k, grid, block, lds, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_conv_f16x2(ConvShape shape, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s) {
   switch (shape) {
+    case CONV1B_FUSED:       return launch_f16_fused1b(cout_pad, a, s);
     case CONV_64_T8x32:
       if (tune_conv64() == 1) return launch_f16<64, 3, 4, 32, 2, 2, 2, 1>(pool, relu, cout_pad, a, s);
       return launch_f16<64, 3, 8, 32, 4, 1, 2, 2>(pool, relu, cout_pad, a, s);

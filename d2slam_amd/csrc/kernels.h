@@ -17,6 +17,8 @@ struct ConvArgs {
   int n_img;
   long in_img_stride;       // floats between images
   long out_img_stride;
+  // fused conv1a prologue (CONV1B_FUSED only): the patch is computed from the u8 frame instead of being loaded
+  const uint8_t* img; int img_stride; long img_istride; const float* w1a; const float* b1a;
   int ablate;               // experiment knob (D2FE_ABLATE): 1 skip patch loads, 2 skip B reloads, 4 skip stores
 };
 
@@ -25,6 +27,7 @@ enum ConvShape {
   CONV_128_T4x32,       // Cin 128, 3x3, tile 4x32, BN 128          (conv3b)
   CONV_128_T4x16,       // Cin 128, 3x3, tile 4x16, BN 128          (conv4a, conv4b, convPa|convDa)
   CONV_256_1x1_T4x16,   // Cin 256, 1x1, tile 4x16, BN 128          (convPb, convDb)
+  CONV1B_FUSED,         // conv1a (1->64, from the u8 frame) fused into conv1b's patch staging, + ReLU + 2x2 pool
 };
 
 // precision: 0 = fp32 exact MFMA, 1 = fp16 hi/lo split MFMA
