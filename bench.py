@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f16x2"], default=os.environ.get("D2FE_BENCH_PRECISION", "f32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--single-mode", action="store_true", help="time only --precision (default: also the other mode)")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event breakdown to stderr")
     args = ap.parse_args()
 
@@ -61,114 +62,128 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    F = args.frames
-    NI = 2 * F
     weights = synthetic_superpoint_weights(dustbin_bias=7.5)
-    prec = api.PREC_F32 if args.precision == "f32" else api.PREC_F16X2
-    cfg = api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=NI, precision=prec,
-                               device_id=local_rank)
-    fe = api.FrontEnd(cfg)
-    fe.load_superpoint(weights)
 
-    # synthetic frames, resident in HBM before the timed region: [L0, R0, L1, R1, ...]
-    host = np.empty((NI, H, W), np.uint8)
-    for f in range(F):
-        l, r = synth_stereo(H, W, seed=rank * 1000 + f)
-        host[2 * f], host[2 * f + 1] = l, r
-    imgs = torch.from_numpy(host).to(dev)
+    def run_mode(precision, want_breakdown):
+        F = args.frames
+        NI = 2 * F
+        prec = api.PREC_F32 if precision == "f32" else api.PREC_F16X2
+        cfg = api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=NI, precision=prec,
+                                   device_id=local_rank)
+        fe = api.FrontEnd(cfg)
+        fe.load_superpoint(weights)
 
-    NPOOL = swarm.pool_rows(F, world)   # current L/R | previous L | gathered remote L
-    desc = torch.zeros((NPOOL, CAP, 256), dtype=torch.float32, device=dev)
-    kps = torch.zeros((NPOOL, CAP, 2), dtype=torch.float32, device=dev)
-    cnt = torch.zeros((NPOOL,), dtype=torch.int32, device=dev)
-    scores = torch.zeros((NI, CAP), dtype=torch.float32, device=dev)
-    kidx = torch.zeros((NI, CAP), dtype=torch.int32, device=dev)
+        # synthetic frames, resident in HBM before the timed region: [L0, R0, L1, R1, ...]
+        host = np.empty((NI, H, W), np.uint8)
+        for f in range(F):
+            l, r = synth_stereo(H, W, seed=rank * 1000 + f)
+            host[2 * f], host[2 * f + 1] = l, r
+        imgs = torch.from_numpy(host).to(dev)
 
-    # pairs: (L_f, R_f), (L_f, prevL_f) and, for N>1, (L_f, remote L_f of every other rank)
-    a_rows, b_rows = swarm.build_pairs(F, world)
-    NP = len(a_rows)
-    a_rows_t = torch.tensor(a_rows, dtype=torch.int64, device=dev)
-    b_rows_t = torch.tensor(b_rows, dtype=torch.int64, device=dev)
-    a_off = (a_rows_t * CAP).to(torch.int32)
-    b_off = (b_rows_t * CAP).to(torch.int32)
-    a_cnt = torch.zeros(NP, dtype=torch.int32, device=dev)
-    b_cnt = torch.zeros(NP, dtype=torch.int32, device=dev)
-    mq = torch.zeros((NP, CAP), dtype=torch.int32, device=dev)
-    mt = torch.zeros((NP, CAP), dtype=torch.int32, device=dev)
-    md = torch.zeros((NP, CAP), dtype=torch.float32, device=dev)
-    mn = torch.zeros((NP,), dtype=torch.int32, device=dev)
-    left_rows = torch.arange(0, NI, 2, device=dev)
-    if world > 1:
-        gath_desc = torch.zeros((world, F, CAP, 256), dtype=torch.float32, device=dev)
-        gath_cnt = torch.zeros((world, F), dtype=torch.int32, device=dev)
+        NPOOL = swarm.pool_rows(F, world)   # current L/R | previous L | gathered remote L
+        desc = torch.zeros((NPOOL, CAP, 256), dtype=torch.float32, device=dev)
+        kps = torch.zeros((NPOOL, CAP, 2), dtype=torch.float32, device=dev)
+        cnt = torch.zeros((NPOOL,), dtype=torch.int32, device=dev)
+        scores = torch.zeros((NI, CAP), dtype=torch.float32, device=dev)
+        kidx = torch.zeros((NI, CAP), dtype=torch.int32, device=dev)
 
-    stream = torch.cuda.current_stream(dev).cuda_stream
-
-    def step():
-        fe.extract_device(imgs.data_ptr(), NI, W, H, kps.data_ptr(), scores.data_ptr(), desc.data_ptr(), kidx.data_ptr(),
-                          CAP, cnt.data_ptr(), stream=stream)
+        # pairs: (L_f, R_f), (L_f, prevL_f) and, for N>1, (L_f, remote L_f of every other rank)
+        a_rows, b_rows = swarm.build_pairs(F, world)
+        NP = len(a_rows)
+        a_rows_t = torch.tensor(a_rows, dtype=torch.int64, device=dev)
+        b_rows_t = torch.tensor(b_rows, dtype=torch.int64, device=dev)
+        a_off = (a_rows_t * CAP).to(torch.int32)
+        b_off = (b_rows_t * CAP).to(torch.int32)
+        a_cnt = torch.zeros(NP, dtype=torch.int32, device=dev)
+        b_cnt = torch.zeros(NP, dtype=torch.int32, device=dev)
+        mq = torch.zeros((NP, CAP), dtype=torch.int32, device=dev)
+        mt = torch.zeros((NP, CAP), dtype=torch.int32, device=dev)
+        md = torch.zeros((NP, CAP), dtype=torch.float32, device=dev)
+        mn = torch.zeros((NP,), dtype=torch.int32, device=dev)
+        left_rows = torch.arange(0, NI, 2, device=dev)
         if world > 1:
-            # cross-agent exchange: one all-gather of the fixed-capacity left-image blocks (RCCL over xGMI)
-            swarm.exchange_blocks(desc, cnt, F, rank, world, gath_desc, gath_cnt)
-        torch.index_select(cnt, 0, a_rows_t, out=a_cnt)
-        torch.index_select(cnt, 0, b_rows_t, out=b_cnt)
-        fe.match_batch_device(desc.data_ptr(), desc.data_ptr(), a_off.data_ptr(), b_off.data_ptr(), a_cnt.data_ptr(),
-                              b_cnt.data_ptr(), NP, 256, CAP, mq.data_ptr(), mt.data_ptr(), md.data_ptr(), mn.data_ptr(),
-                              mode=0, ratio=0.8, radius=-1.0, stream=stream)
-        # this step's left descriptors become the "previous keyframe" of the next step
-        desc[NI:NI + F].copy_(desc[left_rows])
-        cnt[NI:NI + F].copy_(cnt[left_rows])
+            gath_desc = torch.zeros((world, F, CAP, 256), dtype=torch.float32, device=dev)
+            gath_cnt = torch.zeros((world, F), dtype=torch.int32, device=dev)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    fe.profile_enable(1)   # HIP events around the dominant kernel only (2 event records per step)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    t1 = time.perf_counter()
-    prof = fe.profile_read()
-    fe.profile_enable(0)
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    frames_total = F * world * args.steps
-    value = frames_total / elapsed
-    ms_per_step = elapsed / args.steps * 1e3
+        def step():
+            fe.extract_device(imgs.data_ptr(), NI, W, H, kps.data_ptr(), scores.data_ptr(), desc.data_ptr(), kidx.data_ptr(),
+                              CAP, cnt.data_ptr(), stream=stream)
+            if world > 1:
+                # cross-agent exchange: one all-gather of the fixed-capacity left-image blocks (RCCL over xGMI)
+                swarm.exchange_blocks(desc, cnt, F, rank, world, gath_desc, gath_cnt)
+            torch.index_select(cnt, 0, a_rows_t, out=a_cnt)
+            torch.index_select(cnt, 0, b_rows_t, out=b_cnt)
+            fe.match_batch_device(desc.data_ptr(), desc.data_ptr(), a_off.data_ptr(), b_off.data_ptr(), a_cnt.data_ptr(),
+                                  b_cnt.data_ptr(), NP, 256, CAP, mq.data_ptr(), mt.data_ptr(), md.data_ptr(), mn.data_ptr(),
+                                  mode=0, ratio=0.8, radius=-1.0, stream=stream)
+            # this step's left descriptors become the "previous keyframe" of the next step
+            desc[NI:NI + F].copy_(desc[left_rows])
+            cnt[NI:NI + F].copy_(cnt[left_rows])
 
-    # sanity: the step really produced keypoints and matches
-    n_kp = cnt[:NI].float().mean().item()
-    n_match = mn.float().mean().item()
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
 
-    breakdown = None
-    if args.breakdown and rank == 0 and world == 1:
-        fe.profile_enable(2)
-        for _ in range(5):
+        for _ in range(args.warmup):
             step()
-        torch.cuda.synchronize(dev)
-        breakdown = {k: round(v[0] / max(v[1], 1), 4) for k, v in fe.profile_read().items() if v[1]}
+        barrier()
+        fe.profile_enable(1)   # HIP events around the dominant kernel only (2 event records per step)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        prof = fe.profile_read()
         fe.profile_enable(0)
-        print("per-stage ms (avg of 5 steps, %d images/step): %s" % (NI, json.dumps(breakdown)), file=sys.stderr)
+        elapsed = t1 - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        frames_total = F * world * args.steps
+        value = frames_total / elapsed
+        ms_per_step = elapsed / args.steps * 1e3
 
-    c1b_ms, c1b_n = prof["conv1b"]
-    avg_ms = c1b_ms / max(c1b_n, 1)
-    achieved = CONV1B_FLOP_PER_IMG * NI / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-    peak = PEAK_TFLOPS[args.precision]
-    roofline = {"kernel": "conv_%s_kernel<64,3,8,32,...,POOL> (conv1b)" % ("f32" if args.precision == "f32" else "f16x2"),
-                "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
-                "avg_launch_ms": round(avg_ms, 4), "launches": c1b_n,
-                "algorithmic_flop_per_launch": CONV1B_FLOP_PER_IMG * NI,
-                "note": "algorithmic FLOPs (2*MACs); f16x2 executes 3 MFMA FLOPs per algorithmic FLOP"}
+        # sanity: the step really produced keypoints and matches
+        n_kp = cnt[:NI].float().mean().item()
+        n_match = mn.float().mean().item()
+
+        breakdown = None
+        if want_breakdown and rank == 0 and world == 1:
+            fe.profile_enable(2)
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize(dev)
+            breakdown = {k: round(v[0] / max(v[1], 1), 4) for k, v in fe.profile_read().items() if v[1]}
+            fe.profile_enable(0)
+            print("per-stage ms (avg of 5 steps, %d images/step): %s" % (NI, json.dumps(breakdown)), file=sys.stderr)
+
+        c1b_ms, c1b_n = prof["conv1b"]
+        avg_ms = c1b_ms / max(c1b_n, 1)
+        achieved = CONV1B_FLOP_PER_IMG * NI / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        peak = PEAK_TFLOPS[precision]
+        roofline = {"kernel": "conv_%s_kernel<64,3,8,32,...,POOL> (conv1b)" % ("f32" if precision == "f32" else "f16x2"),
+                    "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": c1b_n,
+                    "algorithmic_flop_per_launch": CONV1B_FLOP_PER_IMG * NI,
+                    "note": "algorithmic FLOPs (2*MACs); f16x2 executes 3 MFMA FLOPs per algorithmic FLOP"}
+
+
+        fe.close()
+        return dict(value=value, ms_per_step=ms_per_step, roofline=roofline, n_kp=n_kp, n_match=n_match,
+                    breakdown=breakdown, NI=NI, NP=NP, F=F)
+
+    primary = run_mode(args.precision, args.breakdown)
+    other = None
+    if not args.single_mode:
+        other = run_mode("f16x2" if args.precision == "f32" else "f32", False)
+    value, ms_per_step, roofline = primary["value"], primary["ms_per_step"], primary["roofline"]
+    n_kp, n_match, breakdown, NI, NP, F = (primary[k] for k in ("n_kp", "n_match", "breakdown", "NI", "NP", "F"))
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -190,10 +205,16 @@ def main():
             "avg_keypoints_per_image": round(n_kp, 1), "avg_matches_per_pair": round(n_match, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if other is not None:
+            om = "f16x2" if args.precision == "f32" else "f32"
+            out["fast_mode" if om == "f16x2" else "exact_mode"] = {
+                "precision": om, "value": round(other["value"], 2), "unit": "stereo_frames/s",
+                "ms_per_step": round(other["ms_per_step"], 3), "roofline": other["roofline"],
+                "parity": ("descriptors <= 1e-4 (measured ~3e-7), scores <= 1e-5; keypoint indices equal except at score near-ties"
+                           if om == "f16x2" else "bitwise vs oracle (activations, scores, indices, matches)")}
         if breakdown:
             out["stage_ms"] = breakdown
         print(json.dumps(out), flush=True)
-    fe.close()
     if world > 1:
         dist.destroy_process_group()
 
