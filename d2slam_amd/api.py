@@ -37,7 +37,8 @@ class _Config(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device_id", C.c_int32), ("max_width", C.c_int32),
                 ("max_height", C.c_int32), ("max_batch", C.c_int32), ("max_keypoints", C.c_int32),
                 ("remove_borders", C.c_int32), ("keypoint_threshold", C.c_float), ("postproc", C.c_int32),
-                ("nms_dist", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("nms_dist", C.c_int32), ("precision", C.c_int32), ("keep_score_map", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
 
 
 class _ConvParams(C.Structure):
@@ -137,6 +138,7 @@ class SuperPointConfig:
     postproc: int = POSTPROC_B
     nms_dist: int = 10
     precision: int = PREC_F32
+    keep_score_map: bool = False   # debug: also write the dense score map
 
 
 class FrontEnd:
@@ -156,6 +158,7 @@ class FrontEnd:
         c.postproc = cfg.postproc
         c.nms_dist = cfg.nms_dist
         c.precision = cfg.precision
+        c.keep_score_map = int(cfg.keep_score_map)
         self.cfg = cfg
         self._h = C.c_void_p()
         _check(lib.d2fe_create(C.byref(c), C.byref(self._h)))

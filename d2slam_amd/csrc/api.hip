@@ -187,7 +187,8 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
   { ProfScope ps(h, D2FE_PROF_CONVDB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_DB], h->aPD.p, 512, 256, (long)Hc * Wc * 512, h->draw.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, false)); }
   if (h->cfg.postproc != D2FE_POSTPROC_B) return fail(D2FE_ERR_UNSUPPORTED, "postproc variant A not available in this build");
   { ProfScope ps(h, D2FE_PROF_SOFTMAX, s);
-  HIP_TRY(launch_softmax_cand(h->logits.p, 65, Hc, Wc, n, h->cfg.keypoint_threshold, h->cfg.remove_borders, h->semi.p,
+  HIP_TRY(launch_softmax_cand(h->logits.p, 65, Hc, Wc, n, h->cfg.keypoint_threshold, h->cfg.remove_borders,
+                              h->cfg.keep_score_map ? h->semi.p : nullptr,
                               h->cand, h->cand_count, h->cand_cap, s)); }
   { ProfScope ps(h, D2FE_PROF_SELECT, s);
   HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, W, h->cfg.max_keypoints, cap, d_kps, d_scores, d_idx,
@@ -524,6 +525,7 @@ long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_byte
     if (launch_conv1a(h->last_gray, h->last_stride, (long)h->last_istride, (int)H, (int)W, (int)n, h->w1a, h->b1a, h->a1a.p, h->stream) != hipSuccess)
       return fail(D2FE_ERR_HIP, "conv1a debug launch");
   }
+  if (!strcmp(name, "semi") && !h->cfg.keep_score_map) return fail(D2FE_ERR_NOT_READY, "score map not kept (set keep_score_map)");
   for (auto& e : tab)
     if (!strcmp(e.nm, name)) {
       const size_t bytes = e.per * n * sizeof(float);

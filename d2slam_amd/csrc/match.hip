@@ -41,6 +41,30 @@ __device__ __forceinline__ void cand_insert(Cand (&top)[4], float d, int i) {
   }
 }
 
+// exact distance of one (q, t) row pair with 16 lanes: lane slot s accumulates elements j = 16*i + s
+// (slot s = 4*v + l of OpenCV's four 4-lane accumulators), then the oracle's reduction order.
+__device__ __forceinline__ float exact_dist16(const float* __restrict__ q, const float* __restrict__ t, int dim, int slot,
+                                              int lane) {
+  float acc = 0.f;
+  const int nfull = dim & ~15;
+  for (int j = slot; j < nfull; j += 16) {
+    const float d = q[j] - t[j];
+    const float dd = d * d;
+    acc = acc + dd;
+  }
+  // r[l] = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l]   with slot = 4*v + l
+  const int base = lane & ~15;
+  const int l = slot & 3;
+  const float a0 = __shfl(acc, base + 0 + l, 64), a1 = __shfl(acc, base + 4 + l, 64);
+  const float a2 = __shfl(acc, base + 8 + l, 64), a3 = __shfl(acc, base + 12 + l, 64);
+  const float r = ((a0 + a1) + a2) + a3;  // valid in every lane for its l
+  const float r0 = __shfl(r, base + 0, 64), r1 = __shfl(r, base + 1, 64);
+  const float r2 = __shfl(r, base + 2, 64), r3 = __shfl(r, base + 3, 64);
+  float d = (r0 + r2) + (r1 + r3);
+  for (int j = nfull; j < dim; ++j) { const float e = q[j] - t[j]; d += e * e; }
+  return __builtin_sqrtf(d);
+}
+
 __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;                       // [MQ][QS]
@@ -139,6 +163,8 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
     for (int k = 0; k < 4; ++k) merge[(wave * MQ + lane) * 4 + k] = top[k];
   }
   __syncthreads();
+  int* mcand = reinterpret_cast<int*>(Ts);          // [MQ][4] candidate indices (the train chunk buffer is free now)
+  float* mdist = reinterpret_cast<float*>(Ts) + MQ * 4;  // [MQ][4] exact distances
   if (wave == 0 && lane < 32) {
     for (int w = 1; w < 4; ++w)
 #pragma unroll
@@ -146,36 +172,34 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
         const Cand c = merge[(w * MQ + lane) * 4 + k];
         cand_insert(top, c.d, c.i);
       }
-    if (q0 + lane < nq) {
-      int32_t* out = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + q0 + lane) * 4;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) out[k] = top[k].i == 0x7FFFFFFF ? -1 : top[k].i;
+    for (int k = 0; k < 4; ++k) mcand[lane * 4 + k] = top[k].i == 0x7FFFFFFF ? -1 : top[k].i;
+  }
+  __syncthreads();
+  // exact re-rank: every (query, candidate) distance re-evaluated in the oracle's order, 16 lanes per pair
+  for (int r = 0; r < (MQ * 4 * 16) / 256; ++r) {
+    const int pr = r * 16 + (tid >> 4);
+    const int q = pr >> 2;
+    const int ci = mcand[pr];
+    const float* trow = T + (size_t)(ci >= 0 ? ci : 0) * dim;
+    const float dd = exact_dist16(Qs + q * QS, trow, dim, tid & 15, lane);
+    if ((tid & 15) == 0) mdist[pr] = ci >= 0 ? dd : __builtin_inff();
+  }
+  __syncthreads();
+  if (tid < MQ && q0 + tid < nq) {
+    float bd0 = __builtin_inff(), bd1 = __builtin_inff();
+    int bi0 = -1, bi1 = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dk = mdist[tid * 4 + k];
+      const int ik = mcand[tid * 4 + k];
+      if (ik < 0) continue;
+      if (dk < bd0 || (dk == bd0 && ik < bi0)) { bd1 = bd0; bi1 = bi0; bd0 = dk; bi0 = ik; }
+      else if (dk < bd1 || (dk == bd1 && ik < bi1)) { bd1 = dk; bi1 = ik; }
     }
+    int32_t* out = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + q0 + tid) * 4;   // {nn index, d0 bits, d1 bits, -}
+    out[0] = bi0; out[1] = __float_as_int(bd0); out[2] = __float_as_int(bd1);
   }
-}
-
-// exact distance of one (q, t) row pair with 16 lanes: lane slot s accumulates elements j = 16*i + s
-// (slot s = 4*v + l of OpenCV's four 4-lane accumulators), then the oracle's reduction order.
-__device__ __forceinline__ float exact_dist16(const float* __restrict__ q, const float* __restrict__ t, int dim, int slot,
-                                              int lane) {
-  float acc = 0.f;
-  const int nfull = dim & ~15;
-  for (int j = slot; j < nfull; j += 16) {
-    const float d = q[j] - t[j];
-    const float dd = d * d;
-    acc = acc + dd;
-  }
-  // r[l] = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l]   with slot = 4*v + l
-  const int base = lane & ~15;
-  const int l = slot & 3;
-  const float a0 = __shfl(acc, base + 0 + l, 64), a1 = __shfl(acc, base + 4 + l, 64);
-  const float a2 = __shfl(acc, base + 8 + l, 64), a3 = __shfl(acc, base + 12 + l, 64);
-  const float r = ((a0 + a1) + a2) + a3;  // valid in every lane for its l
-  const float r0 = __shfl(r, base + 0, 64), r1 = __shfl(r, base + 1, 64);
-  const float r2 = __shfl(r, base + 2, 64), r3 = __shfl(r, base + 3, 64);
-  float d = (r0 + r2) + (r1 + r3);
-  for (int j = nfull; j < dim; ++j) { const float e = q[j] - t[j]; d += e * e; }
-  return __builtin_sqrtf(d);
 }
 
 constexpr int FIN_THREADS = 1024;
@@ -190,38 +214,13 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(MatchArgs m
   const int pair = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int na = min(m.a_cnt[pair], m.max_n), nb = min(m.b_cnt[pair], m.max_n);
-  const float* A = m.a + (size_t)m.a_off[pair] * m.dim;
-  const float* B = m.b + (size_t)m.b_off[pair] * m.dim;
-  const int dim = m.dim;
-
-  // phase 1: exact 2-NN among the prefiltered candidates; one wave per row, 16 lanes per candidate
-  for (int task = wave; task < na + nb; task += FIN_THREADS / 64) {
+  // phase 1: exact 2-NN (index, d0, d1) of every row of both directions, computed by the prefilter blocks
+  for (int task = tid; task < na + nb; task += FIN_THREADS) {
     const int dir = task < na ? 0 : 1;
     const int row = dir == 0 ? task : task - na;
-    const float* q = (dir == 0 ? A : B) + (size_t)row * dim;
-    const float* Tm = dir == 0 ? B : A;
     const int32_t* c4 = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + row) * 4;
-    const int ci = c4[lane >> 4];
-    float d = __builtin_inff();
-    // all lanes must run the shuffles: use row 0 as a dummy when the candidate is missing
-    const float* t = Tm + (size_t)(ci >= 0 ? ci : 0) * dim;
-    const float dd = exact_dist16(q, t, dim, lane & 15, lane);
-    if (ci >= 0) d = dd;
-    // gather the four (d, idx) and pick the best two: ascending distance, ties -> lower index
-    float bd0 = __builtin_inff(), bd1 = __builtin_inff();
-    int bi0 = -1, bi1 = -1;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float dk = __shfl(d, k * 16, 64);
-      const int ik = __shfl(ci, k * 16, 64);
-      if (ik < 0) continue;
-      if (dk < bd0 || (dk == bd0 && ik < bi0)) { bd1 = bd0; bi1 = bi0; bd0 = dk; bi0 = ik; }
-      else if (dk < bd1 || (dk == bd1 && ik < bi1)) { bd1 = dk; bi1 = ik; }
-    }
-    if (lane == 0) {
-      if (dir == 0) { f0[row] = bi0; fd0[row] = bd0; fd1[row] = bd1; }
-      else { g0[row] = bi0; gd0[row] = bd0; gd1[row] = bd1; }
-    }
+    if (dir == 0) { f0[row] = c4[0]; fd0[row] = __int_as_float(c4[1]); fd1[row] = __int_as_float(c4[2]); }
+    else { g0[row] = c4[0]; gd0[row] = __int_as_float(c4[1]); gd1[row] = __int_as_float(c4[2]); }
   }
   __syncthreads();
   // phase 2: inverse dictionary (feature_matcher.cpp:16-25)

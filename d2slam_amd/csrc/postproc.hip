@@ -53,8 +53,8 @@ __global__ __launch_bounds__(64) void softmax_cand_kernel(const float* __restric
     sl[c * 65 + k] = lg[(size_t)c * lstride + k];
   }
   __syncthreads();
-  if (tid >= nvalid) return;
-  const float* l = sl + tid * 65;  // stride 65 floats: conflict-free across the wave
+  const bool live = tid < nvalid;
+  const float* l = sl + (live ? tid : 0) * 65;  // stride 65 floats: conflict-free across the wave
   float m = l[0];
   for (int c = 1; c < 65; ++c) m = l[c] > m ? l[c] : m;
   float e[65];
@@ -68,16 +68,37 @@ __global__ __launch_bounds__(64) void softmax_cand_kernel(const float* __restric
   const int cy = cell / Wc, cx = cell % Wc;
   const int W = Wc * 8, H = Hc * 8;
   unsigned long long* cd = cand + (size_t)img * cand_cap;
+  // pass 1: scores, optional dense store, per-thread candidate count
+  int mine = 0;
+  unsigned long long pass_mask = 0;
 #pragma unroll
   for (int c = 0; c < 64; ++c) {
     const float p = e[c] / s;
+    e[c] = p;
     const int y = cy * 8 + (c >> 3), x = cx * 8 + (c & 7);
-    const int idx = y * W + x;
-    if (semi) semi[(size_t)img * H * W + idx] = p;
-    if (p > thr && y >= border && y < H - border && x >= border && x < W - border) {
-      const int slot = atomicAdd(cand_count + img, 1);
+    if (semi && live) semi[(size_t)img * H * W + y * W + x] = p;
+    if (live && p > thr && y >= border && y < H - border && x >= border && x < W - border) { ++mine; pass_mask |= 1ull << c; }
+  }
+  // one reservation per wave: exclusive prefix of the per-lane counts, a single atomic for the wave's total
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (tid >= o) incl += t;
+  }
+  const int total = __shfl(incl, 63, 64);
+  int base = 0;
+  if (tid == 0 && total > 0) base = atomicAdd(cand_count + img, total);
+  base = __shfl(base, 0, 64);
+  int slot = base + incl - mine;
+#pragma unroll
+  for (int c = 0; c < 64; ++c) {
+    if (pass_mask & (1ull << c)) {
+      const int y = cy * 8 + (c >> 3), x = cx * 8 + (c & 7);
+      const unsigned idx = (unsigned)(y * W + x);
       if (slot < cand_cap)
-        cd[slot] = ((unsigned long long)__float_as_uint(p) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
+        cd[slot] = ((unsigned long long)__float_as_uint(e[c]) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+      ++slot;
     }
   }
 }
@@ -142,12 +163,15 @@ __global__ __launch_bounds__(SEL_THREADS) void select_b_kernel(const unsigned lo
         }
         s_digit = d;
         s_need = need - acc;
+        s_cnt = (K - need) + acc + hist[d];   // keys >= the prefix chosen so far
       }
       __syncthreads();
       prefix |= ((unsigned long long)s_digit) << shift;
       mask |= 0xFFull << shift;
       need = s_need;
+      const int above = s_cnt;
       __syncthreads();
+      if (above <= SEL_MAXK) break;   // all of them fit in LDS: sort them there and keep the first K
     }
     thresh = prefix;  // exactly K keys are >= thresh (keys are unique)
     nk = K;

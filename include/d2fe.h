@@ -60,7 +60,9 @@ typedef struct {
   int32_t postproc;           /* d2fe_postproc */
   int32_t nms_dist;           /* variant A: NMS2 dist_thresh (SuperPointONNX::nms_dist) */
   int32_t precision;          /* d2fe_precision */
-  int32_t reserved[8];
+  int32_t keep_score_map;     /* 1: also write the dense H x W score map ("semi", 1.2 MB/image) for d2fe_debug_read;
+                                 variant B does not need it (candidates are emitted by the softmax kernel) */
+  int32_t reserved[7];
 } d2fe_config;
 
 /* One conv layer in PyTorch layout: weight [cout][cin][k][k], bias [cout]. */

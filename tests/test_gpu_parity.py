@@ -21,7 +21,7 @@ def api():
 
 def _fe(api, H, W, n, prec, max_kp=200, thr=0.015):
     fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=max_kp, input_width=W, input_height=H, max_batch=n, precision=prec,
-                                           keypoint_threshold=thr))
+                                           keypoint_threshold=thr, keep_score_map=True))
     return fe
 
 

@@ -17,7 +17,7 @@ def run(H, W, prec, n=2):
     print("== size %dx%d precision %d" % (H, W, prec), flush=True)
     w = synthetic_superpoint_weights(dustbin_bias=7.5)
     imgs = np.stack([synth_image(H, W, s) for s in range(n)])
-    cfg = api.SuperPointConfig(max_keypoints=200, input_width=W, input_height=H, max_batch=n, precision=prec)
+    cfg = api.SuperPointConfig(max_keypoints=200, input_width=W, input_height=H, max_batch=n, precision=prec, keep_score_map=True)
     fe = api.FrontEnd(cfg); fe.load_superpoint(w)
     t = time.time(); res = fe.extract_batch(imgs, cap=200); print("  extract wall %.3fs" % (time.time() - t))
     refs = [orc.superpoint_forward(imgs[i], w, return_trunk=True) for i in range(n)]
