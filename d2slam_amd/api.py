@@ -61,7 +61,7 @@ class _MatchBatch(C.Structure):
 _lib = None
 
 EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_create", "d2fe_destroy",
-           "d2fe_load_superpoint", "d2fe_superpoint_extract", "d2fe_superpoint_extract_batch",
+           "d2fe_load_superpoint", "d2fe_set_superpoint_pca", "d2fe_desc_dim", "d2fe_superpoint_extract", "d2fe_superpoint_extract_batch",
            "d2fe_superpoint_extract_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device",
            "d2fe_half_image_filter", "d2fe_debug_read", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read"]
 
@@ -98,6 +98,8 @@ def load_library():
         lib.d2fe_destroy.argtypes = [C.c_void_p]
         lib.d2fe_load_superpoint.argtypes = [C.c_void_p, C.c_void_p]
         lib.d2fe_sync.argtypes = [C.c_void_p]
+        lib.d2fe_set_superpoint_pca.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        lib.d2fe_desc_dim.argtypes = [C.c_void_p]
         lib.d2fe_profile_enable.argtypes = [C.c_void_p, C.c_int]
         lib.d2fe_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
@@ -193,6 +195,18 @@ class FrontEnd:
             sw.layer[i].cout, sw.layer[i].cin, sw.layer[i].ksize = W.shape[0], W.shape[1], W.shape[2]
         _check(self._lib.d2fe_load_superpoint(self._h, C.byref(sw)))
 
+    def set_pca(self, comp, mean):
+        """comp [pca_dims,256] (CSV layout of superpoint_onnx.cpp:47-53), mean [256]; variant A only."""
+        if comp is None:
+            _check(self._lib.d2fe_set_superpoint_pca(self._h, None, None, 0))
+            return
+        comp = np.ascontiguousarray(comp, np.float32); mean = np.ascontiguousarray(mean, np.float32)
+        _check(self._lib.d2fe_set_superpoint_pca(self._h, _ptr(comp), _ptr(mean), comp.shape[0]))
+
+    @property
+    def desc_dim(self):
+        return int(self._lib.d2fe_desc_dim(self._h))
+
     # ---- extractor ---------------------------------------------------------------------------------------------
     def extract_batch(self, images, cap=None):
         """images: u8 [n,H,W].  Returns list of (kps [k,2], scores [k], desc [k,256])."""
@@ -202,7 +216,7 @@ class FrontEnd:
         n, H, W = images.shape
         cap = cap or self.cfg.max_keypoints
         kps = np.zeros((n, cap, 2), np.float32); sc = np.zeros((n, cap), np.float32)
-        desc = np.zeros((n, cap, 256), np.float32); cnt = np.zeros(n, np.int32)
+        desc = np.zeros((n, cap, self.desc_dim), np.float32); cnt = np.zeros(n, np.int32)
         _check(self._lib.d2fe_superpoint_extract_batch(self._h, _ptr(images), n, W, H, W, H * W, _ptr(kps), _ptr(sc),
                                                        _ptr(desc), cap, _ptr(cnt)))
         return [(kps[i, :cnt[i]].copy(), sc[i, :cnt[i]].copy(), desc[i, :cnt[i]].copy()) for i in range(n)]

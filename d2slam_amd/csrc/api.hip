@@ -68,6 +68,8 @@ struct d2fe_context {
   // last call geometry (for debug reads)
   int last_w = 0, last_h = 0, last_n = 0;
   const uint8_t* last_gray = nullptr; int last_stride = 0; size_t last_istride = 0;
+  float* aconf = nullptr; int* clist = nullptr;     // variant A scratch
+  float* pca_comp_t = nullptr; float* pca_mean = nullptr; int pca_dims = 0;
   bool fuse1a = true;      // conv1a fused into conv1b's staging (D2FE_FUSE1A=0 keeps the stand-alone conv1a kernel)
   // matcher scratch
   std::mutex match_mu;
@@ -185,15 +187,29 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
   { ProfScope ps(h, D2FE_PROF_CONVPADA, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_PADA], h->a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 512, (long)Hc * Wc * 512, Hc, Wc, false, true)); }
   { ProfScope ps(h, D2FE_PROF_CONVPB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_PB], h->aPD.p, 512, 0, (long)Hc * Wc * 512, h->logits.p, 65, (long)Hc * Wc * 65, Hc, Wc, false, false)); }
   { ProfScope ps(h, D2FE_PROF_CONVDB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_DB], h->aPD.p, 512, 256, (long)Hc * Wc * 512, h->draw.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, false)); }
-  if (h->cfg.postproc != D2FE_POSTPROC_B) return fail(D2FE_ERR_UNSUPPORTED, "postproc variant A not available in this build");
+  const bool varA = h->cfg.postproc == D2FE_POSTPROC_A;
   { ProfScope ps(h, D2FE_PROF_SOFTMAX, s);
   HIP_TRY(launch_softmax_cand(h->logits.p, 65, Hc, Wc, n, h->cfg.keypoint_threshold, h->cfg.remove_borders,
-                              h->cfg.keep_score_map ? h->semi.p : nullptr,
-                              h->cand, h->cand_count, h->cand_cap, s)); }
-  { ProfScope ps(h, D2FE_PROF_SELECT, s);
-  HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, W, h->cfg.max_keypoints, cap, d_kps, d_scores, d_idx,
-                          d_n, s)); }
-  { ProfScope ps(h, D2FE_PROF_SAMPLE, s); HIP_TRY(launch_sample_b(h->draw.p, 256, 0, Hc, Wc, n, d_kps, d_n, cap, d_desc, s)); }
+                              (h->cfg.keep_score_map || varA) ? h->semi.p : nullptr,
+                              h->cand, h->cand_count, varA ? 0 : h->cand_cap, s)); }
+  if (varA) {
+    // getKeyPoints + NMS2 (superpoint_common.cpp:12-40,107-177): border = 0, sorted by confidence, max_num
+    ProfScope ps(h, D2FE_PROF_SELECT, s);
+    HIP_TRY(launch_nms2_a(h->semi.p, H, W, n, h->cfg.keypoint_threshold, h->cfg.nms_dist, h->aconf, h->clist, h->cand,
+                          h->cand_count, h->cand_cap, s));
+    HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, W, h->cfg.max_keypoints, cap, 1, d_kps, d_scores, d_idx,
+                            d_n, s));
+  } else {
+    ProfScope ps(h, D2FE_PROF_SELECT, s);
+    HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, W, h->cfg.max_keypoints, cap, 0, d_kps, d_scores, d_idx,
+                            d_n, s));
+  }
+  { ProfScope ps(h, D2FE_PROF_SAMPLE, s);
+    if (varA)
+      HIP_TRY(launch_sample_a(h->draw.p, 256, 0, Hc, Wc, W, H, n, d_kps, d_n, cap, h->pca_dims ? h->pca_comp_t : nullptr,
+                              h->pca_mean, h->pca_dims, d_desc, s));
+    else
+      HIP_TRY(launch_sample_b(h->draw.p, 256, 0, Hc, Wc, n, d_kps, d_n, cap, d_desc, s)); }
   h->last_w = W; h->last_h = H; h->last_n = n;
   h->last_gray = d_gray; h->last_stride = stride; h->last_istride = image_stride;
   return D2FE_OK;
@@ -270,6 +286,10 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   h->cand_cap = (long)(H * W);
   HIP_TRY(hipMalloc(&h->cand, sizeof(unsigned long long) * h->cand_cap * B));
   HIP_TRY(hipMalloc(&h->cand_count, sizeof(int) * B));
+  if (cfg->postproc == D2FE_POSTPROC_A) {
+    HIP_TRY(hipMalloc(&h->aconf, sizeof(float) * H * W * B));
+    HIP_TRY(hipMalloc(&h->clist, sizeof(int) * H * W * B));
+  }
   h->s_cap = 1024;
   HIP_TRY(hipMalloc(&h->s_img, H * W * B));
   HIP_TRY(hipMalloc(&h->s_kps, sizeof(float) * 2 * h->s_cap * B));
@@ -289,7 +309,8 @@ void d2fe_destroy(d2fe_handle h) {
     if (t->p) hipFree(t->p);
   for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
   for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->cand_count, (void*)h->s_img, (void*)h->s_kps,
-                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, h->m_buf, (void*)h->m_cand4})
+                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, h->m_buf, (void*)h->m_cand4, (void*)h->aconf, (void*)h->clist,
+                  (void*)h->pca_comp_t, (void*)h->pca_mean})
     if (p) hipFree(p);
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -337,6 +358,33 @@ int d2fe_load_superpoint(d2fe_handle h, const d2fe_superpoint_weights* w) {
   return D2FE_OK;
 }
 
+int d2fe_set_superpoint_pca(d2fe_handle h, const float* comp, const float* mean, int pca_dims) {
+  if (!h) return fail(D2FE_ERR_INVALID, "null handle");
+  if (pca_dims < 0 || pca_dims > 256 || (pca_dims > 0 && (!comp || !mean))) return fail(D2FE_ERR_INVALID, "bad PCA arguments");
+  if (pca_dims > 0 && h->cfg.postproc != D2FE_POSTPROC_A)
+    return fail(D2FE_ERR_UNSUPPORTED, "PCA is only applied by post-processing variant A (the reference's variant B never applies it)");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->pca_comp_t) { hipFree(h->pca_comp_t); h->pca_comp_t = nullptr; }
+  if (h->pca_mean) { hipFree(h->pca_mean); h->pca_mean = nullptr; }
+  h->pca_dims = 0;
+  if (pca_dims == 0) return D2FE_OK;
+  std::vector<float> t((size_t)256 * pca_dims);
+  for (int j = 0; j < pca_dims; ++j)
+    for (int c = 0; c < 256; ++c) t[(size_t)c * pca_dims + j] = comp[(size_t)j * 256 + c];
+  int rc = upload(t.data(), t.size() * sizeof(float), reinterpret_cast<void**>(&h->pca_comp_t));
+  if (rc) return rc;
+  rc = upload(mean, 256 * sizeof(float), reinterpret_cast<void**>(&h->pca_mean));
+  if (rc) return rc;
+  h->pca_dims = pca_dims;
+  return D2FE_OK;
+}
+
+int d2fe_desc_dim(d2fe_handle h) {
+  if (!h) return fail(D2FE_ERR_INVALID, "null handle");
+  return (h->cfg.postproc == D2FE_POSTPROC_A && h->pca_dims) ? h->pca_dims : 256;
+}
+
 int d2fe_superpoint_extract_device(d2fe_handle h, const uint8_t* d_gray, int n, int width, int height, int stride,
                                    size_t image_stride, float* d_kps_xy, float* d_scores, float* d_desc,
                                    int32_t* d_kps_idx, int cap, int32_t* d_n_out, void* stream) {
@@ -370,6 +418,7 @@ int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int
                       h->s_idx, dcap, h->s_n, s);
   if (rc) return rc;
   std::vector<int32_t> cnt(n);
+  const size_t D = (h->cfg.postproc == D2FE_POSTPROC_A && h->pca_dims) ? (size_t)h->pca_dims : 256;
   HIP_TRY(hipMemcpyAsync(cnt.data(), h->s_n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   for (int i = 0; i < n; ++i) {
@@ -378,7 +427,7 @@ int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int
     if (k > 0) {
       HIP_TRY(hipMemcpyAsync(kps_xy + (size_t)i * cap * 2, h->s_kps + (size_t)i * dcap * 2, sizeof(float) * 2 * k, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipMemcpyAsync(scores + (size_t)i * cap, h->s_scores + (size_t)i * dcap, sizeof(float) * k, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipMemcpyAsync(desc + (size_t)i * cap * 256, h->s_desc + (size_t)i * dcap * 256, sizeof(float) * 256 * k, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(desc + (size_t)i * cap * D, h->s_desc + (size_t)i * dcap * D, sizeof(float) * D * k, hipMemcpyDeviceToHost, s));
     }
   }
   HIP_TRY(hipStreamSynchronize(s));

@@ -52,11 +52,18 @@ hipError_t launch_softmax_cand(const float* logits, int lstride, int Hc, int Wc,
                                hipStream_t s);
 // exact top-K (score desc, raster asc) / raster-ordered pass-through when count <= K (variant B).
 hipError_t launch_select_b(const unsigned long long* cand, const int* cand_count, long cand_cap, int n_img, int W,
-                           int max_kp, int cap, float* kps_xy, float* scores, int32_t* kps_idx, int32_t* n_out,
-                           hipStream_t s);
+                           int max_kp, int cap, int always_sort, float* kps_xy, float* scores, int32_t* kps_idx,
+                           int32_t* n_out, hipStream_t s);
 // variant-B descriptor sampling (normalize_keypoints + grid_sample + normalize_descriptors).
 hipError_t launch_sample_b(const float* desc_raw, int dstride, int dcoff, int Hc, int Wc, int n_img, const float* kps_xy,
                            const int32_t* n_kp, int cap, float* desc_out, hipStream_t s);
+
+// variant A (SuperPointONNX path): NMS2-exact and grid_sampler(align_corners=false) sampling with optional PCA
+hipError_t launch_nms2_a(const float* semi, int H, int W, int n_img, float thr, int dist, float* aconf, int* clist,
+                         unsigned long long* cand, int* cand_count, long cand_cap, hipStream_t s);
+hipError_t launch_sample_a(const float* desc_raw, int dstride, int dcoff, int Hc, int Wc, int img_w, int img_h, int n_img,
+                           const float* kps_xy, const int32_t* n_kp, int cap, const float* comp_t, const float* mean,
+                           int pca_dims, float* desc_out, hipStream_t s);
 
 // ---- matcher --------------------------------------------------------------------------------------
 struct MatchArgs {

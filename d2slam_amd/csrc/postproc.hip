@@ -124,7 +124,8 @@ constexpr int SEL_MAXK = 1024;
 
 __global__ __launch_bounds__(SEL_THREADS) void select_b_kernel(const unsigned long long* __restrict__ cand,
                                                                const int* __restrict__ cand_count, long cand_cap,
-                                                               int W, int max_kp, int cap, float* __restrict__ kps_xy,
+                                                               int W, int max_kp, int cap, int always_sort,
+                                                               float* __restrict__ kps_xy,
                                                                float* __restrict__ scores, int32_t* __restrict__ kps_idx,
                                                                int32_t* __restrict__ n_out) {
   __shared__ unsigned long long keys[SEL_MAXK];
@@ -137,12 +138,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_b_kernel(const unsigned lo
   if (n > cand_cap) n = cand_cap;
   int K = (max_kp < 0) ? cap : min(max_kp, cap);
   if (K > SEL_MAXK) K = SEL_MAXK;
-  const bool take_all = (n <= K);
+  const bool take_all = (n <= K) && !always_sort;   // variant A sorts by confidence even when everything is kept
   // When everything is kept the output order is raster (the reference does not sort): sort on the low word
   // (0xFFFFFFFF - idx, descending == idx ascending) and let the score bits ride along in the low half.
   unsigned long long thresh = 0;  // keep keys >= thresh
-  int nk = (int)n;
-  if (!take_all) {
+  int nk = (int)(n < K ? n : K);
+  if (!take_all && n > K) {
     // radix select: find the K-th largest key
     unsigned long long prefix = 0, mask = 0;
     int need = K;
@@ -173,8 +174,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_b_kernel(const unsigned lo
       __syncthreads();
       if (above <= SEL_MAXK) break;   // all of them fit in LDS: sort them there and keep the first K
     }
-    thresh = prefix;  // exactly K keys are >= thresh (keys are unique)
-    nk = K;
+    thresh = prefix;  // at least K (and <= SEL_MAXK) keys are >= thresh; the sort below keeps the first K
   }
   // gather survivors into LDS
   if (tid == 0) s_cnt = 0;
@@ -214,10 +214,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_b_kernel(const unsigned lo
 }
 
 hipError_t launch_select_b(const unsigned long long* cand, const int* cand_count, long cand_cap, int n_img, int W,
-                           int max_kp, int cap, float* kps_xy, float* scores, int32_t* kps_idx, int32_t* n_out,
+                           int max_kp, int cap, int always_sort, float* kps_xy, float* scores, int32_t* kps_idx, int32_t* n_out,
                            hipStream_t s) {
   hipLaunchKernelGGL(select_b_kernel, dim3(n_img), dim3(SEL_THREADS), 0, s, cand, cand_count, cand_cap, W, max_kp, cap,
-                     kps_xy, scores, kps_idx, n_out);
+                     always_sort, kps_xy, scores, kps_idx, n_out);
   return hipGetLastError();
 }
 
@@ -295,6 +295,172 @@ hipError_t launch_sample_b(const float* desc_raw, int dstride, int dcoff, int Hc
                            const int32_t* n_kp, int cap, float* desc_out, hipStream_t s) {
   dim3 grid((cap + 3) / 4, n_img), block(256);
   hipLaunchKernelGGL(sample_b_kernel, grid, block, 0, s, desc_raw, dstride, dcoff, Hc, Wc, kps_xy, n_kp, cap, desc_out);
+  return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Variant A: getKeyPoints + NMS2 (d2frontend/src/CNN/superpoint_common.cpp:12-40,107-177).
+// NMS2 is a SEQUENTIAL raster-order sweep, not greedy score-ordered NMS.  Its result is the unique
+// solution of   active(P)  <=> no raster-earlier active Q within Chebyshev distance d with conf(Q) > conf(P)
+//               survive(P) <=> active(P) and no raster-later active R within d with conf(R) > conf(P)
+// (well-founded recursion over raster order), so it can be reached by chaotic in-place iteration from any start:
+// after k sweeps the first k candidates in raster order are final.  One 1024-thread block per image iterates until a
+// sweep changes nothing.  `aconf` holds conf for currently-active candidates and 0 elsewhere, so a neighbour test is
+// one float compare.  Survivors are emitted as (conf, raster) keys for select_b_kernel (always_sort = 1).
+// Not reproduced: the reference's CV_16UC1 index-map wrap-around above 65535 candidates (:115,128) -- the true
+// location is returned instead.
+// -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void nms2_a_kernel(const float* __restrict__ semi, int H, int W, float thr, int d,
+                                                      float* __restrict__ aconf, int* __restrict__ clist,
+                                                      unsigned long long* __restrict__ cand, int* __restrict__ cand_count,
+                                                      long cand_cap, int* __restrict__ iters_out) {
+  __shared__ int s_n, s_changed;
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const size_t hw = (size_t)H * W;
+  const float* sm = semi + img * hw;
+  float* ac = aconf + img * hw;
+  int* cl = clist + img * hw;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (size_t i = tid; i < hw; i += 1024) {
+    const float p = sm[i];
+    const bool c = p > thr;
+    ac[i] = c ? p : 0.f;
+    if (c) cl[atomicAdd(&s_n, 1)] = (int)i;
+  }
+  __syncthreads();
+  const int n = s_n;
+  int iters = 0;
+  for (;;) {
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    for (int k = tid; k < n; k += 1024) {
+      const int i = cl[k];
+      const int x = i % W, y = i / W;
+      const float p = sm[i];
+      bool sup = false;
+      for (int yy = max(0, y - d); yy <= y; ++yy) {
+        const int x1 = (yy == y) ? x - 1 : min(W - 1, x + d);
+        for (int xx = max(0, x - d); xx <= x1; ++xx) sup |= (ac[(size_t)yy * W + xx] > p);
+      }
+      const float want = sup ? 0.f : p;
+      if (ac[i] != want) { ac[i] = want; s_changed = 1; }
+    }
+    __syncthreads();   // workgroup-scope release/acquire: the block's own global stores are visible to all its waves (shared L1)
+    ++iters;
+    const int ch = s_changed;
+    __syncthreads();
+    if (!ch) break;
+  }
+  if (tid == 0 && iters_out) iters_out[img] = iters;
+  // survivors
+  unsigned long long* cd = cand + (size_t)img * cand_cap;
+  for (int k = tid; k < n; k += 1024) {
+    const int i = cl[k];
+    const float p = sm[i];
+    if (ac[i] == 0.f) continue;
+    const int x = i % W, y = i / W;
+    bool dead = false;
+    for (int yy = y; yy <= min(H - 1, y + d); ++yy) {
+      const int x0 = (yy == y) ? x + 1 : max(0, x - d);
+      for (int xx = x0; xx <= min(W - 1, x + d); ++xx) dead |= (ac[(size_t)yy * W + xx] > p);
+    }
+    if (!dead) {
+      const int slot = atomicAdd(cand_count + img, 1);
+      if (slot < cand_cap) cd[slot] = ((unsigned long long)__float_as_uint(p) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+    }
+  }
+}
+
+hipError_t launch_nms2_a(const float* semi, int H, int W, int n_img, float thr, int dist, float* aconf, int* clist,
+                         unsigned long long* cand, int* cand_count, long cand_cap, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(cand_count, 0, sizeof(int) * n_img, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(nms2_a_kernel, dim3(n_img), dim3(1024), 0, s, semi, H, W, thr, dist, aconf, clist, cand, cand_count,
+                     cand_cap, (int*)nullptr);
+  return hipGetLastError();
+}
+
+// Variant-A descriptor sampling: computeDescriptors (superpoint_common.cpp:42-99): grid = 2*x/W - 1,
+// torch::grid_sampler(bilinear, zeros padding, align_corners = false), L2, optional PCA (d - mean) * comp^T + row L2.
+// One wave per keypoint.  comp_t: [256][pca_dims] (transposed CSV layout, superpoint_onnx.cpp:47-53) or null.
+__global__ __launch_bounds__(256) void sample_a_kernel(const float* __restrict__ desc_raw, int dstride, int dcoff, int Hc,
+                                                       int Wc, int img_w, int img_h, const float* __restrict__ kps_xy,
+                                                       const int32_t* __restrict__ n_kp, int cap,
+                                                       const float* __restrict__ comp_t, const float* __restrict__ mean,
+                                                       int pca_dims, float* __restrict__ desc_out) {
+  __shared__ float sd[4][256];
+  const int img = blockIdx.y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int k = blockIdx.x * 4 + wv;
+  if (k >= n_kp[img] || k >= cap) return;
+  const size_t o = (size_t)img * cap + k;
+  const float x = kps_xy[2 * o], y = kps_xy[2 * o + 1];
+  const float gx = 2.0f * x / (float)img_w - 1.0f;
+  const float gy = 2.0f * y / (float)img_h - 1.0f;
+  const float ix = ((gx + 1.0f) * (float)Wc - 1.0f) / 2.0f;
+  const float iy = ((gy + 1.0f) * (float)Hc - 1.0f) / 2.0f;
+  const int x0 = (int)__builtin_floorf(ix), y0 = (int)__builtin_floorf(iy), x1 = x0 + 1, y1 = y0 + 1;
+  const float nw = ((float)x1 - ix) * ((float)y1 - iy);
+  const float ne = (ix - (float)x0) * ((float)y1 - iy);
+  const float sw = ((float)x1 - ix) * (iy - (float)y0);
+  const float se = (ix - (float)x0) * (iy - (float)y0);
+  const float* base = desc_raw + (size_t)img * Hc * Wc * dstride + dcoff + lane * 4;
+  auto corner = [&](int yy, int xx, float wgt, f32x4& acc) {
+    if (yy < 0 || yy >= Hc || xx < 0 || xx >= Wc) return;   // zeros padding (wave-uniform branch)
+    const f32x4 v = *reinterpret_cast<const f32x4*>(base + ((size_t)yy * Wc + xx) * dstride);
+    const float nrm = __builtin_sqrtf(wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = acc[j] + (v[j] / nrm) * wgt;
+  };
+  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+  corner(y0, x0, nw, d); corner(y0, x1, ne, d); corner(y1, x0, sw, d); corner(y1, x1, se, d);
+  float ss = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
+  const float n1 = __builtin_sqrtf(ss);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) d[j] = d[j] / n1;
+  if (!comp_t) {
+    ss = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
+    const float n2 = __builtin_sqrtf(ss);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = d[j] / n2;
+    *reinterpret_cast<f32x4*>(desc_out + o * 256 + lane * 4) = d;
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sd[wv][lane * 4 + j] = d[j] - mean[lane * 4 + j];
+  __builtin_amdgcn_wave_barrier();
+  // lane j (and j+64, ...) computes output component j
+  for (int j0 = 0; j0 < pca_dims; j0 += 64) {
+    const int j = j0 + lane;
+    float a = 0.f;
+    if (j < pca_dims)
+      for (int c = 0; c < 256; ++c) a += sd[wv][c] * comp_t[(size_t)c * pca_dims + j];
+    float s2 = wave_sum(j < pca_dims ? a * a : 0.f);
+    // pca_dims <= 64 in every shipped config; for larger dims the norm needs all chunks: accumulate first
+    if (pca_dims <= 64) {
+      const float n2 = __builtin_sqrtf(s2);
+      if (j < pca_dims) desc_out[o * pca_dims + j] = a / n2;
+    } else {
+      if (j < pca_dims) desc_out[o * pca_dims + j] = a;
+    }
+  }
+  if (pca_dims > 64) {
+    __builtin_amdgcn_wave_barrier();
+    float s2 = 0.f;
+    for (int j = lane; j < pca_dims; j += 64) { const float a = desc_out[o * pca_dims + j]; s2 += a * a; }
+    s2 = wave_sum(s2);
+    const float n2 = __builtin_sqrtf(s2);
+    for (int j = lane; j < pca_dims; j += 64) desc_out[o * pca_dims + j] = desc_out[o * pca_dims + j] / n2;
+  }
+}
+
+hipError_t launch_sample_a(const float* desc_raw, int dstride, int dcoff, int Hc, int Wc, int img_w, int img_h, int n_img,
+                           const float* kps_xy, const int32_t* n_kp, int cap, const float* comp_t, const float* mean,
+                           int pca_dims, float* desc_out, hipStream_t s) {
+  dim3 grid((cap + 3) / 4, n_img), block(256);
+  hipLaunchKernelGGL(sample_a_kernel, grid, block, 0, s, desc_raw, dstride, dcoff, Hc, Wc, img_w, img_h, kps_xy, n_kp, cap,
+                     comp_t, mean, pca_dims, desc_out);
   return hipGetLastError();
 }
 

@@ -91,11 +91,18 @@ D2FE_API void d2fe_destroy(d2fe_handle h);
  * weights are copied, re-packed into MFMA fragment order and cached on the device. */
 D2FE_API int d2fe_load_superpoint(d2fe_handle h, const d2fe_superpoint_weights* w);
 
+/* Optional PCA of the local descriptors (variant A only, as in the reference: computeDescriptors,
+ * superpoint_common.cpp:76-85; the variant-B path never applies it).
+ * comp: [pca_dims][256] row-major (the CSV layout read by superpoint_onnx.cpp:47-53), mean: [256].
+ * pca_dims = 0 disables.  d2fe_desc_dim() returns the per-keypoint descriptor length of extract calls (256 or pca_dims). */
+D2FE_API int d2fe_set_superpoint_pca(d2fe_handle h, const float* comp, const float* mean, int pca_dims);
+D2FE_API int d2fe_desc_dim(d2fe_handle h);
+
 /* Extractor.  Replaces: bool SuperPoint::infer(const cv::Mat&, std::vector<cv::Point2f>&, std::vector<float>&
  * descriptors, std::vector<float>& scores) (superpoint_tensorrt.h:47-48, .cpp:161-183), called from
  * LoopCam::extractorImgDescDeepnet (loop_cam.cpp:609-610).
  *   gray: u8 image, height rows of `stride` bytes.   kps_xy: cap*2 floats (x,y).   scores: cap floats.
- *   desc: cap*256 floats keypoint-major.   *n_out = number of keypoints written (0 on failure).
+ *   desc: cap*D floats keypoint-major, D = d2fe_desc_dim() (256 unless PCA is set).   *n_out = number of keypoints written (0 on failure).
  * Order of outputs = selection order of the chosen variant (B: raster if K<=N else score-desc; A: score-desc).
  * Not re-entrant per handle (the reference has one caller thread, d2frontend.cpp:155-169). */
 D2FE_API int d2fe_superpoint_extract(d2fe_handle h, const uint8_t* gray, int width, int height, int stride,
