@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libd2fe_hip.so")
 POSTPROC_B, POSTPROC_A = 0, 1
 PREC_F32, PREC_F16X2 = 0, 1
 PROF_STAGES = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPaDa",
-               "convPb", "convDb", "softmax_cand", "select", "sample", "match"]
+               "convPb", "convDb", "softmax_cand", "select", "sample", "match", "netvlad"]
 
 
 class D2FEError(RuntimeError):
@@ -50,6 +50,17 @@ class _SPWeights(C.Structure):
     _fields_ = [("layer", _ConvParams * 12)]
 
 
+class _NvLayer(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("stride", C.c_int32), ("act", C.c_int32),
+                ("res", C.c_int32), ("weight", C.c_void_p), ("bias", C.c_void_p)]
+
+
+class _NvWeights(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("layers", C.c_void_p), ("feat_dim", C.c_int32), ("proj_dim", C.c_int32),
+                ("n_clusters", C.c_int32), ("pre_w", C.c_void_p), ("pre_b", C.c_void_p), ("assign_w", C.c_void_p),
+                ("assign_b", C.c_void_p), ("centroids", C.c_void_p)]
+
+
 class _MatchBatch(C.Structure):
     _fields_ = [("d_a", C.c_void_p), ("d_b", C.c_void_p), ("d_pts_a", C.c_void_p), ("d_pts_b", C.c_void_p),
                 ("d_a_off", C.c_void_p), ("d_b_off", C.c_void_p), ("d_a_cnt", C.c_void_p), ("d_b_cnt", C.c_void_p),
@@ -62,7 +73,8 @@ _lib = None
 
 EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_create", "d2fe_destroy",
            "d2fe_load_superpoint", "d2fe_set_superpoint_pca", "d2fe_desc_dim", "d2fe_superpoint_extract", "d2fe_superpoint_extract_batch",
-           "d2fe_superpoint_extract_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device",
+           "d2fe_superpoint_extract_device", "d2fe_load_netvlad", "d2fe_set_netvlad_pca", "d2fe_netvlad_dim",
+           "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device",
            "d2fe_half_image_filter", "d2fe_debug_read", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read"]
 
 
@@ -98,6 +110,12 @@ def load_library():
         lib.d2fe_destroy.argtypes = [C.c_void_p]
         lib.d2fe_load_superpoint.argtypes = [C.c_void_p, C.c_void_p]
         lib.d2fe_sync.argtypes = [C.c_void_p]
+        lib.d2fe_load_netvlad.argtypes = [C.c_void_p, C.c_void_p]
+        lib.d2fe_set_netvlad_pca.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        lib.d2fe_netvlad_dim.argtypes = [C.c_void_p]
+        lib.d2fe_netvlad_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
+        lib.d2fe_netvlad.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.d2fe_netvlad_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
         lib.d2fe_set_superpoint_pca.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         lib.d2fe_desc_dim.argtypes = [C.c_void_p]
         lib.d2fe_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -247,6 +265,51 @@ class FrontEnd:
         ms = np.zeros(len(PROF_STAGES), np.float32); cnt = np.zeros(len(PROF_STAGES), np.int32)
         _check(self._lib.d2fe_profile_read(self._h, _ptr(ms), _ptr(cnt)))
         return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(PROF_STAGES)}
+
+    # ---- NetVLAD (MobileNetVLADONNX, mobilenetvlad_onnx.h:18-74) ---------------------------------------------------------
+    def load_netvlad(self, nv):
+        """nv: dict(layers=[dict(kind, cin, cout, stride, act, res, weight, bias)...], head=dict(pre_w, pre_b, assign_w,
+        assign_b, centroids)) as produced by d2slam_amd.netvlad.synthetic_netvlad_weights()."""
+        kinds = {"conv": 0, "pw": 1, "dw": 2}
+        n = len(nv["layers"])
+        arr = (_NvLayer * n)()
+        keep = []
+        for i, l in enumerate(nv["layers"]):
+            w = np.ascontiguousarray(l["weight"], np.float32); b = np.ascontiguousarray(l["bias"], np.float32)
+            keep += [w, b]
+            arr[i] = _NvLayer(kinds[l["kind"]], l["cin"], l["cout"], l["stride"], l["act"], l["res"], w.ctypes.data, b.ctypes.data)
+        hd = {k: np.ascontiguousarray(v, np.float32) for k, v in nv["head"].items()}
+        ws = _NvWeights(n, C.cast(arr, C.c_void_p), hd["pre_w"].shape[1], hd["pre_w"].shape[0], hd["assign_w"].shape[0],
+                        hd["pre_w"].ctypes.data, hd["pre_b"].ctypes.data, hd["assign_w"].ctypes.data,
+                        hd["assign_b"].ctypes.data, hd["centroids"].ctypes.data)
+        _check(self._lib.d2fe_load_netvlad(self._h, C.byref(ws)))
+
+    def set_netvlad_pca(self, comp, mean):
+        if comp is None:
+            _check(self._lib.d2fe_set_netvlad_pca(self._h, None, None, 0))
+            return
+        comp = np.ascontiguousarray(comp, np.float32); mean = np.ascontiguousarray(mean, np.float32)
+        _check(self._lib.d2fe_set_netvlad_pca(self._h, _ptr(comp), _ptr(mean), comp.shape[0]))
+
+    @property
+    def netvlad_dim(self):
+        r = int(self._lib.d2fe_netvlad_dim(self._h))
+        if r < 0:
+            _check(r)
+        return r
+
+    def netvlad(self, images):
+        """MobileNetVLADONNX::inference for a batch of u8 images [n,H,W] -> [n, netvlad_dim]."""
+        images = np.ascontiguousarray(images, np.uint8)
+        if images.ndim == 2:
+            images = images[None]
+        n, H, W = images.shape
+        out = np.zeros((n, self.netvlad_dim), np.float32)
+        _check(self._lib.d2fe_netvlad_batch(self._h, _ptr(images), n, W, H, W, H * W, _ptr(out)))
+        return out
+
+    def netvlad_device(self, d_gray, n, W, H, d_out, stream=None, stride=None, image_stride=None):
+        _check(self._lib.d2fe_netvlad_device(self._h, d_gray, n, W, H, stride or W, image_stride or H * W, d_out, stream))
 
     # ---- matcher -------------------------------------------------------------------------------------------------
     def match_knn(self, desc_a, desc_b, knn_match_ratio=0.8, pts_a=None, pts_b=None, search_local_dist=-1.0):

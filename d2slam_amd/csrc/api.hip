@@ -70,6 +70,15 @@ struct d2fe_context {
   const uint8_t* last_gray = nullptr; int last_stride = 0; size_t last_istride = 0;
   float* aconf = nullptr; int* clist = nullptr;     // variant A scratch
   float* pca_comp_t = nullptr; float* pca_mean = nullptr; int pca_dims = 0;
+  // NetVLAD
+  struct NvLayer { int kind, cin, cout, cout_pad, stride, act, res; float* w = nullptr; float* b = nullptr; float* out = nullptr; };
+  std::vector<NvLayer> nv;
+  bool nv_loaded = false;
+  int nv_feat = 0, nv_proj = 0, nv_k = 0;
+  float *nv_pre_w = nullptr, *nv_pre_b = nullptr, *nv_aw = nullptr, *nv_ab = nullptr, *nv_cen = nullptr;
+  float *nv_feat_buf = nullptr, *nv_raw = nullptr, *nv_pca_out = nullptr;
+  float *nv_pca_comp = nullptr, *nv_pca_mean = nullptr; int nv_pca_m = 0;
+  uint8_t* nv_s_img = nullptr; float* nv_s_out = nullptr;
   bool fuse1a = true;      // conv1a fused into conv1b's staging (D2FE_FUSE1A=0 keeps the stand-alone conv1a kernel)
   // matcher scratch
   std::mutex match_mu;
@@ -301,6 +310,10 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   return D2FE_OK;
 }
 
+}  // extern "C"
+namespace { void nv_free(d2fe_context* h); }
+extern "C" {
+
 void d2fe_destroy(d2fe_handle h) {
   if (!h) return;
   hipSetDevice(h->cfg.device_id);
@@ -312,6 +325,8 @@ void d2fe_destroy(d2fe_handle h) {
                   (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, h->m_buf, (void*)h->m_cand4, (void*)h->aconf, (void*)h->clist,
                   (void*)h->pca_comp_t, (void*)h->pca_mean})
     if (p) hipFree(p);
+  nv_free(h);
+  for (void* p : {(void*)h->nv_pca_comp, (void*)h->nv_pca_mean, (void*)h->nv_s_img, (void*)h->nv_s_out}) if (p) hipFree(p);
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -438,6 +453,173 @@ int d2fe_superpoint_extract(d2fe_handle h, const uint8_t* gray, int width, int h
                             float* scores, float* desc, int cap, int* n_out) {
   return d2fe_superpoint_extract_batch(h, gray, 1, width, height, stride, (size_t)stride * height, kps_xy, scores, desc,
                                        cap, n_out);
+}
+
+// ---- NetVLAD -----------------------------------------------------------------------------------------------------------
+namespace {
+void nv_free(d2fe_context* h) {
+  for (auto& l : h->nv) { if (l.w) hipFree(l.w); if (l.b) hipFree(l.b); if (l.out) hipFree(l.out); }
+  h->nv.clear();
+  for (float** p : {&h->nv_pre_w, &h->nv_pre_b, &h->nv_aw, &h->nv_ab, &h->nv_cen, &h->nv_feat_buf, &h->nv_raw, &h->nv_pca_out})
+    if (*p) { hipFree(*p); *p = nullptr; }
+  h->nv_loaded = false;
+}
+inline int same_out(int in, int stride) { return (in + stride - 1) / stride; }
+
+int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int stride, size_t image_stride, float* d_out,
+                hipStream_t s) {
+  ProfScope ps(h, D2FE_PROF_NETVLAD, s);
+  int ch = H, cw = W;
+  std::vector<int> oh(h->nv.size()), ow(h->nv.size());
+  for (size_t i = 0; i < h->nv.size(); ++i) {
+    auto& l = h->nv[i];
+    const float* in = i ? h->nv[i - 1].out : nullptr;
+    const int ho = same_out(ch, l.stride), wo = same_out(cw, l.stride);
+    if (l.kind == D2FE_NV_CONV) {
+      HIP_TRY(launch_nv_conv0(d_gray, stride, (long)image_stride, ch, cw, ho, wo, l.stride, l.cout, l.act, l.w, l.b, l.out, n, s));
+    } else if (l.kind == D2FE_NV_DW) {
+      HIP_TRY(launch_nv_dw(in, ch, cw, l.cin, ho, wo, l.stride, l.act, l.w, l.b, l.out, n, s));
+    } else {
+      HIP_TRY(launch_nv_pw(in, (long)n * ch * cw, l.cin, l.cout, l.cout_pad, l.act, l.w, l.b, l.res >= 0 ? h->nv[l.res].out : nullptr,
+                           l.out, s));
+    }
+    ch = ho; cw = wo; oh[i] = ho; ow[i] = wo;
+  }
+  const int np = ch * cw;
+  const int pp = (h->nv_proj + 31) / 32 * 32;
+  HIP_TRY(launch_nv_pw(h->nv.back().out, (long)n * np, h->nv_feat, h->nv_proj, pp, 0, h->nv_pre_w, h->nv_pre_b, nullptr, h->nv_feat_buf, s));
+  float* raw = h->nv_pca_m ? h->nv_raw : d_out;
+  HIP_TRY(launch_nv_vlad(h->nv_feat_buf, np, h->nv_proj, h->nv_k, h->nv_aw, h->nv_ab, h->nv_cen, raw, n, s));
+  if (h->nv_pca_m) HIP_TRY(launch_nv_pca(raw, h->nv_k * h->nv_proj, h->nv_pca_comp, h->nv_pca_mean, h->nv_pca_m, d_out, n, s));
+  return D2FE_OK;
+}
+}  // namespace
+
+int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
+  if (!h || !w || !w->layers || w->n_layers < 1) return fail(D2FE_ERR_INVALID, "null argument");
+  if (!w->pre_w || !w->pre_b || !w->assign_w || !w->assign_b || !w->centroids) return fail(D2FE_ERR_INVALID, "null head weights");
+  if (w->n_clusters < 1 || w->n_clusters > 64 || w->proj_dim < 4 || w->proj_dim > 256 || (w->proj_dim & 3) ||
+      w->n_clusters * w->proj_dim > 8192 || (w->feat_dim & 3))
+    return fail(D2FE_ERR_INVALID, "unsupported NetVLAD head shape");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  nv_free(h);
+  const int B = h->cfg.max_batch;
+  int ch = h->cfg.max_height, cw = h->cfg.max_width, cprev = 1;
+  for (int i = 0; i < w->n_layers; ++i) {
+    const d2fe_nv_layer& L = w->layers[i];
+    d2fe_context::NvLayer l;
+    l.kind = L.kind; l.cin = L.cin; l.cout = L.cout; l.stride = L.stride; l.act = L.act; l.res = L.res;
+    if (!L.weight || !L.bias || L.stride < 1 || L.stride > 2 || L.cin != cprev || L.res >= i)
+      return fail(D2FE_ERR_INVALID, "netvlad layer " + std::to_string(i) + ": bad descriptor");
+    std::vector<float> wt, bt;
+    if (L.kind == D2FE_NV_CONV) {
+      if (i != 0 || L.cin != 1 || L.cout > 32) return fail(D2FE_ERR_INVALID, "conv layer must be first, 1 -> <=32 channels");
+      wt.assign(9 * 32, 0.f); bt.assign(32, 0.f);
+      for (int co = 0; co < L.cout; ++co) { bt[co] = L.bias[co]; for (int t = 0; t < 9; ++t) wt[t * 32 + co] = L.weight[co * 9 + t]; }
+      l.cout_pad = 32;
+    } else if (L.kind == D2FE_NV_DW) {
+      if (L.cin != L.cout || (L.cin & 3)) return fail(D2FE_ERR_INVALID, "depthwise layer: channels must match and be a multiple of 4");
+      wt.resize(9 * (size_t)L.cin); bt.assign(L.bias, L.bias + L.cin);
+      for (int c = 0; c < L.cin; ++c) for (int t = 0; t < 9; ++t) wt[(size_t)t * L.cin + c] = L.weight[c * 9 + t];
+      l.cout_pad = L.cout;
+    } else if (L.kind == D2FE_NV_PW) {
+      if ((L.cin & 3) || L.stride != 1) return fail(D2FE_ERR_INVALID, "pointwise layer: cin must be a multiple of 4, stride 1");
+      if (L.res >= 0 && w->layers[L.res].cout != L.cout) return fail(D2FE_ERR_INVALID, "residual channel mismatch");
+      l.cout_pad = (L.cout + 31) / 32 * 32;
+      wt.assign((size_t)L.cin * l.cout_pad, 0.f); bt.assign(l.cout_pad, 0.f);
+      for (int co = 0; co < L.cout; ++co) { bt[co] = L.bias[co]; for (int ci = 0; ci < L.cin; ++ci) wt[(size_t)ci * l.cout_pad + co] = L.weight[(size_t)co * L.cin + ci]; }
+    } else {
+      return fail(D2FE_ERR_INVALID, "unknown layer kind");
+    }
+    ch = same_out(ch, L.stride); cw = same_out(cw, L.stride);
+    int rc = upload(wt.data(), wt.size() * sizeof(float), reinterpret_cast<void**>(&l.w));
+    rc = rc ? rc : upload(bt.data(), bt.size() * sizeof(float), reinterpret_cast<void**>(&l.b));
+    if (rc) return rc;
+    HIP_TRY(hipMalloc(&l.out, sizeof(float) * (size_t)B * ch * cw * L.cout));
+    h->nv.push_back(l);
+    cprev = L.cout;
+  }
+  if (cprev != w->feat_dim) return fail(D2FE_ERR_INVALID, "feat_dim does not match the last layer");
+  h->nv_feat = w->feat_dim; h->nv_proj = w->proj_dim; h->nv_k = w->n_clusters;
+  const int pp = (w->proj_dim + 31) / 32 * 32;
+  std::vector<float> pw((size_t)w->feat_dim * pp, 0.f), pb(pp, 0.f);
+  for (int co = 0; co < w->proj_dim; ++co) { pb[co] = w->pre_b[co]; for (int ci = 0; ci < w->feat_dim; ++ci) pw[(size_t)ci * pp + co] = w->pre_w[(size_t)co * w->feat_dim + ci]; }
+  int rc = upload(pw.data(), pw.size() * sizeof(float), reinterpret_cast<void**>(&h->nv_pre_w));
+  rc = rc ? rc : upload(pb.data(), pb.size() * sizeof(float), reinterpret_cast<void**>(&h->nv_pre_b));
+  rc = rc ? rc : upload(w->assign_w, sizeof(float) * w->n_clusters * w->proj_dim, reinterpret_cast<void**>(&h->nv_aw));
+  rc = rc ? rc : upload(w->assign_b, sizeof(float) * w->n_clusters, reinterpret_cast<void**>(&h->nv_ab));
+  rc = rc ? rc : upload(w->centroids, sizeof(float) * w->n_clusters * w->proj_dim, reinterpret_cast<void**>(&h->nv_cen));
+  if (rc) return rc;
+  HIP_TRY(hipMalloc(&h->nv_feat_buf, sizeof(float) * (size_t)B * ch * cw * w->proj_dim));
+  HIP_TRY(hipMalloc(&h->nv_raw, sizeof(float) * (size_t)B * w->n_clusters * w->proj_dim));
+  if (!h->nv_s_img) HIP_TRY(hipMalloc(&h->nv_s_img, (size_t)h->cfg.max_width * h->cfg.max_height * B));
+  if (!h->nv_s_out) HIP_TRY(hipMalloc(&h->nv_s_out, sizeof(float) * 8192 * B));
+  h->nv_loaded = true;
+  return D2FE_OK;
+}
+
+int d2fe_set_netvlad_pca(d2fe_handle h, const float* comp, const float* mean, int m) {
+  if (!h) return fail(D2FE_ERR_INVALID, "null handle");
+  if (!h->nv_loaded) return fail(D2FE_ERR_NOT_READY, "netvlad weights not loaded");
+  const int G = h->nv_k * h->nv_proj;
+  if (m < 0 || m > 8192 || (m > 0 && (!comp || !mean)) || (G & 3)) return fail(D2FE_ERR_INVALID, "bad PCA arguments");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->nv_pca_comp) { hipFree(h->nv_pca_comp); h->nv_pca_comp = nullptr; }
+  if (h->nv_pca_mean) { hipFree(h->nv_pca_mean); h->nv_pca_mean = nullptr; }
+  h->nv_pca_m = 0;
+  if (m == 0) return D2FE_OK;
+  int rc = upload(comp, sizeof(float) * (size_t)m * G, reinterpret_cast<void**>(&h->nv_pca_comp));
+  rc = rc ? rc : upload(mean, sizeof(float) * G, reinterpret_cast<void**>(&h->nv_pca_mean));
+  if (rc) return rc;
+  h->nv_pca_m = m;
+  return D2FE_OK;
+}
+
+int d2fe_netvlad_dim(d2fe_handle h) {
+  if (!h || !h->nv_loaded) return fail(D2FE_ERR_NOT_READY, "netvlad weights not loaded");
+  return h->nv_pca_m ? h->nv_pca_m : h->nv_k * h->nv_proj;
+}
+
+static int nv_check(d2fe_context* h, int n, int W, int H, int stride) {
+  if (!h) return fail(D2FE_ERR_INVALID, "null handle");
+  if (!h->nv_loaded) return fail(D2FE_ERR_NOT_READY, "netvlad weights not loaded");
+  if (n < 1 || n > h->cfg.max_batch) return fail(D2FE_ERR_INVALID, "batch size out of range");
+  if (W < 32 || H < 32 || W > h->cfg.max_width || H > h->cfg.max_height) return fail(D2FE_ERR_INVALID, "image size out of range");
+  if (stride < W) return fail(D2FE_ERR_INVALID, "stride < width");
+  return D2FE_OK;
+}
+
+int d2fe_netvlad_device(d2fe_handle h, const uint8_t* d_gray, int n, int width, int height, int stride, size_t image_stride,
+                        float* d_out, void* stream) {
+  int rc = nv_check(h, n, width, height, stride);
+  if (rc) return rc;
+  if (!d_gray || !d_out) return fail(D2FE_ERR_INVALID, "null device pointer");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  return run_netvlad(h, d_gray, n, width, height, stride, image_stride, d_out, stream ? (hipStream_t)stream : h->stream);
+}
+
+int d2fe_netvlad_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int height, int stride, size_t image_stride,
+                       float* out) {
+  int rc = nv_check(h, n, width, height, stride);
+  if (rc) return rc;
+  if (!gray || !out) return fail(D2FE_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  hipStream_t s = h->stream;
+  for (int i = 0; i < n; ++i)
+    HIP_TRY(hipMemcpy2DAsync(h->nv_s_img + (size_t)i * width * height, width, gray + i * image_stride, stride, width, height,
+                             hipMemcpyHostToDevice, s));
+  rc = run_netvlad(h, h->nv_s_img, n, width, height, width, (size_t)width * height, h->nv_s_out, s);
+  if (rc) return rc;
+  const int G = d2fe_netvlad_dim(h);
+  HIP_TRY(hipMemcpyAsync(out, h->nv_s_out, sizeof(float) * (size_t)G * n, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return D2FE_OK;
+}
+
+int d2fe_netvlad(d2fe_handle h, const uint8_t* gray, int width, int height, int stride, float* out) {
+  return d2fe_netvlad_batch(h, gray, 1, width, height, stride, (size_t)stride * height, out);
 }
 
 int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* stream) {

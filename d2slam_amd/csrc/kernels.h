@@ -65,6 +65,17 @@ hipError_t launch_sample_a(const float* desc_raw, int dstride, int dcoff, int Hc
                            const float* kps_xy, const int32_t* n_kp, int cap, const float* comp_t, const float* mean,
                            int pca_dims, float* desc_out, hipStream_t s);
 
+// ---- NetVLAD (netvlad.hip) -------------------------------------------------------------------------------------------
+hipError_t launch_nv_conv0(const uint8_t* img, int stride_b, long img_stride, int H, int W, int Ho, int Wo, int cstride,
+                           int cout, int act, const float* w, const float* b, float* out, int n, hipStream_t s);
+hipError_t launch_nv_dw(const float* in, int H, int W, int C, int Ho, int Wo, int cstride, int act, const float* w, const float* b,
+                        float* out, int n, hipStream_t s);
+hipError_t launch_nv_pw(const float* in, long P, int Cin, int Cout, int CoutPad, int act, const float* w, const float* b,
+                        const float* res, float* out, hipStream_t s);
+hipError_t launch_nv_vlad(const float* x, int np, int D, int K, const float* aw, const float* ab, const float* cen, float* out,
+                          int n, hipStream_t s);
+hipError_t launch_nv_pca(const float* x, int nfeat, const float* comp, const float* mean, int m, float* y, int n, hipStream_t s);
+
 // ---- matcher --------------------------------------------------------------------------------------
 struct MatchArgs {
   const float* a; const float* b; const float* pts_a; const float* pts_b;

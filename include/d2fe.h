@@ -122,6 +122,43 @@ D2FE_API int d2fe_superpoint_extract_device(d2fe_handle h, const uint8_t* d_gray
                                             float* d_desc, int32_t* d_kps_idx, int cap, int32_t* d_n_out,
                                             void* stream);
 
+/* ---- NetVLAD global descriptor ---------------------------------------------------------------------------------------
+ * Replaces: MobileNetVLADONNX (d2frontend/include/d2frontend/CNN/mobilenetvlad_onnx.h:18-74): ctor = ORT session + PCA
+ * CSV (:35-46), inference(const cv::Mat&) -> std::vector<float> of 4096 (or PCA dims) (:49-74), called from
+ * LoopCam::extractorImgDescDeepnet (loop_cam.cpp:612-616).  The reference's graph file is not in its tree:
+ * the network is given as a flat layer list (kinds below), so any MobileNetV2-style trunk + NetVLAD head can be loaded;
+ * d2slam_amd/netvlad.py holds the documented stand-in.  Layouts: conv [cout][1][3][3] (3x3 from the 1-channel image, in-graph
+ * (x-128)/128), dw [c][3][3], pw [cout][cin]; TF "SAME" padding; act 0 none / 1 ReLU / 2 ReLU6; res = index of the layer whose
+ * output is added (-1 none).  Head: 1x1 pre-projection feat_dim -> proj_dim, soft-assignment [K][proj_dim], centroids. */
+typedef enum { D2FE_NV_CONV = 0, D2FE_NV_PW = 1, D2FE_NV_DW = 2 } d2fe_nv_kind;
+typedef struct {
+  int32_t kind, cin, cout, stride, act, res;
+  const float* weight;
+  const float* bias;
+} d2fe_nv_layer;
+typedef struct {
+  int32_t n_layers;
+  const d2fe_nv_layer* layers;
+  int32_t feat_dim, proj_dim, n_clusters;
+  const float* pre_w;      /* [proj_dim][feat_dim] */
+  const float* pre_b;      /* [proj_dim] */
+  const float* assign_w;   /* [n_clusters][proj_dim] */
+  const float* assign_b;   /* [n_clusters] */
+  const float* centroids;  /* [n_clusters][proj_dim] */
+} d2fe_netvlad_weights;
+D2FE_API int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w);
+/* PCA of the global descriptor: comp [m][G], mean [G], G = n_clusters*proj_dim (the reference's CSV: row 0 = mean,
+ * rows 1.. = components, mobilenetvlad_onnx.h:35-41).  m = 0 disables. */
+D2FE_API int d2fe_set_netvlad_pca(d2fe_handle h, const float* comp, const float* mean, int m);
+D2FE_API int d2fe_netvlad_dim(d2fe_handle h);   /* length of the descriptor written by the calls below */
+/* std::vector<float> MobileNetVLADONNX::inference(const cv::Mat&): gray u8 at the network's size (the reference resizes with
+ * cv::resize when needed; that stays the caller's job).  out: d2fe_netvlad_dim() floats. */
+D2FE_API int d2fe_netvlad(d2fe_handle h, const uint8_t* gray, int width, int height, int stride, float* out);
+D2FE_API int d2fe_netvlad_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int height, int stride,
+                                size_t image_stride, float* out);
+D2FE_API int d2fe_netvlad_device(d2fe_handle h, const uint8_t* d_gray, int n, int width, int height, int stride,
+                                 size_t image_stride, float* d_out, void* stream);
+
 /* Matcher.  Replaces: std::vector<cv::DMatch> matchKNN(const cv::Mat& desc_a, const cv::Mat& desc_b,
  * double knn_match_ratio, pts_a, pts_b, double search_local_dist) (feature_matcher.h:6-11,
  * feature_matcher.cpp:4-42).  a: na x dim row-major, b: nb x dim.  pts_*: n x 2 floats or NULL.
@@ -167,7 +204,7 @@ D2FE_API long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t
 enum {
   D2FE_PROF_CONV1A = 0, D2FE_PROF_CONV1B, D2FE_PROF_CONV2A, D2FE_PROF_CONV2B, D2FE_PROF_CONV3A, D2FE_PROF_CONV3B,
   D2FE_PROF_CONV4A, D2FE_PROF_CONV4B, D2FE_PROF_CONVPADA, D2FE_PROF_CONVPB, D2FE_PROF_CONVDB, D2FE_PROF_SOFTMAX,
-  D2FE_PROF_SELECT, D2FE_PROF_SAMPLE, D2FE_PROF_MATCH, D2FE_PROF_COUNT
+  D2FE_PROF_SELECT, D2FE_PROF_SAMPLE, D2FE_PROF_MATCH, D2FE_PROF_NETVLAD, D2FE_PROF_COUNT
 };
 D2FE_API int d2fe_profile_enable(d2fe_handle h, int mode);
 D2FE_API int d2fe_profile_read(d2fe_handle h, float* ms /*[D2FE_PROF_COUNT]*/, int32_t* launches /*[D2FE_PROF_COUNT]*/);

@@ -473,3 +473,120 @@ ORC_API int orc_half_img(const float* pts_xy, int n, int require_left, int width
   }
   return c;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * A9  NetVLAD global descriptor.  Reference call site: MobileNetVLADONNX::inference,
+ *     d2frontend/include/d2frontend/CNN/mobilenetvlad_onnx.h:49-74 (input: gray, resized, float, NOT scaled (:60),
+ *     NHWC [1,H,W,1] "image:0" -> "descriptor:0" [1,4096]; optional PCA y = comp (x - mean), y/|y| (:66-71)).
+ *     THE GRAPH ITSELF IS NOT IN THE REFERENCE TREE (mobilenetvlad_dyn_size.onnx is a missing blob):
+ *     the network below is a documented STAND-IN of the HF-Net MobileNetVLAD lineage (MobileNetV2 trunk, in-graph
+ *     (x-128)/128 normalisation, 1x1 pre-projection, NetVLAD soft-assignment/aggregation, intra + global L2).
+ *     Parity for A9 is therefore unpinned twice over: no golden vectors AND no pinned architecture.
+ *     Generic layer primitives (TensorFlow "SAME" padding, BatchNorm folded into weight/bias):
+ * ---------------------------------------------------------------------------------------- */
+static float orc_act(float v, int act) { /* 0 none, 1 relu, 2 relu6 */
+  if (act >= 1 && v < 0.f) v = 0.f;
+  if (act == 2 && v > 6.f) v = 6.f;
+  return v;
+}
+/* TF SAME: out = ceil(in/stride); pad_total = max((out-1)*stride + k - in, 0); pad_before = pad_total/2 */
+static int orc_same_pad(int in, int k, int stride, int* out) {
+  *out = (in + stride - 1) / stride;
+  int pt = (*out - 1) * stride + k - in;
+  if (pt < 0) pt = 0;
+  return pt / 2;
+}
+
+/* full conv, NHWC, wgt [cout][cin][k][k], stride, TF-SAME padding, activation */
+ORC_API void orc_conv2d_same(const float* in, int h, int w, int cin, const float* wgt, const float* bias, int cout,
+                             int k, int stride, int act, float* out) {
+  int ho, wo;
+  const int pt = orc_same_pad(h, k, stride, &ho), pl = orc_same_pad(w, k, stride, &wo);
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < ho; ++y)
+    for (int x = 0; x < wo; ++x)
+      for (int co = 0; co < cout; ++co) {
+        float acc = bias[co];
+        for (int ky = 0; ky < k; ++ky) {
+          const int yy = y * stride + ky - pt;
+          if (yy < 0 || yy >= h) continue;
+          for (int kx = 0; kx < k; ++kx) {
+            const int xx = x * stride + kx - pl;
+            if (xx < 0 || xx >= w) continue;
+            for (int ci = 0; ci < cin; ++ci)
+              acc = fmaf(in[((size_t)yy * w + xx) * cin + ci], wgt[(((size_t)co * cin + ci) * k + ky) * k + kx], acc);
+          }
+        }
+        out[((size_t)y * wo + x) * cout + co] = orc_act(acc, act);
+      }
+}
+
+/* depthwise 3x3, NHWC, wgt [c][3][3], stride, TF-SAME, activation */
+ORC_API void orc_dwconv3x3_same(const float* in, int h, int w, int c, const float* wgt, const float* bias, int stride,
+                                int act, float* out) {
+  int ho, wo;
+  const int pt = orc_same_pad(h, 3, stride, &ho), pl = orc_same_pad(w, 3, stride, &wo);
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < ho; ++y)
+    for (int x = 0; x < wo; ++x)
+      for (int k = 0; k < c; ++k) {
+        float acc = bias[k];
+        for (int ky = 0; ky < 3; ++ky) {
+          const int yy = y * stride + ky - pt;
+          if (yy < 0 || yy >= h) continue;
+          for (int kx = 0; kx < 3; ++kx) {
+            const int xx = x * stride + kx - pl;
+            if (xx < 0 || xx >= w) continue;
+            acc = fmaf(in[((size_t)yy * w + xx) * c + k], wgt[(k * 3 + ky) * 3 + kx], acc);
+          }
+        }
+        out[((size_t)y * wo + x) * c + k] = orc_act(acc, act);
+      }
+}
+
+/* NetVLAD head on a feature map x [np][d] (already pre-projected): soft-assignment a = softmax_k(x W_a + b_a),
+ * V[k][:] = sum_p a[p][k] (c[k][:] - x[p][:])  (HF-Net sign convention), intra-normalise each V[k], flatten k-major,
+ * global L2.  assign_w [K][d], centroids [K][d].  out [K*d]. */
+ORC_API void orc_netvlad_head(const float* x, int np, int d, const float* assign_w, const float* assign_b,
+                              const float* centroids, int K, float* out) {
+  double* V = (double*)calloc((size_t)K * d, sizeof(double));
+  float* a = (float*)malloc(sizeof(float) * K);
+  for (int p = 0; p < np; ++p) {
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      float s = assign_b[k];
+      for (int j = 0; j < d; ++j) s = fmaf(x[(size_t)p * d + j], assign_w[(size_t)k * d + j], s);
+      a[k] = s; if (s > m) m = s;
+    }
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) { a[k] = expf(a[k] - m); sum += a[k]; }
+    for (int k = 0; k < K; ++k) {
+      const float ak = a[k] / sum;
+      for (int j = 0; j < d; ++j) V[(size_t)k * d + j] += (double)ak * ((double)centroids[(size_t)k * d + j] - (double)x[(size_t)p * d + j]);
+    }
+  }
+  double tot = 0.0;
+  for (int k = 0; k < K; ++k) {
+    double s = 0.0;
+    for (int j = 0; j < d; ++j) s += V[(size_t)k * d + j] * V[(size_t)k * d + j];
+    const double n = sqrt(s) > 1e-12 ? sqrt(s) : 1e-12;
+    for (int j = 0; j < d; ++j) { V[(size_t)k * d + j] /= n; tot += V[(size_t)k * d + j] * V[(size_t)k * d + j]; }
+  }
+  const double nt = sqrt(tot) > 1e-12 ? sqrt(tot) : 1e-12;
+  for (size_t i = 0; i < (size_t)K * d; ++i) out[i] = (float)(V[i] / nt);
+  free(V); free(a);
+}
+
+/* PCA of the global descriptor: y = comp (x - mean); y /= |y|   (mobilenetvlad_onnx.h:66-71).  comp [m][n]. */
+ORC_API void orc_netvlad_pca(const float* x, int n, const float* comp, const float* mean, int m, float* out) {
+  double tot = 0.0;
+  double* y = (double*)malloc(sizeof(double) * m);
+  for (int i = 0; i < m; ++i) {
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += (double)comp[(size_t)i * n + j] * ((double)x[j] - (double)mean[j]);
+    y[i] = s; tot += s * s;
+  }
+  const double nt = sqrt(tot);
+  for (int i = 0; i < m; ++i) out[i] = (float)(y[i] / nt);
+  free(y);
+}

@@ -302,3 +302,27 @@ def test_variant_a_raster_dependence(api, orc, sp_weights):
     rk, rs = orc.nms2_a(f["semi"], 0.001, 4, 300)
     assert np.array_equal(kps, rk) and np.array_equal(sc, rs)
     fe.close()
+
+
+@pytest.mark.parametrize("H,W", [(96, 128), (480, 640), (400, 800)])
+def test_netvlad_vs_oracle(api, orc, H, W):
+    """A9: global descriptor (stand-in graph; parity unpinned).  HIP vs the oracle on the same layer list: <= 1e-4."""
+    from d2slam_amd import netvlad as nvm
+    nv = nvm.synthetic_netvlad_weights()
+    imgs = np.stack([synth_image(H, W, 5 + s) for s in range(2)])
+    fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
+    fe.load_netvlad(nv)
+    assert fe.netvlad_dim == 4096
+    got = fe.netvlad(imgs)
+    for i in range(2):
+        ref = orc.netvlad_forward(imgs[i], nv)
+        assert abs(np.linalg.norm(got[i]) - 1.0) < 1e-5          # loop_tensorrt_test.cpp:97-100 prints this norm
+        assert np.abs(got[i] - ref).max() <= 1e-4, np.abs(got[i] - ref).max()
+    # PCA branch: y = comp (x - mean), y/|y|  (mobilenetvlad_onnx.h:66-71), 4096 -> 1024 (netvlad_pca_dims, d435_single.yaml:118)
+    comp, mean = nvm.synthetic_netvlad_pca(1024)
+    fe.set_netvlad_pca(comp, mean)
+    assert fe.netvlad_dim == 1024
+    got2 = fe.netvlad(imgs)
+    ref2 = orc.netvlad_forward(imgs[0], nv, pca=(comp, mean))
+    assert np.abs(got2[0] - ref2).max() <= 1e-4
+    fe.close()

@@ -252,3 +252,40 @@ def test_golden_fixtures(orc, sp_weights):
     m = np.load(os.path.join(GOLDEN, "match_120x90.npz"))
     q, t, d = orc.match_knn(m["a"], m["b"], 0.8, m["pts_a"], m["pts_b"], 40.0)
     assert np.array_equal(q, m["q"]) and np.array_equal(t, m["t"]) and np.array_equal(d, m["d"])
+
+
+def test_netvlad_oracle_vs_torch(orc):
+    """A9 stand-in: the oracle's layer primitives against PyTorch (TF-SAME padding emulated with explicit F.pad)."""
+    from d2slam_amd import netvlad as nvm
+    nv = nvm.synthetic_netvlad_weights()
+    img = synth_image(96, 128, 2)
+    out, layers, feat, raw = orc.netvlad_forward(img, nv, return_layers=True)
+
+    def same(x, k, s):
+        h, w = x.shape[-2:]
+        ph = max((-(-h // s) - 1) * s + k - h, 0); pw = max((-(-w // s) - 1) * s + k - w, 0)
+        return F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+    x = ((torch.from_numpy(img.astype(np.float32)) - 128.0) / 128.0)[None, None].double()
+    outs = []
+    for l in nv["layers"]:
+        W = torch.from_numpy(l["weight"]).double(); b = torch.from_numpy(l["bias"]).double()
+        if l["kind"] == "conv":
+            y = F.conv2d(same(x, 3, l["stride"]), W, b, stride=l["stride"])
+        elif l["kind"] == "dw":
+            y = F.conv2d(same(x, 3, l["stride"]), W[:, None], b, stride=l["stride"], groups=W.shape[0])
+        else:
+            y = F.conv2d(x, W[:, :, None, None], b)
+        if l["act"] == 2:
+            y = y.clamp(0, 6)
+        if l["res"] >= 0:
+            y = y + outs[l["res"]]
+        outs.append(y); x = y
+    for i in (0, 1, 2, 8, 20, len(outs) - 1):
+        assert np.abs(outs[i][0].permute(1, 2, 0).numpy() - layers[i]).max() < 1e-4, i
+    hd = nv["head"]
+    f = F.conv2d(x, torch.from_numpy(hd["pre_w"]).double()[:, :, None, None], torch.from_numpy(hd["pre_b"]).double())[0].permute(1, 2, 0).reshape(-1, 128)
+    a = torch.softmax(f @ torch.from_numpy(hd["assign_w"]).double().T + torch.from_numpy(hd["assign_b"]).double(), 1)
+    V = (a[:, :, None] * (torch.from_numpy(hd["centroids"]).double()[None] - f[:, None, :])).sum(0)
+    V = V / V.norm(dim=1, keepdim=True)
+    v = (V / V.norm()).reshape(-1).numpy()
+    assert np.abs(v - out).max() < 1e-5
