@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f16x2"], default=os.environ.get("D2FE_BENCH_PRECISION", "f32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--netvlad", action="store_true", help="also run the NetVLAD global descriptor on every left image (BASELINE metric with NetVLAD)")
     ap.add_argument("--single-mode", action="store_true", help="time only --precision (default: also the other mode)")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event breakdown to stderr")
     args = ap.parse_args()
@@ -72,6 +73,10 @@ def main():
                                    device_id=local_rank)
         fe = api.FrontEnd(cfg)
         fe.load_superpoint(weights)
+        if args.netvlad:
+            from d2slam_amd import netvlad as nvm
+            fe.load_netvlad(nvm.synthetic_netvlad_weights())
+            gdesc = torch.zeros((F, fe.netvlad_dim), dtype=torch.float32, device=dev)
 
         # synthetic frames, resident in HBM before the timed region: [L0, R0, L1, R1, ...]
         host = np.empty((NI, H, W), np.uint8)
@@ -110,6 +115,9 @@ def main():
         def step():
             fe.extract_device(imgs.data_ptr(), NI, W, H, kps.data_ptr(), scores.data_ptr(), desc.data_ptr(), kidx.data_ptr(),
                               CAP, cnt.data_ptr(), stream=stream)
+            if args.netvlad:
+                # left images are rows 0,2,4,... of imgs: image_stride = 2 frames
+                fe.netvlad_device(imgs.data_ptr(), F, W, H, gdesc.data_ptr(), stream=stream, image_stride=2 * H * W)
             if world > 1:
                 # cross-agent exchange: one all-gather of the fixed-capacity left-image blocks (RCCL over xGMI)
                 swarm.exchange_blocks(desc, cnt, F, rank, world, gath_desc, gath_cnt)
@@ -199,7 +207,7 @@ def main():
             "config": {"workload": "configs[1]: realsense_d435 stereo 640x480, 200 keypoints/frame, SuperPoint (both "
                                    "images) + matchKNN L<->R and L<->prevL" + ("; + RCCL all-gather and cross-agent matchKNN" if world > 1 else ""),
                        "frames_per_step_per_gpu": F, "images_per_step_per_gpu": NI, "match_pairs_per_step_per_gpu": NP,
-                       "max_keypoints": CAP, "postproc": "B", "precision": args.precision,
+                       "max_keypoints": CAP, "postproc": "B", "precision": args.precision, "netvlad": bool(args.netvlad),
                        "weights": "seeded random-init SuperPoint (no checkpoint in tree)"},
             "sp_tflops_algorithmic": round(SP_FLOP_PER_IMG * 2 * value / 1e12, 2),
             "avg_keypoints_per_image": round(n_kp, 1), "avg_matches_per_pair": round(n_match, 1),

@@ -76,7 +76,7 @@ struct d2fe_context {
   bool nv_loaded = false;
   int nv_feat = 0, nv_proj = 0, nv_k = 0;
   float *nv_pre_w = nullptr, *nv_pre_b = nullptr, *nv_aw = nullptr, *nv_ab = nullptr, *nv_cen = nullptr;
-  float *nv_feat_buf = nullptr, *nv_raw = nullptr, *nv_pca_out = nullptr;
+  float *nv_feat_buf = nullptr, *nv_raw = nullptr, *nv_pca_out = nullptr, *nv_part = nullptr;
   float *nv_pca_comp = nullptr, *nv_pca_mean = nullptr; int nv_pca_m = 0;
   uint8_t* nv_s_img = nullptr; float* nv_s_out = nullptr;
   bool fuse1a = true;      // conv1a fused into conv1b's staging (D2FE_FUSE1A=0 keeps the stand-alone conv1a kernel)
@@ -460,7 +460,7 @@ namespace {
 void nv_free(d2fe_context* h) {
   for (auto& l : h->nv) { if (l.w) hipFree(l.w); if (l.b) hipFree(l.b); if (l.out) hipFree(l.out); }
   h->nv.clear();
-  for (float** p : {&h->nv_pre_w, &h->nv_pre_b, &h->nv_aw, &h->nv_ab, &h->nv_cen, &h->nv_feat_buf, &h->nv_raw, &h->nv_pca_out})
+  for (float** p : {&h->nv_pre_w, &h->nv_pre_b, &h->nv_aw, &h->nv_ab, &h->nv_cen, &h->nv_feat_buf, &h->nv_raw, &h->nv_pca_out, &h->nv_part})
     if (*p) { hipFree(*p); *p = nullptr; }
   h->nv_loaded = false;
 }
@@ -489,7 +489,7 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
   const int pp = (h->nv_proj + 31) / 32 * 32;
   HIP_TRY(launch_nv_pw(h->nv.back().out, (long)n * np, h->nv_feat, h->nv_proj, pp, 0, h->nv_pre_w, h->nv_pre_b, nullptr, h->nv_feat_buf, s));
   float* raw = h->nv_pca_m ? h->nv_raw : d_out;
-  HIP_TRY(launch_nv_vlad(h->nv_feat_buf, np, h->nv_proj, h->nv_k, h->nv_aw, h->nv_ab, h->nv_cen, raw, n, s));
+  HIP_TRY(launch_nv_vlad(h->nv_feat_buf, np, h->nv_proj, h->nv_k, h->nv_aw, h->nv_ab, h->nv_cen, h->nv_part, raw, n, s));
   if (h->nv_pca_m) HIP_TRY(launch_nv_pca(raw, h->nv_k * h->nv_proj, h->nv_pca_comp, h->nv_pca_mean, h->nv_pca_m, d_out, n, s));
   return D2FE_OK;
 }
@@ -526,9 +526,11 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
     } else if (L.kind == D2FE_NV_PW) {
       if ((L.cin & 3) || L.stride != 1) return fail(D2FE_ERR_INVALID, "pointwise layer: cin must be a multiple of 4, stride 1");
       if (L.res >= 0 && w->layers[L.res].cout != L.cout) return fail(D2FE_ERR_INVALID, "residual channel mismatch");
+      if (L.cin & 7) return fail(D2FE_ERR_INVALID, "pointwise layer: cin must be a multiple of 8");
       l.cout_pad = (L.cout + 31) / 32 * 32;
-      wt.assign((size_t)L.cin * l.cout_pad, 0.f); bt.assign(l.cout_pad, 0.f);
-      for (int co = 0; co < L.cout; ++co) { bt[co] = L.bias[co]; for (int ci = 0; ci < L.cin; ++ci) wt[(size_t)ci * l.cout_pad + co] = L.weight[(size_t)co * L.cin + ci]; }
+      wt.resize(packed_weight_floats_f32(l.cout_pad, L.cin, 1)); bt.assign(l.cout_pad, 0.f);
+      pack_weights_f32(L.weight, L.cout, L.cin, 1, l.cout_pad, wt.data());
+      for (int co = 0; co < L.cout; ++co) bt[co] = L.bias[co];
     } else {
       return fail(D2FE_ERR_INVALID, "unknown layer kind");
     }
@@ -543,8 +545,10 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
   if (cprev != w->feat_dim) return fail(D2FE_ERR_INVALID, "feat_dim does not match the last layer");
   h->nv_feat = w->feat_dim; h->nv_proj = w->proj_dim; h->nv_k = w->n_clusters;
   const int pp = (w->proj_dim + 31) / 32 * 32;
-  std::vector<float> pw((size_t)w->feat_dim * pp, 0.f), pb(pp, 0.f);
-  for (int co = 0; co < w->proj_dim; ++co) { pb[co] = w->pre_b[co]; for (int ci = 0; ci < w->feat_dim; ++ci) pw[(size_t)ci * pp + co] = w->pre_w[(size_t)co * w->feat_dim + ci]; }
+  if (w->feat_dim & 7) return fail(D2FE_ERR_INVALID, "feat_dim must be a multiple of 8");
+  std::vector<float> pw(packed_weight_floats_f32(pp, w->feat_dim, 1)), pb(pp, 0.f);
+  pack_weights_f32(w->pre_w, w->proj_dim, w->feat_dim, 1, pp, pw.data());
+  for (int co = 0; co < w->proj_dim; ++co) pb[co] = w->pre_b[co];
   int rc = upload(pw.data(), pw.size() * sizeof(float), reinterpret_cast<void**>(&h->nv_pre_w));
   rc = rc ? rc : upload(pb.data(), pb.size() * sizeof(float), reinterpret_cast<void**>(&h->nv_pre_b));
   rc = rc ? rc : upload(w->assign_w, sizeof(float) * w->n_clusters * w->proj_dim, reinterpret_cast<void**>(&h->nv_aw));
@@ -553,6 +557,7 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
   if (rc) return rc;
   HIP_TRY(hipMalloc(&h->nv_feat_buf, sizeof(float) * (size_t)B * ch * cw * w->proj_dim));
   HIP_TRY(hipMalloc(&h->nv_raw, sizeof(float) * (size_t)B * w->n_clusters * w->proj_dim));
+  HIP_TRY(hipMalloc(&h->nv_part, sizeof(float) * (size_t)B * ((ch * cw + 63) / 64) * w->n_clusters * w->proj_dim));
   if (!h->nv_s_img) HIP_TRY(hipMalloc(&h->nv_s_img, (size_t)h->cfg.max_width * h->cfg.max_height * B));
   if (!h->nv_s_out) HIP_TRY(hipMalloc(&h->nv_s_out, sizeof(float) * 8192 * B));
   h->nv_loaded = true;

@@ -4,7 +4,7 @@
 // session run + optional PCA).  The reference's graph is NOT in its tree; the layer kinds below
 // execute whatever flat layer list d2fe_load_netvlad() is given -- the documented stand-in lives in
 // d2slam_amd/netvlad.py and oracle/d2fe_oracle.c (A9 block).  All of it is 0.33 GMAC per 640x480 image (0.6 % of
-// SuperPoint), HBM/latency bound: plain fp32 VALU kernels, weights through the scalar cache, activations NHWC.
+// SuperPoint), HBM/latency bound: 1x1 convs as fp32-MFMA GEMMs, depthwise/first conv on the VALU, activations NHWC.
 #include "kernels.h"
 
 namespace d2fe {
@@ -86,111 +86,139 @@ __global__ __launch_bounds__(256) void nv_dw_kernel(const float* __restrict__ in
   *reinterpret_cast<f32x4*>(out + ((size_t)n * Ho * Wo + p) * C + c4 * 4) = acc;
 }
 
-// ---- pointwise (1x1) conv: [P][Cin] x [Cin][CoutPad] ----------------------------------------------------------------------------
-// Block = 64 pixels x 128 output channels; lane = pixel, wave = 32 output channels held as 32 accumulators.  The pixel tile
-// is one contiguous span of NHWC memory (coalesced float4 staging into LDS, Cin chunked by 256); weights for a wave's 32
-// channels are wave-uniform and arrive through scalar loads (v_fma with an SGPR operand).
-constexpr int PW_CH = 256;
-__global__ __launch_bounds__(256) void nv_pw_kernel(const float* __restrict__ in, long P, int Cin, int Cout, int CoutPad,
-                                                    int act, const float* __restrict__ w /*[Cin][CoutPad]*/,
-                                                    const float* __restrict__ b /*[CoutPad]*/,
-                                                    const float* __restrict__ res /*nullable [P][Cout]*/,
-                                                    float* __restrict__ out) {
-  __shared__ float xs[64 * (PW_CH + 1)];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long p0 = (long)blockIdx.x * 64;
-  const int co0 = blockIdx.y * 128 + wave * 32;
-  float acc[32];
+// ---- pointwise (1x1) conv as a GEMM on fp32 MFMA: [P][Cin] x [Cin][CoutPad] ---------------------------------------------------
+// Block = 128 consecutive pixels (one contiguous NHWC span -> coalesced staging) x up to 128 output channels; wave w owns
+// pixels [32w, 32w+32) and all NT 32-wide channel tiles (v_mfma_f32_32x32x2_f32, NT*16 accumulators).  Cin is staged through
+// LDS in chunks of 64 channels (row stride 65 floats: conflict-free column reads).  Weights are pre-packed on the host in the
+// same fragment order as the SuperPoint convs: [ntile][cin/8][lane] float4, element q = W[co = ntile*32 + (lane&31)][ci = c8*8 + 2q + (lane>>5)].
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int PW_CK = 64;
+template <int NT>
+__global__ __launch_bounds__(256) void nv_pw_mfma_kernel(const float* __restrict__ in, long P, int Cin, int Cout, int act,
+                                                         const f32x4* __restrict__ wpack, const float* __restrict__ b,
+                                                         const float* __restrict__ res, float* __restrict__ out) {
+  __shared__ float xs[128 * (PW_CK + 1)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long p0 = (long)blockIdx.x * 128;
+  const int nt0 = blockIdx.y * NT;
+  const int c8n = (Cin + 7) / 8;                      // Cin is a multiple of 8 for every MobileNetV2 width used here
+  const int npix = (int)((P - p0) < 128 ? (P - p0) : 128);
+  f32x16 acc[NT];
 #pragma unroll
-  for (int j = 0; j < 32; ++j) acc[j] = 0.f;
-  const int npix = (int)((P - p0) < 64 ? (P - p0) : 64);
-  for (int c0 = 0; c0 < Cin; c0 += PW_CH) {
-    const int cc = (Cin - c0) < PW_CH ? (Cin - c0) : PW_CH;
-    __syncthreads();
-    // stage [npix][cc] (Cin and cc are multiples of 4)
+  for (int n = 0; n < NT; ++n) {
+    const float bv = b[(nt0 + n) * 32 + (lane & 31)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = bv;
+  }
+  for (int c0 = 0; c0 < Cin; c0 += PW_CK) {
+    const int cc = (Cin - c0) < PW_CK ? (Cin - c0) : PW_CK;
     const int cc4 = cc / 4;
-    for (int i = tid; i < npix * cc4; i += 256) {
+    __syncthreads();
+    for (int i = tid; i < 128 * cc4; i += 256) {
       const int pp = i / cc4, q = i % cc4;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(in + (size_t)(p0 + pp) * Cin + c0 + q * 4);
-      float* d = xs + pp * (PW_CH + 1) + q * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pp < npix) v = *reinterpret_cast<const f32x4*>(in + (size_t)(p0 + pp) * Cin + c0 + q * 4);
+      float* d = xs + pp * (PW_CK + 1) + q * 4;
       d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
     }
     __syncthreads();
-    if (co0 < CoutPad) {
-      const float* wp = w + (size_t)c0 * CoutPad + co0;
-      const float* xp = xs + lane * (PW_CH + 1);
-      for (int ci = 0; ci < cc; ++ci) {
-        const float xv = xp[ci];
-        const float* wr = wp + (size_t)ci * CoutPad;
+    const float* ap = xs + (wave * 32 + (lane & 31)) * (PW_CK + 1) + (lane >> 5);
+    for (int c8 = 0; c8 < cc / 8; ++c8) {
+      f32x4 bw[NT];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) acc[j] = __builtin_fmaf(xv, wr[j], acc[j]);
-      }
+      for (int n = 0; n < NT; ++n) bw[n] = wpack[((size_t)(nt0 + n) * c8n + (c0 / 8 + c8)) * 64 + lane];
+      float av[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) av[q] = ap[c8 * 8 + 2 * q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bw[n][q], acc[n], 0, 0, 0);
     }
   }
-  if (co0 >= CoutPad || lane >= npix) return;
-  const long p = p0 + lane;
+  // C layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel of this wave's 32)
 #pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    const int co = co0 + j;
-    if (co < Cout) {
-      float v = acc[j] + b[co];
-      if (res) v += res[(size_t)p * Cout + co];
-      out[(size_t)p * Cout + co] = nv_act(v, act);
+  for (int r = 0; r < 16; ++r) {
+    const int pp = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (pp < npix) {
+      const long p = p0 + pp;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int co = (nt0 + n) * 32 + (lane & 31);
+        if (co < Cout) {
+          float v = acc[n][r];
+          if (res) v += res[(size_t)p * Cout + co];
+          out[(size_t)p * Cout + co] = nv_act(v, act);
+        }
+      }
     }
   }
 }
 
 // ---- NetVLAD head: soft-assignment, residual aggregation, intra + global L2 ----------------------------------------------------
-// One 1024-thread block per image.  x: [np][D] (pre-projected features).  out: [K*D].  K <= 64, D <= 256, K*D <= 8192.
-constexpr int VL_PCH = 128;  // positions per chunk kept in LDS
-__global__ __launch_bounds__(1024) void nv_vlad_kernel(const float* __restrict__ x, int np, int D, int K,
-                                                       const float* __restrict__ aw /*[K][D]*/, const float* __restrict__ ab,
-                                                       const float* __restrict__ cen /*[K][D]*/, float* __restrict__ out) {
+// x: [np][D] pre-projected features per image.  Stage 1 (grid: position chunks of 64 x images): features and assignment
+// weights live in LDS; memberships a = softmax_k(x W_a^T + b_a); partial V[k][d] = sum_p a[p][k] (c[k][d] - x[p][d]) written
+// per chunk (deterministic: no float atomics).  Stage 2 (one block per image): chunk sum, intra-normalisation per cluster,
+// flatten k-major, global L2.  K <= 64, D <= 128*2, K*D <= 8192.
+constexpr int VL_PCH = 64;
+__global__ __launch_bounds__(256) void nv_vlad_partial_kernel(const float* __restrict__ x, int np, int D, int K,
+                                                              const float* __restrict__ aw, const float* __restrict__ ab,
+                                                              const float* __restrict__ cen, float* __restrict__ part,
+                                                              int nchunk) {
   extern __shared__ float sm[];
-  float* a = sm;                       // [VL_PCH][K] memberships of the current chunk
-  float* red = a + VL_PCH * 64;        // [64] per-cluster norms, [64] scratch
-  const int img = blockIdx.x, tid = threadIdx.x;
-  const float* xi = x + (size_t)img * np * D;
-  const int KD = K * D;
-  float v[8];                          // this thread's V entries: e = tid + 1024*r
-#pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] = 0.f;
-  for (int pc = 0; pc < np; pc += VL_PCH) {
-    const int pn = (np - pc) < VL_PCH ? (np - pc) : VL_PCH;
-    __syncthreads();
-    // memberships: thread (p, k) = one logit
-    for (int i = tid; i < pn * K; i += 1024) {
-      const int p = i / K, k = i % K;
-      float s = ab[k];
-      const float* xp = xi + (size_t)(pc + p) * D;
-      const float* wk = aw + (size_t)k * D;
-      for (int j = 0; j < D; ++j) s = __builtin_fmaf(xp[j], wk[j], s);
-      a[p * 64 + k] = s;
-    }
-    __syncthreads();
-    for (int p = tid; p < pn; p += 1024) {
-      float m = -__builtin_inff();
-      for (int k = 0; k < K; ++k) m = a[p * 64 + k] > m ? a[p * 64 + k] : m;
-      float sum = 0.f;
-      for (int k = 0; k < K; ++k) { const float e = __expf(a[p * 64 + k] - m); a[p * 64 + k] = e; sum += e; }
-      for (int k = 0; k < K; ++k) a[p * 64 + k] = a[p * 64 + k] / sum;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int e = tid + 1024 * r;
-      if (e < KD) {
-        const int k = e / D, j = e % D;
-        const float c = cen[e];
-        float acc = v[r];
-        for (int p = 0; p < pn; ++p) acc = __builtin_fmaf(a[p * 64 + k], c - xi[(size_t)(pc + p) * D + j], acc);
-        v[r] = acc;
-      }
-    }
-  }
-  // intra-normalisation (per cluster over D), then global L2
+  const int DS = D + 1;
+  float* xs = sm;                    // [VL_PCH][D+1]
+  float* ws = xs + VL_PCH * DS;      // [K][D+1]
+  float* a = ws + K * DS;            // [VL_PCH][K+1]
+  const int img = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int p0 = chunk * VL_PCH;
+  const int pn = (np - p0) < VL_PCH ? (np - p0) : VL_PCH;
+  const float* xi = x + ((size_t)img * np + p0) * D;
+  for (int i = tid; i < VL_PCH * D; i += 256) { const int p = i / D, j = i % D; xs[p * DS + j] = p < pn ? xi[(size_t)p * D + j] : 0.f; }
+  for (int i = tid; i < K * D; i += 256) ws[(i / D) * DS + i % D] = aw[i];
   __syncthreads();
-  for (int i = tid; i < 128; i += 1024) red[i] = 0.f;
+  for (int i = tid; i < pn * K; i += 256) {
+    const int p = i % pn, k = i / pn;          // consecutive lanes -> consecutive positions (distinct LDS rows)
+    float s = ab[k];
+    for (int j = 0; j < D; ++j) s = __builtin_fmaf(xs[p * DS + j], ws[k * DS + j], s);
+    a[p * (K + 1) + k] = s;
+  }
+  __syncthreads();
+  if (tid < pn) {
+    float* ap = a + tid * (K + 1);
+    float m = -__builtin_inff();
+    for (int k = 0; k < K; ++k) m = ap[k] > m ? ap[k] : m;
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) { const float e = __expf(ap[k] - m); ap[k] = e; sum += e; }
+    for (int k = 0; k < K; ++k) ap[k] = ap[k] / sum;
+  }
+  __syncthreads();
+  const int KD = K * D;
+  float* po = part + ((size_t)img * nchunk + chunk) * KD;
+  for (int e = tid; e < KD; e += 256) {
+    const int k = e / D, j = e % D;
+    const float c = cen[e];
+    float acc = 0.f;
+    for (int p = 0; p < pn; ++p) acc = __builtin_fmaf(a[p * (K + 1) + k], c - xs[p * DS + j], acc);
+    po[e] = acc;
+  }
+}
+
+__global__ __launch_bounds__(1024) void nv_vlad_final_kernel(const float* __restrict__ part, int nchunk, int D, int K,
+                                                             float* __restrict__ out) {
+  __shared__ float red[130];
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const int KD = K * D;
+  float v[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int e = tid + 1024 * r;
+    float s = 0.f;
+    if (e < KD)
+      for (int c = 0; c < nchunk; ++c) s += part[((size_t)img * nchunk + c) * KD + e];
+    v[r] = s;
+  }
+  for (int i = tid; i < 130; i += 1024) red[i] = 0.f;
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -210,9 +238,9 @@ __global__ __launch_bounds__(1024) void nv_vlad_kernel(const float* __restrict__
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-  if ((tid & 63) == 0) atomicAdd(&red[64], tot);
+  if ((tid & 63) == 0) atomicAdd(&red[128], tot);
   __syncthreads();
-  const float nt = __builtin_sqrtf(red[64]);
+  const float nt = __builtin_sqrtf(red[128]);
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int e = tid + 1024 * r;
@@ -271,15 +299,24 @@ hipError_t launch_nv_dw(const float* in, int H, int W, int C, int Ho, int Wo, in
 }
 hipError_t launch_nv_pw(const float* in, long P, int Cin, int Cout, int CoutPad, int act, const float* w, const float* b,
                         const float* res, float* out, hipStream_t s) {
-  dim3 grid((unsigned)((P + 63) / 64), (CoutPad + 127) / 128);
-  hipLaunchKernelGGL(nv_pw_kernel, grid, dim3(256), 0, s, in, P, Cin, Cout, CoutPad, act, w, b, res, out);
+  const int ntiles = CoutPad / 32;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(w);
+  const unsigned gx = (unsigned)((P + 127) / 128);
+  if (ntiles % 4 == 0) hipLaunchKernelGGL(nv_pw_mfma_kernel<4>, dim3(gx, ntiles / 4), dim3(256), 0, s, in, P, Cin, Cout, act, wp, b, res, out);
+  else if (ntiles == 3) hipLaunchKernelGGL(nv_pw_mfma_kernel<3>, dim3(gx, 1), dim3(256), 0, s, in, P, Cin, Cout, act, wp, b, res, out);
+  else if (ntiles % 2 == 0) hipLaunchKernelGGL(nv_pw_mfma_kernel<2>, dim3(gx, ntiles / 2), dim3(256), 0, s, in, P, Cin, Cout, act, wp, b, res, out);
+  else hipLaunchKernelGGL(nv_pw_mfma_kernel<1>, dim3(gx, ntiles), dim3(256), 0, s, in, P, Cin, Cout, act, wp, b, res, out);
   return hipGetLastError();
 }
-hipError_t launch_nv_vlad(const float* x, int np, int D, int K, const float* aw, const float* ab, const float* cen, float* out,
-                          int n, hipStream_t s) {
+hipError_t launch_nv_vlad(const float* x, int np, int D, int K, const float* aw, const float* ab, const float* cen, float* part,
+                          float* out, int n, hipStream_t s) {
   if (K > 64 || D > 256 || K * D > 8192) return hipErrorInvalidValue;
-  const size_t lds = sizeof(float) * (VL_PCH * 64 + 128);
-  hipLaunchKernelGGL(nv_vlad_kernel, dim3(n), dim3(1024), lds, s, x, np, D, K, aw, ab, cen, out);
+  const int nchunk = (np + VL_PCH - 1) / VL_PCH;
+  const size_t lds = sizeof(float) * ((size_t)VL_PCH * (D + 1) + (size_t)K * (D + 1) + (size_t)VL_PCH * (K + 1));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nv_vlad_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(nv_vlad_partial_kernel, dim3(nchunk, n), dim3(256), lds, s, x, np, D, K, aw, ab, cen, part, nchunk);
+  hipLaunchKernelGGL(nv_vlad_final_kernel, dim3(n), dim3(1024), 0, s, part, nchunk, D, K, out);
   return hipGetLastError();
 }
 hipError_t launch_nv_pca(const float* x, int nfeat, const float* comp, const float* mean, int m, float* y, int n, hipStream_t s) {
