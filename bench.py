@@ -77,6 +77,7 @@ def main():
             from d2slam_amd import netvlad as nvm
             fe.load_netvlad(nvm.synthetic_netvlad_weights())
             gdesc = torch.zeros((F, fe.netvlad_dim), dtype=torch.float32, device=dev)
+            side = torch.cuda.Stream(device=dev)   # NetVLAD's ~60 small kernels overlap the SuperPoint convs on a 2nd HIP stream
 
         # synthetic frames, resident in HBM before the timed region: [L0, R0, L1, R1, ...]
         host = np.empty((NI, H, W), np.uint8)
@@ -113,11 +114,12 @@ def main():
         stream = torch.cuda.current_stream(dev).cuda_stream
 
         def step():
+            if args.netvlad:
+                # left images are rows 0,2,4,... of imgs (image_stride = 2 frames); issued first, on the side stream
+                side.wait_stream(torch.cuda.current_stream(dev))
+                fe.netvlad_device(imgs.data_ptr(), F, W, H, gdesc.data_ptr(), stream=side.cuda_stream, image_stride=2 * H * W)
             fe.extract_device(imgs.data_ptr(), NI, W, H, kps.data_ptr(), scores.data_ptr(), desc.data_ptr(), kidx.data_ptr(),
                               CAP, cnt.data_ptr(), stream=stream)
-            if args.netvlad:
-                # left images are rows 0,2,4,... of imgs: image_stride = 2 frames
-                fe.netvlad_device(imgs.data_ptr(), F, W, H, gdesc.data_ptr(), stream=stream, image_stride=2 * H * W)
             if world > 1:
                 # cross-agent exchange: one all-gather of the fixed-capacity left-image blocks (RCCL over xGMI)
                 swarm.exchange_blocks(desc, cnt, F, rank, world, gath_desc, gath_cnt)
@@ -126,6 +128,8 @@ def main():
             fe.match_batch_device(desc.data_ptr(), desc.data_ptr(), a_off.data_ptr(), b_off.data_ptr(), a_cnt.data_ptr(),
                                   b_cnt.data_ptr(), NP, 256, CAP, mq.data_ptr(), mt.data_ptr(), md.data_ptr(), mn.data_ptr(),
                                   mode=0, ratio=0.8, radius=-1.0, stream=stream)
+            if args.netvlad:
+                torch.cuda.current_stream(dev).wait_stream(side)
             # this step's left descriptors become the "previous keyframe" of the next step
             desc[NI:NI + F].copy_(desc[left_rows])
             cnt[NI:NI + F].copy_(cnt[left_rows])
