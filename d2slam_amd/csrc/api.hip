@@ -133,7 +133,8 @@ int pack_layer(d2fe_context* h, Layer& L, const std::vector<const d2fe_conv_para
     rc = upload(pk.data(), pk.size() * sizeof(float), &L.wpack);
   } else {
     std::vector<uint16_t> pk(packed_weight_halfs_f16x2(cout_pad, cin, ks));
-    pack_weights_f16x2(w.data(), cout, cin, ks, cout_pad, pk.data());
+    if (f16x2_uses_ldsb_layout(cin, ks)) pack_weights_f16x2_ldsb(w.data(), cout, cin, ks, cout_pad, pk.data());
+    else pack_weights_f16x2(w.data(), cout, cin, ks, cout_pad, pk.data());
     rc = upload(pk.data(), pk.size() * sizeof(uint16_t), &L.wpack);
   }
   if (rc) return rc;

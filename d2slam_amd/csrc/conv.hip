@@ -219,6 +219,7 @@ hipError_t launch_conv_f16x2(ConvShape shape, bool pool, bool relu, int cout_pad
 
 hipError_t launch_conv(ConvShape shape, int precision, bool pool, bool relu, int cout_pad, const ConvArgs& a,
                        hipStream_t s) {
+  if (tune_conv_pc() == 1 || (tune_conv_pc() == 2 && shape != CONV1B_FUSED)) return launch_conv_pc(shape, precision, pool, relu, cout_pad, a, s);
   if (precision == 1) return launch_conv_f16x2(shape, pool, relu, cout_pad, a, s);
   switch (shape) {
     case CONV_64_T8x32:

@@ -12,6 +12,11 @@ static inline int tune_ablate() {
   if (v < 0) { const char* e = getenv("D2FE_ABLATE"); v = e ? atoi(e) : 0; }
   return v;
 }
+static inline int tune_conv_pc() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("D2FE_CONV_PC"); v = e ? atoi(e) : 2; }   // 0 off, 1 every layer, 2 every layer but the fused conv1a+conv1b (measured best)
+  return v;
+}
 static inline int tune_conv64() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("D2FE_CONV64_TILE"); v = e ? atoi(e) : 1; }

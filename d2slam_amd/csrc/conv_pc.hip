@@ -1,0 +1,392 @@
+// conv_pc.hip -- persistent producer/consumer version of the SuperPoint conv kernels (both precisions).
+//
+// PMC on the one-tile-per-block kernels (conv.hip / conv_f16.hip) showed the matrix pipe busy only 72 % (fp32) and
+// 44 % (fp16x2) of the time: a block alternates a VALU/VMEM-heavy phase (stage the input patch: loads, conv1a
+// evaluation, hi/lo split, LDS writes; then the epilogue) with its MFMA phase, and the co-resident blocks of a CU run in
+// lock-step, so the phases do not overlap.  Here a workgroup is persistent (one per CU, grid-stride over tiles) and
+// specialised by wave: waves [0, NC) are CONSUMERS (MFMA main loop + epilogue of tile k from LDS buffer k&1), waves
+// [NC, 2NC) are PRODUCERS (stage tile k+1 into buffer (k+1)&1), one __syncthreads() per tile.  Consumer wave i and
+// producer wave NC+i land on the same SIMD, whose matrix and vector pipes then run concurrently.
+//
+// Arithmetic is unchanged: the fp32 path is still the oracle's (ky,kx,ci) fmaf chain (bitwise), the fp16x2 path the
+// same hi/lo split.  Tiling: 4x32 pixels x 64 channels (Cin 64, waves 2x2), 4x16 x 128 (Cin 128 and the 1x1 heads,
+// waves 1x4); 2x2 max-pool stays lane-local for both tile widths.
+#include "conv_common.h"
+
+namespace d2fe {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr int PC_SA = 4, PC_SW = 8;   // fp16x2 power-of-two operand scalings (same as conv_f16.hip)
+
+struct PcTile { int img, ty0, tx0, cg; };
+
+template <int TH, int TW>
+__device__ __forceinline__ PcTile pc_decode(int t, int tiles_x, int tiles_y, int ncg) {
+  PcTile r;
+  r.cg = t % ncg; t /= ncg;
+  r.tx0 = (t % tiles_x) * TW; t /= tiles_x;
+  r.ty0 = (t % tiles_y) * TH;
+  r.img = t / tiles_y;
+  return r;
+}
+
+// pooled epilogue for 16-wide tiles: an m-tile is 2 rows x 16 columns, so both pooling directions stay inside one
+// accumulator (horizontal: registers r, r+1; vertical: r, r+8).
+template <int MT, int NT, bool RELU>
+__device__ __forceinline__ void pc_epilogue_pool16(const ConvArgs& a, f32x16 (&acc)[MT][NT], float scale, int img, int ty0,
+                                                   int tx0, int wm, int ntile0, int lane) {
+  float* out = a.out + (size_t)img * a.out_img_stride + a.out_coff;
+  const int Ho = a.H >> 1, Wo = a.W >> 1;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int oy = (ty0 + (wm * MT + m) * 2) >> 1;
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+      const int col = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);   // even, < 16
+      const int ox = (tx0 + col) >> 1;
+      if (oy < Ho && ox < Wo) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int co = (ntile0 + n) * 32 + (lane & 31);
+          const float m0 = fmaxf(acc[m][n][r], acc[m][n][r + 1]);
+          const float m1 = fmaxf(acc[m][n][r + 8], acc[m][n][r + 9]);
+          float v = fmaxf(m0, m1) * scale;
+          if (RELU) v = v > 0.f ? v : 0.f;
+          if (co < a.cout_real) out[((size_t)oy * Wo + ox) * a.out_cstride + co] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int MODE, int CIN, int KS, int TH, int TW, int WM, int WN, int MT, int NT, bool POOL, bool RELU, bool FUSE1A>
+__global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int tiles_x, int tiles_y, int ncg, int total) {
+  constexpr int NC = WM * WN;            // consumer waves (== producer waves)
+  constexpr int NPT = NC * 64;           // producer threads
+  constexpr int P = KS / 2;
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1, NPIX = PH * PW;
+  constexpr int TAPS = KS * KS;
+  constexpr int CPF = CIN + 1;           // fp32 pixel stride (floats)
+  constexpr int CPH = CIN + 8;           // fp16 pixel stride (halves), per plane
+  constexpr int BUF_BYTES = MODE == 0 ? NPIX * CPF * 4 : NPIX * CPH * 2 * 2;
+  static_assert(TH * TW == WM * MT * 32, "tile / wave mismatch");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool consumer = wave < NC;
+  // kernel-argument pointers copied to locals: inside the by-reference lambdas hipcc otherwise loses their
+  // uniform/read-only provenance and turns the conv1a weight fetches into per-lane vector loads (measured: 480 VMEM/wave/tile)
+  const float* __restrict__ w1a = a.w1a;
+  const float* __restrict__ b1a = a.b1a;
+  const uint8_t* __restrict__ img_base = a.img;
+  const int img_stride_b = a.img_stride;
+  const long img_istride = a.img_istride;
+  const int aH = a.H, aW = a.W;
+
+  // ------------------------------------------------------------------------------------------------ producer
+  auto stage = [&](const PcTile& T, int buf) {
+    const int ptid = tid - NPT;
+    unsigned char* base = lds_raw + (size_t)buf * BUF_BYTES;
+    float* patch = reinterpret_cast<float*>(base);
+    _Float16* hi = reinterpret_cast<_Float16*>(base);
+    _Float16* lo = hi + NPIX * CPH;
+    const float sa = (float)(1 << PC_SA);
+    if constexpr (FUSE1A) {
+      const uint8_t* ip = img_base + (size_t)T.img * img_istride;
+      for (int pix = ptid; pix < ((NPIX + 63) / 64) * 64; pix += NPT) {
+        const int gy = T.ty0 + pix / PW - P, gx = T.tx0 + pix % PW - P;
+        const bool inpatch = pix < NPIX;
+        const bool valid = inpatch && gy >= 0 && gy < aH && gx >= 0 && gx < aW;
+        float v[9];
+        conv1a_load_taps(ip, img_stride_b, aH, aW, valid ? gy : 0, valid ? gx : 0, v);
+#pragma unroll 1
+        for (int oct = 0; oct < 8; ++oct) {
+          float o[8];
+          conv1a_octet(v, w1a, b1a, oct, valid, o);
+          if constexpr (MODE == 0) {
+            if (inpatch) {
+#pragma unroll
+              for (int c = 0; c < 8; ++c) patch[pix * CPF + oct * 8 + c] = o[c];
+            }
+          } else {
+            f16x8 h8, l8;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const float x = fminf(o[c] * sa, 65000.f);
+              const _Float16 h = (_Float16)x;
+              h8[c] = h;
+              l8[c] = (_Float16)(x - (float)h);
+            }
+            if (inpatch) {
+              *reinterpret_cast<f16x8*>(hi + pix * CPH + oct * 8) = h8;
+              *reinterpret_cast<f16x8*>(lo + pix * CPH + oct * 8) = l8;
+            }
+          }
+        }
+      }
+    } else {
+      const float* in = a.in + (size_t)T.img * a.in_img_stride + a.in_coff;
+      constexpr int C4 = CIN / 4;
+      constexpr int TOTAL = NPIX * C4;
+      constexpr int ITERS = (TOTAL + NPT - 1) / NPT;
+      constexpr int UNR = 8;
+      for (int it0 = 0; it0 < ITERS; it0 += UNR) {
+        f32x4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int idx = (it0 + u) * NPT + ptid;
+          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (it0 + u < ITERS && idx < TOTAL) {
+            const int pix = idx / C4, c4 = idx % C4;
+            const int gy = T.ty0 + pix / PW - P, gx = T.tx0 + pix % PW - P;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && !(a.ablate & 1))
+              v[u] = *reinterpret_cast<const f32x4*>(in + ((size_t)gy * a.W + gx) * a.in_cstride + c4 * 4);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int idx = (it0 + u) * NPT + ptid;
+          if (it0 + u < ITERS && idx < TOTAL) {
+            const int pix = idx / C4, c4 = idx % C4;
+            if constexpr (MODE == 0) {
+              float* d = patch + pix * CPF + c4 * 4;
+              d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+            } else {
+              f16x4 h4, l4;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float x = v[u][j] * sa;
+                x = fminf(fmaxf(x, -65000.f), 65000.f);
+                const _Float16 h = (_Float16)x;
+                h4[j] = h;
+                l4[j] = (_Float16)(x - (float)h);
+              }
+              *reinterpret_cast<f16x4*>(hi + pix * CPH + c4 * 4) = h4;
+              *reinterpret_cast<f16x4*>(lo + pix * CPH + c4 * 4) = l4;
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // ------------------------------------------------------------------------------------------------ consumer
+  auto compute = [&](const PcTile& T, int buf) {
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntile0 = T.cg * (WN * NT) + wn * NT;
+    unsigned char* base = lds_raw + (size_t)buf * BUF_BYTES;
+    f32x16 acc[MT][NT];
+    const float bscale = MODE == 0 ? 1.0f : (float)(1 << (PC_SA + PC_SW));
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const float b = a.bias[(ntile0 + n) * 32 + (lane & 31)] * bscale;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = b;
+    }
+    if constexpr (MODE == 0) {
+      const float* patch = reinterpret_cast<const float*>(base);
+      constexpr int C8 = CIN / 8, G = 8, GPT = C8 / G, NG = TAPS * GPT;
+      int aoff[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        int py, px;
+        mtile_pixel<TW>(wm * MT + m, lane & 31, py, px);
+        aoff[m] = (py * PW + px) * CPF + (lane >> 5);
+      }
+      const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack);
+      const f32x4* wbase[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) wbase[n] = wp + (size_t)(ntile0 + n) * TAPS * C8 * 64 + lane;
+      f32x4 bq[2][G][NT];
+      auto load_grp = [&](int b2, int grp) {
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bq[b2][j][n] = wbase[n][(size_t)(grp * G + j) * 64];
+      };
+      auto compute_grp = [&](int b2, int grp) {
+        const int tap = grp / GPT, c80 = (grp % GPT) * G;
+        const int tap_off = ((tap / KS) * PW + (tap % KS)) * CPF + c80 * 8;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          float av[MT][4];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float* ap = patch + aoff[m] + tap_off + j * 8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[m][q] = ap[2 * q];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int n = 0; n < NT; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], bq[b2][j][n][q], acc[m][n], 0, 0, 0);
+        }
+      };
+      load_grp(0, 0);
+#pragma unroll 1
+      for (int g = 0; g + 1 < NG; g += 2) {
+        load_grp(1, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_grp(0, g);
+        load_grp(0, g + 2 < NG ? g + 2 : NG - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_grp(1, g + 1);
+      }
+      if constexpr (NG & 1) compute_grp(0, NG - 1);
+    } else {
+      const _Float16* hi = reinterpret_cast<const _Float16*>(base);
+      const _Float16* lo = hi + NPIX * CPH;
+      constexpr int KST = CIN / 16;
+      int aoff[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        int py, px;
+        mtile_pixel<TW>(wm * MT + m, lane & 31, py, px);
+        aoff[m] = (py * PW + px) * CPH + 8 * (lane >> 5);
+      }
+      const f16x8* wp = reinterpret_cast<const f16x8*>(a.wpack);
+      const f16x8* wbase[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) wbase[n] = wp + (size_t)(ntile0 + n) * TAPS * KST * 128 + lane;
+      // B fragments (hi, lo per n-tile) travel through a register ring R k-steps deep: the load for step s+R-1 is
+      // issued before the MFMAs of step s, so an L2 round trip is covered by (R-1) * 3*MT*NT MFMAs; A fragments
+      // are read one step ahead.  Fully unrolled (static ring indices).
+      constexpr int S = TAPS * KST;
+      constexpr int R = (NT == 2) ? 8 : 10;
+      f16x8 ring[R][NT][2];
+      auto load_step = [&](int slot, int st) {
+        if (a.ablate & 2) st = 0;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          ring[slot][n][0] = wbase[n][(size_t)st * 128];
+          ring[slot][n][1] = wbase[n][(size_t)st * 128 + 64];
+        }
+      };
+      auto a_off = [&](int st) { const int tap = st / KST, ks = st % KST; return ((tap / KS) * PW + (tap % KS)) * CPH + ks * 16; };
+      f16x8 ah[2][MT], al[2][MT];
+      auto load_a = [&](int slot, int st) {
+        const int o = a_off(st);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          ah[slot][m] = *reinterpret_cast<const f16x8*>(hi + aoff[m] + o);
+          al[slot][m] = *reinterpret_cast<const f16x8*>(lo + aoff[m] + o);
+        }
+      };
+#pragma unroll
+      for (int st = 0; st < R - 1 && st < S; ++st) load_step(st, st);
+      load_a(0, 0);
+#pragma unroll
+      for (int st = 0; st < S; ++st) {
+        if (st + R - 1 < S) load_step((st + R - 1) % R, st + R - 1);
+        if (st + 1 < S) load_a((st + 1) & 1, st + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st & 1][m], ring[st % R][n][0], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][m], ring[st % R][n][1], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][m], ring[st % R][n][0], acc[m][n], 0, 0, 0);
+          }
+      }
+    }
+    const float oscale = MODE == 0 ? 1.0f : 1.0f / bscale;
+    if constexpr (POOL && TW == 16)
+      pc_epilogue_pool16<MT, NT, RELU>(a, acc, oscale, T.img, T.ty0, T.tx0, wm, ntile0, lane);
+    else
+      conv_epilogue<TW, MT, NT, POOL, RELU>(a, acc, oscale, T.img, T.ty0, T.tx0, wm, ntile0, lane);
+  };
+
+  // ------------------------------------------------------------------------------------------------ tile loop
+  int t = blockIdx.x;
+  if (t >= total) return;
+  PcTile cur = pc_decode<TH, TW>(t, tiles_x, tiles_y, ncg);
+  if (!consumer) stage(cur, 0);
+  __syncthreads();
+  int buf = 0;
+  for (;;) {
+    const int tn = t + gridDim.x;
+    const bool more = tn < total;
+    PcTile nxt = cur;
+    if (more) nxt = pc_decode<TH, TW>(tn, tiles_x, tiles_y, ncg);
+    if (consumer) { if (!(a.ablate & 16)) compute(cur, buf); }
+    else if (more && !(a.ablate & 8)) stage(nxt, buf ^ 1);
+    __syncthreads();
+    if (!more) break;
+    t = tn; cur = nxt; buf ^= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MODE, int CIN, int KS, int TH, int TW, int WM, int WN, int MT, int NT, bool POOL, bool RELU, bool FUSE1A>
+static hipError_t launch_pc_one(int cout_pad, const ConvArgs& a, hipStream_t s) {
+  constexpr int BN = WN * NT * 32;
+  constexpr int NPIX = (TH + KS - 1) * (TW + KS - 1);
+  constexpr size_t buf = MODE == 0 ? (size_t)NPIX * (CIN + 1) * 4 : (size_t)NPIX * (CIN + 8) * 4;
+  constexpr size_t lds = 2 * buf;
+  static_assert(lds <= 163840, "double-buffered patch does not fit in LDS");
+  if (cout_pad % BN) return hipErrorInvalidValue;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH, ncg = cout_pad / BN;
+  const int total = tiles_x * tiles_y * ncg * a.n_img;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return hipErrorUnknown;
+    ncu = p.multiProcessorCount;
+  }
+  auto k = conv_pc_kernel<MODE, CIN, KS, TH, TW, WM, WN, MT, NT, POOL, RELU, FUSE1A>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const int grid = total < ncu ? total : ncu;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(WM * WN * 128), lds, s, a, tiles_x, tiles_y, ncg, total);
+  return hipGetLastError();
+}
+
+// D2FE_PC_TILE64: 0 (default, measured best) = 4x32 tiles, 2x2 waves; 1 = 8x16-pixel tiles, consumer waves 4(M) x 1(N), every wave all 64 channels (shared B stream);
+//                 0 = 4x32 tiles, 2x2 waves
+static inline int pc_tile64() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("D2FE_PC_TILE64"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
+template <int MODE>
+static hipError_t launch_pc_mode(ConvShape shape, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s) {
+  switch (shape) {
+    case CONV1B_FUSED:
+      if (pc_tile64() == 1) return launch_pc_one<MODE, 64, 3, 8, 16, 4, 1, 1, 2, true, true, true>(cout_pad, a, s);
+      return launch_pc_one<MODE, 64, 3, 4, 32, 2, 2, 2, 1, true, true, true>(cout_pad, a, s);
+    case CONV_64_T8x32:
+      if (pc_tile64() == 1) {
+        if (pool && relu) return launch_pc_one<MODE, 64, 3, 8, 16, 4, 1, 1, 2, true, true, false>(cout_pad, a, s);
+        if (!pool && relu) return launch_pc_one<MODE, 64, 3, 8, 16, 4, 1, 1, 2, false, true, false>(cout_pad, a, s);
+        break;
+      }
+      if (pool && relu) return launch_pc_one<MODE, 64, 3, 4, 32, 2, 2, 2, 1, true, true, false>(cout_pad, a, s);
+      if (!pool && relu) return launch_pc_one<MODE, 64, 3, 4, 32, 2, 2, 2, 1, false, true, false>(cout_pad, a, s);
+      break;
+    case CONV_128_T4x32:   // conv3b: 2x2 pool on 4x16 tiles
+      if (pool && relu) return launch_pc_one<MODE, 128, 3, 4, 16, 1, 4, 2, 1, true, true, false>(cout_pad, a, s);
+      break;
+    case CONV_128_T4x16:
+      if (!pool && relu) return launch_pc_one<MODE, 128, 3, 4, 16, 1, 4, 2, 1, false, true, false>(cout_pad, a, s);
+      break;
+    case CONV_256_1x1_T4x16:
+      if (!pool && !relu) return launch_pc_one<MODE, 256, 1, 4, 16, 1, 4, 2, 1, false, false, false>(cout_pad, a, s);
+      break;
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv_pc(ConvShape shape, int precision, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s) {
+  return precision == 0 ? launch_pc_mode<0>(shape, pool, relu, cout_pad, a, s)
+                        : launch_pc_mode<1>(shape, pool, relu, cout_pad, a, s);
+}
+
+}  // namespace d2fe

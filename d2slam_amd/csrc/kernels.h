@@ -34,6 +34,9 @@ enum ConvShape {
 hipError_t launch_conv(ConvShape shape, int precision, bool pool, bool relu, int cout_pad, const ConvArgs& a,
                        hipStream_t s);
 
+// persistent producer/consumer kernels (conv_pc.hip); same arithmetic, selected by D2FE_CONV_PC (default 1)
+hipError_t launch_conv_pc(ConvShape shape, int precision, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s);
+
 // conv1a: u8 gray [n][H][stride] -> NHWC fp32 [n][H][W][64], fused (float)u8 * (1/255), bias, ReLU.
 hipError_t launch_conv1a(const uint8_t* img, int stride, long img_stride_bytes, int H, int W, int n,
                          const float* w9x64 /*[9][64]*/, const float* bias, float* out, hipStream_t s);
@@ -43,6 +46,8 @@ size_t packed_weight_floats_f32(int cout_pad, int cin, int ks);
 void pack_weights_f32(const float* w /*[cout][cin][k][k]*/, int cout, int cin, int ks, int cout_pad, float* dst);
 size_t packed_weight_halfs_f16x2(int cout_pad, int cin, int ks);
 void pack_weights_f16x2(const float* w, int cout, int cin, int ks, int cout_pad, uint16_t* dst);
+void pack_weights_f16x2_ldsb(const float* w, int cout, int cin, int ks, int cout_pad, uint16_t* dst);
+bool f16x2_uses_ldsb_layout(int cin, int ks);
 
 // ---- post-processing ------------------------------------------------------------------------------
 // softmax(65) -> drop dustbin -> 8x8 unfold; writes dense semi (optional) and appends variant-B candidates
