@@ -4,7 +4,7 @@ TAG=${1:-r01}; PREC=${2:-f32}
 OUT=$PWD/gpurun_out/prof_${TAG}_${PREC}
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 5 --warmup 2 --precision $PREC --no-cpu-baseline"
+BENCH="python $PWD/bench.py --steps 5 --warmup 2 --precision $PREC --single-mode --no-cpu-baseline"
 REPO=$PWD; cd /tmp
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- $BENCH > $OUT/bench_trace.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o p -- $BENCH > $OUT/bench_pmc_sq.log 2>&1
