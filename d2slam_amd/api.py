@@ -75,7 +75,9 @@ EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_creat
            "d2fe_load_superpoint", "d2fe_set_superpoint_pca", "d2fe_desc_dim", "d2fe_superpoint_extract", "d2fe_superpoint_extract_batch",
            "d2fe_superpoint_extract_device", "d2fe_load_netvlad", "d2fe_set_netvlad_pca", "d2fe_netvlad_dim",
            "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device",
-           "d2fe_half_image_filter", "d2fe_debug_read", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read"]
+           "d2fe_half_image_filter", "d2fe_undistort", "d2fe_undistort_device", "d2fe_db_create", "d2fe_db_destroy",
+           "d2fe_db_ntotal", "d2fe_db_add", "d2fe_db_search", "d2fe_db_query_gated", "d2fe_quantize_int8", "d2fe_dequantize_int8",
+           "d2fe_debug_read", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read"]
 
 
 def load_library():
@@ -110,6 +112,19 @@ def load_library():
         lib.d2fe_destroy.argtypes = [C.c_void_p]
         lib.d2fe_load_superpoint.argtypes = [C.c_void_p, C.c_void_p]
         lib.d2fe_sync.argtypes = [C.c_void_p]
+        lib.d2fe_undistort.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_int, C.c_void_p]
+        lib.d2fe_undistort_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.d2fe_db_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.d2fe_db_destroy.argtypes = [C.c_void_p]
+        lib.d2fe_db_destroy.restype = None
+        lib.d2fe_db_ntotal.argtypes = [C.c_void_p]
+        lib.d2fe_db_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.d2fe_db_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.d2fe_db_query_gated.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        lib.d2fe_quantize_int8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.d2fe_dequantize_int8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.d2fe_load_netvlad.argtypes = [C.c_void_p, C.c_void_p]
         lib.d2fe_set_netvlad_pca.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         lib.d2fe_netvlad_dim.argtypes = [C.c_void_p]
@@ -311,6 +326,28 @@ class FrontEnd:
     def netvlad_device(self, d_gray, n, W, H, d_out, stream=None, stride=None, image_stride=None):
         _check(self._lib.d2fe_netvlad_device(self._h, d_gray, n, W, H, stride or W, image_stride or H * W, d_out, stream))
 
+    # ---- SURVEY 8(f) next rows ------------------------------------------------------------------------------------------------
+    def undistort(self, src, mapx, mapy, gain=None):
+        """FisheyeUndist::undist_id_cuda (fisheye_undistort.h:152-176): remap(INTER_LINEAR) [+ photometric gain] -> u8."""
+        src = np.ascontiguousarray(src, np.uint8); mapx = np.ascontiguousarray(mapx, np.float32); mapy = np.ascontiguousarray(mapy, np.float32)
+        g = np.ascontiguousarray(gain, np.float32) if gain is not None else None
+        dst = np.empty(mapx.shape, np.uint8)
+        _check(self._lib.d2fe_undistort(self._h, _ptr(src), src.shape[1], src.shape[0], src.shape[1], _ptr(mapx), _ptr(mapy),
+                                        _ptr(g), mapx.shape[1], mapx.shape[0], _ptr(dst)))
+        return dst
+
+    def quantize_int8(self, x, double_max=False):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1)
+        out = np.empty(x.shape[0], np.int8)
+        _check(self._lib.d2fe_quantize_int8(self._h, _ptr(x), x.shape[0], int(double_max), _ptr(out)))
+        return out
+
+    def dequantize_int8(self, q, landmark_num=-1):
+        q = np.ascontiguousarray(q, np.int8).reshape(-1)
+        out = np.empty(q.shape[0], np.float32)
+        _check(self._lib.d2fe_dequantize_int8(self._h, _ptr(q), q.shape[0], int(landmark_num), _ptr(out)))
+        return out
+
     # ---- matcher -------------------------------------------------------------------------------------------------
     def match_knn(self, desc_a, desc_b, knn_match_ratio=0.8, pts_a=None, pts_b=None, search_local_dist=-1.0):
         a = np.ascontiguousarray(desc_a, np.float32); b = np.ascontiguousarray(desc_b, np.float32)
@@ -340,6 +377,52 @@ class FrontEnd:
         mb = _MatchBatch(d_a, d_b, d_pts_a, d_pts_b, d_a_off, d_b_off, d_a_cnt, d_b_cnt, npairs, dim, max_n, mode,
                          ratio, radius, d_q, d_t, d_dist, d_n)
         _check(self._lib.d2fe_match_batch_device(self._h, C.byref(mb), stream))
+
+
+class FlatIPDatabase:
+    """faiss::IndexFlatIP stand-in for the NetVLAD keyframe database (loop_detector.h:71-72, loop_detector.cpp:254-263,300-350)."""
+
+    def __init__(self, fe: FrontEnd, dim: int, capacity: int = 65536):
+        self._lib = fe._lib
+        self._db = C.c_void_p()
+        self._fe = fe
+        _check(self._lib.d2fe_db_create(fe.handle, dim, capacity, C.byref(self._db)))
+        self.dim = dim
+
+    def close(self):
+        if self._db.value:
+            self._lib.d2fe_db_destroy(self._db)
+            self._db = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ntotal(self):
+        return int(self._lib.d2fe_db_ntotal(self._db))
+
+    def add(self, vecs):
+        v = np.ascontiguousarray(vecs, np.float32).reshape(-1, self.dim)
+        r = int(self._lib.d2fe_db_add(self._db, _ptr(v), v.shape[0]))
+        if r < 0:
+            _check(r)
+        return r
+
+    def search(self, q, k):
+        q = np.ascontiguousarray(q, np.float32).reshape(-1, self.dim)
+        sims = np.zeros((q.shape[0], k), np.float32); labels = np.zeros((q.shape[0], k), np.int32)
+        _check(self._lib.d2fe_db_search(self._db, _ptr(q), q.shape[0], k, _ptr(sims), _ptr(labels)))
+        return sims, labels
+
+    def query_gated(self, q, max_index, thres):
+        """LoopDetector::queryIndexFromDatabase (loop_detector.cpp:300-350) -> (label or -1, similarity)."""
+        q = np.ascontiguousarray(q, np.float32).reshape(self.dim)
+        label = C.c_int32(-1); sim = C.c_float(0)
+        _check(self._lib.d2fe_db_query_gated(self._db, _ptr(q), int(max_index), float(thres), C.byref(label), C.byref(sim)))
+        return int(label.value), float(sim.value)
 
 
 class SuperPoint:

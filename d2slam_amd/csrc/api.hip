@@ -628,6 +628,159 @@ int d2fe_netvlad(d2fe_handle h, const uint8_t* gray, int width, int height, int 
   return d2fe_netvlad_batch(h, gray, 1, width, height, stride, (size_t)stride * height, out);
 }
 
+// ---- SURVEY 8(f) next rows -------------------------------------------------------------------------------------------------
+struct d2fe_db {
+  d2fe_context* h = nullptr;
+  int dim = 0, cap = 0, ntotal = 0;
+  float* vecs = nullptr;
+  float* sims = nullptr;   // [maxq][cap] scratch
+  float* q = nullptr;      // staged queries
+  float* osims = nullptr; int32_t* olabels = nullptr;
+  std::mutex mu;
+};
+namespace { constexpr int DB_MAXQ = 8, DB_MAXK = 1024; }
+
+int d2fe_undistort_device(d2fe_handle h, const uint8_t* d_src, int n, int sw, int sh, int sstride, size_t src_image_stride,
+                          const float* d_mapx, const float* d_mapy, const float* d_gain, int dw, int dh, uint8_t* d_dst,
+                          void* stream) {
+  if (!h || !d_src || !d_mapx || !d_mapy || !d_dst) return fail(D2FE_ERR_INVALID, "null argument");
+  if (n < 1 || sw < 1 || sh < 1 || sstride < sw || dw < 1 || dh < 1) return fail(D2FE_ERR_INVALID, "bad geometry");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(launch_undistort(d_src, sh, sw, sstride, (long)src_image_stride, d_mapx, d_mapy, d_gain, dh, dw, n, d_dst,
+                           stream ? (hipStream_t)stream : h->stream));
+  return D2FE_OK;
+}
+
+int d2fe_undistort(d2fe_handle h, const uint8_t* src, int sw, int sh, int sstride, const float* mapx, const float* mapy,
+                   const float* gain, int dw, int dh, uint8_t* dst) {
+  if (!h || !src || !mapx || !mapy || !dst) return fail(D2FE_ERR_INVALID, "null argument");
+  if (sw < 1 || sh < 1 || sstride < sw || dw < 1 || dh < 1) return fail(D2FE_ERR_INVALID, "bad geometry");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  const size_t sb = (size_t)sstride * sh, mb = sizeof(float) * (size_t)dw * dh, db = (size_t)dw * dh;
+  char* buf = nullptr;
+  HIP_TRY(hipMalloc(&buf, sb + 3 * mb + db + 64));
+  uint8_t* d_src = reinterpret_cast<uint8_t*>(buf);
+  float* d_mx = reinterpret_cast<float*>(buf + ((sb + 15) / 16) * 16);
+  float* d_my = d_mx + db; float* d_g = d_my + db;
+  uint8_t* d_dst = reinterpret_cast<uint8_t*>(d_g + db);
+  hipStream_t s = h->stream;
+  int rc = D2FE_OK;
+  auto chk = [&](hipError_t e, const char* w) { if (e != hipSuccess && rc == D2FE_OK) rc = fail(D2FE_ERR_HIP, std::string(w) + ": " + hipGetErrorString(e)); };
+  chk(hipMemcpyAsync(d_src, src, sb, hipMemcpyHostToDevice, s), "H2D src");
+  chk(hipMemcpyAsync(d_mx, mapx, mb, hipMemcpyHostToDevice, s), "H2D mapx");
+  chk(hipMemcpyAsync(d_my, mapy, mb, hipMemcpyHostToDevice, s), "H2D mapy");
+  if (gain) chk(hipMemcpyAsync(d_g, gain, mb, hipMemcpyHostToDevice, s), "H2D gain");
+  if (rc == D2FE_OK) chk(launch_undistort(d_src, sh, sw, sstride, 0, d_mx, d_my, gain ? d_g : nullptr, dh, dw, 1, d_dst, s), "undistort");
+  if (rc == D2FE_OK) chk(hipMemcpyAsync(dst, d_dst, db, hipMemcpyDeviceToHost, s), "D2H");
+  chk(hipStreamSynchronize(s), "sync");
+  hipFree(buf);
+  return rc;
+}
+
+int d2fe_db_create(d2fe_handle h, int dim, int capacity, d2fe_db_handle* out) {
+  if (!h || !out) return fail(D2FE_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (dim < 4 || (dim & 3) || dim > 8192 || capacity < 1) return fail(D2FE_ERR_INVALID, "dim must be a multiple of 4 in 4..8192, capacity >= 1");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  d2fe_db* db = new d2fe_db();
+  db->h = h; db->dim = dim; db->cap = capacity;
+  HIP_TRY(hipMalloc(&db->vecs, sizeof(float) * (size_t)dim * capacity));
+  HIP_TRY(hipMalloc(&db->sims, sizeof(float) * (size_t)DB_MAXQ * capacity));
+  HIP_TRY(hipMalloc(&db->q, sizeof(float) * (size_t)DB_MAXQ * dim));
+  HIP_TRY(hipMalloc(&db->osims, sizeof(float) * DB_MAXQ * DB_MAXK));
+  HIP_TRY(hipMalloc(&db->olabels, sizeof(int32_t) * DB_MAXQ * DB_MAXK));
+  *out = db;
+  return D2FE_OK;
+}
+
+void d2fe_db_destroy(d2fe_db_handle db) {
+  if (!db) return;
+  hipSetDevice(db->h->cfg.device_id);
+  for (void* p : {(void*)db->vecs, (void*)db->sims, (void*)db->q, (void*)db->osims, (void*)db->olabels}) if (p) hipFree(p);
+  delete db;
+}
+
+int d2fe_db_ntotal(d2fe_db_handle db) { return db ? db->ntotal : fail(D2FE_ERR_INVALID, "null db"); }
+
+int d2fe_db_add(d2fe_db_handle db, const float* vecs, int n) {
+  if (!db || !vecs || n < 1) return fail(D2FE_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lk(db->mu);
+  if (db->ntotal + n > db->cap) return fail(D2FE_ERR_TRUNCATED, "database capacity exceeded");
+  HIP_TRY(hipSetDevice(db->h->cfg.device_id));
+  HIP_TRY(hipMemcpy(db->vecs + (size_t)db->ntotal * db->dim, vecs, sizeof(float) * (size_t)n * db->dim, hipMemcpyHostToDevice));
+  const int first = db->ntotal;
+  db->ntotal += n;
+  return first;
+}
+
+int d2fe_db_search(d2fe_db_handle db, const float* q, int nq, int k, float* sims, int32_t* labels) {
+  if (!db || !q || !sims || !labels) return fail(D2FE_ERR_INVALID, "null argument");
+  if (nq < 1 || nq > DB_MAXQ || k < 1 || k > DB_MAXK || (size_t)nq * db->dim * 4 > 65536) return fail(D2FE_ERR_INVALID, "nq/k out of range");
+  std::lock_guard<std::mutex> lk(db->mu);
+  for (int i = 0; i < nq * k; ++i) { labels[i] = -1; sims[i] = 0.f; }
+  if (db->ntotal == 0) return D2FE_OK;
+  HIP_TRY(hipSetDevice(db->h->cfg.device_id));
+  hipStream_t s = db->h->stream;
+  const int kk = k < db->ntotal ? k : db->ntotal;
+  HIP_TRY(hipMemcpyAsync(db->q, q, sizeof(float) * (size_t)nq * db->dim, hipMemcpyHostToDevice, s));
+  HIP_TRY(launch_db_search(db->vecs, db->ntotal, db->dim, db->q, nq, kk, db->sims, db->olabels, db->osims, s));
+  std::vector<float> hs((size_t)nq * kk); std::vector<int32_t> hl((size_t)nq * kk);
+  HIP_TRY(hipMemcpyAsync(hs.data(), db->osims, sizeof(float) * hs.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(hl.data(), db->olabels, sizeof(int32_t) * hl.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int qi = 0; qi < nq; ++qi)
+    for (int r = 0; r < kk; ++r) { sims[(size_t)qi * k + r] = hs[(size_t)qi * kk + r]; labels[(size_t)qi * k + r] = hl[(size_t)qi * kk + r]; }
+  return D2FE_OK;
+}
+
+int d2fe_db_query_gated(d2fe_db_handle db, const float* q, int max_index, double thres, int32_t* label, float* sim) {
+  if (!db || !q || !label || !sim || max_index < 0) return fail(D2FE_ERR_INVALID, "bad argument");
+  *label = -1; *sim = 0.f;
+  const int ntotal = db->ntotal;
+  int k = 5 + max_index;                      // SEARCH_NEAREST_NUM, d2frontend_params.h:22
+  if (k > ntotal) k = ntotal;
+  if (k <= 0) return D2FE_OK;
+  if (k > DB_MAXK) k = DB_MAXK;
+  std::vector<float> s(k); std::vector<int32_t> l(k);
+  int rc = d2fe_db_search(db, q, 1, k, s.data(), l.data());
+  if (rc) return rc;
+  for (int i = 0; i < k; ++i) {
+    if (l[i] < 0) continue;
+    if (l[i] <= ntotal - max_index && (double)s[i] > thres) { *label = l[i]; *sim = s[i]; return D2FE_OK; }
+  }
+  return D2FE_OK;
+}
+
+static int codec_run(d2fe_handle h, const void* in, size_t in_bytes, void* out, size_t out_bytes, int n, int arg, bool quant) {
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  char* buf = nullptr;
+  HIP_TRY(hipMalloc(&buf, in_bytes + out_bytes + 64));
+  char* d_out = buf + ((in_bytes + 15) / 16) * 16;
+  hipStream_t s = h->stream;
+  int rc = D2FE_OK;
+  auto chk = [&](hipError_t e, const char* w) { if (e != hipSuccess && rc == D2FE_OK) rc = fail(D2FE_ERR_HIP, std::string(w) + ": " + hipGetErrorString(e)); };
+  chk(hipMemcpyAsync(buf, in, in_bytes, hipMemcpyHostToDevice, s), "H2D");
+  if (rc == D2FE_OK) {
+    if (quant) chk(launch_quant_int8(reinterpret_cast<const float*>(buf), n, arg, reinterpret_cast<int8_t*>(d_out), s), "quant");
+    else chk(launch_dequant_int8(reinterpret_cast<const int8_t*>(buf), n, arg, reinterpret_cast<float*>(d_out), s), "dequant");
+  }
+  if (rc == D2FE_OK) chk(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s), "D2H");
+  chk(hipStreamSynchronize(s), "sync");
+  hipFree(buf);
+  return rc;
+}
+
+int d2fe_quantize_int8(d2fe_handle h, const float* x, int n, int double_max, int8_t* out) {
+  if (!h || !x || !out || n < 1) return fail(D2FE_ERR_INVALID, "bad argument");
+  return codec_run(h, x, sizeof(float) * (size_t)n, out, (size_t)n, n, double_max ? 1 : 0, true);
+}
+
+int d2fe_dequantize_int8(d2fe_handle h, const int8_t* q, int n, int landmark_num, float* out) {
+  if (!h || !q || !out || n < 1) return fail(D2FE_ERR_INVALID, "bad argument");
+  if (landmark_num >= 0 && (n & 31)) return fail(D2FE_ERR_INVALID, "landmark descriptors: n must be a multiple of 32");
+  return codec_run(h, q, (size_t)n, out, sizeof(float) * (size_t)n, n, landmark_num, false);
+}
+
 int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* stream) {
   if (!h || !mb) return fail(D2FE_ERR_INVALID, "null argument");
   if (mb->npairs < 1 || mb->max_n < 1 || mb->max_n > 1024) return fail(D2FE_ERR_INVALID, "npairs/max_n out of range (max_n <= 1024)");

@@ -81,6 +81,14 @@ hipError_t launch_nv_vlad(const float* x, int np, int D, int K, const float* aw,
                           float* out, int n, hipStream_t s);
 hipError_t launch_nv_pca(const float* x, int nfeat, const float* comp, const float* mean, int m, float* y, int n, hipStream_t s);
 
+// ---- SURVEY 8(f) next rows (next.hip) ------------------------------------------------------------------------------------
+hipError_t launch_undistort(const uint8_t* src, int sh, int sw, int sstride, long src_istride, const float* mapx,
+                            const float* mapy, const float* gain, int dh, int dw, int n, uint8_t* dst, hipStream_t s);
+hipError_t launch_db_search(const float* db, int ntotal, int dim, const float* q, int nq, int k, float* sims_scratch,
+                            int32_t* labels, float* out_sims, hipStream_t s);
+hipError_t launch_quant_int8(const float* x, int n, int double_max, int8_t* out, hipStream_t s);
+hipError_t launch_dequant_int8(const int8_t* q, int n, int landmark_num, float* out, hipStream_t s);
+
 // ---- matcher --------------------------------------------------------------------------------------
 struct MatchArgs {
   const float* a; const float* b; const float* pts_a; const float* pts_b;

@@ -1,0 +1,188 @@
+// next.hip -- the components either side of the hot path that SURVEY.md section 8(f) ranks "next":
+//  (f)-1 fisheye undistort + photometric gain  (FisheyeUndist::undist_id_cuda, d2common/include/d2common/fisheye_undistort.h:152-176)
+//  (f)-2 NetVLAD database add/search + gate     (faiss::IndexFlatIP in d2frontend/src/loop_detector.cpp:254-263,300-350)
+//  (f)-3 int8 wire codec of descriptors         (d2common/include/d2common/d2frontend_types.h:228-237,260-268,313-351)
+// All three are HBM/latency-bound byte and float work: coalesced loads, wave reductions, no MFMA.
+#include "kernels.h"
+
+namespace d2fe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ unsigned sat_u8(float v) {   // saturate_cast<uchar>(float): round-to-nearest-even, clamp
+  if (!(v > 0.f)) return 0u;
+  if (v >= 255.f) return 255u;
+  return (unsigned)__builtin_rintf(v);
+}
+
+// ---- (f)-1: one fused pass instead of remap -> convertTo -> multiply -> convertTo (4 kernels, 3 round trips) -----------------
+// The two roundings of the reference (after the remap and after the gain) are both reproduced, in registers.
+__global__ __launch_bounds__(256) void undistort_kernel(const uint8_t* __restrict__ src, int sh, int sw, int sstride,
+                                                        long src_istride, const float* __restrict__ mapx,
+                                                        const float* __restrict__ mapy, const float* __restrict__ gain,
+                                                        int npix, uint8_t* __restrict__ dst) {
+  const int n = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix) return;
+  const uint8_t* s = src + (size_t)n * src_istride;
+  const float x = mapx[i], y = mapy[i];
+  const int x1 = (int)__builtin_floorf(x), y1 = (int)__builtin_floorf(y), x2 = x1 + 1, y2 = y1 + 1;
+  auto S = [&](int yy, int xx) -> float {
+    return (yy >= 0 && yy < sh && xx >= 0 && xx < sw) ? (float)s[(size_t)yy * sstride + xx] : 0.f;
+  };
+  float out = 0.f;
+  out = out + S(y1, x1) * (((float)x2 - x) * ((float)y2 - y));
+  out = out + S(y1, x2) * ((x - (float)x1) * ((float)y2 - y));
+  out = out + S(y2, x1) * (((float)x2 - x) * (y - (float)y1));
+  out = out + S(y2, x2) * ((x - (float)x1) * (y - (float)y1));
+  unsigned u = sat_u8(out);
+  if (gain) u = sat_u8((float)u * gain[i]);
+  dst[(size_t)n * npix + i] = (uint8_t)u;
+}
+
+hipError_t launch_undistort(const uint8_t* src, int sh, int sw, int sstride, long src_istride, const float* mapx,
+                            const float* mapy, const float* gain, int dh, int dw, int n, uint8_t* dst, hipStream_t s) {
+  const int npix = dh * dw;
+  hipLaunchKernelGGL(undistort_kernel, dim3((npix + 255) / 256, n), dim3(256), 0, s, src, sh, sw, sstride, src_istride, mapx,
+                     mapy, gain, npix, dst);
+  return hipGetLastError();
+}
+
+// ---- (f)-2: flat inner-product database ------------------------------------------------------------------------------------------
+// sims[q][i] = <db[i], query[q]>: one wave per database row, the row is read once (coalesced float4) and reused for every
+// query of the batch (queries staged in LDS).  HBM-bound: ntotal*dim*4 bytes per search.
+__global__ __launch_bounds__(256) void db_sims_kernel(const float* __restrict__ db, int ntotal, int dim,
+                                                      const float* __restrict__ q, int nq, float* __restrict__ sims) {
+  extern __shared__ float qs[];   // [nq][dim]
+  for (int i = threadIdx.x; i < nq * dim; i += 256) qs[i] = q[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= ntotal) return;
+  const float* r = db + (size_t)row * dim;
+  for (int qi = 0; qi < nq; ++qi) {
+    float a = 0.f;
+    for (int j = lane * 4; j < dim; j += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(r + j);
+      const float* qq = qs + qi * dim + j;
+      a = __builtin_fmaf(v[0], qq[0], a); a = __builtin_fmaf(v[1], qq[1], a);
+      a = __builtin_fmaf(v[2], qq[2], a); a = __builtin_fmaf(v[3], qq[3], a);
+    }
+    a = wsum(a);
+    if (lane == 0) sims[(size_t)qi * ntotal + row] = a;
+  }
+}
+
+// top-k per query by (similarity desc, label asc): k rounds of a block-wide arg-max over keys (sim bits, ~label).
+__global__ __launch_bounds__(1024) void db_topk_kernel(float* __restrict__ sims, int ntotal, int k, int32_t* __restrict__ labels,
+                                                       float* __restrict__ out_sims) {
+  __shared__ unsigned long long red[16];
+  const int qi = blockIdx.x, tid = threadIdx.x;
+  float* s = sims + (size_t)qi * ntotal;
+  for (int r = 0; r < k; ++r) {
+    unsigned long long best = 0;
+    for (int i = tid; i < ntotal; i += 1024) {
+      const float v = s[i];
+      unsigned b = __float_as_uint(v);
+      b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);          // order-preserving map of float to unsigned
+      const unsigned long long key = ((unsigned long long)b << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+      if (__float_as_uint(v) != 0xFFFFFFFFu && key > best) best = key;   // all-ones NaN pattern marks "already taken"
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long t = __shfl_xor(best, o, 64);
+      best = t > best ? t : best;
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long b = 0;
+      for (int w = 0; w < 16; ++w) b = red[w] > b ? red[w] : b;
+      const int idx = (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFull));
+      labels[(size_t)qi * k + r] = b ? idx : -1;
+      out_sims[(size_t)qi * k + r] = b ? s[idx] : 0.f;
+      if (b) s[idx] = __uint_as_float(0xFFFFFFFFu);
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_db_search(const float* db, int ntotal, int dim, const float* q, int nq, int k, float* sims_scratch,
+                            int32_t* labels, float* out_sims, hipStream_t s) {
+  const size_t lds = sizeof(float) * (size_t)nq * dim;
+  if (lds > 64 * 1024 || (dim & 3)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(db_sims_kernel, dim3((ntotal + 3) / 4), dim3(256), lds, s, db, ntotal, dim, q, nq, sims_scratch);
+  hipLaunchKernelGGL(db_topk_kernel, dim3(nq), dim3(1024), 0, s, sims_scratch, ntotal, k, labels, out_sims);
+  return hipGetLastError();
+}
+
+// ---- (f)-3: int8 codec ----------------------------------------------------------------------------------------------------------------
+// quantise: q = (int8)(x / max|x| * 127) (C cast = truncation); max over the whole tensor (one block per tensor).
+__global__ __launch_bounds__(1024) void quant_int8_kernel(const float* __restrict__ x, int n, int double_max,
+                                                          int8_t* __restrict__ out) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x;
+  float m = 0.f;
+  for (int i = tid; i < n; i += 1024) m = fmaxf(m, __builtin_fabsf(x[i]));
+  m = wmax(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = 0.f;
+  for (int w = 0; w < 16; ++w) m = fmaxf(m, red[w]);
+  if (double_max) {
+    const double md = (double)m;
+    for (int i = tid; i < n; i += 1024) out[i] = (int8_t)(int)((double)x[i] / md * 127.0);
+  } else {
+    for (int i = tid; i < n; i += 1024) out[i] = (int8_t)(int)(x[i] / m * 127.0f);
+  }
+}
+// dequantise: x = (float)(q / 127.0); landmark descriptors: every 32-float segment i < landmark_num re-normalised
+// (the reference's hard-coded 32, d2frontend_types.h:326-328); global descriptor (landmark_num < 0): whole-vector L2.
+__global__ __launch_bounds__(1024) void dequant_int8_kernel(const int8_t* __restrict__ q, int n, int landmark_num,
+                                                            float* __restrict__ out) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x;
+  if (landmark_num >= 0) {
+    for (int i = tid; i < n; i += 1024) {
+      const float v = (float)((double)q[i] / 127.0);
+      const int seg = i >> 5;
+      // 32 consecutive lanes hold one segment: reduce within the half-wave
+      float s = v * v;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const bool full = (seg + 1) * 32 <= n;
+      out[i] = (seg < landmark_num && full) ? v / __builtin_sqrtf(s) : v;
+    }
+  } else {
+    float s = 0.f;
+    for (int i = tid; i < n; i += 1024) { const float v = (float)((double)q[i] / 127.0); s += v * v; }
+    s = wsum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    const float nr = __builtin_sqrtf(t);
+    for (int i = tid; i < n; i += 1024) out[i] = (float)((double)q[i] / 127.0) / nr;
+  }
+}
+
+hipError_t launch_quant_int8(const float* x, int n, int double_max, int8_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(quant_int8_kernel, dim3(1), dim3(1024), 0, s, x, n, double_max, out);
+  return hipGetLastError();
+}
+hipError_t launch_dequant_int8(const int8_t* q, int n, int landmark_num, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(dequant_int8_kernel, dim3(1), dim3(1024), 0, s, q, n, landmark_num, out);
+  return hipGetLastError();
+}
+
+}  // namespace d2fe

@@ -193,6 +193,39 @@ D2FE_API int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, 
 D2FE_API int d2fe_half_image_filter(const float* pts_xy, int n, int require_left, int width_undistort,
                                     double undistort_fov, int32_t* map, int* n_out);
 
+/* ---- the components either side of the hot path --------------------------------------------------
+ * (f)-1 Fisheye undistort + photometric gain.  Replaces FisheyeUndist::undist_id_cuda
+ * (d2common/include/d2common/fisheye_undistort.h:152-176: cv::cuda::remap(INTER_LINEAR, constant 0 border) -> convertTo(32F)
+ * -> cv::cuda::multiply(gain) -> convertTo(8U)) by one fused kernel.  mapx/mapy: dh*dw floats (source coordinates, the
+ * reference's undistMapsGPUX/Y); gain: dh*dw floats or NULL.  Host-pointer form and device-resident form (n frames
+ * sharing the maps, frame i at d_src + i*src_image_stride, output i at d_dst + i*dh*dw). */
+D2FE_API int d2fe_undistort(d2fe_handle h, const uint8_t* src, int sw, int sh, int sstride, const float* mapx,
+                            const float* mapy, const float* gain, int dw, int dh, uint8_t* dst);
+D2FE_API int d2fe_undistort_device(d2fe_handle h, const uint8_t* d_src, int n, int sw, int sh, int sstride,
+                                   size_t src_image_stride, const float* d_mapx, const float* d_mapy, const float* d_gain,
+                                   int dw, int dh, uint8_t* d_dst, void* stream);
+
+/* (f)-2 NetVLAD keyframe database.  Replaces faiss::IndexFlatIP (members d2frontend/include/d2frontend/loop_detector.h:71-72;
+ * add d2frontend/src/loop_detector.cpp:254-263; search :318) and the gate of LoopDetector::queryIndexFromDatabase
+ * (:300-350).  Vectors live in HBM; a search is one streaming pass over the database. */
+typedef struct d2fe_db* d2fe_db_handle;
+D2FE_API int d2fe_db_create(d2fe_handle h, int dim, int capacity, d2fe_db_handle* out);
+D2FE_API void d2fe_db_destroy(d2fe_db_handle db);
+D2FE_API int d2fe_db_ntotal(d2fe_db_handle db);
+D2FE_API int d2fe_db_add(d2fe_db_handle db, const float* vecs, int n);        /* IndexFlatIP::add; returns first new label or <0 */
+/* IndexFlatIP::search(nq, q, k, sims, labels): k best by inner product, descending (ties: lower label); -1 pads. */
+D2FE_API int d2fe_db_search(d2fe_db_handle db, const float* q, int nq, int k, float* sims, int32_t* labels);
+/* queryIndexFromDatabase (loop_detector.cpp:300-350) minus the ROS bookkeeping: k = min(5 + max_index, ntotal) nearest;
+ * the first with label <= ntotal - max_index and similarity > thres is returned in *label (else -1) with its similarity. */
+D2FE_API int d2fe_db_query_gated(d2fe_db_handle db, const float* q, int max_index, double thres, int32_t* label, float* sim);
+
+/* (f)-3 int8 wire codec.  Replaces the quantisation in VisualImageDesc::toLCM (d2common/include/d2common/d2frontend_types.h:
+ * 228-237 landmark descriptors, float max; 260-268 NetVLAD, double max: pass double_max = 1) and the decode of the LCM
+ * constructor (:313-351): x = q/127.0; landmark_num >= 0: the first landmark_num 32-float segments are re-normalised
+ * (the reference's hard-coded 32); landmark_num < 0: whole-vector L2 (global descriptor). */
+D2FE_API int d2fe_quantize_int8(d2fe_handle h, const float* x, int n, int double_max, int8_t* out);
+D2FE_API int d2fe_dequantize_int8(d2fe_handle h, const int8_t* q, int n, int landmark_num, float* out);
+
 /* Debug/inspection: copy an internal device tensor of the last extract call to the host.
  * names: "conv1a".."conv4b","convPaDa","logits","desc_raw","semi".  Returns bytes copied or <0. */
 D2FE_API long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_bytes);

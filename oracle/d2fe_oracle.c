@@ -590,3 +590,99 @@ ORC_API void orc_netvlad_pca(const float* x, int n, const float* comp, const flo
   for (int i = 0; i < m; ++i) out[i] = (float)(y[i] / nt);
   free(y);
 }
+
+/* ==========================================================================================
+ * SURVEY.md section 8(f) "next" rows
+ * ========================================================================================== */
+
+/* (f)-1 fisheye undistort + photometric gain.  Reference: FisheyeUndist::undist_id_cuda,
+ * d2common/include/d2common/fisheye_undistort.h:152-176: cv::cuda::remap(INTER_LINEAR (:28), BORDER_CONSTANT 0) ->
+ * convertTo(CV_32F) -> cv::cuda::multiply(gain) -> convertTo(CV_8U).
+ * Third-party arithmetic restated (OpenCV 4.10 cudev LinearFilter + saturate_cast, not in /root/reference):
+ * x1 = floor(x), x2 = x1+1; out = 0; out += src(y1,x1)*((x2-x)*(y2-y)); += src(y1,x2)*((x-x1)*(y2-y));
+ * += src(y2,x1)*((x2-x)*(y-y1)); += src(y2,x2)*((x-x1)*(y-y1)) with zero outside the image, separate mul and add;
+ * saturate_cast<uchar>(float) = round-to-nearest-even, clamped to [0,255]. */
+static uint8_t orc_sat_u8(float v) {
+  if (!(v > 0.f)) return 0;
+  if (v >= 255.f) return 255;
+  return (uint8_t)rintf(v);
+}
+ORC_API void orc_undistort(const uint8_t* src, int sh, int sw, int sstride, const float* mapx, const float* mapy,
+                           const float* gain, int dh, int dw, uint8_t* dst) {
+  for (int i = 0; i < dh * dw; ++i) {
+    const float x = mapx[i], y = mapy[i];
+    const float fx = floorf(x), fy = floorf(y);
+    const int x1 = (int)fx, y1 = (int)fy, x2 = x1 + 1, y2 = y1 + 1;
+#define ORC_S(yy, xx) (((yy) >= 0 && (yy) < sh && (xx) >= 0 && (xx) < sw) ? (float)src[(size_t)(yy) * sstride + (xx)] : 0.f)
+    float out = 0.f;
+    out = out + ORC_S(y1, x1) * (((float)x2 - x) * ((float)y2 - y));
+    out = out + ORC_S(y1, x2) * ((x - (float)x1) * ((float)y2 - y));
+    out = out + ORC_S(y2, x1) * (((float)x2 - x) * (y - (float)y1));
+    out = out + ORC_S(y2, x2) * ((x - (float)x1) * (y - (float)y1));
+#undef ORC_S
+    uint8_t u = orc_sat_u8(out);
+    if (gain) u = orc_sat_u8((float)u * gain[i]);
+    dst[i] = u;
+  }
+}
+
+/* (f)-2 NetVLAD database: faiss::IndexFlatIP add/search (d2frontend/src/loop_detector.cpp:254-263,318) and the gate of
+ * LoopDetector::queryIndexFromDatabase (:300-350): k = min(SEARCH_NEAREST_NUM(5) + max_index, ntotal) nearest by inner
+ * product, descending; the first one with label <= ntotal - max_index and similarity > thres wins.
+ * faiss 1.7.4's SIMD summation order and heap tie order are unspecified; the oracle uses a sequential fmaf dot and
+ * breaks similarity ties by the lower label.  Returns the gated label (or -1); fills the k labels / similarities. */
+ORC_API int orc_db_query(const float* db, int ntotal, int dim, const float* q, int search_nearest, int max_index,
+                         double thres, int32_t* labels, float* sims, int* k_out, float* sim_out) {
+  int k = search_nearest + max_index;
+  if (k > ntotal) k = ntotal;
+  *k_out = k > 0 ? k : 0;
+  if (k <= 0) return -1;
+  float* s = (float*)malloc(sizeof(float) * ntotal);
+  for (int i = 0; i < ntotal; ++i) {
+    float a = 0.f;
+    for (int j = 0; j < dim; ++j) a = fmaf(db[(size_t)i * dim + j], q[j], a);
+    s[i] = a;
+  }
+  uint8_t* used = (uint8_t*)calloc(ntotal, 1);
+  for (int r = 0; r < k; ++r) {
+    int best = -1;
+    for (int i = 0; i < ntotal; ++i)
+      if (!used[i] && (best < 0 || s[i] > s[best])) best = i;
+    used[best] = 1; labels[r] = best; sims[r] = s[best];
+  }
+  free(used); free(s);
+  for (int r = 0; r < k; ++r)
+    if (labels[r] <= ntotal - max_index && (double)sims[r] > thres) { *sim_out = sims[r]; return labels[r]; }
+  return -1;
+}
+
+/* (f)-3 int8 wire codec of descriptors.  Reference: VisualImageDesc::toLCM
+ * (d2common/include/d2common/d2frontend_types.h:228-237 landmark descriptors: float max; :260-268 NetVLAD: double max)
+ * and the LCM constructor (:313-351): x = q/127.0, landmark descriptors re-normalised in hard-coded 32-float segments
+ * for i < landmark_num (:326-328), the global descriptor normalised as a whole (:337). */
+ORC_API void orc_quant_int8(const float* x, int n, int double_max, int8_t* out) {
+  float m = 0.f;
+  for (int i = 0; i < n; ++i) { const float a = fabsf(x[i]); if (a > m) m = a; }
+  if (double_max) {
+    const double md = (double)m;
+    for (int i = 0; i < n; ++i) out[i] = (int8_t)((double)x[i] / md * 127);
+  } else {
+    for (int i = 0; i < n; ++i) out[i] = (int8_t)(x[i] / m * 127);
+  }
+}
+ORC_API void orc_dequant_int8(const int8_t* q, int n, int landmark_num, float* out) {
+  for (int i = 0; i < n; ++i) out[i] = (float)((double)q[i] / 127.0);
+  if (landmark_num >= 0) {
+    for (int i = 0; i < landmark_num && (i + 1) * 32 <= n; ++i) {
+      float s = 0.f;
+      for (int j = 0; j < 32; ++j) s += out[i * 32 + j] * out[i * 32 + j];
+      const float nr = sqrtf(s);
+      for (int j = 0; j < 32; ++j) out[i * 32 + j] = out[i * 32 + j] / nr;
+    }
+  } else {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += out[i] * out[i];
+    const float nr = sqrtf(s);
+    for (int i = 0; i < n; ++i) out[i] = out[i] / nr;
+  }
+}

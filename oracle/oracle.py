@@ -259,3 +259,37 @@ def netvlad_forward(img_u8, nv, pca=None, return_layers=False):
     if return_layers:
         return out, outs, feat, raw
     return out
+
+
+# ---- SURVEY.md section 8(f) next rows -----------------------------------------------------------------------------------
+def undistort(src_u8, mapx, mapy, gain=None):
+    src = np.ascontiguousarray(src_u8, np.uint8); mapx = _f(mapx); mapy = _f(mapy)
+    sh, sw = src.shape; dh, dw = mapx.shape
+    dst = np.empty((dh, dw), np.uint8)
+    g = _f(gain) if gain is not None else None
+    lib().orc_undistort(_p(src), sh, sw, sw, _p(mapx), _p(mapy), _p(g) if g is not None else None, dh, dw, _p(dst))
+    return dst
+
+
+def db_query(db, q, max_index, thres, search_nearest=5):
+    db = _f(db); q = _f(q)
+    ntotal, dim = db.shape
+    k = C.c_int(0); sim = C.c_float(0)
+    labels = np.empty(max(search_nearest + max_index, 1), np.int32); sims = np.empty_like(labels, dtype=np.float32)
+    r = lib().orc_db_query(_p(db), ntotal, dim, _p(q), search_nearest, max_index, C.c_double(thres), _p(labels), _p(sims),
+                           C.byref(k), C.byref(sim))
+    return int(r), float(sim.value), labels[:k.value].copy(), sims[:k.value].copy()
+
+
+def quant_int8(x, double_max=False):
+    x = _f(x).reshape(-1)
+    out = np.empty(x.shape[0], np.int8)
+    lib().orc_quant_int8(_p(x), x.shape[0], int(double_max), _p(out))
+    return out
+
+
+def dequant_int8(q, landmark_num=-1):
+    q = np.ascontiguousarray(q, np.int8).reshape(-1)
+    out = np.empty(q.shape[0], np.float32)
+    lib().orc_dequant_int8(_p(q), q.shape[0], landmark_num, _p(out))
+    return out
