@@ -51,12 +51,24 @@ __device__ __forceinline__ void mtile_pixel(int mt, int i, int& py, int& px) {
 __device__ __forceinline__ void conv1a_load_taps(const uint8_t* __restrict__ img, int stride, int H, int W, int gy, int gx,
                                                  float (&v)[9]) {
   const float scale = (float)(1.0 / 255.0);
+  // unconditional loads from clamped coordinates (all nine in flight at once; a branch per tap made hipcc wait for each
+  // byte separately: ~9 serialized global round trips per tile), then the zero padding is applied by a select
+  unsigned char raw[9];
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int yy = gy + ky - 1, xx = gx + kx - 1;
-      v[ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (float)img[(size_t)yy * stride + xx] * scale : 0.f;
+      const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+      raw[ky * 3 + kx] = img[(size_t)yc * stride + xc];
+    }
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yy = gy + ky - 1, xx = gx + kx - 1;
+      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      v[ky * 3 + kx] = in ? (float)raw[ky * 3 + kx] * scale : 0.f;
     }
 }
 __device__ __forceinline__ void conv1a_octet(const float (&v)[9], const float* __restrict__ w9x64,
@@ -69,6 +81,79 @@ __device__ __forceinline__ void conv1a_octet(const float (&v)[9], const float* _
     for (int c = 0; c < 8; ++c) o[c] = __builtin_fmaf(v[t], w9x64[t * 64 + oct * 8 + c], o[c]);
 #pragma unroll
   for (int c = 0; c < 8; ++c) o[c] = (valid && o[c] > 0.f) ? o[c] : 0.f;
+}
+
+// conv1a on the matrix pipe, written straight into an LDS patch (used by every fused conv1a+conv1b kernel).
+// A [32 patch pixels x 10] x [10 x 64] problem per m-tile (K = 9 taps padded to 10): v_mfma_f32_32x32x2_f32 IS the oracle's
+// fmaf chain in (ky,kx) order started from the bias, so the values are bit-identical to conv1a_kernel.  c1w/c1b are this
+// lane's B fragments / bias (conv1a_mfma_load_weights), loaded once per workgroup.  MODE 0 writes fp32 (pixel stride CPF
+// floats), MODE 1 writes the 2^SA-scaled fp16 hi/lo planes (pixel stride CPH halves).  wv/nw: this wave's index / wave count.
+__device__ __forceinline__ void conv1a_mfma_load_weights(const float* __restrict__ w9x64, const float* __restrict__ bias, int lane,
+                                                         float (&c1w)[5][2], float (&c1b)[2]) {
+#pragma unroll
+  for (int st = 0; st < 5; ++st) {
+    const int k = 2 * st + (lane >> 5);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) c1w[st][n] = k < 9 ? w9x64[k * 64 + n * 32 + (lane & 31)] : 0.f;
+  }
+  c1b[0] = bias[lane & 31];
+  c1b[1] = bias[32 + (lane & 31)];
+}
+
+template <int MODE, int NPIX, int PW, int CPF, int CPH, int SA>
+__device__ __forceinline__ void conv1a_mfma_stage(const uint8_t* __restrict__ ip, int img_stride_b, int aH, int aW, int ty0, int tx0,
+                                                  const float (&c1w)[5][2], const float (&c1b)[2], int lane, int wv, int nw,
+                                                  float* patch, _Float16* hi, _Float16* lo) {
+  constexpr int NMT = (NPIX + 31) / 32;
+  const float scale = (float)(1.0 / 255.0);
+  const float sa = (float)(1 << SA);
+  for (int mt = wv; mt < NMT; mt += nw) {
+    const int p = mt * 32 + (lane & 31);
+    const int gy = ty0 + p / PW - 1, gx = tx0 + p % PW - 1;       // image coordinates of the patch pixel (conv1b halo incl.)
+    const bool pvalid = p < NPIX && gy >= 0 && gy < aH && gx >= 0 && gx < aW;
+    const unsigned long long vmask = __ballot(pvalid);              // bit i (< 32): patch pixel mt*32+i lies inside the image
+    unsigned char raw[5];
+    bool tin[5];
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      const int k = 2 * st + (lane >> 5);
+      const int yy = gy + k / 3 - 1, xx = gx + k % 3 - 1;
+      tin[st] = k < 9 && pvalid && yy >= 0 && yy < aH && xx >= 0 && xx < aW;
+      const int yc = yy < 0 ? 0 : (yy >= aH ? aH - 1 : yy), xc = xx < 0 ? 0 : (xx >= aW ? aW - 1 : xx);
+      raw[st] = ip[(size_t)yc * img_stride_b + xc];
+    }
+    f32x16 c0, c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c0[r] = c1b[0]; c1[r] = c1b[1]; }
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      const float av = tin[st] ? (float)raw[st] * scale : 0.f;
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, c1w[st][0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, c1w[st][1], c1, 0, 0, 0);
+    }
+    // D layout: column = lane&31 (channel), row i = (r&3) + 8*(r>>2) + 4*(lane>>5) (patch pixel mt*32 + i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int pp = mt * 32 + i;
+      const bool ok = (vmask >> i) & 1ull;
+      const float o0 = (ok && c0[r] > 0.f) ? c0[r] : 0.f;
+      const float o1 = (ok && c1[r] > 0.f) ? c1[r] : 0.f;
+      if (pp < NPIX) {
+        if constexpr (MODE == 0) {
+          patch[pp * CPF + (lane & 31)] = o0;
+          patch[pp * CPF + 32 + (lane & 31)] = o1;
+        } else {
+          const float x0 = fminf(o0 * sa, 65000.f), x1 = fminf(o1 * sa, 65000.f);
+          const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+          hi[pp * CPH + (lane & 31)] = h0;
+          hi[pp * CPH + 32 + (lane & 31)] = h1;
+          lo[pp * CPH + (lane & 31)] = (_Float16)(x0 - (float)h0);
+          lo[pp * CPH + 32 + (lane & 31)] = (_Float16)(x1 - (float)h1);
+        }
+      }
+    }
+  }
 }
 
 // Epilogue: optional power-of-two rescale, ReLU, optional fused 2x2 max pool, NHWC store.

@@ -84,6 +84,16 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
   const long img_istride = a.img_istride;
   const int aH = a.H, aW = a.W;
 
+  // Fused conv1a (FUSE1A): the producers evaluate conv1a for the patch on the matrix pipe as well -- a [32 px x 10] x
+  // [10 x 64] fp32 MFMA problem per 32 patch pixels (K = 9 taps padded to 10; v_mfma_f32_32x32x2_f32 IS the oracle's fmaf
+  // chain in (ky,kx) order, so the values stay bit-exact).  The B fragments (weights) and the bias are loaded ONCE per
+  // persistent workgroup and stay in 12 registers; the A fragment is 5 byte loads per lane per m-tile.
+  float c1w[5][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+  float c1b[2] = {0.f, 0.f};
+  if constexpr (FUSE1A) {
+    if (!consumer) conv1a_mfma_load_weights(w1a, b1a, lane, c1w, c1b);
+  }
+
   // ------------------------------------------------------------------------------------------------ producer
   auto stage = [&](const PcTile& T, int buf) {
     const int ptid = tid - NPT;
@@ -93,38 +103,8 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
     _Float16* lo = hi + NPIX * CPH;
     const float sa = (float)(1 << PC_SA);
     if constexpr (FUSE1A) {
-      const uint8_t* ip = img_base + (size_t)T.img * img_istride;
-      for (int pix = ptid; pix < ((NPIX + 63) / 64) * 64; pix += NPT) {
-        const int gy = T.ty0 + pix / PW - P, gx = T.tx0 + pix % PW - P;
-        const bool inpatch = pix < NPIX;
-        const bool valid = inpatch && gy >= 0 && gy < aH && gx >= 0 && gx < aW;
-        float v[9];
-        conv1a_load_taps(ip, img_stride_b, aH, aW, valid ? gy : 0, valid ? gx : 0, v);
-#pragma unroll 1
-        for (int oct = 0; oct < 8; ++oct) {
-          float o[8];
-          conv1a_octet(v, w1a, b1a, oct, valid, o);
-          if constexpr (MODE == 0) {
-            if (inpatch) {
-#pragma unroll
-              for (int c = 0; c < 8; ++c) patch[pix * CPF + oct * 8 + c] = o[c];
-            }
-          } else {
-            f16x8 h8, l8;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-              const float x = fminf(o[c] * sa, 65000.f);
-              const _Float16 h = (_Float16)x;
-              h8[c] = h;
-              l8[c] = (_Float16)(x - (float)h);
-            }
-            if (inpatch) {
-              *reinterpret_cast<f16x8*>(hi + pix * CPH + oct * 8) = h8;
-              *reinterpret_cast<f16x8*>(lo + pix * CPH + oct * 8) = l8;
-            }
-          }
-        }
-      }
+      conv1a_mfma_stage<MODE, NPIX, PW, CPF, CPH, PC_SA>(img_base + (size_t)T.img * img_istride, img_stride_b, aH, aW, T.ty0, T.tx0,
+                                                         c1w, c1b, lane, wave - NC, NC, patch, hi, lo);
     } else {
       const float* in = a.in + (size_t)T.img * a.in_img_stride + a.in_coff;
       constexpr int C4 = CIN / 4;
