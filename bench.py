@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=8, help="stereo frames per step and per GPU")
+    ap.add_argument("--frames", type=int, default=16, help="stereo frames per step and per GPU")
     ap.add_argument("--precision", choices=["f32", "f16x2"], default=os.environ.get("D2FE_BENCH_PRECISION", "f32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -178,7 +178,7 @@ def main():
         avg_ms = c1b_ms / max(c1b_n, 1)
         achieved = CONV1B_FLOP_PER_IMG * NI / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         peak = PEAK_TFLOPS[precision]
-        roofline = {"kernel": "conv_%s_kernel<64,3,8,32,...,POOL> (conv1b)" % ("f32" if precision == "f32" else "f16x2"),
+        roofline = {"kernel": "conv_%s_kernel<64,3,4,32,2,2,2,1,POOL,RELU,FUSE1A> (conv1a fused into conv1b)" % ("f32" if precision == "f32" else "f16x2"),
                     "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None,
                     "avg_launch_ms": round(avg_ms, 4), "launches": c1b_n,

@@ -326,3 +326,61 @@ def test_netvlad_vs_oracle(api, orc, H, W):
     ref2 = orc.netvlad_forward(imgs[0], nv, pca=(comp, mean))
     assert np.abs(got2[0] - ref2).max() <= 1e-4
     fe.close()
+
+
+def test_stride_cap_and_batch_invariance(api, orc, sp_weights):
+    """Row stride > width (cv::Mat ROI), cap < max_keypoints, and batch-position independence (an image's result must not
+    depend on its neighbours in the batch or on the batch size)."""
+    H, W = 96, 128
+    imgs = np.stack([synth_image(H, W, 50 + s) for s in range(3)])
+    fe = _fe(api, H, W, 3, api.PREC_F32, max_kp=120)
+    fe.load_superpoint(sp_weights)
+    ref = fe.extract_batch(imgs, cap=120)
+    single = [fe.extract_batch(imgs[i:i + 1], cap=120)[0] for i in range(3)]
+    rev = fe.extract_batch(imgs[::-1].copy(), cap=120)[::-1]
+    for i in range(3):
+        for other in (single[i], rev[i]):
+            assert all(np.array_equal(a, b) for a, b in zip(ref[i], other))
+    # strided input through the raw C ABI
+    import ctypes as C
+    lib = api.load_library()
+    stride = W + 40
+    buf = np.zeros((H, stride), np.uint8); buf[:, :W] = imgs[0]; buf[:, W:] = 255
+    kps = np.zeros((120, 2), np.float32); sc = np.zeros(120, np.float32); desc = np.zeros((120, 256), np.float32); n = C.c_int(0)
+    rc = lib.d2fe_superpoint_extract(fe.handle, buf.ctypes.data, W, H, stride, kps.ctypes.data, sc.ctypes.data, desc.ctypes.data, 120, C.byref(n))
+    assert rc == 0 and n.value == len(ref[0][0])
+    assert np.array_equal(kps[:n.value], ref[0][0]) and np.array_equal(desc[:n.value], ref[0][2])
+    # cap smaller than max_keypoints: the first `cap` of the same ordered list
+    small = fe.extract_batch(imgs[:1], cap=40)[0]
+    assert len(small[0]) == 40 and np.array_equal(small[0], ref[0][0][:40]) and np.array_equal(small[1], ref[0][1][:40])
+    fe.close()
+
+
+def test_sliding_window_batch(api, orc):
+    """One new frame against an 11-keyframe sliding window (max_sld_win_size, README.md:116) in ONE batched launch."""
+    torch = pytest.importorskip("torch")
+    fe = _fe(api, 64, 64, 1, api.PREC_F32)
+    dev = torch.device("cuda", 0)
+    cap, nwin = 200, 11
+    pool = np.zeros((nwin + 1, cap, 256), np.float32); cnt = np.zeros(nwin + 1, np.int32)
+    base, _, _, _ = synth_descriptor_pair(200, 200, 256, seed=1)
+    pool[0] = base; cnt[0] = 200
+    rng = np.random.RandomState(2)
+    for k in range(1, nwin + 1):
+        n = int(rng.randint(120, 201))
+        d = base[rng.permutation(200)[:n]] + rng.normal(0, 0.03 * k, size=(n, 256)).astype(np.float32)
+        pool[k, :n] = d / np.linalg.norm(d, axis=1, keepdims=True); cnt[k] = n
+    dp = torch.from_numpy(pool).to(dev); dc = torch.from_numpy(cnt).to(dev)
+    a_off = torch.zeros(nwin, dtype=torch.int32, device=dev); b_off = (torch.arange(1, nwin + 1, dtype=torch.int32, device=dev) * cap)
+    a_cnt = dc[:1].repeat(nwin).contiguous(); b_cnt = dc[1:].contiguous()
+    q = torch.zeros((nwin, cap), dtype=torch.int32, device=dev); t = torch.zeros_like(q)
+    d = torch.zeros((nwin, cap), dtype=torch.float32, device=dev); n = torch.zeros(nwin, dtype=torch.int32, device=dev)
+    fe.match_batch_device(dp.data_ptr(), dp.data_ptr(), a_off.data_ptr(), b_off.data_ptr(), a_cnt.data_ptr(), b_cnt.data_ptr(), nwin, 256,
+                          cap, q.data_ptr(), t.data_ptr(), d.data_ptr(), n.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(nwin):
+        rq, rt, rd = orc.match_knn(pool[0, :200], pool[k + 1, :cnt[k + 1]], 0.8)
+        m = int(n[k])
+        assert m == len(rq) and np.array_equal(q[k, :m].cpu().numpy(), rq) and np.array_equal(t[k, :m].cpu().numpy(), rt)
+        assert np.array_equal(d[k, :m].cpu().numpy(), rd)
+    fe.close()
