@@ -111,7 +111,12 @@ def main():
             gath_desc = torch.zeros((world, F, CAP, 256), dtype=torch.float32, device=dev)
             gath_cnt = torch.zeros((world, F), dtype=torch.int32, device=dev)
 
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        # every torch op, RCCL collective and library launch of a step is ordered on ONE explicit (non-default) HIP stream:
+        # the C ABI treats a NULL stream as "the handle's own stream", which would not be ordered with torch's default stream
+        main = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(main)
+        stream = main.cuda_stream
+        assert stream != 0
 
         def step():
             if args.netvlad:
@@ -188,8 +193,11 @@ def main():
                     "note": "algorithmic FLOPs (2*MACs); f16x2 executes 3 MFMA FLOPs per algorithmic FLOP"}
 
 
+        # keep image 0's result (left frame of stereo frame 0) for the in-run parity check against the oracle
+        k0 = int(cnt[0].item())
+        first = (kps[0, :k0].cpu().numpy(), scores[0, :k0].cpu().numpy(), desc[0, :k0].cpu().numpy())
         fe.close()
-        return dict(value=value, ms_per_step=ms_per_step, roofline=roofline, n_kp=n_kp, n_match=n_match,
+        return dict(first=first, value=value, ms_per_step=ms_per_step, roofline=roofline, n_kp=n_kp, n_match=n_match,
                     breakdown=breakdown, NI=NI, NP=NP, F=F)
 
     primary = run_mode(args.precision, args.breakdown)
@@ -200,8 +208,14 @@ def main():
     n_kp, n_match, breakdown, NI, NP, F = (primary[k] for k in ("n_kp", "n_match", "breakdown", "NI", "NP", "F"))
 
     cpu_baseline = None
+    parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(weights, args.cpu_seconds)
+        cpu_baseline, ofirst = run_cpu_baseline(weights, args.cpu_seconds)
+        gk, gs, gd = primary["first"]
+        parity = {"checked": "left image of stereo frame 0 vs oracle (same run)",
+                  "keypoints_equal": bool(gk.shape == ofirst[0].shape and np.array_equal(gk, ofirst[0])),
+                  "scores_equal": bool(gs.shape == ofirst[1].shape and np.array_equal(gs, ofirst[1])),
+                  "desc_max_abs_diff": float(np.abs(gd - ofirst[2]).max()) if gd.shape == ofirst[2].shape else None}
 
     if rank == 0:
         out = {
@@ -217,7 +231,7 @@ def main():
                        "weights": "seeded random-init SuperPoint (no checkpoint in tree)"},
             "sp_tflops_algorithmic": round(SP_FLOP_PER_IMG * 2 * value / 1e12, 2),
             "avg_keypoints_per_image": round(n_kp, 1), "avg_matches_per_pair": round(n_match, 1),
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }
         if other is not None:
             om = "f16x2" if args.precision == "f32" else "f32"
@@ -240,11 +254,14 @@ def run_cpu_baseline(weights, budget_s):
     from oracle import oracle as orc
     orc.build()
     prev = None
+    first = None
     n = 0
     t0 = time.perf_counter()
     while True:
         l, r = synth_stereo(H, W, seed=n)
         kl, sl, dl, _, _ = orc.extract_b(l, weights, 0.015, 1, CAP)
+        if first is None:
+            first = (kl, sl, dl)
         kr, sr, dr, _, _ = orc.extract_b(r, weights, 0.015, 1, CAP)
         orc.match_knn(dl, dr, 0.8)
         if prev is not None:
@@ -256,8 +273,9 @@ def run_cpu_baseline(weights, budget_s):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 16:
             break
-    return {"value": round(n / el, 4), "unit": "stereo_frames/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d stereo frames 640x480 (oracle/d2fe_oracle.c, OpenMP over all host cores, fp32 fmaf chains), %.1f s" % (n, el)}
+    return ({"value": round(n / el, 4), "unit": "stereo_frames/s", "cores": os.cpu_count(), "kind": "port",
+             "sample": "%d stereo frames 640x480 (oracle/d2fe_oracle.c, OpenMP over all host cores, fp32 fmaf chains), %.1f s" % (n, el)},
+            first)
 
 
 if __name__ == "__main__":
