@@ -57,11 +57,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and os.environ.get("D2FE_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % ndev      # debug only: several ranks share one GPU under gloo
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("D2FE_BENCH_BACKEND", "nccl")   # "gloo" only to exercise the N>1 code path on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     weights = synthetic_superpoint_weights(dustbin_bias=7.5)
 
