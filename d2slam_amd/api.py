@@ -336,6 +336,12 @@ class FrontEnd:
                                         _ptr(g), mapx.shape[1], mapx.shape[0], _ptr(dst)))
         return dst
 
+    def undistort_device(self, d_src, n, sw, sh, d_mapx, d_mapy, d_gain, dw, dh, d_dst, stream=None, sstride=None,
+                         src_image_stride=None):
+        """Device-resident undistort of n frames sharing one map set (raw addresses)."""
+        _check(self._lib.d2fe_undistort_device(self._h, d_src, n, sw, sh, sstride or sw, src_image_stride if src_image_stride is not None else sw * sh,
+                                               d_mapx, d_mapy, d_gain, dw, dh, d_dst, stream))
+
     def quantize_int8(self, x, double_max=False):
         x = np.ascontiguousarray(x, np.float32).reshape(-1)
         out = np.empty(x.shape[0], np.int8)
