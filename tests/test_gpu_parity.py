@@ -384,3 +384,46 @@ def test_sliding_window_batch(api, orc):
         assert m == len(rq) and np.array_equal(q[k, :m].cpu().numpy(), rq) and np.array_equal(t[k, :m].cpu().numpy(), rt)
         assert np.array_equal(d[k, :m].cpu().numpy(), rd)
     fe.close()
+
+
+def test_exact_mode_many_full_size_frames(api, orc, sp_weights):
+    """Statistical weight behind 'indices exact': 8 more 640x480 frames and 4 quadcam-sized 800x400 views, all keypoints,
+    scores and match sets identical to the oracle."""
+    for (H, W, n, seed0) in ((480, 640, 8, 100), (400, 800, 4, 200)):
+        imgs = np.stack([synth_image(H, W, seed0 + s) for s in range(n)])
+        fe = _fe(api, H, W, n, api.PREC_F32)
+        fe.load_superpoint(sp_weights)
+        res = fe.extract_batch(imgs, cap=200)
+        descs = []
+        for i in range(n):
+            rk, rs, rd, ri, f = orc.extract_b(imgs[i], sp_weights, 0.015, 1, 200)
+            assert np.array_equal(res[i][0], rk) and np.array_equal(res[i][1], rs), "frame %d" % i
+            assert np.abs(res[i][2] - rd).max() <= 1e-6
+            descs.append(rd)
+        for i in range(0, n - 1, 2):
+            q, t, d = fe.match_knn(res[i][2], res[i + 1][2], 0.8)
+            rq, rt, rdist = orc.match_knn(res[i][2], res[i + 1][2], 0.8)
+            assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rdist)
+        fe.close()
+
+
+def test_matcher_fuzz(api, orc):
+    """60 random problems (sizes 1..300, dims 32..256, ratios, radii, duplicated rows): indices and distances bit-exact."""
+    fe = _fe(api, 64, 64, 1, api.PREC_F32)
+    rng = np.random.RandomState(123)
+    for case in range(60):
+        na, nb = int(rng.randint(1, 301)), int(rng.randint(1, 301))
+        dim = int(rng.choice([32, 64, 128, 256]))
+        ratio = float(rng.choice([0.7, 0.8, 0.9, 0.95]))
+        radius = float(rng.choice([-1.0, 20.0, 60.0]))
+        a, b, pa, pb = synth_descriptor_pair(na, nb, dim, seed=1000 + case, sigma=float(rng.choice([0.02, 0.1, 0.3])))
+        if case % 5 == 0 and nb > 4:
+            b[nb // 2] = b[0]; b[nb - 1] = b[1]          # exact duplicates -> distance ties
+        q, t, d = fe.match_knn(a, b, ratio, pa, pb, radius)
+        rq, rt, rd = orc.match_knn(a, b, ratio, pa, pb, radius)
+        assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd), (case, na, nb, dim)
+        if case % 3 == 0:
+            q, t, d = fe.match_crosscheck(a, b)
+            rq, rt, rd = orc.match_crosscheck(a, b)
+            assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd), (case, na, nb, dim)
+    fe.close()
