@@ -12,6 +12,8 @@
 // same hi/lo split.  Tiling: 4x32 pixels x 64 channels (Cin 64, waves 2x2), 4x16 x 128 (Cin 128 and the 1x1 heads,
 // waves 1x4); 2x2 max-pool stays lane-local for both tile widths.
 #include "conv_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace d2fe {
 
@@ -19,6 +21,11 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int PC_SA = 4, PC_SW = 8;   // fp16x2 power-of-two operand scalings (same as conv_f16.hip)
 
 struct PcTile { int img, ty0, tx0, cg; };
+
+// D2FE_ABLATE bit 256: workgroup 0 records s_memrealtime (100 MHz) marks of its first consumer and producer wave for the
+// first 64 tiles -- [wave kind][tile][0 start, 1 main loop issued, 2 epilogue/staging issued, 3 past the barrier].
+__device__ unsigned long long g_pc_trace[2][64][4];
+__device__ unsigned long long g_pc_trace_clk[4];   // (s_memtime, s_memrealtime) at tiles 2 and 10 -> shader clock
 
 template <int TH, int TW>
 __device__ __forceinline__ PcTile pc_decode(int t, int tiles_x, int tiles_y, int ncg) {
@@ -37,9 +44,30 @@ __device__ __forceinline__ void pc_epilogue_pool16(const ConvArgs& a, f32x16 (&a
                                                    int tx0, int wm, int ntile0, int lane) {
   float* out = a.out + (size_t)img * a.out_img_stride + a.out_coff;
   const int Ho = a.H >> 1, Wo = a.W >> 1;
+  const int cs = a.out_cstride;
+  const bool cfull = (ntile0 + NT) * 32 <= a.cout_real;
+  const unsigned cs4 = (unsigned)cs * 4u;
+  const unsigned lane_off = (unsigned)(2 * (lane >> 5)) * cs4 + (unsigned)(lane & 31) * 4u;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int oy = (ty0 + (wm * MT + m) * 2) >> 1;
+    if (cfull && ty0 + (wm * MT + m) * 2 + 1 < a.H && tx0 + 15 < a.W) {   // wave-uniform fast path, see conv_epilogue
+      const unsigned base = ((unsigned)oy * (unsigned)Wo + (unsigned)(tx0 >> 1)) * cs4 + (unsigned)ntile0 * 128u;   // uniform
+#pragma unroll
+      for (int r = 0; r < 8; r += 2) {
+        const int cu = (r & 3) + 8 * (r >> 2);
+        const unsigned so = base + (unsigned)(cu >> 1) * cs4;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float m0 = fmaxf(acc[m][n][r], acc[m][n][r + 1]);
+          const float m1 = fmaxf(acc[m][n][r + 8], acc[m][n][r + 9]);
+          float v = fmaxf(m0, m1) * scale;
+          if (RELU) v = v > 0.f ? v : 0.f;
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(out) + (so + n * 128u + lane_off)) = v;
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < 8; r += 2) {
       const int col = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);   // even, < 16
@@ -52,7 +80,7 @@ __device__ __forceinline__ void pc_epilogue_pool16(const ConvArgs& a, f32x16 (&a
           const float m1 = fmaxf(acc[m][n][r + 8], acc[m][n][r + 9]);
           float v = fmaxf(m0, m1) * scale;
           if (RELU) v = v > 0.f ? v : 0.f;
-          if (co < a.cout_real) out[((size_t)oy * Wo + ox) * a.out_cstride + co] = v;
+          if (co < a.cout_real) out[((size_t)oy * Wo + ox) * cs + co] = v;
         }
       }
     }
@@ -93,6 +121,12 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
   if constexpr (FUSE1A) {
     if (!consumer) conv1a_mfma_load_weights(w1a, b1a, lane, c1w, c1b);
   }
+
+  const bool tracing = (a.ablate & 256) && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == NC);
+  int trace_k = 0;
+  auto mark = [&](int slot) {
+    if (tracing && trace_k < 64) g_pc_trace[wave == 0 ? 0 : 1][trace_k][slot] = wall_clock64();
+  };
 
   // ------------------------------------------------------------------------------------------------ producer
   auto stage = [&](const PcTile& T, int buf) {
@@ -152,6 +186,17 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
   };
 
   // ------------------------------------------------------------------------------------------------ consumer
+  // The weight stream is the same for every tile of a workgroup (same channel group), so the B-fragment buffers are
+  // PERSISTENT: the loads wrap around at the end of a tile and the first k-steps of the next tile are already in
+  // registers when it starts (no L2 round trip exposed per tile).  `wcg` = channel group the buffers currently hold.
+  constexpr int F32_C8 = CIN / 8, F32_G = F32_C8 >= 16 ? 8 : 4, F32_GPT = F32_C8 / F32_G, F32_NG = TAPS * F32_GPT;
+  static_assert(F32_C8 % F32_G == 0 && F32_NG % 2 == 0, "fp32 weight groups must tile the k loop evenly");
+  constexpr int F16_KST = CIN / 16, F16_S = TAPS * F16_KST, F16_R = (F16_S % 9 == 0) ? 9 : 8;
+  static_assert(F16_S % F16_R == 0, "ring depth must divide the k-steps of a tile");
+  f32x4 bq[2][MODE == 0 ? F32_G : 1][NT];
+  f16x8 ring[MODE == 1 ? F16_R : 1][NT][2];
+  int wcg = -1;
+
   auto compute = [&](const PcTile& T, int buf) {
     const int wm = wave / WN, wn = wave % WN;
     const int ntile0 = T.cg * (WN * NT) + wn * NT;
@@ -168,7 +213,7 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
     }
     if constexpr (MODE == 0) {
       const float* patch = reinterpret_cast<const float*>(base);
-      constexpr int C8 = CIN / 8, G = 8, GPT = C8 / G, NG = TAPS * GPT;
+      constexpr int C8 = F32_C8, G = F32_G, GPT = F32_GPT, NG = F32_NG;
       int aoff[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -180,7 +225,6 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
       const f32x4* wbase[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) wbase[n] = wp + (size_t)(ntile0 + n) * TAPS * C8 * 64 + lane;
-      f32x4 bq[2][G][NT];
       auto load_grp = [&](int b2, int grp) {
 #pragma unroll
         for (int j = 0; j < G; ++j)
@@ -208,21 +252,20 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], bq[b2][j][n][q], acc[m][n], 0, 0, 0);
         }
       };
-      load_grp(0, 0);
+      if (wcg != T.cg) { load_grp(0, 0); wcg = T.cg; }
 #pragma unroll 1
-      for (int g = 0; g + 1 < NG; g += 2) {
+      for (int g = 0; g < NG; g += 2) {
         load_grp(1, g + 1);
         __builtin_amdgcn_sched_barrier(0);
         compute_grp(0, g);
-        load_grp(0, g + 2 < NG ? g + 2 : NG - 1);
+        load_grp(0, g + 2 < NG ? g + 2 : 0);      // wraps: group 0 of the NEXT tile is in flight during the epilogue
         __builtin_amdgcn_sched_barrier(0);
         compute_grp(1, g + 1);
       }
-      if constexpr (NG & 1) compute_grp(0, NG - 1);
     } else {
       const _Float16* hi = reinterpret_cast<const _Float16*>(base);
       const _Float16* lo = hi + NPIX * CPH;
-      constexpr int KST = CIN / 16;
+      constexpr int KST = F16_KST, S = F16_S, R = F16_R;
       int aoff[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -234,12 +277,8 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
       const f16x8* wbase[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) wbase[n] = wp + (size_t)(ntile0 + n) * TAPS * KST * 128 + lane;
-      // B fragments (hi, lo per n-tile) travel through a register ring R k-steps deep: the load for step s+R-1 is
-      // issued before the MFMAs of step s, so an L2 round trip is covered by (R-1) * 3*MT*NT MFMAs; A fragments
-      // are read one step ahead.  Fully unrolled (static ring indices).
-      constexpr int S = TAPS * KST;
-      constexpr int R = (NT == 2) ? 8 : 10;
-      f16x8 ring[R][NT][2];
+      // B fragments (hi, lo per n-tile) travel through a register ring R k-steps deep that wraps around tile boundaries:
+      // the load for step (s+R-1) mod S is issued before the MFMAs of step s; A fragments are read one step ahead.
       auto load_step = [&](int slot, int st) {
         if (a.ablate & 2) st = 0;
 #pragma unroll
@@ -258,12 +297,15 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
           al[slot][m] = *reinterpret_cast<const f16x8*>(lo + aoff[m] + o);
         }
       };
+      if (wcg != T.cg) {
 #pragma unroll
-      for (int st = 0; st < R - 1 && st < S; ++st) load_step(st, st);
+        for (int st = 0; st < R - 1; ++st) load_step(st, st);
+        wcg = T.cg;
+      }
       load_a(0, 0);
 #pragma unroll
       for (int st = 0; st < S; ++st) {
-        if (st + R - 1 < S) load_step((st + R - 1) % R, st + R - 1);
+        load_step((st + R - 1) % R, (st + R - 1) % S);
         if (st + 1 < S) load_a((st + 1) & 1, st + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -276,6 +318,7 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
           }
       }
     }
+    mark(1);
     const float oscale = MODE == 0 ? 1.0f : 1.0f / bscale;
     if constexpr (POOL && TW == 16)
       pc_epilogue_pool16<MT, NT, RELU>(a, acc, oscale, T.img, T.ty0, T.tx0, wm, ntile0, lane);
@@ -295,9 +338,17 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
     const bool more = tn < total;
     PcTile nxt = cur;
     if (more) nxt = pc_decode<TH, TW>(tn, tiles_x, tiles_y, ncg);
+    mark(0);
+    if (tracing && wave == 0 && (trace_k == 2 || trace_k == 10)) {
+      g_pc_trace_clk[trace_k == 2 ? 0 : 2] = clock64();
+      g_pc_trace_clk[trace_k == 2 ? 1 : 3] = wall_clock64();
+    }
     if (consumer) { if (!(a.ablate & 16)) compute(cur, buf); }
     else if (more && !(a.ablate & 8)) stage(nxt, buf ^ 1);
+    mark(2);
     __syncthreads();
+    mark(3);
+    ++trace_k;
     if (!more) break;
     t = tn; cur = nxt; buf ^= 1;
   }
@@ -325,6 +376,25 @@ static hipError_t launch_pc_one(int cout_pad, const ConvArgs& a, hipStream_t s) 
   if (e != hipSuccess) return e;
   const int grid = total < ncu ? total : ncu;
   hipLaunchKernelGGL(k, dim3(grid), dim3(WM * WN * 128), lds, s, a, tiles_x, tiles_y, ncg, total);
+  if (a.ablate & 256) {
+    static int dumped = 0;
+    const char* e = getenv("D2FE_PC_TRACE_CIN");
+    if (dumped < 2 && (!e || atoi(e) == CIN * 10 + KS + (FUSE1A ? 100000 : 0)) && a.n_img > 1) {
+      ++dumped;
+      unsigned long long tr[2][64][4];
+      if (hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_pc_trace), sizeof(tr)) == hipSuccess) {
+        fprintf(stderr, "pc trace MODE %d CIN %d KS %d tile %dx%d fuse %d (10 ns ticks: start->loop, loop->end, end->barrier)\n", MODE, CIN, KS, TH, TW, (int)FUSE1A);
+        unsigned long long ck[4];
+        if (hipMemcpyFromSymbol(ck, HIP_SYMBOL(g_pc_trace_clk), sizeof(ck)) == hipSuccess && ck[3] > ck[1])
+          fprintf(stderr, "  s_memtime / s_memrealtime over tiles 2..10: %.3f cycles per 10 ns\n", (double)(ck[2] - ck[0]) / (double)(ck[3] - ck[1]));
+        for (int k = 0; k < 24 && k * grid < total; ++k)
+          fprintf(stderr, "  tile %2d  consumer %5lld %5lld %5lld | producer %5lld       %5lld | tile period %5lld\n", k,
+                  (long long)(tr[0][k][1] - tr[0][k][0]), (long long)(tr[0][k][2] - tr[0][k][1]), (long long)(tr[0][k][3] - tr[0][k][2]),
+                  (long long)(tr[1][k][2] - tr[1][k][0]), (long long)(tr[1][k][3] - tr[1][k][2]),
+                  k ? (long long)(tr[0][k][0] - tr[0][k - 1][0]) : 0ll);
+      }
+    }
+  }
   return hipGetLastError();
 }
 
