@@ -197,8 +197,9 @@ def main():
         roofline = {"kernel": "conv_%s_kernel<64,3,4,32,2,2,2,1,POOL,RELU,FUSE1A> (conv1a fused into conv1b)" % ("f32" if precision == "f32" else "f16x2"),
                     "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4),
-                    # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction; profiles/README.md): 21.7 MB/image
-                    "traffic": 21.7e6 * NI if precision == "f32" else None,
+                    # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE in KiB, gfx950 correction; profiles/README.md):
+                    # 2*39.3e3 + 614.4e3 KiB per 32-image launch = 22.2 MB/image in both precisions (19.7 MB of it is the pooled output)
+                    "traffic": 22.2e6 * NI,
                     "avg_launch_ms": round(avg_ms, 4), "launches": c1b_n,
                     "algorithmic_flop_per_launch": CONV1B_FLOP_PER_IMG * NI,
                     "note": "algorithmic FLOPs (2*MACs); f16x2 executes 3 MFMA FLOPs per algorithmic FLOP"}

@@ -6,7 +6,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python $PWD/bench.py --steps 5 --warmup 2 --precision $PREC --single-mode --no-cpu-baseline"
 REPO=$PWD; cd /tmp
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- $BENCH > $OUT/bench_trace.log 2>&1
+# the stats pass runs bench.py with its DEFAULT steps/warmup (the command whose JSON line carries roofline.avg_launch_ms)
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py --precision $PREC --single-mode --no-cpu-baseline > $OUT/bench_trace.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o p -- $BENCH > $OUT/bench_pmc_sq.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $BENCH > $OUT/bench_pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $BENCH > $OUT/bench_pmc_write.log 2>&1

@@ -14,6 +14,17 @@ def main(root):
         rows = list(csv.DictReader(open(f)))
         for r in rows[:25]:
             out.append("  %-112s calls=%-5s total_ms=%9.3f avg_us=%10.2f pct=%s" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    # per-kernel median / min from the raw trace (the stats CSV averages the cold warm-up launches in)
+    for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        dur = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        out.append("== kernel trace: median / min / max duration per launch (us), d2fe kernels")
+        for k in sorted(dur, key=lambda k: -sum(dur[k])):
+            if "at::native" in k or "rocclr" in k or "anonymous" in k:
+                continue
+            v = sorted(dur[k])
+            out.append("  %-112s n=%-4d median=%10.2f min=%10.2f max=%10.2f" % (k, len(v), v[len(v) // 2], v[0], v[-1]))
     for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_lds"):
         fs = glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True)
         for f in fs:
