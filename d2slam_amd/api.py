@@ -77,7 +77,9 @@ EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_creat
            "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device",
            "d2fe_half_image_filter", "d2fe_undistort", "d2fe_undistort_device", "d2fe_db_create", "d2fe_db_destroy",
            "d2fe_db_ntotal", "d2fe_db_add", "d2fe_db_search", "d2fe_db_query_gated", "d2fe_quantize_int8", "d2fe_dequantize_int8",
-           "d2fe_debug_read", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read"]
+           "d2fe_debug_read", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read",
+           "d2fe_lk_frame_create", "d2fe_lk_frame_create_device", "d2fe_lk_frame_destroy", "d2fe_lk_frame_read_level",
+           "d2fe_lk_track", "d2fe_detect_fast_by_region", "d2fe_good_features_to_track"]
 
 
 def load_library():
@@ -135,6 +137,18 @@ def load_library():
         lib.d2fe_desc_dim.argtypes = [C.c_void_p]
         lib.d2fe_profile_enable.argtypes = [C.c_void_p, C.c_int]
         lib.d2fe_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.d2fe_lk_frame_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.d2fe_lk_frame_create_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.d2fe_lk_frame_destroy.argtypes = [C.c_void_p]
+        lib.d2fe_lk_frame_destroy.restype = None
+        lib.d2fe_lk_frame_read_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.d2fe_lk_frame_read_level.restype = C.c_long
+        lib.d2fe_lk_track.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.d2fe_detect_fast_by_region.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                   C.c_void_p, C.c_int, C.c_void_p]
+        lib.d2fe_good_features_to_track.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p,
+                                                    C.c_int, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -429,6 +443,147 @@ class FlatIPDatabase:
         label = C.c_int32(-1); sim = C.c_float(0)
         _check(self._lib.d2fe_db_query_gated(self._db, _ptr(q), int(max_index), float(thres), C.byref(label), C.byref(sim)))
         return int(label.value), float(sim.value)
+
+
+# ---- LK optical-flow tracker (d2frontend/src/opticaltrack_utils.cpp) ---------------------------------
+PYR_LEVEL = 2            # opticaltrack_utils.h:10
+WIN_SIZE = 21            # opticaltrack_utils.cpp:25
+LK_ITERS = 30            # SparsePyrLKOpticalFlow::create(WIN_SIZE, PYR_LEVEL, 30, true), :239
+WHOLE_IMG_MATCH, LEFT_RIGHT_IMG_MATCH, RIGHT_LEFT_IMG_MATCH = 0, 1, 2   # TrackLRType
+
+
+class LKFrame:
+    """Device-resident image pyramid = LKImageInfoGPU::pyr (opticaltrack_utils.h:16-23), built by buildImagePyramid
+    (opticaltrack_utils.cpp:526-542)."""
+
+    def __init__(self, fe: FrontEnd, gray=None, levels=PYR_LEVEL, d_gray=None, width=None, height=None, stride=None, stream=None):
+        self._lib = fe._lib
+        self._fe = fe
+        self._f = C.c_void_p()
+        self.levels = levels
+        if gray is not None:
+            img = np.ascontiguousarray(gray, np.uint8)
+            self.height, self.width = img.shape
+            _check(self._lib.d2fe_lk_frame_create(fe.handle, _ptr(img), self.width, self.height, self.width, levels, C.byref(self._f)))
+        else:
+            self.width, self.height = int(width), int(height)
+            _check(self._lib.d2fe_lk_frame_create_device(fe.handle, C.c_void_p(d_gray), self.width, self.height,
+                                                         int(stride or width), levels, C.c_void_p(stream or 0), C.byref(self._f)))
+
+    def close(self):
+        if self._f.value:
+            self._lib.d2fe_lk_frame_destroy(self._f)
+            self._f = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def level(self, l):
+        w, h = self.width, self.height
+        for _ in range(l):
+            w, h = (w + 1) // 2, (h + 1) // 2
+        out = np.zeros((h, w), np.uint8)
+        r = self._lib.d2fe_lk_frame_read_level(self._f, int(l), _ptr(out), out.nbytes, None, None)
+        if r < 0:
+            _check(int(r))
+        return out
+
+
+def buildImagePyramid(fe: FrontEnd, gray, maxLevel=PYR_LEVEL) -> LKFrame:
+    """buildImagePyramid(GpuMat, maxLevel) (opticaltrack_utils.cpp:526-542)."""
+    return LKFrame(fe, gray, maxLevel)
+
+
+def lk_track(fe: FrontEnd, prev: LKFrame, cur: LKFrame, prev_pts, cur_init, track_type=WHOLE_IMG_MATCH, move_cols=0.0,
+             win=WIN_SIZE, iters=LK_ITERS):
+    """Forward + reverse SparsePyrLK with the 0.5 px and inBorder tests (opticaltrack_utils.cpp:236-272) -> (cur_pts, status)."""
+    pp = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+    ci = np.ascontiguousarray(cur_init, np.float32).reshape(-1, 2)
+    n = pp.shape[0]
+    out = np.zeros((max(n, 1), 2), np.float32); st = np.zeros(max(n, 1), np.uint8)
+    _check(fe._lib.d2fe_lk_track(fe.handle, prev._f, cur._f, _ptr(pp), _ptr(ci), n, int(track_type), float(move_cols), int(win),
+                                 int(iters), _ptr(out), _ptr(st)))
+    return out[:n], st[:n]
+
+
+def opticalflowTrackPyr(fe: FrontEnd, cur_img, prev_lk: dict, track_type=WHOLE_IMG_MATCH, undistort_fov=200.0):
+    """opticalflowTrackPyr(cur_img, prev_lk, type) (opticaltrack_utils.cpp:173-279).  prev_lk / the return value are dicts with
+    the LKImageInfoGPU fields: lk_pts [n,2], lk_ids, lk_local_index, lk_types, pyr (LKFrame)."""
+    cur_img = np.ascontiguousarray(cur_img, np.uint8)
+    cur_pyr = buildImagePyramid(fe, cur_img, PYR_LEVEL)
+    prev_pts = np.asarray(prev_lk.get("lk_pts", np.zeros((0, 2))), np.float32).reshape(-1, 2)
+    ids = np.asarray(prev_lk.get("lk_ids", np.arange(len(prev_pts))))
+    types = np.asarray(prev_lk.get("lk_types", np.zeros(len(prev_pts), np.int32)))
+    local = np.asarray(prev_lk.get("lk_local_index", np.arange(len(prev_pts))))
+    empty = {"lk_pts": np.zeros((0, 2), np.float32), "lk_ids": ids[:0], "lk_local_index": local[:0], "lk_types": types[:0], "pyr": cur_pyr}
+    if len(prev_pts) == 0:
+        return empty
+    move_cols = np.float32(cur_img.shape[1] * 90.0 / undistort_fov)
+    if track_type == WHOLE_IMG_MATCH:
+        cur_pts = prev_pts.copy()
+    else:
+        if track_type == LEFT_RIGHT_IMG_MATCH:
+            keep = prev_pts[:, 0] < np.float32(cur_img.shape[1]) - move_cols
+            cur_pts = prev_pts[keep].copy(); cur_pts[:, 0] += move_cols
+        else:
+            keep = prev_pts[:, 0] >= move_cols
+            cur_pts = prev_pts[keep].copy(); cur_pts[:, 0] -= move_cols
+        prev_pts, ids, types, local = prev_pts[keep], ids[keep], types[keep], local[keep]
+    if len(cur_pts) == 0:
+        return empty
+    out, st = lk_track(fe, prev_lk["pyr"], cur_pyr, prev_pts, cur_pts, track_type, float(move_cols))
+    k = st.astype(bool)
+    return {"lk_pts": out[k], "lk_ids": ids[k], "lk_local_index": local[k], "lk_types": types[k], "pyr": cur_pyr}
+
+
+def detectFastByRegion(fe: FrontEnd, frame: LKFrame, features, cols, rows, threshold=10, with_response=False):
+    """detectFastByRegion(img, mask, features, cols, rows) (opticaltrack_utils.cpp:444-493)."""
+    cap = max(int(features), 1)
+    xy = np.zeros((cap, 2), np.float32); resp = np.zeros(cap, np.int32); n = C.c_int(0)
+    _check(fe._lib.d2fe_detect_fast_by_region(fe.handle, frame._f, int(features), int(cols), int(rows), int(threshold), _ptr(xy),
+                                              _ptr(resp), cap, C.byref(n)))
+    return (xy[:n.value].copy(), resp[:n.value].copy()) if with_response else xy[:n.value].copy()
+
+
+def goodFeaturesToTrack(fe: FrontEnd, frame: LKFrame, max_corners, quality=0.01, min_dist=20.0):
+    """cv::cuda::createGoodFeaturesToTrackDetector(type, max_corners, quality, min_dist)->detect (opticaltrack_utils.cpp:404-412)."""
+    cap = max(int(max_corners), 1) if max_corners > 0 else frame.width * frame.height // 4
+    xy = np.zeros((cap, 2), np.float32); n = C.c_int(0)
+    _check(fe._lib.d2fe_good_features_to_track(fe.handle, frame._f, int(max_corners), float(quality), float(min_dist), _ptr(xy), cap,
+                                               C.byref(n)))
+    return xy[:n.value].copy()
+
+
+def detectPoints(fe: FrontEnd, frame: LKFrame, cur_pts, require_pts, use_fast=False, fast_rows=3, fast_cols=4,
+                 feature_min_dist=20.0):
+    """detectPoints (opticaltrack_utils.cpp:375-442): detect only when more than a quarter of the points are missing, ask for
+    twice the shortfall when some points exist, drop candidates closer than feature_min_dist to an accepted point."""
+    cur_pts = np.asarray(cur_pts, np.float32).reshape(-1, 2)
+    lack = int(require_pts) - len(cur_pts)
+    if not lack > int(require_pts) // 4:
+        return np.zeros((0, 2), np.float32)
+    num = lack * 2 if len(cur_pts) > 0 else lack
+    if use_fast:
+        cand = detectFastByRegion(fe, frame, num, fast_rows, fast_cols)   # (sic) the reference passes rows as `cols`, :391-392
+    else:
+        cand = goodFeaturesToTrack(fe, frame, num, 0.01, feature_min_dist)
+    all_pts = [p for p in cur_pts]
+    out = []
+    for p in cand:
+        near = False
+        for q in all_pts:
+            d = p - q
+            if np.sqrt(np.float64(d[0]) * d[0] + np.float64(d[1]) * d[1]) < feature_min_dist:
+                near = True
+                break
+        if not near:
+            out.append(p); all_pts.append(p)
+        if len(out) >= lack:
+            break
+    return np.asarray(out, np.float32).reshape(-1, 2)
 
 
 class SuperPoint:

@@ -94,6 +94,13 @@ struct d2fe_context {
   std::vector<ProfRec> prof_recs;
 };
 
+// accessors for the translation units that keep their own extern "C" entry points (lk.hip)
+namespace d2fe {
+int ctx_fail(int code, const std::string& msg) { return fail(code, msg); }
+int ctx_device(d2fe_handle h) { return h->cfg.device_id; }
+hipStream_t ctx_stream(d2fe_handle h) { return h->stream; }
+}  // namespace d2fe
+
 namespace {
 
 int alloc_f(Tensor& t, size_t per_img, int batch) {

@@ -226,6 +226,35 @@ D2FE_API int d2fe_db_query_gated(d2fe_db_handle db, const float* q, int max_inde
 D2FE_API int d2fe_quantize_int8(d2fe_handle h, const float* x, int n, int double_max, int8_t* out);
 D2FE_API int d2fe_dequantize_int8(d2fe_handle h, const int8_t* q, int n, int landmark_num, float* out);
 
+/* (f)-4 LK optical-flow tracker (d2frontend/src/opticaltrack_utils.cpp).  A d2fe_lk_frame is the device-resident image
+ * pyramid the reference keeps in LKImageInfoGPU::pyr (opticaltrack_utils.h:16-23): level 0 = the gray frame, level l+1 =
+ * cv::cuda::pyrDown(level l) (buildImagePyramid, opticaltrack_utils.cpp:526-542; PYR_LEVEL = 2, opticaltrack_utils.h:10). */
+typedef struct d2fe_lk_frame_s* d2fe_lk_frame;
+D2FE_API int d2fe_lk_frame_create(d2fe_handle h, const uint8_t* gray, int width, int height, int stride, int levels,
+                                  d2fe_lk_frame* out);
+D2FE_API int d2fe_lk_frame_create_device(d2fe_handle h, const uint8_t* d_gray, int width, int height, int stride, int levels,
+                                         void* stream, d2fe_lk_frame* out);
+D2FE_API void d2fe_lk_frame_destroy(d2fe_lk_frame f);
+/* copy pyramid level `level` (tight rows) to the host; returns bytes or <0 */
+D2FE_API long d2fe_lk_frame_read_level(d2fe_lk_frame f, int level, uint8_t* dst, size_t max_bytes, int* width, int* height);
+/* The tracking block of opticalflowTrackPyr (opticaltrack_utils.cpp:236-272) in one launch: SparsePyrLKOpticalFlow(win, levels,
+ * iters, useInitialFlow).calc(prev, cur) from cur_init, reverse calc(cur, prev) from the result shifted back by move_cols
+ * (type 1 LEFT_RIGHT_IMG_MATCH: -move_cols, 2 RIGHT_LEFT_IMG_MATCH: +move_cols, 0 WHOLE_IMG_MATCH: none), status[i] = both
+ * succeeded && |prev - reverse| <= 0.5 && inBorder(cur) (:35-41).  cur_pts[n][2] and status[n] are written for every point;
+ * the reduceVector() compaction stays with the caller.  Reference constants: win 21 (WIN_SIZE, :25), iters 30 (:239). */
+D2FE_API int d2fe_lk_track(d2fe_handle h, d2fe_lk_frame prev, d2fe_lk_frame cur, const float* prev_pts, const float* cur_init,
+                           int n, int type, float move_cols, int win, int iters, float* cur_pts, uint8_t* status);
+/* detectFastByRegion (opticaltrack_utils.cpp:444-493): cv::cuda::FastFeatureDetector(threshold, nonmax, TYPE_9_16,
+ * max_npoints = features) on each of the cols x rows regions of level 0, sorted by response, top `features`.
+ * response (optional) receives the FAST scores. */
+D2FE_API int d2fe_detect_fast_by_region(d2fe_handle h, d2fe_lk_frame f, int features, int cols, int rows, int threshold,
+                                        float* pts_xy, int32_t* response, int cap, int* n_out);
+/* cv::cuda::createGoodFeaturesToTrackDetector(type, max_corners, quality, min_dist)->detect (detectPoints,
+ * opticaltrack_utils.cpp:404-412): min-eigenvalue corners (blockSize 3, Sobel 3), eig > quality * max, 3x3 local maxima,
+ * sorted by eigenvalue, host min-distance grid filter. */
+D2FE_API int d2fe_good_features_to_track(d2fe_handle h, d2fe_lk_frame f, int max_corners, double quality, double min_dist,
+                                         float* pts_xy, int cap, int* n_out);
+
 /* Debug/inspection: copy an internal device tensor of the last extract call to the host.
  * names: "conv1a".."conv4b","convPaDa","logits","desc_raw","semi".  Returns bytes copied or <0. */
 D2FE_API long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_bytes);

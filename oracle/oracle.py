@@ -19,8 +19,8 @@ SP_LAYERS = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a
 
 def build(force=False):
     so = os.path.join(_HERE, "libd2fe_oracle.so")
-    src = os.path.join(_HERE, "d2fe_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("d2fe_oracle.c", "d2fe_oracle_lk.c", "Makefile")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
 
@@ -29,8 +29,7 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "libd2fe_oracle.so")
-        if not os.path.exists(so):
-            build()
+        build()
         _LIB = C.CDLL(so)
         _LIB.orc_expf.restype = C.c_float
         _LIB.orc_expf.argtypes = [C.c_float]
@@ -293,3 +292,54 @@ def dequant_int8(q, landmark_num=-1):
     out = np.empty(q.shape[0], np.float32)
     lib().orc_dequant_int8(_p(q), q.shape[0], landmark_num, _p(out))
     return out
+
+
+# ---- section 8(f)-4: LK optical-flow tracker (oracle/d2fe_oracle_lk.c) ---------------------------------------------------------
+def pyr_layout(w, h, levels):
+    off = (C.c_int * 16)(); ws = (C.c_int * 16)(); hs = (C.c_int * 16)()
+    total = lib().orc_pyr_layout(int(w), int(h), int(levels), off, ws, hs)
+    return total, list(off[:levels + 1]), list(ws[:levels + 1]), list(hs[:levels + 1])
+
+
+def pyr_build(img_u8, levels=2):
+    img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    h, w = img.shape
+    total, _, _, _ = pyr_layout(w, h, levels)
+    pyr = np.zeros(total, np.uint8)
+    lib().orc_pyr_build(_p(img), w, h, w, int(levels), _p(pyr))
+    return pyr
+
+
+def lk_track(prev_pyr, cur_pyr, w, h, prev_pts, cur_init, track_type=0, move_cols=0.0, levels=2, win=21, iters=30):
+    pp = _f(prev_pts).reshape(-1, 2); ci = _f(cur_init).reshape(-1, 2)
+    n = pp.shape[0]
+    out = np.zeros((n, 2), np.float32); st = np.zeros(n, np.uint8)
+    lib().orc_lk_track(_p(prev_pyr), _p(cur_pyr), int(w), int(h), int(levels), _p(pp), _p(ci), n, int(track_type),
+                       C.c_float(move_cols), int(win), int(iters), _p(out), _p(st))
+    return out, st
+
+
+def fast_by_region(img_u8, features, cols=3, rows=4, threshold=10):
+    img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    h, w = img.shape
+    cap = max(int(features), 1)
+    xy = np.zeros((cap, 2), np.float32); resp = np.zeros(cap, np.int32)
+    n = lib().orc_fast_by_region(_p(img), w, h, w, int(features), int(cols), int(rows), int(threshold), _p(xy), _p(resp), cap)
+    return xy[:n].copy(), resp[:n].copy()
+
+
+def min_eigen(img_u8):
+    img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    h, w = img.shape
+    eig = np.zeros((h, w), np.float32)
+    lib().orc_min_eigen(_p(img), w, h, w, _p(eig))
+    return eig
+
+
+def good_features(img_u8, max_corners, quality=0.01, min_dist=20.0):
+    img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    h, w = img.shape
+    cap = max(int(max_corners), 1) if max_corners > 0 else w * h
+    xy = np.zeros((cap, 2), np.float32)
+    n = lib().orc_good_features(_p(img), w, h, w, int(max_corners), C.c_double(quality), C.c_double(min_dist), _p(xy), cap)
+    return xy[:n].copy()

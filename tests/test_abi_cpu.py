@@ -86,4 +86,4 @@ def test_product_does_not_import_oracle():
         for f in fs:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 s = open(os.path.join(dp, f)).read()
-                assert "from oracle" not in s and "import oracle" not in s and "d2fe_oracle" not in s.replace("oracle/d2fe_oracle.c", ""), f
+                assert "from oracle" not in s and "import oracle" not in s and "d2fe_oracle" not in s.replace("oracle/d2fe_oracle.c", "").replace("oracle/d2fe_oracle_lk.c", ""), f   # comments may cite the files
