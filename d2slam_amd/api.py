@@ -78,6 +78,7 @@ EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_creat
            "d2fe_half_image_filter", "d2fe_undistort", "d2fe_undistort_device", "d2fe_db_create", "d2fe_db_destroy",
            "d2fe_db_ntotal", "d2fe_db_add", "d2fe_db_search", "d2fe_db_query_gated", "d2fe_quantize_int8", "d2fe_dequantize_int8",
            "d2fe_debug_read", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read",
+           "d2fe_gen_cylinder_map", "d2fe_gen_cylinder_map_device", "d2fe_gen_pinhole_map", "d2fe_gen_pinhole_map_device",
            "d2fe_lk_frame_create", "d2fe_lk_frame_create_device", "d2fe_lk_frame_destroy", "d2fe_lk_frame_read_level",
            "d2fe_lk_track", "d2fe_detect_fast_by_region", "d2fe_good_features_to_track"]
 
@@ -137,6 +138,11 @@ def load_library():
         lib.d2fe_desc_dim.argtypes = [C.c_void_p]
         lib.d2fe_profile_enable.argtypes = [C.c_void_p, C.c_int]
         lib.d2fe_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.d2fe_gen_cylinder_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        lib.d2fe_gen_cylinder_map_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.d2fe_gen_pinhole_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        lib.d2fe_gen_pinhole_map_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p]
         lib.d2fe_lk_frame_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         lib.d2fe_lk_frame_create_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         lib.d2fe_lk_frame_destroy.argtypes = [C.c_void_p]
@@ -355,6 +361,30 @@ class FrontEnd:
         """Device-resident undistort of n frames sharing one map set (raw addresses)."""
         _check(self._lib.d2fe_undistort_device(self._h, d_src, n, sw, sh, sstride or sw, src_image_stride if src_image_stride is not None else sw * sh,
                                                d_mapx, d_mapy, d_gain, dw, dh, d_dst, stream))
+
+    @staticmethod
+    def _mei(cam):
+        """cam: dict(xi,k1,k2,p1,p2,gamma1,gamma2,u0,v0) or the 9 values in that order (kalibr 'omni' + 'radtan')."""
+        keys = ("xi", "k1", "k2", "p1", "p2", "gamma1", "gamma2", "u0", "v0")
+        vals = [cam[k] for k in keys] if isinstance(cam, dict) else list(cam)
+        return (C.c_double * 9)(*[float(v) for v in vals])
+
+    def gen_cylinder_map(self, cam, width, height, fov_deg):
+        """FisheyeUndist::generateCylinderMap (fisheye_undistort.h:458-500) -> (mapx, mapy) float32 [height, width]."""
+        mx = np.zeros((height, width), np.float32); my = np.zeros((height, width), np.float32)
+        _check(self._lib.d2fe_gen_cylinder_map(self._h, self._mei(cam), int(width), int(height), float(fov_deg), _ptr(mx), _ptr(my)))
+        return mx, my
+
+    def gen_cylinder_map_device(self, cam, width, height, fov_deg, d_mapx, d_mapy, stream=None):
+        _check(self._lib.d2fe_gen_cylinder_map_device(self._h, self._mei(cam), int(width), int(height), float(fov_deg),
+                                                      C.c_void_p(d_mapx), C.c_void_p(d_mapy), C.c_void_p(stream or 0)))
+
+    def gen_pinhole_map(self, cam, q_wxyz, width, height, f):
+        """genOneUndistMap(id, cam, rotation, w, h, f) (fisheye_undistort.h:615-660) -> (mapx, mapy)."""
+        mx = np.zeros((height, width), np.float32); my = np.zeros((height, width), np.float32)
+        q = (C.c_double * 4)(*[float(v) for v in q_wxyz])
+        _check(self._lib.d2fe_gen_pinhole_map(self._h, self._mei(cam), q, int(width), int(height), float(f), _ptr(mx), _ptr(my)))
+        return mx, my
 
     def quantize_int8(self, x, double_max=False):
         x = np.ascontiguousarray(x, np.float32).reshape(-1)

@@ -684,6 +684,49 @@ int d2fe_undistort(d2fe_handle h, const uint8_t* src, int sw, int sh, int sstrid
   return rc;
 }
 
+static int gen_map(d2fe_handle h, const d2fe_mei_camera* cam, const double* q, int mode, int width, int height, double f,
+                   float* mapx, float* mapy, bool device, void* stream) {
+  if (!h || !cam || !mapx || !mapy || (mode == 1 && !q)) return fail(D2FE_ERR_INVALID, "null argument");
+  if (width < 2 || height < 2 || (size_t)width * height > (1u << 28) || !(f > 0)) return fail(D2FE_ERR_INVALID, "bad map geometry");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  const double c9[9] = {cam->xi, cam->k1, cam->k2, cam->p1, cam->p2, cam->gamma1, cam->gamma2, cam->u0, cam->v0};
+  hipStream_t s = device && stream ? (hipStream_t)stream : h->stream;
+  if (device) {
+    HIP_TRY(launch_gen_map(c9, q, mode, width, height, f, mapx, mapy, s));
+    return D2FE_OK;
+  }
+  const size_t n = (size_t)width * height;
+  float* buf = nullptr;
+  HIP_TRY(hipMalloc(&buf, sizeof(float) * 2 * n));
+  int rc = D2FE_OK;
+  auto chk = [&](hipError_t e, const char* w) { if (e != hipSuccess && rc == D2FE_OK) rc = fail(D2FE_ERR_HIP, std::string(w) + ": " + hipGetErrorString(e)); };
+  chk(launch_gen_map(c9, q, mode, width, height, f, buf, buf + n, s), "gen_map");
+  chk(hipMemcpyAsync(mapx, buf, sizeof(float) * n, hipMemcpyDeviceToHost, s), "D2H mapx");
+  chk(hipMemcpyAsync(mapy, buf + n, sizeof(float) * n, hipMemcpyDeviceToHost, s), "D2H mapy");
+  chk(hipStreamSynchronize(s), "sync");
+  hipFree(buf);
+  return rc;
+}
+static double cyl_focal(int width, double fov_deg) { return (double)(unsigned)width / (fov_deg * (M_PI / 180.0)); }
+
+int d2fe_gen_cylinder_map(d2fe_handle h, const d2fe_mei_camera* cam, int width, int height, double fov_deg, float* mapx, float* mapy) {
+  if (!(fov_deg > 0)) return fail(D2FE_ERR_INVALID, "fov must be positive");
+  return gen_map(h, cam, nullptr, 0, width, height, cyl_focal(width, fov_deg), mapx, mapy, false, nullptr);
+}
+int d2fe_gen_cylinder_map_device(d2fe_handle h, const d2fe_mei_camera* cam, int width, int height, double fov_deg, float* d_mapx,
+                                 float* d_mapy, void* stream) {
+  if (!(fov_deg > 0)) return fail(D2FE_ERR_INVALID, "fov must be positive");
+  return gen_map(h, cam, nullptr, 0, width, height, cyl_focal(width, fov_deg), d_mapx, d_mapy, true, stream);
+}
+int d2fe_gen_pinhole_map(d2fe_handle h, const d2fe_mei_camera* cam, const double* q_wxyz, int width, int height, double f,
+                         float* mapx, float* mapy) {
+  return gen_map(h, cam, q_wxyz, 1, width, height, f, mapx, mapy, false, nullptr);
+}
+int d2fe_gen_pinhole_map_device(d2fe_handle h, const d2fe_mei_camera* cam, const double* q_wxyz, int width, int height, double f,
+                                float* d_mapx, float* d_mapy, void* stream) {
+  return gen_map(h, cam, q_wxyz, 1, width, height, f, d_mapx, d_mapy, true, stream);
+}
+
 int d2fe_db_create(d2fe_handle h, int dim, int capacity, d2fe_db_handle* out) {
   if (!h || !out) return fail(D2FE_ERR_INVALID, "null argument");
   *out = nullptr;

@@ -82,6 +82,8 @@ hipError_t launch_nv_vlad(const float* x, int np, int D, int K, const float* aw,
 hipError_t launch_nv_pca(const float* x, int nfeat, const float* comp, const float* mean, int m, float* y, int n, hipStream_t s);
 
 // ---- SURVEY 8(f) next rows (next.hip) ------------------------------------------------------------------------------------
+hipError_t launch_gen_map(const double* cam9, const double* q4, int mode, int width, int height, double f, float* mapx,
+                          float* mapy, hipStream_t s);
 hipError_t launch_undistort(const uint8_t* src, int sh, int sw, int sstride, long src_istride, const float* mapx,
                             const float* mapy, const float* gain, int dh, int dw, int n, uint8_t* dst, hipStream_t s);
 hipError_t launch_db_search(const float* db, int ntotal, int dim, const float* q, int nq, int k, float* sims_scratch,

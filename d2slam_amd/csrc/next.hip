@@ -58,6 +58,61 @@ hipError_t launch_undistort(const uint8_t* src, int sh, int sw, int sstride, lon
   return hipGetLastError();
 }
 
+// ---- (f)-1, map generation: FisheyeUndist::generateCylinderMap / genOneUndistMap (fisheye_undistort.h:458-500,559-660) --------
+// One thread per map pixel, fp64 like the reference (camodocal works in double); the maps are born in HBM where
+// undistort_kernel reads them.  cam = xi k1 k2 p1 p2 gamma1 gamma2 u0 v0 (CataCamera, CataCamera.cc:495-515,617-633).
+struct MapArgs { double cam[9]; double q[4]; double f; double iK13, iK23; int width, height, mode; float* mapx; float* mapy; };
+
+__device__ __forceinline__ void mei_space_to_plane(const double* cam, double X, double Y, double Z, double& u, double& v) {
+  const double nrm = __builtin_sqrt(X * X + (Y * Y + Z * Z));
+  const double z = Z + cam[0] * nrm;
+  const double pu0 = X / z, pu1 = Y / z;
+  const double mx2 = pu0 * pu0, my2 = pu1 * pu1, mxy = pu0 * pu1, rho2 = mx2 + my2;
+  const double rad = cam[1] * rho2 + cam[2] * rho2 * rho2;
+  const double d0 = pu0 * rad + 2.0 * cam[3] * mxy + cam[4] * (rho2 + 2.0 * mx2);
+  const double d1 = pu1 * rad + 2.0 * cam[4] * mxy + cam[3] * (rho2 + 2.0 * my2);
+  u = cam[5] * (pu0 + d0) + cam[7];
+  v = cam[6] * (pu1 + d1) + cam[8];
+}
+
+__global__ __launch_bounds__(256) void gen_map_kernel(MapArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.width * a.height) return;
+  const int x = i % a.width, y = i / a.width;
+  double X, Y, Z;
+  if (a.mode == 0) {           // cylinder: CylindricalCamera::liftProjective (CylindricalCamera.cc:207-220), m_inv_K11 = m_inv_K22 = 1/f
+    const double ik = 1.0 / a.f;
+    const double phi = ik * (double)x + a.iK13;
+    const double ybr = ik * (double)y + a.iK23;
+    Z = __builtin_fabs(phi) > 1.5707963267948966 ? -1.0 : 1.0;
+    X = Z * tan(phi);
+    Y = ybr * __builtin_sqrt(X * X + Z * Z);
+  } else {                     // pinhole: rotation * (x - w/2, y - h/2, f), Eigen quaternion-vector product
+    const double w = a.q[0], qx = a.q[1], qy = a.q[2], qz = a.q[3];
+    const double vx = (double)x - (double)(unsigned)a.width / 2, vy = (double)y - (double)(unsigned)a.height / 2, vz = a.f;
+    double ux = qy * vz - qz * vy, uy = qz * vx - qx * vz, uz = qx * vy - qy * vx;
+    ux = ux + ux; uy = uy + uy; uz = uz + uz;
+    const double cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
+    X = (vx + w * ux) + cx; Y = (vy + w * uy) + cy; Z = (vz + w * uz) + cz;
+  }
+  double u, v;
+  mei_space_to_plane(a.cam, X, Y, Z, u, v);
+  a.mapx[i] = (float)u;
+  a.mapy[i] = (float)v;
+}
+
+hipError_t launch_gen_map(const double* cam9, const double* q4, int mode, int width, int height, double f, float* mapx,
+                          float* mapy, hipStream_t s) {
+  MapArgs a;
+  for (int i = 0; i < 9; ++i) a.cam[i] = cam9[i];
+  for (int i = 0; i < 4; ++i) a.q[i] = q4 ? q4[i] : (i == 0 ? 1.0 : 0.0);
+  a.f = f; a.width = width; a.height = height; a.mode = mode; a.mapx = mapx; a.mapy = mapy;
+  a.iK13 = -(double)((unsigned)width / 2) / f;     // -cx/fx with cx = imgWidth / 2 (unsigned division, fisheye_undistort.h:494-495)
+  a.iK23 = -(double)((unsigned)height / 2) / f;
+  hipLaunchKernelGGL(gen_map_kernel, dim3((width * height + 255) / 256), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 // ---- (f)-2: flat inner-product database ------------------------------------------------------------------------------------------
 // sims[q][i] = <db[i], query[q]>: one wave per database row, the row is read once (coalesced float4) and reused for every
 // query of the batch (queries staged in LDS).  HBM-bound: ntotal*dim*4 bytes per search.

@@ -205,6 +205,24 @@ D2FE_API int d2fe_undistort_device(d2fe_handle h, const uint8_t* d_src, int n, i
                                    size_t src_image_stride, const float* d_mapx, const float* d_mapy, const float* d_gain,
                                    int dw, int dh, uint8_t* d_dst, void* stream);
 
+/* (f)-1, map generation.  FisheyeUndist::generateCylinderMap + genOneUndistMap (fisheye_undistort.h:458-500,559-613): a
+ * virtual camodocal::CylindricalCamera (fx = fy = width / (fov_deg * pi/180), cx = width/2, cy = height/2) is lifted
+ * (CylindricalCamera.cc:207-220) and projected through the fisheye model; the pinhole form is the other genOneUndistMap
+ * (:615-660, the five virtual cameras of generateAllUndistMap :346-456): objPoint = q * (x - width/2, y - height/2, f).
+ * The fisheye model is camodocal's CataCamera ("omni" + "radtan" in config/quadcam/quad_cam_calib-*.yaml; spaceToPlane
+ * CataCamera.cc:495-515).  Maps are width*height floats each, written to HBM (device form) or copied back (host form). */
+typedef struct {
+  double xi, k1, k2, p1, p2, gamma1, gamma2, u0, v0;   /* kalibr order: intrinsics [xi fu fv pu pv], distortion [k1 k2 p1 p2] */
+} d2fe_mei_camera;
+D2FE_API int d2fe_gen_cylinder_map(d2fe_handle h, const d2fe_mei_camera* cam, int width, int height, double fov_deg,
+                                   float* mapx, float* mapy);
+D2FE_API int d2fe_gen_cylinder_map_device(d2fe_handle h, const d2fe_mei_camera* cam, int width, int height, double fov_deg,
+                                          float* d_mapx, float* d_mapy, void* stream);
+D2FE_API int d2fe_gen_pinhole_map(d2fe_handle h, const d2fe_mei_camera* cam, const double* q_wxyz, int width, int height,
+                                  double f, float* mapx, float* mapy);
+D2FE_API int d2fe_gen_pinhole_map_device(d2fe_handle h, const d2fe_mei_camera* cam, const double* q_wxyz, int width, int height,
+                                         double f, float* d_mapx, float* d_mapy, void* stream);
+
 /* (f)-2 NetVLAD keyframe database.  Replaces faiss::IndexFlatIP (members d2frontend/include/d2frontend/loop_detector.h:71-72;
  * add d2frontend/src/loop_detector.cpp:254-263; search :318) and the gate of LoopDetector::queryIndexFromDatabase
  * (:300-350).  Vectors live in HBM; a search is one streaming pass over the database. */

@@ -686,3 +686,60 @@ ORC_API void orc_dequant_int8(const int8_t* q, int n, int landmark_num, float* o
     for (int i = 0; i < n; ++i) out[i] = out[i] / nr;
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Section 8(f)-1, map generation: FisheyeUndist::generateCylinderMap + genOneUndistMap
+ * (d2common/include/d2common/fisheye_undistort.h:458-500,559-613) and the pinhole variant of genOneUndistMap
+ * (:615-660, used by generateAllUndistMap :346-456).  The fisheye camera is camodocal's CataCamera (MEI model,
+ * "omni" + "radtan" in config/quadcam/quad_cam_calib-*.yaml): spaceToPlane camera_models/src/camera_models/CataCamera.cc:495-515,
+ * distortion :617-633.  The virtual camera is CylindricalCamera::liftProjective (CylindricalCamera.cc:207-220) with
+ * fx = fy = width / fov_rad, cx = width/2, cy = height/2 (integer divisions of the unsigned sizes, as in the reference).
+ * All arithmetic in double; the map stores (float)x, (float)y.  cam[9] = xi k1 k2 p1 p2 gamma1 gamma2 u0 v0.
+ * ------------------------------------------------------------------------------------------ */
+static void mei_space_to_plane(const double* cam, double X, double Y, double Z, double* u, double* v) {
+  const double xi = cam[0], k1 = cam[1], k2 = cam[2], p1 = cam[3], p2 = cam[4];
+  const double nrm = sqrt(X * X + (Y * Y + Z * Z));          /* Eigen's 3-vector redux: x^2 + (y^2 + z^2) */
+  const double z = Z + xi * nrm;
+  const double pu0 = X / z, pu1 = Y / z;
+  const double mx2 = pu0 * pu0, my2 = pu1 * pu1, mxy = pu0 * pu1, rho2 = mx2 + my2;
+  const double rad = k1 * rho2 + k2 * rho2 * rho2;
+  const double d0 = pu0 * rad + 2.0 * p1 * mxy + p2 * (rho2 + 2.0 * mx2);
+  const double d1 = pu1 * rad + 2.0 * p2 * mxy + p1 * (rho2 + 2.0 * my2);
+  *u = cam[5] * (pu0 + d0) + cam[7];
+  *v = cam[6] * (pu1 + d1) + cam[8];
+}
+
+ORC_API void orc_gen_cylinder_map(const double* cam, int width, int height, double fov_deg, float* mapx, float* mapy) {
+  const double fov = fov_deg * (M_PI / 180.0);
+  const double f = (double)(unsigned)width / fov;
+  const double cx = (double)((unsigned)width / 2), cy = (double)((unsigned)height / 2);
+  const double iK11 = 1.0 / f, iK13 = -cx / f, iK22 = 1.0 / f, iK23 = -cy / f;
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) {
+      const double phi = iK11 * (double)x + iK13;
+      const double ybr = iK22 * (double)y + iK23;
+      const double z = fabs(phi) > M_PI / 2 ? -1.0 : 1.0;
+      const double X = z * tan(phi);
+      const double rho = sqrt(X * X + z * z);
+      double u, v;
+      mei_space_to_plane(cam, X, ybr * rho, z, &u, &v);
+      mapx[(size_t)y * width + x] = (float)u;
+      mapy[(size_t)y * width + x] = (float)v;
+    }
+}
+
+/* q = (w, x, y, z); Eigen::Quaterniond * Vector3d: uv = 2 (q.vec x v); v + w uv + q.vec x uv */
+ORC_API void orc_gen_pinhole_map(const double* cam, const double* q, int width, int height, double f, float* mapx, float* mapy) {
+  const double w = q[0], qx = q[1], qy = q[2], qz = q[3];
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) {
+      const double vx = (double)x - (double)(unsigned)width / 2, vy = (double)y - (double)(unsigned)height / 2, vz = f;
+      double ux = qy * vz - qz * vy, uy = qz * vx - qx * vz, uz = qx * vy - qy * vx;
+      ux = ux + ux; uy = uy + uy; uz = uz + uz;
+      const double cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
+      double u, v;
+      mei_space_to_plane(cam, (vx + w * ux) + cx, (vy + w * uy) + cy, (vz + w * uz) + cz, &u, &v);
+      mapx[(size_t)y * width + x] = (float)u;
+      mapy[(size_t)y * width + x] = (float)v;
+    }
+}

@@ -343,3 +343,18 @@ def good_features(img_u8, max_corners, quality=0.01, min_dist=20.0):
     xy = np.zeros((cap, 2), np.float32)
     n = lib().orc_good_features(_p(img), w, h, w, int(max_corners), C.c_double(quality), C.c_double(min_dist), _p(xy), cap)
     return xy[:n].copy()
+
+
+# ---- section 8(f)-1: undistortion map generation (MEI fisheye -> cylinder / pinhole virtual camera) -----------------------------
+def gen_cylinder_map(cam9, width, height, fov_deg):
+    cam = np.ascontiguousarray(cam9, np.float64)
+    mx = np.zeros((height, width), np.float32); my = np.zeros((height, width), np.float32)
+    lib().orc_gen_cylinder_map(_p(cam), int(width), int(height), C.c_double(fov_deg), _p(mx), _p(my))
+    return mx, my
+
+
+def gen_pinhole_map(cam9, q_wxyz, width, height, f):
+    cam = np.ascontiguousarray(cam9, np.float64); q = np.ascontiguousarray(q_wxyz, np.float64)
+    mx = np.zeros((height, width), np.float32); my = np.zeros((height, width), np.float32)
+    lib().orc_gen_pinhole_map(_p(cam), _p(q), int(width), int(height), C.c_double(f), _p(mx), _p(my))
+    return mx, my

@@ -118,3 +118,68 @@ def test_int8_codec_gpu(orc):
     cos = (back * xs).sum(1) / np.linalg.norm(xs, axis=1)
     assert cos.min() > 0.98
     fe.close()
+
+
+# ---- (f)-1 map generation (fisheye_undistort.h:458-500,559-660) --------------------------------------------------------------------
+# cam0 of config/quadcam/quad_cam_calib-camchain-imucam-7-inch-n3.yaml (camera_model omni, distortion radtan)
+QUADCAM_MEI = dict(xi=2.2176903753419963, k1=-0.17703529535292872, k2=0.7517933338735744, p1=-0.0008911425891703079,
+                   p2=2.1653595535258756e-05, gamma1=1162.5434300524314, gamma2=1161.839362615319, u0=660.6393183718625,
+                   v0=386.1663300322095)
+_MEI_KEYS = ("xi", "k1", "k2", "p1", "p2", "gamma1", "gamma2", "u0", "v0")
+
+
+def _mei_np(cam, X, Y, Z):
+    n = np.sqrt(X * X + Y * Y + Z * Z)
+    z = Z + cam["xi"] * n
+    x, y = X / z, Y / z
+    r2 = x * x + y * y
+    rad = cam["k1"] * r2 + cam["k2"] * r2 * r2
+    dx = x * rad + 2 * cam["p1"] * x * y + cam["p2"] * (r2 + 2 * x * x)
+    dy = y * rad + 2 * cam["p2"] * x * y + cam["p1"] * (r2 + 2 * y * y)
+    return cam["gamma1"] * (x + dx) + cam["u0"], cam["gamma2"] * (y + dy) + cam["v0"]
+
+
+def test_gen_maps_oracle_vs_numpy(orc):
+    cam9 = [QUADCAM_MEI[k] for k in _MEI_KEYS]
+    W, H, fov = 800, 400, 200.0                                       # quadcam_single.yaml:18-23
+    mx, my = orc.gen_cylinder_map(cam9, W, H, fov)
+    f = W / np.deg2rad(fov)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    phi = (xx - W // 2) / f
+    z = np.where(np.abs(phi) > np.pi / 2, -1.0, 1.0)
+    X = z * np.tan(phi); rho = np.sqrt(X * X + z * z)
+    u, v = _mei_np(QUADCAM_MEI, X, (yy - H // 2) / f * rho, z)
+    assert np.abs(mx - u).max() < 2e-4 and np.abs(my - v).max() < 2e-4
+    assert abs(mx[H // 2, W // 2] - QUADCAM_MEI["u0"]) < 1e-3 and abs(my[H // 2, W // 2] - QUADCAM_MEI["v0"]) < 1e-3
+    assert (np.diff(mx[H // 2]) > 0).all() and (np.diff(my[:, W // 2]) > 0).all()          # monotone along the axes
+    # pinhole virtual camera rotated -45 deg about y (a side camera of generateAllUndistMap, :429-437)
+    a = -np.pi / 4
+    q = [np.cos(a / 2), 0.0, np.sin(a / 2), 0.0]
+    px, py = orc.gen_pinhole_map(cam9, q, 600, 300, 300.0)
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    yy, xx = np.mgrid[0:300, 0:600].astype(np.float64)
+    P = np.stack([xx - 300, yy - 150, np.full_like(xx, 300.0)], -1) @ R.T
+    u, v = _mei_np(QUADCAM_MEI, P[..., 0], P[..., 1], P[..., 2])
+    assert np.abs(px - u).max() < 2e-4 and np.abs(py - v).max() < 2e-4
+
+
+@pytest.mark.gpu
+def test_gen_maps_gpu(orc):
+    from d2slam_amd import api
+    fe = api.FrontEnd(api.SuperPointConfig(input_width=64, input_height=64, max_batch=1))
+    cam9 = [QUADCAM_MEI[k] for k in _MEI_KEYS]
+    gx, gy = fe.gen_cylinder_map(QUADCAM_MEI, 800, 400, 200.0)
+    rx, ry = orc.gen_cylinder_map(cam9, 800, 400, 200.0)
+    # fp64 evaluation rounded to fp32: the device tan()/sqrt() may differ from glibc's in the last fp64 bit -> at most one fp32 ulp
+    assert np.abs(gx - rx).max() <= 1.3e-4 and np.abs(gy - ry).max() <= 1.3e-4
+    assert (gx == rx).mean() > 0.999 and (gy == ry).mean() > 0.999
+    q = [np.cos(np.pi / 8), 0.0, np.sin(np.pi / 8), 0.0]
+    px, py = fe.gen_pinhole_map(cam9, q, 600, 300, 300.0)
+    ox, oy = orc.gen_pinhole_map(cam9, q, 600, 300, 300.0)
+    assert np.abs(px - ox).max() <= 1.3e-4 and np.abs(py - oy).max() <= 1.3e-4
+    # end to end: raw 1280x800 frame -> cylinder image with device-generated maps == oracle with oracle maps (u8)
+    src = synth_image(800, 1280, 9)
+    got = fe.undistort(src, gx, gy, None)
+    ref = orc.undistort(src, rx, ry, None)
+    assert (got != ref).mean() < 1e-4 and np.abs(got.astype(int) - ref.astype(int)).max() <= 1
+    fe.close()
