@@ -212,7 +212,7 @@ def main():
         return dict(first=first, value=value, ms_per_step=ms_per_step, roofline=roofline, n_kp=n_kp, n_match=n_match,
                     breakdown=breakdown, NI=NI, NP=NP, F=F)
 
-    primary = run_mode(args.precision, args.breakdown)
+    primary = run_mode(args.precision, True)   # the per-stage pass (5 extra untimed steps, rank 0 / N=1 only) feeds hbm_kernels
     other = None
     if not args.single_mode:
         other = run_mode("f16x2" if args.precision == "f32" else "f32", False)
@@ -254,6 +254,18 @@ def main():
                            if om == "f16x2" else "bitwise vs oracle (activations, scores, indices, matches)")}
         if breakdown:
             out["stage_ms"] = breakdown
+            # HBM-bound tail of the path: algorithmic bytes per launch / HIP-event time of the stage.
+            # softmax+candidates: 65*Hc*Wc*4 B of logits read per image (the dense score map is not written in variant B);
+            # select: the candidate keys (8 B each, ~7 % of the pixels pass 0.015 with these weights) -- latency-bound by design;
+            # sample: 4 corner rows x 1 KiB per keypoint; match: (nA + nB) * 256 * 4 B per pair.
+            def _gbps(nbytes, ms):
+                return {"ms_per_launch": ms, "algorithmic_bytes": int(nbytes), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                        "frac_of_hbm_6290GBps": round(nbytes / (ms * 1e-3) / 6.29e12, 4)} if ms else None
+            out["hbm_kernels"] = {
+                "softmax_cand_kernel": _gbps(65 * (H // 8) * (W // 8) * 4 * NI, breakdown.get("softmax_cand")),
+                "sample_b_kernel": _gbps(n_kp * NI * (4 * 1024 + 1024), breakdown.get("sample")),
+                "match_prefilter+finalize": _gbps(2 * CAP * 256 * 4 * NP, breakdown.get("match")),
+            }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -83,10 +83,32 @@ EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_creat
            "d2fe_lk_track", "d2fe_detect_fast_by_region", "d2fe_good_features_to_track"]
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's): whichever copy
+    is loaded first serves both, and torch cannot see the GPU through the system copy.  If torch is installed but not yet
+    imported, load ITS runtime first (located without importing torch) so that a later `import torch` stays consistent."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def load_library():
     """dlopen the C-ABI library.  Raises if it has not been built (python -m d2slam_amd.build)."""
     global _lib
     if _lib is None:
+        _preload_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise D2FEError(-100, "libd2fe_hip.so not built: run `python __graft_entry__.py` or d2slam_amd/build.py "
                                   "(no CPU fallback exists)")

@@ -32,72 +32,108 @@ __device__ __forceinline__ float d2fe_expf(float x) {
 
 // -----------------------------------------------------------------------------------------------------
 // softmax over 65 logits per 8x8 cell, sequential sum c = 0..64 (oracle order), scores e_c / s.
-// Block = 64 threads = 64 consecutive cells: logits are staged through LDS with coalesced loads, then
-// one thread owns one cell.  Variant-B candidates (superpoint_tensorrt.cpp:201-230: score > thr, inside
-// [border, dim-border)) are appended as keys (score_bits << 32) | (0xFFFFFFFF - raster_idx): descending
-// key order == descending score, ties by ascending raster index (the oracle's tie-break).
+// Block = 256 threads = 64 consecutive cells x 4 lanes: the logits are staged through LDS with coalesced loads; the four
+// lanes of a cell own the channel quarters [0,17) [17,33) [33,49) [49,65).  max is order-independent; the exps and the
+// divisions are independent per channel; only the SUM has a prescribed order, and it is kept: the running sum is handed
+// from quarter to quarter (3 shuffles), so the chain is still ((e0 + e1) + e2) + ... + e64 bit for bit.
+// (First version: one lane per cell, 65 serial exps + 64 serial divisions per lane at 2 waves/SIMD: 69 us per 32 images.)
+// Variant-B candidates (superpoint_tensorrt.cpp:201-230: score > thr, inside [border, dim-border)) are appended as
+// keys (score_bits << 32) | (0xFFFFFFFF - raster_idx): descending key order == descending score, ties by ascending
+// raster index (the oracle's tie-break).  The list order is irrelevant (keys are unique, select_b sorts).
 // -----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void softmax_cand_kernel(const float* __restrict__ logits, int lstride, int Hc, int Wc,
-                                                          float thr, int border, float* __restrict__ semi,
-                                                          unsigned long long* __restrict__ cand,
-                                                          int* __restrict__ cand_count, long cand_cap) {
+__global__ __launch_bounds__(256) void softmax_cand_kernel(const float* __restrict__ logits, int lstride, int Hc, int Wc,
+                                                           float thr, int border, float* __restrict__ semi,
+                                                           unsigned long long* __restrict__ cand,
+                                                           int* __restrict__ cand_count, long cand_cap) {
   __shared__ float sl[64 * 65];
   const int img = blockIdx.y;
   const int ncell = Hc * Wc;
   const int cell0 = blockIdx.x * 64;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const float* lg = logits + ((size_t)img * ncell + cell0) * lstride;
   const int nvalid = min(64, ncell - cell0);
-  for (int i = tid; i < nvalid * 65; i += 64) {
-    const int c = i / 65, k = i % 65;
-    sl[c * 65 + k] = lg[(size_t)c * lstride + k];
+  if (lstride == 65) {   // the cells of a block are one contiguous run of floats
+    for (int i = tid; i < nvalid * 65; i += 256) sl[i] = lg[i];
+  } else {
+    for (int i = tid; i < nvalid * 65; i += 256) {
+      const int c = i / 65, k = i % 65;
+      sl[c * 65 + k] = lg[(size_t)c * lstride + k];
+    }
   }
   __syncthreads();
-  const bool live = tid < nvalid;
-  const float* l = sl + (live ? tid : 0) * 65;  // stride 65 floats: conflict-free across the wave
+  const int cl = tid >> 2, q = tid & 3;
+  const bool live = cl < nvalid;
+  const int c0 = q == 0 ? 0 : 1 + 16 * q;          // 0, 17, 33, 49
+  const int nc = q == 0 ? 17 : 16;
+  const float* l = sl + (live ? cl : 0) * 65 + c0;
+  float v[17];
   float m = l[0];
-  for (int c = 1; c < 65; ++c) m = l[c] > m ? l[c] : m;
-  float e[65];
+#pragma unroll
+  for (int i = 0; i < 17; ++i) {
+    v[i] = i < nc ? l[i] : l[0];
+    m = v[i] > m ? v[i] : m;
+  }
+  m = fmaxf(m, __shfl_xor(m, 1, 64));
+  m = fmaxf(m, __shfl_xor(m, 2, 64));
+#pragma unroll
+  for (int i = 0; i < 17; ++i) v[i] = d2fe_expf(v[i] - m);
   float s = 0.f;
 #pragma unroll
-  for (int c = 0; c < 65; ++c) {
-    e[c] = d2fe_expf(l[c] - m);
-    s += e[c];
+  for (int qq = 0; qq < 4; ++qq) {
+    if (q == qq) {
+#pragma unroll
+      for (int i = 0; i < 17; ++i)
+        if (i < nc) s += v[i];
+    }
+    s = __shfl(s, (lane & ~3) | qq, 64);
   }
-  const int cell = cell0 + tid;
+  const int cell = cell0 + cl;
   const int cy = cell / Wc, cx = cell % Wc;
   const int W = Wc * 8, H = Hc * 8;
   unsigned long long* cd = cand + (size_t)img * cand_cap;
-  // pass 1: scores, optional dense store, per-thread candidate count
   int mine = 0;
-  unsigned long long pass_mask = 0;
+  unsigned pass_mask = 0;
 #pragma unroll
-  for (int c = 0; c < 64; ++c) {
-    const float p = e[c] / s;
-    e[c] = p;
-    const int y = cy * 8 + (c >> 3), x = cx * 8 + (c & 7);
-    if (semi && live) semi[(size_t)img * H * W + y * W + x] = p;
-    if (live && p > thr && y >= border && y < H - border && x >= border && x < W - border) { ++mine; pass_mask |= 1ull << c; }
+  for (int i = 0; i < 17; ++i) {
+    const int c = c0 + i;
+    if (i < nc && c < 64) {
+      const float p = v[i] / s;
+      v[i] = p;
+      const int y = cy * 8 + (c >> 3), x = cx * 8 + (c & 7);
+      if (semi && live) semi[(size_t)img * H * W + y * W + x] = p;
+      if (live && p > thr && y >= border && y < H - border && x >= border && x < W - border) { ++mine; pass_mask |= 1u << i; }
+    }
   }
-  // one reservation per wave: exclusive prefix of the per-lane counts, a single atomic for the wave's total
+  // one reservation per BLOCK (same-address atomics serialise in L2 at ~5 ns each; measured): exclusive prefix of the
+  // per-lane counts inside the wave, wave totals through LDS, a single atomic for the block's total
+  __shared__ int wtot[4];
+  __shared__ int s_base;
   int incl = mine;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int t = __shfl_up(incl, o, 64);
-    if (tid >= o) incl += t;
+    if (lane >= o) incl += t;
   }
-  const int total = __shfl(incl, 63, 64);
-  int base = 0;
-  if (tid == 0 && total > 0) base = atomicAdd(cand_count + img, total);
-  base = __shfl(base, 0, 64);
+  const int wave = tid >> 6;
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  if (tid == 0) {
+    const int t = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    s_base = t > 0 ? atomicAdd(cand_count + img, t) : 0;
+  }
+  __syncthreads();
+  int base = s_base;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) base += w < wave ? wtot[w] : 0;
   int slot = base + incl - mine;
 #pragma unroll
-  for (int c = 0; c < 64; ++c) {
-    if (pass_mask & (1ull << c)) {
+  for (int i = 0; i < 17; ++i) {
+    if (pass_mask & (1u << i)) {
+      const int c = c0 + i;
       const int y = cy * 8 + (c >> 3), x = cx * 8 + (c & 7);
       const unsigned idx = (unsigned)(y * W + x);
       if (slot < cand_cap)
-        cd[slot] = ((unsigned long long)__float_as_uint(e[c]) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+        cd[slot] = ((unsigned long long)__float_as_uint(v[i]) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
       ++slot;
     }
   }
@@ -107,7 +143,7 @@ hipError_t launch_softmax_cand(const float* logits, int lstride, int Hc, int Wc,
                                float* semi, unsigned long long* cand, int* cand_count, long cand_cap, hipStream_t s) {
   hipError_t e = hipMemsetAsync(cand_count, 0, sizeof(int) * n_img, s);
   if (e != hipSuccess) return e;
-  dim3 grid((Hc * Wc + 63) / 64, n_img), block(64);
+  dim3 grid((Hc * Wc + 63) / 64, n_img), block(256);
   hipLaunchKernelGGL(softmax_cand_kernel, grid, block, 0, s, logits, lstride, Hc, Wc, thr, border, semi, cand,
                      cand_count, cand_cap);
   return hipGetLastError();
