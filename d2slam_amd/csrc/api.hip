@@ -69,6 +69,7 @@ struct d2fe_context {
   int last_w = 0, last_h = 0, last_n = 0;
   const uint8_t* last_gray = nullptr; int last_stride = 0; size_t last_istride = 0;
   float* aconf = nullptr; int* clist = nullptr;     // variant A scratch
+  float* a_samp = nullptr; float* a_cn = nullptr; int a_scap = 0;   // variant A sampling: [batch][a_scap][256] samples, [batch][256] channel norms
   float* pca_comp_t = nullptr; float* pca_mean = nullptr; int pca_dims = 0;
   // NetVLAD
   struct NvLayer { int kind, cin, cout, cout_pad, stride, act, res; float* w = nullptr; float* b = nullptr; float* out = nullptr; };
@@ -140,8 +141,7 @@ int pack_layer(d2fe_context* h, Layer& L, const std::vector<const d2fe_conv_para
     rc = upload(pk.data(), pk.size() * sizeof(float), &L.wpack);
   } else {
     std::vector<uint16_t> pk(packed_weight_halfs_f16x2(cout_pad, cin, ks));
-    if (f16x2_uses_ldsb_layout(cin, ks)) pack_weights_f16x2_ldsb(w.data(), cout, cin, ks, cout_pad, pk.data());
-    else pack_weights_f16x2(w.data(), cout, cin, ks, cout_pad, pk.data());
+    pack_weights_f16x2(w.data(), cout, cin, ks, cout_pad, pk.data());
     rc = upload(pk.data(), pk.size() * sizeof(uint16_t), &L.wpack);
   }
   if (rc) return rc;
@@ -224,7 +224,7 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
   { ProfScope ps(h, D2FE_PROF_SAMPLE, s);
     if (varA)
       HIP_TRY(launch_sample_a(h->draw.p, 256, 0, Hc, Wc, W, H, n, d_kps, d_n, cap, h->pca_dims ? h->pca_comp_t : nullptr,
-                              h->pca_mean, h->pca_dims, d_desc, s));
+                              h->pca_mean, h->pca_dims, h->a_samp, h->a_scap, h->a_cn, d_desc, s));
     else
       HIP_TRY(launch_sample_b(h->draw.p, 256, 0, Hc, Wc, n, d_kps, d_n, cap, d_desc, s)); }
   h->last_w = W; h->last_h = H; h->last_n = n;
@@ -306,6 +306,9 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   if (cfg->postproc == D2FE_POSTPROC_A) {
     HIP_TRY(hipMalloc(&h->aconf, sizeof(float) * H * W * B));
     HIP_TRY(hipMalloc(&h->clist, sizeof(int) * H * W * B));
+    h->a_scap = h->cfg.max_keypoints < 1024 ? h->cfg.max_keypoints : 1024;   // select keeps at most min(max_keypoints, 1024)
+    HIP_TRY(hipMalloc(&h->a_samp, sizeof(float) * 256 * (size_t)h->a_scap * B));
+    HIP_TRY(hipMalloc(&h->a_cn, sizeof(float) * 256 * B));
   }
   h->s_cap = 1024;
   HIP_TRY(hipMalloc(&h->s_img, H * W * B));
@@ -330,7 +333,7 @@ void d2fe_destroy(d2fe_handle h) {
     if (t->p) hipFree(t->p);
   for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
   for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->cand_count, (void*)h->s_img, (void*)h->s_kps,
-                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, h->m_buf, (void*)h->m_cand4, (void*)h->aconf, (void*)h->clist,
+                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, h->m_buf, (void*)h->m_cand4, (void*)h->aconf, (void*)h->clist, (void*)h->a_samp, (void*)h->a_cn,
                   (void*)h->pca_comp_t, (void*)h->pca_mean})
     if (p) hipFree(p);
   nv_free(h);

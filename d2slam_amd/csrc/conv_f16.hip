@@ -193,185 +193,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f16x2_kernel(ConvArgs a) {
   conv_epilogue<TW, MT, NT, POOL, RELU>(a, acc, 1.0f / bscale, img, ty0, tx0, wm, ntile0, lane);
 }
 
-// =====================================================================================================
-// Cin = 64 layers (conv1b with fused conv1a, conv2a, conv2b, conv3a): weights through LDS.
-// With 3 MFMAs per 1 KiB B fragment the L2 cannot feed per-wave B streams (measured: 35 % MFMA utilisation), so here the
-// block's 64 output channels' weights for ONE TAP (16 KiB: 4 k-steps x hi/lo x 2 n-tiles) are DMA'd into LDS
-// (global_load_lds_dwordx4, double-buffered: tap t+1 lands while tap t is multiplied) and shared by the 4 waves.
-// Tile 8x32 pixels x 64 channels, waves 4(M) x 1(N), each wave 2 m-tiles x 2 n-tiles (12 MFMAs per 8 ds_read_b128).
-// LDS: patch hi+lo 97.9 KB + 2 x 16 KB weights = 130.7 KB -> one block per CU.
-// Packed weight order for this kernel: [cout group of 64][tap][kstep][hi|lo][ntile(2)][lane] f16x8.
-// =====================================================================================================
-typedef __attribute__((address_space(1))) const void gvoid_t;
-typedef __attribute__((address_space(3))) void lvoid_t;
-
-template <bool POOL, bool RELU, bool FUSE1A>
-__global__ __launch_bounds__(256) void conv64_f16x2_ldsb_kernel(ConvArgs a) {
-  constexpr int CIN = 64, KS = 3, TH = 8, TW = 32, MT = 2, NT = 2;
-  constexpr int P = 1, PH = TH + 2, PW = TW + 2, CPH = CIN + 8, NPIX = PH * PW, NTHREADS = 256, TAPS = 9, KST = 4;
-  constexpr int BTAP_HALFS = KST * 2 * NT * 64 * 8;   // 8192 halves = 16 KiB per tap
-  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-  _Float16* hi = lds;
-  _Float16* lo = lds + NPIX * CPH;
-  _Float16* bbuf = lds + 2 * NPIX * CPH;             // [2][BTAP_HALFS]
-
-  const int tiles_x = (a.W + TW - 1) / TW;
-  const int tx0 = (blockIdx.x % tiles_x) * TW;
-  const int ty0 = (blockIdx.x / tiles_x) * TH;
-  const int img = blockIdx.z;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave;
-
-  const _Float16* wsrc = reinterpret_cast<const _Float16*>(a.wpack) + (size_t)blockIdx.y * TAPS * BTAP_HALFS;
-  auto dma_tap = [&](int tap, int buf) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int chunk = wave * 4 + c;   // 16 chunks of 1 KiB per tap
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(wsrc + (size_t)tap * BTAP_HALFS + (chunk * 64 + lane) * 8),
-                                       (lvoid_t*)(bbuf + buf * BTAP_HALFS + chunk * 512), 16, 0, 0);
-    }
-  };
-  dma_tap(0, 0);
-
-  // ---- stage + split the input patch (same arithmetic as conv_f16x2_kernel) -------------------------------------------
-  if constexpr (FUSE1A) {
-    const uint8_t* ip = a.img + (size_t)img * a.img_istride;
-    const float sa = (float)(1 << F16_SA);
-    for (int pix = tid; pix < ((NPIX + 63) / 64) * 64; pix += NTHREADS) {
-      const int gy = ty0 + pix / PW - P, gx = tx0 + pix % PW - P;
-      const bool inpatch = pix < NPIX;
-      const bool valid = inpatch && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      float v[9];
-      conv1a_load_taps(ip, a.img_stride, a.H, a.W, valid ? gy : 0, valid ? gx : 0, v);
-#pragma unroll 1
-      for (int oct = 0; oct < 8; ++oct) {
-        float o[8];
-        conv1a_octet(v, a.w1a, a.b1a, oct, valid, o);
-        f16x8 h8, l8;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          float x = fminf(o[c] * sa, 65000.f);
-          const _Float16 h = (_Float16)x;
-          h8[c] = h;
-          l8[c] = (_Float16)(x - (float)h);
-        }
-        if (inpatch) {
-          *reinterpret_cast<f16x8*>(hi + pix * CPH + oct * 8) = h8;
-          *reinterpret_cast<f16x8*>(lo + pix * CPH + oct * 8) = l8;
-        }
-      }
-    }
-  } else {
-    const float* in = a.in + (size_t)img * a.in_img_stride + a.in_coff;
-    constexpr int C4 = CIN / 4;
-    constexpr int TOTAL = NPIX * C4;
-    constexpr int ITERS = (TOTAL + NTHREADS - 1) / NTHREADS;
-    constexpr int UNR = 8;
-    const float sa = (float)(1 << F16_SA);
-    for (int it0 = 0; it0 < ITERS; it0 += UNR) {
-      f32x4 v[UNR];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int idx = (it0 + u) * NTHREADS + tid;
-        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (it0 + u < ITERS && idx < TOTAL) {
-          const int pix = idx / C4, c4 = idx % C4;
-          const int gy = ty0 + pix / PW - P, gx = tx0 + pix % PW - P;
-          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && !(a.ablate & 1))
-            v[u] = *reinterpret_cast<const f32x4*>(in + ((size_t)gy * a.W + gx) * a.in_cstride + c4 * 4);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int idx = (it0 + u) * NTHREADS + tid;
-        if (it0 + u < ITERS && idx < TOTAL) {
-          const int pix = idx / C4, c4 = idx % C4;
-          f16x4 h4, l4;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float x = v[u][j] * sa;
-            x = fminf(fmaxf(x, -65000.f), 65000.f);
-            const _Float16 h = (_Float16)x;
-            h4[j] = h;
-            l4[j] = (_Float16)(x - (float)h);
-          }
-          *reinterpret_cast<f16x4*>(hi + pix * CPH + c4 * 4) = h4;
-          *reinterpret_cast<f16x4*>(lo + pix * CPH + c4 * 4) = l4;
-        }
-      }
-    }
-  }
-  __syncthreads();   // patch written, tap-0 weights landed (the barrier's release drains the DMA: vmcnt(0))
-
-  const int ntile0 = blockIdx.y * NT;
-  const float bscale = (float)(1 << (F16_SA + F16_SW));
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const float b = a.bias[(ntile0 + n) * 32 + (lane & 31)] * bscale;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = b;
-  }
-  int aoff[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) aoff[m] = ((wm * MT + m) * PW + (lane & 31)) * CPH + 8 * (lane >> 5);
-
-#pragma unroll 1
-  for (int tap = 0; tap < TAPS; ++tap) {
-    if (tap + 1 < TAPS) dma_tap(tap + 1, (tap + 1) & 1);
-    const int tap_off = ((tap / KS) * PW + (tap % KS)) * CPH;
-    const _Float16* bb = bbuf + (tap & 1) * BTAP_HALFS + lane * 8;
-#pragma unroll
-    for (int ks = 0; ks < KST; ++ks) {
-      f16x8 ah[MT], al[MT], bh[NT], bl[NT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        ah[m] = *reinterpret_cast<const f16x8*>(hi + aoff[m] + tap_off + ks * 16);
-        al[m] = *reinterpret_cast<const f16x8*>(lo + aoff[m] + tap_off + ks * 16);
-      }
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        bh[n] = *reinterpret_cast<const f16x8*>(bb + ((ks * 2 + 0) * NT + n) * 512);
-        bl[n] = *reinterpret_cast<const f16x8*>(bb + ((ks * 2 + 1) * NT + n) * 512);
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
-        }
-    }
-    __syncthreads();   // next tap's weights landed; everyone is done with this tap's buffer
-  }
-  conv_epilogue<TW, MT, NT, POOL, RELU>(a, acc, 1.0f / bscale, img, ty0, tx0, wm, ntile0, lane);
-}
-
-static hipError_t launch_f16_ldsb(bool pool, bool relu, bool fuse, int cout_pad, const ConvArgs& a, hipStream_t s) {
-  constexpr int TH = 8, TW = 32;
-  constexpr size_t lds = (size_t)(TH + 2) * (TW + 2) * 72 * sizeof(_Float16) * 2 + 2 * 16384;
-  if (cout_pad % 64) return hipErrorInvalidValue;
-  dim3 grid(((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH), cout_pad / 64, a.n_img), block(256);
-#define D2FE_LAUNCH_LB(PL, RL, FU)                                                                   \
-  do {                                                                                               \
-    auto k = conv64_f16x2_ldsb_kernel<PL, RL, FU>;                                                   \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                             \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-    if (e != hipSuccess) return e;                                                                   \
-    hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                   \
-  } while (0)
-  if (fuse) D2FE_LAUNCH_LB(true, true, true);
-  else if (pool && relu) D2FE_LAUNCH_LB(true, true, false);
-  else if (!pool && relu) D2FE_LAUNCH_LB(false, true, false);
-  else return hipErrorInvalidValue;
-#undef D2FE_LAUNCH_LB
-  return hipGetLastError();
-}
-
 template <int CIN, int KS, int TH, int TW, int WM, int WN, int MT, int NT>
 static hipError_t launch_f16(bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s) {
   constexpr int BN = WN * NT * 32;
@@ -409,15 +230,7 @@ static hipError_t launch_f16_fused1b(int cout_pad, const ConvArgs& a, hipStream_
   return hipGetLastError();
 }
 
-static inline int tune_f16_ldsb() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("D2FE_F16_LDSB"); v = e ? atoi(e) : 0; }
-  return v;
-}
-
 hipError_t launch_conv_f16x2(ConvShape shape, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s) {
-  if (tune_f16_ldsb() && (shape == CONV1B_FUSED || shape == CONV_64_T8x32))
-    return launch_f16_ldsb(pool, relu, shape == CONV1B_FUSED, cout_pad, a, s);
   switch (shape) {
     case CONV1B_FUSED:       return launch_f16_fused1b(cout_pad, a, s);
     case CONV_64_T8x32:
@@ -454,30 +267,5 @@ void pack_weights_f16x2(const float* w, int cout, int cin, int ks, int cout_pad,
             d[(base + 64 + lane) * 8 + i] = l;
           }
 }
-
-// packing for conv64_f16x2_ldsb_kernel: [cout group of 64][tap][kstep][hi|lo][ntile(2)][lane][8]
-void pack_weights_f16x2_ldsb(const float* w, int cout, int cin, int ks, int cout_pad, uint16_t* dst) {
-  const int taps = ks * ks, kst = cin / 16;
-  const float sw = (float)(1 << F16_SW);
-  _Float16* d = reinterpret_cast<_Float16*>(dst);
-  for (int g = 0; g < cout_pad / 64; ++g)
-    for (int tap = 0; tap < taps; ++tap)
-      for (int k = 0; k < kst; ++k)
-        for (int n = 0; n < 2; ++n)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int i = 0; i < 8; ++i) {
-              const int co = g * 64 + n * 32 + (lane & 31);
-              const int ci = k * 16 + 8 * (lane >> 5) + i;
-              float v = co < cout ? w[((size_t)co * cin + ci) * taps + tap] * sw : 0.f;
-              if (v > 65000.f) v = 65000.f;
-              if (v < -65000.f) v = -65000.f;
-              const _Float16 h = (_Float16)v;
-              const _Float16 l = (_Float16)(v - (float)h);
-              const size_t base = ((((size_t)g * taps + tap) * kst + k) * 2) * 2;   // index of (hl = 0, n = 0) in units of 64 lanes
-              d[((base + 0 * 2 + n) * 64 + lane) * 8 + i] = h;
-              d[((base + 1 * 2 + n) * 64 + lane) * 8 + i] = l;
-            }
-}
-bool f16x2_uses_ldsb_layout(int cin, int ks) { return tune_f16_ldsb() && cin == 64 && ks == 3; }
 
 }  // namespace d2fe

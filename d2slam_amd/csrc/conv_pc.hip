@@ -398,26 +398,12 @@ static hipError_t launch_pc_one(int cout_pad, const ConvArgs& a, hipStream_t s) 
   return hipGetLastError();
 }
 
-// D2FE_PC_TILE64: 0 (default, measured best) = 4x32 tiles, 2x2 waves; 1 = 8x16-pixel tiles, consumer waves 4(M) x 1(N), every wave all 64 channels (shared B stream);
-//                 0 = 4x32 tiles, 2x2 waves
-static inline int pc_tile64() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("D2FE_PC_TILE64"); v = e ? atoi(e) : 0; }
-  return v;
-}
-
 template <int MODE>
 static hipError_t launch_pc_mode(ConvShape shape, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s) {
   switch (shape) {
     case CONV1B_FUSED:
-      if (pc_tile64() == 1) return launch_pc_one<MODE, 64, 3, 8, 16, 4, 1, 1, 2, true, true, true>(cout_pad, a, s);
       return launch_pc_one<MODE, 64, 3, 4, 32, 2, 2, 2, 1, true, true, true>(cout_pad, a, s);
     case CONV_64_T8x32:
-      if (pc_tile64() == 1) {
-        if (pool && relu) return launch_pc_one<MODE, 64, 3, 8, 16, 4, 1, 1, 2, true, true, false>(cout_pad, a, s);
-        if (!pool && relu) return launch_pc_one<MODE, 64, 3, 8, 16, 4, 1, 1, 2, false, true, false>(cout_pad, a, s);
-        break;
-      }
       if (pool && relu) return launch_pc_one<MODE, 64, 3, 4, 32, 2, 2, 2, 1, true, true, false>(cout_pad, a, s);
       if (!pool && relu) return launch_pc_one<MODE, 64, 3, 4, 32, 2, 2, 2, 1, false, true, false>(cout_pad, a, s);
       break;

@@ -46,8 +46,6 @@ size_t packed_weight_floats_f32(int cout_pad, int cin, int ks);
 void pack_weights_f32(const float* w /*[cout][cin][k][k]*/, int cout, int cin, int ks, int cout_pad, float* dst);
 size_t packed_weight_halfs_f16x2(int cout_pad, int cin, int ks);
 void pack_weights_f16x2(const float* w, int cout, int cin, int ks, int cout_pad, uint16_t* dst);
-void pack_weights_f16x2_ldsb(const float* w, int cout, int cin, int ks, int cout_pad, uint16_t* dst);
-bool f16x2_uses_ldsb_layout(int cin, int ks);
 
 // ---- post-processing ------------------------------------------------------------------------------
 // softmax(65) -> drop dustbin -> 8x8 unfold; writes dense semi (optional) and appends variant-B candidates
@@ -68,7 +66,7 @@ hipError_t launch_nms2_a(const float* semi, int H, int W, int n_img, float thr, 
                          unsigned long long* cand, int* cand_count, long cand_cap, hipStream_t s);
 hipError_t launch_sample_a(const float* desc_raw, int dstride, int dcoff, int Hc, int Wc, int img_w, int img_h, int n_img,
                            const float* kps_xy, const int32_t* n_kp, int cap, const float* comp_t, const float* mean,
-                           int pca_dims, float* desc_out, hipStream_t s);
+                           int pca_dims, float* samp, int scap, float* cn, float* desc_out, hipStream_t s);
 
 // ---- NetVLAD (netvlad.hip) -------------------------------------------------------------------------------------------
 hipError_t launch_nv_conv0(const uint8_t* img, int stride_b, long img_stride, int H, int W, int Ho, int Wo, int cstride,

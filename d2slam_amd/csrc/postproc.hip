@@ -417,19 +417,21 @@ hipError_t launch_nms2_a(const float* semi, int H, int W, int n_img, float thr, 
   return hipGetLastError();
 }
 
-// Variant-A descriptor sampling: computeDescriptors (superpoint_common.cpp:42-99): grid = 2*x/W - 1,
-// torch::grid_sampler(bilinear, zeros padding, align_corners = false), L2, optional PCA (d - mean) * comp^T + row L2.
-// One wave per keypoint.  comp_t: [256][pca_dims] (transposed CSV layout, superpoint_onnx.cpp:47-53) or null.
+// Variant-A descriptor sampling: computeDescriptors (superpoint_common.cpp:42-99).  Three small kernels, because the reference
+// normalises every CHANNEL over the image's keypoints before it normalises the rows (`torch::norm(desc, 2, 1)` on the
+// [256, N] tensor, :68-69 -- see the oracle's note and tests/golden/reference_notebook.npz):
+//   1. sample_a_kernel   : grid = 2*x/W - 1, torch::grid_sampler(bilinear, zeros padding, align_corners = false) -> S[k][256]
+//   2. chan_norm_a_kernel: cn[c] = sqrt(sum_k S[k][c]^2), keypoints in list order (one thread per channel)
+//   3. finish_a_kernel   : T = S / cn; optional PCA (T - mean) * comp^T; row L2.  One wave per keypoint.
+// comp_t: [256][pca_dims] (transposed CSV layout, superpoint_onnx.cpp:47-53) or null.
 __global__ __launch_bounds__(256) void sample_a_kernel(const float* __restrict__ desc_raw, int dstride, int dcoff, int Hc,
                                                        int Wc, int img_w, int img_h, const float* __restrict__ kps_xy,
-                                                       const int32_t* __restrict__ n_kp, int cap,
-                                                       const float* __restrict__ comp_t, const float* __restrict__ mean,
-                                                       int pca_dims, float* __restrict__ desc_out) {
-  __shared__ float sd[4][256];
+                                                       const int32_t* __restrict__ n_kp, int cap, int scap,
+                                                       float* __restrict__ samp) {
   const int img = blockIdx.y;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int k = blockIdx.x * 4 + wv;
-  if (k >= n_kp[img] || k >= cap) return;
+  if (k >= n_kp[img] || k >= cap || k >= scap) return;
   const size_t o = (size_t)img * cap + k;
   const float x = kps_xy[2 * o], y = kps_xy[2 * o + 1];
   const float gx = 2.0f * x / (float)img_w - 1.0f;
@@ -451,12 +453,35 @@ __global__ __launch_bounds__(256) void sample_a_kernel(const float* __restrict__
   };
   f32x4 d = {0.f, 0.f, 0.f, 0.f};
   corner(y0, x0, nw, d); corner(y0, x1, ne, d); corner(y1, x0, sw, d); corner(y1, x1, se, d);
-  float ss = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
-  const float n1 = __builtin_sqrtf(ss);
+  *reinterpret_cast<f32x4*>(samp + ((size_t)img * scap + k) * 256 + lane * 4) = d;
+}
+
+__global__ __launch_bounds__(256) void chan_norm_a_kernel(const float* __restrict__ samp, const int32_t* __restrict__ n_kp, int cap,
+                                                          int scap, float* __restrict__ cn) {
+  const int img = blockIdx.x, c = threadIdx.x;
+  const int n = min(min(n_kp[img], cap), scap);
+  const float* s = samp + (size_t)img * scap * 256 + c;
+  float ss = 0.f;
+  for (int k = 0; k < n; ++k) { const float v = s[(size_t)k * 256]; ss += v * v; }
+  cn[img * 256 + c] = __builtin_sqrtf(ss);
+}
+
+__global__ __launch_bounds__(256) void finish_a_kernel(const float* __restrict__ samp, const float* __restrict__ cn,
+                                                       const int32_t* __restrict__ n_kp, int cap, int scap,
+                                                       const float* __restrict__ comp_t, const float* __restrict__ mean,
+                                                       int pca_dims, float* __restrict__ desc_out) {
+  __shared__ float sd[4][256];
+  const int img = blockIdx.y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int k = blockIdx.x * 4 + wv;
+  if (k >= n_kp[img] || k >= cap || k >= scap) return;
+  const size_t o = (size_t)img * cap + k;
+  f32x4 d = *reinterpret_cast<const f32x4*>(samp + ((size_t)img * scap + k) * 256 + lane * 4);
+  const f32x4 c4 = *reinterpret_cast<const f32x4*>(cn + img * 256 + lane * 4);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) d[j] = d[j] / n1;
+  for (int j = 0; j < 4; ++j) d[j] = d[j] / c4[j];
   if (!comp_t) {
-    ss = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
+    const float ss = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
     const float n2 = __builtin_sqrtf(ss);
 #pragma unroll
     for (int j = 0; j < 4; ++j) d[j] = d[j] / n2;
@@ -491,12 +516,15 @@ __global__ __launch_bounds__(256) void sample_a_kernel(const float* __restrict__
   }
 }
 
+// samp: scratch [n_img][scap][256]; cn: scratch [n_img][256]
 hipError_t launch_sample_a(const float* desc_raw, int dstride, int dcoff, int Hc, int Wc, int img_w, int img_h, int n_img,
                            const float* kps_xy, const int32_t* n_kp, int cap, const float* comp_t, const float* mean,
-                           int pca_dims, float* desc_out, hipStream_t s) {
-  dim3 grid((cap + 3) / 4, n_img), block(256);
-  hipLaunchKernelGGL(sample_a_kernel, grid, block, 0, s, desc_raw, dstride, dcoff, Hc, Wc, img_w, img_h, kps_xy, n_kp, cap,
-                     comp_t, mean, pca_dims, desc_out);
+                           int pca_dims, float* samp, int scap, float* cn, float* desc_out, hipStream_t s) {
+  const int kmax = cap < scap ? cap : scap;
+  dim3 grid((kmax + 3) / 4, n_img), block(256);
+  hipLaunchKernelGGL(sample_a_kernel, grid, block, 0, s, desc_raw, dstride, dcoff, Hc, Wc, img_w, img_h, kps_xy, n_kp, cap, scap, samp);
+  hipLaunchKernelGGL(chan_norm_a_kernel, dim3(n_img), block, 0, s, samp, n_kp, cap, scap, cn);
+  hipLaunchKernelGGL(finish_a_kernel, grid, block, 0, s, samp, cn, n_kp, cap, scap, comp_t, mean, pca_dims, desc_out);
   return hipGetLastError();
 }
 

@@ -5,13 +5,14 @@
  * bench.py's cpu_baseline leg may load it.  The shipped path (the HIP sources in d2slam_amd/csrc behind
  * include/d2fe.h) never calls into this file and has no CPU fallback.
  *
- * PARITY STATUS: **parity unpinned**.  The reference ships no golden vectors, no
- * assertion-based tests and no model weights for this path, and it cannot
- * be compiled here (needs OpenCV/Eigen/TensorRT/ROS).  The oracle is
- * therefore a line-by-line restatement of the reference sources cited on each function,
- * cross-checked in tests/ against independent PyTorch-CPU implementations of the same ops
- * (conv2d/max_pool2d/softmax fp32+fp64, and F.grid_sample -- the very ATen kernel the
- * reference's variant-A path calls).
+ * PARITY STATUS: pinned in part.  The reference ships no golden vectors, no assertion-based tests and no model weights
+ * for this path, and its C++ cannot be compiled here (needs OpenCV/Eigen/TensorRT/ROS; SURVEY.md
+ * section 8c).  But the network and the variant-A sampling are also defined in PYTHON in the reference
+ * (d2frontend/superpoint.ipynb, modules SuperPointNetHalf / SuperPointNet): tests/golden/make_golden_ref.py executes
+ * those modules verbatim and commits their outputs, and tests/test_reference_golden.py holds orc_prep_u8 .. orc_softmax_semi,
+ * orc_l2norm_rows and orc_sample_a to them (and orc_sample_a's PCA convention to sklearn, the tool behind the CSVs).
+ * Everything else in this file is **parity unpinned**: a line-by-line restatement of the cited C++ (or of the pinned
+ * third-party version it calls), cross-checked in tests/ against independent implementations of the same ops only.
  *
  * Numerical definition.  Where the reference leaves floating-point evaluation order to a
  * third-party engine (TensorRT conv kernels, OpenCV SIMD reductions, Eigen reductions) the
@@ -308,14 +309,22 @@ ORC_API int orc_nms2_a(const float* prob, int h, int w, float thr, int dist_thre
 /* ------------------------------------------------------------------------------------------
  * A7  Variant-A descriptor sampling.  Reference: computeDescriptors superpoint_common.cpp:42-99.
  *     grid = 2*x/W - 1 ; torch::grid_sampler(bilinear, zeros padding, align_corners=false)
- *     => ix = ((g+1)*wc - 1)/2 ; L2 normalise; optional PCA (d - mean) * comp_T then row L2.
+ *     => ix = ((g+1)*wc - 1)/2.  The sampled tensor is squeezed to [256, n_keypoints] and then
+ *     `dn = torch::norm(desc, 2, 1); desc = desc.div(unsqueeze(dn, 1))` (:68-69) -- dim 1 of that tensor is
+ *     the KEYPOINT axis, so every CHANNEL is divided by its L2 norm over the image's keypoints (the
+ *     notebook module the C++ was written from does the same, superpoint.ipynb cell 1; pinned by
+ *     tests/golden/reference_notebook.npz).  Only then: optional PCA (d - mean) * comp_T (:76-78), and the
+ *     per-keypoint L2 normalisation (:79-81 / :87-89).  Reproduced as written.
+ *     Order fixed here: the channel norm sums over keypoints in list order, fp32.
  *     desc_map NHWC [hc][wc][dim] already channel-normalised.  pca_comp: [pca_dims][dim] (the CSV
  *     layout, superpoint_onnx.cpp:47-53) or NULL.
  * ---------------------------------------------------------------------------------------- */
 ORC_API void orc_sample_a(const float* desc_map, int hc, int wc, int dim, int img_w, int img_h,
                           const float* kps_xy, int n, const float* pca_comp, const float* pca_mean,
                           int pca_dims, float* out) {
-  float* tmp = (float*)malloc(sizeof(float) * dim);
+  if (n <= 0) return;
+  float* S = (float*)malloc(sizeof(float) * (size_t)n * dim);
+  float* cn = (float*)malloc(sizeof(float) * dim);
   for (int i = 0; i < n; ++i) {
     /* grid built in float tensors: 2.0 * x / width - 1 */
     const float gx = 2.0f * kps_xy[2 * i] / (float)img_w - 1.0f;
@@ -330,36 +339,41 @@ ORC_API void orc_sample_a(const float* desc_map, int hc, int wc, int dim, int im
     const float ne = (ix - (float)x0) * ((float)y1 - iy);
     const float sw = ((float)x1 - ix) * (iy - (float)y0);
     const float se = (ix - (float)x0) * (iy - (float)y0);
-    float ss = 0.f;
     for (int k = 0; k < dim; ++k) {
       float v = 0.f;
       if (y0 >= 0 && y0 < hc && x0 >= 0 && x0 < wc) v += desc_map[((size_t)y0 * wc + x0) * dim + k] * nw;
       if (y0 >= 0 && y0 < hc && x1 >= 0 && x1 < wc) v += desc_map[((size_t)y0 * wc + x1) * dim + k] * ne;
       if (y1 >= 0 && y1 < hc && x0 >= 0 && x0 < wc) v += desc_map[((size_t)y1 * wc + x0) * dim + k] * sw;
       if (y1 >= 0 && y1 < hc && x1 >= 0 && x1 < wc) v += desc_map[((size_t)y1 * wc + x1) * dim + k] * se;
-      tmp[k] = v;
-      ss += v * v;
+      S[(size_t)i * dim + k] = v;
     }
-    const float nrm = sqrtf(ss);
-    for (int k = 0; k < dim; ++k) tmp[k] = tmp[k] / nrm;   /* :68-69 (and again :87-89: idempotent) */
+  }
+  for (int k = 0; k < dim; ++k) {                 /* :68 torch::norm(desc [dim, n], 2, 1) */
+    float ss = 0.f;
+    for (int i = 0; i < n; ++i) ss += S[(size_t)i * dim + k] * S[(size_t)i * dim + k];
+    cn[k] = sqrtf(ss);
+  }
+  for (int i = 0; i < n; ++i) {
+    float* t = S + (size_t)i * dim;
+    for (int k = 0; k < dim; ++k) t[k] = t[k] / cn[k];   /* :69 */
     if (pca_comp) {
       float s2 = 0.f;
       float* o = out + (size_t)i * pca_dims;
       for (int j = 0; j < pca_dims; ++j) {
         float a = 0.f;
-        for (int k = 0; k < dim; ++k) a += (tmp[k] - pca_mean[k]) * pca_comp[(size_t)j * dim + k];
+        for (int k = 0; k < dim; ++k) a += (t[k] - pca_mean[k]) * pca_comp[(size_t)j * dim + k];
         o[j] = a; s2 += a * a;
       }
       const float n2 = sqrtf(s2);
       for (int j = 0; j < pca_dims; ++j) o[j] = o[j] / n2;
     } else {
       float s2 = 0.f;
-      for (int k = 0; k < dim; ++k) s2 += tmp[k] * tmp[k];
+      for (int k = 0; k < dim; ++k) s2 += t[k] * t[k];
       const float n2 = sqrtf(s2);
-      for (int k = 0; k < dim; ++k) out[(size_t)i * dim + k] = tmp[k] / n2;
+      for (int k = 0; k < dim; ++k) out[(size_t)i * dim + k] = t[k] / n2;
     }
   }
-  free(tmp);
+  free(S); free(cn);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -1,8 +1,9 @@
 """ctypes front-end of the CPU oracle (oracle/d2fe_oracle.c).
 
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
-cpu_baseline leg.  Nothing under d2slam_amd/ imports this module.  Parity status: unpinned
-(the reference has no golden vectors for this path) -- see the header of d2fe_oracle.c.
+cpu_baseline leg.  Nothing under d2slam_amd/ imports this module.  Parity status: network + variant-A sampling
+pinned to the reference's own Python modules (tests/golden/reference_notebook.npz), the rest unpinned -- see the
+header of d2fe_oracle.c.
 """
 import ctypes as C
 import os

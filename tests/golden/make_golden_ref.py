@@ -1,0 +1,65 @@
+"""Golden vectors produced BY THE REFERENCE'S OWN PYTHON CODE (runs only where /root/reference exists; the fixture it writes,
+tests/golden/reference_notebook.npz, travels with the repo).
+
+The reference defines its SuperPoint network in d2frontend/superpoint.ipynb: cell 1 `SuperPointNet` (forward = network +
+softmax/unfold + `semi > 0.2` keypoints + F.grid_sample descriptors + L2 norm, :300-374 in the notebook JSON) and cell 5
+`SuperPointNetHalf` (the module that is exported to ONNX, returns the dense `semi` [1,H,W] and `desc` [1,256,H/8,W/8]).
+This script executes those two class definitions verbatim (read from the notebook at run time, nothing is copied into the
+repo), loads the seeded synthetic weights into them (the trained superpoint_v1.pth is a Dropbox download that is not in the tree)
+and records their outputs in float64 and float32 on seeded synthetic frames.  It also records sklearn's PCA.transform on seeded
+data -- d2frontend/pca.ipynb / quadcam_tools/pca_decomp.ipynb use exactly that object to produce the CSVs the C++ side loads.
+
+Run from the repo root:  python tests/golden/make_golden_ref.py
+"""
+import json, os, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import numpy as np
+import torch
+from d2slam_amd.synth import synth_image
+from d2slam_amd.weights import SP_LAYERS, synthetic_superpoint_weights
+
+NB = "/root/reference/d2frontend/superpoint.ipynb"
+cells = ["".join(c["source"]) for c in json.load(open(NB))["cells"]]
+src_full = cells[1]                                                       # class SuperPointNet
+src_half = cells[5].split("# Input to the model")[0].replace("#Output to onnx.", "")   # class SuperPointNetHalf only
+ns = {"torch": torch}
+exec(compile(src_full, NB + ":cell1", "exec"), ns)
+exec(compile(src_half, NB + ":cell5", "exec"), ns)
+
+# random-init logits are too flat for the notebook's hard-coded `semi > 0.2` (max softmax 0.19): the detector head's 1x1
+# weights are scaled by 8 for this fixture (any weights are legitimate inputs to the reference's module), which keeps ~100 points
+DUSTBIN, PB_SCALE = 0.0, 8.0
+w = synthetic_superpoint_weights(seed=1234, dustbin_bias=DUSTBIN)
+w["convPb"] = (w["convPb"][0] * np.float32(PB_SCALE), w["convPb"][1])
+sd = {}
+for n in SP_LAYERS:
+    sd[n + ".weight"] = torch.from_numpy(w[n][0]); sd[n + ".bias"] = torch.from_numpy(w[n][1])
+
+out = {"dustbin_bias": np.float64(DUSTBIN), "pb_scale": np.float64(PB_SCALE), "seed": np.int64(1234)}
+for tag, (h, wd, seed) in {"a": (64, 96, 3), "b": (120, 160, 5)}.items():
+    img = synth_image(h, wd, seed)
+    out["img_" + tag] = img
+    for dt, dn in ((torch.float64, "f64"), (torch.float32, "f32")):
+        x = torch.from_numpy(img.astype(np.float32) / np.float32(255.0))[None, None].to(dt)   # notebook: img.astype(float32)/255
+        half = ns["SuperPointNetHalf"](); half.load_state_dict(sd); half = half.to(dt).eval()
+        with torch.no_grad():
+            semi, desc = half(x)
+        out["semi_%s_%s" % (dn, tag)] = semi[0].numpy()
+        out["desc_%s_%s" % (dn, tag)] = desc[0].numpy()
+    # the full module (keypoints + grid_sample descriptors) only in its native float32: it casts the grid to torch.FloatTensor
+    full = ns["SuperPointNet"](); full.load_state_dict(sd); full = full.eval()
+    with torch.no_grad():
+        kps, kdesc = full(torch.from_numpy(img.astype(np.float32) / np.float32(255.0))[None, None])
+    out["kps_f32_" + tag] = kps.numpy()                      # (row, col) pairs of torch.nonzero, raster order
+    out["kdesc_f32_" + tag] = kdesc.numpy()
+    print(tag, "keypoints with semi > 0.2:", len(kps))
+
+from sklearn.decomposition import PCA
+rng = np.random.RandomState(7)
+data = rng.randn(400, 256); data /= np.linalg.norm(data, axis=1, keepdims=True)
+pca = PCA(64).fit(data)
+probe = data[:32]
+out.update(pca_components=pca.components_, pca_mean=pca.mean_, pca_probe=probe, pca_transformed=pca.transform(probe))
+np.savez_compressed(os.path.join(HERE, "reference_notebook.npz"), **out)
+print("wrote reference_notebook.npz")

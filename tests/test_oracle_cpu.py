@@ -119,8 +119,9 @@ def test_sample_b(orc):
 
 
 def test_sample_a_vs_aten_grid_sampler(orc):
-    """Variant A calls torch::grid_sampler(bilinear, zeros, align_corners=false) (superpoint_common.cpp:64):
-    compare with the very same ATen kernel."""
+    """Variant A calls torch::grid_sampler(bilinear, zeros, align_corners=false) (superpoint_common.cpp:64), then
+    `torch::norm(desc, 2, 1)` + div on the [256, N] tensor (:68-69, a per-CHANNEL norm over the keypoints), then row L2 (:87-89):
+    replay the same ATen calls."""
     rng = np.random.RandomState(3)
     hc, wc = 8, 10
     desc = rng.randn(hc, wc, 256).astype(np.float32)
@@ -132,13 +133,17 @@ def test_sample_a_vs_aten_grid_sampler(orc):
     grid[0, 0, :, 0] = 2.0 * torch.from_numpy(kps[:, 0]) / (wc * 8) - 1
     grid[0, 0, :, 1] = 2.0 * torch.from_numpy(kps[:, 1]) / (hc * 8) - 1
     t = torch.from_numpy(desc).permute(2, 0, 1)[None]
-    ref = F.grid_sample(t, grid, mode="bilinear", padding_mode="zeros", align_corners=False)[0, :, 0].T
+    smp = F.grid_sample(t, grid, mode="bilinear", padding_mode="zeros", align_corners=False).squeeze(0).squeeze(1)   # [256, N]
+    dn = torch.norm(smp, 2, 1)
+    smp = smp.div(torch.unsqueeze(dn, 1))
+    ref = smp.transpose(0, 1).contiguous()                                   # [N, 256], unit norm per channel
+    chan = ref.numpy().copy()
     ref = ref / ref.norm(dim=1, keepdim=True)
     assert np.abs(got - ref.numpy()).max() < 2e-6
     # PCA branch: (d - mean) @ comp^T then row L2 (superpoint_common.cpp:76-85)
     comp = rng.randn(64, 256).astype(np.float32); mean = rng.randn(256).astype(np.float32) * 0.01
     gp = orc.sample_a(desc, kps, wc * 8, hc * 8, comp, mean)
-    rp = (ref.numpy().astype(np.float64) - mean) @ comp.T.astype(np.float64)
+    rp = (chan.astype(np.float64) - mean) @ comp.T.astype(np.float64)
     rp /= np.linalg.norm(rp, axis=1, keepdims=True)
     assert np.abs(gp - rp).max() < 5e-6
 
