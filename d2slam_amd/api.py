@@ -80,7 +80,7 @@ EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_creat
            "d2fe_debug_read", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read",
            "d2fe_gen_cylinder_map", "d2fe_gen_cylinder_map_device", "d2fe_gen_pinhole_map", "d2fe_gen_pinhole_map_device",
            "d2fe_lk_frame_create", "d2fe_lk_frame_create_device", "d2fe_lk_frame_destroy", "d2fe_lk_frame_read_level",
-           "d2fe_lk_track", "d2fe_detect_fast_by_region", "d2fe_good_features_to_track"]
+           "d2fe_lk_track", "d2fe_lk_track_batch", "d2fe_detect_fast_by_region", "d2fe_good_features_to_track"]
 
 
 def _preload_hip_runtime():
@@ -173,6 +173,8 @@ def load_library():
         lib.d2fe_lk_frame_read_level.restype = C.c_long
         lib.d2fe_lk_track.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.d2fe_lk_track_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p]
         lib.d2fe_detect_fast_by_region.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                    C.c_void_p, C.c_int, C.c_void_p]
         lib.d2fe_good_features_to_track.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p,
@@ -559,6 +561,33 @@ def lk_track(fe: FrontEnd, prev: LKFrame, cur: LKFrame, prev_pts, cur_init, trac
     _check(fe._lib.d2fe_lk_track(fe.handle, prev._f, cur._f, _ptr(pp), _ptr(ci), n, int(track_type), float(move_cols), int(win),
                                  int(iters), _ptr(out), _ptr(st)))
     return out[:n], st[:n]
+
+
+class _LKPair(C.Structure):
+    _fields_ = [("prev", C.c_void_p), ("cur", C.c_void_p), ("first", C.c_int32), ("count", C.c_int32), ("type", C.c_int32),
+                ("move_cols", C.c_float)]
+
+
+def lk_track_batch(fe: FrontEnd, jobs, win=WIN_SIZE, iters=LK_ITERS):
+    """jobs: list of (prev LKFrame, cur LKFrame, prev_pts, cur_init, track_type, move_cols) -> list of (cur_pts, status);
+    all tracks run in one kernel launch (d2fe_lk_track_batch)."""
+    pairs = (_LKPair * max(len(jobs), 1))()
+    pp, ci, first = [], [], 0
+    for k, (prev, cur, p, c, t, mv) in enumerate(jobs):
+        p = np.ascontiguousarray(p, np.float32).reshape(-1, 2); c = np.ascontiguousarray(c, np.float32).reshape(-1, 2)
+        pairs[k] = _LKPair(prev._f, cur._f, first, len(p), int(t), float(mv))
+        pp.append(p); ci.append(c); first += len(p)
+    n = first
+    allp = np.concatenate(pp) if n else np.zeros((0, 2), np.float32)
+    alli = np.concatenate(ci) if n else np.zeros((0, 2), np.float32)
+    out = np.zeros((max(n, 1), 2), np.float32); st = np.zeros(max(n, 1), np.uint8)
+    _check(fe._lib.d2fe_lk_track_batch(fe.handle, pairs, len(jobs), _ptr(np.ascontiguousarray(allp)), _ptr(np.ascontiguousarray(alli)),
+                                       n, int(win), int(iters), _ptr(out), _ptr(st)))
+    res = []
+    for k in range(len(jobs)):
+        a, cnt = pairs[k].first, pairs[k].count
+        res.append((out[a:a + cnt].copy(), st[a:a + cnt].copy()))
+    return res
 
 
 def opticalflowTrackPyr(fe: FrontEnd, cur_img, prev_lk: dict, track_type=WHOLE_IMG_MATCH, undistort_fov=200.0):

@@ -69,6 +69,7 @@ struct d2fe_context {
   int last_w = 0, last_h = 0, last_n = 0;
   const uint8_t* last_gray = nullptr; int last_stride = 0; size_t last_istride = 0;
   float* aconf = nullptr; int* clist = nullptr;     // variant A scratch
+  void* lk_scratch = nullptr; size_t lk_scratch_bytes = 0;   // grow-only scratch of the LK / detector entry points (lk.hip)
   float* a_samp = nullptr; float* a_cn = nullptr; int a_scap = 0;   // variant A sampling: [batch][a_scap][256] samples, [batch][256] channel norms
   float* pca_comp_t = nullptr; float* pca_mean = nullptr; int pca_dims = 0;
   // NetVLAD
@@ -100,6 +101,18 @@ namespace d2fe {
 int ctx_fail(int code, const std::string& msg) { return fail(code, msg); }
 int ctx_device(d2fe_handle h) { return h->cfg.device_id; }
 hipStream_t ctx_stream(d2fe_handle h) { return h->stream; }
+// grow-only device scratch owned by the handle: no hipMalloc/hipFree (a device-wide sync) per tracker call.  Not re-entrant,
+// like the extract calls: one tracker thread per handle (the reference's D2FeatureTracker is single-threaded, d2frontend.cpp:155-169)
+int ctx_scratch(d2fe_handle h, size_t bytes, void** out) {
+  if (bytes > h->lk_scratch_bytes) {
+    if (h->lk_scratch) { hipStreamSynchronize(h->stream); hipFree(h->lk_scratch); h->lk_scratch = nullptr; h->lk_scratch_bytes = 0; }
+    const size_t want = bytes + bytes / 2 + 4096;
+    if (hipMalloc(&h->lk_scratch, want) != hipSuccess) return fail(D2FE_ERR_HIP, "hipMalloc scratch");
+    h->lk_scratch_bytes = want;
+  }
+  *out = h->lk_scratch;
+  return D2FE_OK;
+}
 }  // namespace d2fe
 
 namespace {
@@ -333,7 +346,7 @@ void d2fe_destroy(d2fe_handle h) {
     if (t->p) hipFree(t->p);
   for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
   for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->cand_count, (void*)h->s_img, (void*)h->s_kps,
-                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, h->m_buf, (void*)h->m_cand4, (void*)h->aconf, (void*)h->clist, (void*)h->a_samp, (void*)h->a_cn,
+                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, h->m_buf, (void*)h->m_cand4, (void*)h->aconf, (void*)h->clist, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch,
                   (void*)h->pca_comp_t, (void*)h->pca_mean})
     if (p) hipFree(p);
   nv_free(h);

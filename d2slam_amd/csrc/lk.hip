@@ -54,11 +54,17 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict
 }
 
 // ---- sparse pyramidal LK ---------------------------------------------------------------------------------------------------------
-struct LkArgs {
+// one (previous frame, current frame) pair of a batched call; a point carries the index of its pair
+struct LkPairDev {
   const uint8_t* prev; const uint8_t* cur;
   int off[8], ws[8], hs[8];
-  int levels, w, h, n, type, win, iters;
+  int levels, w, h, type;
   float move_cols;
+  int pad_[3];
+};
+struct LkArgs {
+  const LkPairDev* pairs; const int* pair_of;
+  int n, win, iters;
   const float* prev_pts; const float* cur_init;
   float* cur_pts; uint8_t* status;
 };
@@ -167,33 +173,34 @@ __device__ void lk_level(const uint8_t* __restrict__ I, const uint8_t* __restric
   npx = nx + half; npy = ny + half;
 }
 
-__device__ __forceinline__ void lk_calc(const LkArgs& a, const uint8_t* Ip, const uint8_t* Jp, float ppx, float ppy, float& npx,
-                                        float& npy, int& status, int lane) {
-  const float sc = (float)(1.0 / (double)(1 << a.levels) / 2.0);
+__device__ __forceinline__ void lk_calc(const LkArgs& a, const LkPairDev& P, const uint8_t* Ip, const uint8_t* Jp, float ppx,
+                                        float ppy, float& npx, float& npy, int& status, int lane) {
+  const float sc = (float)(1.0 / (double)(1 << P.levels) / 2.0);
   npx = npx * sc; npy = npy * sc;
   status = 1;
-  for (int l = a.levels; l >= 0; --l)
-    lk_level(Ip + a.off[l], Jp + a.off[l], a.ws[l], a.hs[l], l, a.win, a.iters, ppx, ppy, npx, npy, status, lane);
+  for (int l = P.levels; l >= 0; --l)
+    lk_level(Ip + P.off[l], Jp + P.off[l], P.ws[l], P.hs[l], l, a.win, a.iters, ppx, ppy, npx, npy, status, lane);
 }
 
 __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (i >= a.n) return;
+  const LkPairDev& P = a.pairs[__builtin_amdgcn_readfirstlane(a.pair_of[i])];   // wave-uniform: scalar loads
   const float ppx = a.prev_pts[2 * i], ppy = a.prev_pts[2 * i + 1];
   float cx = a.cur_init[2 * i], cy = a.cur_init[2 * i + 1];
   int st = 1, rst = 1;
-  lk_calc(a, a.prev, a.cur, ppx, ppy, cx, cy, st, lane);
+  lk_calc(a, P, P.prev, P.cur, ppx, ppy, cx, cy, st, lane);
   float rx = cx, ry = cy;
-  if (a.type == 1 && st == 1) rx -= a.move_cols;
-  if (a.type == 2 && st == 1) rx += a.move_cols;
-  lk_calc(a, a.cur, a.prev, cx, cy, rx, ry, rst, lane);
+  if (P.type == 1 && st == 1) rx -= P.move_cols;
+  if (P.type == 2 && st == 1) rx += P.move_cols;
+  lk_calc(a, P, P.cur, P.prev, cx, cy, rx, ry, rst, lane);
   const float dx = ppx - rx, dy = ppy - ry;
   const double nrm = __builtin_sqrt((double)dx * dx + (double)dy * dy);
   int ok = (st && rst && nrm <= 0.5) ? 1 : 0;
   if (ok) {
     const int ix = (int)__builtin_rint((double)cx), iy = (int)__builtin_rint((double)cy);
-    if (!(1 <= ix && ix < a.w - 1 && 1 <= iy && iy < a.h - 1)) ok = 0;
+    if (!(1 <= ix && ix < P.w - 1 && 1 <= iy && iy < P.h - 1)) ok = 0;
   }
   if (lane == 0) {
     a.cur_pts[2 * i] = cx; a.cur_pts[2 * i + 1] = cy;
@@ -352,6 +359,7 @@ __global__ __launch_bounds__(256) void corners_kernel(const float* __restrict__ 
 int ctx_fail(int code, const std::string& msg);
 int ctx_device(d2fe_handle h);
 hipStream_t ctx_stream(d2fe_handle h);
+int ctx_scratch(d2fe_handle h, size_t bytes, void** out);
 
 }  // namespace d2fe
 
@@ -447,36 +455,68 @@ long d2fe_lk_frame_read_level(d2fe_lk_frame f, int level, uint8_t* dst, size_t m
   return (long)bytes;
 }
 
-int d2fe_lk_track(d2fe_handle h, d2fe_lk_frame prev, d2fe_lk_frame cur, const float* prev_pts, const float* cur_init, int n,
-                  int type, float move_cols, int win, int iters, float* cur_pts, uint8_t* status) {
-  if (!h || !prev || !cur || (n > 0 && (!prev_pts || !cur_init || !cur_pts || !status))) return ctx_fail(D2FE_ERR_INVALID, "null argument");
-  if (prev->w != cur->w || prev->hgt != cur->hgt || prev->levels != cur->levels) return ctx_fail(D2FE_ERR_INVALID, "pyramid geometry mismatch");
-  if (n < 0 || type < 0 || type > 2 || win < 3 || win > 24 || !(win & 1) || iters < 1) return ctx_fail(D2FE_ERR_INVALID, "bad LK parameters (win odd, 3..23)");
-  if (n == 0) return D2FE_OK;
+int d2fe_lk_track_batch(d2fe_handle h, const d2fe_lk_pair* pairs, int npairs, const float* prev_pts, const float* cur_init,
+                        int n_total, int win, int iters, float* cur_pts, uint8_t* status) {
+  if (!h || (npairs > 0 && !pairs) || (n_total > 0 && (!prev_pts || !cur_init || !cur_pts || !status))) return ctx_fail(D2FE_ERR_INVALID, "null argument");
+  if (npairs < 0 || npairs > 4096 || n_total < 0 || win < 3 || win > 24 || !(win & 1) || iters < 1) return ctx_fail(D2FE_ERR_INVALID, "bad LK parameters (win odd, 3..23)");
+  if (n_total == 0 || npairs == 0) return D2FE_OK;
+  // host staging block: [pairs table | pair index per point | prev_pts | cur_init]  -> one H2D; [cur_pts | status] <- one D2H
+  const size_t n = (size_t)n_total;
+  const size_t o_pairs = 0, o_idx = sizeof(LkPairDev) * (size_t)npairs, o_prev = o_idx + sizeof(int) * n, o_init = o_prev + sizeof(float) * 2 * n;
+  const size_t in_bytes = o_init + sizeof(float) * 2 * n;
+  const size_t o_cur = (in_bytes + 15) / 16 * 16, o_st = o_cur + sizeof(float) * 2 * n, total = o_st + n;
+  std::vector<char> stage(in_bytes);
+  LkPairDev* tp = reinterpret_cast<LkPairDev*>(stage.data() + o_pairs);
+  int* ti = reinterpret_cast<int*>(stage.data() + o_idx);
+  std::vector<char> seen(n, 0);
+  for (int p = 0; p < npairs; ++p) {
+    const d2fe_lk_pair& q = pairs[p];
+    if (!q.prev || !q.cur) return ctx_fail(D2FE_ERR_INVALID, "null frame in pair");
+    if (q.prev->w != q.cur->w || q.prev->hgt != q.cur->hgt || q.prev->levels != q.cur->levels) return ctx_fail(D2FE_ERR_INVALID, "pyramid geometry mismatch");
+    if (q.type < 0 || q.type > 2 || q.first < 0 || q.count < 0 || (size_t)q.first + (size_t)q.count > n) return ctx_fail(D2FE_ERR_INVALID, "bad pair (type / point range)");
+    LkPairDev& d = tp[p];
+    memset(&d, 0, sizeof(d));
+    d.prev = q.prev->pyr; d.cur = q.cur->pyr;
+    for (int l = 0; l < 8; ++l) { d.off[l] = q.prev->off[l]; d.ws[l] = q.prev->ws[l]; d.hs[l] = q.prev->hs[l]; }
+    d.levels = q.prev->levels; d.w = q.prev->w; d.h = q.prev->hgt; d.type = q.type; d.move_cols = q.move_cols;
+    for (int i = q.first; i < q.first + q.count; ++i) { ti[i] = p; seen[i] = 1; }
+  }
+  for (size_t i = 0; i < n; ++i) if (!seen[i]) return ctx_fail(D2FE_ERR_INVALID, "point not covered by any pair");
+  memcpy(stage.data() + o_prev, prev_pts, sizeof(float) * 2 * n);
+  memcpy(stage.data() + o_init, cur_init, sizeof(float) * 2 * n);
   LK_TRY(hipSetDevice(ctx_device(h)));
   hipStream_t s = ctx_stream(h);
-  float* buf = nullptr;
-  LK_TRY(hipMalloc(&buf, sizeof(float) * 6 * (size_t)n + (size_t)n + 16));
-  float* d_prev = buf; float* d_init = buf + 2 * (size_t)n; float* d_cur = buf + 4 * (size_t)n;
-  uint8_t* d_st = reinterpret_cast<uint8_t*>(buf + 6 * (size_t)n);
+  void* raw = nullptr;
+  { const int rc0 = ctx_scratch(h, total + 16, &raw); if (rc0 != D2FE_OK) return rc0; }
+  char* dev = static_cast<char*>(raw);
   LkArgs a;
-  a.prev = prev->pyr; a.cur = cur->pyr;
-  for (int l = 0; l < 8; ++l) { a.off[l] = prev->off[l]; a.ws[l] = prev->ws[l]; a.hs[l] = prev->hs[l]; }
-  a.levels = prev->levels; a.w = prev->w; a.h = prev->hgt; a.n = n; a.type = type; a.win = win; a.iters = iters; a.move_cols = move_cols;
-  a.prev_pts = d_prev; a.cur_init = d_init; a.cur_pts = d_cur; a.status = d_st;
+  a.pairs = reinterpret_cast<const LkPairDev*>(dev + o_pairs); a.pair_of = reinterpret_cast<const int*>(dev + o_idx);
+  a.n = n_total; a.win = win; a.iters = iters;
+  a.prev_pts = reinterpret_cast<const float*>(dev + o_prev); a.cur_init = reinterpret_cast<const float*>(dev + o_init);
+  a.cur_pts = reinterpret_cast<float*>(dev + o_cur); a.status = reinterpret_cast<uint8_t*>(dev + o_st);
+  std::vector<char> back(total - o_cur);
   int rc = D2FE_OK;
   auto chk = [&](hipError_t e, const char* w) { if (e != hipSuccess && rc == D2FE_OK) rc = ctx_fail(D2FE_ERR_HIP, std::string(w) + ": " + hipGetErrorString(e)); };
-  chk(hipMemcpyAsync(d_prev, prev_pts, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, s), "H2D prev_pts");
-  chk(hipMemcpyAsync(d_init, cur_init, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, s), "H2D cur_init");
+  chk(hipMemcpyAsync(dev, stage.data(), in_bytes, hipMemcpyHostToDevice, s), "H2D");
   if (rc == D2FE_OK) {
-    hipLaunchKernelGGL(lk_track_kernel, dim3((n + 3) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(lk_track_kernel, dim3((n_total + 3) / 4), dim3(256), 0, s, a);
     chk(hipGetLastError(), "lk_track_kernel");
   }
-  chk(hipMemcpyAsync(cur_pts, d_cur, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, s), "D2H cur_pts");
-  chk(hipMemcpyAsync(status, d_st, (size_t)n, hipMemcpyDeviceToHost, s), "D2H status");
+  chk(hipMemcpyAsync(back.data(), dev + o_cur, back.size(), hipMemcpyDeviceToHost, s), "D2H");
   chk(hipStreamSynchronize(s), "sync");
-  hipFree(buf);
+  if (rc == D2FE_OK) {
+    memcpy(cur_pts, back.data(), sizeof(float) * 2 * n);
+    memcpy(status, back.data() + (o_st - o_cur), n);
+  }
   return rc;
+}
+
+int d2fe_lk_track(d2fe_handle h, d2fe_lk_frame prev, d2fe_lk_frame cur, const float* prev_pts, const float* cur_init, int n,
+                  int type, float move_cols, int win, int iters, float* cur_pts, uint8_t* status) {
+  if (!prev || !cur) return ctx_fail(D2FE_ERR_INVALID, "null argument");
+  d2fe_lk_pair p;
+  p.prev = prev; p.cur = cur; p.first = 0; p.count = n; p.type = type; p.move_cols = move_cols;
+  return d2fe_lk_track_batch(h, &p, 1, prev_pts, cur_init, n, win, iters, cur_pts, status);
 }
 
 int d2fe_detect_fast_by_region(d2fe_handle h, d2fe_lk_frame f, int features, int cols, int rows, int threshold, float* pts_xy,
@@ -488,9 +528,10 @@ int d2fe_detect_fast_by_region(d2fe_handle h, d2fe_lk_frame f, int features, int
   LK_TRY(hipSetDevice(ctx_device(h)));
   hipStream_t s = ctx_stream(h);
   const size_t ocap = (size_t)cols * rows * features;
-  char* buf = nullptr;
-  const size_t sbytes = sizeof(int) * (size_t)w * hh;
-  LK_TRY(hipMalloc(&buf, sbytes + sizeof(int4) * ocap + 16));
+  const size_t sbytes = (sizeof(int) * (size_t)w * hh + 15) / 16 * 16;   // keeps the int4 list 16-byte aligned
+  void* raw = nullptr;
+  { const int rc0 = ctx_scratch(h, sbytes + sizeof(int4) * ocap + 16, &raw); if (rc0 != D2FE_OK) return rc0; }
+  char* buf = static_cast<char*>(raw);
   int* d_score = reinterpret_cast<int*>(buf);
   int4* d_out = reinterpret_cast<int4*>(buf + sbytes);
   int* d_cnt = reinterpret_cast<int*>(buf + sbytes + sizeof(int4) * ocap);
@@ -512,7 +553,6 @@ int d2fe_detect_fast_by_region(d2fe_handle h, d2fe_lk_frame f, int features, int
       chk(hipMemcpy(host.data(), d_out, sizeof(int4) * (size_t)cnt, hipMemcpyDeviceToHost), "D2H keypoints");
     }
   }
-  hipFree(buf);
   if (rc != D2FE_OK) return rc;
   // host part of detectFastByRegion (:476-492): sort by response, keep the top `features`
   std::sort(host.begin(), host.end(), [](const int4& p, const int4& q) { return p.z != q.z ? p.z > q.z : p.w < q.w; });
@@ -536,9 +576,10 @@ int d2fe_good_features_to_track(d2fe_handle h, d2fe_lk_frame f, int max_corners,
   const int w = f->w, hh = f->hgt;
   LK_TRY(hipSetDevice(ctx_device(h)));
   hipStream_t s = ctx_stream(h);
-  const size_t np = (size_t)w * hh, ccap = np / 2 + 1024;
-  char* buf = nullptr;
-  LK_TRY(hipMalloc(&buf, sizeof(float) * 3 * np + sizeof(unsigned long long) * ccap + 16));
+  const size_t npix = (size_t)w * hh, np = (npix + 3) / 4 * 4, ccap = npix / 2 + 1024;   // np: plane stride, keeps the 64-bit list aligned
+  void* raw = nullptr;
+  { const int rc0 = ctx_scratch(h, sizeof(float) * 3 * np + sizeof(unsigned long long) * ccap + 16, &raw); if (rc0 != D2FE_OK) return rc0; }
+  char* buf = static_cast<char*>(raw);
   float* d_dx = reinterpret_cast<float*>(buf); float* d_dy = d_dx + np; float* d_eig = d_dy + np;
   unsigned long long* d_c = reinterpret_cast<unsigned long long*>(d_eig + np);
   unsigned* d_max = reinterpret_cast<unsigned*>(d_c + ccap);
@@ -563,7 +604,6 @@ int d2fe_good_features_to_track(d2fe_handle h, d2fe_lk_frame f, int max_corners,
       chk(hipMemcpy(keys.data(), d_c, sizeof(unsigned long long) * (size_t)cnt, hipMemcpyDeviceToHost), "D2H corners");
     }
   }
-  hipFree(buf);
   if (rc != D2FE_OK) return rc;
   std::sort(keys.begin(), keys.end(), [](unsigned long long p, unsigned long long q) { return p > q; });
   // host min-distance filter of cv::goodFeaturesToTrack / cv::cuda::GoodFeaturesToTrackDetector (grid of cell = round(minDistance))

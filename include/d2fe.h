@@ -262,6 +262,17 @@ D2FE_API long d2fe_lk_frame_read_level(d2fe_lk_frame f, int level, uint8_t* dst,
  * the reduceVector() compaction stays with the caller.  Reference constants: win 21 (WIN_SIZE, :25), iters 30 (:239). */
 D2FE_API int d2fe_lk_track(d2fe_handle h, d2fe_lk_frame prev, d2fe_lk_frame cur, const float* prev_pts, const float* cur_init,
                            int n, int type, float move_cols, int win, int iters, float* cur_pts, uint8_t* status);
+/* Batched form: all the tracks of one frame set in ONE launch and one H2D/D2H pair (quadcam: 4 temporal tracks + the
+ * left/right neighbour tracks of trackLK, d2featuretracker.cpp:472-621).  Points are concatenated; pair p owns points
+ * [first, first + count); every point must belong to exactly one pair. */
+typedef struct {
+  d2fe_lk_frame prev, cur;
+  int32_t first, count;
+  int32_t type;          /* 0 WHOLE_IMG_MATCH, 1 LEFT_RIGHT_IMG_MATCH, 2 RIGHT_LEFT_IMG_MATCH */
+  float move_cols;
+} d2fe_lk_pair;
+D2FE_API int d2fe_lk_track_batch(d2fe_handle h, const d2fe_lk_pair* pairs, int npairs, const float* prev_pts,
+                                 const float* cur_init, int n_total, int win, int iters, float* cur_pts, uint8_t* status);
 /* detectFastByRegion (opticaltrack_utils.cpp:444-493): cv::cuda::FastFeatureDetector(threshold, nonmax, TYPE_9_16,
  * max_npoints = features) on each of the cols x rows regions of level 0, sorted by response, top `features`.
  * response (optional) receives the FAST scores. */

@@ -281,3 +281,32 @@ def test_good_features_and_detect_points_gpu(orc):
         d = np.linalg.norm(allp[:, None] - allp[None], axis=-1) + np.eye(len(allp)) * 1e9
         assert d[50:].min() >= 20.0
     f.close(); fe.close()
+
+
+@pytest.mark.gpu
+def test_lk_track_batch_gpu(orc):
+    """d2fe_lk_track_batch: several (prev, cur) pairs of different sizes and types in one launch == the single calls == the oracle."""
+    api, fe = _fe()
+    jobs, refs = [], []
+    frames = []
+    for k, (h, w, ttype, mv) in enumerate(((480, 640, 0, 0.0), (400, 800, 1, 9.0), (400, 800, 2, 9.0), (240, 320, 0, 0.0))):
+        l, r = synth_stereo(h, w, seed=60 + k)
+        pts, _ = orc.fast_by_region(l, 90 + 10 * k)
+        rng = np.random.RandomState(k)
+        init = pts + rng.uniform(-2, 2, pts.shape).astype(np.float32)
+        fl, fr = api.buildImagePyramid(fe, l), api.buildImagePyramid(fe, r)
+        frames += [fl, fr]
+        jobs.append((fl, fr, pts, init, ttype, mv))
+        refs.append(orc.lk_track(orc.pyr_build(l), orc.pyr_build(r), w, h, pts, init, ttype, mv))
+    jobs.append((frames[0], frames[1], np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), 0, 0.0))   # an empty pair is fine
+    out = api.lk_track_batch(fe, jobs)
+    assert len(out) == len(jobs) and len(out[-1][0]) == 0
+    for (got, st), (ref, rst), job in zip(out, refs, jobs):
+        assert np.array_equal(st, rst) and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        one, ost = api.lk_track(fe, job[0], job[1], job[2], job[3], job[4], job[5])
+        assert np.array_equal(ost, st) and np.array_equal(one.view(np.uint32), got.view(np.uint32))
+    with pytest.raises(api.D2FEError):      # geometry mismatch between the frames of a pair
+        api.lk_track_batch(fe, [(frames[0], frames[2], jobs[0][2], jobs[0][3], 0, 0.0)])
+    for f in frames:
+        f.close()
+    fe.close()

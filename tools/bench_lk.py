@@ -27,6 +27,7 @@ def main():
         res = {
             "pyramid (upload + 2 pyrDown)": timeit(lambda: api.buildImagePyramid(fe, l).close()),
             "lk_track fwd+rev, %d pts" % len(pts): timeit(lambda: api.lk_track(fe, fl, fr, pts, pts)),
+            "lk_track_batch, 8 pairs x %d pts (quadcam)" % len(pts): timeit(lambda: api.lk_track_batch(fe, [(fl, fr, pts, pts, 0, 0.0)] * 8)),
             "detectFastByRegion 150 (3x4)": timeit(lambda: api.detectFastByRegion(fe, fl, 150, 3, 4)),
             "goodFeaturesToTrack 150": timeit(lambda: api.goodFeaturesToTrack(fe, fl, 150, 0.01, 20.0)),
         }
@@ -34,11 +35,12 @@ def main():
         cpu = {
             "pyramid (upload + 2 pyrDown)": timeit(lambda: orc.pyr_build(l), 5, 1),
             "lk_track fwd+rev, %d pts" % len(pts): timeit(lambda: orc.lk_track(pl, pr, w, h, pts, pts), 5, 1),
+            "lk_track_batch, 8 pairs x %d pts (quadcam)" % len(pts): 8 * timeit(lambda: orc.lk_track(pl, pr, w, h, pts, pts), 3, 1),
             "detectFastByRegion 150 (3x4)": timeit(lambda: orc.fast_by_region(l, 150, 3, 4), 5, 1),
             "goodFeaturesToTrack 150": timeit(lambda: orc.good_features(l, 150, 0.01, 20.0), 5, 1),
         }
         for k in res:
-            print("%dx%d  %-36s GPU %8.3f ms   oracle (CPU, OpenMP where parallel) %8.3f ms" % (w, h, k, res[k], cpu[k]))
+            print("%dx%d  %-44s GPU %8.3f ms   oracle (CPU, OpenMP where parallel) %8.3f ms" % (w, h, k, res[k], cpu[k]))
     fe.close()
 
 
