@@ -82,6 +82,10 @@ struct d2fe_context {
   float *nv_pca_comp = nullptr, *nv_pca_mean = nullptr; int nv_pca_m = 0;
   uint8_t* nv_s_img = nullptr; float* nv_s_out = nullptr;
   bool fuse1a = true;      // conv1a fused into conv1b's staging (D2FE_FUSE1A=0 keeps the stand-alone conv1a kernel)
+  // host-pointer matcher: pool of (stream, scratch) slots so that concurrent callers (the reference calls matchKNN from three
+  // threads) neither share state nor pay hipStreamCreate / hipMalloc / hipFree (a device-wide sync) per call
+  struct MatchSlot { hipStream_t stream = nullptr; char* buf = nullptr; bool busy = false; };
+  std::vector<MatchSlot> match_slots;
   // matcher scratch
   std::mutex match_mu;
   void* m_buf = nullptr;
@@ -351,6 +355,7 @@ void d2fe_destroy(d2fe_handle h) {
     if (p) hipFree(p);
   nv_free(h);
   for (void* p : {(void*)h->nv_pca_comp, (void*)h->nv_pca_mean, (void*)h->nv_s_img, (void*)h->nv_s_out}) if (p) hipFree(p);
+  for (auto& ms : h->match_slots) { if (ms.stream) { hipStreamSynchronize(ms.stream); (void)hipStreamDestroy(ms.stream); } if (ms.buf) hipFree(ms.buf); }
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -680,8 +685,9 @@ int d2fe_undistort(d2fe_handle h, const uint8_t* src, int sw, int sh, int sstrid
   if (sw < 1 || sh < 1 || sstride < sw || dw < 1 || dh < 1) return fail(D2FE_ERR_INVALID, "bad geometry");
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   const size_t sb = (size_t)sstride * sh, mb = sizeof(float) * (size_t)dw * dh, db = (size_t)dw * dh;
-  char* buf = nullptr;
-  HIP_TRY(hipMalloc(&buf, sb + 3 * mb + db + 64));
+  void* raw = nullptr;
+  { const int rc0 = d2fe::ctx_scratch(h, sb + 3 * mb + db + 64, &raw); if (rc0 != D2FE_OK) return rc0; }
+  char* buf = static_cast<char*>(raw);
   uint8_t* d_src = reinterpret_cast<uint8_t*>(buf);
   float* d_mx = reinterpret_cast<float*>(buf + ((sb + 15) / 16) * 16);
   float* d_my = d_mx + db; float* d_g = d_my + db;
@@ -696,7 +702,6 @@ int d2fe_undistort(d2fe_handle h, const uint8_t* src, int sw, int sh, int sstrid
   if (rc == D2FE_OK) chk(launch_undistort(d_src, sh, sw, sstride, 0, d_mx, d_my, gain ? d_g : nullptr, dh, dw, 1, d_dst, s), "undistort");
   if (rc == D2FE_OK) chk(hipMemcpyAsync(dst, d_dst, db, hipMemcpyDeviceToHost, s), "D2H");
   chk(hipStreamSynchronize(s), "sync");
-  hipFree(buf);
   return rc;
 }
 
@@ -712,15 +717,16 @@ static int gen_map(d2fe_handle h, const d2fe_mei_camera* cam, const double* q, i
     return D2FE_OK;
   }
   const size_t n = (size_t)width * height;
-  float* buf = nullptr;
-  HIP_TRY(hipMalloc(&buf, sizeof(float) * 2 * n));
+  void* raw = nullptr;
+  { const int rc0 = d2fe::ctx_scratch(h, sizeof(float) * 2 * n, &raw); if (rc0 != D2FE_OK) return rc0; }
+  float* buf = static_cast<float*>(raw);
   int rc = D2FE_OK;
   auto chk = [&](hipError_t e, const char* w) { if (e != hipSuccess && rc == D2FE_OK) rc = fail(D2FE_ERR_HIP, std::string(w) + ": " + hipGetErrorString(e)); };
   chk(launch_gen_map(c9, q, mode, width, height, f, buf, buf + n, s), "gen_map");
   chk(hipMemcpyAsync(mapx, buf, sizeof(float) * n, hipMemcpyDeviceToHost, s), "D2H mapx");
   chk(hipMemcpyAsync(mapy, buf + n, sizeof(float) * n, hipMemcpyDeviceToHost, s), "D2H mapy");
   chk(hipStreamSynchronize(s), "sync");
-  hipFree(buf);
+  
   return rc;
 }
 static double cyl_focal(int width, double fov_deg) { return (double)(unsigned)width / (fov_deg * (M_PI / 180.0)); }
@@ -819,8 +825,9 @@ int d2fe_db_query_gated(d2fe_db_handle db, const float* q, int max_index, double
 
 static int codec_run(d2fe_handle h, const void* in, size_t in_bytes, void* out, size_t out_bytes, int n, int arg, bool quant) {
   HIP_TRY(hipSetDevice(h->cfg.device_id));
-  char* buf = nullptr;
-  HIP_TRY(hipMalloc(&buf, in_bytes + out_bytes + 64));
+  void* raw = nullptr;
+  { const int rc0 = d2fe::ctx_scratch(h, in_bytes + out_bytes + 64, &raw); if (rc0 != D2FE_OK) return rc0; }
+  char* buf = static_cast<char*>(raw);
   char* d_out = buf + ((in_bytes + 15) / 16) * 16;
   hipStream_t s = h->stream;
   int rc = D2FE_OK;
@@ -832,7 +839,6 @@ static int codec_run(d2fe_handle h, const void* in, size_t in_bytes, void* out, 
   }
   if (rc == D2FE_OK) chk(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s), "D2H");
   chk(hipStreamSynchronize(s), "sync");
-  hipFree(buf);
   return rc;
 }
 
@@ -885,15 +891,29 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
   const int max_n = na > nb ? na : nb;
   if (max_n > 1024) return fail(D2FE_ERR_UNSUPPORTED, "more than 1024 descriptors per side");
   HIP_TRY(hipSetDevice(h->cfg.device_id));
-  // private stream + scratch per call: re-entrant (the reference calls matchKNN from three threads)
-  hipStream_t s;
-  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   const bool use_pts = mode == 0 && radius > 0 && pts_a && pts_b;
   const size_t fa = (size_t)na * dim, fb = (size_t)nb * dim;
-  const size_t bytes = sizeof(float) * (fa + fb + 2 * (size_t)na + 2 * (size_t)nb + max_n) + sizeof(int32_t) * (2 * (size_t)max_n + 5 + 8 * (size_t)max_n);
-  char* buf = nullptr;
-  hipError_t e = hipMalloc(&buf, bytes);
-  if (e != hipSuccess) { hipStreamDestroy(s); return fail(D2FE_ERR_HIP, "hipMalloc match scratch"); }
+  if (dim < 4 || dim > 256 || (dim & 3)) return fail(D2FE_ERR_INVALID, "dim must be a multiple of 4 in 4..256");
+  // a private (stream, scratch) slot per call in flight: re-entrant; slots are created on demand and reused
+  constexpr size_t MAXN = 1024, MAXD = 256;
+  constexpr size_t SLOT_BYTES = sizeof(float) * (2 * MAXN * MAXD + 4 * MAXN + MAXN) + sizeof(int32_t) * (2 * MAXN + 5 + 8 * MAXN) + 64;
+  int slot = -1;
+  {
+    std::lock_guard<std::mutex> lk(h->match_mu);
+    for (size_t i = 0; i < h->match_slots.size(); ++i)
+      if (!h->match_slots[i].busy) { slot = (int)i; break; }
+    if (slot < 0) {
+      d2fe_context::MatchSlot ms;
+      if (hipStreamCreateWithFlags(&ms.stream, hipStreamNonBlocking) != hipSuccess) return fail(D2FE_ERR_HIP, "hipStreamCreate (match slot)");
+      if (hipMalloc(&ms.buf, SLOT_BYTES) != hipSuccess) { hipStreamDestroy(ms.stream); return fail(D2FE_ERR_HIP, "hipMalloc match scratch"); }
+      h->match_slots.push_back(ms);
+      slot = (int)h->match_slots.size() - 1;
+    }
+    h->match_slots[slot].busy = true;
+  }
+  hipStream_t s = h->match_slots[slot].stream;
+  char* buf = h->match_slots[slot].buf;
+  struct Release { d2fe_context* h; int slot; ~Release() { std::lock_guard<std::mutex> lk(h->match_mu); h->match_slots[slot].busy = false; } } release{h, slot};
   float* d_a = reinterpret_cast<float*>(buf);
   float* d_b = d_a + fa;
   float* d_pa = d_b + fb;
@@ -918,7 +938,6 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
   m.a_off = d_meta; m.b_off = d_meta + 1; m.a_cnt = d_meta + 2; m.b_cnt = d_meta + 3;
   m.npairs = 1; m.dim = dim; m.max_n = max_n; m.mode = mode; m.ratio = ratio; m.radius = use_pts ? radius : -1.0;
   m.q_idx = d_q; m.t_idx = d_t; m.dist = d_dist; m.n_out = d_meta + 4; m.cand4 = d_c4;
-  if (dim < 4 || dim > 256 || (dim & 3)) rc = fail(D2FE_ERR_INVALID, "dim must be a multiple of 4 in 4..256");
   if (rc == D2FE_OK) chk(launch_match(m, s), "launch_match");
   int32_t cnt = 0;
   if (rc == D2FE_OK) chk(hipMemcpyAsync(&cnt, d_meta + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s), "D2H n");
@@ -934,8 +953,6 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
     *n_out = k;
     if (rc == D2FE_OK && cnt > cap) rc = fail(D2FE_ERR_TRUNCATED, "match output capacity too small");
   }
-  hipFree(buf);
-  hipStreamDestroy(s);
   return rc;
 }
 
