@@ -326,6 +326,10 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
       conv_epilogue<TW, MT, NT, POOL, RELU>(a, acc, oscale, T.img, T.ty0, T.tx0, wm, ntile0, lane);
   };
 
+  // producers outrank consumers at the issue arbiter: their few VALU/VMEM/LDS instructions slot in between the consumer's
+  // MFMAs instead of waiting for the consumer wave to stall (D2FE_ABLATE bit 512 switches this off for A/B measurements)
+  if (!consumer && !(a.ablate & 512)) __builtin_amdgcn_s_setprio(3);
+
   // ------------------------------------------------------------------------------------------------ tile loop
   int t = blockIdx.x;
   if (t >= total) return;
