@@ -69,6 +69,7 @@ struct d2fe_context {
   int last_w = 0, last_h = 0, last_n = 0;
   const uint8_t* last_gray = nullptr; int last_stride = 0; size_t last_istride = 0;
   float* aconf = nullptr; int* clist = nullptr;     // variant A scratch
+  float* zeros = nullptr;      // 1 KiB of zeros (ConvArgs::zeros)
   void* lk_scratch = nullptr; size_t lk_scratch_bytes = 0;   // grow-only scratch of the LK / detector entry points (lk.hip)
   float* a_samp = nullptr; float* a_cn = nullptr; int a_scap = 0;   // variant A sampling: [batch][a_scap][256] samples, [batch][256] channel norms
   float* pca_comp_t = nullptr; float* pca_mean = nullptr; int pca_dims = 0;
@@ -201,7 +202,7 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     a.out = out; a.out_cstride = ocs; a.out_coff = 0;
     a.cout_real = L.cout; a.wpack = L.wpack; a.bias = L.bias;
     a.img = d_gray; a.img_stride = stride; a.img_istride = (long)image_stride; a.w1a = h->w1a; a.b1a = h->b1a;
-    a.H = hh; a.W = ww; a.n_img = n; a.in_img_stride = iis; a.out_img_stride = ois;
+    a.H = hh; a.W = ww; a.n_img = n; a.in_img_stride = iis; a.out_img_stride = ois; a.zeros = h->zeros;
     { static int ab = -1; if (ab < 0) { const char* e = getenv("D2FE_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
     return launch_conv(shape, prec, pool, relu, L.cout_pad, a, s);
   };
@@ -320,6 +321,8 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   h->cand_cap = (long)(H * W);
   HIP_TRY(hipMalloc(&h->cand, sizeof(unsigned long long) * h->cand_cap * B));
   HIP_TRY(hipMalloc(&h->cand_count, sizeof(int) * B));
+  HIP_TRY(hipMalloc(&h->zeros, 1024));
+  HIP_TRY(hipMemset(h->zeros, 0, 1024));
   if (cfg->postproc == D2FE_POSTPROC_A) {
     HIP_TRY(hipMalloc(&h->aconf, sizeof(float) * H * W * B));
     HIP_TRY(hipMalloc(&h->clist, sizeof(int) * H * W * B));
@@ -350,7 +353,7 @@ void d2fe_destroy(d2fe_handle h) {
     if (t->p) hipFree(t->p);
   for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
   for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->cand_count, (void*)h->s_img, (void*)h->s_kps,
-                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, h->m_buf, (void*)h->m_cand4, (void*)h->aconf, (void*)h->clist, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch,
+                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, h->m_buf, (void*)h->m_cand4, (void*)h->aconf, (void*)h->clist, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros,
                   (void*)h->pca_comp_t, (void*)h->pca_mean})
     if (p) hipFree(p);
   nv_free(h);

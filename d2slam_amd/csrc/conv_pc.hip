@@ -139,6 +139,26 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
     if constexpr (FUSE1A) {
       conv1a_mfma_stage<MODE, NPIX, PW, CPF, CPH, PC_SA>(img_base + (size_t)T.img * img_istride, img_stride_b, aH, aW, T.ty0, T.tx0,
                                                          c1w, c1b, lane, wave - NC, NC, patch, hi, lo);
+    } else if (MODE == 0 && !(a.ablate & 2048)) {
+      // fp32 patch = a plain copy: one LDS-DMA instruction (global_load_lds_dword, 64 lanes x 4 B) per 64 channels of a patch
+      // pixel, no VGPR round trip and almost no VALU work -- every producer instruction costs the consumer wave of the same
+      // SIMD issue time (measured: ~3.4 us per tile for ~1-2 k instructions).  The LDS destination of an LDS-DMA is
+      // wave-uniform base + lane * 4, which is exactly one pixel's channel run at the odd pixel stride; pixels outside the
+      // image (the conv's zero padding) are copied from a page of zeros.
+      typedef __attribute__((address_space(1))) const void gvoid_t;
+      typedef __attribute__((address_space(3))) void lvoid_t;
+      const float* in = a.in + (size_t)T.img * a.in_img_stride + a.in_coff;
+      const float* zeros = a.zeros;
+      const int in_cs = a.in_cstride;
+      for (int pix = wave - NC; pix < NPIX; pix += NC) {          // wave-uniform: the address arithmetic stays on the SALU
+        const int gy = T.ty0 + pix / PW - P, gx = T.tx0 + pix % PW - P;
+        const bool valid = gy >= 0 && gy < aH && gx >= 0 && gx < aW;
+        const float* src = valid ? in + ((size_t)gy * aW + gx) * in_cs : zeros;
+#pragma unroll
+        for (int c0 = 0; c0 < CIN; c0 += 64)
+          __builtin_amdgcn_global_load_lds((gvoid_t*)(src + c0 + lane), (lvoid_t*)(patch + pix * CPF + c0), 4, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the copies must have landed before the tile barrier
     } else {
       const float* in = a.in + (size_t)T.img * a.in_img_stride + a.in_coff;
       constexpr int C4 = CIN / 4;

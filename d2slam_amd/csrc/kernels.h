@@ -19,6 +19,7 @@ struct ConvArgs {
   long out_img_stride;
   // fused conv1a prologue (CONV1B_FUSED only): the patch is computed from the u8 frame instead of being loaded
   const uint8_t* img; int img_stride; long img_istride; const float* w1a; const float* b1a;
+  const float* zeros;       // >= 256 zero floats in HBM (source of the LDS-DMA copies of out-of-image patch pixels)
   int ablate;               // experiment knob (D2FE_ABLATE): 1 skip patch loads, 2 skip B reloads, 4 skip stores
 };
 
