@@ -78,7 +78,7 @@ EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_creat
            "d2fe_half_image_filter", "d2fe_undistort", "d2fe_undistort_device", "d2fe_db_create", "d2fe_db_destroy",
            "d2fe_db_ntotal", "d2fe_db_add", "d2fe_db_search", "d2fe_db_query_gated", "d2fe_quantize_int8", "d2fe_dequantize_int8",
            "d2fe_debug_read", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read",
-           "d2fe_gen_cylinder_map", "d2fe_gen_cylinder_map_device", "d2fe_gen_pinhole_map", "d2fe_gen_pinhole_map_device",
+           "d2fe_prepare_gray", "d2fe_prepare_gray_device", "d2fe_gen_cylinder_map", "d2fe_gen_cylinder_map_device", "d2fe_gen_pinhole_map", "d2fe_gen_pinhole_map_device",
            "d2fe_lk_frame_create", "d2fe_lk_frame_create_device", "d2fe_lk_frame_destroy", "d2fe_lk_frame_read_level",
            "d2fe_lk_track", "d2fe_lk_track_batch", "d2fe_detect_fast_by_region", "d2fe_good_features_to_track"]
 
@@ -160,6 +160,9 @@ def load_library():
         lib.d2fe_desc_dim.argtypes = [C.c_void_p]
         lib.d2fe_profile_enable.argtypes = [C.c_void_p, C.c_int]
         lib.d2fe_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.d2fe_prepare_gray.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.d2fe_prepare_gray_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int,
+                                                 C.c_int, C.c_void_p, C.c_void_p]
         lib.d2fe_gen_cylinder_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         lib.d2fe_gen_cylinder_map_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.d2fe_gen_pinhole_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
@@ -385,6 +388,15 @@ class FrontEnd:
         """Device-resident undistort of n frames sharing one map set (raw addresses)."""
         _check(self._lib.d2fe_undistort_device(self._h, d_src, n, sw, sh, sstride or sw, src_image_stride if src_image_stride is not None else sw * sh,
                                                d_mapx, d_mapy, d_gain, dw, dh, d_dst, stream))
+
+    def prepare_gray(self, img, width, height):
+        """cv::cvtColor(BGR2GRAY) if 3 channels + cv::resize to (width, height) if the size differs (superpoint_onnx.cpp:76-83)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        sh, sw = img.shape[:2]
+        out = np.zeros((height, width), np.uint8)
+        _check(self._lib.d2fe_prepare_gray(self._h, _ptr(img), ch, sw, sh, sw * ch, int(width), int(height), _ptr(out)))
+        return out
 
     @staticmethod
     def _mei(cam):

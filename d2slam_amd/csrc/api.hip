@@ -708,6 +708,36 @@ int d2fe_undistort(d2fe_handle h, const uint8_t* src, int sw, int sh, int sstrid
   return rc;
 }
 
+int d2fe_prepare_gray_device(d2fe_handle h, const uint8_t* d_src, int n, int channels, int sw, int sh, int sstride,
+                             size_t src_image_stride, int dw, int dh, uint8_t* d_dst, void* stream) {
+  if (!h || !d_src || !d_dst) return fail(D2FE_ERR_INVALID, "null argument");
+  if (n < 1 || (channels != 1 && channels != 3) || sw < 2 || sh < 2 || sstride < sw * channels || dw < 1 || dh < 1)
+    return fail(D2FE_ERR_INVALID, "bad geometry (channels must be 1 or 3)");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(launch_prep_gray(d_src, channels, sw, sh, sstride, (long)src_image_stride, n, dw, dh, d_dst, stream ? (hipStream_t)stream : h->stream));
+  return D2FE_OK;
+}
+
+int d2fe_prepare_gray(d2fe_handle h, const uint8_t* src, int channels, int sw, int sh, int sstride, int dw, int dh, uint8_t* dst) {
+  if (!h || !src || !dst) return fail(D2FE_ERR_INVALID, "null argument");
+  if ((channels != 1 && channels != 3) || sw < 2 || sh < 2 || sstride < sw * channels || dw < 1 || dh < 1)
+    return fail(D2FE_ERR_INVALID, "bad geometry (channels must be 1 or 3)");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  const size_t sb = (size_t)sstride * sh, db = (size_t)dw * dh;
+  void* raw = nullptr;
+  { const int rc0 = d2fe::ctx_scratch(h, sb + db + 64, &raw); if (rc0 != D2FE_OK) return rc0; }
+  uint8_t* d_src = static_cast<uint8_t*>(raw);
+  uint8_t* d_dst = d_src + ((sb + 15) / 16) * 16;
+  hipStream_t s = h->stream;
+  int rc = D2FE_OK;
+  auto chk = [&](hipError_t e, const char* w) { if (e != hipSuccess && rc == D2FE_OK) rc = fail(D2FE_ERR_HIP, std::string(w) + ": " + hipGetErrorString(e)); };
+  chk(hipMemcpyAsync(d_src, src, sb, hipMemcpyHostToDevice, s), "H2D");
+  if (rc == D2FE_OK) chk(launch_prep_gray(d_src, channels, sw, sh, sstride, 0, 1, dw, dh, d_dst, s), "prep_gray");
+  if (rc == D2FE_OK) chk(hipMemcpyAsync(dst, d_dst, db, hipMemcpyDeviceToHost, s), "D2H");
+  chk(hipStreamSynchronize(s), "sync");
+  return rc;
+}
+
 static int gen_map(d2fe_handle h, const d2fe_mei_camera* cam, const double* q, int mode, int width, int height, double f,
                    float* mapx, float* mapy, bool device, void* stream) {
   if (!h || !cam || !mapx || !mapy || (mode == 1 && !q)) return fail(D2FE_ERR_INVALID, "null argument");

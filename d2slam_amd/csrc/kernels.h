@@ -83,6 +83,8 @@ hipError_t launch_nv_pca(const float* x, int nfeat, const float* comp, const flo
 // ---- SURVEY 8(f) next rows (next.hip) ------------------------------------------------------------------------------------
 hipError_t launch_gen_map(const double* cam9, const double* q4, int mode, int width, int height, double f, float* mapx,
                           float* mapy, hipStream_t s);
+hipError_t launch_prep_gray(const uint8_t* src, int ch, int sw, int sh, int sstride, long src_istride, int n, int dw, int dh,
+                            uint8_t* dst, hipStream_t s);
 hipError_t launch_undistort(const uint8_t* src, int sh, int sw, int sstride, long src_istride, const float* mapx,
                             const float* mapy, const float* gain, int dh, int dw, int n, uint8_t* dst, hipStream_t s);
 hipError_t launch_db_search(const float* db, int ntotal, int dim, const float* q, int nq, int k, float* sims_scratch,

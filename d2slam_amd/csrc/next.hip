@@ -113,6 +113,56 @@ hipError_t launch_gen_map(const double* cam9, const double* q4, int mode, int wi
   return hipGetLastError();
 }
 
+// ---- A1, variant A / NetVLAD prep: cv::cvtColor(COLOR_BGR2GRAY) + cv::resize(INTER_LINEAR) fused (superpoint_onnx.cpp:76-83,
+// mobilenetvlad_onnx.h:51-59).  Integer arithmetic of OpenCV 4.10 as restated in the oracle (orc_bgr2gray, orc_resize_linear_u8):
+// one thread per destination pixel, the 4 taps converted to gray on the fly.  HBM-bound: reads <= 4 * channels bytes per pixel.
+__device__ __forceinline__ int prep_px(const uint8_t* __restrict__ row, int x, int ch) {
+  if (ch == 1) return row[x];
+  const uint8_t* p = row + 3 * x;
+  return (p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15;
+}
+__device__ __forceinline__ void resize_coef(int d, int ssize, int dsize, bool clamp_ofs, int& ofs, int& c0, int& c1) {
+  const double scale = 1.0 / ((double)dsize / (double)ssize);
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)__builtin_floorf(f);
+  f -= (float)s;
+  if (clamp_ofs) {
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+  }
+  ofs = s;
+  c0 = (int)__builtin_rintf((1.f - f) * 2048.f);
+  c1 = (int)__builtin_rintf(f * 2048.f);
+}
+__global__ __launch_bounds__(256) void prep_gray_kernel(const uint8_t* __restrict__ src, int ch, int sw, int sh, int sstride,
+                                                        long src_istride, int dw, int dh, uint8_t* __restrict__ dst) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), n = blockIdx.z;
+  if (x >= dw || y >= dh) return;
+  const uint8_t* s = src + (size_t)n * src_istride;
+  uint8_t* d = dst + (size_t)n * dw * dh;
+  if (sw == dw && sh == dh) { d[(size_t)y * dw + x] = (uint8_t)prep_px(s + (size_t)y * sstride, x, ch); return; }
+  if (sw == 2 * dw && sh == 2 * dh) {     // cv::resize turns an exact 2x INTER_LINEAR decimation into INTER_AREA
+    const uint8_t* r0 = s + (size_t)(2 * y) * sstride; const uint8_t* r1 = r0 + sstride;
+    d[(size_t)y * dw + x] = (uint8_t)((prep_px(r0, 2 * x, ch) + prep_px(r0, 2 * x + 1, ch) + prep_px(r1, 2 * x, ch) + prep_px(r1, 2 * x + 1, ch) + 2) >> 2);
+    return;
+  }
+  int sy, b0, b1, sx, a0, a1;
+  resize_coef(y, sh, dh, false, sy, b0, b1);
+  resize_coef(x, sw, dw, true, sx, a0, a1);
+  const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+  const int x1 = sx + 1 < sw ? sx + 1 : sx;
+  const uint8_t* r0 = s + (size_t)y0 * sstride; const uint8_t* r1 = s + (size_t)y1 * sstride;
+  const int S0 = prep_px(r0, sx, ch) * a0 + prep_px(r0, x1, ch) * a1;
+  const int S1 = prep_px(r1, sx, ch) * a0 + prep_px(r1, x1, ch) * a1;
+  d[(size_t)y * dw + x] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+}
+hipError_t launch_prep_gray(const uint8_t* src, int ch, int sw, int sh, int sstride, long src_istride, int n, int dw, int dh,
+                            uint8_t* dst, hipStream_t s) {
+  hipLaunchKernelGGL(prep_gray_kernel, dim3((dw + 63) / 64, (dh + 3) / 4, n), dim3(256), 0, s, src, ch, sw, sh, sstride, src_istride,
+                     dw, dh, dst);
+  return hipGetLastError();
+}
+
 // ---- (f)-2: flat inner-product database ------------------------------------------------------------------------------------------
 // sims[q][i] = <db[i], query[q]>: one wave per database row, the row is read once (coalesced float4) and reused for every
 // query of the batch (queries staged in LDS).  HBM-bound: ntotal*dim*4 bytes per search.

@@ -193,6 +193,15 @@ D2FE_API int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, 
 D2FE_API int d2fe_half_image_filter(const float* pts_xy, int n, int require_left, int width_undistort,
                                     double undistort_fov, int32_t* map, int* n_out);
 
+/* A1, variant A / NetVLAD image prep.  Replaces the cv::cvtColor(COLOR_BGR2GRAY) + cv::resize(INTER_LINEAR) block in front of
+ * SuperPointONNX::infer and MobileNetVLADONNX::inference (superpoint_onnx.cpp:76-83, mobilenetvlad_onnx.h:51-59): channels = 1
+ * (gray) or 3 (BGR, interleaved); the output is dw x dh gray u8, tight rows.  Same size and 1 channel = a copy.  Fused, one
+ * pass; OpenCV's 8-bit fixed-point arithmetic (incl. its silent INTER_AREA for an exact 2x decimation). */
+D2FE_API int d2fe_prepare_gray(d2fe_handle h, const uint8_t* src, int channels, int sw, int sh, int sstride, int dw, int dh,
+                               uint8_t* dst);
+D2FE_API int d2fe_prepare_gray_device(d2fe_handle h, const uint8_t* d_src, int n, int channels, int sw, int sh, int sstride,
+                                      size_t src_image_stride, int dw, int dh, uint8_t* d_dst, void* stream);
+
 /* ---- the components either side of the hot path --------------------------------------------------
  * (f)-1 Fisheye undistort + photometric gain.  Replaces FisheyeUndist::undist_id_cuda
  * (d2common/include/d2common/fisheye_undistort.h:152-176: cv::cuda::remap(INTER_LINEAR, constant 0 border) -> convertTo(32F)

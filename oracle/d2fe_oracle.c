@@ -757,3 +757,60 @@ ORC_API void orc_gen_pinhole_map(const double* cam, const double* q, int width, 
       mapy[(size_t)y * width + x] = (float)v;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * A1, variant A / NetVLAD image prep: cv::cvtColor(COLOR_BGR2GRAY) when the frame has 3 channels and cv::resize(INTER_LINEAR)
+ * when its size differs from the network's (superpoint_onnx.cpp:76-83, mobilenetvlad_onnx.h:51-59).  Third-party arithmetic
+ * (OpenCV 4.10.0, docker/Dockerfile.x86:6) restated -- parity unpinned:
+ *   gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15                       (color_rgb: BY15, GY15, RY15, gray_shift 15)
+ *   resize 8U INTER_LINEAR: 11-bit fixed-point weights saturate_cast<short>(w * 2048), horizontal pass in int,
+ *   vertical pass ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2; source coordinate (d + 0.5)*scale - 0.5 in float;
+ *   an exact 2x decimation is silently computed as INTER_AREA: (s00 + s01 + s10 + s11 + 2) >> 2.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_bgr2gray(const uint8_t* bgr, int w, int h, int stride, uint8_t* gray) {
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const uint8_t* p = bgr + (size_t)y * stride + 3 * x;
+      gray[(size_t)y * w + x] = (uint8_t)((p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15);
+    }
+}
+
+static void resize_coef(int d, int ssize, int dsize, int* ofs, int* c0, int* c1, int clamp_ofs) {
+  const double scale = 1.0 / ((double)dsize / (double)ssize);
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (clamp_ofs) {
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+  }
+  *ofs = s;
+  *c0 = (int)lrintf((1.f - f) * 2048.f);
+  *c1 = (int)lrintf(f * 2048.f);
+}
+
+ORC_API void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh) {
+  if (sw == 2 * dw && sh == 2 * dh) {
+    for (int y = 0; y < dh; ++y)
+      for (int x = 0; x < dw; ++x) {
+        const uint8_t* p = src + (size_t)(2 * y) * sstride + 2 * x;
+        dst[(size_t)y * dw + x] = (uint8_t)((p[0] + p[1] + p[sstride] + p[sstride + 1] + 2) >> 2);
+      }
+    return;
+  }
+  for (int y = 0; y < dh; ++y) {
+    int sy, b0, b1;
+    resize_coef(y, sh, dh, &sy, &b0, &b1, 0);
+    int y0 = sy, y1 = sy + 1;
+    y0 = y0 >= 0 ? (y0 < sh ? y0 : sh - 1) : 0;
+    y1 = y1 >= 0 ? (y1 < sh ? y1 : sh - 1) : 0;
+    for (int x = 0; x < dw; ++x) {
+      int sx, a0, a1;
+      resize_coef(x, sw, dw, &sx, &a0, &a1, 1);
+      const int x1 = sx + 1 < sw ? sx + 1 : sx;            /* dx >= xmax: only S[sx] (its weight is 2048, the other 0) */
+      const int S0 = src[(size_t)y0 * sstride + sx] * a0 + src[(size_t)y0 * sstride + x1] * a1;
+      const int S1 = src[(size_t)y1 * sstride + sx] * a0 + src[(size_t)y1 * sstride + x1] * a1;
+      dst[(size_t)y * dw + x] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+    }
+  }
+}

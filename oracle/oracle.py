@@ -359,3 +359,20 @@ def gen_pinhole_map(cam9, q_wxyz, width, height, f):
     mx = np.zeros((height, width), np.float32); my = np.zeros((height, width), np.float32)
     lib().orc_gen_pinhole_map(_p(cam), _p(q), int(width), int(height), C.c_double(f), _p(mx), _p(my))
     return mx, my
+
+
+# ---- A1 (variant A / NetVLAD): BGR -> gray, resize to the network size ------------------------------------------------------------
+def bgr2gray(bgr_u8):
+    img = np.ascontiguousarray(bgr_u8, np.uint8)
+    h, w, _ = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orc_bgr2gray(_p(img), w, h, 3 * w, _p(out))
+    return out
+
+
+def resize_linear_u8(src_u8, dw, dh):
+    src = np.ascontiguousarray(src_u8, np.uint8)
+    sh, sw = src.shape
+    out = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), sw, sh, sw, _p(out), int(dw), int(dh))
+    return out

@@ -183,3 +183,37 @@ def test_gen_maps_gpu(orc):
     ref = orc.undistort(src, rx, ry, None)
     assert (got != ref).mean() < 1e-4 and np.abs(got.astype(int) - ref.astype(int)).max() <= 1
     fe.close()
+
+
+# ---- A1 variant A / NetVLAD prep: BGR -> gray + resize (superpoint_onnx.cpp:76-83, mobilenetvlad_onnx.h:51-59) -------------------
+def test_prepare_gray_oracle_vs_float(orc):
+    bgr = np.stack([synth_image(300, 400, s) for s in (1, 2, 3)], -1)
+    g = orc.bgr2gray(bgr)
+    assert np.abs(g.astype(int) - np.rint(bgr[..., 0] * 0.114 + bgr[..., 1] * 0.587 + bgr[..., 2] * 0.299)).max() <= 1
+    img = synth_image(400, 800, 1)
+    for (dw, dh) in ((640, 480), (1000, 500), (123, 77)):
+        r = orc.resize_linear_u8(img, dw, dh)
+        yy, xx = np.mgrid[0:dh, 0:dw]
+        fx = (xx + 0.5) * (800 / dw) - 0.5; fy = (yy + 0.5) * (400 / dh) - 0.5
+        x0 = np.floor(fx).astype(int); y0 = np.floor(fy).astype(int); ax = fx - x0; ay = fy - y0
+        c = lambda v, n: np.clip(v, 0, n - 1)
+        a = img.astype(np.float64)
+        ref = (a[c(y0, 400), c(x0, 800)] * (1 - ax) * (1 - ay) + a[c(y0, 400), c(x0 + 1, 800)] * ax * (1 - ay)
+               + a[c(y0 + 1, 400), c(x0, 800)] * (1 - ax) * ay + a[c(y0 + 1, 400), c(x0 + 1, 800)] * ax * ay)
+        assert np.abs(r.astype(int) - np.rint(ref).astype(int)).max() <= 1      # 11-bit fixed point vs exact bilinear
+    # exact 2x decimation = INTER_AREA
+    half = orc.resize_linear_u8(img, 400, 200)
+    assert np.array_equal(half, ((img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+
+
+@pytest.mark.gpu
+def test_prepare_gray_gpu(orc):
+    from d2slam_amd import api
+    fe = api.FrontEnd(api.SuperPointConfig(input_width=64, input_height=64, max_batch=1))
+    bgr = np.stack([synth_image(400, 800, s) for s in (4, 5, 6)], -1)
+    gray = orc.bgr2gray(bgr)
+    assert np.array_equal(fe.prepare_gray(bgr, 800, 400), gray)                                   # colour only
+    for (dw, dh) in ((640, 480), (400, 200), (1280, 800), (123, 77)):
+        assert np.array_equal(fe.prepare_gray(bgr, dw, dh), orc.resize_linear_u8(gray, dw, dh))   # colour + resize, fused
+        assert np.array_equal(fe.prepare_gray(gray, dw, dh), orc.resize_linear_u8(gray, dw, dh))
+    fe.close()
