@@ -427,3 +427,20 @@ def test_matcher_fuzz(api, orc):
             rq, rt, rd = orc.match_crosscheck(a, b)
             assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd), (case, na, nb, dim)
     fe.close()
+
+
+@pytest.mark.parametrize("H,W,maxkp,thr", [(512, 512, 150, 0.015),      # C1: TUM 512x512 (config/tum/tum_single.yaml:20-21)
+                                           (400, 800, 100, 0.015),      # C3: one undistorted quadcam view, 100 keypoints
+                                           (480, 640, 1024, 0.015),     # the largest keypoint budget the ABI accepts
+                                           (480, 640, 200, 0.9999)])    # a threshold nothing passes: zero keypoints, no failure
+def test_other_configs_and_limits(api, orc, sp_weights, H, W, maxkp, thr):
+    img = synth_image(H, W, 91)
+    fe = _fe(api, H, W, 1, api.PREC_F32, max_kp=maxkp, thr=thr)
+    fe.load_superpoint(sp_weights)
+    kps, sc, desc = fe.extract_batch(img[None], cap=maxkp)[0][:3]
+    rk, rs, rd, ri, f = orc.extract_b(img, sp_weights, thr, 1, maxkp)
+    assert len(kps) == len(rk) and (thr < 0.9 or len(kps) == 0) and (thr > 0.9 or len(kps) == maxkp)
+    assert np.array_equal(kps, rk) and np.array_equal(sc, rs)
+    if len(kps):
+        assert np.abs(desc - rd).max() <= 1e-6
+    fe.close()
