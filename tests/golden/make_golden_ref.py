@@ -37,16 +37,26 @@ for n in SP_LAYERS:
     sd[n + ".weight"] = torch.from_numpy(w[n][0]); sd[n + ".bias"] = torch.from_numpy(w[n][1])
 
 out = {"dustbin_bias": np.float64(DUSTBIN), "pb_scale": np.float64(PB_SCALE), "seed": np.int64(1234)}
-for tag, (h, wd, seed) in {"a": (64, 96, 3), "b": (120, 160, 5)}.items():
-    img = synth_image(h, wd, seed)
+# frames: two seeded synthetic ones and a 160x240 crop (decimated by 2) of the only image the reference ships
+# (sample_data/fisheye.jpg, 1280x800): real image statistics for the same checks
+from PIL import Image
+real = np.asarray(Image.open("/root/reference/sample_data/fisheye.jpg").convert("L"))[200:520:2, 400:880:2].copy()
+frames = {"a": synth_image(64, 96, 3), "b": synth_image(120, 160, 5), "c": real}
+for tag, img in frames.items():
     out["img_" + tag] = img
     for dt, dn in ((torch.float64, "f64"), (torch.float32, "f32")):
         x = torch.from_numpy(img.astype(np.float32) / np.float32(255.0))[None, None].to(dt)   # notebook: img.astype(float32)/255
         half = ns["SuperPointNetHalf"](); half.load_state_dict(sd); half = half.to(dt).eval()
         with torch.no_grad():
             semi, desc = half(x)
-        out["semi_%s_%s" % (dn, tag)] = semi[0].numpy()
-        out["desc_%s_%s" % (dn, tag)] = desc[0].numpy()
+        if dn == "f64":
+            ref64 = (semi[0].numpy().copy(), desc[0].numpy().copy())
+        if dn == "f64":          # the float64 run is the reference value; stored rounded to float32 (6e-8) to keep the fixture small
+            out["semi_f64_" + tag] = semi[0].numpy().astype(np.float32)
+            out["desc_f64_" + tag] = desc[0].numpy().astype(np.float32)
+        else:                    # of the module's native float32 run only the worst deviation from the float64 run is kept
+            out["f32_vs_f64_semi_" + tag] = np.float64(np.abs(semi[0].numpy() - ref64[0]).max())
+            out["f32_vs_f64_desc_" + tag] = np.float64(np.abs(desc[0].numpy() - ref64[1]).max())
     # the full module (keypoints + grid_sample descriptors) only in its native float32: it casts the grid to torch.FloatTensor
     full = ns["SuperPointNet"](); full.load_state_dict(sd); full = full.eval()
     with torch.no_grad():
