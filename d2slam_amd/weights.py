@@ -48,3 +48,89 @@ def load_superpoint_npz(path):
 
 def save_superpoint_npz(path, w):
     np.savez(path, **{n + ".weight": w[n][0] for n in SP_LAYERS}, **{n + ".bias": w[n][1] for n in SP_LAYERS})
+
+
+# ---- ONNX initializers without the onnx package -----------------------------------------------------------------------------------
+# The reference loads its SuperPoint weights from an ONNX file (superpoint_v1_sim_int32.onnx, config/quadcam/quadcam_single.yaml:
+# 106-115; produced by d2frontend/superpoint.ipynb cell 5 with torch.onnx.export, whose initializers carry the state_dict names
+# conv1a.weight ... convDb.bias).  Only the initializers are needed, so this reads the protobuf wire format directly:
+# ModelProto.graph (field 7) -> GraphProto.initializer (field 5, repeated TensorProto) -> TensorProto {dims 1, data_type 2,
+# float_data 4, name 8, raw_data 9}.
+def _pb_varint(buf, pos):
+    val, shift = 0, 0
+    while True:
+        b = buf[pos]; pos += 1
+        val |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return val, pos
+        shift += 7
+
+
+def _pb_fields(buf):
+    """Yields (field_number, wire_type, value) of one protobuf message; value is an int (varint / fixed) or a memoryview."""
+    pos, n = 0, len(buf)
+    while pos < n:
+        key, pos = _pb_varint(buf, pos)
+        fno, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _pb_varint(buf, pos)
+        elif wt == 1:
+            v = int.from_bytes(buf[pos:pos + 8], "little"); pos += 8
+        elif wt == 2:
+            ln, pos = _pb_varint(buf, pos)
+            v = buf[pos:pos + ln]; pos += ln
+        elif wt == 5:
+            v = int.from_bytes(buf[pos:pos + 4], "little"); pos += 4
+        else:
+            raise ValueError("unsupported protobuf wire type %d" % wt)
+        yield fno, wt, v
+
+
+def read_onnx_initializers(path):
+    """{name: float32 ndarray} of every FLOAT initializer of an ONNX model file."""
+    data = memoryview(open(path, "rb").read())
+    out = {}
+    for fno, wt, graph in _pb_fields(data):
+        if fno != 7 or wt != 2:
+            continue
+        for gno, gwt, tensor in _pb_fields(graph):
+            if gno != 5 or gwt != 2:
+                continue
+            dims, dtype, name, raw, floats = [], 0, "", None, []
+            for tno, twt, v in _pb_fields(tensor):
+                if tno == 1:
+                    if twt == 2:                                   # packed repeated int64
+                        p = 0
+                        while p < len(v):
+                            d, p = _pb_varint(v, p); dims.append(d)
+                    else:
+                        dims.append(v)
+                elif tno == 2:
+                    dtype = v
+                elif tno == 8:
+                    name = bytes(v).decode()
+                elif tno == 9:
+                    raw = bytes(v)
+                elif tno == 4:
+                    if twt == 2:
+                        floats.append(np.frombuffer(bytes(v), "<f4"))
+                    else:
+                        floats.append(np.array([v], "<u4").view("<f4"))
+            if dtype != 1:                                         # TensorProto.FLOAT
+                continue
+            arr = np.frombuffer(raw, "<f4") if raw is not None else (np.concatenate(floats) if floats else np.zeros(0, np.float32))
+            out[name] = arr.astype(np.float32).reshape(dims if dims else arr.shape).copy()
+    return out
+
+
+def load_superpoint_onnx(path):
+    """SuperPoint weights from the ONNX file the reference uses (initializer names = state_dict names)."""
+    init = read_onnx_initializers(path)
+    missing = [n for n in SP_LAYERS if n + ".weight" not in init or n + ".bias" not in init]
+    if missing:
+        raise KeyError("ONNX file has no initializers for %s (found: %s)" % (missing, sorted(init)[:8]))
+    w = {n: (init[n + ".weight"], init[n + ".bias"]) for n in SP_LAYERS}
+    for n in SP_LAYERS:
+        if tuple(w[n][0].shape) != (SP_SHAPES[n][0], SP_SHAPES[n][1], SP_SHAPES[n][2], SP_SHAPES[n][2]):
+            raise ValueError("unexpected shape for %s: %s" % (n, w[n][0].shape))
+    return w

@@ -87,3 +87,45 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 s = open(os.path.join(dp, f)).read()
                 assert "from oracle" not in s and "import oracle" not in s and "d2fe_oracle" not in s.replace("oracle/d2fe_oracle.c", "").replace("oracle/d2fe_oracle_lk.c", ""), f   # comments may cite the files
+
+
+def _pb_key(fno, wt):
+    return _pb_varint_enc((fno << 3) | wt)
+
+
+def _pb_varint_enc(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F; v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _pb_ld(fno, payload):
+    return _pb_key(fno, 2) + _pb_varint_enc(len(payload)) + payload
+
+
+def test_onnx_initializer_reader_roundtrip(tmp_path):
+    """The reference ships its SuperPoint weights as ONNX; d2slam_amd.weights reads the initializers without the onnx package.
+    A minimal model file is serialised here by hand (ModelProto.graph.initializer[], raw_data and float_data encodings, packed
+    and unpacked dims) and must come back bit for bit."""
+    from d2slam_amd.weights import SP_LAYERS, load_superpoint_onnx, read_onnx_initializers, synthetic_superpoint_weights
+    w = synthetic_superpoint_weights(seed=7)
+    tensors = b""
+    for i, n in enumerate(SP_LAYERS):
+        for suffix, arr in ((".weight", w[n][0]), (".bias", w[n][1])):
+            dims = b"".join(_pb_key(1, 0) + _pb_varint_enc(d) for d in arr.shape) if i % 2 else _pb_ld(1, b"".join(_pb_varint_enc(d) for d in arr.shape))
+            data = _pb_ld(9, arr.astype("<f4").tobytes()) if suffix == ".weight" else _pb_ld(4, arr.astype("<f4").tobytes())
+            t = dims + _pb_key(2, 0) + _pb_varint_enc(1) + _pb_ld(8, (n + suffix).encode()) + data
+            tensors += _pb_ld(5, t)
+    int_tensor = _pb_key(1, 0) + _pb_varint_enc(2) + _pb_key(2, 0) + _pb_varint_enc(7) + _pb_ld(8, b"shape_const") + _pb_ld(9, np.array([1, 2], "<i8").tobytes())
+    graph = _pb_ld(1, _pb_ld(1, b"image")) + _pb_ld(2, b"torch_jit") + tensors + _pb_ld(5, int_tensor)
+    model = _pb_key(1, 0) + _pb_varint_enc(8) + _pb_ld(2, b"pytorch") + _pb_ld(7, graph) + _pb_ld(8, _pb_ld(1, b"") + _pb_key(2, 0) + _pb_varint_enc(16))
+    path = tmp_path / "sp.onnx"
+    path.write_bytes(model)
+    init = read_onnx_initializers(str(path))
+    assert "shape_const" not in init and len(init) == 24
+    back = load_superpoint_onnx(str(path))
+    for n in SP_LAYERS:
+        assert np.array_equal(back[n][0], w[n][0]) and np.array_equal(back[n][1], w[n][1])
