@@ -1,0 +1,298 @@
+// d2fe.hpp -- header-only C++ mirror of the D2SLAM d2frontend interfaces this library stands behind, written on top of the
+// C ABI (d2fe.h).  Same names, argument meaning, ownership and error behaviour as the reference, so that a call site in
+// D2SLAM compiles against either:
+//   SuperPointConfig / SuperPoint::build / SuperPoint::infer   d2frontend/include/d2frontend/CNN/superpoint_tensorrt.h:17-93,
+//                                                              d2frontend/src/CNN/superpoint_tensorrt.cpp:161-183
+//   MobileNetVLADONNX::inference                               d2frontend/include/d2frontend/CNN/mobilenetvlad_onnx.h:49-74
+//   matchKNN                                                   d2frontend/include/d2frontend/feature_matcher.h:6-11
+//   cv::BFMatcher(NORM_L2, true).match                         loop_cam.cpp:167-170, d2featuretracker.cpp:1141-1142
+//   getFeatureHalfImg                                          d2frontend/src/d2featuretracker.cpp:1051-1075
+//   LKImageInfo, buildImagePyramid, opticalflowTrackPyr, detectPoints
+//                                                              d2frontend/include/d2frontend/opticaltrack_utils.h:16-36,
+//                                                              d2frontend/src/opticaltrack_utils.cpp:173-279,375-442
+// OpenCV is not required: Point2f / DMatch / the image and descriptor views are layout-compatible stand-ins for cv::Point2f,
+// cv::DMatch and the (data, rows, cols, step) fields of a cv::Mat; with -DD2FE_WITH_OPENCV the cv:: types convert implicitly.
+#ifndef D2FE_HPP_
+#define D2FE_HPP_
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "d2fe.h"
+
+#ifdef D2FE_WITH_OPENCV
+#include <opencv2/core.hpp>
+#endif
+
+namespace D2FrontEnd {
+
+struct Point2f {                      // == cv::Point2f
+  float x = 0.f, y = 0.f;
+  Point2f() = default;
+  Point2f(float x_, float y_) : x(x_), y(y_) {}
+#ifdef D2FE_WITH_OPENCV
+  Point2f(const cv::Point2f& p) : x(p.x), y(p.y) {}
+  operator cv::Point2f() const { return cv::Point2f(x, y); }
+#endif
+};
+static_assert(sizeof(Point2f) == 2 * sizeof(float), "Point2f must be two packed floats");
+
+struct DMatch {                       // == cv::DMatch
+  int queryIdx = -1, trainIdx = -1, imgIdx = -1;
+  float distance = 0.f;
+  DMatch() = default;
+  DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), imgIdx(-1), distance(d) {}
+};
+
+struct ImageView {                    // borrowed view of a CV_8UC1 / CV_8UC3 cv::Mat
+  const uint8_t* data = nullptr;
+  int rows = 0, cols = 0, channels = 1;
+  size_t step = 0;
+  ImageView() = default;
+  ImageView(const uint8_t* d, int rows_, int cols_, size_t step_ = 0, int channels_ = 1)
+      : data(d), rows(rows_), cols(cols_), channels(channels_), step(step_ ? step_ : (size_t)cols_ * channels_) {}
+#ifdef D2FE_WITH_OPENCV
+  ImageView(const cv::Mat& m) : data(m.data), rows(m.rows), cols(m.cols), channels(m.channels()), step(m.step) {}
+#endif
+  bool empty() const { return !data || rows <= 0 || cols <= 0; }
+};
+
+struct DescView {                     // borrowed view of a continuous CV_32F cv::Mat [rows x cols]
+  const float* data = nullptr;
+  int rows = 0, cols = 0;
+  DescView() = default;
+  DescView(const float* d, int rows_, int cols_) : data(d), rows(rows_), cols(cols_) {}
+#ifdef D2FE_WITH_OPENCV
+  DescView(const cv::Mat& m) : data(m.ptr<float>()), rows(m.rows), cols(m.cols) {}
+#endif
+};
+
+// superpoint_tensorrt.h:17-33 (the fields the path uses) plus what the TensorRT engine carried implicitly
+struct SuperPointConfig {
+  int32_t max_keypoints = 100;
+  int32_t remove_borders = 1;
+  float keypoint_threshold = 0.015f;
+  int32_t input_width = 640, input_height = 480;
+  int32_t dla_core = -1;                 // unused here, kept for source compatibility
+  std::string onnx_path, engine_path;    // the adapter's weight loader reads these; this class takes the tensors in build()
+  int32_t device_id = 0;
+  int32_t max_batch = 2;
+  bool fast_mode = false;                // D2FE_PREC_F16X2 instead of the bit-exact fp32 mode
+};
+
+class SuperPoint {
+ public:
+  explicit SuperPoint(const SuperPointConfig& cfg) : cfg_(cfg) {}
+  ~SuperPoint() { if (h_) d2fe_destroy(h_); }
+  SuperPoint(const SuperPoint&) = delete;
+  SuperPoint& operator=(const SuperPoint&) = delete;
+
+  // reference: build() parses the ONNX / deserialises the engine (superpoint_tensorrt.cpp:22-107); here the 12 conv layers
+  // are passed in (d2slam_amd/weights.py reads .pth / .npz / .onnx; any loader that fills d2fe_superpoint_weights works)
+  bool build(const d2fe_superpoint_weights& w) {
+    d2fe_config c;
+    d2fe_default_config(&c);
+    c.device_id = cfg_.device_id;
+    c.max_width = cfg_.input_width; c.max_height = cfg_.input_height; c.max_batch = cfg_.max_batch;
+    c.max_keypoints = cfg_.max_keypoints; c.remove_borders = cfg_.remove_borders; c.keypoint_threshold = cfg_.keypoint_threshold;
+    c.postproc = D2FE_POSTPROC_B;
+    c.precision = cfg_.fast_mode ? D2FE_PREC_F16X2 : D2FE_PREC_F32;
+    if (d2fe_create(&c, &h_) != D2FE_OK) { report("d2fe_create"); h_ = nullptr; return false; }
+    if (d2fe_load_superpoint(h_, &w) != D2FE_OK) { report("d2fe_load_superpoint"); return false; }
+    return true;
+  }
+
+  // superpoint_tensorrt.cpp:161-183: keypoints are APPENDED (not cleared) on success, all three outputs cleared on failure
+  bool infer(const ImageView& input, std::vector<Point2f>& keypoints, std::vector<float>& local_descriptors,
+             std::vector<float>& scores) {
+    const int cap = cfg_.max_keypoints;
+    kp_.resize(2 * (size_t)cap); sc_.resize(cap); de_.resize((size_t)cap * 256);
+    int n = 0;
+    if (!h_ || input.channels != 1 ||
+        d2fe_superpoint_extract(h_, input.data, input.cols, input.rows, (int)input.step, kp_.data(), sc_.data(), de_.data(), cap, &n) != D2FE_OK) {
+      keypoints.clear(); local_descriptors.clear(); scores.clear();
+      report("superpoint infer failed");
+      return false;
+    }
+    for (int i = 0; i < n; ++i) keypoints.emplace_back(kp_[2 * i], kp_[2 * i + 1]);
+    local_descriptors.insert(local_descriptors.end(), de_.begin(), de_.begin() + (size_t)n * d2fe_desc_dim(h_));
+    scores.assign(sc_.begin(), sc_.begin() + n);
+    return true;
+  }
+
+  d2fe_handle handle() const { return h_; }
+
+ private:
+  static void report(const char* what) { std::fprintf(stderr, "[d2fe] %s: %s\n", what, d2fe_last_error()); }
+  SuperPointConfig cfg_;
+  d2fe_handle h_ = nullptr;
+  std::vector<float> kp_, sc_, de_;
+};
+
+// MobileNetVLADONNX (mobilenetvlad_onnx.h:18-74) on an existing handle: colour conversion / resize / PCA as in inference()
+class MobileNetVLAD {
+ public:
+  MobileNetVLAD(d2fe_handle h, int width, int height) : h_(h), width_(width), height_(height) {}
+  bool load(const d2fe_netvlad_weights& w) { return d2fe_load_netvlad(h_, &w) == D2FE_OK; }
+  bool setPCA(const float* comp, const float* mean, int rows) { return d2fe_set_netvlad_pca(h_, comp, mean, rows) == D2FE_OK; }
+  std::vector<float> inference(const ImageView& input) {
+    std::vector<float> out((size_t)d2fe_netvlad_dim(h_));
+    const uint8_t* img = input.data;
+    int stride = (int)input.step;
+    if (input.channels != 1 || input.rows != height_ || input.cols != width_) {   // :51-59 cvtColor + resize
+      tmp_.resize((size_t)width_ * height_);
+      if (d2fe_prepare_gray(h_, input.data, input.channels, input.cols, input.rows, (int)input.step, width_, height_, tmp_.data()) != D2FE_OK) return {};
+      img = tmp_.data(); stride = width_;
+    }
+    if (d2fe_netvlad(h_, img, width_, height_, stride, out.data()) != D2FE_OK) return {};
+    return out;
+  }
+
+ private:
+  d2fe_handle h_;
+  int width_, height_;
+  std::vector<uint8_t> tmp_;
+};
+
+// feature_matcher.h:6-11.  `h` replaces the implicit global state of cv::BFMatcher; everything else as in the reference.
+inline std::vector<DMatch> matchKNN(d2fe_handle h, const DescView& desc_a, const DescView& desc_b, double knn_match_ratio = 0.8,
+                                    const std::vector<Point2f>& pts_a = std::vector<Point2f>(),
+                                    const std::vector<Point2f>& pts_b = std::vector<Point2f>(), double search_local_dist = -1) {
+  const int na = desc_a.rows, nb = desc_b.rows, cap = na > 0 ? na : 1;
+  std::vector<int32_t> q(cap), t(cap);
+  std::vector<float> d(cap);
+  int n = 0;
+  const bool gate = search_local_dist > 0 && (int)pts_a.size() == na && (int)pts_b.size() == nb && na > 0 && nb > 0;
+  std::vector<DMatch> out;
+  if (d2fe_match_knn(h, desc_a.data, na, desc_b.data, nb, desc_a.cols, knn_match_ratio, gate ? &pts_a[0].x : nullptr,
+                     gate ? &pts_b[0].x : nullptr, search_local_dist, q.data(), t.data(), d.data(), cap, &n) != D2FE_OK)
+    return out;
+  out.reserve(n);
+  for (int i = 0; i < n; ++i) out.emplace_back(q[i], t[i], d[i]);
+  return out;
+}
+
+// cv::BFMatcher(cv::NORM_L2, true).match(desc_a, desc_b, matches)
+inline std::vector<DMatch> matchCrossCheck(d2fe_handle h, const DescView& desc_a, const DescView& desc_b) {
+  const int na = desc_a.rows, cap = na > 0 ? na : 1;
+  std::vector<int32_t> q(cap), t(cap);
+  std::vector<float> d(cap);
+  int n = 0;
+  std::vector<DMatch> out;
+  if (d2fe_match_crosscheck(h, desc_a.data, na, desc_b.data, desc_b.rows, desc_a.cols, q.data(), t.data(), d.data(), cap, &n) != D2FE_OK) return out;
+  for (int i = 0; i < n; ++i) out.emplace_back(q[i], t[i], d[i]);
+  return out;
+}
+
+// getFeatureHalfImg (d2featuretracker.cpp:1051-1075): returns the kept descriptors; pts / tmp_to_idx are filled like the reference's
+inline std::vector<float> getFeatureHalfImg(const std::vector<Point2f>& pts, const DescView& desc, bool require_left, int width_undistort,
+                                            double undistort_fov, std::vector<Point2f>& pts_out, std::vector<int>& tmp_to_idx) {
+  std::vector<int32_t> map(pts.size() ? pts.size() : 1);
+  int n = 0;
+  pts_out.clear(); tmp_to_idx.clear();
+  std::vector<float> out;
+  if (pts.empty() || d2fe_half_image_filter(&pts[0].x, (int)pts.size(), require_left ? 1 : 0, width_undistort, undistort_fov, map.data(), &n) != D2FE_OK)
+    return out;
+  out.reserve((size_t)n * desc.cols);
+  for (int i = 0; i < n; ++i) {
+    tmp_to_idx.push_back(map[i]);
+    pts_out.push_back(pts[map[i]]);
+    out.insert(out.end(), desc.data + (size_t)map[i] * desc.cols, desc.data + (size_t)(map[i] + 1) * desc.cols);
+  }
+  return out;
+}
+
+// ---- LK tracker (opticaltrack_utils.h / .cpp) ---------------------------------------------------------------------------------
+enum TrackLRType { WHOLE_IMG_MATCH = 0, LEFT_RIGHT_IMG_MATCH = 1, RIGHT_LEFT_IMG_MATCH = 2 };
+constexpr int PYR_LEVEL = 2;          // opticaltrack_utils.h:10
+constexpr int LK_WIN_SIZE = 21;       // WIN_SIZE, opticaltrack_utils.cpp:25
+constexpr int LK_ITERS = 30;          // opticaltrack_utils.cpp:239
+
+struct LKImageInfo {                  // LKImageInfoGPU (opticaltrack_utils.h:16-23); pyr is owned by the caller of buildImagePyramid
+  std::vector<Point2f> lk_pts;
+  std::vector<int64_t> lk_ids;
+  std::vector<int> lk_local_index;
+  std::vector<int> lk_types;
+  d2fe_lk_frame pyr = nullptr;
+};
+
+inline d2fe_lk_frame buildImagePyramid(d2fe_handle h, const ImageView& img, int maxLevel = PYR_LEVEL) {
+  d2fe_lk_frame f = nullptr;
+  if (d2fe_lk_frame_create(h, img.data, img.cols, img.rows, (int)img.step, maxLevel, &f) != D2FE_OK) return nullptr;
+  return f;
+}
+
+template <typename T>
+inline void reduceVector(std::vector<T>& v, const std::vector<uint8_t>& status) {
+  size_t j = 0;
+  for (size_t i = 0; i < v.size() && i < status.size(); ++i)
+    if (status[i]) v[j++] = v[i];
+  v.resize(j);
+}
+
+// opticalflowTrackPyr (opticaltrack_utils.cpp:173-279); undistort_fov = params->undistort_fov
+inline LKImageInfo opticalflowTrackPyr(d2fe_handle h, const ImageView& cur_img, const LKImageInfo& prev_lk, TrackLRType type,
+                                       double undistort_fov) {
+  LKImageInfo ret;
+  ret.pyr = buildImagePyramid(h, cur_img, PYR_LEVEL);
+  std::vector<Point2f> prev_pts = prev_lk.lk_pts, cur_pts;
+  std::vector<int64_t> ids = prev_lk.lk_ids;
+  std::vector<int> types = prev_lk.lk_types, local = prev_lk.lk_local_index;
+  if (prev_pts.empty() || !ret.pyr || !prev_lk.pyr) return ret;
+  const float move_cols = (float)(cur_img.cols * 90.0 / undistort_fov);
+  if (type == WHOLE_IMG_MATCH) {
+    cur_pts = prev_pts;
+  } else {
+    std::vector<uint8_t> keep(prev_pts.size(), 0);
+    for (size_t i = 0; i < prev_pts.size(); ++i) {
+      Point2f pt = prev_pts[i];
+      if (type == LEFT_RIGHT_IMG_MATCH ? pt.x < cur_img.cols - move_cols : pt.x >= move_cols) {
+        pt.x += type == LEFT_RIGHT_IMG_MATCH ? move_cols : -move_cols;
+        keep[i] = 1;
+        cur_pts.push_back(pt);
+      }
+    }
+    reduceVector(prev_pts, keep); reduceVector(types, keep); reduceVector(local, keep); reduceVector(ids, keep);
+  }
+  if (cur_pts.empty()) return ret;
+  std::vector<uint8_t> status(cur_pts.size());
+  if (d2fe_lk_track(h, prev_lk.pyr, ret.pyr, &prev_pts[0].x, &cur_pts[0].x, (int)cur_pts.size(), (int)type, move_cols, LK_WIN_SIZE,
+                    LK_ITERS, &cur_pts[0].x, status.data()) != D2FE_OK)
+    return ret;
+  reduceVector(cur_pts, status); reduceVector(ids, status); reduceVector(types, status); reduceVector(local, status);
+  ret.lk_pts = cur_pts; ret.lk_ids = ids; ret.lk_types = types; ret.lk_local_index = local;
+  return ret;
+}
+
+// detectPoints (opticaltrack_utils.cpp:375-442); feature_min_dist = params->feature_min_dist
+inline void detectPoints(d2fe_handle h, d2fe_lk_frame frame, std::vector<Point2f>& n_pts, const std::vector<Point2f>& cur_pts,
+                         int require_pts, bool use_fast = false, int fast_rows = 3, int fast_cols = 4, double feature_min_dist = 20) {
+  const int lack_up_top_pts = require_pts - (int)cur_pts.size();
+  n_pts.clear();
+  if (!(lack_up_top_pts > require_pts / 4)) return;
+  const int num_to_detect = cur_pts.empty() ? lack_up_top_pts : lack_up_top_pts * 2;
+  std::vector<Point2f> n_pts_tmp((size_t)num_to_detect);
+  int n = 0;
+  const int rc = use_fast ? d2fe_detect_fast_by_region(h, frame, num_to_detect, fast_rows, fast_cols, 10, &n_pts_tmp[0].x, nullptr, num_to_detect, &n)
+                          : d2fe_good_features_to_track(h, frame, num_to_detect, 0.01, feature_min_dist, &n_pts_tmp[0].x, num_to_detect, &n);
+  if (rc != D2FE_OK) return;
+  n_pts_tmp.resize(n);
+  std::vector<Point2f> all_pts = cur_pts;
+  for (const Point2f& pt : n_pts_tmp) {
+    bool has_nearby = false;
+    for (const Point2f& pt_j : all_pts) {
+      const float dx = pt.x - pt_j.x, dy = pt.y - pt_j.y;
+      if (std::sqrt((double)dx * dx + (double)dy * dy) < feature_min_dist) { has_nearby = true; break; }
+    }
+    if (!has_nearby) { n_pts.push_back(pt); all_pts.push_back(pt); }
+    if ((int)n_pts.size() >= lack_up_top_pts) break;
+  }
+}
+
+}  // namespace D2FrontEnd
+
+#endif  // D2FE_HPP_

@@ -1,0 +1,82 @@
+// Drives the C++ mirror of the reference interfaces (include/d2fe.hpp) exactly the way D2SLAM's call sites do and dumps the
+// results for tests/test_cpp_mirror.py, which compares them with the oracle.  Usage: mirror_test <in.bin> <out.bin>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "d2fe.hpp"
+
+using namespace D2FrontEnd;
+
+template <typename T>
+static bool rd(FILE* f, T* p, size_t n) { return fread(p, sizeof(T), n, f) == n; }
+template <typename T>
+static void wr(FILE* f, const std::vector<T>& v) {
+  const int32_t n = (int32_t)v.size();
+  fwrite(&n, 4, 1, f);
+  if (n) fwrite(v.data(), sizeof(T), v.size(), f);
+}
+
+int main(int argc, char** argv) {
+  if (argc != 3) return 2;
+  FILE* fi = fopen(argv[1], "rb");
+  if (!fi) return 2;
+  int32_t H, W, maxkp;
+  if (!rd(fi, &H, 1) || !rd(fi, &W, 1) || !rd(fi, &maxkp, 1)) return 2;
+  std::vector<std::vector<float>> ws(12), bs(12);
+  d2fe_superpoint_weights w;
+  for (int l = 0; l < 12; ++l) {
+    int32_t dims[3];
+    if (!rd(fi, dims, 3)) return 2;
+    ws[l].resize((size_t)dims[0] * dims[1] * dims[2] * dims[2]); bs[l].resize(dims[0]);
+    if (!rd(fi, ws[l].data(), ws[l].size()) || !rd(fi, bs[l].data(), bs[l].size())) return 2;
+    w.layer[l].weight = ws[l].data(); w.layer[l].bias = bs[l].data();
+    w.layer[l].cout = dims[0]; w.layer[l].cin = dims[1]; w.layer[l].ksize = dims[2];
+  }
+  std::vector<uint8_t> img0((size_t)H * W), img1((size_t)H * W);
+  if (!rd(fi, img0.data(), img0.size()) || !rd(fi, img1.data(), img1.size())) return 2;
+  fclose(fi);
+
+  SuperPointConfig cfg;
+  cfg.max_keypoints = maxkp; cfg.input_width = W; cfg.input_height = H;
+  SuperPoint sp(cfg);
+  if (!sp.build(w)) return 3;
+  std::vector<Point2f> k0, k1;
+  std::vector<float> d0, d1, s0, s1;
+  if (!sp.infer(ImageView(img0.data(), H, W), k0, d0, s0)) return 4;
+  if (!sp.infer(ImageView(img1.data(), H, W), k1, d1, s1)) return 4;
+  // failure behaviour: a wrong size empties the outputs and returns false (superpoint_tensorrt.cpp:164-170)
+  std::vector<Point2f> kbad(3); std::vector<float> dbad(5), sbad(2);
+  const bool bad = sp.infer(ImageView(img0.data(), H + 8, W), kbad, dbad, sbad);
+  if (bad || !kbad.empty() || !dbad.empty() || !sbad.empty()) return 5;
+
+  const DescView A(d0.data(), (int)k0.size(), 256), B(d1.data(), (int)k1.size(), 256);
+  const std::vector<DMatch> m = matchKNN(sp.handle(), A, B, 0.8, k0, k1, 0.2 * W);
+  const std::vector<DMatch> mc = matchCrossCheck(sp.handle(), A, B);
+  std::vector<Point2f> half_pts; std::vector<int> half_idx;
+  const std::vector<float> half_desc = getFeatureHalfImg(k0, A, true, W, 200.0, half_pts, half_idx);
+
+  // LK tracker: detect on frame 0 (both detectors), track into frame 1
+  LKImageInfo prev;
+  prev.pyr = buildImagePyramid(sp.handle(), ImageView(img0.data(), H, W));
+  std::vector<Point2f> fast_pts, gftt_pts;
+  detectPoints(sp.handle(), prev.pyr, fast_pts, std::vector<Point2f>(), 150, true, 3, 4, 20.0);
+  detectPoints(sp.handle(), prev.pyr, gftt_pts, std::vector<Point2f>(), 150, false, 3, 4, 20.0);
+  prev.lk_pts = fast_pts;
+  for (size_t i = 0; i < fast_pts.size(); ++i) { prev.lk_ids.push_back(1000 + (int64_t)i); prev.lk_local_index.push_back((int)i); prev.lk_types.push_back(0); }
+  LKImageInfo cur = opticalflowTrackPyr(sp.handle(), ImageView(img1.data(), H, W), prev, WHOLE_IMG_MATCH, 200.0);
+
+  FILE* fo = fopen(argv[2], "wb");
+  if (!fo) return 2;
+  auto flat = [](const std::vector<Point2f>& p) { std::vector<float> o; for (auto& q : p) { o.push_back(q.x); o.push_back(q.y); } return o; };
+  auto mflat = [](const std::vector<DMatch>& mm) { std::vector<float> o; for (auto& q : mm) { o.push_back((float)q.queryIdx); o.push_back((float)q.trainIdx); o.push_back(q.distance); } return o; };
+  wr(fo, flat(k0)); wr(fo, s0); wr(fo, d0); wr(fo, flat(k1)); wr(fo, s1); wr(fo, d1);
+  wr(fo, mflat(m)); wr(fo, mflat(mc));
+  wr(fo, half_idx); wr(fo, half_desc);
+  wr(fo, flat(fast_pts)); wr(fo, flat(gftt_pts)); wr(fo, flat(cur.lk_pts)); wr(fo, cur.lk_ids);
+  fclose(fo);
+  d2fe_lk_frame_destroy(prev.pyr);
+  d2fe_lk_frame_destroy(cur.pyr);
+  return 0;
+}
