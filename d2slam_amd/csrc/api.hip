@@ -300,43 +300,47 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   HIP_TRY(hipSetDevice(cfg->device_id));
   d2fe_context* h = new d2fe_context();
   h->cfg = *cfg;
+  const int rc_alloc = [&]() -> int {
   { const char* e = getenv("D2FE_FUSE1A"); if (e) h->fuse1a = atoi(e) != 0; }
-  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  const size_t H = cfg->max_height, W = cfg->max_width;
-  const int B = cfg->max_batch;
-  int rc = 0;
-  rc |= alloc_f(h->a1a, H * W * 64, B);
-  rc |= alloc_f(h->a1b, H * W * 16, B);
-  rc |= alloc_f(h->a2a, H * W * 16, B);
-  rc |= alloc_f(h->a2b, H * W * 4, B);
-  rc |= alloc_f(h->a3a, H * W * 8, B);
-  rc |= alloc_f(h->a3b, H * W * 2, B);
-  rc |= alloc_f(h->a4a, H * W * 2, B);
-  rc |= alloc_f(h->a4b, H * W * 2, B);
-  rc |= alloc_f(h->aPD, H * W * 8, B);
-  rc |= alloc_f(h->logits, (H / 8) * (W / 8) * 65, B);
-  rc |= alloc_f(h->draw, H * W * 4, B);
-  rc |= alloc_f(h->semi, H * W, B);
-  if (rc) { d2fe_destroy(h); return D2FE_ERR_HIP; }
-  h->cand_cap = (long)(H * W);
-  HIP_TRY(hipMalloc(&h->cand, sizeof(unsigned long long) * h->cand_cap * B));
-  HIP_TRY(hipMalloc(&h->cand_count, sizeof(int) * B));
-  HIP_TRY(hipMalloc(&h->zeros, 1024));
-  HIP_TRY(hipMemset(h->zeros, 0, 1024));
-  if (cfg->postproc == D2FE_POSTPROC_A) {
-    HIP_TRY(hipMalloc(&h->aconf, sizeof(float) * H * W * B));
-    HIP_TRY(hipMalloc(&h->clist, sizeof(int) * H * W * B));
-    h->a_scap = h->cfg.max_keypoints < 1024 ? h->cfg.max_keypoints : 1024;   // select keeps at most min(max_keypoints, 1024)
-    HIP_TRY(hipMalloc(&h->a_samp, sizeof(float) * 256 * (size_t)h->a_scap * B));
-    HIP_TRY(hipMalloc(&h->a_cn, sizeof(float) * 256 * B));
-  }
-  h->s_cap = 1024;
-  HIP_TRY(hipMalloc(&h->s_img, H * W * B));
-  HIP_TRY(hipMalloc(&h->s_kps, sizeof(float) * 2 * h->s_cap * B));
-  HIP_TRY(hipMalloc(&h->s_scores, sizeof(float) * h->s_cap * B));
-  HIP_TRY(hipMalloc(&h->s_desc, sizeof(float) * 256 * h->s_cap * B));
-  HIP_TRY(hipMalloc(&h->s_idx, sizeof(int32_t) * h->s_cap * B));
-  HIP_TRY(hipMalloc(&h->s_n, sizeof(int32_t) * B));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const size_t H = cfg->max_height, W = cfg->max_width;
+    const int B = cfg->max_batch;
+    int rc = 0;
+    if (!h->fuse1a) rc |= alloc_f(h->a1a, H * W * 64, B);   // the fused path never materialises conv1a (78.6 MB per image); debug reads allocate it on demand
+    rc |= alloc_f(h->a1b, H * W * 16, B);
+    rc |= alloc_f(h->a2a, H * W * 16, B);
+    rc |= alloc_f(h->a2b, H * W * 4, B);
+    rc |= alloc_f(h->a3a, H * W * 8, B);
+    rc |= alloc_f(h->a3b, H * W * 2, B);
+    rc |= alloc_f(h->a4a, H * W * 2, B);
+    rc |= alloc_f(h->a4b, H * W * 2, B);
+    rc |= alloc_f(h->aPD, H * W * 8, B);
+    rc |= alloc_f(h->logits, (H / 8) * (W / 8) * 65, B);
+    rc |= alloc_f(h->draw, H * W * 4, B);
+    rc |= alloc_f(h->semi, H * W, B);
+    if (rc) return D2FE_ERR_HIP;
+    h->cand_cap = (long)(H * W);
+    HIP_TRY(hipMalloc(&h->cand, sizeof(unsigned long long) * h->cand_cap * B));
+    HIP_TRY(hipMalloc(&h->cand_count, sizeof(int) * B));
+    HIP_TRY(hipMalloc(&h->zeros, 1024));
+    HIP_TRY(hipMemset(h->zeros, 0, 1024));
+    if (cfg->postproc == D2FE_POSTPROC_A) {
+      HIP_TRY(hipMalloc(&h->aconf, sizeof(float) * H * W * B));
+      HIP_TRY(hipMalloc(&h->clist, sizeof(int) * H * W * B));
+      h->a_scap = h->cfg.max_keypoints < 1024 ? h->cfg.max_keypoints : 1024;   // select keeps at most min(max_keypoints, 1024)
+      HIP_TRY(hipMalloc(&h->a_samp, sizeof(float) * 256 * (size_t)h->a_scap * B));
+      HIP_TRY(hipMalloc(&h->a_cn, sizeof(float) * 256 * B));
+    }
+    h->s_cap = 1024;
+    HIP_TRY(hipMalloc(&h->s_img, H * W * B));
+    HIP_TRY(hipMalloc(&h->s_kps, sizeof(float) * 2 * h->s_cap * B));
+    HIP_TRY(hipMalloc(&h->s_scores, sizeof(float) * h->s_cap * B));
+    HIP_TRY(hipMalloc(&h->s_desc, sizeof(float) * 256 * h->s_cap * B));
+    HIP_TRY(hipMalloc(&h->s_idx, sizeof(int32_t) * h->s_cap * B));
+    HIP_TRY(hipMalloc(&h->s_n, sizeof(int32_t) * B));
+    return D2FE_OK;
+  }();
+  if (rc_alloc != D2FE_OK) { d2fe_destroy(h); return rc_alloc; }   // everything allocated so far is released
   *out = h;
   return D2FE_OK;
 }
@@ -782,6 +786,7 @@ int d2fe_gen_pinhole_map_device(d2fe_handle h, const d2fe_mei_camera* cam, const
   return gen_map(h, cam, q_wxyz, 1, width, height, f, d_mapx, d_mapy, true, stream);
 }
 
+void d2fe_db_destroy(d2fe_db_handle db);
 int d2fe_db_create(d2fe_handle h, int dim, int capacity, d2fe_db_handle* out) {
   if (!h || !out) return fail(D2FE_ERR_INVALID, "null argument");
   *out = nullptr;
@@ -789,11 +794,15 @@ int d2fe_db_create(d2fe_handle h, int dim, int capacity, d2fe_db_handle* out) {
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   d2fe_db* db = new d2fe_db();
   db->h = h; db->dim = dim; db->cap = capacity;
-  HIP_TRY(hipMalloc(&db->vecs, sizeof(float) * (size_t)dim * capacity));
-  HIP_TRY(hipMalloc(&db->sims, sizeof(float) * (size_t)DB_MAXQ * capacity));
-  HIP_TRY(hipMalloc(&db->q, sizeof(float) * (size_t)DB_MAXQ * dim));
-  HIP_TRY(hipMalloc(&db->osims, sizeof(float) * DB_MAXQ * DB_MAXK));
-  HIP_TRY(hipMalloc(&db->olabels, sizeof(int32_t) * DB_MAXQ * DB_MAXK));
+  const int rc = [&]() -> int {
+    HIP_TRY(hipMalloc(&db->vecs, sizeof(float) * (size_t)dim * capacity));
+    HIP_TRY(hipMalloc(&db->sims, sizeof(float) * (size_t)DB_MAXQ * capacity));
+    HIP_TRY(hipMalloc(&db->q, sizeof(float) * (size_t)DB_MAXQ * dim));
+    HIP_TRY(hipMalloc(&db->osims, sizeof(float) * DB_MAXQ * DB_MAXK));
+    HIP_TRY(hipMalloc(&db->olabels, sizeof(int32_t) * DB_MAXQ * DB_MAXK));
+    return D2FE_OK;
+  }();
+  if (rc != D2FE_OK) { d2fe_db_destroy(db); return rc; }
   *out = db;
   return D2FE_OK;
 }
@@ -1028,6 +1037,8 @@ long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_byte
       {"logits", &h->logits, (H / 8) * (W / 8) * 65}, {"desc_raw", &h->draw, H * W * 4}, {"semi", &h->semi, H * W}};
   if (!strcmp(name, "conv1a") && h->fuse1a) {
     // fused mode never materialises conv1a: evaluate it on demand from the last input frame(s)
+    if (!h->a1a.p && alloc_f(h->a1a, (size_t)h->cfg.max_height * h->cfg.max_width * 64, h->cfg.max_batch) != 0)
+      return fail(D2FE_ERR_HIP, "hipMalloc conv1a debug buffer");
     if (launch_conv1a(h->last_gray, h->last_stride, (long)h->last_istride, (int)H, (int)W, (int)n, h->w1a, h->b1a, h->a1a.p, h->stream) != hipSuccess)
       return fail(D2FE_ERR_HIP, "conv1a debug launch");
   }
