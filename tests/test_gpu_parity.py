@@ -444,3 +444,37 @@ def test_other_configs_and_limits(api, orc, sp_weights, H, W, maxkp, thr):
     if len(kps):
         assert np.abs(desc - rd).max() <= 1e-6
     fe.close()
+
+
+def test_matcher_is_reentrant(api, orc):
+    """The reference calls matchKNN from three threads (D2FeatureTracker, LoopDetector, remote tracking).
+    Four threads hammer d2fe_match_knn / d2fe_match_crosscheck on one handle (ctypes releases the GIL): every result must equal
+    the oracle's, i.e. the (stream, scratch) slots of concurrent calls never overlap."""
+    import threading
+    fe = api.FrontEnd(api.SuperPointConfig(input_width=64, input_height=64, max_batch=1))
+    cases = []
+    for t in range(4):
+        a, b, pa, pb = synth_descriptor_pair(150 + 10 * t, 120 + 15 * t, 256, seed=40 + t)
+        cases.append((a, b, pa, pb, orc.match_knn(a, b, 0.8, pa, pb, 50.0), orc.match_crosscheck(a, b)))
+    errors = []
+
+    def work(t):
+        a, b, pa, pb, (rq, rt, rd), (cq, ct, cd) = cases[t]
+        try:
+            for _ in range(40):
+                q, tt, d = fe.match_knn(a, b, 0.8, pa, pb, 50.0)
+                if not (np.array_equal(q, rq) and np.array_equal(tt, rt) and np.array_equal(d, rd)):
+                    errors.append("knn mismatch in thread %d" % t); return
+                q, tt, d = fe.match_crosscheck(a, b)
+                if not (np.array_equal(q, cq) and np.array_equal(tt, ct) and np.array_equal(d, cd)):
+                    errors.append("crosscheck mismatch in thread %d" % t); return
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    fe.close()
