@@ -38,7 +38,7 @@ class _Config(C.Structure):
                 ("max_height", C.c_int32), ("max_batch", C.c_int32), ("max_keypoints", C.c_int32),
                 ("remove_borders", C.c_int32), ("keypoint_threshold", C.c_float), ("postproc", C.c_int32),
                 ("nms_dist", C.c_int32), ("precision", C.c_int32), ("keep_score_map", C.c_int32),
-                ("reserved", C.c_int32 * 7)]
+                ("dense_descriptors", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class _ConvParams(C.Structure):
@@ -221,6 +221,7 @@ class SuperPointConfig:
     nms_dist: int = 10
     precision: int = PREC_F32
     keep_score_map: bool = False   # debug: also write the dense score map
+    dense_descriptors: bool = False  # debug: dense descriptor map instead of the sparse descriptor head (variant B)
 
 
 class FrontEnd:
@@ -241,6 +242,7 @@ class FrontEnd:
         c.nms_dist = cfg.nms_dist
         c.precision = cfg.precision
         c.keep_score_map = int(cfg.keep_score_map)
+        c.dense_descriptors = int(cfg.dense_descriptors)
         self.cfg = cfg
         self._h = C.c_void_p()
         _check(lib.d2fe_create(C.byref(c), C.byref(self._h)))

@@ -39,7 +39,7 @@ struct Layer {
   int cout = 0, cout_pad = 0, cin = 0, ks = 0;
 };
 
-enum { L_1B = 0, L_2A, L_2B, L_3A, L_3B, L_4A, L_4B, L_PADA, L_PB, L_DB, L_COUNT };
+enum { L_1B = 0, L_2A, L_2B, L_3A, L_3B, L_4A, L_4B, L_PADA, L_PB, L_DB, L_PA, L_DA32, L_DB32, L_COUNT };   // the last three: sparse descriptor head
 
 struct Tensor {
   float* p = nullptr;
@@ -70,6 +70,9 @@ struct d2fe_context {
   const uint8_t* last_gray = nullptr; int last_stride = 0; size_t last_istride = 0;
   float* aconf = nullptr; int* clist = nullptr;     // variant A scratch
   float* zeros = nullptr;      // 1 KiB of zeros (ConvArgs::zeros)
+  // sparse descriptor head (variant B unless cfg.dense_descriptors): cell flags, cell -> slot map, slot -> cell list, counts, descriptors
+  bool sparse_desc = false; int sp_slots = 0;
+  uint8_t* sp_flags = nullptr; int32_t* sp_slotmap = nullptr; int32_t* sp_cells = nullptr; int32_t* sp_count = nullptr; float* sp_desc = nullptr;
   void* lk_scratch = nullptr; size_t lk_scratch_bytes = 0;   // grow-only scratch of the LK / detector entry points (lk.hip)
   float* a_samp = nullptr; float* a_cn = nullptr; int a_scap = 0;   // variant A sampling: [batch][a_scap][256] samples, [batch][256] channel norms
   float* pca_comp_t = nullptr; float* pca_mean = nullptr; int pca_dims = 0;
@@ -135,7 +138,7 @@ int upload(const void* src, size_t bytes, void** dst) {
 }
 
 // pack one conv (or a channel-concatenation of convs sharing the input) into the kernel's fragment order
-int pack_layer(d2fe_context* h, Layer& L, const std::vector<const d2fe_conv_params*>& parts, int cout_pad) {
+int pack_layer(d2fe_context* h, Layer& L, const std::vector<const d2fe_conv_params*>& parts, int cout_pad, bool force_f32 = false) {
   const int cin = parts[0]->cin, ks = parts[0]->ksize;
   int cout = 0;
   for (auto* p : parts) cout += p->cout;
@@ -153,7 +156,7 @@ int pack_layer(d2fe_context* h, Layer& L, const std::vector<const d2fe_conv_para
   if (L.wpack) { hipFree(L.wpack); L.wpack = nullptr; }
   if (L.bias) { hipFree(L.bias); L.bias = nullptr; }
   int rc;
-  if (h->cfg.precision == D2FE_PREC_F32) {
+  if (h->cfg.precision == D2FE_PREC_F32 || force_f32) {
     std::vector<float> pk(packed_weight_floats_f32(cout_pad, cin, ks));
     pack_weights_f32(w.data(), cout, cin, ks, cout_pad, pk.data());
     rc = upload(pk.data(), pk.size() * sizeof(float), &L.wpack);
@@ -219,9 +222,16 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
   { ProfScope ps(h, D2FE_PROF_CONV3B, s); HIP_TRY(conv(CONV_128_T4x32, h->L[L_3B], h->a3a.p, 128, 0, (long)H4 * W4 * 128, h->a3b.p, 128, (long)Hc * Wc * 128, H4, W4, true, true)); }
   { ProfScope ps(h, D2FE_PROF_CONV4A, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_4A], h->a3b.p, 128, 0, (long)Hc * Wc * 128, h->a4a.p, 128, (long)Hc * Wc * 128, Hc, Wc, false, true)); }
   { ProfScope ps(h, D2FE_PROF_CONV4B, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_4B], h->a4a.p, 128, 0, (long)Hc * Wc * 128, h->a4b.p, 128, (long)Hc * Wc * 128, Hc, Wc, false, true)); }
-  { ProfScope ps(h, D2FE_PROF_CONVPADA, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_PADA], h->a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 512, (long)Hc * Wc * 512, Hc, Wc, false, true)); }
-  { ProfScope ps(h, D2FE_PROF_CONVPB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_PB], h->aPD.p, 512, 0, (long)Hc * Wc * 512, h->logits.p, 65, (long)Hc * Wc * 65, Hc, Wc, false, false)); }
-  { ProfScope ps(h, D2FE_PROF_CONVDB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_DB], h->aPD.p, 512, 256, (long)Hc * Wc * 512, h->draw.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, false)); }
+  const bool sparse = h->sparse_desc;
+  if (sparse) {
+    // detector head only (convPa 128->256, convPb); the descriptor head is evaluated after keypoint selection, at the needed cells
+    { ProfScope ps(h, D2FE_PROF_CONVPADA, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_PA], h->a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, true)); }
+    { ProfScope ps(h, D2FE_PROF_CONVPB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_PB], h->aPD.p, 256, 0, (long)Hc * Wc * 256, h->logits.p, 65, (long)Hc * Wc * 65, Hc, Wc, false, false)); }
+  } else {
+    { ProfScope ps(h, D2FE_PROF_CONVPADA, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_PADA], h->a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 512, (long)Hc * Wc * 512, Hc, Wc, false, true)); }
+    { ProfScope ps(h, D2FE_PROF_CONVPB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_PB], h->aPD.p, 512, 0, (long)Hc * Wc * 512, h->logits.p, 65, (long)Hc * Wc * 65, Hc, Wc, false, false)); }
+    { ProfScope ps(h, D2FE_PROF_CONVDB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_DB], h->aPD.p, 512, 256, (long)Hc * Wc * 512, h->draw.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, false)); }
+  }
   const bool varA = h->cfg.postproc == D2FE_POSTPROC_A;
   { ProfScope ps(h, D2FE_PROF_SOFTMAX, s);
   HIP_TRY(launch_softmax_cand(h->logits.p, 65, Hc, Wc, n, h->cfg.keypoint_threshold, h->cfg.remove_borders,
@@ -243,8 +253,17 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     if (varA)
       HIP_TRY(launch_sample_a(h->draw.p, 256, 0, Hc, Wc, W, H, n, d_kps, d_n, cap, h->pca_dims ? h->pca_comp_t : nullptr,
                               h->pca_mean, h->pca_dims, h->a_samp, h->a_scap, h->a_cn, d_desc, s));
-    else
-      HIP_TRY(launch_sample_b(h->draw.p, 256, 0, Hc, Wc, n, d_kps, d_n, cap, d_desc, s)); }
+    else if (!sparse)
+      HIP_TRY(launch_sample_b(h->draw.p, 256, 0, Hc, Wc, n, d_kps, d_n, cap, nullptr, 0, d_desc, s));
+  }
+  if (sparse) {
+    { ProfScope ps(h, D2FE_PROF_CONVDB, s);
+      HIP_TRY(launch_desc_head_sparse(d_kps, d_n, cap, Hc, Wc, n, h->a4b.p, 128, (long)Hc * Wc * 128, h->L[L_DA32].wpack, h->L[L_DA32].bias,
+                                      h->L[L_DB32].wpack, h->L[L_DB32].bias, h->sp_flags, h->sp_slotmap, h->sp_cells, h->sp_count,
+                                      h->sp_slots, h->sp_desc, s)); }
+    ProfScope ps(h, D2FE_PROF_SAMPLE, s);
+    HIP_TRY(launch_sample_b(h->sp_desc, 256, 0, Hc, Wc, n, d_kps, d_n, cap, h->sp_slotmap, h->sp_slots, d_desc, s));
+  }
   h->last_w = W; h->last_h = H; h->last_n = n;
   h->last_gray = d_gray; h->last_stride = stride; h->last_istride = image_stride;
   return D2FE_OK;
@@ -281,6 +300,7 @@ void d2fe_default_config(d2fe_config* c) {
   c->postproc = D2FE_POSTPROC_B;
   c->nms_dist = 10;
   c->precision = D2FE_PREC_F32;
+  c->dense_descriptors = 0;
 }
 
 int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
@@ -322,6 +342,16 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     h->cand_cap = (long)(H * W);
     HIP_TRY(hipMalloc(&h->cand, sizeof(unsigned long long) * h->cand_cap * B));
     HIP_TRY(hipMalloc(&h->cand_count, sizeof(int) * B));
+    h->sparse_desc = cfg->postproc == D2FE_POSTPROC_B && !cfg->dense_descriptors;
+    if (h->sparse_desc) {
+      const size_t ncell = (H / 8) * (W / 8);
+      h->sp_slots = 4 * cfg->max_keypoints;            // <= 4 corner cells per keypoint
+      HIP_TRY(hipMalloc(&h->sp_flags, ncell * B));
+      HIP_TRY(hipMalloc(&h->sp_slotmap, sizeof(int32_t) * ncell * B));
+      HIP_TRY(hipMalloc(&h->sp_cells, sizeof(int32_t) * (size_t)h->sp_slots * B));
+      HIP_TRY(hipMalloc(&h->sp_count, sizeof(int32_t) * B));
+      HIP_TRY(hipMalloc(&h->sp_desc, sizeof(float) * 256 * (size_t)h->sp_slots * B));
+    }
     HIP_TRY(hipMalloc(&h->zeros, 1024));
     HIP_TRY(hipMemset(h->zeros, 0, 1024));
     if (cfg->postproc == D2FE_POSTPROC_A) {
@@ -357,7 +387,7 @@ void d2fe_destroy(d2fe_handle h) {
     if (t->p) hipFree(t->p);
   for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
   for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->cand_count, (void*)h->s_img, (void*)h->s_kps,
-                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, h->m_buf, (void*)h->m_cand4, (void*)h->aconf, (void*)h->clist, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros,
+                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, h->m_buf, (void*)h->m_cand4, (void*)h->aconf, (void*)h->clist, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc,
                   (void*)h->pca_comp_t, (void*)h->pca_mean})
     if (p) hipFree(p);
   nv_free(h);
@@ -404,6 +434,11 @@ int d2fe_load_superpoint(d2fe_handle h, const d2fe_superpoint_weights* w) {
   rc = rc ? rc : pack_layer(h, h->L[L_PADA], {&l[8], &l[10]}, 512);  // convPa | convDa share their input
   rc = rc ? rc : pack_layer(h, h->L[L_PB], {&l[9]}, 128);
   rc = rc ? rc : pack_layer(h, h->L[L_DB], {&l[11]}, 256);
+  if (h->sparse_desc) {   // detector head alone in the mode's precision; descriptor head always as exact fp32 fragments
+    rc = rc ? rc : pack_layer(h, h->L[L_PA], {&l[8]}, 256);
+    rc = rc ? rc : pack_layer(h, h->L[L_DA32], {&l[10]}, 256, true);
+    rc = rc ? rc : pack_layer(h, h->L[L_DB32], {&l[11]}, 256, true);
+  }
   if (rc) return rc;
   h->sp_loaded = true;
   return D2FE_OK;
@@ -1043,6 +1078,8 @@ long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_byte
       return fail(D2FE_ERR_HIP, "conv1a debug launch");
   }
   if (!strcmp(name, "semi") && !h->cfg.keep_score_map) return fail(D2FE_ERR_NOT_READY, "score map not kept (set keep_score_map)");
+  if (h->sparse_desc && (!strcmp(name, "desc_raw") || !strcmp(name, "convPaDa")))
+    return fail(D2FE_ERR_NOT_READY, "the dense descriptor map does not exist with the sparse descriptor head (set dense_descriptors)");
   for (auto& e : tab)
     if (!strcmp(e.nm, name)) {
       const size_t bytes = e.per * n * sizeof(float);

@@ -6,11 +6,14 @@
 // (softmax / dustbin drop / 8x8 depth-to-space, d2frontend/superpoint.ipynb:355-364).
 // All kernels here are HBM/latency bound integer+fp32 work; the arithmetic follows the oracle
 // (oracle/d2fe_oracle.c) operation by operation so that scores and indices compare exactly.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace d2fe {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // fma-only expf: SAME operation sequence as orc_expf (oracle/d2fe_oracle.c) -> bitwise-equal results.
 __device__ __forceinline__ float d2fe_expf(float x) {
@@ -271,18 +274,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 __device__ __forceinline__ int clipi(int v, int mx) { return v < 0 ? 0 : (v < mx - 1 ? v : mx - 1); }
 
-__global__ __launch_bounds__(256) void sample_b_kernel(const float* __restrict__ desc_raw, int dstride, int dcoff, int Hc,
-                                                       int Wc, const float* __restrict__ kps_xy,
-                                                       const int32_t* __restrict__ n_kp, int cap,
-                                                       float* __restrict__ desc_out) {
-  const int img = blockIdx.y;
-  const int lane = threadIdx.x & 63;
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (k >= n_kp[img] || k >= cap) return;
-  const size_t o = (size_t)img * cap + k;
-  const float x = kps_xy[2 * o], y = kps_xy[2 * o + 1];
+// The four corner cells and weights of one keypoint -- literal transcription of the reference's mixed float/double arithmetic
+// (normalize_keypoints + grid_sample, superpoint_tensorrt.cpp:255-310; see orc_sample_b).  Shared by the sampler and by the
+// kernel that marks which cells of the descriptor map are needed at all.
+struct SampleBCorners { int ix[4], iy[4]; float w[4]; };     // order: nw, ne, sw, se
+__device__ __forceinline__ SampleBCorners sample_b_corners(float x, float y, int Hc, int Wc) {
   const int s = 8;
-  // literal transcription of the reference's mixed float/double arithmetic (see orc_sample_b)
   float k0 = (float)((double)(x - (float)(s / 2)) + 0.5);
   float k1 = (float)((double)(y - (float)(s / 2)) + 0.5);
   k0 = (float)((double)k0 / ((double)(Wc * s - s / 2) - 0.5));
@@ -291,34 +288,51 @@ __global__ __launch_bounds__(256) void sample_b_kernel(const float* __restrict__
   k1 = k1 * 2.0f - 1.0f;
   const float ix = ((k0 + 1.0f) / 2.0f) * (float)(Wc - 1);
   const float iy = ((k1 + 1.0f) / 2.0f) * (float)(Hc - 1);
-  const int ix_nw = clipi((int)__builtin_floorf(ix), Wc), iy_nw = clipi((int)__builtin_floorf(iy), Hc);
-  const int ix_ne = clipi(ix_nw + 1, Wc), iy_ne = clipi(iy_nw, Hc);
-  const int ix_sw = clipi(ix_nw, Wc), iy_sw = clipi(iy_nw + 1, Hc);
-  const int ix_se = clipi(ix_nw + 1, Wc), iy_se = clipi(iy_nw + 1, Hc);
-  const float nw = ((float)ix_se - ix) * ((float)iy_se - iy);
-  const float ne = (ix - (float)ix_sw) * ((float)iy_sw - iy);
-  const float sw = ((float)ix_ne - ix) * (iy - (float)iy_ne);
-  const float se = (ix - (float)ix_nw) * (iy - (float)iy_nw);
-  const float* base = desc_raw + (size_t)img * Hc * Wc * dstride + dcoff + lane * 4;
-  const f32x4 vnw = *reinterpret_cast<const f32x4*>(base + ((size_t)iy_nw * Wc + ix_nw) * dstride);
-  const f32x4 vne = *reinterpret_cast<const f32x4*>(base + ((size_t)iy_ne * Wc + ix_ne) * dstride);
-  const f32x4 vsw = *reinterpret_cast<const f32x4*>(base + ((size_t)iy_sw * Wc + ix_sw) * dstride);
-  const f32x4 vse = *reinterpret_cast<const f32x4*>(base + ((size_t)iy_se * Wc + ix_se) * dstride);
-  auto sq = [](const f32x4& v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; };
-  const float n_nw = __builtin_sqrtf(wave_sum(sq(vnw)));
-  const float n_ne = __builtin_sqrtf(wave_sum(sq(vne)));
-  const float n_sw = __builtin_sqrtf(wave_sum(sq(vsw)));
-  const float n_se = __builtin_sqrtf(wave_sum(sq(vse)));
+  SampleBCorners c;
+  c.ix[0] = clipi((int)__builtin_floorf(ix), Wc); c.iy[0] = clipi((int)__builtin_floorf(iy), Hc);
+  c.ix[1] = clipi(c.ix[0] + 1, Wc); c.iy[1] = clipi(c.iy[0], Hc);
+  c.ix[2] = clipi(c.ix[0], Wc);     c.iy[2] = clipi(c.iy[0] + 1, Hc);
+  c.ix[3] = clipi(c.ix[0] + 1, Wc); c.iy[3] = clipi(c.iy[0] + 1, Hc);
+  c.w[0] = ((float)c.ix[3] - ix) * ((float)c.iy[3] - iy);
+  c.w[1] = (ix - (float)c.ix[2]) * ((float)c.iy[2] - iy);
+  c.w[2] = ((float)c.ix[1] - ix) * (iy - (float)c.iy[1]);
+  c.w[3] = (ix - (float)c.ix[0]) * (iy - (float)c.iy[0]);
+  return c;
+}
+
+// slotmap == nullptr: desc_raw is the dense map [img][Hc*Wc][dstride] (+dcoff).  slotmap != nullptr: desc_raw is the SPARSE
+// descriptor store [img][max_slots][256] and slotmap[img][cell] the slot of a cell (desc_head_sparse_kernel).
+__global__ __launch_bounds__(256) void sample_b_kernel(const float* __restrict__ desc_raw, int dstride, int dcoff, int Hc,
+                                                       int Wc, const float* __restrict__ kps_xy,
+                                                       const int32_t* __restrict__ n_kp, int cap,
+                                                       const int32_t* __restrict__ slotmap, int max_slots,
+                                                       float* __restrict__ desc_out) {
+  const int img = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= n_kp[img] || k >= cap) return;
+  const size_t o = (size_t)img * cap + k;
+  const SampleBCorners c = sample_b_corners(kps_xy[2 * o], kps_xy[2 * o + 1], Hc, Wc);
+  f32x4 v[4];
+  float nrm[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cell = c.iy[q] * Wc + c.ix[q];
+    const float* row = slotmap ? desc_raw + ((size_t)img * max_slots + slotmap[(size_t)img * Hc * Wc + cell]) * 256
+                               : desc_raw + ((size_t)img * Hc * Wc + cell) * dstride + dcoff;
+    v[q] = *reinterpret_cast<const f32x4*>(row + lane * 4);
+    nrm[q] = __builtin_sqrtf(wave_sum(v[q][0] * v[q][0] + v[q][1] * v[q][1] + v[q][2] * v[q][2] + v[q][3] * v[q][3]));
+  }
   f32x4 d;
   float ss = 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    float v = (vnw[j] / n_nw) * nw;
-    v = v + (vne[j] / n_ne) * ne;
-    v = v + (vsw[j] / n_sw) * sw;
-    v = v + (vse[j] / n_se) * se;
-    d[j] = v;
-    ss += v * v;
+    float t = (v[0][j] / nrm[0]) * c.w[0];
+    t = t + (v[1][j] / nrm[1]) * c.w[1];
+    t = t + (v[2][j] / nrm[2]) * c.w[2];
+    t = t + (v[3][j] / nrm[3]) * c.w[3];
+    d[j] = t;
+    ss += t * t;
   }
   ss = wave_sum(ss);
   const float ninv = (float)(1.0 / (double)__builtin_sqrtf(ss));
@@ -327,10 +341,191 @@ __global__ __launch_bounds__(256) void sample_b_kernel(const float* __restrict__
   *reinterpret_cast<f32x4*>(desc_out + o * 256 + lane * 4) = d;
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Sparse descriptor head.  SuperPoint's descriptor branch (convDa 3x3 128->256 + ReLU, convDb 1x1 256->256: 3.46 of the
+// 52.1 GFLOP per 640x480 image) is only ever READ at the <= 4 corner cells of each selected keypoint
+// (superpoint_tensorrt.cpp:272-310), i.e. at <= 800 of 4800 cells for 200 keypoints.  The reference computes it densely because
+// its network is one TensorRT graph; here the detector head runs first, the needed cells are marked and compacted, and the
+// descriptor head is evaluated for those cells only -- same fmaf chains per output (bias, (ky,kx,ci) order), so the result is
+// bit-identical to the dense map at every cell that is read.
+//   desc_mark_kernel    : keypoints -> flags[img][cell]
+//   desc_compact_kernel : flags -> slotmap[img][cell], cell list, count  (cells in raster order; one block per image)
+//   desc_head_sparse_kernel : 32 cells x 256 channels per workgroup: convDa (A tile of one tap staged in LDS per step),
+//                         ReLU, tile kept in LDS, convDb, raw descriptors to desc_sparse[img][slot][256]
+// -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void desc_mark_kernel(const float* __restrict__ kps_xy, const int32_t* __restrict__ n_kp, int cap,
+                                                        int Hc, int Wc, uint8_t* __restrict__ flags) {
+  const int img = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_kp[img] || k >= cap) return;
+  const size_t o = (size_t)img * cap + k;
+  const SampleBCorners c = sample_b_corners(kps_xy[2 * o], kps_xy[2 * o + 1], Hc, Wc);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) flags[(size_t)img * Hc * Wc + c.iy[q] * Wc + c.ix[q]] = 1;
+}
+
+__global__ __launch_bounds__(1024) void desc_compact_kernel(const uint8_t* __restrict__ flags, int ncell, int max_slots,
+                                                            int32_t* __restrict__ slotmap, int32_t* __restrict__ cells,
+                                                            int32_t* __restrict__ count) {
+  __shared__ int wsum[16];
+  __shared__ int s_base;
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < ncell; c0 += 1024) {
+    const int cell = c0 + tid;
+    const bool f = cell < ncell && flags[(size_t)img * ncell + cell];
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) wsum[wv] = __popcll(bal);
+    __syncthreads();
+    int pre = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int c = wsum[k]; pre += k < wv ? c : 0; tot += c; }
+    const int slot = s_base + pre + __popcll(bal & ((1ull << lane) - 1ull));
+    if (cell < ncell) slotmap[(size_t)img * ncell + cell] = (f && slot < max_slots) ? slot : -1;
+    if (f && slot < max_slots) cells[(size_t)img * max_slots + slot] = cell;
+    __syncthreads();
+    if (tid == 0) s_base += tot;
+    __syncthreads();
+  }
+  if (tid == 0) count[img] = s_base < max_slots ? s_base : max_slots;
+}
+
+struct SparseHeadArgs {
+  const float* x; int x_cstride; long x_img_stride;      // conv4b output, NHWC [img][cell][128]
+  const void* w_da; const float* b_da;                   // convDa packed fp32 fragments (8 n-tiles x 9 taps x 16 k-octets), bias[256]
+  const void* w_db; const float* b_db;                   // convDb packed fp32 fragments (8 n-tiles x 1 tap x 32 k-octets), bias[256]
+  const int32_t* cells; const int32_t* count; int max_slots;
+  int Hc, Wc;
+  float* out;                                            // [img][max_slots][256]
+};
+
+__global__ __launch_bounds__(256) void desc_head_sparse_kernel(SparseHeadArgs a) {
+  constexpr int CIN = 128, CPA = CIN + 1, CMID = 256, CPD = CMID + 1, G = 4;
+  __shared__ float A[32 * CPA];      // one tap of the 32 cells' inputs
+  __shared__ float D[32 * CPD];      // ReLU(convDa) of the 32 cells = convDb's input
+  __shared__ int s_cell[32];
+  const int img = blockIdx.y, mt = blockIdx.x;
+  const int n = a.count[img];
+  if (mt * 32 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 32) s_cell[tid] = mt * 32 + tid < n ? a.cells[(size_t)img * a.max_slots + mt * 32 + tid] : -1;
+  __syncthreads();
+  const float* x = a.x + (size_t)img * a.x_img_stride;
+  const f32x4* wda = reinterpret_cast<const f32x4*>(a.w_da);
+  const f32x4* wdb = reinterpret_cast<const f32x4*>(a.w_db);
+  const int nt0 = wave * 2;                               // this wave's two n-tiles (64 output channels)
+
+  // ---- convDa: acc = bias; for tap (ky,kx): for ci ascending: fmaf -- the dense kernels' chain
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float b = a.b_da[(nt0 + t) * 32 + (lane & 31)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = b;
+  }
+  const int arow = (lane & 31) * CPA + (lane >> 5);
+  for (int tap = 0; tap < 9; ++tap) {
+    __syncthreads();                                      // previous tap's A tile fully consumed
+    for (int i = tid; i < 32 * (CIN / 4); i += 256) {
+      const int row = i / (CIN / 4), c4 = i % (CIN / 4);
+      const int cell = s_cell[row];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (cell >= 0) {
+        const int cy = cell / a.Wc + tap / 3 - 1, cx = cell % a.Wc + tap % 3 - 1;
+        if (cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc)
+          v = *reinterpret_cast<const f32x4*>(x + ((size_t)cy * a.Wc + cx) * a.x_cstride + c4 * 4);
+      }
+      float* d = A + row * CPA + c4 * 4;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int g = 0; g < (CIN / 8) / G; ++g) {
+      f32x4 bq[G][2];
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bq[j][t] = wda[((size_t)((nt0 + t) * 9 + tap) * (CIN / 8) + g * G + j) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const float* ap = A + arow + (g * G + j) * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float av = ap[2 * q];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[j][t][q], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ReLU -> D tile.  C layout: col = lane & 31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (cell)
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const float v = acc[t][r];
+      D[row * CPD + (nt0 + t) * 32 + (lane & 31)] = v > 0.f ? v : 0.f;
+    }
+  __syncthreads();
+  // ---- convDb (1x1): acc = bias; ci ascending
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float b = a.b_db[(nt0 + t) * 32 + (lane & 31)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = b;
+  }
+  const int drow = (lane & 31) * CPD + (lane >> 5);
+#pragma unroll 1
+  for (int g = 0; g < (CMID / 8) / G; ++g) {
+    f32x4 bq[G][2];
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bq[j][t] = wdb[((size_t)(nt0 + t) * (CMID / 8) + g * G + j) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const float* ap = D + drow + (g * G + j) * 8;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float av = ap[2 * q];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[j][t][q], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  float* out = a.out + ((size_t)img * a.max_slots + mt * 32) * 256;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (mt * 32 + row < n) out[(size_t)row * 256 + (nt0 + t) * 32 + (lane & 31)] = acc[t][r];
+    }
+}
+
+hipError_t launch_desc_head_sparse(const float* kps_xy, const int32_t* n_kp, int cap, int Hc, int Wc, int n_img, const float* x,
+                                   int x_cstride, long x_img_stride, const void* w_da, const float* b_da, const void* w_db,
+                                   const float* b_db, uint8_t* flags, int32_t* slotmap, int32_t* cells, int32_t* count,
+                                   int max_slots, float* out, hipStream_t s) {
+  const int ncell = Hc * Wc;
+  hipError_t e = hipMemsetAsync(flags, 0, (size_t)n_img * ncell, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(desc_mark_kernel, dim3((cap + 255) / 256, n_img), dim3(256), 0, s, kps_xy, n_kp, cap, Hc, Wc, flags);
+  hipLaunchKernelGGL(desc_compact_kernel, dim3(n_img), dim3(1024), 0, s, flags, ncell, max_slots, slotmap, cells, count);
+  SparseHeadArgs a;
+  a.x = x; a.x_cstride = x_cstride; a.x_img_stride = x_img_stride; a.w_da = w_da; a.b_da = b_da; a.w_db = w_db; a.b_db = b_db;
+  a.cells = cells; a.count = count; a.max_slots = max_slots; a.Hc = Hc; a.Wc = Wc; a.out = out;
+  const int mtiles = (std::min(max_slots, 4 * cap) + 31) / 32;
+  hipLaunchKernelGGL(desc_head_sparse_kernel, dim3(mtiles, n_img), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_sample_b(const float* desc_raw, int dstride, int dcoff, int Hc, int Wc, int n_img, const float* kps_xy,
-                           const int32_t* n_kp, int cap, float* desc_out, hipStream_t s) {
+                           const int32_t* n_kp, int cap, const int32_t* slotmap, int max_slots, float* desc_out, hipStream_t s) {
   dim3 grid((cap + 3) / 4, n_img), block(256);
-  hipLaunchKernelGGL(sample_b_kernel, grid, block, 0, s, desc_raw, dstride, dcoff, Hc, Wc, kps_xy, n_kp, cap, desc_out);
+  hipLaunchKernelGGL(sample_b_kernel, grid, block, 0, s, desc_raw, dstride, dcoff, Hc, Wc, kps_xy, n_kp, cap, slotmap, max_slots,
+                     desc_out);
   return hipGetLastError();
 }
 

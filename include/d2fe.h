@@ -62,7 +62,10 @@ typedef struct {
   int32_t precision;          /* d2fe_precision */
   int32_t keep_score_map;     /* 1: also write the dense H x W score map ("semi", 1.2 MB/image) for d2fe_debug_read;
                                  variant B does not need it (candidates are emitted by the softmax kernel) */
-  int32_t reserved[7];
+  int32_t dense_descriptors;  /* 0 (default): variant B evaluates the descriptor head (convDa, convDb) only at the corner cells of the
+                                 selected keypoints -- bit-identical output, 5 % fewer FLOPs; 1: dense descriptor map (d2fe_debug_read
+                                 "desc_raw" / "convPaDa" need it).  Variant A always computes the dense map. */
+  int32_t reserved[6];
 } d2fe_config;
 
 /* One conv layer in PyTorch layout: weight [cout][cin][k][k], bias [cout]. */

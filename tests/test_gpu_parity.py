@@ -19,9 +19,9 @@ def api():
     return a
 
 
-def _fe(api, H, W, n, prec, max_kp=200, thr=0.015):
+def _fe(api, H, W, n, prec, max_kp=200, thr=0.015, dense=False):
     fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=max_kp, input_width=W, input_height=H, max_batch=n, precision=prec,
-                                           keypoint_threshold=thr, keep_score_map=True))
+                                           keypoint_threshold=thr, keep_score_map=True, dense_descriptors=dense))
     return fe
 
 
@@ -48,7 +48,7 @@ def test_exact_mode_bitwise_every_layer(api, orc, sp_weights, H, W):
     """fp32 MFMA conv stack == oracle fmaf chains, bit for bit, incl. ragged tiles (sizes not multiples of the tile)."""
     n = 2
     imgs = np.stack([synth_image(H, W, 10 + s) for s in range(n)])
-    fe = _fe(api, H, W, n, api.PREC_F32)
+    fe = _fe(api, H, W, n, api.PREC_F32, dense=True)          # the dense descriptor map is inspected below
     fe.load_superpoint(sp_weights)
     res = fe.extract_batch(imgs, cap=200)
     for i in range(n):
@@ -125,7 +125,7 @@ def test_score_ties_use_raster_tiebreak(api, orc, sp_weights):
 @pytest.mark.parametrize("H,W", [(96, 128), (480, 640)])
 def test_fast_mode_tolerances(api, orc, sp_weights, H, W):
     imgs = np.stack(synth_stereo(H, W, seed=3))
-    fe = _fe(api, H, W, 2, api.PREC_F16X2)
+    fe = _fe(api, H, W, 2, api.PREC_F16X2, dense=True)
     fe.load_superpoint(sp_weights)
     res = fe.extract_batch(imgs, cap=200)
     for i in range(2):
@@ -478,3 +478,35 @@ def test_matcher_is_reentrant(api, orc):
         th.join()
     assert not errors, errors
     fe.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x2"])
+def test_sparse_descriptor_head_equals_dense(api, orc, sp_weights, prec):
+    """Default mode evaluates convDa/convDb only at the corner cells of the selected keypoints.  Exact mode: the descriptors are
+    BIT-identical to the dense-map path (same fmaf chains); fast mode: the sparse head runs in exact fp32 on the fp16x2 trunk,
+    so it may only be closer to the oracle than the dense fp16x2 head.  Batch with very different keypoint counts per image,
+    incl. an empty image (flat frame: nothing passes the threshold... the dustbin wins everywhere)."""
+    H, W = 240, 320
+    p = api.PREC_F32 if prec == "f32" else api.PREC_F16X2
+    imgs = np.stack([synth_image(H, W, 71), np.full((H, W), 90, np.uint8), synth_image(H, W, 72)])
+    outs = []
+    for dense in (False, True):
+        fe = _fe(api, H, W, 3, p, max_kp=300, dense=dense)
+        fe.load_superpoint(sp_weights)
+        outs.append(fe.extract_batch(imgs, cap=300))
+        if not dense:
+            with pytest.raises(api.D2FEError):
+                fe.debug_read("desc_raw", (3, H // 8, W // 8, 256))
+        fe.close()
+    for i in range(3):
+        ks, ss, ds = outs[0][i][:3]
+        kd, sd, dd = outs[1][i][:3]
+        assert np.array_equal(ks, kd) and np.array_equal(ss, sd)
+        if prec == "f32":
+            assert np.array_equal(ds.view(np.uint32), dd.view(np.uint32))
+        else:
+            f = orc.superpoint_forward(imgs[i], sp_weights)
+            if len(ks):
+                ref = orc.sample_b(f["desc"], ks)
+                assert np.abs(ds - ref).max() <= np.abs(dd - ref).max() + 1e-7 and np.abs(ds - ref).max() <= 5e-6
+    assert len(outs[0][0][0]) == 300
