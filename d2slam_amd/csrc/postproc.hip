@@ -399,7 +399,7 @@ struct SparseHeadArgs {
   float* out;                                            // [img][max_slots][256]
 };
 
-__global__ __launch_bounds__(256) void desc_head_sparse_kernel(SparseHeadArgs a) {
+__global__ __launch_bounds__(512) void desc_head_sparse_kernel(SparseHeadArgs a) {
   constexpr int CIN = 128, CPA = CIN + 1, CMID = 256, CPD = CMID + 1, G = 4;
   __shared__ float A[32 * CPA];      // one tap of the 32 cells' inputs
   __shared__ float D[32 * CPD];      // ReLU(convDa) of the 32 cells = convDb's input
@@ -413,12 +413,14 @@ __global__ __launch_bounds__(256) void desc_head_sparse_kernel(SparseHeadArgs a)
   const float* x = a.x + (size_t)img * a.x_img_stride;
   const f32x4* wda = reinterpret_cast<const f32x4*>(a.w_da);
   const f32x4* wdb = reinterpret_cast<const f32x4*>(a.w_db);
-  const int nt0 = wave * 2;                               // this wave's two n-tiles (64 output channels)
+  constexpr int NTW = 1;                                  // n-tiles per wave: 8 waves x 32 channels (short per-wave chains: the
+                                                          // kernel is latency-bound when only a stereo pair is in flight)
+  const int nt0 = wave * NTW;
 
   // ---- convDa: acc = bias; for tap (ky,kx): for ci ascending: fmaf -- the dense kernels' chain
-  f32x16 acc[2];
+  f32x16 acc[NTW];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < NTW; ++t) {
     const float b = a.b_da[(nt0 + t) * 32 + (lane & 31)];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = b;
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(256) void desc_head_sparse_kernel(SparseHeadArgs a)
   const int arow = (lane & 31) * CPA + (lane >> 5);
   for (int tap = 0; tap < 9; ++tap) {
     __syncthreads();                                      // previous tap's A tile fully consumed
-    for (int i = tid; i < 32 * (CIN / 4); i += 256) {
+    for (int i = tid; i < 32 * (CIN / 4); i += 512) {
       const int row = i / (CIN / 4), c4 = i % (CIN / 4);
       const int cell = s_cell[row];
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -441,11 +443,11 @@ __global__ __launch_bounds__(256) void desc_head_sparse_kernel(SparseHeadArgs a)
     __syncthreads();
 #pragma unroll 1
     for (int g = 0; g < (CIN / 8) / G; ++g) {
-      f32x4 bq[G][2];
+      f32x4 bq[G][NTW];
 #pragma unroll
       for (int j = 0; j < G; ++j)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) bq[j][t] = wda[((size_t)((nt0 + t) * 9 + tap) * (CIN / 8) + g * G + j) * 64 + lane];
+        for (int t = 0; t < NTW; ++t) bq[j][t] = wda[((size_t)((nt0 + t) * 9 + tap) * (CIN / 8) + g * G + j) * 64 + lane];
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const float* ap = A + arow + (g * G + j) * 8;
@@ -453,14 +455,14 @@ __global__ __launch_bounds__(256) void desc_head_sparse_kernel(SparseHeadArgs a)
         for (int q = 0; q < 4; ++q) {
           const float av = ap[2 * q];
 #pragma unroll
-          for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[j][t][q], acc[t], 0, 0, 0);
+          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[j][t][q], acc[t], 0, 0, 0);
         }
       }
     }
   }
   // ReLU -> D tile.  C layout: col = lane & 31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (cell)
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NTW; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(256) void desc_head_sparse_kernel(SparseHeadArgs a)
   __syncthreads();
   // ---- convDb (1x1): acc = bias; ci ascending
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < NTW; ++t) {
     const float b = a.b_db[(nt0 + t) * 32 + (lane & 31)];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = b;
@@ -478,11 +480,11 @@ __global__ __launch_bounds__(256) void desc_head_sparse_kernel(SparseHeadArgs a)
   const int drow = (lane & 31) * CPD + (lane >> 5);
 #pragma unroll 1
   for (int g = 0; g < (CMID / 8) / G; ++g) {
-    f32x4 bq[G][2];
+    f32x4 bq[G][NTW];
 #pragma unroll
     for (int j = 0; j < G; ++j)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) bq[j][t] = wdb[((size_t)(nt0 + t) * (CMID / 8) + g * G + j) * 64 + lane];
+      for (int t = 0; t < NTW; ++t) bq[j][t] = wdb[((size_t)(nt0 + t) * (CMID / 8) + g * G + j) * 64 + lane];
 #pragma unroll
     for (int j = 0; j < G; ++j) {
       const float* ap = D + drow + (g * G + j) * 8;
@@ -490,13 +492,13 @@ __global__ __launch_bounds__(256) void desc_head_sparse_kernel(SparseHeadArgs a)
       for (int q = 0; q < 4; ++q) {
         const float av = ap[2 * q];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[j][t][q], acc[t], 0, 0, 0);
+        for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[j][t][q], acc[t], 0, 0, 0);
       }
     }
   }
   float* out = a.out + ((size_t)img * a.max_slots + mt * 32) * 256;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NTW; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -517,7 +519,7 @@ hipError_t launch_desc_head_sparse(const float* kps_xy, const int32_t* n_kp, int
   a.x = x; a.x_cstride = x_cstride; a.x_img_stride = x_img_stride; a.w_da = w_da; a.b_da = b_da; a.w_db = w_db; a.b_db = b_db;
   a.cells = cells; a.count = count; a.max_slots = max_slots; a.Hc = Hc; a.Wc = Wc; a.out = out;
   const int mtiles = (std::min(max_slots, 4 * cap) + 31) / 32;
-  hipLaunchKernelGGL(desc_head_sparse_kernel, dim3(mtiles, n_img), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(desc_head_sparse_kernel, dim3(mtiles, n_img), dim3(512), 0, s, a);
   return hipGetLastError();
 }
 

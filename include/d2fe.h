@@ -63,7 +63,8 @@ typedef struct {
   int32_t keep_score_map;     /* 1: also write the dense H x W score map ("semi", 1.2 MB/image) for d2fe_debug_read;
                                  variant B does not need it (candidates are emitted by the softmax kernel) */
   int32_t dense_descriptors;  /* 0 (default): variant B evaluates the descriptor head (convDa, convDb) only at the corner cells of the
-                                 selected keypoints -- bit-identical output, 5 % fewer FLOPs; 1: dense descriptor map (d2fe_debug_read
+                                 selected keypoints when a call carries >= 4 images (below that the dense head is quicker; both give identical bits) -- 5 % fewer
+                                 FLOPs; 1: always the dense descriptor map (d2fe_debug_read
                                  "desc_raw" / "convPaDa" need it).  Variant A always computes the dense map. */
   int32_t reserved[6];
 } d2fe_config;

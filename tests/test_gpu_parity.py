@@ -488,17 +488,17 @@ def test_sparse_descriptor_head_equals_dense(api, orc, sp_weights, prec):
     incl. an empty image (flat frame: nothing passes the threshold... the dustbin wins everywhere)."""
     H, W = 240, 320
     p = api.PREC_F32 if prec == "f32" else api.PREC_F16X2
-    imgs = np.stack([synth_image(H, W, 71), np.full((H, W), 90, np.uint8), synth_image(H, W, 72)])
+    imgs = np.stack([synth_image(H, W, 71), np.full((H, W), 90, np.uint8), synth_image(H, W, 72)] + [synth_image(H, W, 80 + i) for i in range(6)])
     outs = []
     for dense in (False, True):
-        fe = _fe(api, H, W, 3, p, max_kp=300, dense=dense)
+        fe = _fe(api, H, W, 9, p, max_kp=300, dense=dense)      # 9 images per call: above the sparse path's batch threshold (4)
         fe.load_superpoint(sp_weights)
         outs.append(fe.extract_batch(imgs, cap=300))
         if not dense:
             with pytest.raises(api.D2FEError):
-                fe.debug_read("desc_raw", (3, H // 8, W // 8, 256))
+                fe.debug_read("desc_raw", (9, H // 8, W // 8, 256))
         fe.close()
-    for i in range(3):
+    for i in range(9):
         ks, ss, ds = outs[0][i][:3]
         kd, sd, dd = outs[1][i][:3]
         assert np.array_equal(ks, kd) and np.array_equal(ss, sd)
