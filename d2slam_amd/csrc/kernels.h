@@ -35,7 +35,7 @@ enum ConvShape {
 hipError_t launch_conv(ConvShape shape, int precision, bool pool, bool relu, int cout_pad, const ConvArgs& a,
                        hipStream_t s);
 
-// persistent producer/consumer kernels (conv_pc.hip); same arithmetic, selected by D2FE_CONV_PC (default 1)
+// persistent producer/consumer kernels (conv_pc.hip); same arithmetic, selected by D2FE_CONV_PC (default 2: every layer but the fused conv1a+conv1b)
 hipError_t launch_conv_pc(ConvShape shape, int precision, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s);
 
 // conv1a: u8 gray [n][H][stride] -> NHWC fp32 [n][H][W][64], fused (float)u8 * (1/255), bias, ReLU.
