@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--workload", choices=["d435", "quadcam"], default="d435",
                     help="d435 = BASELINE configs[1] (the headline); quadcam = configs[2]: 4 x (1280x800 raw -> 800x400) per frame, undistort + SuperPoint + NetVLAD + neighbour/temporal matchKNN")
     ap.add_argument("--single-mode", action="store_true", help="time only --precision (default: also the other mode)")
+    ap.add_argument("--sync-tail", action="store_true", help="post-processing and matching on the same stream as the convolutions (default: "
+                    "on the handle's tail stream, under the next step's convolutions)")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event breakdown to stderr")
     args = ap.parse_args()
 
@@ -81,7 +83,7 @@ def main():
         NI = 2 * F
         prec = api.PREC_F32 if precision == "f32" else api.PREC_F16X2
         cfg = api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=NI, precision=prec,
-                                   device_id=local_rank)
+                                   device_id=local_rank, async_tail=not args.sync_tail)
         fe = api.FrontEnd(cfg)
         fe.load_superpoint(weights)
         if args.netvlad:
@@ -128,6 +130,11 @@ def main():
         torch.cuda.set_stream(main)
         stream = main.cuda_stream
         assert stream != 0
+        # async_tail (default): the library issues the convolutions of a step on `main` and its post-processing on the handle's
+        # tail stream; matching and the bookkeeping that consume the descriptors are enqueued on that tail stream too, so the
+        # whole latency-bound tail of step k runs under the convolutions of step k+1 (--sync-tail: everything on `main`)
+        tail = torch.cuda.ExternalStream(fe.tail_stream(), device=dev) if fe.tail_stream() else main
+        tstream = tail.cuda_stream
 
         def step():
             if args.netvlad:
@@ -136,19 +143,20 @@ def main():
                 fe.netvlad_device(imgs.data_ptr(), F, W, H, gdesc.data_ptr(), stream=side.cuda_stream, image_stride=2 * H * W)
             fe.extract_device(imgs.data_ptr(), NI, W, H, kps.data_ptr(), scores.data_ptr(), desc.data_ptr(), kidx.data_ptr(),
                               CAP, cnt.data_ptr(), stream=stream)
-            if world > 1:
-                # cross-agent exchange: one all-gather of the fixed-capacity left-image blocks (RCCL over xGMI)
-                swarm.exchange_blocks(desc, cnt, F, rank, world, gath_desc, gath_cnt)
-            torch.index_select(cnt, 0, a_rows_t, out=a_cnt)
-            torch.index_select(cnt, 0, b_rows_t, out=b_cnt)
-            fe.match_batch_device(desc.data_ptr(), desc.data_ptr(), a_off.data_ptr(), b_off.data_ptr(), a_cnt.data_ptr(),
-                                  b_cnt.data_ptr(), NP, 256, CAP, mq.data_ptr(), mt.data_ptr(), md.data_ptr(), mn.data_ptr(),
-                                  mode=0, ratio=0.8, radius=-1.0, stream=stream)
+            with torch.cuda.stream(tail):
+                if world > 1:
+                    # cross-agent exchange: one all-gather of the fixed-capacity left-image blocks (RCCL over xGMI)
+                    swarm.exchange_blocks(desc, cnt, F, rank, world, gath_desc, gath_cnt)
+                torch.index_select(cnt, 0, a_rows_t, out=a_cnt)
+                torch.index_select(cnt, 0, b_rows_t, out=b_cnt)
+                fe.match_batch_device(desc.data_ptr(), desc.data_ptr(), a_off.data_ptr(), b_off.data_ptr(), a_cnt.data_ptr(),
+                                      b_cnt.data_ptr(), NP, 256, CAP, mq.data_ptr(), mt.data_ptr(), md.data_ptr(), mn.data_ptr(),
+                                      mode=0, ratio=0.8, radius=-1.0, stream=tstream)
+                # this step's left descriptors become the "previous keyframe" of the next step
+                desc[NI:NI + F].copy_(desc[left_rows])
+                cnt[NI:NI + F].copy_(cnt[left_rows])
             if args.netvlad:
                 torch.cuda.current_stream(dev).wait_stream(side)
-            # this step's left descriptors become the "previous keyframe" of the next step
-            desc[NI:NI + F].copy_(desc[left_rows])
-            cnt[NI:NI + F].copy_(cnt[left_rows])
 
         def barrier():
             if world > 1:
@@ -239,7 +247,7 @@ def main():
             "config": {"workload": "configs[1]: realsense_d435 stereo 640x480, 200 keypoints/frame, SuperPoint (both "
                                    "images) + matchKNN L<->R and L<->prevL" + ("; + RCCL all-gather and cross-agent matchKNN" if world > 1 else ""),
                        "frames_per_step_per_gpu": F, "images_per_step_per_gpu": NI, "match_pairs_per_step_per_gpu": NP,
-                       "max_keypoints": CAP, "postproc": "B", "precision": args.precision, "netvlad": bool(args.netvlad),
+                       "async_tail": not args.sync_tail, "max_keypoints": CAP, "postproc": "B", "precision": args.precision, "netvlad": bool(args.netvlad),
                        "weights": "seeded random-init SuperPoint (no checkpoint in tree)"},
             "sp_tflops_algorithmic": round(SP_FLOP_PER_IMG * 2 * value / 1e12, 2),
             "avg_keypoints_per_image": round(n_kp, 1), "avg_matches_per_pair": round(n_match, 1),

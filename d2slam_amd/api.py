@@ -38,7 +38,7 @@ class _Config(C.Structure):
                 ("max_height", C.c_int32), ("max_batch", C.c_int32), ("max_keypoints", C.c_int32),
                 ("remove_borders", C.c_int32), ("keypoint_threshold", C.c_float), ("postproc", C.c_int32),
                 ("nms_dist", C.c_int32), ("precision", C.c_int32), ("keep_score_map", C.c_int32),
-                ("dense_descriptors", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("dense_descriptors", C.c_int32), ("async_tail", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class _ConvParams(C.Structure):
@@ -73,7 +73,7 @@ _lib = None
 
 EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_create", "d2fe_destroy",
            "d2fe_load_superpoint", "d2fe_set_superpoint_pca", "d2fe_desc_dim", "d2fe_superpoint_extract", "d2fe_superpoint_extract_batch",
-           "d2fe_superpoint_extract_device", "d2fe_load_netvlad", "d2fe_set_netvlad_pca", "d2fe_netvlad_dim",
+           "d2fe_superpoint_extract_device", "d2fe_tail_stream", "d2fe_superpoint_wait_tail", "d2fe_load_netvlad", "d2fe_set_netvlad_pca", "d2fe_netvlad_dim",
            "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device",
            "d2fe_half_image_filter", "d2fe_undistort", "d2fe_undistort_device", "d2fe_db_create", "d2fe_db_destroy",
            "d2fe_db_ntotal", "d2fe_db_add", "d2fe_db_search", "d2fe_db_query_gated", "d2fe_quantize_int8", "d2fe_dequantize_int8",
@@ -137,6 +137,9 @@ def load_library():
         lib.d2fe_destroy.argtypes = [C.c_void_p]
         lib.d2fe_load_superpoint.argtypes = [C.c_void_p, C.c_void_p]
         lib.d2fe_sync.argtypes = [C.c_void_p]
+        lib.d2fe_tail_stream.argtypes = [C.c_void_p]
+        lib.d2fe_tail_stream.restype = C.c_void_p
+        lib.d2fe_superpoint_wait_tail.argtypes = [C.c_void_p, C.c_void_p]
         lib.d2fe_undistort.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_void_p]
         lib.d2fe_undistort_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
@@ -222,6 +225,7 @@ class SuperPointConfig:
     precision: int = PREC_F32
     keep_score_map: bool = False   # debug: also write the dense score map
     dense_descriptors: bool = False  # debug: dense descriptor map instead of the sparse descriptor head (variant B)
+    async_tail: bool = False         # extract_device: post-processing on the handle's tail stream, under the next call's convolutions
 
 
 class FrontEnd:
@@ -243,6 +247,7 @@ class FrontEnd:
         c.precision = cfg.precision
         c.keep_score_map = int(cfg.keep_score_map)
         c.dense_descriptors = int(cfg.dense_descriptors)
+        c.async_tail = int(cfg.async_tail)
         self.cfg = cfg
         self._h = C.c_void_p()
         _check(lib.d2fe_create(C.byref(c), C.byref(self._h)))
@@ -308,6 +313,13 @@ class FrontEnd:
         """Device-resident form; arguments are raw device addresses (ints)."""
         _check(self._lib.d2fe_superpoint_extract_device(self._h, d_gray, n, W, H, stride or W, image_stride or H * W,
                                                         d_kps, d_scores, d_desc, d_idx, cap, d_n, stream))
+
+    def tail_stream(self):
+        """async_tail mode: raw hipStream_t on which the outputs of extract_device become valid (0 when the mode is off)."""
+        return int(self._lib.d2fe_tail_stream(self._h) or 0)
+
+    def wait_tail(self, stream=None):
+        _check(self._lib.d2fe_superpoint_wait_tail(self._h, C.c_void_p(stream or 0)))
 
     def debug_read(self, name, shape):
         out = np.empty(shape, np.float32)

@@ -57,6 +57,12 @@ struct d2fe_context {
   Layer L[L_COUNT];
   // activations (NHWC fp32), separate buffer per layer so that d2fe_debug_read can inspect any of them
   Tensor a1a, a1b, a2a, a2b, a3a, a3b, a4a, a4b, aPD, logits, draw, semi;
+  // async_tail: the post-processing (softmax .. descriptors) of call k runs on tail_stream under the convolutions of call k+1,
+  // so the three tensors the tail reads exist twice (buffer set = call parity) and events order trunk / tail / reuse
+  Tensor a4b2, logits2, draw2;
+  hipStream_t tail_stream = nullptr;
+  hipEvent_t ev_trunk[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
+  int parity = 0, last_set = 0;
   unsigned long long* cand = nullptr;
   int* cand_count = nullptr;
   long cand_cap = 0;
@@ -195,7 +201,13 @@ struct ProfScope {
 
 // the launch sequence == one TensorRT executeV2 + processOutput of the reference
 int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int stride, size_t image_stride,
-                   float* d_kps, float* d_scores, float* d_desc, int32_t* d_idx, int cap, int32_t* d_n, hipStream_t s) {
+                   float* d_kps, float* d_scores, float* d_desc, int32_t* d_idx, int cap, int32_t* d_n, hipStream_t s,
+                   hipStream_t s_tail = nullptr, int bs = 0) {
+  // s: the convolutions ("trunk"); s_tail (default: s): softmax, selection, descriptor head, sampling ("tail"); bs: buffer set
+  Tensor& a4b = bs ? h->a4b2 : h->a4b;
+  Tensor& logits = bs ? h->logits2 : h->logits;
+  Tensor& draw = bs ? h->draw2 : h->draw;
+  h->last_set = bs;
   const int prec = h->cfg.precision;
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8;
   auto conv = [&](ConvShape shape, const Layer& L, const float* in, int ics, int ico, long iis, float* out, int ocs,
@@ -221,23 +233,28 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
   { ProfScope ps(h, D2FE_PROF_CONV3A, s); HIP_TRY(conv(CONV_64_T8x32, h->L[L_3A], h->a2b.p, 64, 0, (long)H4 * W4 * 64, h->a3a.p, 128, (long)H4 * W4 * 128, H4, W4, false, true)); }
   { ProfScope ps(h, D2FE_PROF_CONV3B, s); HIP_TRY(conv(CONV_128_T4x32, h->L[L_3B], h->a3a.p, 128, 0, (long)H4 * W4 * 128, h->a3b.p, 128, (long)Hc * Wc * 128, H4, W4, true, true)); }
   { ProfScope ps(h, D2FE_PROF_CONV4A, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_4A], h->a3b.p, 128, 0, (long)Hc * Wc * 128, h->a4a.p, 128, (long)Hc * Wc * 128, Hc, Wc, false, true)); }
-  { ProfScope ps(h, D2FE_PROF_CONV4B, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_4B], h->a4a.p, 128, 0, (long)Hc * Wc * 128, h->a4b.p, 128, (long)Hc * Wc * 128, Hc, Wc, false, true)); }
+  { ProfScope ps(h, D2FE_PROF_CONV4B, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_4B], h->a4a.p, 128, 0, (long)Hc * Wc * 128, a4b.p, 128, (long)Hc * Wc * 128, Hc, Wc, false, true)); }
   // both paths give identical bits; with fewer than 4 images per call the dense head is quicker (the sparse kernels are
   // latency-bound with so few 32-cell workgroups in flight; measured per step, exact mode: 2 images 1.079 ms dense / 1.096 sparse,
   // 4 images 1.877 / 1.862, 8 images 3.42 / 3.28, 16 images 6.48 / 6.20)
   const bool sparse = h->sparse_desc && n >= h->sp_min_batch;
   if (sparse) {
     // detector head only (convPa 128->256, convPb); the descriptor head is evaluated after keypoint selection, at the needed cells
-    { ProfScope ps(h, D2FE_PROF_CONVPADA, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_PA], h->a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, true)); }
-    { ProfScope ps(h, D2FE_PROF_CONVPB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_PB], h->aPD.p, 256, 0, (long)Hc * Wc * 256, h->logits.p, 65, (long)Hc * Wc * 65, Hc, Wc, false, false)); }
+    { ProfScope ps(h, D2FE_PROF_CONVPADA, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_PA], a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, true)); }
+    { ProfScope ps(h, D2FE_PROF_CONVPB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_PB], h->aPD.p, 256, 0, (long)Hc * Wc * 256, logits.p, 65, (long)Hc * Wc * 65, Hc, Wc, false, false)); }
   } else {
-    { ProfScope ps(h, D2FE_PROF_CONVPADA, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_PADA], h->a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 512, (long)Hc * Wc * 512, Hc, Wc, false, true)); }
-    { ProfScope ps(h, D2FE_PROF_CONVPB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_PB], h->aPD.p, 512, 0, (long)Hc * Wc * 512, h->logits.p, 65, (long)Hc * Wc * 65, Hc, Wc, false, false)); }
-    { ProfScope ps(h, D2FE_PROF_CONVDB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_DB], h->aPD.p, 512, 256, (long)Hc * Wc * 512, h->draw.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, false)); }
+    { ProfScope ps(h, D2FE_PROF_CONVPADA, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_PADA], a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 512, (long)Hc * Wc * 512, Hc, Wc, false, true)); }
+    { ProfScope ps(h, D2FE_PROF_CONVPB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_PB], h->aPD.p, 512, 0, (long)Hc * Wc * 512, logits.p, 65, (long)Hc * Wc * 65, Hc, Wc, false, false)); }
+    { ProfScope ps(h, D2FE_PROF_CONVDB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_DB], h->aPD.p, 512, 256, (long)Hc * Wc * 512, draw.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, false)); }
   }
   const bool varA = h->cfg.postproc == D2FE_POSTPROC_A;
+  if (s_tail && s_tail != s) {       // trunk done -> tail may start; from here on everything is issued on the tail stream
+    HIP_TRY(hipEventRecord(h->ev_trunk[bs], s));
+    HIP_TRY(hipStreamWaitEvent(s_tail, h->ev_trunk[bs], 0));
+    s = s_tail;
+  }
   { ProfScope ps(h, D2FE_PROF_SOFTMAX, s);
-  HIP_TRY(launch_softmax_cand(h->logits.p, 65, Hc, Wc, n, h->cfg.keypoint_threshold, h->cfg.remove_borders,
+  HIP_TRY(launch_softmax_cand(logits.p, 65, Hc, Wc, n, h->cfg.keypoint_threshold, h->cfg.remove_borders,
                               (h->cfg.keep_score_map || varA) ? h->semi.p : nullptr,
                               h->cand, h->cand_count, varA ? 0 : h->cand_cap, s)); }
   if (varA) {
@@ -254,14 +271,14 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
   }
   { ProfScope ps(h, D2FE_PROF_SAMPLE, s);
     if (varA)
-      HIP_TRY(launch_sample_a(h->draw.p, 256, 0, Hc, Wc, W, H, n, d_kps, d_n, cap, h->pca_dims ? h->pca_comp_t : nullptr,
+      HIP_TRY(launch_sample_a(draw.p, 256, 0, Hc, Wc, W, H, n, d_kps, d_n, cap, h->pca_dims ? h->pca_comp_t : nullptr,
                               h->pca_mean, h->pca_dims, h->a_samp, h->a_scap, h->a_cn, d_desc, s));
     else if (!sparse)
-      HIP_TRY(launch_sample_b(h->draw.p, 256, 0, Hc, Wc, n, d_kps, d_n, cap, nullptr, 0, d_desc, s));
+      HIP_TRY(launch_sample_b(draw.p, 256, 0, Hc, Wc, n, d_kps, d_n, cap, nullptr, 0, d_desc, s));
   }
   if (sparse) {
     { ProfScope ps(h, D2FE_PROF_CONVDB, s);
-      HIP_TRY(launch_desc_head_sparse(d_kps, d_n, cap, Hc, Wc, n, h->a4b.p, 128, (long)Hc * Wc * 128, h->L[L_DA32].wpack, h->L[L_DA32].bias,
+      HIP_TRY(launch_desc_head_sparse(d_kps, d_n, cap, Hc, Wc, n, a4b.p, 128, (long)Hc * Wc * 128, h->L[L_DA32].wpack, h->L[L_DA32].bias,
                                       h->L[L_DB32].wpack, h->L[L_DB32].bias, h->sp_flags, h->sp_slotmap, h->sp_cells, h->sp_count,
                                       h->sp_slots, h->sp_desc, s)); }
     ProfScope ps(h, D2FE_PROF_SAMPLE, s);
@@ -304,6 +321,7 @@ void d2fe_default_config(d2fe_config* c) {
   c->nms_dist = 10;
   c->precision = D2FE_PREC_F32;
   c->dense_descriptors = 0;
+  c->async_tail = 0;
 }
 
 int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
@@ -345,6 +363,14 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     h->cand_cap = (long)(H * W);
     HIP_TRY(hipMalloc(&h->cand, sizeof(unsigned long long) * h->cand_cap * B));
     HIP_TRY(hipMalloc(&h->cand_count, sizeof(int) * B));
+    if (cfg->async_tail) {
+      HIP_TRY(hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
+      for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_trunk[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_tail[i], hipEventDisableTiming));
+      }
+      if (alloc_f(h->a4b2, H * W * 2, B) || alloc_f(h->logits2, (H / 8) * (W / 8) * 65, B) || alloc_f(h->draw2, H * W * 4, B)) return D2FE_ERR_HIP;
+    }
     h->sparse_desc = cfg->postproc == D2FE_POSTPROC_B && !cfg->dense_descriptors;
     { const char* e = getenv("D2FE_SPARSE_MIN_BATCH"); if (e) h->sp_min_batch = atoi(e); }
     if (h->sparse_desc) {
@@ -387,7 +413,9 @@ void d2fe_destroy(d2fe_handle h) {
   if (!h) return;
   hipSetDevice(h->cfg.device_id);
   if (h->stream) hipStreamSynchronize(h->stream);
-  for (Tensor* t : {&h->a1a, &h->a1b, &h->a2a, &h->a2b, &h->a3a, &h->a3b, &h->a4a, &h->a4b, &h->aPD, &h->logits, &h->draw, &h->semi})
+  if (h->tail_stream) { hipStreamSynchronize(h->tail_stream); (void)hipStreamDestroy(h->tail_stream); }
+  for (int i = 0; i < 2; ++i) { if (h->ev_trunk[i]) (void)hipEventDestroy(h->ev_trunk[i]); if (h->ev_tail[i]) (void)hipEventDestroy(h->ev_tail[i]); }
+  for (Tensor* t : {&h->a1a, &h->a1b, &h->a2a, &h->a2b, &h->a3a, &h->a3b, &h->a4a, &h->a4b, &h->aPD, &h->logits, &h->draw, &h->semi, &h->a4b2, &h->logits2, &h->draw2})
     if (t->p) hipFree(t->p);
   for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
   for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->cand_count, (void*)h->s_img, (void*)h->s_kps,
@@ -483,8 +511,29 @@ int d2fe_superpoint_extract_device(d2fe_handle h, const uint8_t* d_gray, int n, 
   if (!d_gray || !d_kps_xy || !d_scores || !d_desc || !d_n_out) return fail(D2FE_ERR_INVALID, "null device pointer");
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-  return run_superpoint(h, d_gray, n, width, height, stride, image_stride, d_kps_xy, d_scores, d_desc, d_kps_idx, cap,
-                        d_n_out, s);
+  if (!h->cfg.async_tail)
+    return run_superpoint(h, d_gray, n, width, height, stride, image_stride, d_kps_xy, d_scores, d_desc, d_kps_idx, cap,
+                          d_n_out, s);
+  // async_tail: convolutions on `s`, post-processing on the handle's tail stream.  Buffer set p was last read by the tail of
+  // the call before the previous one: the trunk may only overwrite it once that tail is done.
+  const int p = h->parity;
+  HIP_TRY(hipStreamWaitEvent(s, h->ev_tail[p], 0));       // never-recorded event: no-op
+  rc = run_superpoint(h, d_gray, n, width, height, stride, image_stride, d_kps_xy, d_scores, d_desc, d_kps_idx, cap, d_n_out, s,
+                      h->tail_stream, p);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(h->ev_tail[p], h->tail_stream));
+  h->parity = p ^ 1;
+  return D2FE_OK;
+}
+
+void* d2fe_tail_stream(d2fe_handle h) { return h ? (void*)h->tail_stream : nullptr; }
+
+int d2fe_superpoint_wait_tail(d2fe_handle h, void* stream) {
+  if (!h) return fail(D2FE_ERR_INVALID, "null handle");
+  if (!h->cfg.async_tail) return D2FE_OK;
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(hipStreamWaitEvent(stream ? (hipStream_t)stream : h->stream, h->ev_tail[h->parity ^ 1], 0));
+  return D2FE_OK;
 }
 
 int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int height, int stride,
@@ -1072,8 +1121,8 @@ long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_byte
   struct { const char* nm; Tensor* t; size_t per; } tab[] = {
       {"conv1a", &h->a1a, H * W * 64},           {"conv1b", &h->a1b, H * W * 16},        {"conv2a", &h->a2a, H * W * 16},
       {"conv2b", &h->a2b, H * W * 4},            {"conv3a", &h->a3a, H * W * 8},         {"conv3b", &h->a3b, H * W * 2},
-      {"conv4a", &h->a4a, H * W * 2},            {"conv4b", &h->a4b, H * W * 2},         {"convPaDa", &h->aPD, H * W * 8},
-      {"logits", &h->logits, (H / 8) * (W / 8) * 65}, {"desc_raw", &h->draw, H * W * 4}, {"semi", &h->semi, H * W}};
+      {"conv4a", &h->a4a, H * W * 2},            {"conv4b", h->last_set ? &h->a4b2 : &h->a4b, H * W * 2},         {"convPaDa", &h->aPD, H * W * 8},
+      {"logits", h->last_set ? &h->logits2 : &h->logits, (H / 8) * (W / 8) * 65}, {"desc_raw", h->last_set ? &h->draw2 : &h->draw, H * W * 4}, {"semi", &h->semi, H * W}};
   if (!strcmp(name, "conv1a") && h->fuse1a) {
     // fused mode never materialises conv1a: evaluate it on demand from the last input frame(s)
     if (!h->a1a.p && alloc_f(h->a1a, (size_t)h->cfg.max_height * h->cfg.max_width * 64, h->cfg.max_batch) != 0)
@@ -1088,7 +1137,7 @@ long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_byte
     if (!strcmp(e.nm, name)) {
       const size_t bytes = e.per * n * sizeof(float);
       if (bytes > max_bytes) return fail(D2FE_ERR_TRUNCATED, "destination too small");
-      if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(D2FE_ERR_HIP, "sync");
+      if (hipStreamSynchronize(h->stream) != hipSuccess || (h->tail_stream && hipStreamSynchronize(h->tail_stream) != hipSuccess)) return fail(D2FE_ERR_HIP, "sync");
       if (hipMemcpy(dst, e.t->p, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(D2FE_ERR_HIP, "D2H");
       return (long)bytes;
     }
@@ -1122,6 +1171,7 @@ int d2fe_profile_read(d2fe_handle h, float* ms, int32_t* launches) {
 }
 
 int d2fe_sync(d2fe_handle h) {
+  if (h && h->tail_stream) (void)hipStreamSynchronize(h->tail_stream);
   if (!h) return fail(D2FE_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   HIP_TRY(hipStreamSynchronize(h->stream));

@@ -66,7 +66,11 @@ typedef struct {
                                  selected keypoints when a call carries >= 4 images (below that the dense head is quicker; both give identical bits) -- 5 % fewer
                                  FLOPs; 1: always the dense descriptor map (d2fe_debug_read
                                  "desc_raw" / "convPaDa" need it).  Variant A always computes the dense map. */
-  int32_t reserved[6];
+  int32_t async_tail;         /* 1: d2fe_superpoint_extract_device issues the convolutions on the caller's stream and the post-processing
+                                 (softmax .. descriptors) on the handle's tail stream (d2fe_tail_stream), so that it runs UNDER the
+                                 convolutions of the next call; outputs are complete on the tail stream -- enqueue consumers there, or
+                                 call d2fe_superpoint_wait_tail(h, stream).  Host-pointer calls are unaffected.  Default 0. */
+  int32_t reserved[5];
 } d2fe_config;
 
 /* One conv layer in PyTorch layout: weight [cout][cin][k][k], bias [cout]. */
@@ -114,6 +118,10 @@ D2FE_API int d2fe_superpoint_extract(d2fe_handle h, const uint8_t* gray, int wid
 
 /* Batched form of the same call: n images of identical size, image i at gray + i*image_stride bytes;
  * outputs of image i at kps_xy + i*cap*2, scores + i*cap, desc + i*cap*256, n_out[i]. */
+/* async_tail mode: the stream on which the outputs of the last d2fe_superpoint_extract_device call become valid, and a helper
+ * that makes another stream wait for them. */
+D2FE_API void* d2fe_tail_stream(d2fe_handle h);
+D2FE_API int d2fe_superpoint_wait_tail(d2fe_handle h, void* stream);
 D2FE_API int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int height,
                                            int stride, size_t image_stride, float* kps_xy, float* scores,
                                            float* desc, int cap, int* n_out);

@@ -510,3 +510,42 @@ def test_sparse_descriptor_head_equals_dense(api, orc, sp_weights, prec):
                 ref = orc.sample_b(f["desc"], ks)
                 assert np.abs(ds - ref).max() <= np.abs(dd - ref).max() + 1e-7 and np.abs(ds - ref).max() <= 5e-6
     assert len(outs[0][0][0]) == 300
+
+
+@pytest.mark.parametrize("n", [2, 6])
+def test_async_tail_equals_synchronous(api, sp_weights, n):
+    """async_tail: convolutions on the caller's stream, post-processing on the handle's tail stream with double-buffered inputs.
+    Five back-to-back calls on different frames WITHOUT any host synchronisation in between (so call k+1's convolutions really
+    run while call k's tail is pending), each into its own output buffers, must reproduce the synchronous results bit for bit;
+    n = 2 exercises the dense descriptor head, n = 6 the sparse one."""
+    torch = pytest.importorskip("torch")
+    H, W, cap, calls = 120, 160, 120, 5
+    dev = torch.device("cuda", 0)
+    frames = [torch.from_numpy(np.stack([synth_image(H, W, 300 + 10 * c + s) for s in range(n)])).to(dev) for c in range(calls)]
+
+    def run(async_tail):
+        fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=cap, input_width=W, input_height=H, max_batch=n, async_tail=async_tail))
+        fe.load_superpoint(sp_weights)
+        assert (fe.tail_stream() != 0) == async_tail
+        outs = []
+        st = torch.cuda.Stream(device=dev)
+        for c in range(calls):
+            o = dict(kps=torch.zeros((n, cap, 2), device=dev), sc=torch.zeros((n, cap), device=dev), desc=torch.zeros((n, cap, 256), device=dev),
+                     idx=torch.zeros((n, cap), dtype=torch.int32, device=dev), cnt=torch.zeros(n, dtype=torch.int32, device=dev))
+            outs.append(o)
+        torch.cuda.synchronize()
+        for c in range(calls):
+            o = outs[c]
+            fe.extract_device(frames[c].data_ptr(), n, W, H, o["kps"].data_ptr(), o["sc"].data_ptr(), o["desc"].data_ptr(), o["idx"].data_ptr(),
+                              cap, o["cnt"].data_ptr(), stream=st.cuda_stream)
+        fe.wait_tail(st.cuda_stream)          # st now also waits for the last tail (earlier tails precede it on the tail stream)
+        st.synchronize()
+        res = [{k: v.cpu().numpy() for k, v in o.items()} for o in outs]
+        fe.close()
+        return res
+
+    a, b = run(True), run(False)
+    for c in range(calls):
+        assert a[c]["cnt"].sum() > 0
+        for k in ("cnt", "kps", "sc", "desc", "idx"):
+            assert np.array_equal(a[c][k], b[c][k]), (c, k)
