@@ -78,12 +78,15 @@ def main():
     if args.workload == "quadcam":
         return run_quadcam(args, torch, api, weights, dev, local_rank, rank, world)
 
+    # with NetVLAD on its own side stream a third concurrent stream costs more than it hides (measured 1191 vs 1253 stereo fps)
+    use_async_tail = not args.sync_tail and not args.netvlad
+
     def run_mode(precision, want_breakdown):
         F = args.frames
         NI = 2 * F
         prec = api.PREC_F32 if precision == "f32" else api.PREC_F16X2
         cfg = api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=NI, precision=prec,
-                                   device_id=local_rank, async_tail=not args.sync_tail)
+                                   device_id=local_rank, async_tail=use_async_tail)
         fe = api.FrontEnd(cfg)
         fe.load_superpoint(weights)
         if args.netvlad:
@@ -156,7 +159,7 @@ def main():
                 desc[NI:NI + F].copy_(desc[left_rows])
                 cnt[NI:NI + F].copy_(cnt[left_rows])
             if args.netvlad:
-                torch.cuda.current_stream(dev).wait_stream(side)
+                tail.wait_stream(side)      # the step's global descriptors are complete when its tail is (the convolutions of the next step do not wait for them)
 
         def barrier():
             if world > 1:
@@ -247,7 +250,7 @@ def main():
             "config": {"workload": "configs[1]: realsense_d435 stereo 640x480, 200 keypoints/frame, SuperPoint (both "
                                    "images) + matchKNN L<->R and L<->prevL" + ("; + RCCL all-gather and cross-agent matchKNN" if world > 1 else ""),
                        "frames_per_step_per_gpu": F, "images_per_step_per_gpu": NI, "match_pairs_per_step_per_gpu": NP,
-                       "async_tail": not args.sync_tail, "max_keypoints": CAP, "postproc": "B", "precision": args.precision, "netvlad": bool(args.netvlad),
+                       "async_tail": use_async_tail, "max_keypoints": CAP, "postproc": "B", "precision": args.precision, "netvlad": bool(args.netvlad),
                        "weights": "seeded random-init SuperPoint (no checkpoint in tree)"},
             "sp_tflops_algorithmic": round(SP_FLOP_PER_IMG * 2 * value / 1e12, 2),
             "avg_keypoints_per_image": round(n_kp, 1), "avg_matches_per_pair": round(n_match, 1),
