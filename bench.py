@@ -42,8 +42,10 @@ def main():
     ap.add_argument("--workload", choices=["d435", "quadcam"], default="d435",
                     help="d435 = BASELINE configs[1] (the headline); quadcam = configs[2]: 4 x (1280x800 raw -> 800x400) per frame, undistort + SuperPoint + NetVLAD + neighbour/temporal matchKNN")
     ap.add_argument("--single-mode", action="store_true", help="time only --precision (default: also the other mode)")
-    ap.add_argument("--sync-tail", action="store_true", help="post-processing and matching on the same stream as the convolutions (default: "
-                    "on the handle's tail stream, under the next step's convolutions)")
+    ap.add_argument("--async-tail", action="store_true",
+                    help="d2fe_config.async_tail: post-processing and matching of step k on the handle's tail stream, under the convolutions of "
+                         "step k+1 (+1 %% stereo fps at 16 frames per step, +7 %% at 1, +6 %% in the fp16x2 mode).  Off by default: the overlapped "
+                         "kernels stretch the dominant kernel's wall time, which would blur its roofline figure")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event breakdown to stderr")
     args = ap.parse_args()
 
@@ -79,7 +81,7 @@ def main():
         return run_quadcam(args, torch, api, weights, dev, local_rank, rank, world)
 
     # with NetVLAD on its own side stream a third concurrent stream costs more than it hides (measured 1191 vs 1253 stereo fps)
-    use_async_tail = not args.sync_tail and not args.netvlad
+    use_async_tail = args.async_tail and not args.netvlad
 
     def run_mode(precision, want_breakdown):
         F = args.frames
@@ -133,9 +135,9 @@ def main():
         torch.cuda.set_stream(main)
         stream = main.cuda_stream
         assert stream != 0
-        # async_tail (default): the library issues the convolutions of a step on `main` and its post-processing on the handle's
+        # --async-tail: the library issues the convolutions of a step on `main` and its post-processing on the handle's
         # tail stream; matching and the bookkeeping that consume the descriptors are enqueued on that tail stream too, so the
-        # whole latency-bound tail of step k runs under the convolutions of step k+1 (--sync-tail: everything on `main`)
+        # whole latency-bound tail of step k runs under the convolutions of step k+1 (default: everything on `main`)
         tail = torch.cuda.ExternalStream(fe.tail_stream(), device=dev) if fe.tail_stream() else main
         tstream = tail.cuda_stream
 
