@@ -549,3 +549,25 @@ def test_async_tail_equals_synchronous(api, sp_weights, n):
         assert a[c]["cnt"].sum() > 0
         for k in ("cnt", "kps", "sc", "desc", "idx"):
             assert np.array_equal(a[c][k], b[c][k]), (c, k)
+
+
+def test_variant_a_batch_and_pca(api, orc, sp_weights):
+    """Variant A on a batch of 3 different frames with the 64-D PCA: every image's keypoints / descriptors equal the oracle's
+    (the channel-over-keypoints normalisation of computeDescriptors is per image: batching must not mix the lists)."""
+    H, W, maxkp, d = 120, 160, 80, 6
+    imgs = np.stack([synth_image(H, W, 200 + s) for s in range(3)])
+    rng = np.random.RandomState(1)
+    comp = np.linalg.qr(rng.randn(256, 64))[0].T.astype(np.float32); mean = (rng.randn(256) * 0.01).astype(np.float32)
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=maxkp, input_width=W, input_height=H, max_batch=3, postproc=api.POSTPROC_A, nms_dist=d))
+    fe.load_superpoint(sp_weights)
+    plain = fe.extract_batch(imgs, cap=maxkp)
+    fe.set_pca(comp, mean)
+    withpca = fe.extract_batch(imgs, cap=maxkp)
+    for i in range(3):
+        f = orc.superpoint_forward(imgs[i], sp_weights)
+        rk, rs = orc.nms2_a(f["semi"], 0.015, d, maxkp)
+        assert len(rk) > 5 and np.array_equal(plain[i][0], rk) and np.array_equal(withpca[i][0], rk) and np.array_equal(plain[i][1], rs)
+        assert np.abs(plain[i][2] - orc.sample_a(f["desc"], rk, W, H)).max() <= 1e-6
+        assert withpca[i][2].shape == (len(rk), 64)
+        assert np.abs(withpca[i][2] - orc.sample_a(f["desc"], rk, W, H, comp, mean)).max() <= 1e-5
+    fe.close()
