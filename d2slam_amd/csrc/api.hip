@@ -269,20 +269,24 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, W, h->cfg.max_keypoints, cap, 0, d_kps, d_scores, d_idx,
                             d_n, s));
   }
-  { ProfScope ps(h, D2FE_PROF_SAMPLE, s);
+  if (!sparse) {
+    ProfScope ps(h, D2FE_PROF_SAMPLE, s);
     if (varA)
       HIP_TRY(launch_sample_a(draw.p, 256, 0, Hc, Wc, W, H, n, d_kps, d_n, cap, h->pca_dims ? h->pca_comp_t : nullptr,
-                              h->pca_mean, h->pca_dims, h->a_samp, h->a_scap, h->a_cn, d_desc, s));
-    else if (!sparse)
+                              h->pca_mean, h->pca_dims, h->a_samp, h->a_scap, h->a_cn, nullptr, 0, d_desc, s));
+    else
       HIP_TRY(launch_sample_b(draw.p, 256, 0, Hc, Wc, n, d_kps, d_n, cap, nullptr, 0, d_desc, s));
-  }
-  if (sparse) {
+  } else {
     { ProfScope ps(h, D2FE_PROF_CONVDB, s);
       HIP_TRY(launch_desc_head_sparse(d_kps, d_n, cap, Hc, Wc, n, a4b.p, 128, (long)Hc * Wc * 128, h->L[L_DA32].wpack, h->L[L_DA32].bias,
                                       h->L[L_DB32].wpack, h->L[L_DB32].bias, h->sp_flags, h->sp_slotmap, h->sp_cells, h->sp_count,
-                                      h->sp_slots, h->sp_desc, s)); }
+                                      h->sp_slots, h->sp_desc, varA ? W : 0, varA ? H : 0, s)); }
     ProfScope ps(h, D2FE_PROF_SAMPLE, s);
-    HIP_TRY(launch_sample_b(h->sp_desc, 256, 0, Hc, Wc, n, d_kps, d_n, cap, h->sp_slotmap, h->sp_slots, d_desc, s));
+    if (varA)
+      HIP_TRY(launch_sample_a(h->sp_desc, 256, 0, Hc, Wc, W, H, n, d_kps, d_n, cap, h->pca_dims ? h->pca_comp_t : nullptr,
+                              h->pca_mean, h->pca_dims, h->a_samp, h->a_scap, h->a_cn, h->sp_slotmap, h->sp_slots, d_desc, s));
+    else
+      HIP_TRY(launch_sample_b(h->sp_desc, 256, 0, Hc, Wc, n, d_kps, d_n, cap, h->sp_slotmap, h->sp_slots, d_desc, s));
   }
   h->last_w = W; h->last_h = H; h->last_n = n;
   h->last_gray = d_gray; h->last_stride = stride; h->last_istride = image_stride;
@@ -371,7 +375,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
       }
       if (alloc_f(h->a4b2, H * W * 2, B) || alloc_f(h->logits2, (H / 8) * (W / 8) * 65, B) || alloc_f(h->draw2, H * W * 4, B)) return D2FE_ERR_HIP;
     }
-    h->sparse_desc = cfg->postproc == D2FE_POSTPROC_B && !cfg->dense_descriptors;
+    h->sparse_desc = !cfg->dense_descriptors;
     { const char* e = getenv("D2FE_SPARSE_MIN_BATCH"); if (e) h->sp_min_batch = atoi(e); }
     if (h->sparse_desc) {
       const size_t ncell = (H / 8) * (W / 8);

@@ -353,14 +353,35 @@ __global__ __launch_bounds__(256) void sample_b_kernel(const float* __restrict__
 //   desc_head_sparse_kernel : 32 cells x 256 channels per workgroup: convDa (A tile of one tap staged in LDS per step),
 //                         ReLU, tile kept in LDS, convDb, raw descriptors to desc_sparse[img][slot][256]
 // -----------------------------------------------------------------------------------------------------
+// variant A corners (computeDescriptors / ATen grid_sampler, align_corners = false, zeros padding): only in-bounds cells exist
+__device__ __forceinline__ void sample_a_origin(float x, float y, int Hc, int Wc, int img_w, int img_h, float& ix, float& iy) {
+  const float gx = 2.0f * x / (float)img_w - 1.0f;
+  const float gy = 2.0f * y / (float)img_h - 1.0f;
+  ix = ((gx + 1.0f) * (float)Wc - 1.0f) / 2.0f;
+  iy = ((gy + 1.0f) * (float)Hc - 1.0f) / 2.0f;
+}
+
+// img_w > 0 selects the variant-A corner rule
 __global__ __launch_bounds__(256) void desc_mark_kernel(const float* __restrict__ kps_xy, const int32_t* __restrict__ n_kp, int cap,
-                                                        int Hc, int Wc, uint8_t* __restrict__ flags) {
+                                                        int Hc, int Wc, int img_w, int img_h, uint8_t* __restrict__ flags) {
   const int img = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
   if (k >= n_kp[img] || k >= cap) return;
   const size_t o = (size_t)img * cap + k;
+  uint8_t* f = flags + (size_t)img * Hc * Wc;
+  if (img_w > 0) {
+    float ix, iy;
+    sample_a_origin(kps_xy[2 * o], kps_xy[2 * o + 1], Hc, Wc, img_w, img_h, ix, iy);
+    const int x0 = (int)__builtin_floorf(ix), y0 = (int)__builtin_floorf(iy);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int xx = x0 + (q & 1), yy = y0 + (q >> 1);
+      if (yy >= 0 && yy < Hc && xx >= 0 && xx < Wc) f[yy * Wc + xx] = 1;
+    }
+    return;
+  }
   const SampleBCorners c = sample_b_corners(kps_xy[2 * o], kps_xy[2 * o + 1], Hc, Wc);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) flags[(size_t)img * Hc * Wc + c.iy[q] * Wc + c.ix[q]] = 1;
+  for (int q = 0; q < 4; ++q) f[c.iy[q] * Wc + c.ix[q]] = 1;
 }
 
 __global__ __launch_bounds__(1024) void desc_compact_kernel(const uint8_t* __restrict__ flags, int ncell, int max_slots,
@@ -509,11 +530,11 @@ __global__ __launch_bounds__(512) void desc_head_sparse_kernel(SparseHeadArgs a)
 hipError_t launch_desc_head_sparse(const float* kps_xy, const int32_t* n_kp, int cap, int Hc, int Wc, int n_img, const float* x,
                                    int x_cstride, long x_img_stride, const void* w_da, const float* b_da, const void* w_db,
                                    const float* b_db, uint8_t* flags, int32_t* slotmap, int32_t* cells, int32_t* count,
-                                   int max_slots, float* out, hipStream_t s) {
+                                   int max_slots, float* out, int img_w, int img_h, hipStream_t s) {
   const int ncell = Hc * Wc;
   hipError_t e = hipMemsetAsync(flags, 0, (size_t)n_img * ncell, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(desc_mark_kernel, dim3((cap + 255) / 256, n_img), dim3(256), 0, s, kps_xy, n_kp, cap, Hc, Wc, flags);
+  hipLaunchKernelGGL(desc_mark_kernel, dim3((cap + 255) / 256, n_img), dim3(256), 0, s, kps_xy, n_kp, cap, Hc, Wc, img_w, img_h, flags);
   hipLaunchKernelGGL(desc_compact_kernel, dim3(n_img), dim3(1024), 0, s, flags, ncell, max_slots, slotmap, cells, count);
   SparseHeadArgs a;
   a.x = x; a.x_cstride = x_cstride; a.x_img_stride = x_img_stride; a.w_da = w_da; a.b_da = b_da; a.w_db = w_db; a.b_db = b_db;
@@ -624,17 +645,15 @@ hipError_t launch_nms2_a(const float* semi, int H, int W, int n_img, float thr, 
 __global__ __launch_bounds__(256) void sample_a_kernel(const float* __restrict__ desc_raw, int dstride, int dcoff, int Hc,
                                                        int Wc, int img_w, int img_h, const float* __restrict__ kps_xy,
                                                        const int32_t* __restrict__ n_kp, int cap, int scap,
+                                                       const int32_t* __restrict__ slotmap, int max_slots,
                                                        float* __restrict__ samp) {
   const int img = blockIdx.y;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int k = blockIdx.x * 4 + wv;
   if (k >= n_kp[img] || k >= cap || k >= scap) return;
   const size_t o = (size_t)img * cap + k;
-  const float x = kps_xy[2 * o], y = kps_xy[2 * o + 1];
-  const float gx = 2.0f * x / (float)img_w - 1.0f;
-  const float gy = 2.0f * y / (float)img_h - 1.0f;
-  const float ix = ((gx + 1.0f) * (float)Wc - 1.0f) / 2.0f;
-  const float iy = ((gy + 1.0f) * (float)Hc - 1.0f) / 2.0f;
+  float ix, iy;
+  sample_a_origin(kps_xy[2 * o], kps_xy[2 * o + 1], Hc, Wc, img_w, img_h, ix, iy);
   const int x0 = (int)__builtin_floorf(ix), y0 = (int)__builtin_floorf(iy), x1 = x0 + 1, y1 = y0 + 1;
   const float nw = ((float)x1 - ix) * ((float)y1 - iy);
   const float ne = (ix - (float)x0) * ((float)y1 - iy);
@@ -643,7 +662,9 @@ __global__ __launch_bounds__(256) void sample_a_kernel(const float* __restrict__
   const float* base = desc_raw + (size_t)img * Hc * Wc * dstride + dcoff + lane * 4;
   auto corner = [&](int yy, int xx, float wgt, f32x4& acc) {
     if (yy < 0 || yy >= Hc || xx < 0 || xx >= Wc) return;   // zeros padding (wave-uniform branch)
-    const f32x4 v = *reinterpret_cast<const f32x4*>(base + ((size_t)yy * Wc + xx) * dstride);
+    const float* row = slotmap ? desc_raw + ((size_t)img * max_slots + slotmap[(size_t)img * Hc * Wc + yy * Wc + xx]) * 256 + lane * 4
+                               : base + ((size_t)yy * Wc + xx) * dstride;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row);
     const float nrm = __builtin_sqrtf(wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = acc[j] + (v[j] / nrm) * wgt;
@@ -716,10 +737,12 @@ __global__ __launch_bounds__(256) void finish_a_kernel(const float* __restrict__
 // samp: scratch [n_img][scap][256]; cn: scratch [n_img][256]
 hipError_t launch_sample_a(const float* desc_raw, int dstride, int dcoff, int Hc, int Wc, int img_w, int img_h, int n_img,
                            const float* kps_xy, const int32_t* n_kp, int cap, const float* comp_t, const float* mean,
-                           int pca_dims, float* samp, int scap, float* cn, float* desc_out, hipStream_t s) {
+                           int pca_dims, float* samp, int scap, float* cn, const int32_t* slotmap, int max_slots, float* desc_out,
+                           hipStream_t s) {
   const int kmax = cap < scap ? cap : scap;
   dim3 grid((kmax + 3) / 4, n_img), block(256);
-  hipLaunchKernelGGL(sample_a_kernel, grid, block, 0, s, desc_raw, dstride, dcoff, Hc, Wc, img_w, img_h, kps_xy, n_kp, cap, scap, samp);
+  hipLaunchKernelGGL(sample_a_kernel, grid, block, 0, s, desc_raw, dstride, dcoff, Hc, Wc, img_w, img_h, kps_xy, n_kp, cap, scap, slotmap,
+                     max_slots, samp);
   hipLaunchKernelGGL(chan_norm_a_kernel, dim3(n_img), block, 0, s, samp, n_kp, cap, scap, cn);
   hipLaunchKernelGGL(finish_a_kernel, grid, block, 0, s, samp, cn, n_kp, cap, scap, comp_t, mean, pca_dims, desc_out);
   return hipGetLastError();

@@ -62,10 +62,10 @@ typedef struct {
   int32_t precision;          /* d2fe_precision */
   int32_t keep_score_map;     /* 1: also write the dense H x W score map ("semi", 1.2 MB/image) for d2fe_debug_read;
                                  variant B does not need it (candidates are emitted by the softmax kernel) */
-  int32_t dense_descriptors;  /* 0 (default): variant B evaluates the descriptor head (convDa, convDb) only at the corner cells of the
+  int32_t dense_descriptors;  /* 0 (default): the descriptor head is evaluated (convDa, convDb) only at the corner cells of the
                                  selected keypoints when a call carries >= 4 images (below that the dense head is quicker; both give identical bits) -- 5 % fewer
                                  FLOPs; 1: always the dense descriptor map (d2fe_debug_read
-                                 "desc_raw" / "convPaDa" need it).  Variant A always computes the dense map. */
+                                 "desc_raw" / "convPaDa" need it). */
   int32_t async_tail;         /* 1: d2fe_superpoint_extract_device issues the convolutions on the caller's stream and the post-processing
                                  (softmax .. descriptors) on the handle's tail stream (d2fe_tail_stream), so that it runs UNDER the
                                  convolutions of the next call; outputs are complete on the tail stream -- enqueue consumers there, or

@@ -555,15 +555,22 @@ def test_variant_a_batch_and_pca(api, orc, sp_weights):
     """Variant A on a batch of 3 different frames with the 64-D PCA: every image's keypoints / descriptors equal the oracle's
     (the channel-over-keypoints normalisation of computeDescriptors is per image: batching must not mix the lists)."""
     H, W, maxkp, d = 120, 160, 80, 6
-    imgs = np.stack([synth_image(H, W, 200 + s) for s in range(3)])
+    imgs = np.stack([synth_image(H, W, 200 + s) for s in range(5)])      # 5 images per call: the sparse descriptor head runs
     rng = np.random.RandomState(1)
     comp = np.linalg.qr(rng.randn(256, 64))[0].T.astype(np.float32); mean = (rng.randn(256) * 0.01).astype(np.float32)
-    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=maxkp, input_width=W, input_height=H, max_batch=3, postproc=api.POSTPROC_A, nms_dist=d))
+    fd = api.FrontEnd(api.SuperPointConfig(max_keypoints=maxkp, input_width=W, input_height=H, max_batch=5, postproc=api.POSTPROC_A, nms_dist=d,
+                                           dense_descriptors=True))
+    fd.load_superpoint(sp_weights)
+    dense = fd.extract_batch(imgs, cap=maxkp)
+    fd.close()
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=maxkp, input_width=W, input_height=H, max_batch=5, postproc=api.POSTPROC_A, nms_dist=d))
     fe.load_superpoint(sp_weights)
     plain = fe.extract_batch(imgs, cap=maxkp)
+    for i in range(5):          # sparse head == dense map path, bit for bit
+        assert np.array_equal(plain[i][0], dense[i][0]) and np.array_equal(plain[i][2].view(np.uint32), dense[i][2].view(np.uint32))
     fe.set_pca(comp, mean)
     withpca = fe.extract_batch(imgs, cap=maxkp)
-    for i in range(3):
+    for i in range(5):
         f = orc.superpoint_forward(imgs[i], sp_weights)
         rk, rs = orc.nms2_a(f["semi"], 0.015, d, maxkp)
         assert len(rk) > 5 and np.array_equal(plain[i][0], rk) and np.array_equal(withpca[i][0], rk) and np.array_equal(plain[i][1], rs)
