@@ -23,7 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MQ = 32;         // queries per block
 constexpr int TB = 128;        // train rows per staged block (4 waves x 32)
-constexpr int KCH = 128;       // K chunk staged per pass
+constexpr int KCH = 64;        // K chunk staged per pass (64: 67 KB of LDS per block -> two blocks per CU)
 constexpr int QS = 257;        // LDS row stride of the query tile (odd -> conflict-free column reads)
 constexpr int TS = KCH + 1;    // LDS row stride of the train chunk
 constexpr int MAXDIM = 256;
@@ -47,10 +47,19 @@ __device__ __forceinline__ float exact_dist16(const float* __restrict__ q, const
                                               int lane) {
   float acc = 0.f;
   const int nfull = dim & ~15;
-  for (int j = slot; j < nfull; j += 16) {
-    const float d = q[j] - t[j];
-    const float dd = d * d;
-    acc = acc + dd;
+  // the train row comes from global memory: eight loads are issued before the first use (one L2 round trip per batch instead
+  // of one per element); the accumulation itself stays in ascending j, the oracle's order
+  for (int j0 = slot; j0 < nfull; j0 += 128) {
+    float tv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) tv[u] = j0 + 16 * u < nfull ? t[j0 + 16 * u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (j0 + 16 * u < nfull) {
+        const float d = q[j0 + 16 * u] - tv[u];
+        const float dd = d * d;
+        acc = acc + dd;
+      }
   }
   // r[l] = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l]   with slot = 4*v + l
   const int base = lane & ~15;
@@ -93,10 +102,12 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
     d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
   }
   __syncthreads();
-  if (tid < MQ) {
+  {   // |q|^2 with 8 threads per row (the prefilter distance is approximate by design: any summation order will do)
+    const int r = tid >> 3, part = tid & 7;
     float s = 0.f;
-    for (int k = 0; k < dim; ++k) s = __builtin_fmaf(Qs[tid * QS + k], Qs[tid * QS + k], s);
-    qn[tid] = s;
+    for (int k = part; k < dim; k += 8) s = __builtin_fmaf(Qs[r * QS + k], Qs[r * QS + k], s);
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (part == 0) qn[r] = s;
   }
 
   Cand top[4];
@@ -120,10 +131,12 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
         d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
       }
       __syncthreads();
-      if (tid < TB) {
-        float s = tnorm;
-        for (int k = 0; k < KCH; ++k) s = __builtin_fmaf(Ts[tid * TS + k], Ts[tid * TS + k], s);
-        tnorm = s;
+      {   // |t|^2 of the staged chunk, 2 threads per row
+        const int r = tid >> 1, part = tid & 1;
+        float s = 0.f;
+        for (int k = part; k < KCH; k += 2) s = __builtin_fmaf(Ts[r * TS + k], Ts[r * TS + k], s);
+        s += __shfl_xor(s, 1, 64);
+        tnorm += s;
       }
       // A = train rows of this wave (row = lane&31), B = queries (col = lane&31); k = 2*step + (lane>>5)
       const float* ap = Ts + (wave * 32 + (lane & 31)) * TS + (lane >> 5);
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
       for (int ks = 0; ks < KCH / 2; ++ks)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
     }
-    if (tid < TB) tn[tid] = tnorm;
+    if ((tid & 1) == 0) tn[tid >> 1] = tnorm;
     __syncthreads();
     // acc[r]: train row i = (r&3) + 8*(r>>2) + 4*(lane>>5) of this wave's 32, query j = lane&31
     const float qq = qn[lane & 31];
