@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=16, help="stereo frames per step and per GPU")
+    ap.add_argument("--frames", type=int, default=32, help="stereo frames per step and per GPU (32: 64 images per launch; throughput saturates: 16 -> 1327, 32 -> 1351 stereo fps)")
     ap.add_argument("--precision", choices=["f32", "f16x2"], default=os.environ.get("D2FE_BENCH_PRECISION", "f32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
