@@ -206,6 +206,72 @@ inline std::vector<float> getFeatureHalfImg(const std::vector<Point2f>& pts, con
   return out;
 }
 
+// ---- A8: struct fill of LoopCam::extractorImgDescDeepnet (loop_cam.cpp:619-645) -------------------------------------------------
+// Host work on <= max_keypoints points: liftProjective of the camera the keypoints live in, normalisation, NaN rejection.
+// The three camera models the shipped configurations use are restated from the reference's camera_models package
+// (camodocal): pinhole + radtan (realsense_d435), MEI / "omni" + radtan (raw fisheye), cylindrical (undistorted quadcam views).
+struct Vec3d { double x = 0, y = 0, z = 0; };
+
+struct RadTan { double k1 = 0, k2 = 0, p1 = 0, p2 = 0; };
+inline void radtanDistortion(const RadTan& d, double mx, double my, double& dx, double& dy) {   // PinholeCamera/CataCamera::distortion
+  const double mx2 = mx * mx, my2 = my * my, mxy = mx * my, rho2 = mx2 + my2;
+  const double rad = d.k1 * rho2 + d.k2 * rho2 * rho2;
+  dx = mx * rad + 2.0 * d.p1 * mxy + d.p2 * (rho2 + 2.0 * mx2);
+  dy = my * rad + 2.0 * d.p2 * mxy + d.p1 * (rho2 + 2.0 * my2);
+}
+inline void radtanUndistort(const RadTan& d, double mx_d, double my_d, double& mx_u, double& my_u) {   // the "recursive distortion model", n = 8
+  double dx, dy;
+  radtanDistortion(d, mx_d, my_d, dx, dy);
+  mx_u = mx_d - dx; my_u = my_d - dy;
+  for (int i = 1; i < 8; ++i) {
+    radtanDistortion(d, mx_u, my_u, dx, dy);
+    mx_u = mx_d - dx; my_u = my_d - dy;
+  }
+}
+// PinholeCamera::liftProjective (camera_models/src/camera_models/PinholeCamera.cc:337-395)
+inline Vec3d liftProjectivePinhole(double fx, double fy, double cx, double cy, const RadTan& d, const Point2f& p) {
+  const double mx_d = (1.0 / fx) * p.x + (-cx / fx), my_d = (1.0 / fy) * p.y + (-cy / fy);
+  double mx_u = mx_d, my_u = my_d;
+  if (d.k1 != 0 || d.k2 != 0 || d.p1 != 0 || d.p2 != 0) radtanUndistort(d, mx_d, my_d, mx_u, my_u);
+  return Vec3d{mx_u, my_u, 1.0};
+}
+// CataCamera::liftProjective (CataCamera.cc:425-487); cam as in d2fe_mei_camera
+inline Vec3d liftProjectiveMEI(const d2fe_mei_camera& c, const Point2f& p) {
+  const double mx_d = (1.0 / c.gamma1) * p.x + (-c.u0 / c.gamma1), my_d = (1.0 / c.gamma2) * p.y + (-c.v0 / c.gamma2);
+  double mx_u = mx_d, my_u = my_d;
+  const RadTan d{c.k1, c.k2, c.p1, c.p2};
+  if (d.k1 != 0 || d.k2 != 0 || d.p1 != 0 || d.p2 != 0) radtanUndistort(d, mx_d, my_d, mx_u, my_u);
+  const double xi = c.xi;
+  if (xi == 1.0) return Vec3d{mx_u, my_u, (1.0 - mx_u * mx_u - my_u * my_u) / 2.0};
+  const double rho2 = mx_u * mx_u + my_u * my_u;
+  return Vec3d{mx_u, my_u, 1.0 - xi * (rho2 + 1.0) / (xi + std::sqrt(1.0 + (1.0 - xi * xi) * rho2))};
+}
+// CylindricalCamera::liftProjective (CylindricalCamera.cc:207-220)
+inline Vec3d liftProjectiveCylindrical(double fx, double fy, double cx, double cy, const Point2f& p) {
+  const double phi = (1.0 / fx) * p.x + (-cx / fx), y_by_rho = (1.0 / fy) * p.y + (-cy / fy);
+  const double z = std::fabs(phi) > M_PI / 2 ? -1.0 : 1.0;
+  const double x = z * std::tan(phi);
+  return Vec3d{x, y_by_rho * std::sqrt(x * x + z * z), z};
+}
+
+struct Landmark { Point2f pt2d; Vec3d pt3d_norm; int index = -1; };   // index = position of the keypoint (and of its descriptor)
+// loop_cam.cpp:619-645: lift, normalise, SKIP on NaN.  The reference does not remove the skipped keypoint's descriptor (its own
+// warning, :627-629), so landmark i and descriptor i go out of step after a NaN; `index` keeps the association here.
+template <typename Lift>
+inline std::vector<Landmark> fillLandmarks(const std::vector<Point2f>& keypoints, Lift lift) {
+  std::vector<Landmark> out;
+  out.reserve(keypoints.size());
+  for (size_t i = 0; i < keypoints.size(); ++i) {
+    Vec3d P = lift(keypoints[i]);
+    const double n = std::sqrt(P.x * P.x + P.y * P.y + P.z * P.z);
+    P.x /= n; P.y /= n; P.z /= n;
+    if (std::isnan(P.x) || std::isnan(P.y) || std::isnan(P.z)) continue;
+    Landmark lm; lm.pt2d = keypoints[i]; lm.pt3d_norm = P; lm.index = (int)i;
+    out.push_back(lm);
+  }
+  return out;
+}
+
 // ---- LK tracker (opticaltrack_utils.h / .cpp) ---------------------------------------------------------------------------------
 enum TrackLRType { WHOLE_IMG_MATCH = 0, LEFT_RIGHT_IMG_MATCH = 1, RIGHT_LEFT_IMG_MATCH = 2 };
 constexpr int PYR_LEVEL = 2;          // opticaltrack_utils.h:10

@@ -67,6 +67,18 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < fast_pts.size(); ++i) { prev.lk_ids.push_back(1000 + (int64_t)i); prev.lk_local_index.push_back((int)i); prev.lk_types.push_back(0); }
   LKImageInfo cur = opticalflowTrackPyr(sp.handle(), ImageView(img1.data(), H, W), prev, WHOLE_IMG_MATCH, 200.0);
 
+  // A8: lift the keypoints of frame 0 through the three camera models (values checked against numpy by the Python side)
+  d2fe_mei_camera mei{2.2176903753419963, -0.17703529535292872, 0.7517933338735744, -0.0008911425891703079, 2.1653595535258756e-05,
+                      1162.5434300524314, 1161.839362615319, 660.6393183718625, 386.1663300322095};
+  d2fe_mei_camera mei_c = mei;   // same lens, principal point inside this test's small image; `mei` itself puts most of the image past the
+  mei_c.u0 = W / 2 + 0.3; mei_c.v0 = H / 2 + 0.2; mei_c.gamma1 = mei_c.gamma2 = 0.9 * W;   // model's valid cone -> NaN -> skipped (:625-631)
+  std::vector<double> lifts;
+  auto push = [&](const std::vector<Landmark>& v) { for (auto& l : v) { lifts.push_back(l.pt3d_norm.x); lifts.push_back(l.pt3d_norm.y); lifts.push_back(l.pt3d_norm.z); } };
+  push(fillLandmarks(k0, [&](const Point2f& p) { return liftProjectivePinhole(385.0, 386.0, 322.5, 241.0, RadTan{0.01, -0.02, 0.001, -0.0005}, p); }));
+  push(fillLandmarks(k0, [&](const Point2f& p) { return liftProjectiveMEI(mei_c, p); }));
+  push(fillLandmarks(k0, [&](const Point2f& p) { return liftProjectiveMEI(mei, p); }));
+  push(fillLandmarks(k0, [&](const Point2f& p) { return liftProjectiveCylindrical(W / 3.4906585039886591, W / 3.4906585039886591, W / 2, H / 2, p); }));
+
   FILE* fo = fopen(argv[2], "wb");
   if (!fo) return 2;
   auto flat = [](const std::vector<Point2f>& p) { std::vector<float> o; for (auto& q : p) { o.push_back(q.x); o.push_back(q.y); } return o; };
@@ -75,6 +87,7 @@ int main(int argc, char** argv) {
   wr(fo, mflat(m)); wr(fo, mflat(mc));
   wr(fo, half_idx); wr(fo, half_desc);
   wr(fo, flat(fast_pts)); wr(fo, flat(gftt_pts)); wr(fo, flat(cur.lk_pts)); wr(fo, cur.lk_ids);
+  wr(fo, lifts);
   fclose(fo);
   d2fe_lk_frame_destroy(prev.pyr);
   d2fe_lk_frame_destroy(cur.pyr);

@@ -58,8 +58,8 @@ def test_cpp_mirror_matches_oracle(tmp_path, orc, sp_weights):
     env = dict(os.environ)
     res = subprocess.run([exe, fin, fout], capture_output=True, text=True, env=env, timeout=300)
     assert res.returncode == 0, res.stderr
-    k0, s0, d0, k1, s1, d1, m, mc, hidx, hdesc, fast, gftt, lkp, lkid = _read_vecs(
-        fout, ["<f4"] * 8 + ["<i4", "<f4", "<f4", "<f4", "<f4", "<i8"])
+    k0, s0, d0, k1, s1, d1, m, mc, hidx, hdesc, fast, gftt, lkp, lkid, lifts = _read_vecs(
+        fout, ["<f4"] * 8 + ["<i4", "<f4", "<f4", "<f4", "<f4", "<i8", "<f8"])
     for img, k, s, d in ((l, k0, s0, d0), (r, k1, s1, d1)):
         rk, rs, rd, _, _ = orc.extract_b(img, sp_weights, 0.015, 1, maxkp)
         assert np.array_equal(k.reshape(-1, 2), rk) and np.array_equal(s, rs) and np.abs(d.reshape(-1, 256) - rd).max() <= 1e-6
@@ -79,6 +79,43 @@ def test_cpp_mirror_matches_oracle(tmp_path, orc, sp_weights):
     fp = fast.reshape(-1, 2)
     rp, rst = orc.lk_track(orc.pyr_build(l), orc.pyr_build(r), W, H, fp, fp)
     assert np.array_equal(lkp.reshape(-1, 2), rp[rst > 0]) and np.array_equal(lkid, 1000 + np.nonzero(rst)[0])
+    # A8 helpers of the C++ mirror: liftProjective (pinhole+radtan, MEI, cylindrical) + normalisation
+    ref = _lift_reference(ka, H, W)
+    assert lifts.shape == ref.shape and np.abs(lifts - ref).max() < 1e-12
+
+
+def _lift_reference(kps, H, W):
+    """numpy fp64 restatement of the three liftProjective models (camera_models/src/camera_models/*.cc), normalised."""
+    x, y = kps[:, 0].astype(np.float64), kps[:, 1].astype(np.float64)
+
+    def undist(mx_d, my_d, k1, k2, p1, p2):
+        mx, my = mx_d.copy(), my_d.copy()
+        for i in range(8):
+            ax, ay = (mx_d, my_d) if i == 0 else (mx, my)
+            r2 = ax * ax + ay * ay
+            rad = k1 * r2 + k2 * r2 * r2
+            dx = ax * rad + 2 * p1 * ax * ay + p2 * (r2 + 2 * ax * ax)
+            dy = ay * rad + 2 * p2 * ax * ay + p1 * (r2 + 2 * ay * ay)
+            mx, my = mx_d - dx, my_d - dy
+        return mx, my
+    out = []
+    mx, my = undist(x / 385.0 - 322.5 / 385.0, y / 386.0 - 241.0 / 386.0, 0.01, -0.02, 0.001, -0.0005)
+    out.append(np.stack([mx, my, np.ones_like(mx)], 1))
+    xi, k1, k2, p1, p2 = 2.2176903753419963, -0.17703529535292872, 0.7517933338735744, -0.0008911425891703079, 2.1653595535258756e-05
+    for g1, g2, u0, v0 in ((0.9 * W, 0.9 * W, W // 2 + 0.3, H // 2 + 0.2),
+                           (1162.5434300524314, 1161.839362615319, 660.6393183718625, 386.1663300322095)):
+        mx, my = undist(x / g1 - u0 / g1, y / g2 - v0 / g2, k1, k2, p1, p2)
+        r2 = mx * mx + my * my
+        with np.errstate(invalid="ignore"):
+            out.append(np.stack([mx, my, 1.0 - xi * (r2 + 1.0) / (xi + np.sqrt(1.0 + (1.0 - xi * xi) * r2))], 1))
+    f = W / 3.4906585039886591
+    phi = x / f - (W // 2) / f
+    z = np.where(np.abs(phi) > np.pi / 2, -1.0, 1.0)
+    X = z * np.tan(phi)
+    out.append(np.stack([X, (y / f - (H // 2) / f) * np.sqrt(X * X + z * z), z], 1))
+    out = [v / np.linalg.norm(v, axis=1, keepdims=True) for v in out]
+    out = [v[~np.isnan(v).any(1)] for v in out]      # loop_cam.cpp:625-631: a NaN lift drops the landmark
+    return np.concatenate(out).reshape(-1)
 
 
 def _thin(pts, min_dist, lack):
