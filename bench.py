@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 H, W, CAP = 480, 640, 200
 CONV1B_FLOP_PER_IMG = 2.0 * H * W * 64 * 64 * 9          # 22.65 GFLOP (SURVEY.md section 8a layer table)
 SP_FLOP_PER_IMG = 52.1e9
-PEAK_TFLOPS = {"f32": 157.3, "f16x2": 2500.0}             # MI355X_MICROARCH.md: fp32 MFMA / dense f16 MFMA
+PEAK_TFLOPS = {"f32": 157.3, "f16x2": 2500.0, "wino": 157.3}             # MI355X_MICROARCH.md: fp32 MFMA / dense f16 MFMA
 
 
 def main():
@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=32, help="stereo frames per step and per GPU (32: 64 images per launch; throughput saturates: 16 -> 1327, 32 -> 1351 stereo fps)")
-    ap.add_argument("--precision", choices=["f32", "f16x2"], default=os.environ.get("D2FE_BENCH_PRECISION", "f32"))
+    ap.add_argument("--precision", choices=["f32", "f16x2", "wino"], default=os.environ.get("D2FE_BENCH_PRECISION", "f32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--netvlad", action="store_true", help="also run the NetVLAD global descriptor on every left image (BASELINE metric with NetVLAD)")
@@ -86,7 +86,7 @@ def main():
     def run_mode(precision, want_breakdown):
         F = args.frames
         NI = 2 * F
-        prec = api.PREC_F32 if precision == "f32" else api.PREC_F16X2
+        prec = {"f32": api.PREC_F32, "f16x2": api.PREC_F16X2, "wino": api.PREC_F32_WINO}[precision]
         cfg = api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=NI, precision=prec,
                                    device_id=local_rank, async_tail=use_async_tail)
         fe = api.FrontEnd(cfg)

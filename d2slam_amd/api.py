@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libd2fe_hip.so")
 
 POSTPROC_B, POSTPROC_A = 0, 1
-PREC_F32, PREC_F16X2 = 0, 1
+PREC_F32, PREC_F16X2, PREC_F32_WINO = 0, 1, 2
 PROF_STAGES = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPaDa",
                "convPb", "convDb", "softmax_cand", "select", "sample", "match", "netvlad"]
 
@@ -77,7 +77,7 @@ EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_creat
            "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device",
            "d2fe_half_image_filter", "d2fe_undistort", "d2fe_undistort_device", "d2fe_db_create", "d2fe_db_destroy",
            "d2fe_db_ntotal", "d2fe_db_add", "d2fe_db_search", "d2fe_db_query_gated", "d2fe_quantize_int8", "d2fe_dequantize_int8",
-           "d2fe_debug_read", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read",
+           "d2fe_debug_read", "d2fe_debug_conv3x3_wino", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read",
            "d2fe_prepare_gray", "d2fe_prepare_gray_device", "d2fe_gen_cylinder_map", "d2fe_gen_cylinder_map_device", "d2fe_gen_pinhole_map", "d2fe_gen_pinhole_map_device",
            "d2fe_lk_frame_create", "d2fe_lk_frame_create_device", "d2fe_lk_frame_destroy", "d2fe_lk_frame_read_level",
            "d2fe_lk_track", "d2fe_lk_track_batch", "d2fe_detect_fast_by_region", "d2fe_good_features_to_track"]
@@ -329,6 +329,18 @@ class FrontEnd:
         if r != out.nbytes:
             raise D2FEError(-1, "debug_read size mismatch %d vs %d" % (r, out.nbytes))
         return out
+
+    def debug_conv3x3_wino(self, x, weight, bias, pool=False, relu=True, iters=0):
+        """One 3x3 layer through the Winograd kernels: x [n,H,W,Cin] NHWC, weight [Cout,Cin,3,3].  Returns (out, ms_per_launch)."""
+        x = np.ascontiguousarray(x, np.float32); weight = np.ascontiguousarray(weight, np.float32)
+        bias = np.ascontiguousarray(bias, np.float32)
+        n, H, W, cin = x.shape
+        cout = weight.shape[0]
+        out = np.empty((n, H // 2, W // 2, cout) if pool else (n, H, W, cout), np.float32)
+        ms = C.c_float(0.0)
+        _check(self._lib.d2fe_debug_conv3x3_wino(self._h, _ptr(x), n, H, W, cin, _ptr(weight), _ptr(bias), cout, int(pool),
+                                                 int(relu), _ptr(out), int(iters), C.byref(ms)))
+        return out, float(ms.value)
 
     def sync(self):
         _check(self._lib.d2fe_sync(self._h))

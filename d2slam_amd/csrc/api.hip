@@ -162,7 +162,11 @@ int pack_layer(d2fe_context* h, Layer& L, const std::vector<const d2fe_conv_para
   if (L.wpack) { hipFree(L.wpack); L.wpack = nullptr; }
   if (L.bias) { hipFree(L.bias); L.bias = nullptr; }
   int rc;
-  if (h->cfg.precision == D2FE_PREC_F32 || force_f32) {
+  if (h->cfg.precision == D2FE_PREC_F32_WINO && ks == 3 && cin >= 64 && !force_f32) {
+    std::vector<float> pk(packed_weight_floats_wino(cout_pad, cin));
+    pack_weights_wino(w.data(), cout, cin, cout_pad, pk.data());
+    rc = upload(pk.data(), pk.size() * sizeof(float), &L.wpack);
+  } else if (h->cfg.precision != D2FE_PREC_F16X2 || force_f32) {
     std::vector<float> pk(packed_weight_floats_f32(cout_pad, cin, ks));
     pack_weights_f32(w.data(), cout, cin, ks, cout_pad, pk.data());
     rc = upload(pk.data(), pk.size() * sizeof(float), &L.wpack);
@@ -219,6 +223,8 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     a.img = d_gray; a.img_stride = stride; a.img_istride = (long)image_stride; a.w1a = h->w1a; a.b1a = h->b1a;
     a.H = hh; a.W = ww; a.n_img = n; a.in_img_stride = iis; a.out_img_stride = ois; a.zeros = h->zeros;
     { static int ab = -1; if (ab < 0) { const char* e = getenv("D2FE_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
+    if (prec == D2FE_PREC_F32_WINO)   // 3x3 layers: Winograd kernels; the 1x1 heads: the exact fp32 kernels
+      return L.ks == 3 ? launch_conv_wino(L.cin, pool, relu, L.cout_pad, a, s) : launch_conv(shape, D2FE_PREC_F32, pool, relu, L.cout_pad, a, s);
     return launch_conv(shape, prec, pool, relu, L.cout_pad, a, s);
   };
   if (h->fuse1a) {
@@ -336,7 +342,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     return fail(D2FE_ERR_INVALID, "max_width/max_height must be multiples of 8");
   if (cfg->max_batch < 1) return fail(D2FE_ERR_INVALID, "max_batch < 1");
   if (cfg->max_keypoints < 1 || cfg->max_keypoints > 1024) return fail(D2FE_ERR_INVALID, "max_keypoints must be in 1..1024");
-  if (cfg->precision != D2FE_PREC_F32 && cfg->precision != D2FE_PREC_F16X2) return fail(D2FE_ERR_INVALID, "bad precision");
+  if (cfg->precision != D2FE_PREC_F32 && cfg->precision != D2FE_PREC_F16X2 && cfg->precision != D2FE_PREC_F32_WINO) return fail(D2FE_ERR_INVALID, "bad precision");
   if (cfg->postproc != D2FE_POSTPROC_B && cfg->postproc != D2FE_POSTPROC_A) return fail(D2FE_ERR_INVALID, "bad postproc");
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
@@ -347,6 +353,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   h->cfg = *cfg;
   const int rc_alloc = [&]() -> int {
   { const char* e = getenv("D2FE_FUSE1A"); if (e) h->fuse1a = atoi(e) != 0; }
+  if (h->cfg.precision == D2FE_PREC_F32_WINO) h->fuse1a = false;   // the Winograd conv1b reads the materialised conv1a activation
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     const size_t H = cfg->max_height, W = cfg->max_width;
     const int B = cfg->max_batch;
@@ -1146,6 +1153,58 @@ long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_byte
       return (long)bytes;
     }
   return fail(D2FE_ERR_INVALID, "unknown tensor name");
+}
+
+// One 3x3 layer through the Winograd kernels, host buffers in and out (layer-level parity tests and timing; not a product path).
+int d2fe_debug_conv3x3_wino(d2fe_handle h, const float* in, int n, int H, int W, int cin, const float* weight, const float* bias,
+                            int cout, int pool, int relu, float* out, int iters, float* ms_per_launch) {
+  if (!h || !in || !weight || !bias || !out) return fail(D2FE_ERR_INVALID, "null argument");
+  if ((cin != 64 && cin != 128) || cout < 1 || n < 1 || H < 2 || W < 2 || (pool && ((H | W) & 1)) || !relu)
+    return fail(D2FE_ERR_INVALID, "unsupported layer shape");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  const int cout_pad = (cout + 63) / 64 * 64;
+  const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+  const size_t in_fl = (size_t)n * H * W * cin, out_fl = (size_t)n * Ho * Wo * cout;
+  if ((size_t)H * W * cin * 4 >= (1ull << 31)) return fail(D2FE_ERR_INVALID, "image too large");
+  std::vector<float> pk(packed_weight_floats_wino(cout_pad, cin)), bp(cout_pad, 0.f);
+  pack_weights_wino(weight, cout, cin, cout_pad, pk.data());
+  memcpy(bp.data(), bias, sizeof(float) * cout);
+  float *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = [&]() -> int {
+    HIP_TRY(hipMalloc(&d_in, in_fl * 4));
+    HIP_TRY(hipMalloc(&d_out, out_fl * 4));
+    HIP_TRY(hipMalloc(&d_w, pk.size() * 4));
+    HIP_TRY(hipMalloc(&d_b, bp.size() * 4));
+    HIP_TRY(hipMemcpy(d_in, in, in_fl * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_out, 0xff, out_fl * 4));
+    ConvArgs a{};
+    a.in = d_in; a.in_cstride = cin; a.in_coff = 0; a.out = d_out; a.out_cstride = cout; a.out_coff = 0;
+    a.cout_real = cout; a.wpack = d_w; a.bias = d_b; a.H = H; a.W = W; a.n_img = n;
+    a.in_img_stride = (long)H * W * cin; a.out_img_stride = (long)Ho * Wo * cout; a.zeros = h->zeros;
+    { const char* e = getenv("D2FE_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+    HIP_TRY(launch_conv_wino(cin, pool != 0, relu != 0, cout_pad, a, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, d_out, out_fl * 4, hipMemcpyDeviceToHost));
+    if (iters > 0 && ms_per_launch) {
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      HIP_TRY(hipEventRecord(e0, h->stream));
+      for (int i = 0; i < iters; ++i) HIP_TRY(launch_conv_wino(cin, pool != 0, relu != 0, cout_pad, a, h->stream));
+      HIP_TRY(hipEventRecord(e1, h->stream));
+      HIP_TRY(hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+      *ms_per_launch = ms / iters;
+    }
+    return D2FE_OK;
+  }();
+  for (void* p : {(void*)d_in, (void*)d_out, (void*)d_w, (void*)d_b}) if (p) hipFree(p);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  return rc;
 }
 
 int d2fe_profile_enable(d2fe_handle h, int mode) {

@@ -1,0 +1,403 @@
+// conv_wino.hip -- 3x3 / stride 1 / pad 1 convolutions as Winograd F(2x2,3x3) on the fp32 matrix pipe (precision mode 2).
+//
+// Replaces the TensorRT engine execution at d2frontend/src/CNN/superpoint_tensorrt.cpp:150 for the eight 3x3 layers with
+// Cin >= 64 (network: d2frontend/superpoint.ipynb:300-374).  TensorRT itself picks Winograd kernels for such layers; the
+// reference fixes no accumulation order, so this mode fixes one (below) and the oracle restates it (orc_conv3x3_wino):
+// outputs are bit-identical to that restatement and within ~1e-6 of the direct-convolution chain of the exact mode.
+//
+// Arithmetic per 2x2 output tile and (ci, co):  Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A  -- 16 multiplies instead of 36.
+// The sum over ci for each of the 16 transform positions xi = (i,j) is a GEMM  M_xi[tile][co] = V_xi[tile][ci] U_xi[ci][co]:
+// v_mfma_f32_32x32x2_f32 with A = 32 tiles x 2 channels, B = 2 channels x 32 output channels.
+//
+// Fixed evaluation order (what the oracle restates):
+//   U = (float)(G g G^T) evaluated in double, term order (a, b) ascending;
+//   B^T d B: rows first (t0 = d0-d2, t1 = d1+d2, t2 = d2-d1, t3 = d1-d3 down each column), then the same along each row;
+//   M: one fmaf chain from +0, channels in the order 0,4,1,5,2,6,3,7 of every block of 8 (lanes 0-31 / 32-63 of the MFMA
+//      read the two 16-byte channel quads of a pixel);
+//   A^T M A: s_i0 = (m_i0 + m_i1) + m_i2, s_i1 = (m_i1 - m_i2) - m_i3; y_0b = (s_0b + s_1b) + s_2b, y_1b = (s_1b - s_2b) - s_3b;
+//   y + bias, ReLU, max-pool.
+//
+// Work split.  Measured on gfx950 (tools/ubench/mfma_f32_valu.hip): with ONE wave on a SIMD a VALU instruction between two
+// v_mfma_f32_32x32x2_f32 is not hidden -- 64.7 cycles per MFMA bare, 77.5 with two VALU per gap, 87 with four -- so the
+// input transform (2 VALU per MFMA) must come from a second wave of the same SIMD.  A wave therefore owns 32 tiles (4 x 8) x
+// 32 output channels x HALF of the transform positions (rows i = 2p, 2p+1 of M: 128 accumulator registers, 2 waves/SIMD); a
+// workgroup is 4 waves = (p, 32-channel half) and handles 8 x 16 output pixels x 64 channels, two workgroups per CU.  The
+// output transform needs all four rows of M: after the K loop each wave forms its two rows of s = M A, the partner waves swap
+// the halves belonging to the other's tiles through LDS (32 floats per lane), and each finishes A^T s, bias, ReLU, the 2x2
+// max-pool (the Winograd tile IS the pool window) and the stores for 16 of the 32 tiles.
+//
+// Data movement.  Persistent workgroups walk a list of work items; the K loop runs over chunks of 8 input channels.  A chunk of
+// the 10 x 18 input patch is brought in by LDS-DMA (buffer_load_dwordx4 ... lds: 16 bytes = 4 channels of one pixel per lane,
+// no VGPR round trip; out-of-image pixels are out-of-range buffer offsets, which read as 0) into a ring of three 8 KiB
+// buffers that runs on across work items.  LDS layout of a chunk: [channel quad 2][pixel parity plane 4][5 rows x 12 (9 used)]
+// [4 channels]: the 32 tiles of a wave read the same (dy,dx) of their 4x4 input window from ONE parity plane at positions
+// 12*ty + tx, and the tile -> MFMA-row assignment (below) makes that conflict-free for ds_read_b128's lane groups.  U streams
+// from L2 in MFMA lane order (8 values per lane per k-step, requested one k-step ahead, running on across work items).
+#include "conv_common.h"
+
+#include <cstdio>
+#include <type_traits>
+
+namespace d2fe {
+
+namespace {
+
+constexpr int WR = 3;                       // ring depth
+constexpr int WCHUNK = 2 * 4 * 64 * 4;      // floats per chunk buffer (8 KiB): [quad 2][plane 4][64 slots][4 channels]
+constexpr int WROW = 12;                    // plane row stride in positions (9 used)
+constexpr int WXCH = 4 * 8 * 64 * 4;        // floats of the epilogue exchange area: [wave 4][8 float4][64 lanes]
+
+struct WItem { int img, by, bx, cb; };
+template <int V> using IC = std::integral_constant<int, V>;
+
+__device__ __forceinline__ WItem w_decode(int t, int nbx, int nby, int ncb) {
+  WItem r;
+  r.cb = t % ncb; t /= ncb;
+  r.bx = t % nbx; t /= nbx;
+  r.by = t % nby;
+  r.img = t / nby;
+  return r;
+}
+
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+// buffer-addressed loads (SGPR resource + 32-bit lane offset + SGPR offset), kept in plain device functions
+__device__ __forceinline__ f32x4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  f32x4 o;
+  __builtin_memcpy(&o, &v, 16);
+  return o;
+}
+__device__ __forceinline__ void buf_load_lds16(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {   // LDS-DMA, 16 B per lane
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lvoid_t*)lds, 16, voff, soff, 0, 0);
+}
+
+}  // namespace
+
+// ABL 256: workgroup 0 / wave 0 records shader-clock marks (s_memtime) for its first 4 items
+__device__ long long g_wino_trace[4][16][6];
+
+// Tile <-> MFMA row.  Row t (= lane & 31 of the A operand, = (r&3) + 8*(r>>2) + 4*(lane>>5) of an accumulator register r)
+// holds tile  ty = 2*(q>>2) + parity(q),  tx = 4*((q>>1)&1) + (t&3),  q = t>>2.  ds_read_b128 serves a wave in the lane groups
+// {0-3,12-15,20-27} and {4-11,16-19,28-31} (+32): with this assignment a group holds tile rows {0,2} or {1,3}, whose
+// positions 12*ty + tx cover every residue mod 16 exactly once -- one 16-byte slot per lane, no bank conflict.
+template <int CIN, bool POOL, bool RELU, int ABL, int P>
+__device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, int ncb, int total, float* wlds) {
+  constexpr int NCH = CIN / 8;               // chunks per work item
+  constexpr int KSTEPS = CIN / 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = wave & 1;                   // 32-channel half of the 64-channel block; P = wave >> 1: rows 2P, 2P+1 of M
+  const int aH = a.H, aW = a.W, in_cs = a.in_cstride;
+
+  const int t0 = blockIdx.x, tstride = gridDim.x;
+  const int n_my = (total - t0 + tstride - 1) / tstride;
+  const int G = n_my * NCH;                  // chunks this workgroup walks through
+
+  // ---- LDS-DMA: wave w copies channel quad (w>>1), parity planes 2(w&1), 2(w&1)+1 (64 slots = one instruction each) ---------
+  struct DmaItem { __amdgpu_buffer_rsrc_t rsrc; int off[2]; };
+  const int in_bytes = aH * aW * in_cs * 4;
+  auto dma_prepare = [&](const WItem& T) {
+    DmaItem d;
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)T.img * a.in_img_stride), 0, in_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int plane = 2 * (wave & 1) + j;
+      const int Y = lane / WROW, X = lane % WROW;
+      const int gy = T.by * 8 - 1 + 2 * Y + (plane >> 1), gx = T.bx * 16 - 1 + 2 * X + (plane & 1);
+      const bool ok = Y < 5 && X < 9 && gy >= 0 && gy < aH && gx >= 0 && gx < aW;
+      d.off[j] = ok ? (gy * aW + gx) * in_cs * 4 : (int)0x80000000;     // beyond num_records: the load returns 0
+    }
+    return d;
+  };
+  const int dma_soff0 = (a.in_coff + (wave >> 1) * 4) * 4;
+  auto dma_issue = [&](const DmaItem& d, int ch, int buf) {
+    if constexpr ((ABL & 1) != 0) return;
+    float* dst = wlds + buf * WCHUNK + ((wave >> 1) * 4 + 2 * (wave & 1)) * 256;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) buf_load_lds16(d.rsrc, dst + j * 256, d.off[j], dma_soff0 + ch * 32);
+  };
+
+  // ---- per-lane constants ----------------------------------------------------------------------------------------------------
+  const int trow = lane & 31, q8 = trow >> 2, hh = lane >> 5;
+  const int ty = 2 * (q8 >> 2) + (__builtin_popcount(q8) & 1), tx = 4 * ((q8 >> 1) & 1) + (trow & 3);
+  const int rd_off = hh * 1024 + (ty * WROW + tx) * 4;       // floats: quad hh, plane 0, this lane's tile origin
+  // U: one buffer resource over the packed weights; wave-uniform byte offset of a 32-channel group's stream + lane * 16
+  const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, ncb * 2 * KSTEPS * 4096, 0x00020000);
+  auto u_ptr = [&](const WItem& T) { return (T.cb * 2 + cg) * KSTEPS * 4096; };
+  const int lane16 = lane * 16 + 2 * P * 1024;   // xi quads 2P, 2P+1 of the 4 KiB k-step record
+
+  f32x16 acc[8];           // xi = (2P + li, j) -> acc[li*4 + j]
+  f32x4 dq[12];            // dq[r*4+dx] = the 4 channels of this lane's quad at window position (dy = P + r, dx)
+  f32x4 ub[2][2];          // [k-step parity][li]: the fragments of k-step k+1 are requested before the MFMAs of k-step k
+
+  auto read_d = [&](int buf) {
+    const float* p = wlds + buf * WCHUNK + rd_off;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) {
+        const int dy = P + r;
+        dq[r * 4 + dx] = *reinterpret_cast<const f32x4*>(p + ((dy & 1) * 2 + (dx & 1)) * 256 + ((dy >> 1) * WROW + (dx >> 1)) * 4);
+      }
+  };
+  auto load_u = [&](int slot, int up, int ks) {
+    if constexpr ((ABL & 2) != 0) return;
+#pragma unroll
+    for (int li = 0; li < 2; ++li) ub[slot][li] = buf_load_f32x4(u_rsrc, lane16 + li * 1024, up + ks * 4096);
+  };
+  // rows 2P, 2P+1 of B^T d B for channel j of the quad:  P = 0: t0 = d0 - d2, t1 = d1 + d2;  P = 1: t2 = d2 - d1, t3 = d1 - d3
+  auto transform = [&](auto j_c, float (&v)[8]) {
+    constexpr int j = decltype(j_c)::value;
+    float t[2][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float r0 = dq[0 + c][j], r1 = dq[4 + c][j], r2 = dq[8 + c][j];
+      if constexpr (P == 0) { t[0][c] = r0 - r2; t[1][c] = r1 + r2; }
+      else { t[0][c] = r1 - r0; t[1][c] = r0 - r2; }
+    }
+#pragma unroll
+    for (int li = 0; li < 2; ++li) {
+      v[li * 4 + 0] = t[li][0] - t[li][2]; v[li * 4 + 1] = t[li][1] + t[li][2];
+      v[li * 4 + 2] = t[li][2] - t[li][1]; v[li * 4 + 3] = t[li][1] - t[li][3];
+    }
+  };
+  auto mfmas = [&](auto slot_c, const float (&v)[8]) {
+    constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+      acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[x], ub[slot][x >> 2][x & 3], acc[x], 0, 0, 0);
+  };
+
+  // ---- epilogue: s = M A for this wave's two rows, swap with the partner wave, A^T s, bias, ReLU, pool, store ----------------
+  float* xch = wlds + WR * WCHUNK;
+  auto epilogue = [&](const WItem& T) {
+    const int n32 = T.cb * 2 + cg;
+    const int co = n32 * 32 + (lane & 31);
+    const float bias = a.bias[co];
+    float* out = a.out + (size_t)T.img * a.out_img_stride + a.out_coff;
+    const int cs = a.out_cstride;
+    const bool cok = co < a.cout_real && !(ABL & 4);
+    f32x4 sk[8];           // kept tiles (registers r = 8P .. 8P+7): (s_l0_0, s_l0_1, s_l1_0, s_l1_1)
+    f32x4* xw = reinterpret_cast<f32x4*>(xch) + (wave * 8) * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      f32x4 sv;
+#pragma unroll
+      for (int li = 0; li < 2; ++li) {
+        const float m0 = acc[li * 4 + 0][r], m1 = acc[li * 4 + 1][r], m2 = acc[li * 4 + 2][r], m3 = acc[li * 4 + 3][r];
+        sv[li * 2 + 0] = (m0 + m1) + m2;
+        sv[li * 2 + 1] = (m1 - m2) - m3;
+      }
+      if ((r >> 3) == P) sk[r & 7] = sv; else xw[(r & 7) * 64] = sv;
+    }
+    __syncthreads();
+    const f32x4* xr = reinterpret_cast<const f32x4*>(xch) + ((wave ^ 2) * 8) * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = 8 * P + k;
+      const f32x4 o = xr[k * 64];          // the partner's rows for this tile
+      float s[4][2];
+      s[2 * P + 0][0] = sk[k][0]; s[2 * P + 0][1] = sk[k][1]; s[2 * P + 1][0] = sk[k][2]; s[2 * P + 1][1] = sk[k][3];
+      s[2 * (1 - P) + 0][0] = o[0]; s[2 * (1 - P) + 0][1] = o[1]; s[2 * (1 - P) + 1][0] = o[2]; s[2 * (1 - P) + 1][1] = o[3];
+      float y[2][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        y[0][b] = (s[0][b] + s[1][b]) + s[2][b];
+        y[1][b] = (s[1][b] - s[2][b]) - s[3][b];
+      }
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float v = y[pp][b] + bias;
+          if (RELU) v = v > 0.f ? v : 0.f;
+          y[pp][b] = v;
+        }
+      // tile of register r in this lane: q = 2*(r>>2) + hh
+      const int q = 2 * (r >> 2) + hh;
+      const int tyr = 2 * (q >> 2) + (__builtin_popcount(q) & 1), txr = 4 * ((q >> 1) & 1) + (r & 3);
+      const int oy = T.by * 8 + 2 * tyr, ox = T.bx * 16 + 2 * txr;
+      if constexpr (POOL) {
+        const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+        if (cok && oy + 1 < aH && ox + 1 < aW) out[((size_t)(oy >> 1) * (aW >> 1) + (ox >> 1)) * cs + co] = v;
+      } else {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            if (cok && oy + pp < aH && ox + b < aW) out[((size_t)(oy + pp) * aW + ox + b) * cs + co] = y[pp][b];
+      }
+    }
+    __syncthreads();         // the exchange area is free again (the next item's epilogue writes it)
+  };
+
+  // ---- prologue ---------------------------------------------------------------------------------------------------------------
+  WItem cur = w_decode(t0, nbx, nby, ncb);
+  WItem nxt = n_my > 1 ? w_decode(t0 + tstride, nbx, nby, ncb) : cur;
+  DmaItem dcur = dma_prepare(cur), dnxt = dma_prepare(nxt);
+  // chunk c of the walk belongs to item c / NCH: the DMA cursor is at most WR chunks (< NCH) ahead, i.e. in `cur` or `nxt`
+#pragma unroll
+  for (int c = 0; c < WR; ++c)
+    if (c < G) dma_issue(c < NCH ? dcur : dnxt, c % NCH, c);
+  int ucur = u_ptr(cur), unxt = u_ptr(nxt);
+  load_u(0, ucur, 0);
+  if (G > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // chunk 0 landed (younger: 2 x 2 copies + 2 U loads)
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  read_d(0);
+
+  const bool tracing = (ABL & 256) && blockIdx.x == 0 && tid == 0;
+  auto mark = [&](int item, int ch, int slot) { if constexpr ((ABL & 256) != 0) { if (tracing && item < 4) g_wino_trace[item][ch][slot] = clock64(); } };
+
+  // ---- walk: items x chunks; g counts chunks across items (ring position) ---------------------------------------------------
+  int g = 0;
+#pragma unroll 1
+  for (int item = 0; item < n_my; ++item) {
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch, ++g) {
+      const bool last_ch = ch == NCH - 1;
+      float v[8];
+      mark(item, ch, 0);
+      load_u(1, ucur, ch * 4 + 1);
+      transform(IC<0>{}, v);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(IC<0>{}, v);
+      __builtin_amdgcn_sched_barrier(0);
+      load_u(0, ucur, ch * 4 + 2);
+      transform(IC<1>{}, v);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(IC<1>{}, v);
+      __builtin_amdgcn_sched_barrier(0);
+      load_u(1, ucur, ch * 4 + 3);
+      transform(IC<2>{}, v);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(IC<0>{}, v);
+      __builtin_amdgcn_sched_barrier(0);
+      // k-step 0 of the next chunk (the next item's first chunk at an item boundary; wraps harmlessly at the very end)
+      if (last_ch) load_u(0, unxt, 0); else load_u(0, ucur, ch * 4 + 4);
+      // the last k-step: its transform frees dq, then chunk g+1 is made visible and read while its MFMAs run
+      transform(IC<3>{}, v);
+      __builtin_amdgcn_sched_barrier(0);
+      mark(item, ch, 1);
+      if (g + 1 < G) {
+        // chunk g+1 (copied WR-1 iterations ago) must have landed: the loads younger than it are this iteration's 8 U loads
+        // and the 2 copies of chunk g+2 -- loads complete in order, so "at most 10 outstanding" implies it is complete
+        if (g + 2 < G) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      mark(item, ch, 2);
+      if constexpr (!(ABL & 8)) __syncthreads();   // every wave's part of chunk g+1 is in LDS; every wave has read chunk g out of its buffer
+      mark(item, ch, 3);
+      if (g + WR < G) {
+        const int c3 = ch + WR;      // chunk g+WR of the walk, relative to the current item
+        if (c3 < NCH) dma_issue(dcur, c3, g % WR); else dma_issue(dnxt, c3 - NCH, g % WR);
+      }
+      if constexpr (!(ABL & 16)) read_d((g + 1) % WR);        // unconditional (a stale buffer after the very last chunk): no phi copies
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(IC<1>{}, v);
+    }
+    mark(item, 0, 4);
+    if constexpr (!(ABL & 32)) epilogue(cur);
+    mark(item, 0, 5);
+    cur = nxt; dcur = dnxt; ucur = unxt;
+    if (item + 2 < n_my) {
+      nxt = w_decode(t0 + (item + 2) * tstride, nbx, nby, ncb);
+      dnxt = dma_prepare(nxt);
+      unxt = u_ptr(nxt);
+    }
+  }
+}
+
+template <int CIN, bool POOL, bool RELU, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a, int nbx, int nby, int ncb, int total) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  if ((int)blockIdx.x >= total) return;
+  // the two halves of the transform positions run different (compile-time) row arithmetic; the branch is wave-uniform
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) wino_body<CIN, POOL, RELU, ABL, 0>(a, nbx, nby, ncb, total, wlds);
+  else wino_body<CIN, POOL, RELU, ABL, 1>(a, nbx, nby, ncb, total, wlds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s) {
+  if (cout_pad % 64 || (a.in_cstride & 3) || (a.in_coff & 3)) return hipErrorInvalidValue;
+  const int nbx = (a.W + 15) / 16, nby = (a.H + 7) / 8, ncb = cout_pad / 64;
+  const int total = nbx * nby * ncb * a.n_img;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return hipErrorUnknown;
+    ncu = p.multiProcessorCount;
+  }
+  const int grid = total < 2 * ncu ? total : 2 * ncu;      // two workgroups per CU (2 waves per SIMD)
+  constexpr size_t lds = (size_t)(WR * WCHUNK + WXCH) * sizeof(float);
+#define D2FE_WINO_K(K)                                                                                       \
+  do {                                                                                                      \
+    auto k = K;                                                                                             \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return e;                                                                          \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a, nbx, nby, ncb, total);                          \
+  } while (0)
+  if (a.ablate && cin == 64 && !pool && relu) {     // timing experiments through d2fe_debug_conv3x3_wino (D2FE_ABLATE)
+    switch (a.ablate) {
+      case 1: D2FE_WINO_K((conv_wino_kernel<64, false, true, 1>)); return hipGetLastError();
+      case 2: D2FE_WINO_K((conv_wino_kernel<64, false, true, 2>)); return hipGetLastError();
+      case 16: D2FE_WINO_K((conv_wino_kernel<64, false, true, 16>)); return hipGetLastError();
+      case 19: D2FE_WINO_K((conv_wino_kernel<64, false, true, 19>)); return hipGetLastError();
+      case 256: {
+        D2FE_WINO_K((conv_wino_kernel<64, false, true, 256>));
+        static int dumped = 0;
+        long long tr[4][16][6];
+        if (!dumped++ && hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_wino_trace), sizeof(tr)) == hipSuccess) {
+          for (int it = 0; it < 3; ++it) {
+            for (int c = 0; c < 8; ++c)
+              fprintf(stderr, "item %d chunk %d: 3 k-steps+transform %5lld | vmcnt wait %5lld | barrier %5lld | to next chunk start %5lld\n", it, c,
+                      tr[it][c][1] - tr[it][c][0], tr[it][c][2] - tr[it][c][1], tr[it][c][3] - tr[it][c][2],
+                      (c < 7 ? tr[it][c + 1][0] : tr[it][0][4]) - tr[it][c][3]);
+            fprintf(stderr, "item %d epilogue %5lld, item period %5lld\n", it, tr[it][0][5] - tr[it][0][4], tr[it + 1][0][0] - tr[it][0][0]);
+          }
+        }
+        return hipGetLastError();
+      }
+      default: break;
+    }
+  }
+  if (cin == 64 && pool && relu) { D2FE_WINO_K((conv_wino_kernel<64, true, true>)); return hipGetLastError(); }
+  if (cin == 64 && !pool && relu) { D2FE_WINO_K((conv_wino_kernel<64, false, true>)); return hipGetLastError(); }
+  if (cin == 128 && pool && relu) { D2FE_WINO_K((conv_wino_kernel<128, true, true>)); return hipGetLastError(); }
+  if (cin == 128 && !pool && relu) { D2FE_WINO_K((conv_wino_kernel<128, false, true>)); return hipGetLastError(); }
+#undef D2FE_WINO_K
+  return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host-side weight transform + packing:  [32-channel group][k-step][xi quad][lane] float4,
+//   float4[e] = U[xi = 4q+e][ci = 8*(ks/4) + 4*(lane>>5) + ks%4][co = group*32 + (lane&31)]
+// ---------------------------------------------------------------------------------------------------------------------
+size_t packed_weight_floats_wino(int cout_pad, int cin) { return (size_t)16 * cout_pad * cin; }
+
+void pack_weights_wino(const float* w, int cout, int cin, int cout_pad, float* dst) {
+  static const double Gm[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+  const int ksteps = cin / 2;
+  for (int grp = 0; grp < cout_pad / 32; ++grp)
+    for (int ks = 0; ks < ksteps; ++ks)
+      for (int q = 0; q < 4; ++q)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 4; ++e) {
+            const int xi = 4 * q + e, i = xi >> 2, j = xi & 3;
+            const int co = grp * 32 + (lane & 31), ci = 8 * (ks / 4) + 4 * (lane >> 5) + (ks % 4);
+            double sum = 0.0;
+            if (co < cout) {
+              const float* g = w + ((size_t)co * cin + ci) * 9;
+              for (int p = 0; p < 3; ++p)
+                for (int r = 0; r < 3; ++r) sum += Gm[i][p] * Gm[j][r] * (double)g[p * 3 + r];
+            }
+            dst[((((size_t)grp * ksteps + ks) * 4 + q) * 64 + lane) * 4 + e] = (float)sum;
+          }
+}
+
+}  // namespace d2fe

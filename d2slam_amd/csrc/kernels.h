@@ -38,6 +38,11 @@ hipError_t launch_conv(ConvShape shape, int precision, bool pool, bool relu, int
 // persistent producer/consumer kernels (conv_pc.hip); same arithmetic, selected by D2FE_CONV_PC (default 2: every layer but the fused conv1a+conv1b)
 hipError_t launch_conv_pc(ConvShape shape, int precision, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s);
 
+// Winograd F(2x2,3x3) fp32 kernels (conv_wino.hip, precision mode 2): 3x3 layers with Cin 64 / 128, cout_pad a multiple of 64
+hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s);
+size_t packed_weight_floats_wino(int cout_pad, int cin);
+void pack_weights_wino(const float* w /*[cout][cin][3][3]*/, int cout, int cin, int cout_pad, float* dst);
+
 // conv1a: u8 gray [n][H][stride] -> NHWC fp32 [n][H][W][64], fused (float)u8 * (1/255), bias, ReLU.
 hipError_t launch_conv1a(const uint8_t* img, int stride, long img_stride_bytes, int H, int W, int n,
                          const float* w9x64 /*[9][64]*/, const float* bias, float* out, hipStream_t s);

@@ -43,7 +43,10 @@ typedef enum {
 
 typedef enum {
   D2FE_PREC_F32 = 0,   /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): bitwise equal to the oracle's fmaf chains */
-  D2FE_PREC_F16X2 = 1  /* fp16 hi/lo split operands, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate (~2^-22 rel.) */
+  D2FE_PREC_F16X2 = 1, /* fp16 hi/lo split operands, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate (~2^-22 rel.) */
+  D2FE_PREC_F32_WINO = 2 /* fp32 throughout; the eight 3x3 layers with Cin >= 64 as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32
+                            (16 instead of 36 multiplies per output and channel pair).  Bitwise equal to the oracle's restatement
+                            of that evaluation order (orc_conv3x3_wino), ~1e-6 relative to the direct chains of D2FE_PREC_F32 */
 } d2fe_precision;
 
 /* Mirrors SuperPointConfig (d2frontend/include/d2frontend/CNN/superpoint_tensorrt.h:17-33) plus the
@@ -308,6 +311,11 @@ D2FE_API int d2fe_good_features_to_track(d2fe_handle h, d2fe_lk_frame f, int max
 /* Debug/inspection: copy an internal device tensor of the last extract call to the host.
  * names: "conv1a".."conv4b","convPaDa","logits","desc_raw","semi".  Returns bytes copied or <0. */
 D2FE_API long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_bytes);
+/* One 3x3 / pad 1 layer (cin 64 or 128, ReLU, optional 2x2 max-pool) through the Winograd kernels of D2FE_PREC_F32_WINO, host
+ * NHWC buffers in and out; iters > 0 also times `iters` back-to-back launches (HIP events on the handle's stream).  For the
+ * layer-level parity tests (tests/test_wino.py) and tools/; the product path is d2fe_superpoint_extract*. */
+D2FE_API int d2fe_debug_conv3x3_wino(d2fe_handle h, const float* in, int n, int H, int W, int cin, const float* weight,
+                                     const float* bias, int cout, int pool, int relu, float* out, int iters, float* ms_per_launch);
 
 /* Stage timing with HIP events recorded on the stream the kernels run on.
  * mode 0 = off, 1 = bracket only the dominant kernel (conv1b), 2 = bracket every stage.

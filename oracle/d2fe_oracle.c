@@ -98,6 +98,92 @@ ORC_API void orc_conv(const float* in, int h, int w, int cin, const float* wgt, 
   free(wt);
 }
 
+/* 3x3 / stride 1 / pad 1 convolution evaluated as Winograd F(2x2,3x3) in fp32 -- the restatement of the HIP library's
+ * precision mode 2 (d2slam_amd/csrc/conv_wino.hip).  The reference leaves the algorithm and the accumulation order of its
+ * convolutions to TensorRT (superpoint_tensorrt.cpp:150), which itself selects Winograd kernels for such layers; this
+ * function fixes ONE order so that the GPU result can be compared bit for bit, and tests/ hold it to orc_conv (the direct
+ * chain) within a few 1e-6 relative:
+ *   U[xi=(i,j)][ci][co] = (float) sum_{a,b ascending} G[i][a] G[j][b] g[co][ci][a][b]   (double)
+ *   V = B^T d B per 4x4 input window d (zero outside the image): down the columns first
+ *       t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3, then the same along each row
+ *   M[xi][co] = fmaf chain from +0 over ci in the order 0,4,1,5,2,6,3,7 of each block of 8
+ *   A^T M A: s_i0 = (m_i0 + m_i1) + m_i2, s_i1 = (m_i1 - m_i2) - m_i3; y_0b = (s_0b + s_1b) + s_2b, y_1b = (s_1b - s_2b) - s_3b
+ *   out = y + bias, optional ReLU.            cin must be a multiple of 8. */
+ORC_API void orc_conv3x3_wino(const float* in, int h, int w, int cin, const float* wgt, const float* bias, int cout, int relu,
+                              float* out) {
+  static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+  float* U = (float*)malloc(sizeof(float) * 16 * (size_t)cin * cout);   /* [xi][ci][co] */
+  for (int xi = 0; xi < 16; ++xi)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int co = 0; co < cout; ++co) {
+        const float* g = wgt + ((size_t)co * cin + ci) * 9;
+        double s = 0.0;
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) s += G[xi >> 2][a] * G[xi & 3][b] * (double)g[a * 3 + b];
+        U[((size_t)xi * cin + ci) * cout + co] = (float)s;
+      }
+  const int th = (h + 1) / 2, tw = (w + 1) / 2;
+#pragma omp parallel for schedule(static)
+  for (int ty = 0; ty < th; ++ty) {
+    float* V = (float*)malloc(sizeof(float) * 16 * cin);
+    float* M = (float*)malloc(sizeof(float) * 16 * cout);
+    for (int tx = 0; tx < tw; ++tx) {
+      for (int ci = 0; ci < cin; ++ci) {
+        float d[4][4], t[4][4];
+        for (int r = 0; r < 4; ++r)
+          for (int c = 0; c < 4; ++c) {
+            const int yy = 2 * ty - 1 + r, xx = 2 * tx - 1 + c;
+            d[r][c] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? in[((size_t)yy * w + xx) * cin + ci] : 0.f;
+          }
+        for (int c = 0; c < 4; ++c) {
+          t[0][c] = d[0][c] - d[2][c]; t[1][c] = d[1][c] + d[2][c];
+          t[2][c] = d[2][c] - d[1][c]; t[3][c] = d[1][c] - d[3][c];
+        }
+        for (int i = 0; i < 4; ++i) {
+          V[(i * 4 + 0) * cin + ci] = t[i][0] - t[i][2]; V[(i * 4 + 1) * cin + ci] = t[i][1] + t[i][2];
+          V[(i * 4 + 2) * cin + ci] = t[i][2] - t[i][1]; V[(i * 4 + 3) * cin + ci] = t[i][1] - t[i][3];
+        }
+      }
+      for (int xi = 0; xi < 16; ++xi) {
+        float* m = M + (size_t)xi * cout;
+        for (int co = 0; co < cout; ++co) m[co] = 0.f;
+        for (int c8 = 0; c8 < cin; c8 += 8)
+          for (int j = 0; j < 4; ++j)
+            for (int hh = 0; hh < 2; ++hh) {
+              const int ci = c8 + 4 * hh + j;
+              const float v = V[xi * cin + ci];
+              const float* u = U + ((size_t)xi * cin + ci) * cout;
+              for (int co = 0; co < cout; ++co) m[co] = fmaf(v, u[co], m[co]);
+            }
+      }
+      for (int co = 0; co < cout; ++co) {
+        float s[4][2], y[2][2];
+        for (int i = 0; i < 4; ++i) {
+          const float m0 = M[(i * 4 + 0) * cout + co], m1 = M[(i * 4 + 1) * cout + co], m2 = M[(i * 4 + 2) * cout + co],
+                      m3 = M[(i * 4 + 3) * cout + co];
+          s[i][0] = (m0 + m1) + m2;
+          s[i][1] = (m1 - m2) - m3;
+        }
+        for (int b = 0; b < 2; ++b) {
+          y[0][b] = (s[0][b] + s[1][b]) + s[2][b];
+          y[1][b] = (s[1][b] - s[2][b]) - s[3][b];
+        }
+        for (int p = 0; p < 2; ++p)
+          for (int b = 0; b < 2; ++b) {
+            const int oy = 2 * ty + p, ox = 2 * tx + b;
+            if (oy >= h || ox >= w) continue;
+            float v = y[p][b] + bias[co];
+            if (relu) v = v > 0.f ? v : 0.f;
+            out[((size_t)oy * w + ox) * cout + co] = v;
+          }
+      }
+    }
+    free(V);
+    free(M);
+  }
+  free(U);
+}
+
 /* MaxPool2d(kernel 2, stride 2), NHWC.  superpoint.ipynb:304,336,339,342 */
 ORC_API void orc_maxpool2(const float* in, int h, int w, int c, float* out) {
   const int ho = h / 2, wo = w / 2;

@@ -65,6 +65,17 @@ def conv(x, wgt, bias, relu):
     return out
 
 
+def conv_wino(x, wgt, bias, relu):
+    """3x3 conv as Winograd F(2x2,3x3) in the evaluation order of the HIP library's precision mode 2 (orc_conv3x3_wino)."""
+    x = _f(x); wgt = _f(wgt); bias = _f(bias)
+    h, w, cin = x.shape
+    cout, cin2, k, _ = wgt.shape
+    assert cin == cin2 and k == 3 and cin % 8 == 0
+    out = np.empty((h, w, cout), np.float32)
+    lib().orc_conv3x3_wino(_p(x), h, w, cin, _p(wgt), _p(bias), cout, int(relu), _p(out))
+    return out
+
+
 def maxpool2(x):
     x = _f(x)
     h, w, c = x.shape
@@ -95,25 +106,27 @@ def l2norm_rows(x):
     return out.reshape(shp)
 
 
-def superpoint_forward(img_u8, weights, return_trunk=False):
+def superpoint_forward(img_u8, weights, return_trunk=False, wino=False):
     """A1+A2 (d2frontend/superpoint.ipynb:300-374). Returns semi [H,W], desc_map [H/8,W/8,256] (normalised),
-    plus raw logits / raw desc for finer-grained checks."""
+    plus raw logits / raw desc for finer-grained checks.  wino=True: the eight 3x3 layers with Cin >= 64 in the Winograd
+    evaluation order of the HIP library's precision mode 2 (conv1a and the 1x1 heads are the same chains in every mode)."""
     x = prep_u8(img_u8)[:, :, None]
     w = weights
+    c3 = conv_wino if wino else conv
     x = conv(x, *w["conv1a"], True)
-    x = conv(x, *w["conv1b"], True)
+    x = c3(x, *w["conv1b"], True)
     x = maxpool2(x)
-    x = conv(x, *w["conv2a"], True)
-    x = conv(x, *w["conv2b"], True)
+    x = c3(x, *w["conv2a"], True)
+    x = c3(x, *w["conv2b"], True)
     x = maxpool2(x)
-    x = conv(x, *w["conv3a"], True)
-    x = conv(x, *w["conv3b"], True)
+    x = c3(x, *w["conv3a"], True)
+    x = c3(x, *w["conv3b"], True)
     x = maxpool2(x)
-    x = conv(x, *w["conv4a"], True)
-    x = conv(x, *w["conv4b"], True)
-    cpa = conv(x, *w["convPa"], True)
+    x = c3(x, *w["conv4a"], True)
+    x = c3(x, *w["conv4b"], True)
+    cpa = c3(x, *w["convPa"], True)
     logits = conv(cpa, *w["convPb"], False)
-    cda = conv(x, *w["convDa"], True)
+    cda = c3(x, *w["convDa"], True)
     draw = conv(cda, *w["convDb"], False)
     semi = softmax_semi(logits)
     desc = l2norm_rows(draw)
