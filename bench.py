@@ -35,7 +35,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=32, help="stereo frames per step and per GPU (32: 64 images per launch; throughput saturates: 16 -> 1327, 32 -> 1351 stereo fps)")
-    ap.add_argument("--precision", choices=["f32", "f16x2", "wino"], default=os.environ.get("D2FE_BENCH_PRECISION", "f32"))
+    ap.add_argument("--precision", choices=["f32", "f16x2", "wino"], default=os.environ.get("D2FE_BENCH_PRECISION", "wino"),
+                    help="wino: fp32, 3x3 layers as Winograd F(2x2,3x3) on the fp32 MFMA pipe (headline); f32: direct convolutions, "
+                         "bitwise equal to the oracle's fmaf chains; f16x2: fp16 hi/lo split operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--netvlad", action="store_true", help="also run the NetVLAD global descriptor on every left image (BASELINE metric with NetVLAD)")
@@ -205,18 +207,30 @@ def main():
 
         c1b_ms, c1b_n = prof["conv1b"]
         avg_ms = c1b_ms / max(c1b_n, 1)
-        achieved = CONV1B_FLOP_PER_IMG * NI / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         peak = PEAK_TFLOPS[precision]
-        roofline = {"kernel": "conv_%s_kernel<64,3,4,32,2,2,2,1,POOL,RELU,FUSE1A> (conv1a fused into conv1b)" % ("f32" if precision == "f32" else "f16x2"),
-                    "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4),
-                    # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE in KiB, gfx950 correction; profiles/README.md):
-                    # 2*39.3e3 + 614.4e3 KiB per 32-image launch = 22.2 MB/image in both precisions (19.7 MB of it is the pooled output)
-                    "traffic": 22.2e6 * NI,
-                    "avg_launch_ms": round(avg_ms, 4), "launches": c1b_n,
-                    "algorithmic_flop_per_launch": CONV1B_FLOP_PER_IMG * NI,
-                    "note": "algorithmic FLOPs (2*MACs); f16x2 executes 3 MFMA FLOPs per algorithmic FLOP"}
-
+        if precision == "wino":
+            # Winograd F(2x2,3x3) executes 16 multiply-adds where the direct convolution has 36: `achieved` is the EXECUTED
+            # MFMA rate (what the matrix pipe does; this is the hardware roofline fraction), the direct-equivalent rate beside it
+            executed = CONV1B_FLOP_PER_IMG * NI * 16.0 / 36.0
+            achieved = executed / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            roofline = {"kernel": "conv_wino_kernel<64,POOL,RELU> (conv1b as Winograd F(2x2,3x3); conv1a materialised by conv1a_kernel)",
+                        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                        "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": c1b_n,
+                        "algorithmic_flop_per_launch": CONV1B_FLOP_PER_IMG * NI, "executed_mfma_flop_per_launch": executed,
+                        "direct_equivalent_tflops": round(achieved * 2.25, 2),
+                        "note": "achieved = executed MFMA FLOPs (algorithmic direct-convolution FLOPs x 16/36) / HIP-event time; "
+                                "direct_equivalent_tflops = algorithmic FLOPs / time (exceeds the fp32 MFMA peak: the algorithm does less work)"}
+        else:
+            achieved = CONV1B_FLOP_PER_IMG * NI / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            roofline = {"kernel": "conv_%s_kernel<64,3,4,32,2,2,2,1,POOL,RELU,FUSE1A> (conv1a fused into conv1b)" % ("f32" if precision == "f32" else "f16x2"),
+                        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4),
+                        # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE in KiB, gfx950 correction; profiles/README.md):
+                        # 2*39.3e3 + 614.4e3 KiB per 32-image launch = 22.2 MB/image in both precisions (19.7 MB of it is the pooled output)
+                        "traffic": 22.2e6 * NI,
+                        "avg_launch_ms": round(avg_ms, 4), "launches": c1b_n,
+                        "algorithmic_flop_per_launch": CONV1B_FLOP_PER_IMG * NI,
+                        "note": "algorithmic FLOPs (2*MACs); f16x2 executes 3 MFMA FLOPs per algorithmic FLOP"}
 
         # keep image 0's result (left frame of stereo frame 0) for the in-run parity check against the oracle
         k0 = int(cnt[0].item())
@@ -226,9 +240,11 @@ def main():
                     breakdown=breakdown, NI=NI, NP=NP, F=F)
 
     primary = run_mode(args.precision, True)   # the per-stage pass (5 extra untimed steps, rank 0 / N=1 only) feeds hbm_kernels
-    other = None
+    others = {}
     if not args.single_mode:
-        other = run_mode("f16x2" if args.precision == "f32" else "f32", False)
+        for om in ("f32", "f16x2", "wino"):
+            if om != args.precision:
+                others[om] = run_mode(om, False)
     value, ms_per_step, roofline = primary["value"], primary["ms_per_step"], primary["roofline"]
     n_kp, n_match, breakdown, NI, NP, F = (primary[k] for k in ("n_kp", "n_match", "breakdown", "NI", "NP", "F"))
 
@@ -236,8 +252,12 @@ def main():
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline, ofirst = run_cpu_baseline(weights, args.cpu_seconds)
+        if args.precision == "wino":    # the oracle's restatement of the Winograd evaluation order for the same image
+            from oracle import oracle as orc
+            from d2slam_amd.synth import synth_stereo as _ss
+            ofirst = orc.extract_b(_ss(H, W, seed=0)[0], weights, 0.015, 1, CAP, wino=True)[:3]
         gk, gs, gd = primary["first"]
-        parity = {"checked": "left image of stereo frame 0 vs oracle (same run)",
+        parity = {"checked": "left image of stereo frame 0 vs oracle (same run%s)" % ("; oracle in the mode's Winograd evaluation order, descriptors of the sparse head are direct chains" if args.precision == "wino" else ""),
                   "keypoints_equal": bool(gk.shape == ofirst[0].shape and np.array_equal(gk, ofirst[0])),
                   "scores_equal": bool(gs.shape == ofirst[1].shape and np.array_equal(gs, ofirst[1])),
                   "desc_max_abs_diff": float(np.abs(gd - ofirst[2]).max()) if gd.shape == ofirst[2].shape else None}
@@ -247,7 +267,7 @@ def main():
             "metric": "stereo frames/sec SuperPoint+match, 640x480 stereo",
             "value": round(value, 2), "unit": "stereo_frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16x2(hi+lo split)/f32-acc",
+            "vs_baseline": None, "dtype": {"f32": "f32", "f16x2": "f16x2(hi+lo split)/f32-acc", "wino": "f32"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "configs[1]: realsense_d435 stereo 640x480, 200 keypoints/frame, SuperPoint (both "
                                    "images) + matchKNN L<->R and L<->prevL" + ("; + RCCL all-gather and cross-agent matchKNN" if world > 1 else ""),
@@ -258,13 +278,15 @@ def main():
             "avg_keypoints_per_image": round(n_kp, 1), "avg_matches_per_pair": round(n_match, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }
-        if other is not None:
-            om = "f16x2" if args.precision == "f32" else "f32"
-            out["fast_mode" if om == "f16x2" else "exact_mode"] = {
-                "precision": om, "value": round(other["value"], 2), "unit": "stereo_frames/s",
-                "ms_per_step": round(other["ms_per_step"], 3), "roofline": other["roofline"],
-                "parity": ("descriptors <= 1e-4 (measured ~3e-7), scores <= 1e-5; keypoint indices equal except at score near-ties"
-                           if om == "f16x2" else "bitwise vs oracle (activations, scores, indices, matches)")}
+        PAR = {"f32": "bitwise vs oracle (activations, scores, indices, matches)",
+               "f16x2": "descriptors <= 1e-4 (measured ~3e-7), scores <= 1e-5; keypoint indices equal except at score near-ties",
+               "wino": "bitwise vs the oracle's restatement of the Winograd evaluation order; vs the direct chains: scores <= 3e-6, "
+                       "descriptors <= 1e-5, keypoint indices equal except at score near-ties"}
+        for om, o in others.items():
+            out[{"f32": "exact_mode", "f16x2": "fast_mode", "wino": "wino_mode"}[om]] = {
+                "precision": om, "value": round(o["value"], 2), "unit": "stereo_frames/s",
+                "ms_per_step": round(o["ms_per_step"], 3), "roofline": o["roofline"], "parity": PAR[om]}
+        out["mode_parity"] = PAR[args.precision]
         if breakdown:
             out["stage_ms"] = breakdown
             # HBM-bound tail of the path: algorithmic bytes per launch / HIP-event time of the stage.
@@ -295,7 +317,7 @@ def run_quadcam(args, torch, api, weights, dev, local_rank, rank, world):
     RH, RW, UH, UW, CAPQ = 800, 1280, 400, 800, 100
     Q = max(1, args.frames // 4)          # quad frames per step
     NI = 4 * Q
-    prec = api.PREC_F32 if args.precision == "f32" else api.PREC_F16X2
+    prec = {"f32": api.PREC_F32, "f16x2": api.PREC_F16X2, "wino": api.PREC_F32_WINO}[args.precision]
     fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAPQ, input_width=UW, input_height=UH, max_batch=NI, precision=prec,
                                            keypoint_threshold=0.15, device_id=local_rank))
     fe.load_superpoint(synthetic_sp_for_threshold(weights))
@@ -359,14 +381,16 @@ def run_quadcam(args, torch, api, weights, dev, local_rank, rank, world):
     avg_ms = c1b_ms / max(c1b_n, 1)
     flop = 2.0 * UH * UW * 64 * 576 * NI
     peak = PEAK_TFLOPS[args.precision]
+    wf = 16.0 / 36.0 if args.precision == "wino" else 1.0      # Winograd executes 16 of the direct convolution's 36 multiply-adds
     out = {"metric": "quad frames/sec undistort+SuperPoint+NetVLAD+match, 4x(1280x800->800x400)", "value": round(Q * args.steps / el, 2),
            "unit": "quad_frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
            "config": {"workload": "configs[2]: quadcam FOURCORNER_FISHEYE 1280x800 x4 virtual cams, undistort + SuperPoint + NetVLAD + "
                                   "neighbour/temporal matchKNN, 1 MI355X", "quad_frames_per_step": Q, "max_keypoints": CAPQ, "threshold": 0.15},
            "avg_keypoints_per_image": round(cnt[:NI].float().mean().item(), 1), "avg_matches_per_pair": round(mn.float().mean().item(), 1),
-           "roofline": {"kernel": "conv1a+conv1b fused", "bound": "mfma", "achieved": round(flop / (avg_ms * 1e-3) / 1e12, 2) if avg_ms else 0,
-                        "peak": peak, "unit": "TFLOP/s", "frac": round(flop / (avg_ms * 1e-3) / 1e12 / peak, 4) if avg_ms else 0, "traffic": None},
+           "roofline": {"kernel": "conv1b (Winograd; executed MFMA FLOPs)" if args.precision == "wino" else "conv1a+conv1b fused", "bound": "mfma",
+                        "achieved": round(flop * wf / (avg_ms * 1e-3) / 1e12, 2) if avg_ms else 0,
+                        "peak": peak, "unit": "TFLOP/s", "frac": round(flop * wf / (avg_ms * 1e-3) / 1e12 / peak, 4) if avg_ms else 0, "traffic": None},
            "cpu_baseline": None}
     print(json.dumps(out), flush=True)
     fe.close()

@@ -68,6 +68,9 @@ __device__ __forceinline__ f32x4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, int vo
   __builtin_memcpy(&o, &v, 16);
   return o;
 }
+__device__ __forceinline__ void buf_store_f32(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
 __device__ __forceinline__ void buf_load_lds16(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {   // LDS-DMA, 16 B per lane
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lvoid_t*)lds, 16, voff, soff, 0, 0);
 }
@@ -129,7 +132,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
 
   f32x16 acc[8];           // xi = (2P + li, j) -> acc[li*4 + j]
   f32x4 dq[12];            // dq[r*4+dx] = the 4 channels of this lane's quad at window position (dy = P + r, dx)
-  f32x4 ub[2][2];          // [k-step parity][li]: the fragments of k-step k+1 are requested before the MFMAs of k-step k
+  f32x4 ub[4][2];          // [k-step of the chunk][li]: the fragments of k-step k+2 are requested before the MFMAs of k-step k
 
   auto read_d = [&](int buf) {
     const float* p = wlds + buf * WCHUNK + rd_off;
@@ -178,6 +181,14 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     float* out = a.out + (size_t)T.img * a.out_img_stride + a.out_coff;
     const int cs = a.out_cstride;
     const bool cok = co < a.cout_real && !(ABL & 4);
+    // fast path (item inside the image, all 32 channels real): buffer stores, wave-uniform offsets on the SALU
+    const int cs4 = cs * 4;
+    const bool full = T.by * 8 + 8 <= aH && T.bx * 16 + 16 <= aW && (n32 + 1) * 32 <= a.cout_real && !(ABL & 4);
+    const int Wo = POOL ? (aW >> 1) : aW, Ho = POOL ? (aH >> 1) : aH;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, Ho * Wo * cs4, 0x00020000);
+    const int rowpair = (POOL ? Wo : 2 * Wo) * cs4;               // bytes between tile rows ty and ty + 1
+    const int vo0 = (lane & 31) * 4 + hh * rowpair, vo1 = (lane & 31) * 4 + (1 - hh) * rowpair;
+    const int obase = ((POOL ? T.by * 4 * Wo + T.bx * 8 : T.by * 8 * Wo + T.bx * 16)) * cs4 + n32 * 128;
     f32x4 sk[8];           // kept tiles (registers r = 8P .. 8P+7): (s_l0_0, s_l0_1, s_l1_0, s_l1_1)
     f32x4* xw = reinterpret_cast<f32x4*>(xch) + (wave * 8) * 64 + lane;
 #pragma unroll
@@ -193,9 +204,9 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     }
     __syncthreads();
     const f32x4* xr = reinterpret_cast<const f32x4*>(xch) + ((wave ^ 2) * 8) * 64 + lane;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int r = 8 * P + k;
+    auto finish_tile = [&](auto k_c) {
+      constexpr int k = decltype(k_c)::value;
+      constexpr int r = 8 * P + k;
       const f32x4 o = xr[k * 64];          // the partner's rows for this tile
       float s[4][2];
       s[2 * P + 0][0] = sk[k][0]; s[2 * P + 0][1] = sk[k][1]; s[2 * P + 1][0] = sk[k][2]; s[2 * P + 1][1] = sk[k][3];
@@ -214,21 +225,38 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
           if (RELU) v = v > 0.f ? v : 0.f;
           y[pp][b] = v;
         }
-      // tile of register r in this lane: q = 2*(r>>2) + hh
-      const int q = 2 * (r >> 2) + hh;
-      const int tyr = 2 * (q >> 2) + (__builtin_popcount(q) & 1), txr = 4 * ((q >> 1) & 1) + (r & 3);
-      const int oy = T.by * 8 + 2 * tyr, ox = T.bx * 16 + 2 * txr;
-      if constexpr (POOL) {
-        const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
-        if (cok && oy + 1 < aH && ox + 1 < aW) out[((size_t)(oy >> 1) * (aW >> 1) + (ox >> 1)) * cs + co] = v;
+      // tile of register r in this lane: q = 2*(r>>2) + hh -> ty = 2*(r>>3) + (parity(r>>2) ^ hh), tx = 4*((r>>2)&1) + (r&3)
+      constexpr int par = ((r >> 2) ^ (r >> 3)) & 1;
+      const int txr = 4 * ((r >> 2) & 1) + (r & 3);
+      if (full) {
+        // interior item: uniform byte offset (SALU) + one of two per-lane offsets (channel, and the tile row this lane half holds)
+        const int vo = par ? vo1 : vo0;
+        if constexpr (POOL) {
+          const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+          buf_store_f32(v, orsrc, vo, obase + ((2 * (r >> 3)) * (aW >> 1) + txr) * cs4);
+        } else {
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) buf_store_f32(y[pp][b], orsrc, vo, obase + ((4 * (r >> 3) + pp) * aW + 2 * txr + b) * cs4);
+        }
       } else {
+        const int tyr = 2 * (r >> 3) + (par ^ hh);
+        const int oy = T.by * 8 + 2 * tyr, ox = T.bx * 16 + 2 * txr;
+        if constexpr (POOL) {
+          const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+          if (cok && oy + 1 < aH && ox + 1 < aW) out[((size_t)(oy >> 1) * (aW >> 1) + (ox >> 1)) * cs + co] = v;
+        } else {
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp)
+          for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
-            if (cok && oy + pp < aH && ox + b < aW) out[((size_t)(oy + pp) * aW + ox + b) * cs + co] = y[pp][b];
+            for (int b = 0; b < 2; ++b)
+              if (cok && oy + pp < aH && ox + b < aW) out[((size_t)(oy + pp) * aW + ox + b) * cs + co] = y[pp][b];
+        }
       }
-    }
+    };
+    finish_tile(IC<0>{}); finish_tile(IC<1>{}); finish_tile(IC<2>{}); finish_tile(IC<3>{});
+    finish_tile(IC<4>{}); finish_tile(IC<5>{}); finish_tile(IC<6>{}); finish_tile(IC<7>{});
     __syncthreads();         // the exchange area is free again (the next item's epilogue writes it)
   };
 
@@ -242,7 +270,8 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     if (c < G) dma_issue(c < NCH ? dcur : dnxt, c % NCH, c);
   int ucur = u_ptr(cur), unxt = u_ptr(nxt);
   load_u(0, ucur, 0);
-  if (G > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // chunk 0 landed (younger: 2 x 2 copies + 2 U loads)
+  load_u(1, ucur, 1);
+  if (G > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // chunk 0 landed (younger: 2 x 2 copies + 4 U loads)
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   read_d(0);
@@ -263,23 +292,23 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
       const bool last_ch = ch == NCH - 1;
       float v[8];
       mark(item, ch, 0);
-      load_u(1, ucur, ch * 4 + 1);
+      load_u(2, ucur, ch * 4 + 2);
       transform(IC<0>{}, v);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(IC<0>{}, v);
       __builtin_amdgcn_sched_barrier(0);
-      load_u(0, ucur, ch * 4 + 2);
+      load_u(3, ucur, ch * 4 + 3);
       transform(IC<1>{}, v);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(IC<1>{}, v);
       __builtin_amdgcn_sched_barrier(0);
-      load_u(1, ucur, ch * 4 + 3);
+      // k-steps 0 and 1 of the next chunk (the next item's first chunk at an item boundary; wraps harmlessly at the very end)
+      if (last_ch) load_u(0, unxt, 0); else load_u(0, ucur, ch * 4 + 4);
       transform(IC<2>{}, v);
       __builtin_amdgcn_sched_barrier(0);
-      mfmas(IC<0>{}, v);
+      mfmas(IC<2>{}, v);
       __builtin_amdgcn_sched_barrier(0);
-      // k-step 0 of the next chunk (the next item's first chunk at an item boundary; wraps harmlessly at the very end)
-      if (last_ch) load_u(0, unxt, 0); else load_u(0, ucur, ch * 4 + 4);
+      if (last_ch) load_u(1, unxt, 1); else load_u(1, ucur, ch * 4 + 5);
       // the last k-step: its transform frees dq, then chunk g+1 is made visible and read while its MFMAs run
       transform(IC<3>{}, v);
       __builtin_amdgcn_sched_barrier(0);
@@ -299,7 +328,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
       }
       if constexpr (!(ABL & 16)) read_d((g + 1) % WR);        // unconditional (a stale buffer after the very last chunk): no phi copies
       __builtin_amdgcn_sched_barrier(0);
-      mfmas(IC<1>{}, v);
+      mfmas(IC<3>{}, v);
     }
     mark(item, 0, 4);
     if constexpr (!(ABL & 32)) epilogue(cur);

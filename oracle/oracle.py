@@ -178,9 +178,9 @@ def sample_a(desc_map, kps, img_w, img_h, pca_comp=None, pca_mean=None):
     return out
 
 
-def extract_b(img_u8, weights, thr=0.015, border=1, max_kp=200):
+def extract_b(img_u8, weights, thr=0.015, border=1, max_kp=200, wino=False):
     """Full variant-B extractor == SuperPoint::infer (superpoint_tensorrt.cpp:161-183)."""
-    f = superpoint_forward(img_u8, weights)
+    f = superpoint_forward(img_u8, weights, wino=wino)
     kps, sc, idx = select_b(f["semi"], thr, border, max_kp)
     d = sample_b(f["desc"], kps)
     return kps, sc, d, idx, f
