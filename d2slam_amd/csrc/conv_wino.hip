@@ -17,14 +17,17 @@
 //   A^T M A: s_i0 = (m_i0 + m_i1) + m_i2, s_i1 = (m_i1 - m_i2) - m_i3; y_0b = (s_0b + s_1b) + s_2b, y_1b = (s_1b - s_2b) - s_3b;
 //   y + bias, ReLU, max-pool.
 //
-// Work split.  Measured on gfx950 (tools/ubench/mfma_f32_valu.hip): with ONE wave on a SIMD a VALU instruction between two
-// v_mfma_f32_32x32x2_f32 is not hidden -- 64.7 cycles per MFMA bare, 77.5 with two VALU per gap, 87 with four -- so the
-// input transform (2 VALU per MFMA) must come from a second wave of the same SIMD.  A wave therefore owns 32 tiles (4 x 8) x
-// 32 output channels x HALF of the transform positions (rows i = 2p, 2p+1 of M: 128 accumulator registers, 2 waves/SIMD); a
-// workgroup is 4 waves = (p, 32-channel half) and handles 8 x 16 output pixels x 64 channels, two workgroups per CU.  The
-// output transform needs all four rows of M: after the K loop each wave forms its two rows of s = M A, the partner waves swap
-// the halves belonging to the other's tiles through LDS (32 floats per lane), and each finishes A^T s, bias, ReLU, the 2x2
-// max-pool (the Winograd tile IS the pool window) and the stores for 16 of the 32 tiles.
+// Work split.  Measured on gfx950 (tools/ubench/mfma_f32_valu.hip): a VALU instruction next to v_mfma_f32_32x32x2_f32 is not
+// hidden -- 64.7 cycles per MFMA bare, 77.5 with two VALU per gap, 87 with four, and a second wave on the SIMD does not change
+// that -- so the kernel is built to issue as few VALU instructions per MFMA as possible.  A wave owns ONE ROW i of the 4x4
+// transform domain: 32 tiles (4 x 8) x 64 output channels x the 4 positions (i, 0..3) = 128 accumulator registers, two
+// waves per SIMD.  Row i of B^T d B needs two rows of the input window and 4 + 4 subtractions per channel, which feed 8 MFMAs
+// (1 VALU per MFMA; the earlier split by halves of the domain needed 2, a wave with all 16 positions 2 and one wave per
+// SIMD).  A workgroup is the 4 waves i = 0..3 and handles 8 x 16 output pixels x 64 channels, two workgroups per CU.  The
+// output transform needs all four rows: after the K loop each wave forms its row of s = M A, the waves swap rows through
+// LDS (each keeps a quarter of the tiles, 48 floats per lane go each way) and finish A^T s, bias, ReLU, the 2x2 max-pool (the
+// Winograd tile IS the pool window) and the stores for their 8 of the 32 tiles.  The first k-step of an item multiplies into
+// a zero C operand instead of zeroing 128 registers.
 //
 // Data movement.  Persistent workgroups walk a list of work items; the K loop runs over chunks of 8 input channels.  A chunk of
 // the 10 x 18 input patch is brought in by LDS-DMA (buffer_load_dwordx4 ... lds: 16 bytes = 4 channels of one pixel per lane,
@@ -45,7 +48,7 @@ namespace {
 constexpr int WR = 3;                       // ring depth
 constexpr int WCHUNK = 2 * 4 * 64 * 4;      // floats per chunk buffer (8 KiB): [quad 2][plane 4][64 slots][4 channels]
 constexpr int WROW = 12;                    // plane row stride in positions (9 used)
-constexpr int WXCH = 4 * 8 * 64 * 4;        // floats of the epilogue exchange area: [wave 4][8 float4][64 lanes]
+constexpr int WXCH = 4 * 12 * 64 * 4;       // floats of the epilogue exchange area: [wave 4][12 float4][64 lanes]
 
 struct WItem { int img, by, bx, cb; };
 template <int V> using IC = std::integral_constant<int, V>;
@@ -84,13 +87,12 @@ __device__ long long g_wino_trace[4][16][6];
 // holds tile  ty = 2*(q>>2) + parity(q),  tx = 4*((q>>1)&1) + (t&3),  q = t>>2.  ds_read_b128 serves a wave in the lane groups
 // {0-3,12-15,20-27} and {4-11,16-19,28-31} (+32): with this assignment a group holds tile rows {0,2} or {1,3}, whose
 // positions 12*ty + tx cover every residue mod 16 exactly once -- one 16-byte slot per lane, no bank conflict.
-template <int CIN, bool POOL, bool RELU, int ABL, int P>
+template <int CIN, bool POOL, bool RELU, int ABL, int I>
 __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, int ncb, int total, float* wlds) {
   constexpr int NCH = CIN / 8;               // chunks per work item
   constexpr int KSTEPS = CIN / 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cg = wave & 1;                   // 32-channel half of the 64-channel block; P = wave >> 1: rows 2P, 2P+1 of M
   const int aH = a.H, aW = a.W, in_cs = a.in_cstride;
 
   const int t0 = blockIdx.x, tstride = gridDim.x;
@@ -127,136 +129,145 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   const int rd_off = hh * 1024 + (ty * WROW + tx) * 4;       // floats: quad hh, plane 0, this lane's tile origin
   // U: one buffer resource over the packed weights; wave-uniform byte offset of a 32-channel group's stream + lane * 16
   const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, ncb * 2 * KSTEPS * 4096, 0x00020000);
-  auto u_ptr = [&](const WItem& T) { return (T.cb * 2 + cg) * KSTEPS * 4096; };
-  const int lane16 = lane * 16 + 2 * P * 1024;   // xi quads 2P, 2P+1 of the 4 KiB k-step record
+  auto u_ptr = [&](const WItem& T) { return T.cb * 2 * KSTEPS * 4096; };      // first of the item's two 32-channel streams
+  const int lane16 = lane * 16 + I * 1024;       // xi quad I (row I) of the 4 KiB k-step record
 
-  f32x16 acc[8];           // xi = (2P + li, j) -> acc[li*4 + j]
-  f32x4 dq[12];            // dq[r*4+dx] = the 4 channels of this lane's quad at window position (dy = P + r, dx)
-  f32x4 ub[4][2];          // [k-step of the chunk][li]: the fragments of k-step k+2 are requested before the MFMAs of k-step k
+  f32x16 acc[8];           // acc[nt*4 + j]: position (I, j), 32-channel half nt
+  f32x4 dq[8];             // dq[r*4+dx] = the 4 channels of this lane's quad at window position (dy = DY[r], dx)
+  f32x4 ub[4][2];          // [k-step of the chunk][nt]: the fragments of k-step k+3 are requested before the MFMAs of k-step k
+  // the two window rows row I of B^T d B is made of:  t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3
+  constexpr int DYA = I == 0 ? 0 : 1, DYB = I == 3 ? 3 : 2;
 
   auto read_d = [&](int buf) {
     const float* p = wlds + buf * WCHUNK + rd_off;
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int dx = 0; dx < 4; ++dx) {
-        const int dy = P + r;
+        const int dy = r == 0 ? DYA : DYB;
         dq[r * 4 + dx] = *reinterpret_cast<const f32x4*>(p + ((dy & 1) * 2 + (dx & 1)) * 256 + ((dy >> 1) * WROW + (dx >> 1)) * 4);
       }
   };
   auto load_u = [&](int slot, int up, int ks) {
     if constexpr ((ABL & 2) != 0) return;
 #pragma unroll
-    for (int li = 0; li < 2; ++li) ub[slot][li] = buf_load_f32x4(u_rsrc, lane16 + li * 1024, up + ks * 4096);
+    for (int nt = 0; nt < 2; ++nt) ub[slot][nt] = buf_load_f32x4(u_rsrc, lane16, up + (nt * KSTEPS + ks) * 4096);
   };
-  // rows 2P, 2P+1 of B^T d B for channel j of the quad:  P = 0: t0 = d0 - d2, t1 = d1 + d2;  P = 1: t2 = d2 - d1, t3 = d1 - d3
-  auto transform = [&](auto j_c, float (&v)[8]) {
+  // row I of B^T d B for channel j of the quad, then the row transform
+  auto transform = [&](auto j_c, float (&v)[4]) {
     constexpr int j = decltype(j_c)::value;
-    float t[2][4];
+    float t[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float r0 = dq[0 + c][j], r1 = dq[4 + c][j], r2 = dq[8 + c][j];
-      if constexpr (P == 0) { t[0][c] = r0 - r2; t[1][c] = r1 + r2; }
-      else { t[0][c] = r1 - r0; t[1][c] = r0 - r2; }
+      const float ra = dq[c][j], rb = dq[4 + c][j];
+      if constexpr (I == 0 || I == 3) t[c] = ra - rb;
+      else if constexpr (I == 1) t[c] = ra + rb;
+      else t[c] = rb - ra;
     }
-#pragma unroll
-    for (int li = 0; li < 2; ++li) {
-      v[li * 4 + 0] = t[li][0] - t[li][2]; v[li * 4 + 1] = t[li][1] + t[li][2];
-      v[li * 4 + 2] = t[li][2] - t[li][1]; v[li * 4 + 3] = t[li][1] - t[li][3];
-    }
+    v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
   };
-  auto mfmas = [&](auto slot_c, const float (&v)[8]) {
+  auto mfmas = [&](auto slot_c, auto first_c, const float (&v)[4]) {
     constexpr int slot = decltype(slot_c)::value;
+    constexpr bool first = decltype(first_c)::value != 0;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int x = 0; x < 8; ++x)
-      acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[x], ub[slot][x >> 2][x & 3], acc[x], 0, 0, 0);
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[nt * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], ub[slot][nt][j], first ? zero : acc[nt * 4 + j], 0, 0, 0);
   };
 
-  // ---- epilogue: s = M A for this wave's two rows, swap with the partner wave, A^T s, bias, ReLU, pool, store ----------------
+  // ---- epilogue: s = M A for this wave's row, swap rows between the four waves, A^T s, bias, ReLU, pool, store ----------------
   float* xch = wlds + WR * WCHUNK;
   auto epilogue = [&](const WItem& T) {
-    const int n32 = T.cb * 2 + cg;
-    const int co = n32 * 32 + (lane & 31);
-    const float bias = a.bias[co];
     float* out = a.out + (size_t)T.img * a.out_img_stride + a.out_coff;
-    const int cs = a.out_cstride;
-    const bool cok = co < a.cout_real && !(ABL & 4);
-    // fast path (item inside the image, all 32 channels real): buffer stores, wave-uniform offsets on the SALU
-    const int cs4 = cs * 4;
-    const bool full = T.by * 8 + 8 <= aH && T.bx * 16 + 16 <= aW && (n32 + 1) * 32 <= a.cout_real && !(ABL & 4);
+    const int cs = a.out_cstride, cs4 = cs * 4;
+    const int n32 = T.cb * 2;
+    const int co0 = n32 * 32 + (lane & 31);
+    const float bias0 = a.bias[co0], bias1 = a.bias[co0 + 32];
+    // fast path (item inside the image, all 64 channels real): buffer stores, wave-uniform offsets on the SALU
+    const bool full = T.by * 8 + 8 <= aH && T.bx * 16 + 16 <= aW && (n32 + 2) * 32 <= a.cout_real && !(ABL & 4);
     const int Wo = POOL ? (aW >> 1) : aW, Ho = POOL ? (aH >> 1) : aH;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, Ho * Wo * cs4, 0x00020000);
     const int rowpair = (POOL ? Wo : 2 * Wo) * cs4;               // bytes between tile rows ty and ty + 1
     const int vo0 = (lane & 31) * 4 + hh * rowpair, vo1 = (lane & 31) * 4 + (1 - hh) * rowpair;
     const int obase = ((POOL ? T.by * 4 * Wo + T.bx * 8 : T.by * 8 * Wo + T.bx * 16)) * cs4 + n32 * 128;
-    f32x4 sk[8];           // kept tiles (registers r = 8P .. 8P+7): (s_l0_0, s_l0_1, s_l1_0, s_l1_1)
-    f32x4* xw = reinterpret_cast<f32x4*>(xch) + (wave * 8) * 64 + lane;
+    f32x4 sk[4];           // kept tiles (registers r = 4I .. 4I+3): (s_nt0_b0, s_nt0_b1, s_nt1_b0, s_nt1_b1) of row I
+    f32x4* xw = reinterpret_cast<f32x4*>(xch) + (I * 12) * 64 + lane;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       f32x4 sv;
 #pragma unroll
-      for (int li = 0; li < 2; ++li) {
-        const float m0 = acc[li * 4 + 0][r], m1 = acc[li * 4 + 1][r], m2 = acc[li * 4 + 2][r], m3 = acc[li * 4 + 3][r];
-        sv[li * 2 + 0] = (m0 + m1) + m2;
-        sv[li * 2 + 1] = (m1 - m2) - m3;
+      for (int nt = 0; nt < 2; ++nt) {
+        const float m0 = acc[nt * 4 + 0][r], m1 = acc[nt * 4 + 1][r], m2 = acc[nt * 4 + 2][r], m3 = acc[nt * 4 + 3][r];
+        sv[nt * 2 + 0] = (m0 + m1) + m2;
+        sv[nt * 2 + 1] = (m1 - m2) - m3;
       }
-      if ((r >> 3) == P) sk[r & 7] = sv; else xw[(r & 7) * 64] = sv;
+      const int o = r >> 2;                               // the wave that finishes this tile
+      if (o == I) sk[r & 3] = sv; else xw[((o < I ? o : o - 1) * 4 + (r & 3)) * 64] = sv;
     }
     __syncthreads();
-    const f32x4* xr = reinterpret_cast<const f32x4*>(xch) + ((wave ^ 2) * 8) * 64 + lane;
     auto finish_tile = [&](auto k_c) {
       constexpr int k = decltype(k_c)::value;
-      constexpr int r = 8 * P + k;
-      const f32x4 o = xr[k * 64];          // the partner's rows for this tile
-      float s[4][2];
-      s[2 * P + 0][0] = sk[k][0]; s[2 * P + 0][1] = sk[k][1]; s[2 * P + 1][0] = sk[k][2]; s[2 * P + 1][1] = sk[k][3];
-      s[2 * (1 - P) + 0][0] = o[0]; s[2 * (1 - P) + 0][1] = o[1]; s[2 * (1 - P) + 1][0] = o[2]; s[2 * (1 - P) + 1][1] = o[3];
-      float y[2][2];
+      constexpr int r = 4 * I + k;
+      f32x4 srow[4];       // rows 0..3 of s for this tile: (nt0 b0, nt0 b1, nt1 b0, nt1 b1)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        y[0][b] = (s[0][b] + s[1][b]) + s[2][b];
-        y[1][b] = (s[1][b] - s[2][b]) - s[3][b];
+      for (int w = 0; w < 4; ++w) {
+        if (w == I) srow[w] = sk[k];
+        else srow[w] = (reinterpret_cast<const f32x4*>(xch) + (w * 12 + (I < w ? I : I - 1) * 4 + k) * 64)[lane];
       }
-#pragma unroll
-      for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          float v = y[pp][b] + bias;
-          if (RELU) v = v > 0.f ? v : 0.f;
-          y[pp][b] = v;
-        }
-      // tile of register r in this lane: q = 2*(r>>2) + hh -> ty = 2*(r>>3) + (parity(r>>2) ^ hh), tx = 4*((r>>2)&1) + (r&3)
       constexpr int par = ((r >> 2) ^ (r >> 3)) & 1;
       const int txr = 4 * ((r >> 2) & 1) + (r & 3);
-      if (full) {
-        // interior item: uniform byte offset (SALU) + one of two per-lane offsets (channel, and the tile row this lane half holds)
-        const int vo = par ? vo1 : vo0;
-        if constexpr (POOL) {
-          const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
-          buf_store_f32(v, orsrc, vo, obase + ((2 * (r >> 3)) * (aW >> 1) + txr) * cs4);
-        } else {
 #pragma unroll
-          for (int pp = 0; pp < 2; ++pp)
+      for (int nt = 0; nt < 2; ++nt) {
+        float y[2][2];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) buf_store_f32(y[pp][b], orsrc, vo, obase + ((4 * (r >> 3) + pp) * aW + 2 * txr + b) * cs4);
+        for (int b = 0; b < 2; ++b) {
+          const float s0 = srow[0][nt * 2 + b], s1 = srow[1][nt * 2 + b], s2 = srow[2][nt * 2 + b], s3 = srow[3][nt * 2 + b];
+          y[0][b] = (s0 + s1) + s2;
+          y[1][b] = (s1 - s2) - s3;
         }
-      } else {
-        const int tyr = 2 * (r >> 3) + (par ^ hh);
-        const int oy = T.by * 8 + 2 * tyr, ox = T.bx * 16 + 2 * txr;
-        if constexpr (POOL) {
-          const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
-          if (cok && oy + 1 < aH && ox + 1 < aW) out[((size_t)(oy >> 1) * (aW >> 1) + (ox >> 1)) * cs + co] = v;
+        const float bias = nt ? bias1 : bias0;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            float v = y[pp][b] + bias;
+            if (RELU) v = v > 0.f ? v : 0.f;
+            y[pp][b] = v;
+          }
+        if (full) {
+          // interior item: uniform byte offset (SALU) + one of two per-lane offsets (channel, and the tile row this lane half holds)
+          const int vo = par ? vo1 : vo0;
+          if constexpr (POOL) {
+            const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+            buf_store_f32(v, orsrc, vo, obase + ((2 * (r >> 3)) * (aW >> 1) + txr) * cs4 + nt * 128);
+          } else {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+              for (int b = 0; b < 2; ++b)
+                buf_store_f32(y[pp][b], orsrc, vo, obase + ((4 * (r >> 3) + pp) * aW + 2 * txr + b) * cs4 + nt * 128);
+          }
         } else {
+          const int co = co0 + nt * 32;
+          const bool cok = co < a.cout_real && !(ABL & 4);
+          const int tyr = 2 * (r >> 3) + (par ^ hh);
+          const int oy = T.by * 8 + 2 * tyr, ox = T.bx * 16 + 2 * txr;
+          if constexpr (POOL) {
+            const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+            if (cok && oy + 1 < aH && ox + 1 < aW) out[((size_t)(oy >> 1) * (aW >> 1) + (ox >> 1)) * cs + co] = v;
+          } else {
 #pragma unroll
-          for (int pp = 0; pp < 2; ++pp)
+            for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-              if (cok && oy + pp < aH && ox + b < aW) out[((size_t)(oy + pp) * aW + ox + b) * cs + co] = y[pp][b];
+              for (int b = 0; b < 2; ++b)
+                if (cok && oy + pp < aH && ox + b < aW) out[((size_t)(oy + pp) * aW + ox + b) * cs + co] = y[pp][b];
+          }
         }
       }
     };
     finish_tile(IC<0>{}); finish_tile(IC<1>{}); finish_tile(IC<2>{}); finish_tile(IC<3>{});
-    finish_tile(IC<4>{}); finish_tile(IC<5>{}); finish_tile(IC<6>{}); finish_tile(IC<7>{});
     __syncthreads();         // the exchange area is free again (the next item's epilogue writes it)
   };
 
@@ -271,7 +282,8 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   int ucur = u_ptr(cur), unxt = u_ptr(nxt);
   load_u(0, ucur, 0);
   load_u(1, ucur, 1);
-  if (G > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // chunk 0 landed (younger: 2 x 2 copies + 4 U loads)
+  load_u(2, ucur, 2);
+  if (G > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // chunk 0 landed (younger: 2 x 2 copies + 6 U loads)
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   read_d(0);
@@ -281,55 +293,55 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
 
   // ---- walk: items x chunks; g counts chunks across items (ring position) ---------------------------------------------------
   int g = 0;
+  auto chunk = [&](auto first_c, int item, int ch) {
+    const bool last_ch = ch == NCH - 1;
+    float v[4];
+    mark(item, ch, 0);
+    // U fragments run three k-steps ahead through four register slots: slot (k+3)&3 held k-step k-1, whose MFMAs are issued
+    load_u(3, ucur, ch * 4 + 3);
+    transform(IC<0>{}, v);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(IC<0>{}, first_c, v);
+    __builtin_amdgcn_sched_barrier(0);
+    // k-steps 0..2 of the next chunk (the next item's first chunk at an item boundary; wraps harmlessly at the very end)
+    if (last_ch) load_u(0, unxt, 0); else load_u(0, ucur, ch * 4 + 4);
+    transform(IC<1>{}, v);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(IC<1>{}, IC<0>{}, v);
+    __builtin_amdgcn_sched_barrier(0);
+    if (last_ch) load_u(1, unxt, 1); else load_u(1, ucur, ch * 4 + 5);
+    transform(IC<2>{}, v);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(IC<2>{}, IC<0>{}, v);
+    __builtin_amdgcn_sched_barrier(0);
+    if (last_ch) load_u(2, unxt, 2); else load_u(2, ucur, ch * 4 + 6);
+    // the last k-step: its transform frees dq, then chunk g+1 is made visible and read while its MFMAs run
+    transform(IC<3>{}, v);
+    __builtin_amdgcn_sched_barrier(0);
+    mark(item, ch, 1);
+    if (g + 1 < G) {
+      // chunk g+1 (copied WR-1 iterations ago) must have landed: the loads younger than it are this iteration's 8 U loads
+      // and the 2 copies of chunk g+2 -- loads complete in order, so "at most 10 outstanding" implies it is complete
+      if (g + 2 < G) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    mark(item, ch, 2);
+    if constexpr (!(ABL & 8)) __syncthreads();   // every wave's part of chunk g+1 is in LDS; every wave has read chunk g out of its buffer
+    mark(item, ch, 3);
+    if (g + WR < G) {
+      const int c3 = ch + WR;      // chunk g+WR of the walk, relative to the current item
+      if (c3 < NCH) dma_issue(dcur, c3, g % WR); else dma_issue(dnxt, c3 - NCH, g % WR);
+    }
+    if constexpr (!(ABL & 16)) read_d((g + 1) % WR);        // unconditional (a stale buffer after the very last chunk): no phi copies
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(IC<3>{}, IC<0>{}, v);
+    ++g;
+  };
 #pragma unroll 1
   for (int item = 0; item < n_my; ++item) {
-#pragma unroll
-    for (int x = 0; x < 8; ++x)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    chunk(IC<1>{}, item, 0);       // the first k-step multiplies into C = 0: no accumulator clearing
 #pragma unroll 1
-    for (int ch = 0; ch < NCH; ++ch, ++g) {
-      const bool last_ch = ch == NCH - 1;
-      float v[8];
-      mark(item, ch, 0);
-      load_u(2, ucur, ch * 4 + 2);
-      transform(IC<0>{}, v);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(IC<0>{}, v);
-      __builtin_amdgcn_sched_barrier(0);
-      load_u(3, ucur, ch * 4 + 3);
-      transform(IC<1>{}, v);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(IC<1>{}, v);
-      __builtin_amdgcn_sched_barrier(0);
-      // k-steps 0 and 1 of the next chunk (the next item's first chunk at an item boundary; wraps harmlessly at the very end)
-      if (last_ch) load_u(0, unxt, 0); else load_u(0, ucur, ch * 4 + 4);
-      transform(IC<2>{}, v);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(IC<2>{}, v);
-      __builtin_amdgcn_sched_barrier(0);
-      if (last_ch) load_u(1, unxt, 1); else load_u(1, ucur, ch * 4 + 5);
-      // the last k-step: its transform frees dq, then chunk g+1 is made visible and read while its MFMAs run
-      transform(IC<3>{}, v);
-      __builtin_amdgcn_sched_barrier(0);
-      mark(item, ch, 1);
-      if (g + 1 < G) {
-        // chunk g+1 (copied WR-1 iterations ago) must have landed: the loads younger than it are this iteration's 8 U loads
-        // and the 2 copies of chunk g+2 -- loads complete in order, so "at most 10 outstanding" implies it is complete
-        if (g + 2 < G) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      mark(item, ch, 2);
-      if constexpr (!(ABL & 8)) __syncthreads();   // every wave's part of chunk g+1 is in LDS; every wave has read chunk g out of its buffer
-      mark(item, ch, 3);
-      if (g + WR < G) {
-        const int c3 = ch + WR;      // chunk g+WR of the walk, relative to the current item
-        if (c3 < NCH) dma_issue(dcur, c3, g % WR); else dma_issue(dnxt, c3 - NCH, g % WR);
-      }
-      if constexpr (!(ABL & 16)) read_d((g + 1) % WR);        // unconditional (a stale buffer after the very last chunk): no phi copies
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(IC<3>{}, v);
-    }
+    for (int ch = 1; ch < NCH; ++ch) chunk(IC<0>{}, item, ch);
     mark(item, 0, 4);
     if constexpr (!(ABL & 32)) epilogue(cur);
     mark(item, 0, 5);
@@ -346,9 +358,13 @@ template <int CIN, bool POOL, bool RELU, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a, int nbx, int nby, int ncb, int total) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   if ((int)blockIdx.x >= total) return;
-  // the two halves of the transform positions run different (compile-time) row arithmetic; the branch is wave-uniform
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) wino_body<CIN, POOL, RELU, ABL, 0>(a, nbx, nby, ncb, total, wlds);
-  else wino_body<CIN, POOL, RELU, ABL, 1>(a, nbx, nby, ncb, total, wlds);
+  // the four rows of the transform domain run different (compile-time) row arithmetic; the branch is wave-uniform
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+    case 0: wino_body<CIN, POOL, RELU, ABL, 0>(a, nbx, nby, ncb, total, wlds); break;
+    case 1: wino_body<CIN, POOL, RELU, ABL, 1>(a, nbx, nby, ncb, total, wlds); break;
+    case 2: wino_body<CIN, POOL, RELU, ABL, 2>(a, nbx, nby, ncb, total, wlds); break;
+    default: wino_body<CIN, POOL, RELU, ABL, 3>(a, nbx, nby, ncb, total, wlds); break;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
