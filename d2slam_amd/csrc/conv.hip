@@ -295,10 +295,74 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const uint8_t* __restrict__
   }
 }
 
+// conv1a on the matrix pipe (the stand-alone form of conv1a_mfma_stage): a wave walks 8 consecutive m-tiles of 32 pixels of one
+// image row; per m-tile a [32 px x 10] x [10 x 64] problem = 10 v_mfma_f32_32x32x2_f32 started from the bias (the same fmaf chain
+// in (ky,kx) order as conv1a_kernel, K = 9 padded with a zero tap), ReLU, 32 stores of 2 x 128 contiguous bytes.  The B fragments
+// and the bias stay in 12 registers.  Used by the Winograd mode, whose conv1b reads the materialised activation.
+constexpr int C1A_TILES_PER_WAVE = 8;
+__global__ __launch_bounds__(256) void conv1a_mfma_kernel(const uint8_t* __restrict__ img, int stride, long img_stride, int H, int W,
+                                                          int tiles_x, long total_tiles, const float* __restrict__ w9x64,
+                                                          const float* __restrict__ bias, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  float c1w[5][2], c1b[2];
+  conv1a_mfma_load_weights(w9x64, bias, lane, c1w, c1b);
+  const float scale = (float)(1.0 / 255.0);
+#pragma unroll 1
+  for (int u = 0; u < C1A_TILES_PER_WAVE; ++u) {
+    const long t = wave * C1A_TILES_PER_WAVE + u;
+    if (t >= total_tiles) return;
+    const int xt = (int)(t % tiles_x);
+    const long row = t / tiles_x;                 // n * H + y
+    const int y = (int)(row % H);
+    const uint8_t* ip = img + (size_t)(row / H) * img_stride;
+    const int gx = xt * 32 + (lane & 31);
+    unsigned char raw[5];
+    bool tin[5];
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      const int k = 2 * st + (lane >> 5);
+      const int yy = y + k / 3 - 1, xx = gx + k % 3 - 1;
+      tin[st] = k < 9 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+      raw[st] = ip[(size_t)yc * stride + xc];
+    }
+    f32x16 c0, c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c0[r] = c1b[0]; c1[r] = c1b[1]; }
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      const float av = tin[st] ? (float)raw[st] * scale : 0.f;
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, c1w[st][0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, c1w[st][1], c1, 0, 0, 0);
+    }
+    float* op = out + ((size_t)row * W + xt * 32 + 4 * (lane >> 5)) * 64 + (lane & 31);
+    const bool fullw = xt * 32 + 32 <= W;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2);       // + 4 * (lane >> 5): pixel of the m-tile
+      if (fullw || xt * 32 + i + 4 * (lane >> 5) < W) {
+        op[(size_t)i * 64] = c0[r] > 0.f ? c0[r] : 0.f;
+        op[(size_t)i * 64 + 32] = c1[r] > 0.f ? c1[r] : 0.f;
+      }
+    }
+  }
+}
+
 hipError_t launch_conv1a(const uint8_t* img, int stride, long img_stride_bytes, int H, int W, int n,
                          const float* w9x64, const float* bias, float* out, hipStream_t s) {
-  dim3 grid((W + 63) / 64, H, n), block(256);
-  hipLaunchKernelGGL(conv1a_kernel, grid, block, 0, s, img, stride, img_stride_bytes, H, W, w9x64, bias, out);
+  static int valu = -1;
+  if (valu < 0) { const char* e = getenv("D2FE_CONV1A_VALU"); valu = e ? atoi(e) : 0; }   // 1: the VALU kernel (A/B timing)
+  if (valu) {
+    dim3 grid((W + 63) / 64, H, n), block(256);
+    hipLaunchKernelGGL(conv1a_kernel, grid, block, 0, s, img, stride, img_stride_bytes, H, W, w9x64, bias, out);
+    return hipGetLastError();
+  }
+  const int tiles_x = (W + 31) / 32;
+  const long total = (long)tiles_x * H * n;
+  const long waves = (total + C1A_TILES_PER_WAVE - 1) / C1A_TILES_PER_WAVE;
+  hipLaunchKernelGGL(conv1a_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, img, stride, img_stride_bytes, H, W,
+                     tiles_x, total, w9x64, bias, out);
   return hipGetLastError();
 }
 
