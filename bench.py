@@ -215,7 +215,8 @@ def main():
             achieved = executed / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
             roofline = {"kernel": "conv_wino_kernel<64,POOL,RELU> (conv1b as Winograd F(2x2,3x3); conv1a materialised by conv1a_kernel)",
                         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                        "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": c1b_n,
+                        # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, profiles/README.md): 7.0 GB per 64 images
+                        "traffic": 109.3e6 * NI, "avg_launch_ms": round(avg_ms, 4), "launches": c1b_n,
                         "algorithmic_flop_per_launch": CONV1B_FLOP_PER_IMG * NI, "executed_mfma_flop_per_launch": executed,
                         "direct_equivalent_tflops": round(achieved * 2.25, 2),
                         "note": "achieved = executed MFMA FLOPs (algorithmic direct-convolution FLOPs x 16/36) / HIP-event time; "

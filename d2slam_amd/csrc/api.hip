@@ -222,6 +222,7 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     a.cout_real = L.cout; a.wpack = L.wpack; a.bias = L.bias;
     a.img = d_gray; a.img_stride = stride; a.img_istride = (long)image_stride; a.w1a = h->w1a; a.b1a = h->b1a;
     a.H = hh; a.W = ww; a.n_img = n; a.in_img_stride = iis; a.out_img_stride = ois; a.zeros = h->zeros;
+    a.tag = (&L == &h->L[L_1B]) ? 1 : 0;
     { static int ab = -1; if (ab < 0) { const char* e = getenv("D2FE_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
     if (prec == D2FE_PREC_F32_WINO)   // 3x3 layers: Winograd kernels; the 1x1 heads: the exact fp32 kernels
       return L.ks == 3 ? launch_conv_wino(L.cin, pool, relu, L.cout_pad, a, s) : launch_conv(shape, D2FE_PREC_F32, pool, relu, L.cout_pad, a, s);

@@ -354,7 +354,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   }
 }
 
-template <int CIN, bool POOL, bool RELU, int ABL = 0>
+template <int CIN, bool POOL, bool RELU, int ABL = 0, int TAG = 0>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a, int nbx, int nby, int ncb, int total) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   if ((int)blockIdx.x >= total) return;
@@ -411,6 +411,7 @@ hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const C
       default: break;
     }
   }
+  if (cin == 64 && pool && relu && a.tag == 1) { D2FE_WINO_K((conv_wino_kernel<64, true, true, 0, 1>)); return hipGetLastError(); }   // conv1b
   if (cin == 64 && pool && relu) { D2FE_WINO_K((conv_wino_kernel<64, true, true>)); return hipGetLastError(); }
   if (cin == 64 && !pool && relu) { D2FE_WINO_K((conv_wino_kernel<64, false, true>)); return hipGetLastError(); }
   if (cin == 128 && pool && relu) { D2FE_WINO_K((conv_wino_kernel<128, true, true>)); return hipGetLastError(); }

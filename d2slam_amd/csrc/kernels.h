@@ -20,6 +20,7 @@ struct ConvArgs {
   // fused conv1a prologue (CONV1B_FUSED only): the patch is computed from the u8 frame instead of being loaded
   const uint8_t* img; int img_stride; long img_istride; const float* w1a; const float* b1a;
   const float* zeros;       // >= 256 zero floats in HBM (source of the LDS-DMA copies of out-of-image patch pixels)
+  int tag;                  // 1: conv1b (the dominant launch gets its own kernel instantiation so that rocprofv3 --stats lists it by itself)
   int ablate;               // experiment knob (D2FE_ABLATE): 1 skip patch loads, 2 skip B reloads, 4 skip stores
 };
 
