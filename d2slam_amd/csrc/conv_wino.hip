@@ -370,6 +370,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a, int nbx, 
 // ---------------------------------------------------------------------------------------------------------------------
 hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s) {
   if (cout_pad % 64 || (a.in_cstride & 3) || (a.in_coff & 3)) return hipErrorInvalidValue;
+  // buffer addressing: 32-bit byte offsets inside one image's tensor, 0x80000000 must stay out of range
+  if ((long)a.H * a.W * a.in_cstride * 4 >= (1l << 31) || (long)a.H * a.W * a.out_cstride * 4 >= (1l << 31)) return hipErrorInvalidValue;
   const int nbx = (a.W + 15) / 16, nby = (a.H + 7) / 8, ncb = cout_pad / 64;
   const int total = nbx * nby * ncb * a.n_img;
   static int ncu = 0;

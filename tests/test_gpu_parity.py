@@ -512,8 +512,8 @@ def test_sparse_descriptor_head_equals_dense(api, orc, sp_weights, prec):
     assert len(outs[0][0][0]) == 300
 
 
-@pytest.mark.parametrize("n", [2, 6])
-def test_async_tail_equals_synchronous(api, sp_weights, n):
+@pytest.mark.parametrize("n,wino", [(2, False), (6, False), (6, True)])
+def test_async_tail_equals_synchronous(api, sp_weights, n, wino):
     """async_tail: convolutions on the caller's stream, post-processing on the handle's tail stream with double-buffered inputs.
     Five back-to-back calls on different frames WITHOUT any host synchronisation in between (so call k+1's convolutions really
     run while call k's tail is pending), each into its own output buffers, must reproduce the synchronous results bit for bit;
@@ -524,7 +524,8 @@ def test_async_tail_equals_synchronous(api, sp_weights, n):
     frames = [torch.from_numpy(np.stack([synth_image(H, W, 300 + 10 * c + s) for s in range(n)])).to(dev) for c in range(calls)]
 
     def run(async_tail):
-        fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=cap, input_width=W, input_height=H, max_batch=n, async_tail=async_tail))
+        fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=cap, input_width=W, input_height=H, max_batch=n, async_tail=async_tail,
+                                               precision=api.PREC_F32_WINO if wino else api.PREC_F32))
         fe.load_superpoint(sp_weights)
         assert (fe.tail_stream() != 0) == async_tail
         outs = []

@@ -125,3 +125,23 @@ def test_wino_sparse_head_matches_dense_within_tolerance(api):
     for (k0, s0, d0), (k1, s1, d1) in zip(*outs):
         assert np.array_equal(k0, k1) and np.array_equal(s0, s1)
         assert np.abs(d0 - d1).max() <= 1e-5
+
+
+@pytest.mark.gpu
+def test_wino_variant_a_matches_its_oracle(api, orc):
+    # post-processing variant A (NMS2 + grid_sampler sampling) on top of the Winograd network: keypoints exact, descriptors 1e-6
+    H, W, n, cap = 96, 128, 4, 60
+    w = synthetic_superpoint_weights(dustbin_bias=7.5)
+    imgs = np.stack([synth_stereo(H, W, seed=31 + i)[i & 1] for i in range(n)])
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=cap, input_width=W, input_height=H, max_batch=n, precision=api.PREC_F32_WINO,
+                                           postproc=api.POSTPROC_A, nms_dist=4))
+    fe.load_superpoint(w)
+    res = fe.extract_batch(imgs, cap=cap)
+    fe.close()
+    for i in range(n):
+        f = orc.superpoint_forward(imgs[i], w, wino=True)
+        rk, rs = orc.nms2_a(f["semi"], 0.015, 4, cap)[:2]
+        kps, sc, desc = res[i]
+        assert np.array_equal(kps, rk) and np.array_equal(sc, rs)
+        rd = orc.sample_a(f["desc"], rk, W, H)
+        assert np.abs(desc - rd).max() <= 1e-5   # sparse head: direct chains at the keypoint cells vs the dense Winograd map
