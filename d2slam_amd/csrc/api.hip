@@ -225,7 +225,8 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     a.tag = (&L == &h->L[L_1B]) ? 1 : 0;
     { static int ab = -1; if (ab < 0) { const char* e = getenv("D2FE_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
     if (prec == D2FE_PREC_F32_WINO)   // 3x3 layers: Winograd kernels; the 1x1 heads: the exact fp32 kernels
-      return L.ks == 3 ? launch_conv_wino(L.cin, pool, relu, L.cout_pad, a, s) : launch_conv(shape, D2FE_PREC_F32, pool, relu, L.cout_pad, a, s);
+      return shape == CONV1B_FUSED ? launch_conv_wino_fused1b(L.cout_pad, a, s)
+             : L.ks == 3 ? launch_conv_wino(L.cin, pool, relu, L.cout_pad, a, s) : launch_conv(shape, D2FE_PREC_F32, pool, relu, L.cout_pad, a, s);
     return launch_conv(shape, prec, pool, relu, L.cout_pad, a, s);
   };
   if (h->fuse1a) {
@@ -353,8 +354,10 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   d2fe_context* h = new d2fe_context();
   h->cfg = *cfg;
   const int rc_alloc = [&]() -> int {
+  // Winograd mode: conv1a materialised by its own (HBM-bound) kernel by default; D2FE_FUSE1A=1 evaluates it inside conv1b's
+  // staging instead (measured: the same throughput, 78.6 MB per image less memory and traffic, a lower MFMA fraction for conv1b)
+  if (h->cfg.precision == D2FE_PREC_F32_WINO) h->fuse1a = false;
   { const char* e = getenv("D2FE_FUSE1A"); if (e) h->fuse1a = atoi(e) != 0; }
-  if (h->cfg.precision == D2FE_PREC_F32_WINO) h->fuse1a = false;   // the Winograd conv1b reads the materialised conv1a activation
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     const size_t H = cfg->max_height, W = cfg->max_width;
     const int B = cfg->max_batch;

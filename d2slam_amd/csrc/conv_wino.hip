@@ -87,10 +87,15 @@ __device__ long long g_wino_trace[4][16][6];
 // holds tile  ty = 2*(q>>2) + parity(q),  tx = 4*((q>>1)&1) + (t&3),  q = t>>2.  ds_read_b128 serves a wave in the lane groups
 // {0-3,12-15,20-27} and {4-11,16-19,28-31} (+32): with this assignment a group holds tile rows {0,2} or {1,3}, whose
 // positions 12*ty + tx cover every residue mod 16 exactly once -- one 16-byte slot per lane, no bank conflict.
-template <int CIN, bool POOL, bool RELU, int ABL, int I>
+template <int CIN, bool POOL, bool RELU, int ABL, int I, bool FUSE>
 __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, int ncb, int total, float* wlds) {
   constexpr int NCH = CIN / 8;               // chunks per work item
   constexpr int KSTEPS = CIN / 2;
+  // FUSE (conv1b): the whole 64-channel patch is produced in LDS by conv1a on the matrix pipe instead of being copied in; its
+  // planes are 272 floats apart (16 floats of padding keep the four parity planes on different banks for the float4 writes)
+  constexpr int PL = FUSE ? 272 : 256;       // floats per parity plane
+  constexpr int CHF = 2 * 4 * PL;            // floats per 8-channel chunk
+  static_assert(!FUSE || CIN == 64, "the fused prologue is conv1a -> conv1b");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int aH = a.H, aW = a.W, in_cs = a.in_cstride;
@@ -126,7 +131,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   // ---- per-lane constants ----------------------------------------------------------------------------------------------------
   const int trow = lane & 31, q8 = trow >> 2, hh = lane >> 5;
   const int ty = 2 * (q8 >> 2) + (__builtin_popcount(q8) & 1), tx = 4 * ((q8 >> 1) & 1) + (trow & 3);
-  const int rd_off = hh * 1024 + (ty * WROW + tx) * 4;       // floats: quad hh, plane 0, this lane's tile origin
+  const int rd_off = hh * 4 * PL + (ty * WROW + tx) * 4;     // floats: quad hh, plane 0, this lane's tile origin
   // U: one buffer resource over the packed weights; wave-uniform byte offset of a 32-channel group's stream + lane * 16
   const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, ncb * 2 * KSTEPS * 4096, 0x00020000);
   auto u_ptr = [&](const WItem& T) { return T.cb * 2 * KSTEPS * 4096; };      // first of the item's two 32-channel streams
@@ -139,13 +144,13 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   constexpr int DYA = I == 0 ? 0 : 1, DYB = I == 3 ? 3 : 2;
 
   auto read_d = [&](int buf) {
-    const float* p = wlds + buf * WCHUNK + rd_off;
+    const float* p = wlds + buf * CHF + rd_off;
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int dx = 0; dx < 4; ++dx) {
         const int dy = r == 0 ? DYA : DYB;
-        dq[r * 4 + dx] = *reinterpret_cast<const f32x4*>(p + ((dy & 1) * 2 + (dx & 1)) * 256 + ((dy >> 1) * WROW + (dx >> 1)) * 4);
+        dq[r * 4 + dx] = *reinterpret_cast<const f32x4*>(p + ((dy & 1) * 2 + (dx & 1)) * PL + ((dy >> 1) * WROW + (dx >> 1)) * 4);
       }
   };
   auto load_u = [&](int slot, int up, int ks) {
@@ -178,7 +183,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   };
 
   // ---- epilogue: s = M A for this wave's row, swap rows between the four waves, A^T s, bias, ReLU, pool, store ----------------
-  float* xch = wlds + WR * WCHUNK;
+  float* xch = FUSE ? wlds : wlds + WR * WCHUNK;      // FUSE: the patch is dead once the K loop is through, the exchange area reuses it
   auto epilogue = [&](const WItem& T) {
     float* out = a.out + (size_t)T.img * a.out_img_stride + a.out_coff;
     const int cs = a.out_cstride, cs4 = cs * 4;
@@ -192,6 +197,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     const int rowpair = (POOL ? Wo : 2 * Wo) * cs4;               // bytes between tile rows ty and ty + 1
     const int vo0 = (lane & 31) * 4 + hh * rowpair, vo1 = (lane & 31) * 4 + (1 - hh) * rowpair;
     const int obase = ((POOL ? T.by * 4 * Wo + T.bx * 8 : T.by * 8 * Wo + T.bx * 16)) * cs4 + n32 * 128;
+    if constexpr (FUSE) __syncthreads();      // every wave is through with the patch before the exchange overwrites it
     f32x4 sk[4];           // kept tiles (registers r = 4I .. 4I+3): (s_nt0_b0, s_nt0_b1, s_nt1_b0, s_nt1_b1) of row I
     f32x4* xw = reinterpret_cast<f32x4*>(xch) + (I * 12) * 64 + lane;
 #pragma unroll
@@ -271,22 +277,94 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     __syncthreads();         // the exchange area is free again (the next item's epilogue writes it)
   };
 
+  // ---- FUSE: conv1a for the 10 x 18 patch on the matrix pipe, straight into the chunk layout ------------------------------------
+  // D[channel][pixel] = sum_k W[channel][k] * tap[k][pixel]: the weights are the A operand, so that a lane (= pixel) holds 4
+  // consecutive channels in registers 4q..4q+3 -- one 16-byte LDS write per channel quad.  K = 10: k = 0 carries the bias against a
+  // tap of 1.0 (fmaf(1, b, +0) = b exactly), k = 1..9 the taps in (ky,kx) order -- the same chain as conv1a_kernel, bit for bit.
+  // unit u = wave + 4*uu covers m-tile u >> 1 and channel half u & 1 = wave & 1: a wave only ever needs one half of the weights
+  float c1a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      const int k = 2 * st + (lane >> 5);
+      c1a[st] = k == 0 ? a.b1a[(wave & 1) * 32 + (lane & 31)] : a.w1a[(k - 1) * 64 + (wave & 1) * 32 + (lane & 31)];
+    }
+  }
+  // the 15 tap bytes of a lane (3 units x 5 k-steps) are requested one item ahead, so their latency falls under the K loop
+  unsigned char rawt[3][5];
+  auto load_taps = [&](const WItem& T) {
+    const uint8_t* ip = a.img + (size_t)T.img * a.img_istride;
+#pragma unroll
+    for (int uu = 0; uu < 3; ++uu) {
+      const int pidx = ((wave >> 1) + 2 * uu) * 32 + (lane & 31);
+      const int gy = T.by * 8 - 1 + pidx / 18, gx = T.bx * 16 - 1 + pidx % 18;
+#pragma unroll
+      for (int st = 0; st < 5; ++st) {
+        const int k = 2 * st + (lane >> 5);
+        const int yy = gy + (k - 1) / 3 - 1, xx = gx + (k - 1) % 3 - 1;
+        const int yc = yy < 0 ? 0 : (yy >= aH ? aH - 1 : yy), xc = xx < 0 ? 0 : (xx >= aW ? aW - 1 : xx);
+        rawt[uu][st] = ip[(size_t)yc * a.img_stride + xc];
+      }
+    }
+  };
+  auto stage_fused = [&](const WItem& T) {
+    const float scale = (float)(1.0 / 255.0);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int uu = 0; uu < 3; ++uu) {
+      const int m = (wave >> 1) + 2 * uu, nt = wave & 1;        // 12 units = 6 m-tiles of 32 patch pixels x 2 halves of the channels
+      const int pidx = m * 32 + (lane & 31);
+      const int py = pidx / 18, px = pidx % 18;
+      const int gy = T.by * 8 - 1 + py, gx = T.bx * 16 - 1 + px;
+      const bool pvalid = pidx < 180 && gy >= 0 && gy < aH && gx >= 0 && gx < aW;
+      float tap[5];
+#pragma unroll
+      for (int st = 0; st < 5; ++st) {
+        const int k = 2 * st + (lane >> 5);                     // 0: the bias slot, 1..9: tap k-1
+        const int yy = gy + (k - 1) / 3 - 1, xx = gx + (k - 1) % 3 - 1;
+        const bool in = k > 0 && yy >= 0 && yy < aH && xx >= 0 && xx < aW;
+        tap[st] = k == 0 ? 1.0f : (in ? (float)rawt[uu][st] * scale : 0.f);
+      }
+      f32x16 d = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[0], tap[0], zero, 0, 0, 0);
+#pragma unroll
+      for (int st = 1; st < 5; ++st) d = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[st], tap[st], d, 0, 0, 0);
+      // rows (channels) of this lane: 8*q + 4*hh + (0..3) of half nt -> channel quad Q = nt*8 + 2*q + hh; column = patch pixel
+      if (pidx < 180) {
+        float* dst = wlds + ((py & 1) * 2 + (px & 1)) * PL + ((py >> 1) * WROW + (px >> 1)) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int Q = nt * 8 + 2 * q + hh;
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float v = d[4 * q + e]; o[e] = (pvalid && v > 0.f) ? v : 0.f; }
+          *reinterpret_cast<f32x4*>(dst + (Q >> 1) * CHF + (Q & 1) * 4 * PL) = o;
+        }
+      }
+    }
+  };
+
   // ---- prologue ---------------------------------------------------------------------------------------------------------------
   WItem cur = w_decode(t0, nbx, nby, ncb);
   WItem nxt = n_my > 1 ? w_decode(t0 + tstride, nbx, nby, ncb) : cur;
-  DmaItem dcur = dma_prepare(cur), dnxt = dma_prepare(nxt);
-  // chunk c of the walk belongs to item c / NCH: the DMA cursor is at most WR chunks (< NCH) ahead, i.e. in `cur` or `nxt`
+  DmaItem dcur{}, dnxt{};
+  if constexpr (!FUSE) {
+    dcur = dma_prepare(cur); dnxt = dma_prepare(nxt);
+    // chunk c of the walk belongs to item c / NCH: the DMA cursor is at most WR chunks (< NCH) ahead, i.e. in `cur` or `nxt`
 #pragma unroll
-  for (int c = 0; c < WR; ++c)
-    if (c < G) dma_issue(c < NCH ? dcur : dnxt, c % NCH, c);
+    for (int c = 0; c < WR; ++c)
+      if (c < G) dma_issue(c < NCH ? dcur : dnxt, c % NCH, c);
+  }
+  if constexpr (FUSE) load_taps(cur);
   int ucur = u_ptr(cur), unxt = u_ptr(nxt);
   load_u(0, ucur, 0);
   load_u(1, ucur, 1);
   load_u(2, ucur, 2);
-  if (G > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // chunk 0 landed (younger: 2 x 2 copies + 6 U loads)
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  read_d(0);
+  if constexpr (!FUSE) {
+    if (G > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // chunk 0 landed (younger: 2 x 2 copies + 6 U loads)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    read_d(0);
+  }
 
   const bool tracing = (ABL & 256) && blockIdx.x == 0 && tid == 0;
   auto mark = [&](int item, int ch, int slot) { if constexpr ((ABL & 256) != 0) { if (tracing && item < 4) g_wino_trace[item][ch][slot] = clock64(); } };
@@ -319,26 +397,37 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     transform(IC<3>{}, v);
     __builtin_amdgcn_sched_barrier(0);
     mark(item, ch, 1);
-    if (g + 1 < G) {
-      // chunk g+1 (copied WR-1 iterations ago) must have landed: the loads younger than it are this iteration's 8 U loads
-      // and the 2 copies of chunk g+2 -- loads complete in order, so "at most 10 outstanding" implies it is complete
-      if (g + 2 < G) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (FUSE) {
+      // the whole patch is in LDS: read the next chunk (after the last one: a harmless re-read of chunk 0)
+      read_d((ch + 1) & (NCH - 1));
+    } else {
+      if (g + 1 < G) {
+        // chunk g+1 (copied WR-1 iterations ago) must have landed: the loads younger than it are this iteration's 8 U loads
+        // and the 2 copies of chunk g+2 -- loads complete in order, so "at most 10 outstanding" implies it is complete
+        if (g + 2 < G) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      mark(item, ch, 2);
+      if constexpr (!(ABL & 8)) __syncthreads();   // every wave's part of chunk g+1 is in LDS; every wave has read chunk g out of its buffer
+      mark(item, ch, 3);
+      if (g + WR < G) {
+        const int c3 = ch + WR;      // chunk g+WR of the walk, relative to the current item
+        if (c3 < NCH) dma_issue(dcur, c3, g % WR); else dma_issue(dnxt, c3 - NCH, g % WR);
+      }
+      if constexpr (!(ABL & 16)) read_d((g + 1) % WR);        // unconditional (a stale buffer after the very last chunk): no phi copies
     }
-    mark(item, ch, 2);
-    if constexpr (!(ABL & 8)) __syncthreads();   // every wave's part of chunk g+1 is in LDS; every wave has read chunk g out of its buffer
-    mark(item, ch, 3);
-    if (g + WR < G) {
-      const int c3 = ch + WR;      // chunk g+WR of the walk, relative to the current item
-      if (c3 < NCH) dma_issue(dcur, c3, g % WR); else dma_issue(dnxt, c3 - NCH, g % WR);
-    }
-    if constexpr (!(ABL & 16)) read_d((g + 1) % WR);        // unconditional (a stale buffer after the very last chunk): no phi copies
     __builtin_amdgcn_sched_barrier(0);
     mfmas(IC<3>{}, IC<0>{}, v);
     ++g;
   };
 #pragma unroll 1
   for (int item = 0; item < n_my; ++item) {
+    if constexpr (FUSE) {
+      stage_fused(cur);
+      __syncthreads();
+      read_d(0);
+      if (item + 1 < n_my) load_taps(nxt);      // the next item's frame bytes, in flight during this item's K loop
+    }
     chunk(IC<1>{}, item, 0);       // the first k-step multiplies into C = 0: no accumulator clearing
 #pragma unroll 1
     for (int ch = 1; ch < NCH; ++ch) chunk(IC<0>{}, item, ch);
@@ -348,22 +437,22 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     cur = nxt; dcur = dnxt; ucur = unxt;
     if (item + 2 < n_my) {
       nxt = w_decode(t0 + (item + 2) * tstride, nbx, nby, ncb);
-      dnxt = dma_prepare(nxt);
+      if constexpr (!FUSE) dnxt = dma_prepare(nxt);
       unxt = u_ptr(nxt);
     }
   }
 }
 
-template <int CIN, bool POOL, bool RELU, int ABL = 0, int TAG = 0>
+template <int CIN, bool POOL, bool RELU, int ABL = 0, int TAG = 0, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a, int nbx, int nby, int ncb, int total) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   if ((int)blockIdx.x >= total) return;
   // the four rows of the transform domain run different (compile-time) row arithmetic; the branch is wave-uniform
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-    case 0: wino_body<CIN, POOL, RELU, ABL, 0>(a, nbx, nby, ncb, total, wlds); break;
-    case 1: wino_body<CIN, POOL, RELU, ABL, 1>(a, nbx, nby, ncb, total, wlds); break;
-    case 2: wino_body<CIN, POOL, RELU, ABL, 2>(a, nbx, nby, ncb, total, wlds); break;
-    default: wino_body<CIN, POOL, RELU, ABL, 3>(a, nbx, nby, ncb, total, wlds); break;
+    case 0: wino_body<CIN, POOL, RELU, ABL, 0, FUSE>(a, nbx, nby, ncb, total, wlds); break;
+    case 1: wino_body<CIN, POOL, RELU, ABL, 1, FUSE>(a, nbx, nby, ncb, total, wlds); break;
+    case 2: wino_body<CIN, POOL, RELU, ABL, 2, FUSE>(a, nbx, nby, ncb, total, wlds); break;
+    default: wino_body<CIN, POOL, RELU, ABL, 3, FUSE>(a, nbx, nby, ncb, total, wlds); break;
   }
 }
 
@@ -420,6 +509,28 @@ hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const C
   if (cin == 128 && !pool && relu) { D2FE_WINO_K((conv_wino_kernel<128, false, true>)); return hipGetLastError(); }
 #undef D2FE_WINO_K
   return hipErrorInvalidValue;
+}
+
+// conv1a (from the u8 frame) fused into the Winograd conv1b: a.img / a.w1a / a.b1a instead of a.in
+hipError_t launch_conv_wino_fused1b(int cout_pad, const ConvArgs& a, hipStream_t s) {
+  if (cout_pad != 64 || !a.img || !a.w1a || !a.b1a) return hipErrorInvalidValue;
+  if ((long)a.H * a.W * a.out_cstride >= (1l << 29)) return hipErrorInvalidValue;
+  const int nbx = (a.W + 15) / 16, nby = (a.H + 7) / 8, ncb = 1;
+  const int total = nbx * nby * a.n_img;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return hipErrorUnknown;
+    ncu = p.multiProcessorCount;
+  }
+  const int grid = total < 2 * ncu ? total : 2 * ncu;
+  constexpr size_t lds = (size_t)8 * 2 * 4 * 272 * sizeof(float);      // the 64-channel patch; the exchange area (48 KiB) reuses it
+  static_assert(lds >= (size_t)WXCH * sizeof(float), "exchange area must fit into the patch buffer");
+  auto k = conv_wino_kernel<64, true, true, 0, 1, true>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a, nbx, nby, ncb, total);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

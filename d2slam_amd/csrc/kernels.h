@@ -41,6 +41,7 @@ hipError_t launch_conv_pc(ConvShape shape, int precision, bool pool, bool relu, 
 
 // Winograd F(2x2,3x3) fp32 kernels (conv_wino.hip, precision mode 2): 3x3 layers with Cin 64 / 128, cout_pad a multiple of 64
 hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s);
+hipError_t launch_conv_wino_fused1b(int cout_pad, const ConvArgs& a, hipStream_t s);   // conv1a (u8 frame) + conv1b, ReLU, 2x2 pool
 size_t packed_weight_floats_wino(int cout_pad, int cin);
 void pack_weights_wino(const float* w /*[cout][cin][3][3]*/, int cout, int cin, int cout_pad, float* dst);
 

@@ -145,3 +145,22 @@ def test_wino_variant_a_matches_its_oracle(api, orc):
         assert np.array_equal(kps, rk) and np.array_equal(sc, rs)
         rd = orc.sample_a(f["desc"], rk, W, H)
         assert np.abs(desc - rd).max() <= 1e-5   # sparse head: direct chains at the keypoint cells vs the dense Winograd map
+
+
+@pytest.mark.gpu
+def test_wino_fused_conv1a_is_bit_identical(api, monkeypatch):
+    # D2FE_FUSE1A=1: conv1a evaluated on the matrix pipe inside the Winograd conv1b's staging -- same bits as the two-kernel form
+    H, W, n, cap = 120, 168, 4, 100
+    w = synthetic_superpoint_weights(dustbin_bias=7.5)
+    imgs = np.stack([synth_stereo(H, W, seed=41 + i)[i & 1] for i in range(n)])
+    outs, trunks = [], []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("D2FE_FUSE1A", fuse)
+        fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=cap, input_width=W, input_height=H, max_batch=n, precision=api.PREC_F32_WINO))
+        fe.load_superpoint(w)
+        outs.append(fe.extract_batch(imgs, cap=cap))
+        trunks.append(fe.debug_read("conv1b", (n, H // 2, W // 2, 64)))
+        fe.close()
+    assert np.array_equal(trunks[0], trunks[1])
+    for (k0, s0, d0), (k1, s1, d1) in zip(*outs):
+        assert np.array_equal(k0, k1) and np.array_equal(s0, s1) and np.array_equal(d0, d1)
