@@ -17,13 +17,13 @@
 //   A^T M A: s_i0 = (m_i0 + m_i1) + m_i2, s_i1 = (m_i1 - m_i2) - m_i3; y_0b = (s_0b + s_1b) + s_2b, y_1b = (s_1b - s_2b) - s_3b;
 //   y + bias, ReLU, max-pool.
 //
-// Work split.  Measured on gfx950 (tools/ubench/mfma_f32_valu.hip): a VALU instruction next to v_mfma_f32_32x32x2_f32 is not
-// hidden -- 64.7 cycles per MFMA bare, 77.5 with two VALU per gap, 87 with four, and a second wave on the SIMD does not change
-// that -- so the kernel is built to issue as few VALU instructions per MFMA as possible.  A wave owns ONE ROW i of the 4x4
+// Work split.  Measured on gfx950 (tools/ubench/mfma_f32_valu.hip): with ONE wave on a SIMD a VALU instruction next to
+// v_mfma_f32_32x32x2_f32 is not hidden (64.6 cycles per MFMA bare, 77.5 with two VALU per gap, 87.5 with four); with TWO waves the
+// partner's MFMAs cover it (64.2 bare, 69.8 with two or four per gap).  So a wave must fit 2 per SIMD: it owns ONE ROW i of the 4x4
 // transform domain: 32 tiles (4 x 8) x 64 output channels x the 4 positions (i, 0..3) = 128 accumulator registers, two
 // waves per SIMD.  Row i of B^T d B needs two rows of the input window and 4 + 4 subtractions per channel, which feed 8 MFMAs
-// (1 VALU per MFMA; the earlier split by halves of the domain needed 2, a wave with all 16 positions 2 and one wave per
-// SIMD).  A workgroup is the 4 waves i = 0..3 and handles 8 x 16 output pixels x 64 channels, two workgroups per CU.  The
+// (1 VALU per MFMA and 8 instead of 12 or 16 LDS reads per chunk; a wave with all 16 positions needs 256 accumulators, i.e. one
+// wave per SIMD).  A workgroup is the 4 waves i = 0..3 and handles 8 x 16 output pixels x 64 channels, two workgroups per CU.  The
 // output transform needs all four rows: after the K loop each wave forms its row of s = M A, the waves swap rows through
 // LDS (each keeps a quarter of the tiles, 48 floats per lane go each way) and finish A^T s, bias, ReLU, the 2x2 max-pool (the
 // Winograd tile IS the pool window) and the stores for their 8 of the 32 tiles.  The first k-step of an item multiplies into
@@ -35,7 +35,8 @@
 // buffers that runs on across work items.  LDS layout of a chunk: [channel quad 2][pixel parity plane 4][5 rows x 12 (9 used)]
 // [4 channels]: the 32 tiles of a wave read the same (dy,dx) of their 4x4 input window from ONE parity plane at positions
 // 12*ty + tx, and the tile -> MFMA-row assignment (below) makes that conflict-free for ds_read_b128's lane groups.  U streams
-// from L2 in MFMA lane order (8 values per lane per k-step, requested one k-step ahead, running on across work items).
+// from L2 in MFMA lane order (8 values per lane per k-step, requested three k-steps ahead, running on across work items).
+// With FUSE (conv1b, D2FE_FUSE1A=1) the copies are replaced by conv1a evaluated on the matrix pipe into a whole-K patch.
 #include "conv_common.h"
 
 #include <cstdio>
