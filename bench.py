@@ -85,7 +85,9 @@ def main():
     # with NetVLAD on its own side stream a third concurrent stream costs more than it hides (measured 1191 vs 1253 stereo fps)
     use_async_tail = args.async_tail and not args.netvlad
 
-    def run_mode(precision, want_breakdown):
+    def run_mode(precision, want_breakdown, netvlad=None):
+        nv = args.netvlad if netvlad is None else netvlad
+        use_async_tail = args.async_tail and not nv
         F = args.frames
         NI = 2 * F
         prec = {"f32": api.PREC_F32, "f16x2": api.PREC_F16X2, "wino": api.PREC_F32_WINO}[precision]
@@ -93,11 +95,14 @@ def main():
                                    device_id=local_rank, async_tail=use_async_tail)
         fe = api.FrontEnd(cfg)
         fe.load_superpoint(weights)
-        if args.netvlad:
+        if nv:
             from d2slam_amd import netvlad as nvm
             fe.load_netvlad(nvm.synthetic_netvlad_weights())
             gdesc = torch.zeros((F, fe.netvlad_dim), dtype=torch.float32, device=dev)
-            side = torch.cuda.Stream(device=dev)   # NetVLAD's ~60 small kernels overlap the SuperPoint convs on a 2nd HIP stream
+            # NetVLAD's ~60 small kernels overlap the direct-mode SuperPoint convs on a 2nd HIP stream; the Winograd kernels are
+            # persistent with two 72 KB workgroups per CU, beside which nothing else fits -- there NetVLAD runs in line (D2FE_NV_SIDE=1 forces the side stream)
+            use_side = precision != "wino" or os.environ.get("D2FE_NV_SIDE") == "1"
+            side = torch.cuda.Stream(device=dev) if use_side else None
 
         # synthetic frames, resident in HBM before the timed region: [L0, R0, L1, R1, ...]
         host = np.empty((NI, H, W), np.uint8)
@@ -144,10 +149,11 @@ def main():
         tstream = tail.cuda_stream
 
         def step():
-            if args.netvlad:
+            if nv:
                 # left images are rows 0,2,4,... of imgs (image_stride = 2 frames); issued first, on the side stream
-                side.wait_stream(torch.cuda.current_stream(dev))
-                fe.netvlad_device(imgs.data_ptr(), F, W, H, gdesc.data_ptr(), stream=side.cuda_stream, image_stride=2 * H * W)
+                if side is not None:
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                fe.netvlad_device(imgs.data_ptr(), F, W, H, gdesc.data_ptr(), stream=(side.cuda_stream if side is not None else stream), image_stride=2 * H * W)
             fe.extract_device(imgs.data_ptr(), NI, W, H, kps.data_ptr(), scores.data_ptr(), desc.data_ptr(), kidx.data_ptr(),
                               CAP, cnt.data_ptr(), stream=stream)
             with torch.cuda.stream(tail):
@@ -162,7 +168,7 @@ def main():
                 # this step's left descriptors become the "previous keyframe" of the next step
                 desc[NI:NI + F].copy_(desc[left_rows])
                 cnt[NI:NI + F].copy_(cnt[left_rows])
-            if args.netvlad:
+            if nv and side is not None:
                 tail.wait_stream(side)      # the step's global descriptors are complete when its tail is (the convolutions of the next step do not wait for them)
 
         def barrier():
@@ -246,6 +252,7 @@ def main():
         for om in ("f32", "f16x2", "wino"):
             if om != args.precision:
                 others[om] = run_mode(om, False)
+    nv_leg = run_mode(args.precision, False, netvlad=True) if (not args.single_mode and not args.netvlad) else None
     value, ms_per_step, roofline = primary["value"], primary["ms_per_step"], primary["roofline"]
     n_kp, n_match, breakdown, NI, NP, F = (primary[k] for k in ("n_kp", "n_match", "breakdown", "NI", "NP", "F"))
 
@@ -288,6 +295,9 @@ def main():
                 "precision": om, "value": round(o["value"], 2), "unit": "stereo_frames/s",
                 "ms_per_step": round(o["ms_per_step"], 3), "roofline": o["roofline"], "parity": PAR[om]}
         out["mode_parity"] = PAR[args.precision]
+        if nv_leg is not None:   # the same step with the NetVLAD global descriptor of every left image added (BASELINE.json's metric names it)
+            out["with_netvlad"] = {"value": round(nv_leg["value"], 2), "unit": "stereo_frames/s", "ms_per_step": round(nv_leg["ms_per_step"], 3),
+                                   "note": "SuperPoint (L+R) + NetVLAD (L) + 2 matchKNN per stereo frame; stand-in MobileNetVLAD graph (DESIGN.md section 4)"}
         if breakdown:
             out["stage_ms"] = breakdown
             # HBM-bound tail of the path: algorithmic bytes per launch / HIP-event time of the stage.

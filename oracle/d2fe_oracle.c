@@ -9,7 +9,8 @@
  * for this path, and its C++ cannot be compiled here (needs OpenCV/Eigen/TensorRT/ROS; SURVEY.md
  * section 8c).  But the network and the variant-A sampling are also defined in PYTHON in the reference
  * (d2frontend/superpoint.ipynb, modules SuperPointNetHalf / SuperPointNet): tests/golden/make_golden_ref.py executes
- * those modules verbatim and commits their outputs, and tests/test_reference_golden.py holds orc_prep_u8 .. orc_softmax_semi,
+ * those modules verbatim and commits their outputs, and tests/test_reference_golden.py holds orc_prep_u8 .. orc_softmax_semi
+ * (with the 3x3 layers through orc_conv as well as through orc_conv3x3_wino, the restatement of the Winograd mode),
  * orc_l2norm_rows and orc_sample_a to them (and orc_sample_a's PCA convention to sklearn, the tool behind the CSVs).
  * Everything else in this file is **parity unpinned**: a line-by-line restatement of the cited C++ (or of the pinned
  * third-party version it calls), cross-checked in tests/ against independent implementations of the same ops only.
