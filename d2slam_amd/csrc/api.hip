@@ -1159,6 +1159,16 @@ long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_byte
   return fail(D2FE_ERR_INVALID, "unknown tensor name");
 }
 
+// Host-side half of the Winograd mode, callable without a GPU: U = G g G^T in the kernels' fragment order (see pack_weights_wino).
+long d2fe_debug_pack_wino(const float* weight, int cout, int cin, float* out, long max_floats) {
+  if (!weight || !out || cout < 1 || cin < 8 || (cin & 7)) return fail(D2FE_ERR_INVALID, "bad argument");
+  const int cout_pad = (cout + 63) / 64 * 64;
+  const size_t n = packed_weight_floats_wino(cout_pad, cin);
+  if ((long)n > max_floats) return fail(D2FE_ERR_TRUNCATED, "destination too small");
+  pack_weights_wino(weight, cout, cin, cout_pad, out);
+  return (long)n;
+}
+
 // One 3x3 layer through the Winograd kernels, host buffers in and out (layer-level parity tests and timing; not a product path).
 int d2fe_debug_conv3x3_wino(d2fe_handle h, const float* in, int n, int H, int W, int cin, const float* weight, const float* bias,
                             int cout, int pool, int relu, float* out, int iters, float* ms_per_launch) {

@@ -314,6 +314,9 @@ D2FE_API long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t
 /* One 3x3 / pad 1 layer (cin 64 or 128, ReLU, optional 2x2 max-pool) through the Winograd kernels of D2FE_PREC_F32_WINO, host
  * NHWC buffers in and out; iters > 0 also times `iters` back-to-back launches (HIP events on the handle's stream).  For the
  * layer-level parity tests (tests/test_wino.py) and tools/; the product path is d2fe_superpoint_extract*. */
+/* The host-side weight transform of that mode (U = G g G^T, packed [32-channel group][k-step][row i][lane][4]); needs no GPU.
+ * Returns the number of floats written (16 * cin * cout rounded up to 64 channels). */
+D2FE_API long d2fe_debug_pack_wino(const float* weight /*[cout][cin][3][3]*/, int cout, int cin, float* out, long max_floats);
 D2FE_API int d2fe_debug_conv3x3_wino(d2fe_handle h, const float* in, int n, int H, int W, int cin, const float* weight,
                                      const float* bias, int cout, int pool, int relu, float* out, int iters, float* ms_per_launch);
 

@@ -49,6 +49,30 @@ def test_oracle_forward_wino_close_to_direct(orc):
     assert np.abs(a["desc"] - b["desc"]).max() <= 1e-5
 
 
+def test_weight_transform_packing_cpu():
+    """pack_weights_wino (host code of the library, no GPU needed): U = G g G^T in double, rounded once, in MFMA fragment order."""
+    import ctypes as C
+    from d2slam_amd import build
+    lib = C.CDLL(build.LIB)
+    lib.d2fe_debug_pack_wino.restype = C.c_long
+    rng = np.random.default_rng(3)
+    cout, cin = 72, 64                       # 72 -> padded to 128 channels: the padding must come out as zeros
+    w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+    out = np.full(16 * cin * 128, np.nan, np.float32)
+    n = lib.d2fe_debug_pack_wino(w.ctypes.data_as(C.c_void_p), cout, cin, out.ctypes.data_as(C.c_void_p), C.c_long(out.size))
+    assert n == out.size
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+    U = np.einsum("ia,ocab,jb->ijoc", G, w.astype(np.float64), G)          # [i][j][co][ci]
+    pk = out.reshape(128 // 32, cin // 2, 4, 64, 4)                           # [group][k-step][row i][lane][j]
+    for grp in range(4):
+        for ks in (0, 1, 5, 31):
+            for lane in (0, 17, 32, 63):
+                co, ci = grp * 32 + (lane & 31), 8 * (ks // 4) + 4 * (lane >> 5) + ks % 4
+                ref = U[:, :, co, ci].astype(np.float32) if co < cout else np.zeros((4, 4), np.float32)
+                assert np.allclose(pk[grp, ks, :, lane, :], ref, rtol=0, atol=1e-7 * max(1.0, float(np.abs(ref).max())))
+    assert not np.isnan(out).any()
+
+
 WINO_LAYERS = [  # n, H, W, Cin, Cout, pool
     (2, 16, 64, 64, 64, False), (1, 24, 96, 64, 64, True), (1, 16, 32, 64, 128, False), (2, 8, 32, 128, 128, True),
     (1, 60, 80, 128, 256, False), (1, 30, 46, 64, 64, False), (1, 22, 34, 128, 128, True), (3, 8, 32, 64, 65, False),
