@@ -257,6 +257,11 @@ def test_golden_fixtures(orc, sp_weights):
     m = np.load(os.path.join(GOLDEN, "match_120x90.npz"))
     q, t, d = orc.match_knn(m["a"], m["b"], 0.8, m["pts_a"], m["pts_b"], 40.0)
     assert np.array_equal(q, m["q"]) and np.array_equal(t, m["t"]) and np.array_equal(d, m["d"])
+    # the Winograd restatement of the 3x3 layers against the same PyTorch-fp64 outputs, same bars
+    fw = orc.superpoint_forward(z["image"], sp_weights, wino=True)
+    assert np.abs(fw["logits"] - z["torch_logits"]).max() < 5e-5
+    assert np.abs(fw["semi"] - z["torch_semi"]).max() < 5e-6
+    assert np.abs(fw["desc"] - z["torch_desc"]).max() < 1e-5
 
 
 def test_netvlad_oracle_vs_torch(orc):
