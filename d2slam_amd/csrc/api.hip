@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -74,7 +75,7 @@ struct d2fe_context {
   // last call geometry (for debug reads)
   int last_w = 0, last_h = 0, last_n = 0;
   const uint8_t* last_gray = nullptr; int last_stride = 0; size_t last_istride = 0;
-  float* aconf = nullptr; int* clist = nullptr;     // variant A scratch
+  float* aconf = nullptr; int* clist = nullptr; int* a_ncand = nullptr;     // variant A scratch
   float* zeros = nullptr;      // 1 KiB of zeros (ConvArgs::zeros)
   // sparse descriptor head (variant B unless cfg.dense_descriptors): cell flags, cell -> slot map, slot -> cell list, counts, descriptors
   bool sparse_desc = false; int sp_slots = 0; int sp_min_batch = 4;
@@ -95,13 +96,11 @@ struct d2fe_context {
   // host-pointer matcher: pool of (stream, scratch) slots so that concurrent callers (the reference calls matchKNN from three
   // threads) neither share state nor pay hipStreamCreate / hipMalloc / hipFree (a device-wide sync) per call
   struct MatchSlot { hipStream_t stream = nullptr; char* buf = nullptr; bool busy = false; };
-  std::vector<MatchSlot> match_slots;
-  // matcher scratch
+  std::deque<MatchSlot> match_slots;     // deque: growing it never relocates the slots other threads are using
   std::mutex match_mu;
-  void* m_buf = nullptr;
-  size_t m_bytes = 0;
-  int32_t* m_cand4 = nullptr;
-  size_t m_cand4_bytes = 0;
+  // device-API matcher scratch (cand4), one per caller stream: calls on different streams may overlap on the GPU
+  struct MatchScratch { hipStream_t stream = nullptr; int32_t* cand4 = nullptr; size_t bytes = 0; };
+  std::deque<MatchScratch> m_scratch;
   // profiling (HIP events on the launch stream)
   int prof_mode = 0;
   std::vector<hipEvent_t> prof_pool;
@@ -269,9 +268,11 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     // getKeyPoints + NMS2 (superpoint_common.cpp:12-40,107-177): border = 0, sorted by confidence, max_num
     ProfScope ps(h, D2FE_PROF_SELECT, s);
     HIP_TRY(launch_nms2_a(h->semi.p, H, W, n, h->cfg.keypoint_threshold, h->cfg.nms_dist, h->aconf, h->clist, h->cand,
-                          h->cand_count, h->cand_cap, s));
+                          h->cand_count, h->cand_cap, h->a_ncand, s));
     HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, W, h->cfg.max_keypoints, cap, 1, d_kps, d_scores, d_idx,
                             d_n, s));
+    if ((long)H * W > 65536)     // the reference's CV_16UC1 index map wraps above 65 536 candidates; reproduced (no-op below that)
+      HIP_TRY(launch_nms2_wrap_fix(h->clist, h->a_ncand, H, W, n, d_kps, d_n, cap, s));
   } else {
     ProfScope ps(h, D2FE_PROF_SELECT, s);
     HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, W, h->cfg.max_keypoints, cap, 0, d_kps, d_scores, d_idx,
@@ -402,6 +403,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     if (cfg->postproc == D2FE_POSTPROC_A) {
       HIP_TRY(hipMalloc(&h->aconf, sizeof(float) * H * W * B));
       HIP_TRY(hipMalloc(&h->clist, sizeof(int) * H * W * B));
+      HIP_TRY(hipMalloc(&h->a_ncand, sizeof(int) * B));
       h->a_scap = h->cfg.max_keypoints < 1024 ? h->cfg.max_keypoints : 1024;   // select keeps at most min(max_keypoints, 1024)
       HIP_TRY(hipMalloc(&h->a_samp, sizeof(float) * 256 * (size_t)h->a_scap * B));
       HIP_TRY(hipMalloc(&h->a_cn, sizeof(float) * 256 * B));
@@ -434,11 +436,12 @@ void d2fe_destroy(d2fe_handle h) {
     if (t->p) hipFree(t->p);
   for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
   for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->cand_count, (void*)h->s_img, (void*)h->s_kps,
-                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, h->m_buf, (void*)h->m_cand4, (void*)h->aconf, (void*)h->clist, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc,
+                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc,
                   (void*)h->pca_comp_t, (void*)h->pca_mean})
     if (p) hipFree(p);
   nv_free(h);
   for (void* p : {(void*)h->nv_pca_comp, (void*)h->nv_pca_mean, (void*)h->nv_s_img, (void*)h->nv_s_out}) if (p) hipFree(p);
+  for (auto& sc : h->m_scratch) if (sc.cand4) hipFree(sc.cand4);
   for (auto& ms : h->match_slots) { if (ms.stream) { hipStreamSynchronize(ms.stream); (void)hipStreamDestroy(ms.stream); } if (ms.buf) hipFree(ms.buf); }
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -568,6 +571,10 @@ int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int
       HIP_TRY(hipMemcpy2DAsync(h->s_img + (size_t)i * width * height, width, gray + i * image_stride, stride, width, height,
                                hipMemcpyHostToDevice, s));
   }
+  // async_tail handles: a preceding d2fe_superpoint_extract_device call may still have its post-processing running on the tail
+  // stream against the single-buffered scratch (candidates, score map, sparse-head slots) that this run uses too
+  if (h->cfg.async_tail)
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(s, h->ev_tail[i], 0));
   rc = run_superpoint(h, h->s_img, n, width, height, width, (size_t)width * height, h->s_kps, h->s_scores, h->s_desc,
                       h->s_idx, dcap, h->s_n, s);
   if (rc) return rc;
@@ -1006,13 +1013,18 @@ int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* str
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   std::lock_guard<std::mutex> lk(h->match_mu);
+  // the candidate scratch is keyed by the caller's stream: two calls on different streams (main and tail, two threads) can
+  // overlap on the GPU and must not share cand4[pair][dir][row]; calls on one stream are ordered by the stream itself
+  d2fe_context::MatchScratch* sc = nullptr;
+  for (auto& e : h->m_scratch) if (e.stream == s) { sc = &e; break; }
+  if (!sc) { h->m_scratch.emplace_back(); sc = &h->m_scratch.back(); sc->stream = s; }
   const size_t need = sizeof(int32_t) * 4 * 2 * (size_t)mb->max_n * mb->npairs;
-  if (need > h->m_cand4_bytes) {
-    HIP_TRY(hipStreamSynchronize(s));
-    if (h->m_cand4) hipFree(h->m_cand4);
-    h->m_cand4 = nullptr; h->m_cand4_bytes = 0;
-    HIP_TRY(hipMalloc(&h->m_cand4, need));
-    h->m_cand4_bytes = need;
+  if (need > sc->bytes) {
+    HIP_TRY(hipStreamSynchronize(s));      // the only work that can still read the old scratch is on this stream
+    if (sc->cand4) hipFree(sc->cand4);
+    sc->cand4 = nullptr; sc->bytes = 0;
+    HIP_TRY(hipMalloc(&sc->cand4, need));
+    sc->bytes = need;
   }
   MatchArgs m;
   m.a = mb->d_a; m.b = mb->d_b; m.pts_a = mb->d_pts_a; m.pts_b = mb->d_pts_b;
@@ -1020,7 +1032,7 @@ int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* str
   m.npairs = mb->npairs; m.dim = mb->dim; m.max_n = mb->max_n; m.mode = mb->mode;
   m.ratio = mb->ratio; m.radius = mb->radius;
   m.q_idx = mb->d_q_idx; m.t_idx = mb->d_t_idx; m.dist = mb->d_dist; m.n_out = mb->d_n_out;
-  m.cand4 = h->m_cand4;
+  m.cand4 = sc->cand4;
   { ProfScope ps(h, D2FE_PROF_MATCH, s); HIP_TRY(launch_match(m, s)); }
   return D2FE_OK;
 }
@@ -1043,6 +1055,8 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
   constexpr size_t MAXN = 1024, MAXD = 256;
   constexpr size_t SLOT_BYTES = sizeof(float) * (2 * MAXN * MAXD + 4 * MAXN + MAXN) + sizeof(int32_t) * (2 * MAXN + 5 + 8 * MAXN) + 64;
   int slot = -1;
+  hipStream_t s = nullptr;
+  char* buf = nullptr;
   {
     std::lock_guard<std::mutex> lk(h->match_mu);
     for (size_t i = 0; i < h->match_slots.size(); ++i)
@@ -1055,9 +1069,9 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
       slot = (int)h->match_slots.size() - 1;
     }
     h->match_slots[slot].busy = true;
+    s = h->match_slots[slot].stream;      // read under the lock: another thread may be appending a slot right now
+    buf = h->match_slots[slot].buf;
   }
-  hipStream_t s = h->match_slots[slot].stream;
-  char* buf = h->match_slots[slot].buf;
   struct Release { d2fe_context* h; int slot; ~Release() { std::lock_guard<std::mutex> lk(h->match_mu); h->match_slots[slot].busy = false; } } release{h, slot};
   float* d_a = reinterpret_cast<float*>(buf);
   float* d_b = d_a + fa;

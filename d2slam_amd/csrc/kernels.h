@@ -76,7 +76,9 @@ hipError_t launch_desc_head_sparse(const float* kps_xy, const int32_t* n_kp, int
 
 // variant A (SuperPointONNX path): NMS2-exact and grid_sampler(align_corners=false) sampling with optional PCA
 hipError_t launch_nms2_a(const float* semi, int H, int W, int n_img, float thr, int dist, float* aconf, int* clist,
-                         unsigned long long* cand, int* cand_count, long cand_cap, hipStream_t s);
+                         unsigned long long* cand, int* cand_count, long cand_cap, int* ncand, hipStream_t s);
+hipError_t launch_nms2_wrap_fix(const int* clist, const int* ncand, int H, int W, int n_img, float* kps_xy, const int32_t* n_kp,
+                                int cap, hipStream_t s);
 hipError_t launch_sample_a(const float* desc_raw, int dstride, int dcoff, int Hc, int Wc, int img_w, int img_h, int n_img,
                            const float* kps_xy, const int32_t* n_kp, int cap, const float* comp_t, const float* mean,
                            int pca_dims, float* samp, int scap, float* cn, const int32_t* slotmap, int max_slots, float* desc_out,

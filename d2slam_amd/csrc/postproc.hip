@@ -561,29 +561,50 @@ hipError_t launch_sample_b(const float* desc_raw, int dstride, int dcoff, int Hc
 // after k sweeps the first k candidates in raster order are final.  One 1024-thread block per image iterates until a
 // sweep changes nothing.  `aconf` holds conf for currently-active candidates and 0 elsewhere, so a neighbour test is
 // one float compare.  Survivors are emitted as (conf, raster) keys for select_b_kernel (always_sort = 1).
-// Not reproduced: the reference's CV_16UC1 index-map wrap-around above 65535 candidates (:115,128) -- the true
-// location is returned instead.
+// The reference's CV_16UC1 index map (:115,128: `inds` holds the candidate's raster rank modulo 65536, and the output point is
+// pts_raw[inds(v,u)], :160-163) is reproduced by nms2_wrap_fix_kernel after the selection: above 65 536 candidates a survivor
+// of rank r is reported at the coordinates of candidate r mod 65536, exactly as the reference (and the oracle) do.
 // -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void nms2_a_kernel(const float* __restrict__ semi, int H, int W, float thr, int d,
                                                       float* __restrict__ aconf, int* __restrict__ clist,
                                                       unsigned long long* __restrict__ cand, int* __restrict__ cand_count,
-                                                      long cand_cap, int* __restrict__ iters_out) {
+                                                      long cand_cap, int* __restrict__ iters_out,
+                                                      int* __restrict__ ncand_out) {
   __shared__ int s_n, s_changed;
   const int img = blockIdx.x, tid = threadIdx.x;
   const size_t hw = (size_t)H * W;
   const float* sm = semi + img * hw;
   float* ac = aconf + img * hw;
   int* cl = clist + img * hw;
-  if (tid == 0) s_n = 0;
-  __syncthreads();
-  for (size_t i = tid; i < hw; i += 1024) {
-    const float p = sm[i];
-    const bool c = p > thr;
-    ac[i] = c ? p : 0.f;
-    if (c) cl[atomicAdd(&s_n, 1)] = (int)i;
+  // candidate list in RASTER order (cv::findNonZero order, :17-19): wave w owns the contiguous pixel segment
+  // [w*seg, (w+1)*seg); pass 1 counts per segment, pass 2 writes at the segment's prefix with ballot/mbcnt offsets.
+  // The order itself does not matter to the fixpoint below; it is what lets nms2_wrap_fix_kernel reproduce the
+  // reference's CV_16UC1 index map (rank -> pixel, pixel -> rank by binary search).
+  __shared__ int s_wcnt[16];
+  const int lane = tid & 63, wv = tid >> 6;
+  const size_t seg = ((hw + 15) / 16 + 63) / 64 * 64;
+  const size_t seg0 = wv * seg, seg1 = (seg0 + seg < hw) ? seg0 + seg : hw;
+  int wcnt = 0;
+  for (size_t i0 = seg0; i0 < seg1; i0 += 64) {
+    const size_t i = i0 + lane;
+    const float p = i < seg1 ? sm[i] : 0.f;
+    const bool c = i < seg1 && p > thr;
+    if (i < seg1) ac[i] = c ? p : 0.f;
+    wcnt += __popcll(__ballot(c));
   }
+  if (lane == 0) s_wcnt[wv] = wcnt;
   __syncthreads();
-  const int n = s_n;
+  int wbase = 0, n = 0;
+  for (int w = 0; w < 16; ++w) { if (w < wv) wbase += s_wcnt[w]; n += s_wcnt[w]; }
+  for (size_t i0 = seg0; i0 < seg1; i0 += 64) {
+    const size_t i = i0 + lane;
+    const bool c = i < seg1 && ac[i] != 0.f;
+    const unsigned long long m = __ballot(c);
+    if (c) cl[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (int)i;
+    wbase += __popcll(m);
+  }
+  if (tid == 0) { s_n = n; if (ncand_out) ncand_out[img] = n; }
+  __syncthreads();
   int iters = 0;
   for (;;) {
     if (tid == 0) s_changed = 0;
@@ -627,11 +648,34 @@ __global__ __launch_bounds__(1024) void nms2_a_kernel(const float* __restrict__ 
 }
 
 hipError_t launch_nms2_a(const float* semi, int H, int W, int n_img, float thr, int dist, float* aconf, int* clist,
-                         unsigned long long* cand, int* cand_count, long cand_cap, hipStream_t s) {
+                         unsigned long long* cand, int* cand_count, long cand_cap, int* ncand, hipStream_t s) {
   hipError_t e = hipMemsetAsync(cand_count, 0, sizeof(int) * n_img, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(nms2_a_kernel, dim3(n_img), dim3(1024), 0, s, semi, H, W, thr, dist, aconf, clist, cand, cand_count,
-                     cand_cap, (int*)nullptr);
+                     cand_cap, (int*)nullptr, ncand);
+  return hipGetLastError();
+}
+
+// CV_16UC1 wrap of NMS2's index map (superpoint_common.cpp:115,128,160-163), applied to the selected keypoints of an image
+// with more than 65 536 candidates: keypoint at pixel i (rank r in the raster-ordered candidate list) -> pixel clist[r & 0xFFFF].
+__global__ __launch_bounds__(256) void nms2_wrap_fix_kernel(const int* __restrict__ clist, const int* __restrict__ ncand, int H, int W,
+                                                            float* __restrict__ kps_xy, const int32_t* __restrict__ n_kp, int cap) {
+  const int img = blockIdx.y;
+  const int n = ncand[img];
+  if (n <= 65536) return;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_kp[img] || k >= cap) return;
+  const int* cl = clist + (size_t)img * H * W;
+  float* kp = kps_xy + ((size_t)img * cap + k) * 2;
+  const int i = (int)kp[1] * W + (int)kp[0];
+  int lo = 0, hi = n;                       // lower_bound: the list is ascending in pixel index
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (cl[mid] < i) lo = mid + 1; else hi = mid; }
+  const int j = cl[lo & 0xFFFF];
+  kp[0] = (float)(j % W); kp[1] = (float)(j / W);
+}
+hipError_t launch_nms2_wrap_fix(const int* clist, const int* ncand, int H, int W, int n_img, float* kps_xy, const int32_t* n_kp,
+                                int cap, hipStream_t s) {
+  hipLaunchKernelGGL(nms2_wrap_fix_kernel, dim3((cap + 255) / 256, n_img), dim3(256), 0, s, clist, ncand, H, W, kps_xy, n_kp, cap);
   return hipGetLastError();
 }
 

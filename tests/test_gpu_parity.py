@@ -289,6 +289,27 @@ def test_variant_a_nms2_exact(api, orc, sp_weights, H, W, d, maxkp):
     fe.close()
 
 
+def test_variant_a_u16_index_wrap(api, orc, sp_weights):
+    """NMS2's index map is CV_16UC1 (superpoint_common.cpp:115,128): above 65 536 candidates a survivor of raster rank r is
+    reported at the coordinates of candidate r mod 65536 (:160-163).  Oracle and device both reproduce it."""
+    H, W = 256, 320                                         # 81 920 pixels
+    img = synth_image(H, W, 5)
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=400, input_width=W, input_height=H, max_batch=1,
+                                           postproc=api.POSTPROC_A, nms_dist=3, keypoint_threshold=1e-6, keep_score_map=True))
+    fe.load_superpoint(sp_weights)
+    (kps, sc, desc), = fe.extract_batch(img[None], cap=400)
+    f = orc.superpoint_forward(img, sp_weights)
+    assert int((f["semi"] > 1e-6).sum()) > 70000            # the wrap really happens
+    rk, rs = orc.nms2_a(f["semi"], 1e-6, 3, 400)
+    assert np.array_equal(kps, rk) and np.array_equal(sc, rs)
+    # ... and it does move points: the score at the reported location is not the reported score for the wrapped ones
+    moved = sum(1 for (x, y), s in zip(rk.astype(int), rs) if f["semi"][y, x] != s)
+    assert moved > 0
+    rd = orc.sample_a(f["desc"], rk, W, H)
+    assert np.abs(desc - rd).max() <= 1e-6
+    fe.close()
+
+
 def test_variant_a_raster_dependence(api, orc, sp_weights):
     """NMS2 is raster-order dependent: the device fixpoint must reproduce the sequential sweep on a crafted
     score map.  Uses the NMS kernel through a frontend whose score map is replaced is not possible from outside, so this
