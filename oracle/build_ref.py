@@ -1,0 +1,85 @@
+"""oracle/build_ref.py -- builds oracle/_ref/libspref.so from the reference's OWN C++ (test infrastructure).
+
+The hot path's post-processing and matching glue in the reference depend on nothing but a handful of Eigen / OpenCV
+types, so the line ranges below are compiled exactly where they lie under /root/reference against the stand-in
+headers of oracle/ref_shim/ (what is and is not pinned by this: oracle/ref_shim/README.md).  Nothing is copied into
+the repository: the extracted text exists only in a temporary directory for the duration of the g++ call, and the
+only output is oracle/_ref/libspref.so (git-ignored, NOT gpurun-ignored: it travels to the GPU box like the product's
+own .so).  /root/reference does not exist on the GPU box; there the prebuilt library is used as is.
+
+Each range carries anchors (text that must appear on its first and last line) so that a reference tree that differs
+from the surveyed one (HKUST-Aerial-Robotics/D2SLAM @ 2024-12-18) fails the build instead of compiling something else.
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("D2FE_REFERENCE", "/root/reference")
+OUT_DIR = os.path.join(HERE, "_ref")
+LIB = os.path.join(OUT_DIR, "libspref.so")
+SHIM = os.path.join(HERE, "ref_shim")
+
+# macro -> (file under REF, first line, last line, anchor on first line, anchor on last line)
+RANGES = {
+    "SPREF_GEN_TENSORRT_INFER": ("d2frontend/src/CNN/superpoint_tensorrt.cpp", 161, 183, "bool SuperPoint::infer(const cv::Mat & input", "}"),
+    "SPREF_GEN_TENSORRT_POST": ("d2frontend/src/CNN/superpoint_tensorrt.cpp", 200, 350, "//replace to NMS", "}"),
+    "SPREF_GEN_COMMON_KPS": ("d2frontend/src/CNN/superpoint_common.cpp", 8, 40, "namespace D2FrontEnd {", "}"),
+    "SPREF_GEN_COMMON_NMS": ("d2frontend/src/CNN/superpoint_common.cpp", 101, 178, "bool pt_conf_comp(", "}  // namespace D2FrontEnd"),
+    "SPREF_GEN_MATCHER": ("d2frontend/src/feature_matcher.cpp", 3, 43, "namespace D2FrontEnd {", "}"),
+    "SPREF_GEN_HALFIMG": ("d2frontend/src/d2featuretracker.cpp", 1051, 1075, "getFeatureHalfImg(", "}"),
+    "SPREF_GEN_NEIGHBOUR": ("d2frontend/src/d2featuretracker.cpp", 1146, 1181, "std::map<int, int> tmp_to_idx_a, tmp_to_idx_b;", "}"),
+}
+
+
+def available():
+    return os.path.isdir(os.path.join(REF, "d2frontend", "src"))
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.abspath(__file__)]
+    for root, _, files in os.walk(SHIM):
+        deps += [os.path.join(root, f) for f in files]
+    deps += [os.path.join(REF, r[0]) for r in RANGES.values()]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Returns the library path, or None when /root/reference is absent and no prebuilt library exists."""
+    if not available():
+        return LIB if os.path.exists(LIB) else None
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with tempfile.TemporaryDirectory(prefix="spref_") as tmp:
+        defs = []
+        for macro, (rel, a, b, anchor_a, anchor_b) in RANGES.items():
+            path = os.path.join(REF, rel)
+            with open(path, encoding="utf-8") as f:
+                lines = f.read().split("\n")
+            first, last = lines[a - 1], lines[b - 1]
+            if anchor_a not in first or anchor_b not in last:
+                raise RuntimeError("%s:%d-%d does not look like the surveyed reference (anchors %r / %r not found in %r / %r)"
+                                   % (rel, a, b, anchor_a, anchor_b, first, last))
+            inc = os.path.join(tmp, macro.lower() + ".inc")
+            with open(inc, "w", encoding="utf-8") as f:
+                f.write('#line %d "%s"\n' % (a, path))
+                f.write("\n".join(lines[a - 1:b]) + "\n")
+            defs.append('-D%s="%s"' % (macro, inc))
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-w",
+               "-I" + SHIM, "-I" + os.path.join(REF, "d2frontend", "include")] + defs + \
+              [os.path.join(SHIM, "spref_api.cpp"), "-o", LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building oracle/_ref/libspref.so failed:\n" + r.stdout + r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="-f" in sys.argv, verbose=True))
