@@ -77,7 +77,7 @@ EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_creat
            "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device",
            "d2fe_half_image_filter", "d2fe_undistort", "d2fe_undistort_device", "d2fe_db_create", "d2fe_db_destroy",
            "d2fe_db_ntotal", "d2fe_db_add", "d2fe_db_search", "d2fe_db_query_gated", "d2fe_quantize_int8", "d2fe_dequantize_int8",
-           "d2fe_debug_read", "d2fe_debug_pack_wino", "d2fe_debug_conv3x3_wino", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read",
+           "d2fe_debug_read", "d2fe_debug_netvlad_layer", "d2fe_debug_pack_wino", "d2fe_debug_conv3x3_wino", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read",
            "d2fe_prepare_gray", "d2fe_prepare_gray_device", "d2fe_gen_cylinder_map", "d2fe_gen_cylinder_map_device", "d2fe_gen_pinhole_map", "d2fe_gen_pinhole_map_device",
            "d2fe_lk_frame_create", "d2fe_lk_frame_create_device", "d2fe_lk_frame_destroy", "d2fe_lk_frame_read_level",
            "d2fe_lk_track", "d2fe_lk_track_batch", "d2fe_detect_fast_by_region", "d2fe_good_features_to_track"]
@@ -385,6 +385,18 @@ class FrontEnd:
         if r < 0:
             _check(r)
         return r
+
+    def debug_netvlad_layer(self, layer, shape):
+        """Output of one layer of the last netvlad call ([n,h,w,c] fp32) or None when it only exists inside a fused block."""
+        out = np.empty(shape, np.float32)
+        self._lib.d2fe_debug_netvlad_layer.restype = C.c_long
+        r = self._lib.d2fe_debug_netvlad_layer(self._h, int(layer), int(shape[0]), _ptr(out), C.c_size_t(out.nbytes))
+        if r == -3:      # D2FE_ERR_NOT_READY
+            return None
+        if r < 0:
+            _check(int(r))
+        assert r == out.nbytes, (r, out.nbytes)
+        return out
 
     def netvlad(self, images):
         """MobileNetVLADONNX::inference for a batch of u8 images [n,H,W] -> [n, netvlad_dim]."""

@@ -3,6 +3,7 @@
 // conv_f16.hip, postproc.hip and match.hip.  There is deliberately NO CPU fallback in this library.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -84,8 +85,15 @@ struct d2fe_context {
   float* a_samp = nullptr; float* a_cn = nullptr; int a_scap = 0;   // variant A sampling: [batch][a_scap][256] samples, [batch][256] channel norms
   float* pca_comp_t = nullptr; float* pca_mean = nullptr; int pca_dims = 0;
   // NetVLAD
-  struct NvLayer { int kind, cin, cout, cout_pad, stride, act, res; float* w = nullptr; float* b = nullptr; float* out = nullptr; };
+  struct NvLayer { int kind, cin, cout, cout_pad, stride, act, res; float* w = nullptr; float* b = nullptr; float* out = nullptr; int oh = 0, ow = 0;
+                   int gmax = 1;                 // slabs `out` has room for (a fused block may split its hidden channels over workgroup groups)
+                   int slabs = 1; long slab_stride = 0; };   // of the last call: out = sum of `slabs` partial tensors `slab_stride` floats apart
   std::vector<NvLayer> nv;
+  // execution plan over the flat layer list: fused MobileNetV2 blocks (netvlad_fused.hip) where the pattern matches, single layers otherwise;
+  // only the LAST layer of a step is materialised in HBM (NvLayer::out), everything inside a fused block lives in LDS
+  struct NvStep { int l0 = 0, l1 = 0; bool fused = false, expand = false, front = false, tail = false; float* we = nullptr; float* wp = nullptr; float* bp = nullptr; float* w0 = nullptr; };
+  int nv_feat_gmax = 1, nv_feat_slabs = 1; long nv_feat_slab_stride = 0;      // the pre-projected features (input of the VLAD stage), same slab scheme
+  std::vector<NvStep> nv_plan;
   bool nv_loaded = false;
   int nv_feat = 0, nv_proj = 0, nv_k = 0;
   float *nv_pre_w = nullptr, *nv_pre_b = nullptr, *nv_aw = nullptr, *nv_ab = nullptr, *nv_cen = nullptr;
@@ -606,36 +614,107 @@ namespace {
 void nv_free(d2fe_context* h) {
   for (auto& l : h->nv) { if (l.w) hipFree(l.w); if (l.b) hipFree(l.b); if (l.out) hipFree(l.out); }
   h->nv.clear();
+  for (auto& st : h->nv_plan) { if (st.we) hipFree(st.we); if (st.wp) hipFree(st.wp); if (st.bp) hipFree(st.bp); if (st.w0) hipFree(st.w0); }
+  h->nv_plan.clear();
   for (float** p : {&h->nv_pre_w, &h->nv_pre_b, &h->nv_aw, &h->nv_ab, &h->nv_cen, &h->nv_feat_buf, &h->nv_raw, &h->nv_pca_out, &h->nv_part})
     if (*p) { hipFree(*p); *p = nullptr; }
   h->nv_loaded = false;
 }
 inline int same_out(int in, int stride) { return (in + stride - 1) / stride; }
+inline int same_pad_begin(int in, int stride, int out) { const int t = (out - 1) * stride + 3 - in; return t > 0 ? t / 2 : 0; }   // TF "SAME", 3x3
+
+// hidden-channel groups for a fused step: enough workgroups to fill the chip (2 per CU), at least 4 chunks of 16 per group (every
+// group stages the whole input patch again, and its consumer reads one more partial slab)
+inline void nv_groups(long base_blocks, int nchunk, int gmax, int* groups, int* cpg) {
+  static int target = -1;
+  if (target < 0) { const char* e = getenv("D2FE_NV_BLOCKS"); target = e ? atoi(e) : 512; }
+  int g = (int)((target + base_blocks - 1) / base_blocks);
+  if (g > gmax) g = gmax;
+  if (g > nchunk / 4) g = nchunk / 4;
+  if (g < 1) g = 1;
+  *cpg = (nchunk + g - 1) / g;
+  *groups = (nchunk + *cpg - 1) / *cpg;
+}
 
 int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int stride, size_t image_stride, float* d_out,
                 hipStream_t s) {
   ProfScope ps(h, D2FE_PROF_NETVLAD, s);
   int ch = H, cw = W;
-  std::vector<int> oh(h->nv.size()), ow(h->nv.size());
-  for (size_t i = 0; i < h->nv.size(); ++i) {
-    auto& l = h->nv[i];
-    const float* in = i ? h->nv[i - 1].out : nullptr;
-    const int ho = same_out(ch, l.stride), wo = same_out(cw, l.stride);
-    if (l.kind == D2FE_NV_CONV) {
-      HIP_TRY(launch_nv_conv0(d_gray, stride, (long)image_stride, ch, cw, ho, wo, l.stride, l.cout, l.act, l.w, l.b, l.out, n, s));
-    } else if (l.kind == D2FE_NV_DW) {
-      HIP_TRY(launch_nv_dw(in, ch, cw, l.cin, ho, wo, l.stride, l.act, l.w, l.b, l.out, n, s));
-    } else {
-      HIP_TRY(launch_nv_pw(in, (long)n * ch * cw, l.cin, l.cout, l.cout_pad, l.act, l.w, l.b, l.res >= 0 ? h->nv[l.res].out : nullptr,
-                           l.out, s));
+  bool feat_done = false;
+  for (size_t si = 0; si < h->nv_plan.size(); ++si) {
+    const auto& st = h->nv_plan[si];
+    const bool next_fused = si + 1 < h->nv_plan.size() && h->nv_plan[si + 1].fused;
+    if (!st.fused) {
+      auto& l = h->nv[st.l0];
+      const float* in = st.l0 ? h->nv[st.l0 - 1].out : nullptr;
+      const int ho = same_out(ch, l.stride), wo = same_out(cw, l.stride);
+      if (l.kind == D2FE_NV_CONV) {
+        HIP_TRY(launch_nv_conv0(d_gray, stride, (long)image_stride, ch, cw, ho, wo, l.stride, l.cout, l.act, l.w, l.b, l.out, n, s));
+      } else if (l.kind == D2FE_NV_DW) {
+        HIP_TRY(launch_nv_dw(in, ch, cw, l.cin, ho, wo, l.stride, l.act, l.w, l.b, l.out, n, s));
+      } else {
+        HIP_TRY(launch_nv_pw(in, (long)n * ch * cw, l.cin, l.cout, l.cout_pad, l.act, l.w, l.b, l.res >= 0 ? h->nv[l.res].out : nullptr,
+                             l.out, s));
+      }
+      l.slabs = 1; l.slab_stride = 0;
+      ch = ho; cw = wo;
+      continue;
     }
-    ch = ho; cw = wo; oh[i] = ho; ow[i] = wo;
+    NvBlockArgs a{};
+    int li = st.l0;
+    if (st.front) {
+      const auto& c0 = h->nv[li++];
+      a.img = d_gray; a.img_stride = stride; a.img_istride = (long)image_stride; a.H0 = ch; a.W0 = cw;
+      const int ho = same_out(ch, c0.stride), wo = same_out(cw, c0.stride);
+      a.c0_stride = c0.stride; a.c0_pt = same_pad_begin(ch, c0.stride, ho); a.c0_pl = same_pad_begin(cw, c0.stride, wo);
+      a.act0 = c0.act; a.w0 = st.w0;
+      ch = ho; cw = wo;
+    } else {
+      const auto& pin = h->nv[st.l0 - 1];
+      a.in = pin.out; a.in_slabs = pin.slabs; a.in_slab_stride = pin.slab_stride;
+    }
+    int groups = 1, cpg = 0;
+    if (st.tail) {
+      // the trunk's last 1x1 (expand: feat_dim hidden channels) chained with the NetVLAD pre-projection, over the flat pixel list
+      const auto& e = h->nv[li];
+      a.we = st.we; a.act_e = e.act;
+      a.H = ch; a.W = cw; a.Ho = ch; a.Wo = cw; a.Cin = e.cin; a.Chid = e.cout; a.Cout = h->nv_proj; a.stride = 1;
+      a.P = (long)n * ch * cw;
+      a.wp = st.wp; a.bp = st.bp; a.act_p = 0;
+      nv_groups((a.P + 127) / 128, a.Chid / 16, h->nv_feat_gmax, &groups, &cpg);
+      a.cpg = cpg; a.out = h->nv_feat_buf; a.out_slab_stride = a.P * a.Cout;
+      h->nv_feat_slabs = groups; h->nv_feat_slab_stride = a.out_slab_stride;
+      if (nv_tail_supported(a.Cin, a.Cout)) HIP_TRY(launch_nv_tail(a, groups, s));     // st.we was packed in that kernel's K order
+      else HIP_TRY(launch_nv_block(a, true, 2, n, groups, s));
+      feat_done = true;
+      continue;
+    }
+    if (st.expand) { const auto& e = h->nv[li++]; a.we = st.we; a.act_e = e.act; }
+    const auto& d = h->nv[li++];
+    auto& pj = h->nv[li];
+    a.H = ch; a.W = cw; a.Cin = st.expand ? h->nv[st.l0].cin : d.cin; a.Chid = d.cin; a.Cout = pj.cout; a.stride = d.stride;
+    a.Ho = same_out(ch, d.stride); a.Wo = same_out(cw, d.stride);
+    a.pt = same_pad_begin(ch, d.stride, a.Ho); a.pl = same_pad_begin(cw, d.stride, a.Wo);
+    a.act_d = d.act;
+    a.wp = st.wp; a.bp = st.bp; a.act_p = pj.act;
+    if (pj.res >= 0) { const auto& r = h->nv[pj.res]; a.res = r.out; a.res_slabs = r.slabs; a.res_slab_stride = r.slab_stride; }
+    const long tiles = (long)((a.Wo + 15) / 16) * ((a.Ho + 7) / 8) * n;
+    // partial slabs are summed by the consumer's staging: only when that consumer is a fused step
+    nv_groups(tiles, a.Chid / 16, next_fused ? pj.gmax : 1, &groups, &cpg);
+    a.cpg = cpg; a.out = pj.out; a.out_slab_stride = (long)n * a.Ho * a.Wo * a.Cout;
+    pj.slabs = groups; pj.slab_stride = a.out_slab_stride;
+    HIP_TRY(launch_nv_block(a, st.expand, st.front ? 1 : 0, n, groups, s));
+    ch = a.Ho; cw = a.Wo;
   }
   const int np = ch * cw;
-  const int pp = (h->nv_proj + 31) / 32 * 32;
-  HIP_TRY(launch_nv_pw(h->nv.back().out, (long)n * np, h->nv_feat, h->nv_proj, pp, 0, h->nv_pre_w, h->nv_pre_b, nullptr, h->nv_feat_buf, s));
+  if (!feat_done) {
+    const int pp = (h->nv_proj + 31) / 32 * 32;
+    HIP_TRY(launch_nv_pw(h->nv.back().out, (long)n * np, h->nv_feat, h->nv_proj, pp, 0, h->nv_pre_w, h->nv_pre_b, nullptr, h->nv_feat_buf, s));
+    h->nv_feat_slabs = 1; h->nv_feat_slab_stride = 0;
+  }
   float* raw = h->nv_pca_m ? h->nv_raw : d_out;
-  HIP_TRY(launch_nv_vlad(h->nv_feat_buf, np, h->nv_proj, h->nv_k, h->nv_aw, h->nv_ab, h->nv_cen, h->nv_part, raw, n, s));
+  HIP_TRY(launch_nv_vlad(h->nv_feat_buf, h->nv_feat_slabs, h->nv_feat_slab_stride, np, h->nv_proj, h->nv_k, h->nv_aw, h->nv_ab, h->nv_cen,
+                         h->nv_part, raw, n, s));
   if (h->nv_pca_m) HIP_TRY(launch_nv_pca(raw, h->nv_k * h->nv_proj, h->nv_pca_comp, h->nv_pca_mean, h->nv_pca_m, d_out, n, s));
   return D2FE_OK;
 }
@@ -652,11 +731,13 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
   nv_free(h);
   const int B = h->cfg.max_batch;
   int ch = h->cfg.max_height, cw = h->cfg.max_width, cprev = 1;
+  // any failure below leaves the handle without a NetVLAD network and frees what was uploaded so far
+  struct Guard { d2fe_context* h; bool ok = false; ~Guard() { if (!ok) nv_free(h); } } guard{h};
   for (int i = 0; i < w->n_layers; ++i) {
     const d2fe_nv_layer& L = w->layers[i];
     d2fe_context::NvLayer l;
     l.kind = L.kind; l.cin = L.cin; l.cout = L.cout; l.stride = L.stride; l.act = L.act; l.res = L.res;
-    if (!L.weight || !L.bias || L.stride < 1 || L.stride > 2 || L.cin != cprev || L.res >= i)
+    if (!L.weight || !L.bias || L.stride < 1 || L.stride > 2 || L.cin != cprev || L.res >= i || L.act < 0 || L.act > 2)
       return fail(D2FE_ERR_INVALID, "netvlad layer " + std::to_string(i) + ": bad descriptor");
     std::vector<float> wt, bt;
     if (L.kind == D2FE_NV_CONV) {
@@ -671,7 +752,6 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
       l.cout_pad = L.cout;
     } else if (L.kind == D2FE_NV_PW) {
       if ((L.cin & 3) || L.stride != 1) return fail(D2FE_ERR_INVALID, "pointwise layer: cin must be a multiple of 4, stride 1");
-      if (L.res >= 0 && w->layers[L.res].cout != L.cout) return fail(D2FE_ERR_INVALID, "residual channel mismatch");
       if (L.cin & 7) return fail(D2FE_ERR_INVALID, "pointwise layer: cin must be a multiple of 8");
       l.cout_pad = (L.cout + 31) / 32 * 32;
       wt.resize(packed_weight_floats_f32(l.cout_pad, L.cin, 1)); bt.assign(l.cout_pad, 0.f);
@@ -681,12 +761,95 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
       return fail(D2FE_ERR_INVALID, "unknown layer kind");
     }
     ch = same_out(ch, L.stride); cw = same_out(cw, L.stride);
-    int rc = upload(wt.data(), wt.size() * sizeof(float), reinterpret_cast<void**>(&l.w));
-    rc = rc ? rc : upload(bt.data(), bt.size() * sizeof(float), reinterpret_cast<void**>(&l.b));
+    l.oh = ch; l.ow = cw;
+    if (L.res >= 0) {
+      // a skip connection adds two tensors of the SAME shape: channels and spatial size (a stride-2 layer in between would make
+      // the 1x1 kernel read past the smaller buffer)
+      const auto& r = h->nv[L.res];
+      if (L.kind != D2FE_NV_PW || r.cout != L.cout || r.oh != ch || r.ow != cw)
+        return fail(D2FE_ERR_INVALID, "netvlad layer " + std::to_string(i) + ": residual source has a different shape");
+    }
+    h->nv.push_back(l);                 // pushed before the uploads: nv_free() releases whatever made it to the device
+    auto& dl = h->nv.back();
+    int rc = upload(wt.data(), wt.size() * sizeof(float), reinterpret_cast<void**>(&dl.w));
+    rc = rc ? rc : upload(bt.data(), bt.size() * sizeof(float), reinterpret_cast<void**>(&dl.b));
     if (rc) return rc;
-    HIP_TRY(hipMalloc(&l.out, sizeof(float) * (size_t)B * ch * cw * L.cout));
-    h->nv.push_back(l);
     cprev = L.cout;
+  }
+  // ---- plan: fuse [conv0 ->] [pw expand ->] dw -> pw project where the kernels support the shape (D2FE_NV_LEGACY=1: one launch per layer)
+  {
+    const char* e = getenv("D2FE_NV_LEGACY");
+    const bool legacy = e && atoi(e) != 0;
+    const int nl = w->n_layers;
+    auto K = [&](int i) { return i < nl ? h->nv[i].kind : -1; };
+    std::vector<char> materialised(nl, 0);
+    int i = 0;
+    while (i < nl) {
+      d2fe_context::NvStep st;
+      st.l0 = st.l1 = i;
+      if (!legacy) {
+        if (K(i) == D2FE_NV_CONV && K(i + 1) == D2FE_NV_DW && K(i + 2) == D2FE_NV_PW && h->nv[i + 1].res < 0 && h->nv[i + 2].res < 0 &&
+            nv_block_supported(h->nv[i + 1].cin, h->nv[i + 1].cin, h->nv[i + 2].cout, h->nv[i + 1].stride, false, 1)) {
+          st.fused = true; st.front = true; st.l1 = i + 2;
+        } else if (i > 0 && K(i) == D2FE_NV_PW && K(i + 1) == D2FE_NV_DW && K(i + 2) == D2FE_NV_PW && h->nv[i].res < 0 &&
+                   nv_block_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride, true, 0)) {
+          st.fused = true; st.expand = true; st.l1 = i + 2;
+        } else if (i > 0 && K(i) == D2FE_NV_DW && K(i + 1) == D2FE_NV_PW &&
+                   nv_block_supported(h->nv[i].cin, h->nv[i].cin, h->nv[i + 1].cout, h->nv[i].stride, false, 0)) {
+          st.fused = true; st.l1 = i + 1;
+        } else if (i > 0 && i == nl - 1 && K(i) == D2FE_NV_PW && h->nv[i].res < 0 &&
+                   nv_block_supported(h->nv[i].cin, h->nv[i].cout, w->proj_dim, 1, true, 2)) {
+          st.fused = true; st.tail = true; st.expand = true;        // last 1x1 of the trunk + the NetVLAD pre-projection in one launch
+        }
+        // a residual must read a tensor that exists in HBM: the output of an earlier step
+        if (st.fused && !st.tail && h->nv[st.l1].res >= 0 && !materialised[h->nv[st.l1].res]) { st = d2fe_context::NvStep(); st.l0 = st.l1 = i; }
+      }
+      if (!st.fused && h->nv[i].res >= 0 && !materialised[h->nv[i].res])
+        return fail(D2FE_ERR_UNSUPPORTED, "netvlad layer " + std::to_string(i) + ": residual source is internal to a fused block");
+      if (st.fused) {
+        int li = st.l0 + (st.front ? 1 : 0);
+        if (st.front) {
+          std::vector<float> pk(384);
+          pack_nv_conv0(w->layers[st.l0].weight, w->layers[st.l0].bias, w->layers[st.l0].cout, pk.data());
+          const int rc = upload(pk.data(), pk.size() * sizeof(float), reinterpret_cast<void**>(&st.w0));
+          if (rc) { h->nv_plan.push_back(st); return rc; }
+        }
+        if (st.expand) {
+          const d2fe_nv_layer& E = w->layers[li++];
+          std::vector<float> pk(pack_nv_expand_floats(E.cout, E.cin));
+          if (st.tail && nv_tail_supported(E.cin, w->proj_dim)) pack_nv_expand_tail(E.weight, E.bias, E.cout, E.cin, pk.data());
+          else pack_nv_expand(E.weight, E.bias, E.cout, E.cin, pk.data());
+          const int rc = upload(pk.data(), pk.size() * sizeof(float), reinterpret_cast<void**>(&st.we));
+          if (rc) { h->nv_plan.push_back(st); return rc; }
+        }
+        // depthwise + project record: the block's dw 3x3 and last 1x1, or (tail) no dw and the NetVLAD pre-projection [proj_dim][feat_dim]
+        const float* pwt = st.tail ? w->pre_w : w->layers[li + 1].weight;
+        const float* pbs = st.tail ? w->pre_b : w->layers[li + 1].bias;
+        const int pco = st.tail ? w->proj_dim : w->layers[li + 1].cout, pci = st.tail ? w->feat_dim : w->layers[li + 1].cin;
+        const int nt = nv_block_ntiles(pco);
+        std::vector<float> pk(pack_nv_dwproj_floats(pci, nt)), pb(nt * 16, 0.f);
+        pack_nv_dwproj(st.tail ? nullptr : w->layers[li].weight, st.tail ? nullptr : w->layers[li].bias, pwt, pco, pci, nt, pk.data());
+        for (int co = 0; co < pco; ++co) pb[co] = pbs[co];
+        h->nv_plan.push_back(st);
+        auto& ds = h->nv_plan.back();
+        int rc = upload(pk.data(), pk.size() * sizeof(float), reinterpret_cast<void**>(&ds.wp));
+        rc = rc ? rc : upload(pb.data(), pb.size() * sizeof(float), reinterpret_cast<void**>(&ds.bp));
+        if (rc) return rc;
+        if (st.tail) {
+          h->nv_feat_gmax = std::max(1, std::min(16, w->feat_dim / 32));
+        } else if (h->nv[st.l1].act == 0) {
+          // a linear bottleneck output may be written as partial slabs (hidden channels split over workgroup groups)
+          const int nchunk = h->nv[st.l1].cin / 16;
+          h->nv[st.l1].gmax = std::max(1, std::min(16, nchunk / 2));
+        }
+      } else {
+        h->nv_plan.push_back(st);
+      }
+      if (!st.tail) materialised[st.l1] = 1;
+      i = st.l1 + 1;
+    }
+    for (int li = 0; li < nl; ++li)
+      if (materialised[li]) HIP_TRY(hipMalloc(&h->nv[li].out, sizeof(float) * (size_t)h->nv[li].gmax * B * h->nv[li].oh * h->nv[li].ow * h->nv[li].cout));
   }
   if (cprev != w->feat_dim) return fail(D2FE_ERR_INVALID, "feat_dim does not match the last layer");
   h->nv_feat = w->feat_dim; h->nv_proj = w->proj_dim; h->nv_k = w->n_clusters;
@@ -701,13 +864,38 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
   rc = rc ? rc : upload(w->assign_b, sizeof(float) * w->n_clusters, reinterpret_cast<void**>(&h->nv_ab));
   rc = rc ? rc : upload(w->centroids, sizeof(float) * w->n_clusters * w->proj_dim, reinterpret_cast<void**>(&h->nv_cen));
   if (rc) return rc;
-  HIP_TRY(hipMalloc(&h->nv_feat_buf, sizeof(float) * (size_t)B * ch * cw * w->proj_dim));
+  HIP_TRY(hipMalloc(&h->nv_feat_buf, sizeof(float) * (size_t)h->nv_feat_gmax * B * ch * cw * w->proj_dim));
   HIP_TRY(hipMalloc(&h->nv_raw, sizeof(float) * (size_t)B * w->n_clusters * w->proj_dim));
   HIP_TRY(hipMalloc(&h->nv_part, sizeof(float) * (size_t)B * ((ch * cw + 63) / 64) * w->n_clusters * w->proj_dim));
   if (!h->nv_s_img) HIP_TRY(hipMalloc(&h->nv_s_img, (size_t)h->cfg.max_width * h->cfg.max_height * B));
   if (!h->nv_s_out) HIP_TRY(hipMalloc(&h->nv_s_out, sizeof(float) * 8192 * B));
   h->nv_loaded = true;
+  guard.ok = true;
   return D2FE_OK;
+}
+
+/* test hook: the output of layer `layer` of the loaded network for the last d2fe_netvlad* call (NHWC fp32), if the execution plan
+ * materialises it (the last layer of every fused block and every unfused layer); D2FE_ERR_NOT_READY otherwise. */
+long d2fe_debug_netvlad_layer(d2fe_handle h, int layer, int n_images, void* dst, size_t max_bytes) {
+  if (!h || !dst || !h->nv_loaded || layer < 0 || layer >= (int)h->nv.size() || n_images < 1 || n_images > h->cfg.max_batch)
+    return fail(D2FE_ERR_INVALID, "bad argument");
+  const auto& l = h->nv[layer];
+  if (!l.out) return fail(D2FE_ERR_NOT_READY, "layer output lives inside a fused block");
+  // spatial size of the LAST call: the plan works for any size up to the maximum; the caller passes images of the handle's maximum size here
+  const size_t bytes = sizeof(float) * (size_t)n_images * l.oh * l.ow * l.cout;
+  if (bytes > max_bytes) return fail(D2FE_ERR_TRUNCATED, "destination too small");
+  hipSetDevice(h->cfg.device_id);
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(dst, l.out, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(D2FE_ERR_HIP, "D2H");
+  if (l.slabs > 1) {      // hidden-channel groups wrote partial slabs: the tensor is their sum (what the consumer's staging forms)
+    if ((size_t)l.slab_stride * sizeof(float) != bytes) return fail(D2FE_ERR_INVALID, "n_images differs from the last call");
+    std::vector<float> tmp(bytes / sizeof(float));
+    float* o = static_cast<float*>(dst);
+    for (int sl = 1; sl < l.slabs; ++sl) {
+      if (hipMemcpy(tmp.data(), l.out + (size_t)sl * l.slab_stride, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(D2FE_ERR_HIP, "D2H");
+      for (size_t i = 0; i < tmp.size(); ++i) o[i] += tmp[i];
+    }
+  }
+  return (long)bytes;
 }
 
 int d2fe_set_netvlad_pca(d2fe_handle h, const float* comp, const float* mean, int m) {

@@ -91,9 +91,38 @@ hipError_t launch_nv_dw(const float* in, int H, int W, int C, int Ho, int Wo, in
                         float* out, int n, hipStream_t s);
 hipError_t launch_nv_pw(const float* in, long P, int Cin, int Cout, int CoutPad, int act, const float* w, const float* b,
                         const float* res, float* out, hipStream_t s);
-hipError_t launch_nv_vlad(const float* x, int np, int D, int K, const float* aw, const float* ab, const float* cen, float* part,
-                          float* out, int n, hipStream_t s);
+hipError_t launch_nv_vlad(const float* x, int slabs, long slab_stride, int np, int D, int K, const float* aw, const float* ab,
+                          const float* cen, float* part, float* out, int n, hipStream_t s);
 hipError_t launch_nv_pca(const float* x, int nfeat, const float* comp, const float* mean, int m, float* y, int n, hipStream_t s);
+
+// fused MobileNetV2 blocks (netvlad_fused.hip): [pw expand ->] dw 3x3 -> pw project (+ residual) in one launch, the expanded
+// tensor only ever in LDS; `front`: the block input is the first 3x3 convolution of the u8 frame, evaluated inside the staging
+struct NvBlockArgs {
+  const float* in;                 // NHWC [n][H][W][Cin]                     (unused when front)
+  int in_slabs; long in_slab_stride;     // the input is the sum of `in_slabs` partial tensors, `in_slab_stride` floats apart
+  const uint8_t* img; int img_stride; long img_istride; int H0, W0;           // front: the u8 frames
+  int c0_stride, c0_pt, c0_pl, act0; const float* w0;                         // front: first conv as B fragments (pack_nv_conv0)
+  float* out; long out_slab_stride;      // NHWC [n][Ho][Wo][Cout]; hidden-channel group g writes slab g
+  const float* res; int res_slabs; long res_slab_stride;   // residual: same shape as out (sum of res_slabs slabs) or null
+  int H, W, Cin, Chid, Cout, stride, Ho, Wo, pt, pl;
+  long P;                          // mode 2: number of pixels in the flat list
+  int cpg;                         // chunks of 16 hidden channels per workgroup group
+  const float* we;                    // expand weights + bias, one record per chunk (pack_nv_expand)
+  const float* wp;                    // depthwise weights + bias + project weights, one record per chunk (pack_nv_dwproj)
+  const float* bp;                    // project bias [Cout padded to the n-tiles]
+  int act_e, act_d, act_p;
+};
+bool nv_block_supported(int cin, int chid, int cout, int stride, bool expand, int mode);
+int nv_block_ntiles(int cout);
+hipError_t launch_nv_block(const NvBlockArgs& a, bool expand, int mode, int n, int groups, hipStream_t s);
+void pack_nv_expand(const float* w /*[chid][cin]*/, const float* b, int chid, int cin, float* dst);
+size_t pack_nv_expand_floats(int chid, int cin);
+void pack_nv_dwproj(const float* wd /*[chid][9] or null*/, const float* bd, const float* wp /*[cout][chid]*/, int cout, int chid, int nt, float* dst);
+size_t pack_nv_dwproj_floats(int chid, int nt);
+void pack_nv_expand_tail(const float* w, const float* b, int chid, int cin, float* dst);    // K order of nv_tail_kernel
+bool nv_tail_supported(int cin, int cout);
+hipError_t launch_nv_tail(const NvBlockArgs& a, int groups, hipStream_t s);
+void pack_nv_conv0(const float* w /*[cout][9]*/, const float* b, int cout, float* dst /*[384]*/);
 
 // ---- SURVEY 8(f) next rows (next.hip) ------------------------------------------------------------------------------------
 hipError_t launch_gen_map(const double* cam9, const double* q4, int mode, int width, int height, double f, float* mapx,

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void nv_pw_mfma_kernel(const float* __restrict
 // per chunk (deterministic: no float atomics).  Stage 2 (one block per image): chunk sum, intra-normalisation per cluster,
 // flatten k-major, global L2.  K <= 64, D <= 128*2, K*D <= 8192.
 constexpr int VL_PCH = 64;
-__global__ __launch_bounds__(256) void nv_vlad_partial_kernel(const float* __restrict__ x, int np, int D, int K,
+__global__ __launch_bounds__(256) void nv_vlad_partial_kernel(const float* __restrict__ x, int slabs, long slab_stride, int np, int D, int K,
                                                               const float* __restrict__ aw, const float* __restrict__ ab,
                                                               const float* __restrict__ cen, float* __restrict__ part,
                                                               int nchunk) {
@@ -174,7 +174,21 @@ __global__ __launch_bounds__(256) void nv_vlad_partial_kernel(const float* __res
   const int p0 = chunk * VL_PCH;
   const int pn = (np - p0) < VL_PCH ? (np - p0) : VL_PCH;
   const float* xi = x + ((size_t)img * np + p0) * D;
-  for (int i = tid; i < VL_PCH * D; i += 256) { const int p = i / D, j = i % D; xs[p * DS + j] = p < pn ? xi[(size_t)p * D + j] : 0.f; }
+  // x = sum of `slabs` partial tensors (the fused tail splits its hidden channels over workgroup groups); D is a multiple of 4
+  {
+    const int D4 = D >> 2;
+    for (int i = tid; i < VL_PCH * D4; i += 256) {
+      const int p = i / D4, j4 = i - p * D4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (p < pn) {
+        const float* s0 = xi + (size_t)p * D + j4 * 4;
+        v = *reinterpret_cast<const f32x4*>(s0);
+        for (int sl = 1; sl < slabs; ++sl) v += *reinterpret_cast<const f32x4*>(s0 + (size_t)sl * slab_stride);
+      }
+      float* d = xs + p * DS + j4 * 4;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+  }
   for (int i = tid; i < K * D; i += 256) ws[(i / D) * DS + i % D] = aw[i];
   __syncthreads();
   for (int i = tid; i < pn * K; i += 256) {
@@ -308,14 +322,14 @@ hipError_t launch_nv_pw(const float* in, long P, int Cin, int Cout, int CoutPad,
   else hipLaunchKernelGGL(nv_pw_mfma_kernel<1>, dim3(gx, ntiles), dim3(256), 0, s, in, P, Cin, Cout, act, wp, b, res, out);
   return hipGetLastError();
 }
-hipError_t launch_nv_vlad(const float* x, int np, int D, int K, const float* aw, const float* ab, const float* cen, float* part,
-                          float* out, int n, hipStream_t s) {
+hipError_t launch_nv_vlad(const float* x, int slabs, long slab_stride, int np, int D, int K, const float* aw, const float* ab,
+                          const float* cen, float* part, float* out, int n, hipStream_t s) {
   if (K > 64 || D > 256 || K * D > 8192) return hipErrorInvalidValue;
   const int nchunk = (np + VL_PCH - 1) / VL_PCH;
   const size_t lds = sizeof(float) * ((size_t)VL_PCH * (D + 1) + (size_t)K * (D + 1) + (size_t)VL_PCH * (K + 1));
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nv_vlad_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(nv_vlad_partial_kernel, dim3(nchunk, n), dim3(256), lds, s, x, np, D, K, aw, ab, cen, part, nchunk);
+  hipLaunchKernelGGL(nv_vlad_partial_kernel, dim3(nchunk, n), dim3(256), lds, s, x, slabs, slab_stride, np, D, K, aw, ab, cen, part, nchunk);
   hipLaunchKernelGGL(nv_vlad_final_kernel, dim3(n), dim3(1024), 0, s, part, nchunk, D, K, out);
   return hipGetLastError();
 }

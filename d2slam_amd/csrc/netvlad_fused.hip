@@ -1,0 +1,571 @@
+// netvlad_fused.hip -- MobileNetV2 inverted-residual blocks of the NetVLAD trunk as ONE kernel per block (gfx950).
+//
+// Replaces the per-layer launches of netvlad.hip for the layer patterns  [pw expand -> dw 3x3 -> pw project (+ residual)]  and
+// [dw 3x3 -> pw project]  (optionally with the network's first 3x3 convolution from the u8 frame evaluated inside the block's
+// input staging), and for the trunk's last 1x1 chained with the NetVLAD pre-projection.  Reference boundary:
+// MobileNetVLADONNX::inference, d2frontend/include/d2frontend/CNN/mobilenetvlad_onnx.h:49-74 (one ONNX Runtime session run);
+// the layer list is whatever d2fe_load_netvlad() was given.
+//
+// Why: the expanded tensor (6x the block's input) is the largest thing the trunk touches -- 472 MB for 32 images after the first
+// expand at 640x480 -- and it exists only between two layers of the same block.  Here it lives in LDS, 16 channels at a time:
+//
+//   workgroup = 8 x 16 output pixels x all output channels, 4 waves.
+//   X  [Cin + 4][XP]  input patch ((8-1)s+3) x ((16-1)s+3) pixels, channel-major in LDS, zeros outside the image (TF "SAME");
+//                     row Cin is the in-image mask: the expand bias enters the GEMM as one more k-step against it, so that
+//                     out-of-image pixels expand to act(0) = 0 without a compare per element
+//   per chunk of 16 hidden channels:
+//     expand  E[16][EP] = act([X; mask]^T [We; be])                      v_mfma_f32_16x16x4_f32, M = patch pixels, K = Cin + 4
+//     dw      d = act(sum_9 E[c][p + tap] wd[tap][c] + bd[c])           v_pk_fma_f32 (two output rows per instruction); each lane
+//                                                                       computes exactly the A-fragment elements (pixel = lane & 15,
+//                                                                       channel = 4 ks + lane >> 4) it feeds to
+//     project acc[pixel][cout] += d * Wp                                v_mfma_f32_16x16x4_f32, M = 128 output pixels, K = 16
+//   epilogue: + bias (+ residual), activation, NHWC store.
+//
+// The kernels are instruction-bound, not memory- or MFMA-bound (rocprofv3 PMC, profiles/): everything that is not an MFMA or one of
+// the 9 multiply-adds per depthwise output is overhead, so the code below keeps index arithmetic out of the loops (per-pixel
+// staging loop, 32-bit offsets, weights as whole-workgroup coalesced records through LDS, v_med3 activations).
+//
+// LDS pitches: XP = 16 (mod 32) floats so that the two channel rows a 32-lane group of ds_read_b32 touches fall on
+// disjoint bank halves; E uses the same pitch for stride 1 and an odd pitch for stride 2 (the 16 pixels of a lane group are
+// then 2 apart: even banks for one channel row, odd for the other).
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace d2fe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// act 0 none / 1 ReLU / 2 ReLU6 as one v_med3_f32 with the bounds in registers
+__device__ __forceinline__ float nvf_lo(int act) { return act >= 1 ? 0.f : -__builtin_inff(); }
+__device__ __forceinline__ float nvf_hi(int act) { return act == 2 ? 6.f : __builtin_inff(); }
+__device__ __forceinline__ float nvf_clamp(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+
+int nv_block_ntiles(int cout);
+constexpr int NVB_TH = 8, NVB_TW = 16;
+// MODE 0: spatial block (depthwise 3x3 between expand and project); 1: the same with the network's first conv evaluated into X from
+// the u8 frame; 2: no depthwise stage -- two chained 1x1 convolutions over a flat list of pixels (the trunk's last 1x1 + the
+// NetVLAD pre-projection), 128 consecutive pixels per workgroup
+__host__ __device__ constexpr int nvb_ih(int s) { return (NVB_TH - 1) * s + 3; }
+__host__ __device__ constexpr int nvb_iw(int s) { return (NVB_TW - 1) * s + 3; }
+__host__ __device__ constexpr int nvb_mt_in(int s, int mode) { return mode == 2 ? 8 : (nvb_ih(s) * nvb_iw(s) + 15) / 16; }
+__host__ __device__ constexpr int nvb_xp(int s, int mode) { return (nvb_mt_in(s, mode) * 16 + 31) / 32 * 32 + 16; }
+__host__ __device__ constexpr int nvb_ep(int s, int mode) { return (s == 1 || mode == 2) ? nvb_xp(s, mode) : nvb_mt_in(s, mode) * 16 + 1; }
+// E is double-buffered (one barrier per chunk instead of two) when that still leaves room for two workgroups per CU
+constexpr size_t NVB_LDS_2PER_CU = 80 * 1024;
+constexpr int NVB_U8_PITCH = 40;      // MODE 1: u8 patch rows ((10-1)*2+3 = 21 rows x 37 bytes for a stride-2 first conv)
+// per-chunk weight records as the host packs them and as they sit in LDS, sizes rounded up to 256 floats (one per thread and pass):
+//   WE record: [Cin/4 + 1][64] expand B fragments; the last k-step carries the bias (k = 0 row: be[16], rows 1..3: zeros)
+//   WD record: wd[9][16] (tap-major), bd[16], pad to 256, then [4][NT][64] project B fragments
+__host__ __device__ constexpr int nvb_we_rec(int cin) { return ((cin / 4 + 1) * 64 + 255) / 256 * 256; }
+__host__ __device__ constexpr int nvb_wd_rec(int nt) { return 256 + nt * 256; }
+static size_t nvb_lds_bytes(int cin, int s, int mode, bool expand, int nbuf, int nt) {
+  size_t fl = (size_t)(cin + (expand ? 4 : 0)) * nvb_xp(s, mode) + 2 * (size_t)nvb_wd_rec(nt) +
+              (expand ? (size_t)nbuf * 16 * nvb_ep(s, mode) + 2 * (size_t)nvb_we_rec(cin) : 0);
+  if (mode == 1) fl += 24 * NVB_U8_PITCH / 4 + 3 * 2 * 64;     // u8 patch + the first conv's B fragments
+  return fl * sizeof(float);
+}
+
+template <bool EXPAND, int MODE, int S, int NT, int NBUF>
+__global__ __launch_bounds__(256) void nv_block_kernel(NvBlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int IH = nvb_ih(S), IW = nvb_iw(S), NPX = MODE == 2 ? 128 : IH * IW, MT_IN = nvb_mt_in(S, MODE), XP = nvb_xp(S, MODE),
+                EP = nvb_ep(S, MODE);
+  constexpr int MPW = MT_IN / 4;                 // input m-tiles per wave (3, 9 or 2): exact, the wave loop has no remainder
+  constexpr int GI = MPW % 3 == 0 ? 3 : 2;       // independent MFMA chains in flight in the expand stage
+  static_assert(MT_IN % 4 == 0 && MPW % GI == 0, "m-tile split");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane >> 4, lp = lane & 15;
+  const int Cin = a.Cin;
+  float* X = lds;                                         // [Cin (+ 4: mask row, 3 zero rows)][XP]
+  float* E = X + (Cin + (EXPAND ? 4 : 0)) * XP;           // [NBUF][16][EP]         (EXPAND only)
+  float* WE = E + (EXPAND ? NBUF * 16 * EP : 0);          // [2][nvb_we_rec(Cin)]   (EXPAND only)
+  float* WD = WE + (EXPAND ? 2 * nvb_we_rec(Cin) : 0);    // [2][nvb_wd_rec(NT)]
+
+  const int tiles_x = (a.Wo + NVB_TW - 1) / NVB_TW;
+  const int n = blockIdx.y;
+  const int ty = MODE == 2 ? 0 : (int)blockIdx.x / tiles_x;
+  const int oy0 = ty * NVB_TH, ox0 = MODE == 2 ? 0 : ((int)blockIdx.x - ty * tiles_x) * NVB_TW;
+  const int iy0 = oy0 * S - a.pt, ix0 = ox0 * S - a.pl;
+  const int p0 = (int)blockIdx.x * 128;            // MODE 2: first pixel of the flat list (images folded into the list, gridDim.y == 1)
+
+  // ---- weights: no per-lane global loads.  A chunk's weights are one contiguous record (packed by the host in exactly the layout the
+  // lanes read), fetched by the whole workgroup with coalesced loads one chunk ahead and parked in two LDS double buffers; the
+  // barrier that already separates expand from depthwise publishes them:
+  //   top(ch): fetch WE(ch+1), WD(ch+1) -> regs | expand(ch) | regs -> WE[next] | barrier | dw+project(ch) | regs -> WD[next]
+  // (WD[next] was last read by dw+project(ch-1), which every wave left before this chunk's barrier.)
+  const int we_n = nvb_we_rec(Cin);
+  constexpr int WD_N = nvb_wd_rec(NT);
+  constexpr int WER = 8, WDR = WD_N / 256;                  // staged floats per thread (WER * 256 >= we_n: Cin <= 124, host check)
+  const int wer_n = we_n >> 8;
+  float wes[WER], wds[WDR];
+  const int nchunk = a.Chid >> 4;
+  const int ch0 = blockIdx.z * a.cpg, ch1 = min(nchunk, ch0 + a.cpg);      // this workgroup's share of the hidden channels
+  auto fetch_w = [&](int ch) {
+    if (EXPAND) {
+      const float* wb = a.we + (size_t)ch * we_n + tid;
+#pragma unroll
+      for (int i = 0; i < WER; ++i) if (i < wer_n) wes[i] = wb[256 * i];
+    }
+    const float* wb = a.wp + (size_t)ch * WD_N + tid;
+#pragma unroll
+    for (int i = 0; i < WDR; ++i) wds[i] = wb[256 * i];
+  };
+  auto store_we = [&](int buf) {
+    if (!EXPAND) return;
+    float* wl = WE + buf * we_n + tid;
+#pragma unroll
+    for (int i = 0; i < WER; ++i) if (i < wer_n) wl[256 * i] = wes[i];
+  };
+  auto store_wd = [&](int buf) {
+    float* wl = WD + buf * WD_N + tid;
+#pragma unroll
+    for (int i = 0; i < WDR; ++i) wl[256 * i] = wds[i];
+  };
+  if (ch0 < ch1) fetch_w(ch0);
+
+  // ---- stage the input patch -----------------------------------------------------------------------------------------
+  if (MODE == 1) {
+    // first conv on the matrix pipe: M = patch pixels, K = 9 taps + 1 bias row (+ 2 zero rows), N = Cin channels.  A = (u8 - 128)/128
+    // read from a u8 copy of the patch's receptive field in LDS; a pixel outside the conv's output zeroes its whole A row (bias row
+    // included), so X is act(0) = 0 there -- the depthwise stage's zero padding.
+    uint8_t* u8p = reinterpret_cast<uint8_t*>(WD + 2 * WD_N);
+    float* w0l = reinterpret_cast<float*>(u8p + 24 * NVB_U8_PITCH);      // [3][2][64]
+    const uint8_t* ip = a.img + (size_t)n * a.img_istride;
+    const int cs = a.c0_stride;
+    const int uy0 = iy0 * cs - a.c0_pt, ux0 = ix0 * cs - a.c0_pl;
+    const int UH = (IH - 1) * cs + 3, UW = (IW - 1) * cs + 3;       // 21 x 37 for cs = 2 (host checks UH <= 24, UW <= NVB_U8_PITCH)
+    for (int i = tid; i < UH * NVB_U8_PITCH; i += 256) {
+      const int uy = i / NVB_U8_PITCH, ux = i - uy * NVB_U8_PITCH;
+      const int yy = uy0 + uy, xx = ux0 + ux;
+      u8p[i] = (ux < UW && yy >= 0 && yy < a.H0 && xx >= 0 && xx < a.W0) ? ip[yy * a.img_stride + xx] : (uint8_t)128;   // 128 -> exactly 0 after (x-128)/128
+    }
+    for (int i = tid; i < 3 * 2 * 64; i += 256) w0l[i] = a.w0[i];
+    __syncthreads();
+    const int nt0 = Cin >> 4;                     // 1 or 2 n-tiles of 16 channels
+    const float lo0 = nvf_lo(a.act0), hi0 = nvf_hi(a.act0);
+#pragma unroll
+    for (int j = 0; j < MPW; ++j) {
+      const int mt = wave + 4 * j;
+      const int p = mt * 16 + lp;
+      const int iy = p / IW, ix = p - iy * IW;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      const bool ok = p < NPX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const uint8_t* up = u8p + (p < NPX ? (iy * cs) * NVB_U8_PITCH + ix * cs : 0);
+      // this lane's three k-steps: k = 4 ks + lq; k < 9 a tap, k == 9 the bias row (A = 1), k > 9 nothing
+      float av[3];
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const int k = ks * 4 + lq;
+        const int toff = k < 9 ? (k / 3) * NVB_U8_PITCH + (k % 3) : 0;
+        const float t = ((float)up[toff] - 128.0f) * 0.0078125f;
+        av[ks] = ok ? (k < 9 ? t : (k == 9 ? 1.f : 0.f)) : 0.f;
+      }
+      for (int t = 0; t < nt0; ++t) {
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], w0l[(ks * 2 + t) * 64 + lane], c, 0, 0, 0);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = nvf_clamp(c[r], lo0, hi0);
+        *reinterpret_cast<f32x4*>(X + (t * 16 + lp) * XP + mt * 16 + lq * 4) = o;
+      }
+    }
+  } else {
+    // one pixel per thread and pass, its channels in an inner loop: no division by a run-time channel count anywhere.
+    // The producer may have split its hidden channels over `in_slabs` workgroup groups: the input is the sum of its partial slabs.
+    const int c4n = Cin >> 2;
+    const float* ip = MODE == 2 ? a.in : a.in + (size_t)n * a.H * a.W * Cin;
+    constexpr int PXT = MODE == 2 ? 128 : MT_IN * 16;
+    // MODE 2: 128 pixels, two threads per pixel (each half of the channels)
+    const int half = MODE == 2 ? (tid >> 7) : 0;
+    const int cbeg = MODE == 2 ? half * (c4n >> 1) : 0, cend = MODE == 2 ? (half ? c4n : (c4n >> 1)) : c4n;
+    for (int p = MODE == 2 ? (tid & 127) : tid; p < PXT; p += 256) {
+      bool ok; int off;
+      if (MODE == 2) {
+        ok = p0 + p < a.P; off = (p0 + p) * Cin;
+      } else {
+        const int iy = p / IW, ix = p - iy * IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        ok = p < NPX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        off = (gy * a.W + gx) * Cin;
+      }
+      const float* src = ip + (ok ? off : 0);
+      float* d = X + p;
+      for (int c4 = cbeg; c4 < cend; ++c4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + c4 * 4);
+        for (int sl = 1; sl < a.in_slabs; ++sl) v += *reinterpret_cast<const f32x4*>(src + (size_t)sl * a.in_slab_stride + c4 * 4);
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        float* dc = d + (c4 * 4) * XP;
+        dc[0] = v[0]; dc[XP] = v[1]; dc[2 * XP] = v[2]; dc[3 * XP] = v[3];
+      }
+      if (EXPAND && half == 0) {
+        float* dm = d + Cin * XP;
+        dm[0] = ok ? 1.f : 0.f; dm[XP] = 0.f; dm[2 * XP] = 0.f; dm[3 * XP] = 0.f;
+      }
+    }
+  }
+  if (ch0 < ch1) { store_we(0); store_wd(0); }
+  __syncthreads();                                   // X (with its mask row) and the first chunk's weights are complete
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kse1 = (Cin >> 2) + 1;                   // k-steps of the expand GEMM incl. the bias step
+  const float lo_e = nvf_lo(a.act_e), hi_e = nvf_hi(a.act_e), lo_d = nvf_lo(a.act_d), hi_d = nvf_hi(a.act_d);
+
+  for (int ch = ch0; ch < ch1; ++ch) {
+    const int wb_i = (ch - ch0) & 1;
+    const float* Esrc;
+    if (ch + 1 < ch1) fetch_w(ch + 1);
+    if (EXPAND) {
+      float* Eb = E + (NBUF == 2 ? wb_i : 0) * 16 * EP;
+      const float* wl = WE + wb_i * we_n + lane;
+      if (NBUF == 1 && ch > ch0) __syncthreads();            // everybody is done reading the previous chunk
+#pragma unroll
+      for (int g = 0; g < MPW / GI; ++g) {
+        f32x4 c[GI];
+        const float* xa[GI];
+#pragma unroll
+        for (int j = 0; j < GI; ++j) {
+          c[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          xa[j] = X + lq * XP + (wave + 4 * (g * GI + j)) * 16 + lp;
+        }
+#pragma unroll 2
+        for (int ks = 0; ks < kse1; ++ks) {
+          const float wv = wl[ks * 64];
+#pragma unroll
+          for (int j = 0; j < GI; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j][ks * 4 * XP], wv, c[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < GI; ++j) {
+          const int mt = wave + 4 * (g * GI + j);
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = nvf_clamp(c[j][r], lo_e, hi_e);
+          float* e = Eb + lp * EP + mt * 16 + lq * 4;
+          if (EP % 4 == 0) *reinterpret_cast<f32x4*>(e) = o;
+          else { e[0] = o[0]; e[1] = o[1]; e[2] = o[2]; e[3] = o[3]; }
+        }
+      }
+      if (ch + 1 < ch1) store_we(wb_i ^ 1);
+      __syncthreads();
+      Esrc = Eb;
+    } else {
+      Esrc = X + ch * 16 * XP;
+    }
+    constexpr int PITCH = EXPAND ? EP : XP;
+    const float* wd = WD + wb_i * WD_N;
+    const float* wpl = wd + 256 + lane;
+    // the wave's two output rows (m-tiles 2 wave, 2 wave + 1) go through the depthwise stage as the halves of v_pk_fma_f32
+    const float* eb0 = MODE == 2 ? Esrc + (wave * 2) * 16 + lp : Esrc + (wave * 2 * S) * IW + lp * S;
+    constexpr int ROW2 = MODE == 2 ? 16 : S * IW;          // distance between the two rows' patch pixels
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float* e = eb0 + (ks * 4 + lq) * PITCH;
+      f32x2 d;
+      if (MODE == 2) {
+        d = f32x2{e[0], e[ROW2]};
+      } else {
+        const float bd = wd[144 + ks * 4 + lq];
+        d = f32x2{bd, bd};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float w = wd[(ky * 3 + kx) * 16 + ks * 4 + lq];
+            d = __builtin_elementwise_fma(f32x2{e[ky * IW + kx], e[ROW2 + ky * IW + kx]}, f32x2{w, w}, d);
+          }
+        d[0] = nvf_clamp(d[0], lo_d, hi_d); d[1] = nvf_clamp(d[1], lo_d, hi_d);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float wv = wpl[(ks * NT + t) * 64];
+        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[0], wv, acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[1], wv, acc[1][t], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < ch1) store_wd(wb_i ^ 1);
+    if (!EXPAND && ch + 1 < ch1) __syncthreads();   // no expand stage, hence no barrier of its own between the chunks
+  }
+
+  // ---- epilogue: C layout col = lane & 15 (channel within the n-tile), row = 4 (lane >> 4) + r (pixel = column ox of row oy) ------
+  // hidden-channel group g > 0 stores its bare partial sum into slab g; group 0 adds the bias and the residual.  32-bit offsets.
+  const bool lead = blockIdx.z == 0;
+  const int Cout = a.Cout;
+  float* op = a.out + (size_t)blockIdx.z * a.out_slab_stride + (MODE == 2 ? 0 : (size_t)n * a.Ho * a.Wo * Cout);
+  const float* rp = (a.res && lead) ? a.res + (size_t)n * a.Ho * a.Wo * Cout : nullptr;
+  const float lo_p = nvf_lo(a.act_p), hi_p = nvf_hi(a.act_p);
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2) {
+    int base, nvalid;
+    if (MODE == 2) {
+      const int p = p0 + (wave * 2 + m2) * 16 + lq * 4;
+      nvalid = (int)min((long)4, a.P - p);
+      base = p * Cout + lp;
+    } else {
+      const int gy = oy0 + wave * 2 + m2, gx = ox0 + lq * 4;
+      nvalid = gy < a.Ho ? min(4, a.Wo - gx) : 0;
+      base = (gy * a.Wo + gx) * Cout + lp;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t * 16 + lp >= Cout) continue;
+      const float bv = lead ? a.bp[t * 16 + lp] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r >= nvalid) continue;
+        const int o = base + r * Cout + t * 16;
+        float v = acc[m2][t][r] + bv;
+        if (rp) { for (int sl = 0; sl < a.res_slabs; ++sl) v += rp[(size_t)sl * a.res_slab_stride + o]; }
+        op[o] = nvf_clamp(v, lo_p, hi_p);
+      }
+    }
+  }
+}
+
+template <bool EXPAND, int MODE, int S, int NT, int NBUF>
+static hipError_t launch_block_b(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
+  const size_t lds = nvb_lds_bytes(a.Cin, S, MODE, EXPAND, NBUF, NT);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  auto k = nv_block_kernel<EXPAND, MODE, S, NT, NBUF>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const long tiles = MODE == 2 ? (a.P + 127) / 128 : (long)((a.Wo + NVB_TW - 1) / NVB_TW) * ((a.Ho + NVB_TH - 1) / NVB_TH);
+  hipLaunchKernelGGL(k, dim3((unsigned)tiles, MODE == 2 ? 1 : n, groups), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+template <bool EXPAND, int MODE, int S, int NT>
+static hipError_t launch_block_t(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
+  if (EXPAND && (S == 1 || MODE == 2) && nvb_lds_bytes(a.Cin, S, MODE, true, 2, NT) <= NVB_LDS_2PER_CU) return launch_block_b<EXPAND, MODE, S, NT, 2>(a, n, groups, s);
+  return launch_block_b<EXPAND, MODE, S, NT, 1>(a, n, groups, s);
+}
+
+template <bool EXPAND, int MODE, int S>
+static hipError_t launch_block_nt(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
+  const int nt = (a.Cout + 15) / 16;
+  if (nt == 1) return launch_block_t<EXPAND, MODE, S, 1>(a, n, groups, s);
+  if (nt == 2) return launch_block_t<EXPAND, MODE, S, 2>(a, n, groups, s);
+  if (nt <= 4) return launch_block_t<EXPAND, MODE, S, 4>(a, n, groups, s);
+  if (nt <= 8) return launch_block_t<EXPAND, MODE, S, 8>(a, n, groups, s);
+  return hipErrorInvalidValue;
+}
+
+// ---- the trunk's last 1x1 + the NetVLAD pre-projection, register-resident input ------------------------------------------------------
+// Same arithmetic as MODE 2 above, organised for the shape it really has (Cin = 112 -> 1280 hidden -> 128): a wave owns 32 pixels for
+// BOTH GEMMs, so the input (2 m-tiles x Cin values per lane group = NJ float4 per m-tile and lane) stays in registers for the whole
+// kernel, the expanded chunk only crosses LDS inside the wave (C layout -> A layout, no workgroup barrier), and the workgroup's LDS is
+// just the two weight double buffers (35 KB: four workgroups per CU instead of one).  A float4 load hands a lane 4 CONSECUTIVE input
+// channels of its pixel, so the K dimension is walked in the permuted order k = (lq + 4 j) * 4 + e (j = load, e = element); the host
+// packs the expand fragments in the same order (pack_nv_expand_tail).
+template <int NJ, int NT>
+__global__ __launch_bounds__(256) void nv_tail_kernel(NvBlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CIN = NJ * 16, KSE1 = CIN / 4 + 1, WE_N = nvb_we_rec(CIN), WD_N = nvb_wd_rec(NT), EPW = 48;
+  constexpr int WER = WE_N / 256, WDR = WD_N / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane >> 4, lp = lane & 15;
+  float* WE = lds;                    // [2][WE_N]
+  float* WD = WE + 2 * WE_N;          // [2][WD_N]
+  float* Ew = WD + 2 * WD_N + wave * 16 * EPW;   // [16][EPW] per wave
+  const int p0 = (int)blockIdx.x * 128 + wave * 32;
+  const int nchunk = a.Chid >> 4;
+  const int ch0 = blockIdx.z * a.cpg, ch1 = min(nchunk, ch0 + a.cpg);
+  float wes[WER], wds[WDR];
+  auto fetch_w = [&](int ch) {
+    const float* wb = a.we + (size_t)ch * WE_N + tid;
+#pragma unroll
+    for (int i = 0; i < WER; ++i) wes[i] = wb[256 * i];
+    const float* wc = a.wp + (size_t)ch * WD_N + tid;
+#pragma unroll
+    for (int i = 0; i < WDR; ++i) wds[i] = wc[256 * i];
+  };
+  auto store_w = [&](int buf) {
+    float* wl = WE + buf * WE_N + tid;
+#pragma unroll
+    for (int i = 0; i < WER; ++i) wl[256 * i] = wes[i];
+    float* wm = WD + buf * WD_N + tid;
+#pragma unroll
+    for (int i = 0; i < WDR; ++i) wm[256 * i] = wds[i];
+  };
+  if (ch0 < ch1) fetch_w(ch0);
+  // input: pixel p0 + mt*16 + lp, channels (lq + 4 j) * 4 .. + 3, summed over the producer's partial slabs
+  f32x4 xr[2][NJ];
+  float one[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int p = p0 + mt * 16 + lp;
+    const bool ok = p < a.P;
+    one[mt] = ok ? 1.f : 0.f;
+    const float* src = a.in + (ok ? p * CIN : 0) + lq * 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(src + j * 16);
+      for (int sl = 1; sl < a.in_slabs; ++sl) v += *reinterpret_cast<const f32x4*>(src + (size_t)sl * a.in_slab_stride + j * 16);
+      xr[mt][j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  if (ch0 < ch1) store_w(0);
+  __syncthreads();
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float lo_e = nvf_lo(a.act_e), hi_e = nvf_hi(a.act_e);
+  for (int ch = ch0; ch < ch1; ++ch) {
+    const int b = (ch - ch0) & 1;
+    if (ch + 1 < ch1) fetch_w(ch + 1);
+    const float* wl = WE + b * WE_N + lane;
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float wv = wl[(j * 4 + e) * 64];
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[0][j][e], wv, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[1][j][e], wv, c1, 0, 0, 0);
+      }
+    {
+      const float wv = wl[(KSE1 - 1) * 64];          // bias step
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(one[0], wv, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(one[1], wv, c1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c0[r] = nvf_clamp(c0[r], lo_e, hi_e); c1[r] = nvf_clamp(c1[r], lo_e, hi_e); }
+    // C layout (channel = lp, pixels lq*4 + r) -> wave-private LDS -> A layout (pixel = lp, channel = 4 ks + lq)
+    *reinterpret_cast<f32x4*>(Ew + lp * EPW + lq * 4) = c0;
+    *reinterpret_cast<f32x4*>(Ew + lp * EPW + 16 + lq * 4) = c1;
+    const float* wpl = WD + b * WD_N + 256 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float d0 = Ew[(ks * 4 + lq) * EPW + lp], d1 = Ew[(ks * 4 + lq) * EPW + 16 + lp];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float wv = wpl[(ks * NT + t) * 64];
+        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d0, wv, acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1, wv, acc[1][t], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < ch1) store_w(b ^ 1);
+    __syncthreads();          // the next chunk's weights are in place; everybody is done with this chunk's
+  }
+  const bool lead = blockIdx.z == 0;
+  const int Cout = a.Cout;
+  float* op = a.out + (size_t)blockIdx.z * a.out_slab_stride;
+  const float lo_p = nvf_lo(a.act_p), hi_p = nvf_hi(a.act_p);
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2) {
+    const int p = p0 + m2 * 16 + lq * 4;
+    const int nvalid = (int)min((long)4, a.P - p);
+    const int base = p * Cout + lp;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t * 16 + lp >= Cout) continue;
+      const float bv = lead ? a.bp[t * 16 + lp] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r >= nvalid) continue;
+        op[base + r * Cout + t * 16] = nvf_clamp(acc[m2][t][r] + bv, lo_p, hi_p);
+      }
+    }
+  }
+}
+// expand record for nv_tail_kernel: k-step (j, e) holds input channel (lq + 4 j) * 4 + e for lane group lq; bias step last
+void pack_nv_expand_tail(const float* w /*[chid][cin]*/, const float* b, int chid, int cin, float* dst) {
+  const int rec = nvb_we_rec(cin), nj = cin / 16;
+  for (int ch = 0; ch < chid / 16; ++ch) {
+    float* d = dst + (size_t)ch * rec;
+    for (int i = 0; i < rec; ++i) d[i] = 0.f;
+    for (int j = 0; j < nj; ++j)
+      for (int e = 0; e < 4; ++e)
+        for (int l = 0; l < 64; ++l) d[(j * 4 + e) * 64 + l] = w[(size_t)(ch * 16 + (l & 15)) * cin + ((l >> 4) + 4 * j) * 4 + e];
+    for (int c = 0; c < 16; ++c) d[(cin / 4) * 64 + c] = b[ch * 16 + c];
+  }
+}
+bool nv_tail_supported(int cin, int cout) { return (cin == 112 || cin == 128) && nv_block_ntiles(cout) == 8; }
+hipError_t launch_nv_tail(const NvBlockArgs& a, int groups, hipStream_t s) {
+  if (a.P * (long)std::max(a.Cin, a.Cout) >= (1l << 31)) return hipErrorInvalidValue;
+  const size_t lds = sizeof(float) * (2 * (size_t)nvb_we_rec(a.Cin) + 2 * (size_t)nvb_wd_rec(8) + 4 * 16 * 48);
+  auto k = a.Cin == 112 ? nv_tail_kernel<7, 8> : nv_tail_kernel<8, 8>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3((unsigned)((a.P + 127) / 128), 1, groups), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+int nv_block_ntiles(int cout) { const int nt = (cout + 15) / 16; return nt <= 2 ? nt : nt <= 4 ? 4 : nt <= 8 ? 8 : -1; }
+
+// mode: 0 spatial block, 1 spatial block behind the first conv (front), 2 two chained 1x1 convolutions (flat)
+bool nv_block_supported(int cin, int chid, int cout, int stride, bool expand, int mode) {
+  if (stride != 1 && stride != 2) return false;
+  if ((cin & 3) || (chid & 15) || cin < 4 || cout < 1 || nv_block_ntiles(cout) < 0) return false;
+  if (!expand && chid != cin) return false;
+  if (mode == 1 && (expand || stride != 1 || (cin != 16 && cin != 32))) return false;
+  if (mode == 2 && (!expand || stride != 1 || (cin & 7))) return false;
+  if (expand && nvb_we_rec(cin) > 8 * 256) return false;       // the expand-weight staging covers 8 x 256 floats per chunk (Cin <= 124)
+  return nvb_lds_bytes(cin, stride, mode, expand, 1, nv_block_ntiles(cout)) <= 160 * 1024;
+}
+
+// groups: the hidden channels are split over `groups` workgroup groups (grid.z); group g writes slab g of a.out (a.cpg chunks of 16 each)
+hipError_t launch_nv_block(const NvBlockArgs& a, bool expand, int mode, int n, int groups, hipStream_t s) {
+  // 32-bit element offsets inside the kernels
+  if ((long)a.H * a.W * a.Cin >= (1l << 31) || (long)a.Ho * a.Wo * a.Cout >= (1l << 31) || a.P * (long)std::max(a.Cin, a.Cout) >= (1l << 31))
+    return hipErrorInvalidValue;
+  if (mode == 1) {
+    if ((nvb_ih(1) - 1) * a.c0_stride + 3 > 24 || (nvb_iw(1) - 1) * a.c0_stride + 3 > NVB_U8_PITCH) return hipErrorInvalidValue;
+    return launch_block_nt<false, 1, 1>(a, n, groups, s);
+  }
+  if (mode == 2) return launch_block_nt<true, 2, 1>(a, n, groups, s);
+  if (expand) return a.stride == 1 ? launch_block_nt<true, 0, 1>(a, n, groups, s) : launch_block_nt<true, 0, 2>(a, n, groups, s);
+  return a.stride == 1 ? launch_block_nt<false, 0, 1>(a, n, groups, s) : launch_block_nt<false, 0, 2>(a, n, groups, s);
+}
+
+// ---- host-side packing: one record per chunk of 16 hidden channels, B fragments in v_mfma_f32_16x16x4_f32 order B[k = lane >> 4][n = lane & 15] ----
+// expand record (nvb_we_rec(cin) floats): [ks = cin/4][lane] = W[chunk*16 + (lane & 15)][ks*4 + (lane >> 4)], then the bias k-step
+// (k = 0 row: b[chunk*16 + (lane & 15)], rows 1..3: 0), zero padding
+void pack_nv_expand(const float* w /*[chid][cin]*/, const float* b /*[chid]*/, int chid, int cin, float* dst) {
+  const int rec = nvb_we_rec(cin);
+  for (int ch = 0; ch < chid / 16; ++ch) {
+    float* d = dst + (size_t)ch * rec;
+    for (int i = 0; i < rec; ++i) d[i] = 0.f;
+    for (int ks = 0; ks < cin / 4; ++ks)
+      for (int l = 0; l < 64; ++l) d[ks * 64 + l] = w[(size_t)(ch * 16 + (l & 15)) * cin + ks * 4 + (l >> 4)];
+    for (int c = 0; c < 16; ++c) d[(cin / 4) * 64 + c] = b[ch * 16 + c];
+  }
+}
+size_t pack_nv_expand_floats(int chid, int cin) { return (size_t)(chid / 16) * nvb_we_rec(cin); }
+// depthwise + project record (nvb_wd_rec(nt) floats): wd[tap][c] (c = channel within the chunk), bd[16], padding to 256,
+// then [ks = 4][t = nt][lane] = Wp[t*16 + (lane & 15)][chunk*16 + ks*4 + (lane >> 4)] (0 beyond cout).  wd/bd may be null (mode 2).
+void pack_nv_dwproj(const float* wd /*[chid][9]*/, const float* bd, const float* wp /*[cout][chid]*/, int cout, int chid, int nt, float* dst) {
+  const int rec = nvb_wd_rec(nt);
+  for (int ch = 0; ch < chid / 16; ++ch) {
+    float* d = dst + (size_t)ch * rec;
+    for (int i = 0; i < 256; ++i) d[i] = 0.f;
+    for (int t = 0; t < 9; ++t)
+      for (int c = 0; c < 16; ++c) d[t * 16 + c] = wd ? wd[(size_t)(ch * 16 + c) * 9 + t] : 0.f;
+    for (int c = 0; c < 16; ++c) d[144 + c] = bd ? bd[ch * 16 + c] : 0.f;
+    for (int ks = 0; ks < 4; ++ks)
+      for (int t = 0; t < nt; ++t)
+        for (int l = 0; l < 64; ++l) {
+          const int co = t * 16 + (l & 15), k = ch * 16 + ks * 4 + (l >> 4);
+          d[256 + (ks * nt + t) * 64 + l] = co < cout ? wp[(size_t)co * chid + k] : 0.f;
+        }
+  }
+}
+size_t pack_nv_dwproj_floats(int chid, int nt) { return (size_t)(chid / 16) * nvb_wd_rec(nt); }
+// first conv (mode 1) as B fragments [ks = 3][t = 2][lane]: k = ks*4 + (lane >> 4): k < 9 tap weight w[c][k], k == 9 the bias, else 0
+void pack_nv_conv0(const float* w /*[cout][9]*/, const float* b, int cout, float* dst /*[384]*/) {
+  for (int ks = 0; ks < 3; ++ks)
+    for (int t = 0; t < 2; ++t)
+      for (int l = 0; l < 64; ++l) {
+        const int k = ks * 4 + (l >> 4), c = t * 16 + (l & 15);
+        dst[(ks * 2 + t) * 64 + l] = c < cout ? (k < 9 ? w[c * 9 + k] : k == 9 ? b[c] : 0.f) : 0.f;
+      }
+}
+
+}  // namespace d2fe

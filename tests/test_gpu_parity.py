@@ -349,6 +349,35 @@ def test_netvlad_vs_oracle(api, orc, H, W):
     fe.close()
 
 
+@pytest.mark.parametrize("H,W", [(96, 128), (120, 200), (480, 640)])
+def test_netvlad_fused_blocks_layerwise(api, orc, H, W):
+    """Every tensor the fused MobileNetV2 block kernels (netvlad_fused.hip) write to HBM -- the last layer of each block -- against
+    the oracle's layer outputs: catches a wrong block long before the 4096-D descriptor would.  Sizes include a width that is not a
+    multiple of the 16-pixel tile and odd intermediate sizes (TF SAME padding with pad_begin = 1 on stride-2 layers)."""
+    from d2slam_amd import netvlad as nvm
+    nv = nvm.synthetic_netvlad_weights()
+    imgs = np.stack([synth_image(H, W, 9 + s) for s in range(2)])
+    fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
+    fe.load_netvlad(nv)
+    got = fe.netvlad(imgs)
+    fused = 0
+    refs = [orc.netvlad_forward(imgs[i], nv, return_layers=True) for i in range(2)]
+    for li, l in enumerate(nv["layers"]):
+        shp = (2,) + refs[0][1][li].shape
+        g = fe.debug_netvlad_layer(li, shp)
+        if g is None:
+            fused += 1
+            continue
+        for i in range(2):
+            r = refs[i][1][li]
+            err = np.abs(g[i] - r).max()
+            assert err <= 2e-5 * max(1.0, np.abs(r).max()), (li, l["kind"], err)
+    assert fused >= 30, "the fused block plan is not the one that ran (%d layers inside blocks)" % fused
+    for i in range(2):
+        assert np.abs(got[i] - refs[i][0]).max() <= 1e-4
+    fe.close()
+
+
 def test_stride_cap_and_batch_invariance(api, orc, sp_weights):
     """Row stride > width (cv::Mat ROI), cap < max_keypoints, and batch-position independence (an image's result must not
     depend on its neighbours in the batch or on the batch size)."""

@@ -1,21 +1,34 @@
-import sys, time
-sys.path.insert(0, '/root/repo')
+"""NetVLAD (A9) timing on the GPU: fused-block plan vs one launch per layer, HIP-event timed on the launch stream.
+usage: python tools/bench_netvlad.py [n_images ...]   (default 1 4 32)"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from d2slam_amd import api, netvlad as nvm
 from d2slam_amd.synth import synth_image
 H, W = 480, 640
-for n in (1, 4, 16):
-    fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=n))
-    fe.load_netvlad(nvm.synthetic_netvlad_weights())
-    dev = torch.device("cuda", 0)
-    imgs = torch.from_numpy(np.stack([synth_image(H, W, s) for s in range(n)])).to(dev)
-    out = torch.zeros((n, fe.netvlad_dim), device=dev)
-    st = torch.cuda.Stream()
-    def run():
-        fe.netvlad_device(imgs.data_ptr(), n, W, H, out.data_ptr(), stream=st.cuda_stream)
-    for _ in range(5): run()
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(30): run()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 30 * 1e3
-    print("NetVLAD n=%d: %.3f ms per call (%.3f ms per image)" % (n, dt, dt / n))
-    fe.close()
+ns = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 4, 32]
+modes = ["fused"] if "--fused-only" in sys.argv else ["legacy", "fused"]
+for mode in modes:
+    os.environ["D2FE_NV_LEGACY"] = "1" if mode == "legacy" else "0"
+    for n in ns:
+        fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=n))
+        fe.load_netvlad(nvm.synthetic_netvlad_weights())
+        dev = torch.device("cuda", 0)
+        imgs = torch.from_numpy(np.stack([synth_image(H, W, s) for s in range(min(n, 4))] * ((n + 3) // 4))[:n].copy()).to(dev)
+        out = torch.zeros((n, fe.netvlad_dim), device=dev)
+        st = torch.cuda.Stream()
+        def run():
+            fe.netvlad_device(imgs.data_ptr(), n, W, H, out.data_ptr(), stream=st.cuda_stream)
+        for _ in range(5): run()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(30): run()
+            e1.record(st)
+        torch.cuda.synchronize(); dt = e0.elapsed_time(e1) / 30
+        gf = 0.33e9 * 2 * n / (dt * 1e-3) / 1e12
+        print("NetVLAD %-6s n=%2d: %.3f ms per call (%.4f ms per image, %.1f TFLOP/s)" % (mode, n, dt, dt / n, gf), flush=True)
+        fe.close()
