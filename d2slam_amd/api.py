@@ -75,6 +75,8 @@ EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_creat
            "d2fe_load_superpoint", "d2fe_set_superpoint_pca", "d2fe_desc_dim", "d2fe_superpoint_extract", "d2fe_superpoint_extract_batch",
            "d2fe_superpoint_extract_device", "d2fe_tail_stream", "d2fe_superpoint_wait_tail", "d2fe_load_netvlad", "d2fe_set_netvlad_pca", "d2fe_netvlad_dim",
            "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device",
+           "d2fe_block_words", "d2fe_block_field_offset", "d2fe_pack_blocks_device", "d2fe_gate_pairs_device",
+           "d2fe_half_move_cols", "d2fe_half_image_compact_device", "d2fe_remap_matches_device",
            "d2fe_half_image_filter", "d2fe_undistort", "d2fe_undistort_device", "d2fe_db_create", "d2fe_db_destroy",
            "d2fe_db_ntotal", "d2fe_db_add", "d2fe_db_search", "d2fe_db_query_gated", "d2fe_quantize_int8", "d2fe_dequantize_int8",
            "d2fe_debug_read", "d2fe_debug_netvlad_layer", "d2fe_debug_pack_wino", "d2fe_debug_conv3x3_wino", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read",
@@ -117,6 +119,8 @@ def load_library():
         lib.d2fe_version.restype = C.c_char_p
         lib.d2fe_debug_read.restype = C.c_long
         lib.d2fe_destroy.restype = None
+        lib.d2fe_half_move_cols.restype = C.c_float
+        lib.d2fe_half_move_cols.argtypes = [C.c_int, C.c_double]
         lib.d2fe_default_config.restype = None
         lib.d2fe_superpoint_extract_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                       C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -496,11 +500,53 @@ class FrontEnd:
                                                C.byref(n)))
         return q[:n.value].copy(), t[:n.value].copy(), d[:n.value].copy()
 
+    def pack_blocks_device(self, d_desc, d_kps, d_scores, d_n, d_netvlad, row0, row_step, nframes, cap, netvlad_dim, d_blocks, stream=None):
+        """One exchange block per frame (desc | kps | scores | netvlad | n), raw device addresses; see include/d2fe.h."""
+        _check(self._lib.d2fe_pack_blocks_device(self._h, C.c_void_p(d_desc), C.c_void_p(d_kps), C.c_void_p(d_scores), C.c_void_p(d_n),
+                                                 C.c_void_p(d_netvlad or 0), int(row0), int(row_step), int(nframes), int(cap), int(netvlad_dim),
+                                                 C.c_void_p(d_blocks), C.c_void_p(stream or 0)))
+
+    def gate_pairs_device(self, d_q, q_stride, d_db, db_stride, dim, d_pair_q, d_pair_db, npairs, thres, d_cnt_inout=None, d_pass=None,
+                          d_sims=None, d_n_pass=None, stream=None):
+        """NetVLAD gate of a pair list (getMatchedPrevKeyframe's similarity test), raw device addresses."""
+        _check(self._lib.d2fe_gate_pairs_device(self._h, C.c_void_p(d_q), C.c_size_t(q_stride), C.c_void_p(d_db), C.c_size_t(db_stride), int(dim),
+                                                C.c_void_p(d_pair_q), C.c_void_p(d_pair_db), int(npairs), C.c_double(thres),
+                                                C.c_void_p(d_cnt_inout or 0), C.c_void_p(d_pass or 0), C.c_void_p(d_sims or 0),
+                                                C.c_void_p(d_n_pass or 0), C.c_void_p(stream or 0)))
+
+    def half_image_compact_device(self, d_desc, d_pts, d_n, d_job_row, d_job_left, d_job_shift, njobs, cap, dim, width_undistort, undistort_fov,
+                                  d_out_desc, d_out_pts, d_out_map, d_out_n, stream=None):
+        """getFeatureHalfImg for a batch of jobs + the a-side x shift (d2featuretracker.cpp:1051-1075,1161-1170); raw device addresses."""
+        V = C.c_void_p
+        _check(self._lib.d2fe_half_image_compact_device(self._h, V(d_desc), V(d_pts), V(d_n), V(d_job_row), V(d_job_left), V(d_job_shift), int(njobs),
+                                                        int(cap), int(dim), int(width_undistort), C.c_double(undistort_fov), V(d_out_desc), V(d_out_pts),
+                                                        V(d_out_map), V(d_out_n), V(stream or 0)))
+
+    def half_move_cols(self, width_undistort, undistort_fov):
+        """move_cols of getFeatureHalfImg: (float)(width_undistort * 90.0 / undistort_fov)."""
+        return float(self._lib.d2fe_half_move_cols(int(width_undistort), float(undistort_fov)))
+
+    def remap_matches_device(self, d_q, d_t, d_n_match, d_map_a_job, d_map_b_job, d_maps, npairs, cap_match, cap_map, stream=None):
+        """Index remap of matchLocalFeatures (d2featuretracker.cpp:1178-1181) for a batch of pairs; raw device addresses."""
+        V = C.c_void_p
+        _check(self._lib.d2fe_remap_matches_device(self._h, V(d_q), V(d_t), V(d_n_match), V(d_map_a_job), V(d_map_b_job), V(d_maps), int(npairs),
+                                                   int(cap_match), int(cap_map), V(stream or 0)))
+
     def match_batch_device(self, d_a, d_b, d_a_off, d_b_off, d_a_cnt, d_b_cnt, npairs, dim, max_n, d_q, d_t, d_dist,
                            d_n, mode=0, ratio=0.8, radius=-1.0, d_pts_a=None, d_pts_b=None, stream=None):
         mb = _MatchBatch(d_a, d_b, d_pts_a, d_pts_b, d_a_off, d_b_off, d_a_cnt, d_b_cnt, npairs, dim, max_n, mode,
                          ratio, radius, d_q, d_t, d_dist, d_n)
         _check(self._lib.d2fe_match_batch_device(self._h, C.byref(mb), stream))
+
+
+def block_words(cap, netvlad_dim):
+    """Float words of one exchange block (include/d2fe.h, d2fe_block_words); callable without a GPU."""
+    return int(load_library().d2fe_block_words(int(cap), int(netvlad_dim)))
+
+
+def block_field_offset(cap, netvlad_dim, field):
+    """Word offset of a block field: 'desc', 'kps', 'scores', 'netvlad', 'n'."""
+    return int(load_library().d2fe_block_field_offset(int(cap), int(netvlad_dim), ["desc", "kps", "scores", "netvlad", "n"].index(field)))
 
 
 class FlatIPDatabase:

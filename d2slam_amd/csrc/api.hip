@@ -91,7 +91,7 @@ struct d2fe_context {
   std::vector<NvLayer> nv;
   // execution plan over the flat layer list: fused MobileNetV2 blocks (netvlad_fused.hip) where the pattern matches, single layers otherwise;
   // only the LAST layer of a step is materialised in HBM (NvLayer::out), everything inside a fused block lives in LDS
-  struct NvStep { int l0 = 0, l1 = 0; bool fused = false, expand = false, front = false, tail = false; float* we = nullptr; float* wp = nullptr; float* bp = nullptr; float* w0 = nullptr; };
+  struct NvStep { int l0 = 0, l1 = 0; bool fused = false, expand = false, front = false, tail = false, xblock = false; float* we = nullptr; float* wp = nullptr; float* bp = nullptr; float* w0 = nullptr; };
   int nv_feat_gmax = 1, nv_feat_slabs = 1; long nv_feat_slab_stride = 0;      // the pre-projected features (input of the VLAD stage), same slab scheme
   std::vector<NvStep> nv_plan;
   bool nv_loaded = false;
@@ -195,7 +195,7 @@ int check_layer(const d2fe_conv_params& p, int cout, int cin, int ks, const char
 struct ProfScope {
   d2fe_context* h; int stage; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on = false;
   ProfScope(d2fe_context* h_, int stage_, hipStream_t s_) : h(h_), stage(stage_), s(s_) {
-    on = h->prof_mode == 2 || (h->prof_mode == 1 && stage == D2FE_PROF_CONV1B);
+    on = h->prof_mode == 2 || (h->prof_mode == 1 && (stage == D2FE_PROF_CONV1B || stage == D2FE_PROF_NETVLAD));
     if (!on) return;
     if (h->prof_used + 2 > h->prof_pool.size()) {
       for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } h->prof_pool.push_back(e); }
@@ -363,9 +363,8 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   d2fe_context* h = new d2fe_context();
   h->cfg = *cfg;
   const int rc_alloc = [&]() -> int {
-  // Winograd mode: conv1a materialised by its own (HBM-bound) kernel by default; D2FE_FUSE1A=1 evaluates it inside conv1b's
-  // staging instead (measured: the same throughput, 78.6 MB per image less memory and traffic, a lower MFMA fraction for conv1b)
-  if (h->cfg.precision == D2FE_PREC_F32_WINO) h->fuse1a = false;
+  // conv1a is evaluated inside conv1b's staging in every mode (the Winograd kernel runs it on the matrix pipe): the 78.6 MB/image
+  // activation never exists.  D2FE_FUSE1A=0 falls back to a stand-alone conv1a kernel (bit-identical; kept for A/B measurements).
   { const char* e = getenv("D2FE_FUSE1A"); if (e) h->fuse1a = atoi(e) != 0; }
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     const size_t H = cfg->max_height, W = cfg->max_width;
@@ -698,12 +697,15 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     a.act_d = d.act;
     a.wp = st.wp; a.bp = st.bp; a.act_p = pj.act;
     if (pj.res >= 0) { const auto& r = h->nv[pj.res]; a.res = r.out; a.res_slabs = r.slabs; a.res_slab_stride = r.slab_stride; }
-    const long tiles = (long)((a.Wo + 15) / 16) * ((a.Ho + 7) / 8) * n;
+    a.th = 8; a.tw = 16;
+    if (st.xblock) nv_xblock_tile(a.Ho, a.Wo, a.stride, &a.th, &a.tw);
+    const long tiles = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th) * n;
     // partial slabs are summed by the consumer's staging: only when that consumer is a fused step
     nv_groups(tiles, a.Chid / 16, next_fused ? pj.gmax : 1, &groups, &cpg);
     a.cpg = cpg; a.out = pj.out; a.out_slab_stride = (long)n * a.Ho * a.Wo * a.Cout;
     pj.slabs = groups; pj.slab_stride = a.out_slab_stride;
-    HIP_TRY(launch_nv_block(a, st.expand, st.front ? 1 : 0, n, groups, s));
+    if (st.xblock) HIP_TRY(launch_nv_xblock(a, n, groups, s));
+    else HIP_TRY(launch_nv_block(a, st.expand, st.front ? 1 : 0, n, groups, s));
     ch = a.Ho; cw = a.Wo;
   }
   const int np = ch * cw;
@@ -794,6 +796,8 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
         } else if (i > 0 && K(i) == D2FE_NV_PW && K(i + 1) == D2FE_NV_DW && K(i + 2) == D2FE_NV_PW && h->nv[i].res < 0 &&
                    nv_block_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride, true, 0)) {
           st.fused = true; st.expand = true; st.l1 = i + 2;
+          { const char* x = getenv("D2FE_NV_XBLOCK");      // input-in-registers form of the block (default on; 0: the LDS-resident form)
+            st.xblock = !(x && atoi(x) == 0) && nv_xblock_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride); }
         } else if (i > 0 && K(i) == D2FE_NV_DW && K(i + 1) == D2FE_NV_PW &&
                    nv_block_supported(h->nv[i].cin, h->nv[i].cin, h->nv[i + 1].cout, h->nv[i].stride, false, 0)) {
           st.fused = true; st.l1 = i + 1;
@@ -818,6 +822,7 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
           const d2fe_nv_layer& E = w->layers[li++];
           std::vector<float> pk(pack_nv_expand_floats(E.cout, E.cin));
           if (st.tail && nv_tail_supported(E.cin, w->proj_dim)) pack_nv_expand_tail(E.weight, E.bias, E.cout, E.cin, pk.data());
+          else if (st.xblock) { pk.assign(pack_nv_expand_perm_floats(E.cout, E.cin), 0.f); pack_nv_expand_perm(E.weight, E.bias, E.cout, E.cin, pk.data()); }
           else pack_nv_expand(E.weight, E.bias, E.cout, E.cin, pk.data());
           const int rc = upload(pk.data(), pk.size() * sizeof(float), reinterpret_cast<void**>(&st.we));
           if (rc) { h->nv_plan.push_back(st); return rc; }
@@ -1191,6 +1196,60 @@ int d2fe_dequantize_int8(d2fe_handle h, const int8_t* q, int n, int landmark_num
   if (!h || !q || !out || n < 1) return fail(D2FE_ERR_INVALID, "bad argument");
   if (landmark_num >= 0 && (n & 31)) return fail(D2FE_ERR_INVALID, "landmark descriptors: n must be a multiple of 32");
   return codec_run(h, q, (size_t)n, out, sizeof(float) * (size_t)n, n, landmark_num, false);
+}
+
+int d2fe_block_field_offset(int cap, int netvlad_dim, int field) {
+  if (cap < 1 || netvlad_dim < 0 || field < 0 || field > 4) return fail(D2FE_ERR_INVALID, "bad argument");
+  const int off[5] = {0, cap * 256, cap * 258, cap * 259, cap * 259 + netvlad_dim};
+  return off[field];
+}
+int d2fe_block_words(int cap, int netvlad_dim) {
+  if (cap < 1 || netvlad_dim < 0 || (netvlad_dim & 3)) return fail(D2FE_ERR_INVALID, "bad argument");
+  return (cap * 259 + netvlad_dim + 1 + 255) / 256 * 256;
+}
+int d2fe_pack_blocks_device(d2fe_handle h, const float* d_desc, const float* d_kps_xy, const float* d_scores, const int32_t* d_n,
+                            const float* d_netvlad, int row0, int row_step, int nframes, int cap, int netvlad_dim, float* d_blocks,
+                            void* stream) {
+  if (!h || !d_desc || !d_kps_xy || !d_scores || !d_n || !d_blocks) return fail(D2FE_ERR_INVALID, "null argument");
+  if (nframes < 1 || cap < 1 || row0 < 0 || row_step < 1 || netvlad_dim < 0 || (netvlad_dim & 3)) return fail(D2FE_ERR_INVALID, "bad geometry");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(launch_pack_blocks(d_desc, d_kps_xy, d_scores, d_n, d_netvlad, row0, row_step, nframes, cap, netvlad_dim,
+                             d2fe_block_words(cap, netvlad_dim), d_blocks, stream ? (hipStream_t)stream : h->stream));
+  return D2FE_OK;
+}
+int d2fe_gate_pairs_device(d2fe_handle h, const float* d_q, size_t q_stride, const float* d_db, size_t db_stride, int dim,
+                           const int32_t* d_pair_q, const int32_t* d_pair_db, int npairs, double thres, int32_t* d_cnt_inout,
+                           int32_t* d_pass, float* d_sims, int32_t* d_n_pass, void* stream) {
+  if (!h || !d_q || !d_db || !d_pair_q || !d_pair_db) return fail(D2FE_ERR_INVALID, "null argument");
+  if (npairs < 1 || dim < 4 || (dim & 3) || (q_stride & 3) || (db_stride & 3)) return fail(D2FE_ERR_INVALID, "dim and strides must be multiples of 4");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(launch_gate_pairs(d_q, (long)q_stride, d_db, (long)db_stride, dim, d_pair_q, d_pair_db, npairs, thres, d_cnt_inout, d_pass,
+                            d_sims, d_n_pass, stream ? (hipStream_t)stream : h->stream));
+  return D2FE_OK;
+}
+
+float d2fe_half_move_cols(int width_undistort, double undistort_fov) { return (float)((double)width_undistort * 90.0 / undistort_fov); }
+int d2fe_half_image_compact_device(d2fe_handle h, const float* d_desc, const float* d_pts_xy, const int32_t* d_n, const int32_t* d_job_row,
+                                   const int32_t* d_job_left, const float* d_job_shift_x, int njobs, int cap, int dim, int width_undistort,
+                                   double undistort_fov, float* d_out_desc, float* d_out_pts, int32_t* d_out_map, int32_t* d_out_n,
+                                   void* stream) {
+  if (!h || !d_desc || !d_pts_xy || !d_n || !d_job_row || !d_job_left || !d_job_shift_x || !d_out_desc || !d_out_pts || !d_out_map || !d_out_n)
+    return fail(D2FE_ERR_INVALID, "null argument");
+  if (njobs < 1 || cap < 1 || cap > 1024 || dim < 4 || (dim & 3) || width_undistort < 1 || !(undistort_fov > 0)) return fail(D2FE_ERR_INVALID, "bad geometry");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(launch_half_compact(d_desc, d_pts_xy, d_n, d_job_row, d_job_left, d_job_shift_x, njobs, cap, dim, (float)width_undistort,
+                              d2fe_half_move_cols(width_undistort, undistort_fov), d_out_desc, d_out_pts, d_out_map, d_out_n,
+                              stream ? (hipStream_t)stream : h->stream));
+  return D2FE_OK;
+}
+int d2fe_remap_matches_device(d2fe_handle h, int32_t* d_q_idx, int32_t* d_t_idx, const int32_t* d_n_match, const int32_t* d_map_a_job,
+                              const int32_t* d_map_b_job, const int32_t* d_maps, int npairs, int cap_match, int cap_map, void* stream) {
+  if (!h || !d_q_idx || !d_t_idx || !d_n_match || !d_map_a_job || !d_map_b_job || !d_maps) return fail(D2FE_ERR_INVALID, "null argument");
+  if (npairs < 1 || cap_match < 1 || cap_map < 1) return fail(D2FE_ERR_INVALID, "bad geometry");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(launch_remap_matches(d_q_idx, d_t_idx, d_n_match, d_map_a_job, d_map_b_job, d_maps, npairs, cap_match, cap_map,
+                               stream ? (hipStream_t)stream : h->stream));
+  return D2FE_OK;
 }
 
 int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* stream) {

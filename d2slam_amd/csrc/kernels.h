@@ -106,6 +106,7 @@ struct NvBlockArgs {
   const float* res; int res_slabs; long res_slab_stride;   // residual: same shape as out (sum of res_slabs slabs) or null
   int H, W, Cin, Chid, Cout, stride, Ho, Wo, pt, pl;
   long P;                          // mode 2: number of pixels in the flat list
+  int th, tw;                      // nv_xblock_kernel: output tile (th x tw <= 128 pixels)
   int cpg;                         // chunks of 16 hidden channels per workgroup group
   const float* we;                    // expand weights + bias, one record per chunk (pack_nv_expand)
   const float* wp;                    // depthwise weights + bias + project weights, one record per chunk (pack_nv_dwproj)
@@ -122,6 +123,12 @@ size_t pack_nv_dwproj_floats(int chid, int nt);
 void pack_nv_expand_tail(const float* w, const float* b, int chid, int cin, float* dst);    // K order of nv_tail_kernel
 bool nv_tail_supported(int cin, int cout);
 hipError_t launch_nv_tail(const NvBlockArgs& a, int groups, hipStream_t s);
+// expand blocks with the input in registers and a run-time tile shape (nv_xblock_kernel)
+bool nv_xblock_supported(int cin, int chid, int cout, int stride);
+void nv_xblock_tile(int Ho, int Wo, int stride, int* th, int* tw);
+size_t pack_nv_expand_perm_floats(int chid, int cin);
+void pack_nv_expand_perm(const float* w, const float* b, int chid, int cin, float* dst);
+hipError_t launch_nv_xblock(const NvBlockArgs& a, int n, int groups, hipStream_t s);
 void pack_nv_conv0(const float* w /*[cout][9]*/, const float* b, int cout, float* dst /*[384]*/);
 
 // ---- SURVEY 8(f) next rows (next.hip) ------------------------------------------------------------------------------------
@@ -135,6 +142,19 @@ hipError_t launch_db_search(const float* db, int ntotal, int dim, const float* q
                             int32_t* labels, float* out_sims, hipStream_t s);
 hipError_t launch_quant_int8(const float* x, int n, int double_max, int8_t* out, hipStream_t s);
 hipError_t launch_dequant_int8(const int8_t* q, int n, int landmark_num, float* out, hipStream_t s);
+
+// ---- cross-agent exchange (swarm.hip) -----------------------------------------------------------------------------------------
+hipError_t launch_pack_blocks(const float* desc, const float* kps, const float* scores, const int32_t* n_kp, const float* gdesc,
+                              int row0, int row_step, int nframes, int cap, int G, int blk_words, float* blocks, hipStream_t s);
+hipError_t launch_gate_pairs(const float* q, long q_stride, const float* db, long db_stride, int dim, const int32_t* pair_q,
+                             const int32_t* pair_db, int npairs, double thres, int32_t* cnt_inout, int32_t* pass, float* sims,
+                             int32_t* n_pass, hipStream_t s);
+
+hipError_t launch_half_compact(const float* desc, const float* pts, const int32_t* n_kp, const int32_t* job_row, const int32_t* job_left,
+                               const float* job_shift, int njobs, int cap, int dim, float width_undistort, float move_cols,
+                               float* out_desc, float* out_pts, int32_t* out_map, int32_t* out_n, hipStream_t s);
+hipError_t launch_remap_matches(int32_t* q_idx, int32_t* t_idx, const int32_t* n_match, const int32_t* map_a_job, const int32_t* map_b_job,
+                                const int32_t* maps, int npairs, int cap_match, int cap_map, hipStream_t s);
 
 // ---- matcher --------------------------------------------------------------------------------------
 struct MatchArgs {

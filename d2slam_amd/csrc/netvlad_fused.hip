@@ -355,6 +355,265 @@ static hipError_t launch_block_nt(const NvBlockArgs& a, int n, int groups, hipSt
   return hipErrorInvalidValue;
 }
 
+// ---- expand -> depthwise -> project with the block INPUT in registers ------------------------------------------------------------------
+// What limits the LDS-resident form above on the low-resolution layers is occupancy: the input patch (Cin x 208 floats) plus two
+// E buffers leave room for two workgroups per CU, i.e. ~1.3 waves per SIMD on average, and every LDS round trip and barrier is
+// exposed (PMC: waves wait two thirds of their lifetime).  A wave only ever multiplies ITS OWN patch m-tiles in the expand stage, so
+// the input it needs is MPW x ceil(Cin/16) float4 per lane, loaded once, straight from HBM/L2 into registers -- no staging pass, no
+// A-operand LDS reads, and the workgroup's LDS shrinks to E plus the weight double buffers (~40 KB: four workgroups per CU).
+// K order: a float4 hands a lane 4 consecutive channels of its pixel, so k-step (j, e) carries channel (lq + 4 j) * 4 + e
+// (zero rows beyond Cin); pack_nv_expand_perm packs the B fragments to match.
+// Tile shape is a run-time choice (th x tw <= 128 output pixels, row-major flat index -> m-tiles), so that 15x20 or 30x40 maps are
+// cut into 5x20 / 6x20 tiles without padding instead of 47 % / 78 % useful 8x16 tiles; the lane -> pixel maps are computed once.
+template <int S, int NT, int NJ>
+__global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int MT_IN = nvb_mt_in(S, 0), EP = nvb_ep(S, 0), NBUF = S == 1 ? 2 : 1;
+  constexpr int MPW = MT_IN / 4, GI = 3;
+  constexpr int KSE1 = NJ * 4 + 1, WE_N = (KSE1 * 64 + 255) / 256 * 256, WD_N = nvb_wd_rec(NT), WER = WE_N / 256, WDR = WD_N / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane >> 4, lp = lane & 15;
+  float* E = lds;                         // [NBUF][16][EP]
+  float* WE = E + NBUF * 16 * EP;         // [2][WE_N]
+  float* WD = WE + 2 * WE_N;              // [2][WD_N]
+  const int Cin = a.Cin, th = a.th, tw = a.tw;
+  const int iw = (tw - 1) * S + 3, npx = ((th - 1) * S + 3) * iw;
+  const int tiles_x = (a.Wo + tw - 1) / tw;
+  const int n = blockIdx.y;
+  const int ty = (int)blockIdx.x / tiles_x;
+  const int oy0 = ty * th, ox0 = ((int)blockIdx.x - ty * tiles_x) * tw;
+  const int iy0 = oy0 * S - a.pt, ix0 = ox0 * S - a.pl;
+  const int nchunk = a.Chid >> 4;
+  const int ch0 = blockIdx.z * a.cpg, ch1 = min(nchunk, ch0 + a.cpg);
+  float wes[WER], wds[WDR];
+  auto fetch_w = [&](int ch) {
+    const float* wb = a.we + (size_t)ch * WE_N + tid;
+#pragma unroll
+    for (int i = 0; i < WER; ++i) wes[i] = wb[256 * i];
+    const float* wc = a.wp + (size_t)ch * WD_N + tid;
+#pragma unroll
+    for (int i = 0; i < WDR; ++i) wds[i] = wc[256 * i];
+  };
+  auto store_we = [&](int buf) {
+    float* wl = WE + buf * WE_N + tid;
+#pragma unroll
+    for (int i = 0; i < WER; ++i) wl[256 * i] = wes[i];
+  };
+  auto store_wd = [&](int buf) {
+    float* wm = WD + buf * WD_N + tid;
+#pragma unroll
+    for (int i = 0; i < WDR; ++i) wm[256 * i] = wds[i];
+  };
+  if (ch0 < ch1) fetch_w(ch0);
+
+  // ---- the wave's MPW patch m-tiles: pixel mt*16 + lp, channels (lq + 4 j) * 4 .. + 3, summed over the producer's partial slabs ----
+  f32x4 xr[MPW][NJ];
+  float one[MPW];
+  {
+    const float* ip = a.in + (size_t)n * a.H * a.W * Cin;
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
+      const int p = (wave + 4 * m) * 16 + lp;
+      const int iy = p / iw, ix = p - iy * iw;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      const bool ok = p < npx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      one[m] = ok ? 1.f : 0.f;
+      const float* src = ip + (ok ? (gy * a.W + gx) * Cin : 0) + lq * 4;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok && (lq + 4 * j) * 4 < Cin) {
+          v = *reinterpret_cast<const f32x4*>(src + j * 16);
+          for (int sl = 1; sl < a.in_slabs; ++sl) v += *reinterpret_cast<const f32x4*>(src + (size_t)sl * a.in_slab_stride + j * 16);
+        }
+        xr[m][j] = v;
+      }
+    }
+  }
+  // ---- the wave's two output m-tiles (flat index q = (2 wave + m2) * 16 + lp over the th x tw tile) -> patch pixel of tap (0,0) ----
+  int ebase[2];
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2) {
+    const int q = (wave * 2 + m2) * 16 + lp;
+    const int oy = q / tw, ox = q - oy * tw;
+    ebase[m2] = q < th * tw ? (oy * S) * iw + ox * S : 0;
+  }
+  if (ch0 < ch1) { store_we(0); store_wd(0); }
+  __syncthreads();
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float lo_e = nvf_lo(a.act_e), hi_e = nvf_hi(a.act_e), lo_d = nvf_lo(a.act_d), hi_d = nvf_hi(a.act_d);
+
+  for (int ch = ch0; ch < ch1; ++ch) {
+    const int wb_i = (ch - ch0) & 1;
+    if (ch + 1 < ch1) fetch_w(ch + 1);
+    float* Eb = E + (NBUF == 2 ? wb_i : 0) * 16 * EP;
+    const float* wl = WE + wb_i * WE_N + lane;
+    if (NBUF == 1 && ch > ch0) __syncthreads();            // everybody is done reading the previous chunk
+#pragma unroll
+    for (int g = 0; g < MPW / GI; ++g) {
+      f32x4 c[GI];
+#pragma unroll
+      for (int i = 0; i < GI; ++i) c[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float wv = wl[(j * 4 + e) * 64];
+#pragma unroll
+          for (int i = 0; i < GI; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[g * GI + i][j][e], wv, c[i], 0, 0, 0);
+        }
+      {
+        const float wv = wl[(KSE1 - 1) * 64];          // bias step against the in-image mask
+#pragma unroll
+        for (int i = 0; i < GI; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(one[g * GI + i], wv, c[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < GI; ++i) {
+        const int mt = wave + 4 * (g * GI + i);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = nvf_clamp(c[i][r], lo_e, hi_e);
+        float* e = Eb + lp * EP + mt * 16 + lq * 4;
+        if (EP % 4 == 0) *reinterpret_cast<f32x4*>(e) = o;
+        else { e[0] = o[0]; e[1] = o[1]; e[2] = o[2]; e[3] = o[3]; }
+      }
+    }
+    if (ch + 1 < ch1) store_we(wb_i ^ 1);
+    __syncthreads();
+    const float* wd = WD + wb_i * WD_N;
+    const float* wpl = wd + 256 + lane;
+    // depthwise: the two output m-tiles as the halves of v_pk_fma_f32; three row pointers per m-tile, kx and the channel as immediates
+    const float* e0 = Eb + lq * EP + ebase[0];
+    const float* e1 = Eb + lq * EP + ebase[1];
+    const float* r0[3] = {e0, e0 + iw, e0 + 2 * iw};
+    const float* r1[3] = {e1, e1 + iw, e1 + 2 * iw};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float bd = wd[144 + ks * 4 + lq];
+      f32x2 d = {bd, bd};
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float w = wd[(ky * 3 + kx) * 16 + ks * 4 + lq];
+          d = __builtin_elementwise_fma(f32x2{r0[ky][ks * 4 * EP + kx], r1[ky][ks * 4 * EP + kx]}, f32x2{w, w}, d);
+        }
+      d[0] = nvf_clamp(d[0], lo_d, hi_d); d[1] = nvf_clamp(d[1], lo_d, hi_d);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float wv = wpl[(ks * NT + t) * 64];
+        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[0], wv, acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[1], wv, acc[1][t], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < ch1) store_wd(wb_i ^ 1);
+  }
+
+  // ---- epilogue: C row = pixel q = (2 wave + m2) * 16 + 4 lq + r of the flat tile, col = channel lp of n-tile t ----------------------
+  const bool lead = blockIdx.z == 0;
+  const int Cout = a.Cout;
+  float* op = a.out + (size_t)blockIdx.z * a.out_slab_stride + (size_t)n * a.Ho * a.Wo * Cout;
+  const float* rp = (a.res && lead) ? a.res + (size_t)n * a.Ho * a.Wo * Cout : nullptr;
+  const float lo_p = nvf_lo(a.act_p), hi_p = nvf_hi(a.act_p);
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = (wave * 2 + m2) * 16 + lq * 4 + r;
+      const int oy = q / tw, ox = q - oy * tw;
+      const int gy = oy0 + oy, gx = ox0 + ox;
+      if (q >= th * tw || gy >= a.Ho || gx >= a.Wo) continue;
+      const int base = (gy * a.Wo + gx) * Cout + lp;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (t * 16 + lp >= Cout) continue;
+        const int o = base + t * 16;
+        float v = acc[m2][t][r] + (lead ? a.bp[t * 16 + lp] : 0.f);
+        if (rp) { for (int sl = 0; sl < a.res_slabs; ++sl) v += rp[(size_t)sl * a.res_slab_stride + o]; }
+        op[o] = nvf_clamp(v, lo_p, hi_p);
+      }
+    }
+  }
+}
+
+// tile shape for a th x tw <= 128 pixel output tile whose patch fits the kernel's m-tiles: maximise the useful fraction of the MFMA rows
+void nv_xblock_tile(int Ho, int Wo, int stride, int* th_out, int* tw_out) {
+  const int lim = nvb_mt_in(stride, 0) * 16;
+  double best = -1; int bth = 8, btw = 16;
+  for (int th = 1; th <= 32; ++th)
+    for (int tw = 4; tw <= 64; ++tw) {
+      if (th * tw > 128) continue;
+      if (((th - 1) * stride + 3) * ((tw - 1) * stride + 3) > lim) continue;
+      const long tiles = (long)((Ho + th - 1) / th) * ((Wo + tw - 1) / tw);
+      const double eff = (double)Ho * Wo / (double)(tiles * 128);     // a workgroup always pays for 8 output m-tiles
+      const double halo = (double)(th * tw) / (double)(((th - 1) * stride + 3) * ((tw - 1) * stride + 3));
+      const double score = eff * (0.75 + 0.25 * halo);
+      if (score > best + 1e-9) { best = score; bth = th; btw = tw; }
+    }
+  *th_out = bth; *tw_out = btw;
+}
+int nv_xblock_nj(int cin) { const int nj = (cin + 15) / 16; return nj <= 2 ? nj : nj <= 4 ? 4 : nj <= 7 ? 7 : -1; }
+bool nv_xblock_supported(int cin, int chid, int cout, int stride) {
+  return (stride == 1 || stride == 2) && !(cin & 3) && !(chid & 15) && cin >= 4 && nv_xblock_nj(cin) > 0 && nv_block_ntiles(cout) > 0 &&
+         (stride == 1 || nv_xblock_nj(cin) <= 2);      // stride 2 keeps 9 m-tiles of input per lane: Cin <= 32
+}
+// expand record for nv_xblock_kernel: k-step (j, e) holds input channel (lq + 4 j) * 4 + e for lane group lq (zero beyond cin); bias step last
+size_t pack_nv_expand_perm_floats(int chid, int cin) { const int nj = nv_xblock_nj(cin); return (size_t)(chid / 16) * (((nj * 4 + 1) * 64 + 255) / 256 * 256); }
+void pack_nv_expand_perm(const float* w /*[chid][cin]*/, const float* b, int chid, int cin, float* dst) {
+  const int nj = nv_xblock_nj(cin), rec = ((nj * 4 + 1) * 64 + 255) / 256 * 256;
+  for (int ch = 0; ch < chid / 16; ++ch) {
+    float* d = dst + (size_t)ch * rec;
+    for (int i = 0; i < rec; ++i) d[i] = 0.f;
+    for (int j = 0; j < nj; ++j)
+      for (int e = 0; e < 4; ++e)
+        for (int l = 0; l < 64; ++l) {
+          const int k = ((l >> 4) + 4 * j) * 4 + e;
+          d[(j * 4 + e) * 64 + l] = k < cin ? w[(size_t)(ch * 16 + (l & 15)) * cin + k] : 0.f;
+        }
+    for (int c = 0; c < 16; ++c) d[nj * 4 * 64 + c] = b[ch * 16 + c];
+  }
+}
+template <int S, int NT, int NJ>
+static hipError_t launch_xblock_t(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
+  constexpr int EP = nvb_ep(S, 0), NBUF = S == 1 ? 2 : 1, WE_N = ((NJ * 4 + 1) * 64 + 255) / 256 * 256;
+  const size_t lds = sizeof(float) * ((size_t)NBUF * 16 * EP + 2 * WE_N + 2 * nvb_wd_rec(NT));
+  auto k = nv_xblock_kernel<S, NT, NJ>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const long tiles = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th);
+  hipLaunchKernelGGL(k, dim3((unsigned)tiles, n, groups), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+template <int S, int NJ>
+static hipError_t launch_xblock_nt(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
+  switch (nv_block_ntiles(a.Cout)) {
+    case 1: return launch_xblock_t<S, 1, NJ>(a, n, groups, s);
+    case 2: return launch_xblock_t<S, 2, NJ>(a, n, groups, s);
+    case 4: return launch_xblock_t<S, 4, NJ>(a, n, groups, s);
+    case 8: return launch_xblock_t<S, 8, NJ>(a, n, groups, s);
+  }
+  return hipErrorInvalidValue;
+}
+hipError_t launch_nv_xblock(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
+  if ((long)a.H * a.W * a.Cin >= (1l << 31) || (long)a.Ho * a.Wo * a.Cout >= (1l << 31)) return hipErrorInvalidValue;
+  const int nj = nv_xblock_nj(a.Cin);
+  if (a.stride == 1) {
+    if (nj == 1) return launch_xblock_nt<1, 1>(a, n, groups, s);
+    if (nj == 2) return launch_xblock_nt<1, 2>(a, n, groups, s);
+    if (nj == 4) return launch_xblock_nt<1, 4>(a, n, groups, s);
+    if (nj == 7) return launch_xblock_nt<1, 7>(a, n, groups, s);
+  } else {
+    if (nj == 1) return launch_xblock_nt<2, 1>(a, n, groups, s);
+    if (nj == 2) return launch_xblock_nt<2, 2>(a, n, groups, s);
+  }
+  return hipErrorInvalidValue;
+}
+
 // ---- the trunk's last 1x1 + the NetVLAD pre-projection, register-resident input ------------------------------------------------------
 // Same arithmetic as MODE 2 above, organised for the shape it really has (Cin = 112 -> 1280 hidden -> 128): a wave owns 32 pixels for
 // BOTH GEMMs, so the input (2 m-tiles x Cin values per lane group = NJ float4 per m-tile and lane) stays in registers for the whole

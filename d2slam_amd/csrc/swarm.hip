@@ -1,0 +1,164 @@
+// swarm.hip -- the cross-agent exchange block and the NetVLAD gate.
+//
+// Reference analogue: every agent broadcasts its keyframe's {landmark positions, scores, descriptors, NetVLAD descriptor} over LCM
+// (d2frontend/src/loop_net.cpp:24-87); a receiver tracks a remote frame only if the NetVLAD similarity with one of its own keyframes
+// reaches track_remote_netvlad_thres (D2FeatureTracker::getMatchedPrevKeyframe, d2frontend/src/d2featuretracker.cpp:185-203) and then
+// runs matchKNN on the descriptors (trackRemoteFrames, :237-310).  Here the broadcast is ONE all-gather of fixed-capacity blocks:
+//
+//   block (float words) = desc[cap][256] | kps[cap][2] | scores[cap] | netvlad[G] | n (int32) | zero padding to a multiple of 256
+//
+// descriptors first, block size a multiple of 256 words: a gathered block's descriptors are directly addressable by the batched
+// matcher, whose offsets count rows of `dim` floats (d2fe_match_batch).
+#include "kernels.h"
+
+namespace d2fe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// one workgroup per frame; `row0 + f * row_step` is the frame's row in the dense extract outputs ([rows][cap][...]),
+// f its row in the NetVLAD output [F][G] (null: the block's NetVLAD part is zero-filled)
+__global__ __launch_bounds__(256) void pack_blocks_kernel(const float* __restrict__ desc, const float* __restrict__ kps,
+                                                          const float* __restrict__ scores, const int32_t* __restrict__ n_kp,
+                                                          const float* __restrict__ gdesc, int row0, int row_step, int cap, int G,
+                                                          int blk_words, float* __restrict__ blocks) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int row = row0 + f * row_step;
+  float* b = blocks + (size_t)f * blk_words;
+  const int n = min(n_kp[row], cap);
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  // descriptors: n valid rows, the rest zero (so that a block is a pure function of the frame, whatever the buffers held before)
+  const f32x4* dsrc = reinterpret_cast<const f32x4*>(desc + (size_t)row * cap * 256);
+  f32x4* ddst = reinterpret_cast<f32x4*>(b);
+  for (int i = tid; i < cap * 64; i += 256) ddst[i] = (i >> 6) < n ? dsrc[i] : z;
+  float* bk = b + (size_t)cap * 256;
+  for (int i = tid; i < cap * 2; i += 256) bk[i] = (i >> 1) < n ? kps[(size_t)row * cap * 2 + i] : 0.f;
+  float* bs = bk + cap * 2;
+  for (int i = tid; i < cap; i += 256) bs[i] = i < n ? scores[(size_t)row * cap + i] : 0.f;
+  float* bg = bs + cap;
+  for (int i = tid; i < G; i += 256) bg[i] = gdesc ? gdesc[(size_t)f * G + i] : 0.f;
+  const int used = cap * 259 + G;
+  if (tid == 0) reinterpret_cast<int32_t*>(b)[used] = n;
+  for (int i = used + 1 + tid; i < blk_words; i += 256) b[i] = 0.f;
+}
+
+// NetVLAD gate of a pair list: pair p passes iff dot(q[pair_q[p]], db[pair_db[p]]) >= thres (the reference rejects `< thres`,
+// d2featuretracker.cpp:189-190; the dot product is accumulated in fp32 like Eigen's VectorXf::dot, the comparison is in double).
+// pass[p] = 1/0; *n_pass += number passing; if cnt_inout != null a rejected pair's count is set to 0 (the batched matcher then
+// returns no matches for it).  One wave per pair.
+__global__ __launch_bounds__(256) void gate_pairs_kernel(const float* __restrict__ q, long q_stride, const float* __restrict__ db,
+                                                         long db_stride, int dim, const int32_t* __restrict__ pair_q,
+                                                         const int32_t* __restrict__ pair_db, int npairs, double thres,
+                                                         int32_t* __restrict__ cnt_inout, int32_t* __restrict__ pass,
+                                                         float* __restrict__ sims, int32_t* __restrict__ n_pass) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= npairs) return;
+  const float* a = q + (size_t)pair_q[p] * q_stride;
+  const float* b = db + (size_t)pair_db[p] * db_stride;
+  float s = 0.f;
+  for (int j = lane * 4; j < dim; j += 256) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(a + j), y = *reinterpret_cast<const f32x4*>(b + j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s = __builtin_fmaf(x[e], y[e], s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) {
+    const bool ok = !((double)s < thres);
+    if (pass) pass[p] = ok ? 1 : 0;
+    if (sims) sims[p] = s;
+    if (!ok && cnt_inout) cnt_inout[p] = 0;
+    if (ok && n_pass) atomicAdd(n_pass, 1);
+  }
+}
+
+hipError_t launch_pack_blocks(const float* desc, const float* kps, const float* scores, const int32_t* n_kp, const float* gdesc,
+                              int row0, int row_step, int nframes, int cap, int G, int blk_words, float* blocks, hipStream_t s) {
+  hipLaunchKernelGGL(pack_blocks_kernel, dim3(nframes), dim3(256), 0, s, desc, kps, scores, n_kp, gdesc, row0, row_step, cap, G, blk_words, blocks);
+  return hipGetLastError();
+}
+hipError_t launch_gate_pairs(const float* q, long q_stride, const float* db, long db_stride, int dim, const int32_t* pair_q,
+                             const int32_t* pair_db, int npairs, double thres, int32_t* cnt_inout, int32_t* pass, float* sims,
+                             int32_t* n_pass, hipStream_t s) {
+  hipLaunchKernelGGL(gate_pairs_kernel, dim3((npairs + 3) / 4), dim3(256), 0, s, q, q_stride, db, db_stride, dim, pair_q, pair_db, npairs,
+                     thres, cnt_inout, pass, sims, n_pass);
+  return hipGetLastError();
+}
+
+// ---- quadcam neighbour matching (A12): getFeatureHalfImg + the +-move_cols shift, and the index remap, on the device --------------------
+// Reference: getFeatureHalfImg (d2frontend/src/d2featuretracker.cpp:1051-1075) keeps the keypoints of one half of the undistorted view
+// (x < W_u - move_cols for the left set, x >= move_cols for the right set, move_cols = W_u * 90 / fov as a float) and copies their
+// descriptors; matchLocalFeatures (:1161-1170) shifts the a-side x by +-move_cols before the radius gate and (:1178-1181) maps the
+// match indices back.  One workgroup per job: ordered compaction (ballot + prefix over <= 1024 points), descriptor rows copied as
+// float4, `map[c] = original index`.
+__global__ __launch_bounds__(256) void half_compact_kernel(const float* __restrict__ desc, const float* __restrict__ pts,
+                                                           const int32_t* __restrict__ n_kp, const int32_t* __restrict__ job_row,
+                                                           const int32_t* __restrict__ job_left, const float* __restrict__ job_shift,
+                                                           int cap, int dim, float width_undistort, float move_cols,
+                                                           float* __restrict__ out_desc, float* __restrict__ out_pts,
+                                                           int32_t* __restrict__ out_map, int32_t* __restrict__ out_n) {
+  __shared__ int s_wcnt[4], s_base;
+  __shared__ int s_src[1024];
+  const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int row = job_row[j];
+  const bool left = job_left[j] != 0;
+  const float shift = job_shift[j];
+  const int n = min(n_kp[row], cap);
+  const float* p = pts + (size_t)row * cap * 2;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + tid;
+    bool keep = false;
+    if (i < n) { const float x = p[2 * i]; keep = left ? (x < width_undistort - move_cols) : (x >= move_cols); }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) s_wcnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wv; ++w) off += s_wcnt[w];
+    if (keep) {
+      const int c = off + __popcll(m & ((1ull << lane) - 1ull));
+      s_src[c] = i;
+      out_map[(size_t)j * cap + c] = i;
+      out_pts[((size_t)j * cap + c) * 2] = p[2 * i] + shift;
+      out_pts[((size_t)j * cap + c) * 2 + 1] = p[2 * i + 1];
+    }
+    __syncthreads();
+    if (tid == 0) s_base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    __syncthreads();
+  }
+  const int c_n = s_base;
+  if (tid == 0) out_n[j] = c_n;
+  const int d4 = dim >> 2;
+  const f32x4* src = reinterpret_cast<const f32x4*>(desc + (size_t)row * cap * dim);
+  f32x4* dst = reinterpret_cast<f32x4*>(out_desc + (size_t)j * cap * dim);
+  for (int i = tid; i < c_n * d4; i += 256) { const int c = i / d4, q = i - c * d4; dst[i] = src[(size_t)s_src[c] * d4 + q]; }
+}
+
+__global__ __launch_bounds__(256) void remap_matches_kernel(int32_t* __restrict__ q_idx, int32_t* __restrict__ t_idx,
+                                                            const int32_t* __restrict__ n_match, const int32_t* __restrict__ map_a_job,
+                                                            const int32_t* __restrict__ map_b_job, const int32_t* __restrict__ maps,
+                                                            int cap_match, int cap_map) {
+  const int p = blockIdx.x;
+  const int n = min(n_match[p], cap_match);
+  const int32_t* ma = maps + (size_t)map_a_job[p] * cap_map;
+  const int32_t* mb = maps + (size_t)map_b_job[p] * cap_map;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    q_idx[(size_t)p * cap_match + i] = ma[q_idx[(size_t)p * cap_match + i]];
+    t_idx[(size_t)p * cap_match + i] = mb[t_idx[(size_t)p * cap_match + i]];
+  }
+}
+
+hipError_t launch_half_compact(const float* desc, const float* pts, const int32_t* n_kp, const int32_t* job_row, const int32_t* job_left,
+                               const float* job_shift, int njobs, int cap, int dim, float width_undistort, float move_cols,
+                               float* out_desc, float* out_pts, int32_t* out_map, int32_t* out_n, hipStream_t s) {
+  hipLaunchKernelGGL(half_compact_kernel, dim3(njobs), dim3(256), 0, s, desc, pts, n_kp, job_row, job_left, job_shift, cap, dim, width_undistort,
+                     move_cols, out_desc, out_pts, out_map, out_n);
+  return hipGetLastError();
+}
+hipError_t launch_remap_matches(int32_t* q_idx, int32_t* t_idx, const int32_t* n_match, const int32_t* map_a_job, const int32_t* map_b_job,
+                                const int32_t* maps, int npairs, int cap_match, int cap_map, hipStream_t s) {
+  hipLaunchKernelGGL(remap_matches_kernel, dim3(npairs), dim3(256), 0, s, q_idx, t_idx, n_match, map_a_job, map_b_job, maps, cap_match, cap_map);
+  return hipGetLastError();
+}
+
+}  // namespace d2fe

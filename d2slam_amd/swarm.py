@@ -1,50 +1,78 @@
 """Cross-agent exchange for N>1 GPUs: the MI355X-native stand-in for the reference's LCM broadcast of keyframe
-descriptors (d2frontend/src/loop_net.cpp:24-87, SURVEY.md C1 / section 8e).
+descriptors (d2frontend/src/loop_net.cpp:24-87, SURVEY.md section 8e).
 
-Every agent (rank) owns F frames per step.  After extraction each rank contributes one fixed-capacity block per
-frame -- descriptors [cap,256] and a keypoint count -- and ONE all-gather (RCCL over xGMI with backend "nccl",
-gloo in the CPU tests) delivers every agent's blocks to every rank; each rank then matches its own frames against
-all remote ones (row-block decomposition of the all-to-all match matrix, no second exchange).
+Every agent (rank) owns F stereo frames per step.  After extraction each rank packs ONE fixed-capacity block per left frame
+(include/d2fe.h, d2fe_pack_blocks_device):
 
-Device-agnostic on purpose: works on whatever device the tensors live on.
+    desc[cap][256] | kps[cap][2] | scores[cap] | netvlad[G] | n (int32) | zero padding to a multiple of 256 words
+
+and ONE all-gather (RCCL over xGMI with backend "nccl"; gloo in the tests) delivers every agent's blocks to every rank.  The
+gathered buffer lives directly behind the rank's own descriptor rows in one pool of 256-float rows, so the batched matcher
+addresses remote descriptors in place; each rank matches its own left frames against every remote left frame (row-block
+decomposition of the all-to-all match matrix, no second exchange).  The reference only tracks a remote frame whose NetVLAD similarity
+reaches track_remote_netvlad_thres (d2featuretracker.cpp:185-203): d2fe_gate_pairs_device evaluates that gate for the pair list on
+the device and reports how many pairs pass.
+
+Device-agnostic on purpose: works on whatever device the tensors live on (the block layout helpers are pure Python).
 """
-from typing import List, Tuple
+from typing import List
 
 import torch
 import torch.distributed as dist
 
 
-def pool_rows(F: int, world: int) -> int:
-    """Rows of the descriptor pool: [0,2F) current L/R interleaved | [2F,3F) previous L | remote L of other ranks."""
-    return 3 * F + (world - 1) * F
+def block_words(cap: int, netvlad_dim: int) -> int:
+    """Mirror of d2fe_block_words (api.hip): float words of one block."""
+    return (cap * 259 + netvlad_dim + 1 + 255) // 256 * 256
 
 
-def build_pairs(F: int, world: int) -> Tuple[List[int], List[int]]:
-    """(a_row, b_row) pool rows of every matchKNN problem of one step on one rank:
-    L_f<->R_f and L_f<->prevL_f (the two calls of D2FeatureTracker::trackLocalFrames, d2featuretracker.cpp:403-456,
-    658-695), then L_f<->remoteL_f for each other agent (trackRemoteFrames, d2featuretracker.cpp:237-310)."""
-    NI = 2 * F
-    a_rows, b_rows = [], []
-    for f in range(F):
-        a_rows += [2 * f, 2 * f]
-        b_rows += [2 * f + 1, NI + f]
-    for o in range(world - 1):
+def block_field_offset(cap: int, netvlad_dim: int, field: str) -> int:
+    return {"desc": 0, "kps": cap * 256, "scores": cap * 258, "netvlad": cap * 259, "n": cap * 259 + netvlad_dim}[field]
+
+
+class PairList:
+    """The matchKNN problems of one step on one rank, as row offsets into the pool of 256-float rows
+       [0, F*cap)            left descriptors of the current step (frame f at row f*cap)
+       [F*cap, 2F*cap)       right descriptors
+       [2F*cap, 3F*cap)      left descriptors of the previous step
+       [3F*cap, ...)         gathered blocks, block (r, f) at row 3F*cap + (r*F + f) * blk_words/256
+    local pairs first: L_f<->R_f and L_f<->prevL_f (D2FeatureTracker::trackLocalFrames, d2featuretracker.cpp:403-456,658-695),
+    then L_f <-> the left frame with the same time index f of every OTHER rank (trackRemoteFrames, d2featuretracker.cpp:237-310: an
+    agent tracks the frame a remote agent has just broadcast against its own current keyframe).  The F frames of a step are F
+    consecutive time steps of one agent, batched for throughput."""
+
+    def __init__(self, F: int, cap: int, world: int, rank: int, blk_words: int):
+        self.a_off: List[int] = []; self.b_off: List[int] = []
+        self.a_cnt_row: List[int] = []; self.b_cnt_row: List[int] = []     # rows of the local count array [3F] (local pairs)
+        self.remote_block: List[int] = []; self.remote_q_frame: List[int] = []
         for f in range(F):
-            a_rows.append(2 * f)
-            b_rows.append(NI + F + o * F + f)
-    return a_rows, b_rows
+            self.a_off += [f * cap, f * cap]
+            self.b_off += [(F + f) * cap, (2 * F + f) * cap]
+            self.a_cnt_row += [f, f]
+            self.b_cnt_row += [F + f, 2 * F + f]
+        self.n_local = len(self.a_off)
+        if world > 1:
+            assert blk_words % 256 == 0
+            rows_per_block = blk_words // 256
+            for r in range(world):
+                if r == rank:
+                    continue
+                for f in range(F):
+                    self.a_off.append(f * cap)
+                    self.b_off.append(3 * F * cap + (r * F + f) * rows_per_block)
+                    self.a_cnt_row.append(f)
+                    self.remote_block.append(r * F + f)
+                    self.remote_q_frame.append(f)
+        self.npairs = len(self.a_off)
+        self.n_remote = self.npairs - self.n_local
 
 
-def exchange_blocks(desc_pool: torch.Tensor, cnt_pool: torch.Tensor, F: int, rank: int, world: int,
-                    gath_desc: torch.Tensor, gath_cnt: torch.Tensor, group=None) -> None:
-    """All-gather the left-image blocks of this rank's F frames and scatter the OTHER ranks' blocks into the pool
-    rows [3F, 3F+(world-1)F) in ascending rank order (own rank skipped)."""
-    if world == 1:
-        return
-    NI = 2 * F
-    left = torch.arange(0, NI, 2, device=desc_pool.device)
-    dist.all_gather_into_tensor(gath_desc.view(-1), desc_pool[left].contiguous().view(-1), group=group)
-    dist.all_gather_into_tensor(gath_cnt.view(-1), cnt_pool[left].contiguous(), group=group)
-    others = [r for r in range(world) if r != rank]
-    desc_pool[NI + F:] = gath_desc[others].reshape(-1, desc_pool.shape[1], desc_pool.shape[2])
-    cnt_pool[NI + F:] = gath_cnt[others].reshape(-1)
+def all_gather_blocks(gath: torch.Tensor, blocks: torch.Tensor, group=None) -> None:
+    """ONE collective per step: gath [world][F][BLK] <- every rank's blocks [F][BLK].  gloo (tests, 1-GPU debugging) cannot gather
+    device tensors: stage through the host there."""
+    if dist.get_backend(group) == "gloo" and blocks.is_cuda:
+        g = torch.empty(gath.shape, dtype=gath.dtype)
+        dist.all_gather_into_tensor(g.view(-1), blocks.detach().cpu().contiguous().view(-1), group=group)
+        gath.copy_(g)
+    else:
+        dist.all_gather_into_tensor(gath.view(-1), blocks.view(-1), group=group)

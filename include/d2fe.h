@@ -308,6 +308,47 @@ D2FE_API int d2fe_detect_fast_by_region(d2fe_handle h, d2fe_lk_frame f, int feat
 D2FE_API int d2fe_good_features_to_track(d2fe_handle h, d2fe_lk_frame f, int max_corners, double quality, double min_dist,
                                          float* pts_xy, int cap, int* n_out);
 
+/* ---- cross-agent exchange --------------------------------------------------------------------------------
+ * Replaces the LCM broadcast of a keyframe's image descriptor (d2frontend/src/loop_net.cpp:24-87: landmark positions, scores,
+ * SuperPoint descriptors, NetVLAD descriptor) by one fixed-capacity block per frame, so that the exchange is ONE all-gather:
+ *   block (float words) = desc[cap][256] | kps[cap][2] | scores[cap] | netvlad[G] | n (int32) | zero padding to a multiple of 256.
+ * Descriptors come first and the size is a multiple of 256 words: a gathered block's descriptors are addressable by
+ * d2fe_match_batch_device (offsets in rows of `dim` floats) without unpacking. */
+D2FE_API int d2fe_block_words(int cap, int netvlad_dim);                 /* words of one block */
+D2FE_API int d2fe_block_field_offset(int cap, int netvlad_dim, int field);   /* word offset of field 0 desc, 1 kps, 2 scores, 3 netvlad, 4 n */
+/* Packs nframes frames of a d2fe_superpoint_extract_device result (dense [rows][cap][...] arrays; frame f is row row0 + f*row_step)
+ * and of a d2fe_netvlad_device result (d_netvlad [nframes][G], may be NULL) into d_blocks [nframes][d2fe_block_words]. */
+D2FE_API int d2fe_pack_blocks_device(d2fe_handle h, const float* d_desc, const float* d_kps_xy, const float* d_scores,
+                                     const int32_t* d_n, const float* d_netvlad, int row0, int row_step, int nframes, int cap,
+                                     int netvlad_dim, float* d_blocks, void* stream);
+/* NetVLAD gate of a pair list.  Replaces the similarity test of D2FeatureTracker::getMatchedPrevKeyframe
+ * (d2frontend/src/d2featuretracker.cpp:185-203: `vlad_desc.dot(vlad_desc_remote) < track_remote_netvlad_thres` rejects) and of
+ * LoopDetector::queryIndexFromDatabase (loop_detector.cpp:339).  Pair p compares row d_pair_q[p] of d_q (rows q_stride words apart)
+ * with row d_pair_db[p] of d_db.  Outputs (each may be NULL): d_pass[p] = 1/0, d_sims[p], *d_n_pass += passing pairs (the caller
+ * zeroes it), and d_cnt_inout[p] = 0 for a rejected pair -- with the matcher's a_cnt array there, d2fe_match_batch_device returns
+ * no matches for pairs the reference would not have tracked. */
+D2FE_API int d2fe_gate_pairs_device(d2fe_handle h, const float* d_q, size_t q_stride, const float* d_db, size_t db_stride, int dim,
+                                    const int32_t* d_pair_q, const int32_t* d_pair_db, int npairs, double thres,
+                                    int32_t* d_cnt_inout, int32_t* d_pass, float* d_sims, int32_t* d_n_pass, void* stream);
+
+/* ---- quadcam neighbour matching on the device (A12) -------------------------------------------------------------------------------
+ * d2fe_half_image_compact_device = getFeatureHalfImg (d2frontend/src/d2featuretracker.cpp:1051-1075) for a batch of jobs, plus the
+ * a-side shift of matchLocalFeatures (:1161-1170).  Job j reads row d_job_row[j] of the dense extract outputs (d_desc [rows][cap][dim],
+ * d_pts_xy [rows][cap][2], d_n [rows]), keeps x < W_u - move_cols (d_job_left[j] != 0) or x >= move_cols (move_cols = (float)(W_u * 90.0 /
+ * undistort_fov), as the reference computes it), and writes, in order: d_out_desc [njobs][cap][dim], d_out_pts [njobs][cap][2] with
+ * d_job_shift_x[j] added to x (pass +move_cols / -move_cols / 0), d_out_map [njobs][cap] (compacted index -> original index), d_out_n [njobs].
+ * d2fe_half_move_cols returns that float.  cap <= 1024.
+ * d2fe_remap_matches_device = the index remap of :1178-1181 for a batch of pairs: q_idx[p][i] = map[d_map_a_job[p]][q_idx[p][i]], same for
+ * t_idx with d_map_b_job (d_maps [njobs][cap_map], match arrays [npairs][cap_match]). */
+D2FE_API float d2fe_half_move_cols(int width_undistort, double undistort_fov);
+D2FE_API int d2fe_half_image_compact_device(d2fe_handle h, const float* d_desc, const float* d_pts_xy, const int32_t* d_n,
+                                            const int32_t* d_job_row, const int32_t* d_job_left, const float* d_job_shift_x, int njobs,
+                                            int cap, int dim, int width_undistort, double undistort_fov, float* d_out_desc,
+                                            float* d_out_pts, int32_t* d_out_map, int32_t* d_out_n, void* stream);
+D2FE_API int d2fe_remap_matches_device(d2fe_handle h, int32_t* d_q_idx, int32_t* d_t_idx, const int32_t* d_n_match,
+                                       const int32_t* d_map_a_job, const int32_t* d_map_b_job, const int32_t* d_maps, int npairs,
+                                       int cap_match, int cap_map, void* stream);
+
 /* Debug/inspection: copy an internal device tensor of the last extract call to the host.
  * names: "conv1a".."conv4b","convPaDa","logits","desc_raw","semi".  Returns bytes copied or <0. */
 D2FE_API long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_bytes);

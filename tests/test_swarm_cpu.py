@@ -1,4 +1,5 @@
-"""world_size-2 gloo test of the N>1 exchange path used by bench.py (d2slam_amd/swarm.py)."""
+"""world_size-2 gloo test of the N>1 exchange path used by bench.py (d2slam_amd/swarm.py): block layout, the single all-gather,
+and the pair list's addressing of remote descriptors inside the gathered buffer."""
 import os
 import socket
 import sys
@@ -15,48 +16,85 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, F, cap, q):
+def _pack_host(desc, kps, scores, n, gdesc, cap, G):
+    """Host restatement of d2fe_pack_blocks_device (csrc/swarm.hip) for the CPU test."""
+    from d2slam_amd import swarm
+    BLK = swarm.block_words(cap, G)
+    b = np.zeros(BLK, np.float32)
+    o = lambda f: swarm.block_field_offset(cap, G, f)
+    b[o("desc"):o("desc") + n * 256] = desc[:n].reshape(-1)
+    b[o("kps"):o("kps") + n * 2] = kps[:n].reshape(-1)
+    b[o("scores"):o("scores") + n] = scores[:n]
+    b[o("netvlad"):o("netvlad") + G] = gdesc
+    b.view(np.int32)[o("n")] = n
+    return b
+
+
+def _worker(rank, world, port, F, cap, G, q):
     sys.path.insert(0, ROOT)
     from d2slam_amd import swarm
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    NP = swarm.pool_rows(F, world)
-    desc = torch.zeros(NP, cap, 256); cnt = torch.zeros(NP, dtype=torch.int32)
-    # current frames of this rank: row r filled with value 1000*rank + r
-    for r in range(2 * F):
-        desc[r] = 1000 * rank + r; cnt[r] = 10 * rank + r + 1
-    gd = torch.zeros(world, F, cap, 256); gc = torch.zeros(world, F, dtype=torch.int32)
-    swarm.exchange_blocks(desc, cnt, F, rank, world, gd, gc)
-    q.put((rank, desc[:, 0, 0].numpy().copy(), cnt.numpy().copy()))
+    BLK = swarm.block_words(cap, G)
+    rng = np.random.RandomState(100 + rank)
+    blocks = np.zeros((F, BLK), np.float32)
+    for f in range(F):
+        n = 1 + (rank * 3 + f) % cap
+        blocks[f] = _pack_host(rng.randn(cap, 256).astype(np.float32) + 1000 * rank + f, rng.rand(cap, 2).astype(np.float32),
+                               rng.rand(cap).astype(np.float32), n, np.full(G, 10 * rank + f, np.float32), cap, G)
+    # the pool: local descriptor rows, then the gathered blocks (as bench.py lays it out)
+    pool = torch.zeros(3 * F * cap * 256 + world * F * BLK)
+    gath = pool[3 * F * cap * 256:].view(world, F, BLK)
+    swarm.all_gather_blocks(gath, torch.from_numpy(blocks))
+    pl = swarm.PairList(F, cap, world, rank, BLK)
+    rows = pool.view(-1, 256)
+    rem = [(int(pl.b_off[pl.n_local + i]), int(pl.remote_block[i])) for i in range(pl.n_remote)]
+    first_rows = [float(rows[off][0]) for off, _ in rem]
+    n_field = [int(gath.view(torch.int32).view(world * F, BLK)[blk, swarm.block_field_offset(cap, G, "n")]) for _, blk in rem]
+    g_field = [float(gath.view(world * F, BLK)[blk, swarm.block_field_offset(cap, G, "netvlad")]) for _, blk in rem]
+    q.put((rank, blocks[:, :4].copy(), first_rows, n_field, g_field, pl.n_local, pl.n_remote))
     dist.destroy_process_group()
 
 
 def test_exchange_blocks_world2():
-    F, cap, world = 3, 4, 2
+    F, cap, G, world = 3, 4, 8, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, F, cap, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, F, cap, G, q)) for r in range(world)]
     [p.start() for p in ps]
     res = {}
     for _ in range(world):
-        r, d, c = q.get(timeout=120)
-        res[r] = (d, c)
+        r = q.get(timeout=120)
+        res[r[0]] = r[1:]
     [p.join(60) for p in ps]
     for rank in range(world):
         other = 1 - rank
-        d, c = res[rank]
-        # remote region holds the OTHER rank's left frames (rows 0,2,4 of that rank)
-        assert d[3 * F:].tolist() == [1000 * other + 2 * f for f in range(F)]
-        assert c[3 * F:].tolist() == [10 * other + 2 * f + 1 for f in range(F)]
-        # own rows untouched
-        assert d[:2 * F].tolist() == [1000 * rank + r for r in range(2 * F)]
+        blocks_other = res[other][0]
+        _, first_rows, n_field, g_field, n_local, n_remote = res[rank]
+        assert n_local == 2 * F and n_remote == (world - 1) * F
+        # remote pair f addresses the first descriptor row of the OTHER rank's block f, in place inside the gathered buffer
+        assert first_rows == [float(blocks_other[f, 0]) for f in range(F)]
+        assert n_field == [1 + (other * 3 + f) % cap for f in range(F)]
+        assert g_field == [float(10 * other + f) for f in range(F)]
 
 
-def test_build_pairs_layout():
+def test_pair_list_layout():
     from d2slam_amd import swarm
-    a, b = swarm.build_pairs(2, 1)
-    assert (a, b) == ([0, 0, 2, 2], [1, 4, 3, 5])
-    a, b = swarm.build_pairs(2, 3)
-    assert len(a) == 2 * 2 + 2 * 2 and swarm.pool_rows(2, 3) == 10
-    assert a[4:] == [0, 2, 0, 2] and b[4:] == [6, 7, 8, 9]
+    pl = swarm.PairList(2, 10, 1, 0, 0)
+    assert (pl.a_off, pl.b_off) == ([0, 0, 10, 10], [20, 40, 30, 50]) and pl.n_remote == 0
+    assert pl.a_cnt_row == [0, 0, 1, 1] and pl.b_cnt_row == [2, 4, 3, 5]
+    BLK = swarm.block_words(10, 16)
+    assert BLK % 256 == 0 and BLK >= 10 * 259 + 16 + 1
+    pl = swarm.PairList(2, 10, 3, 1, BLK)
+    assert pl.n_local == 4 and pl.n_remote == 4 and pl.remote_block == [0, 1, 4, 5] and pl.remote_q_frame == [0, 1, 0, 1]
+    assert pl.b_off[4:] == [60 + b * (BLK // 256) for b in (0, 1, 4, 5)]
+
+
+def test_block_layout_matches_the_abi():
+    """swarm.block_words / block_field_offset (pure Python, used by the CPU tests) == the C ABI's (d2fe_block_words / _field_offset)."""
+    from d2slam_amd import api, swarm
+    for cap, G in [(200, 4096), (100, 1024), (4, 8), (150, 0)]:
+        assert api.block_words(cap, G) == swarm.block_words(cap, G)
+        for f in ("desc", "kps", "scores", "netvlad", "n"):
+            assert api.block_field_offset(cap, G, f) == swarm.block_field_offset(cap, G, f)

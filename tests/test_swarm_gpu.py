@@ -1,0 +1,92 @@
+"""The N>1 path on ONE GPU (-m gpu): two processes share GPU 0 and talk over gloo, so the cross-agent exchange, the NetVLAD gate and
+the gated cross-agent matching are checked against the oracle without an 8-GPU node (tests/helpers/swarm_worker.py), the block /
+gate / half-image kernels are checked against numpy, and bench.py's own --gpus 2 path is run end to end."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _torchrun(script_args, env_extra, timeout=900):
+    env = dict(os.environ); env.update(env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _rank_errors(r):
+    """the ranks' own tracebacks (torchrun's summary that follows them is noise)"""
+    lines = [l for l in (r.stdout + "\n" + r.stderr).splitlines() if l.startswith("[rank") or "Error" in l or "assert" in l]
+    return "\n".join(lines[:60])
+
+
+def test_world2_cross_agent_matches_equal_oracle():
+    r = _torchrun([os.path.join(ROOT, "tests", "helpers", "swarm_worker.py")], {})
+    assert r.returncode == 0, _rank_errors(r)
+    assert r.stdout.count(" OK: ") == 2, r.stdout[-2000:]
+
+
+def test_bench_gpus2_path_runs_under_gloo():
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "2", "--single-mode", "--no-cpu-baseline"],
+                  {"D2FE_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, _rank_errors(r)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["match_pairs_per_step_per_gpu"] == 2 * 2 + 2
+    assert j["netvlad_gate"]["pairs"] == 2 and 0 <= j["netvlad_gate"]["passing_netvlad_gate"] <= 2
+    assert j["avg_matches_per_pair"] > 1
+
+
+def test_pack_blocks_and_gate_kernels():
+    import torch
+    from d2slam_amd import api
+    dev = torch.device("cuda", 0)
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=50, input_width=64, input_height=64, max_batch=1))
+    cap, G, rows = 50, 64, 6
+    rng = np.random.RandomState(0)
+    desc = rng.randn(rows, cap, 256).astype(np.float32); kps = rng.rand(rows, cap, 2).astype(np.float32) * 100
+    sc = rng.rand(rows, cap).astype(np.float32); n = np.array([50, 0, 7, 33, 60, 1], np.int32)       # 60 > cap: clamped
+    g = rng.randn(3, G).astype(np.float32)
+    BLK = api.block_words(cap, G)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_desc, d_kps, d_sc, d_n, d_g = t(desc), t(kps), t(sc), t(n), t(g)
+    blocks = torch.full((3, BLK), 7.0, device=dev)
+    fe.pack_blocks_device(d_desc.data_ptr(), d_kps.data_ptr(), d_sc.data_ptr(), d_n.data_ptr(), d_g.data_ptr(), 1, 2, 3, cap, G, blocks.data_ptr())
+    fe.sync(); torch.cuda.synchronize()
+    b = blocks.cpu().numpy()
+    off = {f: api.block_field_offset(cap, G, f) for f in ("desc", "kps", "scores", "netvlad", "n")}
+    for f in range(3):
+        row = 1 + 2 * f; k = min(int(n[row]), cap)
+        exp = np.zeros(BLK, np.float32)
+        exp[:k * 256] = desc[row, :k].reshape(-1); exp[off["kps"]:off["kps"] + 2 * k] = kps[row, :k].reshape(-1)
+        exp[off["scores"]:off["scores"] + k] = sc[row, :k]; exp[off["netvlad"]:off["netvlad"] + G] = g[f]
+        exp.view(np.int32)[off["n"]] = k
+        assert np.array_equal(b[f].view(np.int32), exp.view(np.int32)), f
+    # gate: pairs (q row, db row) with strided rows
+    q = rng.randn(4, G).astype(np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    db = np.zeros((5, 2 * G), np.float32); db[:, :G] = q[[0, 1, 2, 3, 0]] + 0.3 * rng.randn(5, G).astype(np.float32)
+    db[:, :G] /= np.linalg.norm(db[:, :G], axis=1, keepdims=True)
+    pq = np.array([0, 1, 2, 3, 1, 2], np.int32); pd = np.array([0, 1, 2, 3, 4, 0], np.int32)
+    sims = np.array([np.dot(q[a], db[c, :G]) for a, c in zip(pq, pd)])
+    thres = 0.5
+    cnt = torch.full((6,), 9, dtype=torch.int32, device=dev); pas = torch.zeros(6, dtype=torch.int32, device=dev)
+    gs = torch.zeros(6, device=dev); gn = torch.zeros(1, dtype=torch.int32, device=dev)
+    fe.gate_pairs_device(t(q).data_ptr(), G, t(db).data_ptr(), 2 * G, G, t(pq).data_ptr(), t(pd).data_ptr(), 6, thres, d_cnt_inout=cnt.data_ptr(),
+                         d_pass=pas.data_ptr(), d_sims=gs.data_ptr(), d_n_pass=gn.data_ptr())
+    fe.sync(); torch.cuda.synchronize()
+    assert np.abs(gs.cpu().numpy() - sims).max() <= 1e-5
+    exp_pass = (sims >= thres).astype(np.int32)
+    assert np.array_equal(pas.cpu().numpy(), exp_pass) and int(gn.item()) == exp_pass.sum()
+    assert np.array_equal(cnt.cpu().numpy(), np.where(exp_pass == 1, 9, 0))
+    fe.close()

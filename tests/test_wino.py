@@ -95,7 +95,7 @@ def test_wino_layer_bitwise(api, orc, n, H, W, cin, cout, pool):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("H,W,n", [(96, 128, 2), (480, 640, 4), (120, 168, 1)])
+@pytest.mark.parametrize("H,W,n", [(96, 128, 2), (480, 640, 4), (120, 168, 1), (400, 800, 2), (512, 512, 2)])   # incl. every BASELINE geometry
 def test_wino_extract_vs_oracles(api, orc, H, W, n):
     w = synthetic_superpoint_weights(dustbin_bias=7.5)
     imgs = np.stack([synth_stereo(H, W, seed=11 + i)[i & 1] for i in range(n)])
