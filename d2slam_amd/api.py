@@ -376,6 +376,11 @@ class FrontEnd:
                         hd["assign_b"].ctypes.data, hd["centroids"].ctypes.data)
         _check(self._lib.d2fe_load_netvlad(self._h, C.byref(ws)))
 
+    def load_netvlad_onnx(self, path):
+        """MobileNetVLADONNX's constructor takes an ONNX file (mobilenetvlad_onnx.h:18-47): graph -> layer list -> d2fe_load_netvlad."""
+        from . import onnx_graph
+        self.load_netvlad(onnx_graph.load_netvlad_onnx(path))
+
     def set_netvlad_pca(self, comp, mean):
         if comp is None:
             _check(self._lib.d2fe_set_netvlad_pca(self._h, None, None, 0))

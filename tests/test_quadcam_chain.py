@@ -26,8 +26,9 @@ def test_half_compact_and_remap_kernels(orc):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     od = torch.zeros((len(jobs), cap, 256), device=dev); op = torch.zeros((len(jobs), cap, 2), device=dev)
     om = torch.full((len(jobs), cap), -1, dtype=torch.int32, device=dev); on = torch.zeros(len(jobs), dtype=torch.int32, device=dev)
-    fe.half_image_compact_device(t(desc).data_ptr(), t(pts).data_ptr(), t(n).data_ptr(), t(np.array([j[0] for j in jobs], np.int32)).data_ptr(),
-                                 t(np.array([j[1] for j in jobs], np.int32)).data_ptr(), t(np.array([j[2] for j in jobs], np.float32)).data_ptr(),
+    d_desc, d_pts, d_n = t(desc), t(pts), t(n)               # keep the device tensors alive across the launch
+    d_jr, d_jl, d_js = t(np.array([j[0] for j in jobs], np.int32)), t(np.array([j[1] for j in jobs], np.int32)), t(np.array([j[2] for j in jobs], np.float32))
+    fe.half_image_compact_device(d_desc.data_ptr(), d_pts.data_ptr(), d_n.data_ptr(), d_jr.data_ptr(), d_jl.data_ptr(), d_js.data_ptr(),
                                  len(jobs), cap, 256, W_u, fov, od.data_ptr(), op.data_ptr(), om.data_ptr(), on.data_ptr())
     fe.sync(); torch.cuda.synchronize()
     for j, (row, left, shift) in enumerate(jobs):

@@ -82,7 +82,8 @@ def test_pack_blocks_and_gate_kernels():
     thres = 0.5
     cnt = torch.full((6,), 9, dtype=torch.int32, device=dev); pas = torch.zeros(6, dtype=torch.int32, device=dev)
     gs = torch.zeros(6, device=dev); gn = torch.zeros(1, dtype=torch.int32, device=dev)
-    fe.gate_pairs_device(t(q).data_ptr(), G, t(db).data_ptr(), 2 * G, G, t(pq).data_ptr(), t(pd).data_ptr(), 6, thres, d_cnt_inout=cnt.data_ptr(),
+    d_q, d_db, d_pq, d_pd = t(q), t(db), t(pq), t(pd)        # keep the device tensors alive across the launch
+    fe.gate_pairs_device(d_q.data_ptr(), G, d_db.data_ptr(), 2 * G, G, d_pq.data_ptr(), d_pd.data_ptr(), 6, thres, d_cnt_inout=cnt.data_ptr(),
                          d_pass=pas.data_ptr(), d_sims=gs.data_ptr(), d_n_pass=gn.data_ptr())
     fe.sync(); torch.cuda.synchronize()
     assert np.abs(gs.cpu().numpy() - sims).max() <= 1e-5
