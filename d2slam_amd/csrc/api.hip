@@ -352,7 +352,10 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   if (cfg->max_width < 16 || cfg->max_height < 16 || (cfg->max_width & 7) || (cfg->max_height & 7))
     return fail(D2FE_ERR_INVALID, "max_width/max_height must be multiples of 8");
   if (cfg->max_batch < 1) return fail(D2FE_ERR_INVALID, "max_batch < 1");
-  if (cfg->max_keypoints < 1 || cfg->max_keypoints > 1024) return fail(D2FE_ERR_INVALID, "max_keypoints must be in 1..1024");
+  // -1 = keep every keypoint above the threshold (SuperPoint::topKeypoints only truncates when k != -1, superpoint_tensorrt.cpp:241-253;
+  // NMS2's `i < max_num` is an unsigned compare, superpoint_common.cpp:173): the calls then return up to min(cap, 1024) keypoints, in raster
+  // order for variant B, and D2FE_ERR_TRUNCATED from the host-pointer entry points if an image had more
+  if ((cfg->max_keypoints < 1 && cfg->max_keypoints != -1) || cfg->max_keypoints > 1024) return fail(D2FE_ERR_INVALID, "max_keypoints must be -1 (keep all) or in 1..1024");
   if (cfg->precision != D2FE_PREC_F32 && cfg->precision != D2FE_PREC_F16X2 && cfg->precision != D2FE_PREC_F32_WINO) return fail(D2FE_ERR_INVALID, "bad precision");
   if (cfg->postproc != D2FE_POSTPROC_B && cfg->postproc != D2FE_POSTPROC_A) return fail(D2FE_ERR_INVALID, "bad postproc");
   int ndev = 0;
@@ -398,7 +401,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     { const char* e = getenv("D2FE_SPARSE_MIN_BATCH"); if (e) h->sp_min_batch = atoi(e); }
     if (h->sparse_desc) {
       const size_t ncell = (H / 8) * (W / 8);
-      h->sp_slots = 4 * cfg->max_keypoints;            // <= 4 corner cells per keypoint
+      h->sp_slots = 4 * (cfg->max_keypoints < 0 ? 1024 : cfg->max_keypoints);            // <= 4 corner cells per keypoint
       HIP_TRY(hipMalloc(&h->sp_flags, ncell * B));
       HIP_TRY(hipMalloc(&h->sp_slotmap, sizeof(int32_t) * ncell * B));
       HIP_TRY(hipMalloc(&h->sp_cells, sizeof(int32_t) * (size_t)h->sp_slots * B));
@@ -411,7 +414,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
       HIP_TRY(hipMalloc(&h->aconf, sizeof(float) * H * W * B));
       HIP_TRY(hipMalloc(&h->clist, sizeof(int) * H * W * B));
       HIP_TRY(hipMalloc(&h->a_ncand, sizeof(int) * B));
-      h->a_scap = h->cfg.max_keypoints < 1024 ? h->cfg.max_keypoints : 1024;   // select keeps at most min(max_keypoints, 1024)
+      h->a_scap = (h->cfg.max_keypoints > 0 && h->cfg.max_keypoints < 1024) ? h->cfg.max_keypoints : 1024;   // select keeps at most min(max_keypoints, 1024)
       HIP_TRY(hipMalloc(&h->a_samp, sizeof(float) * 256 * (size_t)h->a_scap * B));
       HIP_TRY(hipMalloc(&h->a_cn, sizeof(float) * 256 * B));
     }
@@ -588,6 +591,8 @@ int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int
   std::vector<int32_t> cnt(n);
   const size_t D = (h->cfg.postproc == D2FE_POSTPROC_A && h->pca_dims) ? (size_t)h->pca_dims : 256;
   HIP_TRY(hipMemcpyAsync(cnt.data(), h->s_n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+  std::vector<int32_t> ncand(h->cfg.max_keypoints < 0 ? n : 0);
+  if (!ncand.empty()) HIP_TRY(hipMemcpyAsync(ncand.data(), h->cand_count, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   for (int i = 0; i < n; ++i) {
     const int k = cnt[i];
@@ -599,6 +604,8 @@ int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int
     }
   }
   HIP_TRY(hipStreamSynchronize(s));
+  for (int32_t c : ncand)
+    if (c > dcap) return fail(D2FE_ERR_TRUNCATED, "max_keypoints = -1: an image has more keypoints than the call's capacity; the strongest were kept");
   return D2FE_OK;
 }
 

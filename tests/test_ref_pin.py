@@ -235,3 +235,24 @@ def test_hip_match_knn_vs_reference_cpp(api, na, nb, dim, ratio, radius, sigma):
     rq, rt, rd = spref.match_knn(a, b, ratio, pa, pb, radius)
     assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd)
     fe.close()
+
+
+@pytest.mark.gpu
+def test_hip_keep_all_vs_reference_cpp(api, orc, sp_weights):
+    """max_keypoints = -1 (SuperPoint::topKeypoints keeps everything when k == -1, superpoint_tensorrt.cpp:241-253): all keypoints above
+    the threshold, in raster order, like the reference; more than the call's capacity -> D2FE_ERR_TRUNCATED with the strongest kept."""
+    H, W = 120, 160
+    img = synth_image(H, W, 14)
+    f = orc.superpoint_forward(img, sp_weights)
+    thr = float(np.sort(f["semi"].reshape(-1))[-700])                        # ~700 candidates
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=-1, input_width=W, input_height=H, max_batch=1, keypoint_threshold=thr,
+                                           keep_score_map=True, dense_descriptors=True))
+    fe.load_superpoint(sp_weights)
+    (kps, sc, desc), = fe.extract_batch(img[None], cap=1024)
+    rk, rs, rd = spref.superpoint_post(f["semi"], f["desc"], thr, 1, -1)
+    assert 600 < len(rk) < 1024 and np.array_equal(kps, rk) and np.array_equal(sc, rs)
+    assert np.abs(desc - rd).max() <= 1e-6
+    with pytest.raises(api.D2FEError) as e:
+        fe.extract_batch(img[None], cap=256)
+    assert e.value.code == -4                                                 # D2FE_ERR_TRUNCATED
+    fe.close()
