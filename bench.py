@@ -51,7 +51,11 @@ def main():
                     help="d435 = the metric's configuration; quadcam = configs[2]: 4 x (1280x800 raw -> 800x400) per frame, undistort + "
                          "SuperPoint + NetVLAD + neighbour (half-image, shifted, radius-gated) and temporal matchKNN")
     ap.add_argument("--single-mode", action="store_true", help="time only the headline leg (no configs1 / other modes / quadcam legs)")
-    ap.add_argument("--async-tail", action="store_true", help="d2fe_config.async_tail (post-processing of step k under the convolutions of step k+1)")
+    ap.add_argument("--async-tail", action="store_true", help="d2fe_config.async_tail without NetVLAD in between (post-processing of step k under the convolutions of step k+1)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="d2fe_config.async_tail with NetVLAD queued on the main stream right behind the SuperPoint convolutions, beside SuperPoint's "
+                         "latency-bound tail on the handle's tail stream.  Measured slower than plain stream order (2214 vs 2258 stereo fps: the two "
+                         "sequences stretch each other, NetVLAD 0.94 -> 1.28 ms), hence off by default")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event breakdown to stderr")
     args = ap.parse_args()
 
@@ -97,8 +101,9 @@ def main():
         F = args.frames
         NI = 2 * F
         prec = {"f32": api.PREC_F32, "f16x2": api.PREC_F16X2, "wino": api.PREC_F32_WINO}[precision]
+        overlap = netvlad and args.overlap
         cfg = api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=NI, precision=prec,
-                                   device_id=local_rank, async_tail=args.async_tail)
+                                   device_id=local_rank, async_tail=bool(args.async_tail or overlap))
         fe = api.FrontEnd(cfg)
         fe.load_superpoint(weights)
         G = 0
@@ -151,6 +156,7 @@ def main():
         assert stream != 0
         tail = torch.cuda.ExternalStream(fe.tail_stream(), device=dev) if fe.tail_stream() else main
         tstream = tail.cuda_stream
+        ev_nv = torch.cuda.Event()
         ev_copy = [torch.cuda.Event() for _ in range(2)]
         ev_free = [torch.cuda.Event() for _ in range(2)]
         use_h2d = not args.no_h2d
@@ -169,16 +175,23 @@ def main():
                 main.wait_event(ev_copy[b])
                 upload(b ^ 1)                      # next step's frames travel while this step computes
             im = imgs[b]
-            if netvlad:
+            if netvlad and not overlap:
                 fe.netvlad_device(im.data_ptr(), F, W, H, gdesc.data_ptr(), stream=stream)
             fe.extract_device(im.data_ptr(), NI, W, H, kps.data_ptr(), scores.data_ptr(), desc.data_ptr(), kidx.data_ptr(),
                               CAP, cnt.data_ptr(), stream=stream)
+            if netvlad and overlap:
+                # behind the convolutions on `main`, beside SuperPoint's tail on the tail stream
+                fe.netvlad_device(im.data_ptr(), F, W, H, gdesc.data_ptr(), stream=stream)
+                if world > 1:
+                    ev_nv.record(main)
             if use_h2d:
                 ev_free[b].record(main)            # the convolutions were the last readers of the frames (async tail: the trunk is on `main`)
             with torch.cuda.stream(tail):
                 torch.index_select(cnt, 0, a_src, out=a_cnt)
                 b_cnt[:pl.n_local] = cnt[b_src_local]
                 if world > 1:
+                    if netvlad and overlap:
+                        tail.wait_event(ev_nv)        # the blocks carry this step's NetVLAD descriptors
                     # cross-agent exchange: one block per left frame, ONE all-gather (RCCL over xGMI), the NetVLAD gate on the device
                     fe.pack_blocks_device(desc.data_ptr(), kps.data_ptr(), scores.data_ptr(), cnt.data_ptr(), gdesc.data_ptr() if netvlad else 0,
                                           0, 1, F, CAP, G, blocks.data_ptr(), stream=tstream)
@@ -304,7 +317,8 @@ def main():
                                    + "matchKNN L<->R and L<->prevL"
                                    + ("; + one RCCL all-gather of exchange blocks, device NetVLAD gate, cross-agent matchKNN vs every remote frame" if world > 1 else ""),
                        "frames_per_step_per_gpu": F, "images_per_step_per_gpu": NI, "match_pairs_per_step_per_gpu": NP,
-                       "h2d_in_timed_region": not args.no_h2d, "async_tail": bool(args.async_tail), "max_keypoints": CAP, "postproc": "B",
+                       "h2d_in_timed_region": not args.no_h2d, "async_tail": bool(args.async_tail or (use_nv and args.overlap)),
+                       "netvlad_overlaps_superpoint_tail": bool(use_nv and args.overlap), "max_keypoints": CAP, "postproc": "B",
                        "precision": args.precision, "netvlad": use_nv,
                        "weights": "seeded random-init SuperPoint / MobileNetVLAD stand-in (no checkpoints in the reference tree)"},
             "sp_tflops_algorithmic": round(SP_FLOP_PER_IMG * 2 * value / 1e12, 2),

@@ -96,7 +96,7 @@ struct d2fe_context {
   std::vector<NvStep> nv_plan;
   bool nv_loaded = false;
   int nv_feat = 0, nv_proj = 0, nv_k = 0;
-  float *nv_pre_w = nullptr, *nv_pre_b = nullptr, *nv_aw = nullptr, *nv_ab = nullptr, *nv_cen = nullptr;
+  float *nv_pre_w = nullptr, *nv_pre_b = nullptr, *nv_aw = nullptr, *nv_aw_pack = nullptr, *nv_ab = nullptr, *nv_cen = nullptr;
   float *nv_feat_buf = nullptr, *nv_raw = nullptr, *nv_pca_out = nullptr, *nv_part = nullptr;
   float *nv_pca_comp = nullptr, *nv_pca_mean = nullptr; int nv_pca_m = 0;
   uint8_t* nv_s_img = nullptr; float* nv_s_out = nullptr;
@@ -622,7 +622,7 @@ void nv_free(d2fe_context* h) {
   h->nv.clear();
   for (auto& st : h->nv_plan) { if (st.we) hipFree(st.we); if (st.wp) hipFree(st.wp); if (st.bp) hipFree(st.bp); if (st.w0) hipFree(st.w0); }
   h->nv_plan.clear();
-  for (float** p : {&h->nv_pre_w, &h->nv_pre_b, &h->nv_aw, &h->nv_ab, &h->nv_cen, &h->nv_feat_buf, &h->nv_raw, &h->nv_pca_out, &h->nv_part})
+  for (float** p : {&h->nv_pre_w, &h->nv_pre_b, &h->nv_aw, &h->nv_aw_pack, &h->nv_ab, &h->nv_cen, &h->nv_feat_buf, &h->nv_raw, &h->nv_pca_out, &h->nv_part})
     if (*p) { hipFree(*p); *p = nullptr; }
   h->nv_loaded = false;
 }
@@ -631,9 +631,10 @@ inline int same_pad_begin(int in, int stride, int out) { const int t = (out - 1)
 
 // hidden-channel groups for a fused step: enough workgroups to fill the chip (2 per CU), at least 4 chunks of 16 per group (every
 // group stages the whole input patch again, and its consumer reads one more partial slab)
-inline void nv_groups(long base_blocks, int nchunk, int gmax, int* groups, int* cpg) {
-  static int target = -1;
-  if (target < 0) { const char* e = getenv("D2FE_NV_BLOCKS"); target = e ? atoi(e) : 512; }
+inline void nv_groups(long base_blocks, int nchunk, int gmax, int* groups, int* cpg, int target_default = 512) {
+  static int target_env = -2;
+  if (target_env == -2) { const char* e = getenv("D2FE_NV_BLOCKS"); target_env = e ? atoi(e) : -1; }
+  const int target = target_env > 0 ? target_env : target_default;
   int g = (int)((target + base_blocks - 1) / base_blocks);
   if (g > gmax) g = gmax;
   if (g > nchunk / 4) g = nchunk / 4;
@@ -687,7 +688,9 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
       a.H = ch; a.W = cw; a.Ho = ch; a.Wo = cw; a.Cin = e.cin; a.Chid = e.cout; a.Cout = h->nv_proj; a.stride = 1;
       a.P = (long)n * ch * cw;
       a.wp = st.wp; a.bp = st.bp; a.act_p = 0;
-      nv_groups((a.P + 127) / 128, a.Chid / 16, h->nv_feat_gmax, &groups, &cpg);
+      // three workgroups per CU fit (registers), and the MFMA pipe is the limit: ~768 workgroups of equal length load every SIMD alike
+      { static int tt = -1; if (tt < 0) { const char* e = getenv("D2FE_NV_TAIL_BLOCKS"); tt = e ? atoi(e) : 768; }
+        nv_groups((a.P + 127) / 128, a.Chid / 16, h->nv_feat_gmax, &groups, &cpg, tt); }
       a.cpg = cpg; a.out = h->nv_feat_buf; a.out_slab_stride = a.P * a.Cout;
       h->nv_feat_slabs = groups; h->nv_feat_slab_stride = a.out_slab_stride;
       if (nv_tail_supported(a.Cin, a.Cout)) HIP_TRY(launch_nv_tail(a, groups, s));     // st.we was packed in that kernel's K order
@@ -722,7 +725,7 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     h->nv_feat_slabs = 1; h->nv_feat_slab_stride = 0;
   }
   float* raw = h->nv_pca_m ? h->nv_raw : d_out;
-  HIP_TRY(launch_nv_vlad(h->nv_feat_buf, h->nv_feat_slabs, h->nv_feat_slab_stride, np, h->nv_proj, h->nv_k, h->nv_aw, h->nv_ab, h->nv_cen,
+  HIP_TRY(launch_nv_vlad(h->nv_feat_buf, h->nv_feat_slabs, h->nv_feat_slab_stride, np, h->nv_proj, h->nv_k, h->nv_aw, h->nv_aw_pack, h->nv_ab, h->nv_cen,
                          h->nv_part, raw, n, s));
   if (h->nv_pca_m) HIP_TRY(launch_nv_pca(raw, h->nv_k * h->nv_proj, h->nv_pca_comp, h->nv_pca_mean, h->nv_pca_m, d_out, n, s));
   return D2FE_OK;
@@ -873,12 +876,17 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
   int rc = upload(pw.data(), pw.size() * sizeof(float), reinterpret_cast<void**>(&h->nv_pre_w));
   rc = rc ? rc : upload(pb.data(), pb.size() * sizeof(float), reinterpret_cast<void**>(&h->nv_pre_b));
   rc = rc ? rc : upload(w->assign_w, sizeof(float) * w->n_clusters * w->proj_dim, reinterpret_cast<void**>(&h->nv_aw));
+  if (w->n_clusters % 16 == 0 && w->proj_dim % 4 == 0) {
+    std::vector<float> ap((size_t)w->n_clusters * w->proj_dim);
+    pack_nv_assign(w->assign_w, w->n_clusters, w->proj_dim, ap.data());
+    rc = rc ? rc : upload(ap.data(), ap.size() * sizeof(float), reinterpret_cast<void**>(&h->nv_aw_pack));
+  }
   rc = rc ? rc : upload(w->assign_b, sizeof(float) * w->n_clusters, reinterpret_cast<void**>(&h->nv_ab));
   rc = rc ? rc : upload(w->centroids, sizeof(float) * w->n_clusters * w->proj_dim, reinterpret_cast<void**>(&h->nv_cen));
   if (rc) return rc;
   HIP_TRY(hipMalloc(&h->nv_feat_buf, sizeof(float) * (size_t)h->nv_feat_gmax * B * ch * cw * w->proj_dim));
   HIP_TRY(hipMalloc(&h->nv_raw, sizeof(float) * (size_t)B * w->n_clusters * w->proj_dim));
-  HIP_TRY(hipMalloc(&h->nv_part, sizeof(float) * (size_t)B * ((ch * cw + 63) / 64) * w->n_clusters * w->proj_dim));
+  HIP_TRY(hipMalloc(&h->nv_part, sizeof(float) * (size_t)B * nv_vlad_part_floats(ch * cw, w->proj_dim, w->n_clusters)));
   if (!h->nv_s_img) HIP_TRY(hipMalloc(&h->nv_s_img, (size_t)h->cfg.max_width * h->cfg.max_height * B));
   if (!h->nv_s_out) HIP_TRY(hipMalloc(&h->nv_s_out, sizeof(float) * 8192 * B));
   h->nv_loaded = true;

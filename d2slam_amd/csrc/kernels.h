@@ -91,8 +91,10 @@ hipError_t launch_nv_dw(const float* in, int H, int W, int C, int Ho, int Wo, in
                         float* out, int n, hipStream_t s);
 hipError_t launch_nv_pw(const float* in, long P, int Cin, int Cout, int CoutPad, int act, const float* w, const float* b,
                         const float* res, float* out, hipStream_t s);
-hipError_t launch_nv_vlad(const float* x, int slabs, long slab_stride, int np, int D, int K, const float* aw, const float* ab,
-                          const float* cen, float* part, float* out, int n, hipStream_t s);
+hipError_t launch_nv_vlad(const float* x, int slabs, long slab_stride, int np, int D, int K, const float* aw, const float* aw_pack,
+                          const float* ab, const float* cen, float* part, float* out, int n, hipStream_t s);
+void pack_nv_assign(const float* aw /*[K][D]*/, int K, int D, float* dst);
+size_t nv_vlad_part_floats(int np, int D, int K);
 hipError_t launch_nv_pca(const float* x, int nfeat, const float* comp, const float* mean, int m, float* y, int n, hipStream_t s);
 
 // fused MobileNetV2 blocks (netvlad_fused.hip): [pw expand ->] dw 3x3 -> pw project (+ residual) in one launch, the expanded

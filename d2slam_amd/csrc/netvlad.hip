@@ -262,6 +262,125 @@ __global__ __launch_bounds__(1024) void nv_vlad_final_kernel(const float* __rest
   }
 }
 
+// ---- the same head on the matrix pipe (K = 32 clusters, D = 128: the shape the 4096-D descriptor implies) ------------------------------
+// One workgroup per (64-position chunk, image).  Both contractions are small GEMMs on v_mfma_f32_16x16x4_f32:
+//   logits  L[64 px][32] = X[64][128] Wa^T + ba                    M = px (one m-tile per wave), N = 32, K = 128
+//   sums    P[32][128 + 1] = A^T[32][64] [X | 1]                    M = clusters, N = 128 channels + a column of ones (-> S[k] = sum_p a[p][k])
+// so that V[k][d] = sum_p a[p][k] (c[k][d] - x[p][d]) = c[k][d] S[k] - P[k][d] is finished by the final kernel over the chunks.
+// X sits pixel-major in LDS with an odd pitch (145): the A fragments of the first GEMM (lanes = pixels) and the B fragments of the
+// second (lanes = channels) both read it conflict-free.  Partial record per chunk: [32][144] (128 channels, S, zero padding).
+constexpr int VM_DP = 145, VM_PP = 144;
+__global__ __launch_bounds__(256) void nv_vlad_mfma_kernel(const float* __restrict__ x, int slabs, long slab_stride, int np,
+                                                           const float* __restrict__ wa_pack, const float* __restrict__ ab,
+                                                           float* __restrict__ part, int nchunk) {
+  __shared__ float Xr[64 * VM_DP];
+  __shared__ float As[64 * 33];
+  const int img = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane >> 4, lp = lane & 15;
+  const int p0 = chunk * 64;
+  const int pn = (np - p0) < 64 ? (np - p0) : 64;
+  const float* xi = x + ((size_t)img * np + p0) * 128;
+  for (int i = tid; i < 64 * 32; i += 256) {
+    const int p = i >> 5, j4 = i & 31;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (p < pn) {
+      const float* s0 = xi + (size_t)p * 128 + j4 * 4;
+      v = *reinterpret_cast<const f32x4*>(s0);
+      for (int sl = 1; sl < slabs; ++sl) v += *reinterpret_cast<const f32x4*>(s0 + (size_t)sl * slab_stride);
+    }
+    float* d = Xr + p * VM_DP + j4 * 4;
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+  for (int i = tid; i < 64 * 17; i += 256) { const int p = i / 17, c = i - p * 17; Xr[p * VM_DP + 128 + c] = (c == 0 && p < pn) ? 1.f : 0.f; }
+  __syncthreads();
+  // ---- logits + softmax: wave w owns pixels 16 w .. 16 w + 15 ----
+  {
+    f32x4 c0, c1;
+    const float b0 = ab[lp], b1 = ab[16 + lp];
+    c0 = f32x4{b0, b0, b0, b0}; c1 = f32x4{b1, b1, b1, b1};
+    const float* xa = Xr + (wave * 16 + lp) * VM_DP + lq;
+    const float* wb = wa_pack + lane;
+#pragma unroll 4
+    for (int ks = 0; ks < 32; ++ks) {
+      const float a = xa[ks * 4];
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wb[(ks * 2) * 64], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wb[(ks * 2 + 1) * 64], c1, 0, 0, 0);
+    }
+    // row r of the C tiles = pixel 16 w + 4 lq + r; its 32 logits sit in lanes lp = 0..15 of this lq group (c0: clusters 0-15, c1: 16-31)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float m = fmaxf(c0[r], c1[r]);
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+      const float e0 = __expf(c0[r] - m), e1 = __expf(c1[r] - m);
+      float sum = e0 + e1;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 16);
+      const int p = wave * 16 + lq * 4 + r;
+      const bool ok = p < pn;
+      As[p * 33 + lp] = ok ? e0 / sum : 0.f;
+      As[p * 33 + 16 + lp] = ok ? e1 / sum : 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- P = A^T [X | 1]: 2 m-tiles (clusters) x 9 n-tiles (128 channels + the ones column), K = 64 pixels ----
+  float* po = part + ((size_t)img * nchunk + chunk) * 32 * VM_PP;
+  for (int t = wave; t < 18; t += 4) {
+    const int mt = t / 9, nt = t - mt * 9;
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    const float* aa = As + lq * 33 + mt * 16 + lp;
+    const float* bb = Xr + lq * VM_DP + nt * 16 + lp;
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) c = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[ks * 4 * 33], bb[ks * 4 * VM_DP], c, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) po[(mt * 16 + lq * 4 + r) * VM_PP + nt * 16 + lp] = c[r];
+  }
+}
+
+// V[k][d] = c[k][d] * sum_chunks S[k] - sum_chunks P[k][d], then intra-normalisation per cluster, flatten k-major, global L2
+__global__ __launch_bounds__(1024) void nv_vlad_final_mfma_kernel(const float* __restrict__ part, int nchunk, const float* __restrict__ cen,
+                                                                  float* __restrict__ out) {
+  __shared__ float red[34];
+  __shared__ float S[32];
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const float* pp = part + (size_t)img * nchunk * 32 * VM_PP;
+  if (tid < 32) {
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += pp[((size_t)c * 32 + tid) * VM_PP + 128];
+    S[tid] = s;
+  }
+  for (int i = tid; i < 34; i += 1024) red[i] = 0.f;
+  __syncthreads();
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = tid + 1024 * r, k = e >> 7, d = e & 127;
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += pp[((size_t)c * 32 + k) * VM_PP + d];
+    v[r] = cen[e] * S[k] - s;
+    float q = v[r] * v[r];           // the 128 channels of cluster k are 2 waves' worth of lanes: reduce per wave, then one atomic
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if ((tid & 63) == 0) atomicAdd(&red[k], q);
+  }
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = (tid + 1024 * r) >> 7;
+    const float n = __builtin_sqrtf(red[k]);
+    v[r] = v[r] / (n > 1e-12f ? n : 1e-12f);
+    tot += v[r] * v[r];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+  if ((tid & 63) == 0) atomicAdd(&red[32], tot);
+  __syncthreads();
+  const float nt = __builtin_sqrtf(red[32]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[(size_t)img * 4096 + tid + 1024 * r] = v[r] / (nt > 1e-12f ? nt : 1e-12f);
+}
+
 // ---- PCA: y = comp (x - mean); y /= |y|  (mobilenetvlad_onnx.h:66-71).  One wave per output row, then a normalise pass.
 __global__ __launch_bounds__(256) void nv_pca_kernel(const float* __restrict__ x, int n, const float* __restrict__ comp,
                                                      const float* __restrict__ mean, int m, float* __restrict__ y) {
@@ -322,10 +441,22 @@ hipError_t launch_nv_pw(const float* in, long P, int Cin, int Cout, int CoutPad,
   else hipLaunchKernelGGL(nv_pw_mfma_kernel<1>, dim3(gx, ntiles), dim3(256), 0, s, in, P, Cin, Cout, act, wp, b, res, out);
   return hipGetLastError();
 }
-hipError_t launch_nv_vlad(const float* x, int slabs, long slab_stride, int np, int D, int K, const float* aw, const float* ab,
-                          const float* cen, float* part, float* out, int n, hipStream_t s) {
+// aw_pack: the soft-assignment weights as B fragments [ks = D/4][nt = K/16][lane] = Wa[nt*16 + (lane & 15)][ks*4 + (lane >> 4)] (or null)
+void pack_nv_assign(const float* aw /*[K][D]*/, int K, int D, float* dst) {
+  for (int ks = 0; ks < D / 4; ++ks)
+    for (int nt = 0; nt < K / 16; ++nt)
+      for (int l = 0; l < 64; ++l) dst[((size_t)ks * (K / 16) + nt) * 64 + l] = aw[(size_t)(nt * 16 + (l & 15)) * D + ks * 4 + (l >> 4)];
+}
+size_t nv_vlad_part_floats(int np, int D, int K) { return (size_t)((np + VL_PCH - 1) / VL_PCH) * K * (D + 16); }
+hipError_t launch_nv_vlad(const float* x, int slabs, long slab_stride, int np, int D, int K, const float* aw, const float* aw_pack,
+                          const float* ab, const float* cen, float* part, float* out, int n, hipStream_t s) {
   if (K > 64 || D > 256 || K * D > 8192) return hipErrorInvalidValue;
   const int nchunk = (np + VL_PCH - 1) / VL_PCH;
+  if (K == 32 && D == 128 && aw_pack) {
+    hipLaunchKernelGGL(nv_vlad_mfma_kernel, dim3(nchunk, n), dim3(256), 0, s, x, slabs, slab_stride, np, aw_pack, ab, part, nchunk);
+    hipLaunchKernelGGL(nv_vlad_final_mfma_kernel, dim3(n), dim3(1024), 0, s, part, nchunk, cen, out);
+    return hipGetLastError();
+  }
   const size_t lds = sizeof(float) * ((size_t)VL_PCH * (D + 1) + (size_t)K * (D + 1) + (size_t)VL_PCH * (K + 1));
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nv_vlad_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

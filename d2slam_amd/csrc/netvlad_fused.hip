@@ -622,7 +622,7 @@ hipError_t launch_nv_xblock(const NvBlockArgs& a, int n, int groups, hipStream_t
 // channels of its pixel, so the K dimension is walked in the permuted order k = (lq + 4 j) * 4 + e (j = load, e = element); the host
 // packs the expand fragments in the same order (pack_nv_expand_tail).
 template <int NJ, int NT>
-__global__ __launch_bounds__(256) void nv_tail_kernel(NvBlockArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void nv_tail_kernel(NvBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CIN = NJ * 16, KSE1 = CIN / 4 + 1, WE_N = nvb_we_rec(CIN), WD_N = nvb_wd_rec(NT), EPW = 48;
   constexpr int WER = WE_N / 256, WDR = WD_N / 256;

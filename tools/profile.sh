@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + PMC passes of bench.py.  Usage: tools/profile.sh <tag> <precision>
-TAG=${1:-r01}; PREC=${2:-f32}
+TAG=${1:-r02}; PREC=${2:-wino}
 OUT=$PWD/gpurun_out/prof_${TAG}_${PREC}
 mkdir -p $OUT
 export TMPDIR=/tmp
