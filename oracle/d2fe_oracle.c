@@ -5,15 +5,22 @@
  * bench.py's cpu_baseline leg may load it.  The shipped path (the HIP sources in d2slam_amd/csrc behind
  * include/d2fe.h) never calls into this file and has no CPU fallback.
  *
- * PARITY STATUS: pinned in part.  The reference ships no golden vectors, no assertion-based tests and no model weights
- * for this path, and its C++ cannot be compiled here (needs OpenCV/Eigen/TensorRT/ROS; SURVEY.md
- * section 8c).  But the network and the variant-A sampling are also defined in PYTHON in the reference
- * (d2frontend/superpoint.ipynb, modules SuperPointNetHalf / SuperPointNet): tests/golden/make_golden_ref.py executes
- * those modules verbatim and commits their outputs, and tests/test_reference_golden.py holds orc_prep_u8 .. orc_softmax_semi
- * (with the 3x3 layers through orc_conv as well as through orc_conv3x3_wino, the restatement of the Winograd mode),
- * orc_l2norm_rows and orc_sample_a to them (and orc_sample_a's PCA convention to sklearn, the tool behind the CSVs).
- * Everything else in this file is **parity unpinned**: a line-by-line restatement of the cited C++ (or of the pinned
- * third-party version it calls), cross-checked in tests/ against independent implementations of the same ops only.
+ * PARITY STATUS: pinned in part, to the reference's OWN code in two ways.
+ *  (1) oracle/_ref/libspref.so (oracle/build_ref.py): the reference's own C++ line ranges -- SuperPoint::infer / processOutput and
+ *      everything they call (superpoint_tensorrt.cpp:161-183,200-350), getKeyPoints / NMS2 (superpoint_common.cpp:8-40,101-178),
+ *      matchKNN (feature_matcher.cpp), getFeatureHalfImg and the quadcam neighbour branch of matchLocalFeatures
+ *      (d2featuretracker.cpp:1051-1075,1146-1181) -- compiled from /root/reference against stand-in Eigen/OpenCV headers
+ *      (oracle/ref_shim/).  tests/test_ref_pin.py holds orc_select_b, orc_sample_b, orc_nms2_a, orc_match_knn, orc_half_img and the
+ *      neighbour chain to it, bit for bit, at the BASELINE geometries.  Third-party arithmetic under that code stays a restatement
+ *      (cv::BFMatcher's normL2Sqr_ order and K-best insertion, Eigen's norm() order, libstdc++'s order among equal scores).
+ *  (2) The network and the variant-A sampling are also defined in PYTHON in the reference (d2frontend/superpoint.ipynb, modules
+ *      SuperPointNetHalf / SuperPointNet): tests/golden/make_golden_ref.py and make_golden_headline.py execute those modules verbatim
+ *      and commit their outputs (incl. 640x480 / 800x400 / 512x512), and tests/test_reference_golden.py holds orc_prep_u8 ..
+ *      orc_softmax_semi (3x3 layers through orc_conv as well as orc_conv3x3_wino), orc_l2norm_rows and orc_sample_a to them (and
+ *      orc_sample_a's PCA convention to sklearn, the tool behind the CSVs).
+ * Still **parity unpinned** (restatements of third-party code that is not in the reference tree, cross-checked against independent
+ * implementations only): cv::BFMatcher(NORM_L2, true).match (A11), NetVLAD (graph not in the tree), undistort (cv::remap), the int8
+ * codec's consumers, the database, and everything in d2fe_oracle_lk.c (OpenCV-CUDA).
  *
  * Numerical definition.  Where the reference leaves floating-point evaluation order to a
  * third-party engine (TensorRT conv kernels, OpenCV SIMD reductions, Eigen reductions) the
