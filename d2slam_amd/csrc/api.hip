@@ -283,8 +283,8 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
       HIP_TRY(launch_nms2_wrap_fix(h->clist, h->a_ncand, H, W, n, d_kps, d_n, cap, s));
   } else {
     ProfScope ps(h, D2FE_PROF_SELECT, s);
-    HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, W, h->cfg.max_keypoints, cap, 0, d_kps, d_scores, d_idx,
-                            d_n, s));
+    HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, Wc * 8, h->cfg.max_keypoints, cap, 0, d_kps, d_scores, d_idx,
+                            d_n, s));      // raster indices and keypoints are in score-map coordinates: (W/8)*8 wide
   }
   if (!sparse) {
     ProfScope ps(h, D2FE_PROF_SAMPLE, s);
@@ -314,8 +314,14 @@ int check_geometry(d2fe_context* h, int n, int W, int H, int stride, int cap) {
   if (!h) return fail(D2FE_ERR_INVALID, "null handle");
   if (!h->sp_loaded) return fail(D2FE_ERR_NOT_READY, "superpoint weights not loaded");
   if (n < 1 || n > h->cfg.max_batch) return fail(D2FE_ERR_INVALID, "batch size out of range");
-  if (W < 16 || H < 16 || (W & 7) || (H & 7) || W > h->cfg.max_width || H > h->cfg.max_height || (long)W * H > (long)h->cfg.max_width * h->cfg.max_height)
-    return fail(D2FE_ERR_INVALID, "image size must be a multiple of 8 within the configured maximum");
+  if (W < 16 || H < 16 || W > h->cfg.max_width || H > h->cfg.max_height || (long)W * H > (long)h->cfg.max_width * h->cfg.max_height)
+    return fail(D2FE_ERR_INVALID, "image size must be at least 16x16 and within the configured maximum");
+  // Sizes that are not multiples of 8 (the reference's TensorRT profile admits 100x100 .. 1500x1500, superpoint_tensorrt.cpp:50-55): the
+  // three 2x2 max-pools floor, the score map is (H/8)*8 x (W/8)*8 and keypoints live in ITS coordinates, as processOutput reads
+  // semi_dims_ (:331-336).  Variant A sizes its cv::Mat views from the configured width/height (superpoint_onnx.cpp:86-94), which only
+  // describes the network output for multiples of 8.
+  if (((W | H) & 7) && h->cfg.postproc == D2FE_POSTPROC_A)
+    return fail(D2FE_ERR_INVALID, "post-processing variant A needs image sizes that are multiples of 8");
   if (stride < W) return fail(D2FE_ERR_INVALID, "stride < width");
   if (cap < 1) return fail(D2FE_ERR_INVALID, "cap < 1");
   return D2FE_OK;
@@ -349,8 +355,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   if (!cfg || !out) return fail(D2FE_ERR_INVALID, "null argument");
   *out = nullptr;
   if (cfg->struct_size != (int32_t)sizeof(d2fe_config)) return fail(D2FE_ERR_INVALID, "d2fe_config size mismatch");
-  if (cfg->max_width < 16 || cfg->max_height < 16 || (cfg->max_width & 7) || (cfg->max_height & 7))
-    return fail(D2FE_ERR_INVALID, "max_width/max_height must be multiples of 8");
+  if (cfg->max_width < 16 || cfg->max_height < 16) return fail(D2FE_ERR_INVALID, "max_width/max_height must be at least 16");
   if (cfg->max_batch < 1) return fail(D2FE_ERR_INVALID, "max_batch < 1");
   // -1 = keep every keypoint above the threshold (SuperPoint::topKeypoints only truncates when k != -1, superpoint_tensorrt.cpp:241-253;
   // NMS2's `i < max_num` is an unsigned compare, superpoint_common.cpp:173): the calls then return up to min(cap, 1024) keypoints, in raster
@@ -1410,10 +1415,11 @@ long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_byte
   hipSetDevice(h->cfg.device_id);
   const size_t H = h->last_h, W = h->last_w, n = h->last_n;
   struct { const char* nm; Tensor* t; size_t per; } tab[] = {
-      {"conv1a", &h->a1a, H * W * 64},           {"conv1b", &h->a1b, H * W * 16},        {"conv2a", &h->a2a, H * W * 16},
-      {"conv2b", &h->a2b, H * W * 4},            {"conv3a", &h->a3a, H * W * 8},         {"conv3b", &h->a3b, H * W * 2},
-      {"conv4a", &h->a4a, H * W * 2},            {"conv4b", h->last_set ? &h->a4b2 : &h->a4b, H * W * 2},         {"convPaDa", &h->aPD, H * W * 8},
-      {"logits", h->last_set ? &h->logits2 : &h->logits, (H / 8) * (W / 8) * 65}, {"desc_raw", h->last_set ? &h->draw2 : &h->draw, H * W * 4}, {"semi", &h->semi, H * W}};
+      // pooled sizes floor (sizes need not be multiples of 8)
+      {"conv1a", &h->a1a, H * W * 64},           {"conv1b", &h->a1b, (H / 2) * (W / 2) * 64},   {"conv2a", &h->a2a, (H / 2) * (W / 2) * 64},
+      {"conv2b", &h->a2b, (H / 4) * (W / 4) * 64},   {"conv3a", &h->a3a, (H / 4) * (W / 4) * 128},  {"conv3b", &h->a3b, (H / 8) * (W / 8) * 128},
+      {"conv4a", &h->a4a, (H / 8) * (W / 8) * 128},  {"conv4b", h->last_set ? &h->a4b2 : &h->a4b, (H / 8) * (W / 8) * 128},  {"convPaDa", &h->aPD, (H / 8) * (W / 8) * 512},
+      {"logits", h->last_set ? &h->logits2 : &h->logits, (H / 8) * (W / 8) * 65}, {"desc_raw", h->last_set ? &h->draw2 : &h->draw, (H / 8) * (W / 8) * 256}, {"semi", &h->semi, (H / 8) * (W / 8) * 64}};
   if (!strcmp(name, "conv1a") && h->fuse1a) {
     // fused mode never materialises conv1a: evaluate it on demand from the last input frame(s)
     if (!h->a1a.p && alloc_f(h->a1a, (size_t)h->cfg.max_height * h->cfg.max_width * 64, h->cfg.max_batch) != 0)

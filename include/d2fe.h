@@ -54,8 +54,8 @@ typedef enum {
 typedef struct {
   int32_t struct_size;        /* sizeof(d2fe_config), for forward compatibility */
   int32_t device_id;          /* HIP device ordinal */
-  int32_t max_width;          /* largest input width (multiple of 8)  -- SuperPointConfig::input_width  */
-  int32_t max_height;         /* largest input height (multiple of 8) -- SuperPointConfig::input_height */
+  int32_t max_width;          /* largest input width (>= 16)   -- SuperPointConfig::input_width  */
+  int32_t max_height;         /* largest input height (>= 16)  -- SuperPointConfig::input_height */
   int32_t max_batch;          /* images per batched call (>= 1) */
   int32_t max_keypoints;      /* SuperPointConfig::max_keypoints (1..1024)  [params->max_superpoint_cnt] */
   int32_t remove_borders;     /* SuperPointConfig::remove_borders (variant B), default 1 */

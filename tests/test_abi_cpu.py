@@ -59,8 +59,10 @@ def test_invalid_arguments_do_not_crash(lib):
     from d2slam_amd.api import _Config
     c = _Config()
     lib.d2fe_default_config(C.byref(c))
-    c.max_width = 641
-    assert lib.d2fe_create(C.byref(c), C.byref(h)) == -1 and b"multiples of 8" in lib.d2fe_last_error()
+    c.max_width = 8
+    assert lib.d2fe_create(C.byref(c), C.byref(h)) == -1 and b"at least 16" in lib.d2fe_last_error()
+    c.max_width = 640; c.max_keypoints = 0
+    assert lib.d2fe_create(C.byref(c), C.byref(h)) == -1 and b"max_keypoints" in lib.d2fe_last_error()
     n = C.c_int(5)
     assert lib.d2fe_match_knn(None, None, 3, None, 3, 256, C.c_double(0.8), None, None, C.c_double(-1.0), None, None, None,
                               3, C.byref(n)) == -1 and n.value == 0

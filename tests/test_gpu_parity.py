@@ -67,6 +67,36 @@ def test_exact_mode_bitwise_every_layer(api, orc, sp_weights, H, W):
     fe.close()
 
 
+@pytest.mark.parametrize("prec", ["f32", "wino", "f16x2"])
+@pytest.mark.parametrize("H,W", [(100, 100), (150, 134), (101, 99), (487, 645)])
+def test_sizes_that_are_not_multiples_of_8(api, orc, sp_weights, H, W, prec):
+    """The reference's engine profile admits any size in 100x100 .. 1500x1500 (superpoint_tensorrt.cpp:50-55).  The three max-pools floor,
+    the score map is (H/8)*8 x (W/8)*8 and processOutput works in ITS coordinates (semi_dims_, :331-336): same here, bit for bit in
+    the fp32 modes (incl. odd sizes at every pooling level)."""
+    n = 4
+    imgs = np.stack([synth_image(H, W, 20 + s) for s in range(n)])
+    P = {"f32": api.PREC_F32, "wino": api.PREC_F32_WINO, "f16x2": api.PREC_F16X2}[prec]
+    for dense in (True, False):
+        fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=150, input_width=W, input_height=H, max_batch=n, precision=P,
+                                               keep_score_map=True, dense_descriptors=dense))
+        fe.load_superpoint(sp_weights)
+        res = fe.extract_batch(imgs, cap=150)
+        Hs, Ws = (H // 8) * 8, (W // 8) * 8
+        semi = fe.debug_read("semi", (n, Hs, Ws))
+        for i in (0, n - 1):
+            f = orc.superpoint_forward(imgs[i], sp_weights, wino=(prec == "wino"))
+            assert f["semi"].shape == (Hs, Ws)
+            kps, sc, desc = res[i]
+            if prec == "f16x2":
+                assert np.abs(semi[i] - f["semi"]).max() <= 1e-5
+                continue
+            assert np.array_equal(semi[i], f["semi"])
+            rk, rs, ri = orc.select_b(f["semi"], 0.015, 1, 150)
+            assert np.array_equal(kps, rk) and np.array_equal(sc, rs)
+            assert np.abs(desc - orc.sample_b(f["desc"], rk)).max() <= (1e-6 if dense or prec == "f32" else 1e-5)
+        fe.close()
+
+
 def test_exact_mode_full_size_stereo(api, orc, sp_weights):
     """BASELINE config[1] size: 640x480 stereo pair, 200 keypoints: indices exact, descriptors <= 1e-6."""
     l, r = synth_stereo(480, 640, seed=1)
