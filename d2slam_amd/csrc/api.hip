@@ -700,6 +700,8 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
       h->nv_feat_slabs = groups; h->nv_feat_slab_stride = a.out_slab_stride;
       if (nv_tail_supported(a.Cin, a.Cout)) HIP_TRY(launch_nv_tail(a, groups, s));     // st.we was packed in that kernel's K order
       else HIP_TRY(launch_nv_block(a, true, 2, n, groups, s));
+      { static int thr = -1; if (thr < 0) { const char* e = getenv("D2FE_NV_SLABSUM"); thr = e ? atoi(e) : 3; }
+        if (groups >= thr && thr > 0) { HIP_TRY(launch_nv_slab_sum(h->nv_feat_buf, groups, a.out_slab_stride, a.out_slab_stride, s)); h->nv_feat_slabs = 1; } }
       feat_done = true;
       continue;
     }
@@ -721,6 +723,9 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     pj.slabs = groups; pj.slab_stride = a.out_slab_stride;
     if (st.xblock) HIP_TRY(launch_nv_xblock(a, n, groups, s));
     else HIP_TRY(launch_nv_block(a, st.expand, st.front ? 1 : 0, n, groups, s));
+    // three or more partial slabs: sum them once instead of in every consumer workgroup (and in every residual read)
+    { static int thr = -1; if (thr < 0) { const char* e = getenv("D2FE_NV_SLABSUM"); thr = e ? atoi(e) : 3; }
+      if (groups >= thr && thr > 0) { HIP_TRY(launch_nv_slab_sum(pj.out, groups, pj.slab_stride, pj.slab_stride, s)); pj.slabs = 1; } }
     ch = a.Ho; cw = a.Wo;
   }
   const int np = ch * cw;

@@ -131,6 +131,7 @@ void nv_xblock_tile(int Ho, int Wo, int stride, int* th, int* tw);
 size_t pack_nv_expand_perm_floats(int chid, int cin);
 void pack_nv_expand_perm(const float* w, const float* b, int chid, int cin, float* dst);
 hipError_t launch_nv_xblock(const NvBlockArgs& a, int n, int groups, hipStream_t s);
+hipError_t launch_nv_slab_sum(float* t, int slabs, long slab_stride, long count, hipStream_t s);   // slab 0 += slabs 1..
 void pack_nv_conv0(const float* w /*[cout][9]*/, const float* b, int cout, float* dst /*[384]*/);
 
 // ---- SURVEY 8(f) next rows (next.hip) ------------------------------------------------------------------------------------
