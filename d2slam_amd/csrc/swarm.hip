@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void pack_blocks_kernel(const float* __restric
   const int f = blockIdx.x, tid = threadIdx.x;
   const int row = row0 + f * row_step;
   float* b = blocks + (size_t)f * blk_words;
-  const int n = min(n_kp[row], cap);
+  const int n = max(0, min(n_kp[row], cap));
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   // descriptors: n valid rows, the rest zero (so that a block is a pure function of the frame, whatever the buffers held before)
   const f32x4* dsrc = reinterpret_cast<const f32x4*>(desc + (size_t)row * cap * 256);
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void half_compact_kernel(const float* __restri
   const int row = job_row[j];
   const bool left = job_left[j] != 0;
   const float shift = job_shift[j];
-  const int n = min(n_kp[row], cap);
+  const int n = max(0, min(n_kp[row], cap));
   const float* p = pts + (size_t)row * cap * 2;
   if (tid == 0) s_base = 0;
   __syncthreads();

@@ -168,6 +168,8 @@ D2FE_API int d2fe_set_netvlad_pca(d2fe_handle h, const float* comp, const float*
 D2FE_API int d2fe_netvlad_dim(d2fe_handle h);   /* length of the descriptor written by the calls below */
 /* std::vector<float> MobileNetVLADONNX::inference(const cv::Mat&): gray u8 at the network's size (the reference resizes with
  * cv::resize when needed; that stays the caller's job).  out: d2fe_netvlad_dim() floats. */
+/* Like the extract calls, the NetVLAD calls are not re-entrant per handle (they reuse the handle's layer buffers and record the slab
+ * layout of the call in it); the reference calls MobileNetVLADONNX::inference from its one front-end thread (d2frontend.cpp:155-169). */
 D2FE_API int d2fe_netvlad(d2fe_handle h, const uint8_t* gray, int width, int height, int stride, float* out);
 D2FE_API int d2fe_netvlad_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int height, int stride,
                                 size_t image_stride, float* out);
