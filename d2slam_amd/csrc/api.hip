@@ -92,7 +92,11 @@ struct d2fe_context {
   // execution plan over the flat layer list: fused MobileNetV2 blocks (netvlad_fused.hip) where the pattern matches, single layers otherwise;
   // only the LAST layer of a step is materialised in HBM (NvLayer::out), everything inside a fused block lives in LDS
   struct NvStep { int l0 = 0, l1 = 0; bool fused = false, expand = false, front = false, tail = false, xblock = false; float* we = nullptr; float* wp = nullptr; float* bp = nullptr; float* w0 = nullptr; };
-  int nv_feat_gmax = 1, nv_feat_slabs = 1; long nv_feat_slab_stride = 0;      // the pre-projected features (input of the VLAD stage), same slab scheme
+  int nv_feat_gmax = 1, nv_feat_slabs = 1; long nv_feat_slab_stride = 0;
+  // scheduling knobs of the fused plan, read from the environment by d2fe_load_netvlad (A/B measurements; defaults measured best):
+  // workgroups per launch the hidden-channel split aims at (D2FE_NV_BLOCKS), the same for the tail kernel (D2FE_NV_TAIL_BLOCKS),
+  // and the number of partial slabs from which they are summed once instead of by every consumer (D2FE_NV_SLABSUM, 0 = never)
+  int nv_blocks_target = 512, nv_tail_blocks = 768, nv_slabsum = 3;      // the pre-projected features (input of the VLAD stage), same slab scheme
   std::vector<NvStep> nv_plan;
   bool nv_loaded = false;
   int nv_feat = 0, nv_proj = 0, nv_k = 0;
@@ -636,10 +640,7 @@ inline int same_pad_begin(int in, int stride, int out) { const int t = (out - 1)
 
 // hidden-channel groups for a fused step: enough workgroups to fill the chip (2 per CU), at least 4 chunks of 16 per group (every
 // group stages the whole input patch again, and its consumer reads one more partial slab)
-inline void nv_groups(long base_blocks, int nchunk, int gmax, int* groups, int* cpg, int target_default = 512) {
-  static int target_env = -2;
-  if (target_env == -2) { const char* e = getenv("D2FE_NV_BLOCKS"); target_env = e ? atoi(e) : -1; }
-  const int target = target_env > 0 ? target_env : target_default;
+inline void nv_groups(long base_blocks, int nchunk, int gmax, int* groups, int* cpg, int target) {
   int g = (int)((target + base_blocks - 1) / base_blocks);
   if (g > gmax) g = gmax;
   if (g > nchunk / 4) g = nchunk / 4;
@@ -694,14 +695,12 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
       a.P = (long)n * ch * cw;
       a.wp = st.wp; a.bp = st.bp; a.act_p = 0;
       // three workgroups per CU fit (registers), and the MFMA pipe is the limit: ~768 workgroups of equal length load every SIMD alike
-      { static int tt = -1; if (tt < 0) { const char* e = getenv("D2FE_NV_TAIL_BLOCKS"); tt = e ? atoi(e) : 768; }
-        nv_groups((a.P + 127) / 128, a.Chid / 16, h->nv_feat_gmax, &groups, &cpg, tt); }
+      nv_groups((a.P + 127) / 128, a.Chid / 16, h->nv_feat_gmax, &groups, &cpg, h->nv_tail_blocks);
       a.cpg = cpg; a.out = h->nv_feat_buf; a.out_slab_stride = a.P * a.Cout;
       h->nv_feat_slabs = groups; h->nv_feat_slab_stride = a.out_slab_stride;
       if (nv_tail_supported(a.Cin, a.Cout)) HIP_TRY(launch_nv_tail(a, groups, s));     // st.we was packed in that kernel's K order
       else HIP_TRY(launch_nv_block(a, true, 2, n, groups, s));
-      { static int thr = -1; if (thr < 0) { const char* e = getenv("D2FE_NV_SLABSUM"); thr = e ? atoi(e) : 3; }
-        if (groups >= thr && thr > 0) { HIP_TRY(launch_nv_slab_sum(h->nv_feat_buf, groups, a.out_slab_stride, a.out_slab_stride, s)); h->nv_feat_slabs = 1; } }
+      if (h->nv_slabsum > 0 && groups >= h->nv_slabsum) { HIP_TRY(launch_nv_slab_sum(h->nv_feat_buf, groups, a.out_slab_stride, a.out_slab_stride, s)); h->nv_feat_slabs = 1; }
       feat_done = true;
       continue;
     }
@@ -718,14 +717,13 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     if (st.xblock) nv_xblock_tile(a.Ho, a.Wo, a.stride, &a.th, &a.tw);
     const long tiles = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th) * n;
     // partial slabs are summed by the consumer's staging: only when that consumer is a fused step
-    nv_groups(tiles, a.Chid / 16, next_fused ? pj.gmax : 1, &groups, &cpg);
+    nv_groups(tiles, a.Chid / 16, next_fused ? pj.gmax : 1, &groups, &cpg, h->nv_blocks_target);
     a.cpg = cpg; a.out = pj.out; a.out_slab_stride = (long)n * a.Ho * a.Wo * a.Cout;
     pj.slabs = groups; pj.slab_stride = a.out_slab_stride;
     if (st.xblock) HIP_TRY(launch_nv_xblock(a, n, groups, s));
     else HIP_TRY(launch_nv_block(a, st.expand, st.front ? 1 : 0, n, groups, s));
     // three or more partial slabs: sum them once instead of in every consumer workgroup (and in every residual read)
-    { static int thr = -1; if (thr < 0) { const char* e = getenv("D2FE_NV_SLABSUM"); thr = e ? atoi(e) : 3; }
-      if (groups >= thr && thr > 0) { HIP_TRY(launch_nv_slab_sum(pj.out, groups, pj.slab_stride, pj.slab_stride, s)); pj.slabs = 1; } }
+    if (h->nv_slabsum > 0 && groups >= h->nv_slabsum) { HIP_TRY(launch_nv_slab_sum(pj.out, groups, pj.slab_stride, pj.slab_stride, s)); pj.slabs = 1; }
     ch = a.Ho; cw = a.Wo;
   }
   const int np = ch * cw;
@@ -802,6 +800,9 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
   {
     const char* e = getenv("D2FE_NV_LEGACY");
     const bool legacy = e && atoi(e) != 0;
+    if (const char* v = getenv("D2FE_NV_BLOCKS")) { if (atoi(v) > 0) h->nv_blocks_target = atoi(v); }
+    if (const char* v = getenv("D2FE_NV_TAIL_BLOCKS")) { if (atoi(v) > 0) h->nv_tail_blocks = atoi(v); }
+    if (const char* v = getenv("D2FE_NV_SLABSUM")) h->nv_slabsum = atoi(v);
     const int nl = w->n_layers;
     auto K = [&](int i) { return i < nl ? h->nv[i].kind : -1; };
     std::vector<char> materialised(nl, 0);

@@ -408,6 +408,30 @@ def test_netvlad_fused_blocks_layerwise(api, orc, H, W):
     fe.close()
 
 
+def test_netvlad_plans_agree(api, orc, monkeypatch):
+    """The fused plan (default), the LDS-resident block form (D2FE_NV_XBLOCK=0), no slab sums (D2FE_NV_SLABSUM=0) and one launch per
+    layer (D2FE_NV_LEGACY=1) are four schedules of the same arithmetic up to summation order: all within 1e-4 of the oracle, and a batch
+    of one image equals the same image inside a batch of five (different group counts, hence different slab layouts)."""
+    from d2slam_amd import netvlad as nvm
+    nv = nvm.synthetic_netvlad_weights()
+    H, W = 240, 320
+    imgs = np.stack([synth_image(H, W, 30 + s) for s in range(5)])
+    ref = orc.netvlad_forward(imgs[2], nv)
+    for env in ({}, {"D2FE_NV_XBLOCK": "0"}, {"D2FE_NV_SLABSUM": "0"}, {"D2FE_NV_LEGACY": "1"}):
+        for k in ("D2FE_NV_XBLOCK", "D2FE_NV_SLABSUM", "D2FE_NV_LEGACY"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=5))
+        fe.load_netvlad(nv)
+        got5 = fe.netvlad(imgs)
+        got1 = fe.netvlad(imgs[2:3])
+        assert np.abs(got5[2] - ref).max() <= 1e-4, env
+        assert np.abs(got1[0] - ref).max() <= 1e-4, env
+        assert np.abs(got1[0] - got5[2]).max() <= 2e-6, env
+        fe.close()
+
+
 def test_stride_cap_and_batch_invariance(api, orc, sp_weights):
     """Row stride > width (cv::Mat ROI), cap < max_keypoints, and batch-position independence (an image's result must not
     depend on its neighbours in the batch or on the batch size)."""
