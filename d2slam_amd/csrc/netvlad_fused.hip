@@ -386,10 +386,14 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
   const int nchunk = a.Chid >> 4;
   const int ch0 = blockIdx.z * a.cpg, ch1 = min(nchunk, ch0 + a.cpg);
   float wes[WER], wds[WDR];
-  auto fetch_w = [&](int ch) {
+  // weight records travel global -> registers -> LDS; the loads for chunk ch + 2 are issued right after the registers holding chunk
+  // ch + 1 have been written to LDS, so a full chunk of work covers their L2 latency (a chunk's MFMA time is ~0.5 us, a miss ~1-2 us)
+  auto fetch_we = [&](int ch) {
     const float* wb = a.we + (size_t)ch * WE_N + tid;
 #pragma unroll
     for (int i = 0; i < WER; ++i) wes[i] = wb[256 * i];
+  };
+  auto fetch_wd = [&](int ch) {
     const float* wc = a.wp + (size_t)ch * WD_N + tid;
 #pragma unroll
     for (int i = 0; i < WDR; ++i) wds[i] = wc[256 * i];
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
 #pragma unroll
     for (int i = 0; i < WDR; ++i) wm[256 * i] = wds[i];
   };
-  if (ch0 < ch1) fetch_w(ch0);
+  if (ch0 < ch1) { fetch_we(ch0); fetch_wd(ch0); }
 
   // ---- the wave's MPW patch m-tiles: pixel mt*16 + lp, channels (lq + 4 j) * 4 .. + 3, summed over the producer's partial slabs ----
   f32x4 xr[MPW][NJ];
@@ -439,6 +443,7 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
     ebase[m2] = q < th * tw ? (oy * S) * iw + ox * S : 0;
   }
   if (ch0 < ch1) { store_we(0); store_wd(0); }
+  if (ch0 + 1 < ch1) { fetch_we(ch0 + 1); fetch_wd(ch0 + 1); }
   __syncthreads();
 
   f32x4 acc[2][NT];
@@ -450,7 +455,6 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
 
   for (int ch = ch0; ch < ch1; ++ch) {
     const int wb_i = (ch - ch0) & 1;
-    if (ch + 1 < ch1) fetch_w(ch + 1);
     float* Eb = E + (NBUF == 2 ? wb_i : 0) * 16 * EP;
     const float* wl = WE + wb_i * WE_N + lane;
     if (NBUF == 1 && ch > ch0) __syncthreads();            // everybody is done reading the previous chunk
@@ -483,7 +487,8 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
         else { e[0] = o[0]; e[1] = o[1]; e[2] = o[2]; e[3] = o[3]; }
       }
     }
-    if (ch + 1 < ch1) store_we(wb_i ^ 1);
+    if (ch + 1 < ch1) store_we(wb_i ^ 1);              // WE[wb_i ^ 1] was last read by the previous chunk's expand stage
+    if (ch + 2 < ch1) fetch_we(ch + 2);
     __syncthreads();
     const float* wd = WD + wb_i * WD_N;
     const float* wpl = wd + 256 + lane;
@@ -511,7 +516,8 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
         acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[1], wv, acc[1][t], 0, 0, 0);
       }
     }
-    if (ch + 1 < ch1) store_wd(wb_i ^ 1);
+    if (ch + 1 < ch1) store_wd(wb_i ^ 1);              // WD[wb_i ^ 1]: everybody passed this chunk's barrier, so chunk ch - 1 is done with it
+    if (ch + 2 < ch1) fetch_wd(ch + 2);
   }
 
   // ---- epilogue: C row = pixel q = (2 wave + m2) * 16 + 4 lq + r of the flat tile, col = channel lp of n-tile t ----------------------
