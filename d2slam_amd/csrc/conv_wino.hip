@@ -183,6 +183,16 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
         acc[nt * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], ub[slot][nt][j], first ? zero : acc[nt * 4 + j], 0, 0, 0);
   };
 
+  // FUSE: the frame bytes of the next item (see the staging below)
+  unsigned char* u8p = reinterpret_cast<unsigned char*>(wlds + 8 * CHF);     // [12][20] bytes behind the patch
+  const int fr = tid / 20, fc = tid - fr * 20;
+  int fbyte = 0;
+  auto load_frame = [&](const WItem& T) {
+    const int gy = T.by * 8 - 2 + fr, gx = T.bx * 16 - 2 + fc;
+    fbyte = 0;
+    if (tid < 240 && gy >= 0 && gy < aH && gx >= 0 && gx < aW) fbyte = a.img[(size_t)T.img * a.img_istride + (size_t)gy * a.img_stride + gx];
+  };
+  auto store_frame = [&]() { if (tid < 240) u8p[tid] = (unsigned char)fbyte; };
   // ---- epilogue: s = M A for this wave's row, swap rows between the four waves, A^T s, bias, ReLU, pool, store ----------------
   float* xch = FUSE ? wlds : wlds + WR * WCHUNK;      // FUSE: the patch is dead once the K loop is through, the exchange area reuses it
   auto epilogue = [&](const WItem& T) {
@@ -198,7 +208,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     const int rowpair = (POOL ? Wo : 2 * Wo) * cs4;               // bytes between tile rows ty and ty + 1
     const int vo0 = (lane & 31) * 4 + hh * rowpair, vo1 = (lane & 31) * 4 + (1 - hh) * rowpair;
     const int obase = ((POOL ? T.by * 4 * Wo + T.bx * 8 : T.by * 8 * Wo + T.bx * 16)) * cs4 + n32 * 128;
-    if constexpr (FUSE) __syncthreads();      // every wave is through with the patch before the exchange overwrites it
+    if constexpr (FUSE) { store_frame(); __syncthreads(); }   // the next item's frame bytes; every wave is through with the patch before the exchange overwrites it
     f32x4 sk[4];           // kept tiles (registers r = 4I .. 4I+3): (s_nt0_b0, s_nt0_b1, s_nt1_b0, s_nt1_b1) of row I
     f32x4* xw = reinterpret_cast<f32x4*>(xch) + (I * 12) * 64 + lane;
 #pragma unroll
@@ -291,53 +301,56 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
       c1a[st] = k == 0 ? a.b1a[(wave & 1) * 32 + (lane & 31)] : a.w1a[(k - 1) * 64 + (wave & 1) * 32 + (lane & 31)];
     }
   }
-  // the 15 tap bytes of a lane (3 units x 5 k-steps) are requested one item ahead, so their latency falls under the K loop
-  unsigned char rawt[3][5];
-  auto load_taps = [&](const WItem& T) {
-    const uint8_t* ip = a.img + (size_t)T.img * a.img_istride;
+  // The frame bytes under the patch (12 x 20: the 10 x 18 patch plus conv1a's own ring) are staged through LDS: thread t < 240 fetches
+  // ONE byte per item, one item ahead (out-of-image bytes are 0 = conv1a's zero padding), and writes it at the start of the running
+  // item's epilogue, in front of a barrier that is there anyway.  Every address below is a per-lane constant of the kernel, so what is
+  // left per item and unit is 5 byte reads + conversions, the in-image test of the patch pixel and the MFMA chain.
+  int tb[3], dsto[3], pyx[3];            // unit uu: byte index of tap (0,0), float index of the patch pixel in the chunk layout, (py, px)
+  int koff[5];                           // k-step st: this lane half's tap (ky, kx) as a byte offset
+  if constexpr (FUSE) {
 #pragma unroll
     for (int uu = 0; uu < 3; ++uu) {
       const int pidx = ((wave >> 1) + 2 * uu) * 32 + (lane & 31);
-      const int gy = T.by * 8 - 1 + pidx / 18, gx = T.bx * 16 - 1 + pidx % 18;
-#pragma unroll
-      for (int st = 0; st < 5; ++st) {
-        const int k = 2 * st + (lane >> 5);
-        const int yy = gy + (k - 1) / 3 - 1, xx = gx + (k - 1) % 3 - 1;
-        const int yc = yy < 0 ? 0 : (yy >= aH ? aH - 1 : yy), xc = xx < 0 ? 0 : (xx >= aW ? aW - 1 : xx);
-        rawt[uu][st] = ip[(size_t)yc * a.img_stride + xc];
-      }
+      const int py = pidx / 18, px = pidx - py * 18;
+      tb[uu] = pidx < 180 ? py * 20 + px : 0;
+      pyx[uu] = pidx < 180 ? (py << 8) | px : (int)0x8080;         // 0x8080 marks the 12 lanes of the last m-tile beyond the patch: computed, not stored
+      dsto[uu] = ((py & 1) * 2 + (px & 1)) * PL + ((py >> 1) * WROW + (px >> 1)) * 4;
     }
-  };
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      const int t = 2 * st + (lane >> 5) - 1;                      // tap index; -1 is the bias slot (k = 0)
+      koff[st] = t < 0 ? 0 : (t / 3) * 20 + t % 3;
+    }
+  }
   auto stage_fused = [&](const WItem& T) {
     const float scale = (float)(1.0 / 255.0);
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int gy0 = T.by * 8 - 1, gx0 = T.bx * 16 - 1;
 #pragma unroll
     for (int uu = 0; uu < 3; ++uu) {
-      const int m = (wave >> 1) + 2 * uu, nt = wave & 1;        // 12 units = 6 m-tiles of 32 patch pixels x 2 halves of the channels
-      const int pidx = m * 32 + (lane & 31);
-      const int py = pidx / 18, px = pidx % 18;
-      const int gy = T.by * 8 - 1 + py, gx = T.bx * 16 - 1 + px;
-      const bool pvalid = pidx < 180 && gy >= 0 && gy < aH && gx >= 0 && gx < aW;
+      // 12 units = 6 m-tiles of 32 patch pixels x 2 halves of the channels; unit u = wave + 4*uu covers m-tile u >> 1, half wave & 1
+      const int nt = wave & 1;
+      // a patch pixel outside the image is conv1b's zero padding: all its taps AND the bias slot are 0, so the chain gives +0
+      const bool pvalid = (unsigned)(gy0 + (pyx[uu] >> 8)) < (unsigned)aH && (unsigned)(gx0 + (pyx[uu] & 255)) < (unsigned)aW;
       float tap[5];
 #pragma unroll
       for (int st = 0; st < 5; ++st) {
-        const int k = 2 * st + (lane >> 5);                     // 0: the bias slot, 1..9: tap k-1
-        const int yy = gy + (k - 1) / 3 - 1, xx = gx + (k - 1) % 3 - 1;
-        const bool in = k > 0 && yy >= 0 && yy < aH && xx >= 0 && xx < aW;
-        tap[st] = k == 0 ? 1.0f : (in ? (float)rawt[uu][st] * scale : 0.f);
+        float v = (float)u8p[tb[uu] + koff[st]] * scale;
+        if (st == 0) v = hh ? v : 1.0f;                           // k = 0 (lanes 0-31 of the first step) carries the bias against 1.0
+        tap[st] = pvalid ? v : 0.f;
       }
       f32x16 d = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[0], tap[0], zero, 0, 0, 0);
 #pragma unroll
       for (int st = 1; st < 5; ++st) d = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[st], tap[st], d, 0, 0, 0);
       // rows (channels) of this lane: 8*q + 4*hh + (0..3) of half nt -> channel quad Q = nt*8 + 2*q + hh; column = patch pixel
-      if (pidx < 180) {
-        float* dst = wlds + ((py & 1) * 2 + (px & 1)) * PL + ((py >> 1) * WROW + (px >> 1)) * 4;
+      if (pyx[uu] != (int)0x8080) {
+        float* dst = wlds + dsto[uu];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int Q = nt * 8 + 2 * q + hh;
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const float v = d[4 * q + e]; o[e] = (pvalid && v > 0.f) ? v : 0.f; }
+          for (int e = 0; e < 4; ++e) o[e] = __builtin_amdgcn_fmed3f(d[4 * q + e], 0.f, __builtin_inff());     // ReLU (the chain never yields -0)
           *reinterpret_cast<f32x4*>(dst + (Q >> 1) * CHF + (Q & 1) * 4 * PL) = o;
         }
       }
@@ -355,7 +368,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     for (int c = 0; c < WR; ++c)
       if (c < G) dma_issue(c < NCH ? dcur : dnxt, c % NCH, c);
   }
-  if constexpr (FUSE) load_taps(cur);
+  if constexpr (FUSE) { load_frame(cur); store_frame(); __syncthreads(); }
   int ucur = u_ptr(cur), unxt = u_ptr(nxt);
   load_u(0, ucur, 0);
   load_u(1, ucur, 1);
@@ -424,10 +437,10 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
 #pragma unroll 1
   for (int item = 0; item < n_my; ++item) {
     if constexpr (FUSE) {
-      stage_fused(cur);
+      if (!(a.ablate & 64) || item == 0) stage_fused(cur);     // D2FE_ABLATE=64: timing experiment, the staging runs for the first item only
       __syncthreads();
       read_d(0);
-      if (item + 1 < n_my) load_taps(nxt);      // the next item's frame bytes, in flight during this item's K loop
+      if (item + 1 < n_my && !(a.ablate & 64)) load_frame(nxt);     // the next item's frame bytes, in flight during this item's K loop
     }
     chunk(IC<1>{}, item, 0);       // the first k-step multiplies into C = 0: no accumulator clearing
 #pragma unroll 1
@@ -525,7 +538,7 @@ hipError_t launch_conv_wino_fused1b(int cout_pad, const ConvArgs& a, hipStream_t
     ncu = p.multiProcessorCount;
   }
   const int grid = total < 2 * ncu ? total : 2 * ncu;
-  constexpr size_t lds = (size_t)8 * 2 * 4 * 272 * sizeof(float);      // the 64-channel patch; the exchange area (48 KiB) reuses it
+  constexpr size_t lds = (size_t)8 * 2 * 4 * 272 * sizeof(float) + 256;      // the 64-channel patch (the exchange area, 48 KiB, reuses it) + the 12 x 20 frame bytes
   static_assert(lds >= (size_t)WXCH * sizeof(float), "exchange area must fit into the patch buffer");
   auto k = conv_wino_kernel<64, true, true, 0, 1, true>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
