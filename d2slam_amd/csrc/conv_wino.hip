@@ -326,22 +326,31 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     const float scale = (float)(1.0 / 255.0);
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int gy0 = T.by * 8 - 1, gx0 = T.bx * 16 - 1;
+    // 12 units = 6 m-tiles of 32 patch pixels x 2 halves of the channels; unit u = wave + 4*uu covers m-tile u >> 1, half wave & 1.
+    // The three chains of a wave are independent: all 15 bytes are read first and the MFMAs issue round-robin, so that the
+    // conversions, the ReLU and the LDS writes of one unit run under the MFMAs of the others (the accumulators are idle here).
+    float tap[3][5];
 #pragma unroll
     for (int uu = 0; uu < 3; ++uu) {
-      // 12 units = 6 m-tiles of 32 patch pixels x 2 halves of the channels; unit u = wave + 4*uu covers m-tile u >> 1, half wave & 1
-      const int nt = wave & 1;
       // a patch pixel outside the image is conv1b's zero padding: all its taps AND the bias slot are 0, so the chain gives +0
       const bool pvalid = (unsigned)(gy0 + (pyx[uu] >> 8)) < (unsigned)aH && (unsigned)(gx0 + (pyx[uu] & 255)) < (unsigned)aW;
-      float tap[5];
 #pragma unroll
       for (int st = 0; st < 5; ++st) {
         float v = (float)u8p[tb[uu] + koff[st]] * scale;
         if (st == 0) v = hh ? v : 1.0f;                           // k = 0 (lanes 0-31 of the first step) carries the bias against 1.0
-        tap[st] = pvalid ? v : 0.f;
+        tap[uu][st] = pvalid ? v : 0.f;
       }
-      f32x16 d = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[0], tap[0], zero, 0, 0, 0);
+    }
+    f32x16 d[3];
 #pragma unroll
-      for (int st = 1; st < 5; ++st) d = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[st], tap[st], d, 0, 0, 0);
+    for (int uu = 0; uu < 3; ++uu) d[uu] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[0], tap[uu][0], zero, 0, 0, 0);
+#pragma unroll
+    for (int st = 1; st < 5; ++st)
+#pragma unroll
+      for (int uu = 0; uu < 3; ++uu) d[uu] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[st], tap[uu][st], d[uu], 0, 0, 0);
+    const int nt = wave & 1;
+#pragma unroll
+    for (int uu = 0; uu < 3; ++uu) {
       // rows (channels) of this lane: 8*q + 4*hh + (0..3) of half nt -> channel quad Q = nt*8 + 2*q + hh; column = patch pixel
       if (pyx[uu] != (int)0x8080) {
         float* dst = wlds + dsto[uu];
@@ -350,7 +359,8 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
           const int Q = nt * 8 + 2 * q + hh;
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = __builtin_amdgcn_fmed3f(d[4 * q + e], 0.f, __builtin_inff());     // ReLU (the chain never yields -0)
+          for (int e = 0; e < 4; ++e)      // ReLU as one v_max (the chain never yields -0 or a NaN; the builtins add a canonicalising second one)
+            asm("v_max_f32 %0, 0, %1" : "=v"(o[e]) : "v"(d[uu][4 * q + e]));
           *reinterpret_cast<f32x4*>(dst + (Q >> 1) * CHF + (Q & 1) * 4 * PL) = o;
         }
       }
