@@ -31,8 +31,8 @@
 //
 // Data movement.  Persistent workgroups walk a list of work items; the K loop runs over chunks of 8 input channels.  A chunk of
 // the 10 x 18 input patch is brought in by LDS-DMA (buffer_load_dwordx4 ... lds: 16 bytes = 4 channels of one pixel per lane,
-// no VGPR round trip; out-of-image pixels are out-of-range buffer offsets, which read as 0) into a ring of three 8 KiB
-// buffers that runs on across work items.  LDS layout of a chunk: [channel quad 2][pixel parity plane 4][5 rows x 12 (9 used)]
+// no VGPR round trip; out-of-image pixels are out-of-range buffer offsets, which read as 0) into a ring of four 8 KiB
+// buffers that runs on across work items (with the 48 KiB exchange area: 80 KiB, exactly two workgroups per CU; three buffers: 2.7 % slower).  LDS layout of a chunk: [channel quad 2][pixel parity plane 4][5 rows x 12 (9 used)]
 // [4 channels]: the 32 tiles of a wave read the same (dy,dx) of their 4x4 input window from ONE parity plane at positions
 // 12*ty + tx, and the tile -> MFMA-row assignment (below) makes that conflict-free for ds_read_b128's lane groups.  U streams
 // from L2 in MFMA lane order (8 values per lane per k-step, requested three k-steps ahead, running on across work items).
@@ -46,7 +46,7 @@ namespace d2fe {
 
 namespace {
 
-constexpr int WR = 3;                       // ring depth
+constexpr int WR = 4;                       // ring depth
 constexpr int WCHUNK = 2 * 4 * 64 * 4;      // floats per chunk buffer (8 KiB): [quad 2][plane 4][64 slots][4 channels]
 constexpr int WROW = 12;                    // plane row stride in positions (9 used)
 constexpr int WXCH = 4 * 12 * 64 * 4;       // floats of the epilogue exchange area: [wave 4][12 float4][64 lanes]
@@ -384,7 +384,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   load_u(1, ucur, 1);
   load_u(2, ucur, 2);
   if constexpr (!FUSE) {
-    if (G > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // chunk 0 landed (younger: 2 x 2 copies + 6 U loads)
+    if (G > 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // chunk 0 landed (younger: 3 x 2 copies + 6 U loads)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     read_d(0);
@@ -428,7 +428,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
       if (g + 1 < G) {
         // chunk g+1 (copied WR-1 iterations ago) must have landed: the loads younger than it are this iteration's 8 U loads
         // and the 2 copies of chunk g+2 -- loads complete in order, so "at most 10 outstanding" implies it is complete
-        if (g + 2 < G) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        if (g + 3 < G) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       mark(item, ch, 2);
