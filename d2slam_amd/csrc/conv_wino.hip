@@ -32,7 +32,7 @@
 // Data movement.  Persistent workgroups walk a list of work items; the K loop runs over chunks of 8 input channels.  A chunk of
 // the 10 x 18 input patch is brought in by LDS-DMA (buffer_load_dwordx4 ... lds: 16 bytes = 4 channels of one pixel per lane,
 // no VGPR round trip; out-of-image pixels are out-of-range buffer offsets, which read as 0) into a ring of four 8 KiB
-// buffers that runs on across work items (with the 48 KiB exchange area: 80 KiB, exactly two workgroups per CU; three buffers: 2.7 % slower).  LDS layout of a chunk: [channel quad 2][pixel parity plane 4][5 rows x 12 (9 used)]
+// buffers that runs on across work items (with the 48 KiB exchange area: 80 KiB, exactly two workgroups per CU; three buffers measure the same within 0.2 %).  LDS layout of a chunk: [channel quad 2][pixel parity plane 4][5 rows x 12 (9 used)]
 // [4 channels]: the 32 tiles of a wave read the same (dy,dx) of their 4x4 input window from ONE parity plane at positions
 // 12*ty + tx, and the tile -> MFMA-row assignment (below) makes that conflict-free for ds_read_b128's lane groups.  U streams
 // from L2 in MFMA lane order (8 values per lane per k-step, requested three k-steps ahead, running on across work items).
@@ -285,7 +285,9 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
       }
     };
     finish_tile(IC<0>{}); finish_tile(IC<1>{}); finish_tile(IC<2>{}); finish_tile(IC<3>{});
-    __syncthreads();         // the exchange area is free again (the next item's epilogue writes it)
+    // FUSE: the next item's staging overwrites the patch = the exchange area, so every wave must be through with it.  Otherwise the
+    // next writer of the exchange area is the next item's epilogue, eight chunk barriers away: no barrier needed here.
+    if constexpr (FUSE) __syncthreads();
   };
 
   // ---- FUSE: conv1a for the 10 x 18 patch on the matrix pipe, straight into the chunk layout ------------------------------------
@@ -426,8 +428,9 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
       read_d((ch + 1) & (NCH - 1));
     } else {
       if (g + 1 < G) {
-        // chunk g+1 (copied WR-1 iterations ago) must have landed: the loads younger than it are this iteration's 8 U loads
-        // and the 2 copies of chunk g+2 -- loads complete in order, so "at most 10 outstanding" implies it is complete
+        // chunk g+1 (copied WR-1 iterations ago) must have landed: allowed outstanding are this and the last iteration's 8 U loads
+        // (the latter long consumed) and the copies of chunks g+2 and g+3 -- loads complete in order, so "at most 20 outstanding"
+        // implies chunk g+1 is complete
         if (g + 3 < G) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
