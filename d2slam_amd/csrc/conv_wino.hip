@@ -509,6 +509,7 @@ hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const C
     switch (a.ablate) {
       case 1: D2FE_WINO_K((conv_wino_kernel<64, false, true, 1>)); return hipGetLastError();
       case 2: D2FE_WINO_K((conv_wino_kernel<64, false, true, 2>)); return hipGetLastError();
+      case 8: D2FE_WINO_K((conv_wino_kernel<64, false, true, 8>)); return hipGetLastError();
       case 16: D2FE_WINO_K((conv_wino_kernel<64, false, true, 16>)); return hipGetLastError();
       case 19: D2FE_WINO_K((conv_wino_kernel<64, false, true, 19>)); return hipGetLastError();
       case 256: {
