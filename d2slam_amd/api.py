@@ -20,6 +20,8 @@ from .weights import SP_LAYERS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libd2fe_hip.so")
+if os.environ.get("D2FE_LIB"):      # developer knob: same-box A/B of two builds of the library (tools/gpu_ab_lib.sh)
+    LIB_PATH = os.path.abspath(os.environ["D2FE_LIB"])
 
 POSTPROC_B, POSTPROC_A = 0, 1
 PREC_F32, PREC_F16X2, PREC_F32_WINO = 0, 1, 2
