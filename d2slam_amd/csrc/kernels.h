@@ -109,6 +109,7 @@ struct NvBlockArgs {
   int H, W, Cin, Chid, Cout, stride, Ho, Wo, pt, pl;
   long P;                          // mode 2: number of pixels in the flat list
   int th, tw;                      // nv_xblock_kernel: output tile (th x tw <= 128 pixels)
+  unsigned inv_iw, inv_tw;         // ceil(2^20 / d) for d = patch width, tile width: n / d = (n * inv) >> 20 for n < 1024 (filled in by the launcher)
   int cpg;                         // chunks of 16 hidden channels per workgroup group
   const float* we;                    // expand weights + bias, one record per chunk (pack_nv_expand)
   const float* wp;                    // depthwise weights + bias + project weights, one record per chunk (pack_nv_dwproj)

@@ -261,33 +261,41 @@ __global__ __launch_bounds__(256) void nv_block_kernel(NvBlockArgs a) {
     constexpr int PITCH = EXPAND ? EP : XP;
     const float* wd = WD + wb_i * WD_N;
     const float* wpl = wd + 256 + lane;
-    // the wave's two output rows (m-tiles 2 wave, 2 wave + 1) go through the depthwise stage as the halves of v_pk_fma_f32
+    // depthwise on v_pk_fma_f32 with two HIDDEN CHANNELS (k-steps 2 kp, 2 kp + 1) of one pixel as the halves: their E values are a
+    // constant 4 * PITCH apart and their weights 4 floats, so both operands are real register pairs straight out of the LDS reads.
+    // (Pairing the wave's two output rows instead makes the rows they share -- row ky + 1 of the first is row ky of the second -- one
+    // load feeding two different pair positions: two v_mov per FMA in a loop that is VALU-bound.)  Same fma chain per channel.
     const float* eb0 = MODE == 2 ? Esrc + (wave * 2) * 16 + lp : Esrc + (wave * 2 * S) * IW + lp * S;
     constexpr int ROW2 = MODE == 2 ? 16 : S * IW;          // distance between the two rows' patch pixels
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const float* e = eb0 + (ks * 4 + lq) * PITCH;
-      f32x2 d;
+    for (int kp = 0; kp < 2; ++kp) {
+      const float* ea = eb0 + (kp * 8 + lq) * PITCH;
+      const float* ec = ea + 4 * PITCH;
+      f32x2 d0, d1;
       if (MODE == 2) {
-        d = f32x2{e[0], e[ROW2]};
+        d0 = f32x2{ea[0], ec[0]}; d1 = f32x2{ea[ROW2], ec[ROW2]};
       } else {
-        const float bd = wd[144 + ks * 4 + lq];
-        d = f32x2{bd, bd};
+        const float* wk = wd + kp * 8 + lq;
+        d0 = f32x2{wk[144], wk[148]}; d1 = d0;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
-            const float w = wd[(ky * 3 + kx) * 16 + ks * 4 + lq];
-            d = __builtin_elementwise_fma(f32x2{e[ky * IW + kx], e[ROW2 + ky * IW + kx]}, f32x2{w, w}, d);
+            const f32x2 w = {wk[(ky * 3 + kx) * 16], wk[(ky * 3 + kx) * 16 + 4]};
+            d0 = __builtin_elementwise_fma(f32x2{ea[ky * IW + kx], ec[ky * IW + kx]}, w, d0);
+            d1 = __builtin_elementwise_fma(f32x2{ea[ROW2 + ky * IW + kx], ec[ROW2 + ky * IW + kx]}, w, d1);
           }
-        d[0] = nvf_clamp(d[0], lo_d, hi_d); d[1] = nvf_clamp(d[1], lo_d, hi_d);
+        d0[0] = nvf_clamp(d0[0], lo_d, hi_d); d0[1] = nvf_clamp(d0[1], lo_d, hi_d);
+        d1[0] = nvf_clamp(d1[0], lo_d, hi_d); d1[1] = nvf_clamp(d1[1], lo_d, hi_d);
       }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float wv = wpl[(ks * NT + t) * 64];
-        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[0], wv, acc[0][t], 0, 0, 0);
-        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[1], wv, acc[1][t], 0, 0, 0);
-      }
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float wv = wpl[((kp * 2 + h) * NT + t) * 64];
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d0[h], wv, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1[h], wv, acc[1][t], 0, 0, 0);
+        }
     }
     if (ch + 1 < ch1) store_wd(wb_i ^ 1);
     if (!EXPAND && ch + 1 < ch1) __syncthreads();   // no expand stage, hence no barrier of its own between the chunks
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
 #pragma unroll
     for (int m = 0; m < MPW; ++m) {
       const int p = (wave + 4 * m) * 16 + lp;
-      const int iy = p / iw, ix = p - iy * iw;
+      const int iy = (int)(((unsigned)p * a.inv_iw) >> 20), ix = p - iy * iw;     // p / iw without the 25-instruction division
       const int gy = iy0 + iy, gx = ix0 + ix;
       const bool ok = p < npx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       one[m] = ok ? 1.f : 0.f;
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
 #pragma unroll
   for (int m2 = 0; m2 < 2; ++m2) {
     const int q = (wave * 2 + m2) * 16 + lp;
-    const int oy = q / tw, ox = q - oy * tw;
+    const int oy = (int)(((unsigned)q * a.inv_tw) >> 20), ox = q - oy * tw;
     ebase[m2] = q < th * tw ? (oy * S) * iw + ox * S : 0;
   }
   if (ch0 < ch1) { store_we(0); store_wd(0); }
@@ -492,29 +500,34 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
     __syncthreads();
     const float* wd = WD + wb_i * WD_N;
     const float* wpl = wd + 256 + lane;
-    // depthwise: the two output m-tiles as the halves of v_pk_fma_f32; three row pointers per m-tile, kx and the channel as immediates
+    // depthwise: two hidden channels (k-steps 2 kp, 2 kp + 1) of one pixel as the halves of v_pk_fma_f32 (see nv_block_kernel); three row
+    // pointers per m-tile, kx and the channel as immediates
     const float* e0 = Eb + lq * EP + ebase[0];
     const float* e1 = Eb + lq * EP + ebase[1];
     const float* r0[3] = {e0, e0 + iw, e0 + 2 * iw};
     const float* r1[3] = {e1, e1 + iw, e1 + 2 * iw};
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const float bd = wd[144 + ks * 4 + lq];
-      f32x2 d = {bd, bd};
+    for (int kp = 0; kp < 2; ++kp) {
+      const float* wk = wd + kp * 8 + lq;
+      f32x2 d0 = {wk[144], wk[148]}, d1 = d0;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const float w = wd[(ky * 3 + kx) * 16 + ks * 4 + lq];
-          d = __builtin_elementwise_fma(f32x2{r0[ky][ks * 4 * EP + kx], r1[ky][ks * 4 * EP + kx]}, f32x2{w, w}, d);
+          const f32x2 w = {wk[(ky * 3 + kx) * 16], wk[(ky * 3 + kx) * 16 + 4]};
+          d0 = __builtin_elementwise_fma(f32x2{r0[ky][kp * 8 * EP + kx], r0[ky][(kp * 8 + 4) * EP + kx]}, w, d0);
+          d1 = __builtin_elementwise_fma(f32x2{r1[ky][kp * 8 * EP + kx], r1[ky][(kp * 8 + 4) * EP + kx]}, w, d1);
         }
-      d[0] = nvf_clamp(d[0], lo_d, hi_d); d[1] = nvf_clamp(d[1], lo_d, hi_d);
+      d0[0] = nvf_clamp(d0[0], lo_d, hi_d); d0[1] = nvf_clamp(d0[1], lo_d, hi_d);
+      d1[0] = nvf_clamp(d1[0], lo_d, hi_d); d1[1] = nvf_clamp(d1[1], lo_d, hi_d);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float wv = wpl[(ks * NT + t) * 64];
-        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[0], wv, acc[0][t], 0, 0, 0);
-        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[1], wv, acc[1][t], 0, 0, 0);
-      }
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float wv = wpl[((kp * 2 + h) * NT + t) * 64];
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d0[h], wv, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1[h], wv, acc[1][t], 0, 0, 0);
+        }
     }
     if (ch + 1 < ch1) store_wd(wb_i ^ 1);              // WD[wb_i ^ 1]: everybody passed this chunk's barrier, so chunk ch - 1 is done with it
     if (ch + 2 < ch1) fetch_wd(ch + 2);
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int q = (wave * 2 + m2) * 16 + lq * 4 + r;
-      const int oy = q / tw, ox = q - oy * tw;
+      const int oy = (int)(((unsigned)q * a.inv_tw) >> 20), ox = q - oy * tw;
       const int gy = oy0 + oy, gx = ox0 + ox;
       if (q >= th * tw || gy >= a.Ho || gx >= a.Wo) continue;
       const int base = (gy * a.Wo + gx) * Cout + lp;
@@ -605,7 +618,11 @@ static hipError_t launch_xblock_nt(const NvBlockArgs& a, int n, int groups, hipS
   }
   return hipErrorInvalidValue;
 }
-hipError_t launch_nv_xblock(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
+hipError_t launch_nv_xblock(const NvBlockArgs& a_in, int n, int groups, hipStream_t s) {
+  NvBlockArgs a = a_in;
+  const int iw = (a.tw - 1) * a.stride + 3;
+  if (a.tw < 1 || a.tw > 128 || iw > 1024) return hipErrorInvalidValue;
+  a.inv_iw = ((1u << 20) + iw - 1) / iw; a.inv_tw = ((1u << 20) + a.tw - 1) / a.tw;     // exact for n < 2^20 / d: n < 1024 here
   if ((long)a.H * a.W * a.Cin >= (1l << 31) || (long)a.Ho * a.Wo * a.Cout >= (1l << 31)) return hipErrorInvalidValue;
   const int nj = nv_xblock_nj(a.Cin);
   if (a.stride == 1) {
