@@ -188,3 +188,39 @@ def test_wino_fused_conv1a_is_bit_identical(api, monkeypatch):
     assert np.array_equal(trunks[0], trunks[1])
     for (k0, s0, d0), (k1, s1, d1) in zip(*outs):
         assert np.array_equal(k0, k1) and np.array_equal(s0, s1) and np.array_equal(d0, d1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(100, 150), (24, 40), (75, 133)])
+def test_wino_fused_staging_borders_and_stride(api, monkeypatch, H, W):
+    """The fused conv1a staging reads the frame through a 12 x 20 byte patch in LDS: sizes that are no multiple of the 8 x 16 work item
+    (items cut by the right / bottom border, patches hanging over every edge) and a row stride > width whose padding is poisoned
+    must give the bits of the two-kernel form (which reads the frame in a different kernel altogether)."""
+    import ctypes as C
+    n, cap = 3, 60
+    w = synthetic_superpoint_weights(dustbin_bias=7.5)
+    rng = np.random.RandomState(H * 1000 + W)
+    imgs = rng.randint(0, 256, size=(n, H, W)).astype(np.uint8)
+    imgs[0, :2, :] = 255; imgs[0, -2:, :] = 255; imgs[0, :, :2] = 255; imgs[0, :, -2:] = 255      # bright frame border: padding errors show
+    trunks, outs, strided = [], [], []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("D2FE_FUSE1A", fuse)
+        fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=cap, input_width=W, input_height=H, max_batch=n, precision=api.PREC_F32_WINO))
+        fe.load_superpoint(w)
+        outs.append(fe.extract_batch(imgs, cap=cap))
+        trunks.append(fe.debug_read("conv1b", (n, H // 2, W // 2, 64)))
+        stride = W + 23
+        buf = np.full((H, stride), 255, np.uint8); buf[:, :W] = imgs[1]
+        kps = np.zeros((cap, 2), np.float32); sc = np.zeros(cap, np.float32); desc = np.zeros((cap, 256), np.float32); k = C.c_int(0)
+        rc = api.load_library().d2fe_superpoint_extract(fe.handle, buf.ctypes.data, W, H, stride, kps.ctypes.data, sc.ctypes.data,
+                                                        desc.ctypes.data, cap, C.byref(k))
+        assert rc == 0
+        strided.append((kps[:k.value].copy(), sc[:k.value].copy(), desc[:k.value].copy()))
+        fe.close()
+    assert np.array_equal(trunks[0], trunks[1])
+    for (k0, s0, d0), (k1, s1, d1) in zip(*outs):
+        assert np.array_equal(k0, k1) and np.array_equal(s0, s1) and np.array_equal(d0, d1)
+    for a, b in zip(strided[0], strided[1]):
+        assert np.array_equal(a, b)
+    for a, b in zip(strided[1], outs[1][1]):        # the strided call sees the same image as batch entry 1
+        assert np.array_equal(a, b)
