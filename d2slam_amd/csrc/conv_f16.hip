@@ -44,31 +44,64 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f16x2_kernel(ConvArgs a) {
 
   // ---- stage + split the input patch ---------------------------------------------------------------------
   if constexpr (FUSE1A) {
-    // conv1a evaluated on the fly (exact fp32 chain, see conv1a_octet), then scaled and split into hi/lo
-    static_assert(CIN == 64 && KS == 3, "fused prologue is conv1a -> conv1b");
+    // conv1a on the fp32 matrix pipe (the Winograd kernel's fused staging, conv_wino.hip): the (PH+2) x (PW+2) frame bytes under the
+    // patch go through LDS once (zero outside the image = conv1a's padding), a unit = 32 patch pixels x 32 channels is a chain of five
+    // v_mfma_f32_32x32x2_f32 with the WEIGHTS as the A operand (k = 0: the bias against a tap of 1.0, then the taps in (ky,kx) order --
+    // bit for bit the fmaf chain of conv1a_octet), so a lane (= pixel) ends up with 4 x 4 consecutive channels: scaled, split into
+    // hi/lo and stored as 8-byte runs.  A patch pixel outside the image (conv1b's padding) gets all taps and the bias slot zeroed.
+    static_assert(CIN == 64 && KS == 3 && NTHREADS == 256, "fused prologue is conv1a -> conv1b, four waves");
+    constexpr int FR = PH + 2, FC = PW + 2, NMT = (NPIX + 31) / 32;
+    unsigned char* u8p = reinterpret_cast<unsigned char*>(lds + 2 * NPIX * CPH);
     const uint8_t* ip = a.img + (size_t)img * a.img_istride;
-    const float sa = (float)(1 << F16_SA);
-    for (int pix = tid; pix < ((NPIX + 63) / 64) * 64; pix += NTHREADS) {
-      const int gy = ty0 + pix / PW - P, gx = tx0 + pix % PW - P;
-      const bool inpatch = pix < NPIX;
-      const bool valid = inpatch && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      float v[9];
-      conv1a_load_taps(ip, a.img_stride, a.H, a.W, valid ? gy : 0, valid ? gx : 0, v);
-#pragma unroll 1
-      for (int oct = 0; oct < 8; ++oct) {
-        float o[8];
-        conv1a_octet(v, a.w1a, a.b1a, oct, valid, o);
-        f16x8 h8, l8;
+    for (int i = tid; i < FR * FC; i += NTHREADS) {
+      const int r = i / FC, c = i - r * FC;
+      const int gy = ty0 - P - 1 + r, gx = tx0 - P - 1 + c;
+      u8p[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? ip[(size_t)gy * a.img_stride + gx] : (unsigned char)0;
+    }
+    const int hh = lane >> 5, nt = wave & 1;
+    float c1a[5];
+    int koff[5];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          float x = fminf(o[c] * sa, 65000.f);
-          const _Float16 h = (_Float16)x;
-          h8[c] = h;
-          l8[c] = (_Float16)(x - (float)h);
-        }
-        if (inpatch) {
-          *reinterpret_cast<f16x8*>(hi + pix * CPH + oct * 8) = h8;
-          *reinterpret_cast<f16x8*>(lo + pix * CPH + oct * 8) = l8;
+    for (int st = 0; st < 5; ++st) {
+      const int k = 2 * st + hh;
+      c1a[st] = k == 0 ? a.b1a[nt * 32 + (lane & 31)] : a.w1a[(k - 1) * 64 + nt * 32 + (lane & 31)];
+      koff[st] = k == 0 ? 0 : ((k - 1) / 3) * FC + (k - 1) % 3;
+    }
+    const float sa = (float)(1 << F16_SA), scale = (float)(1.0 / 255.0);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int u = wave; u < 2 * NMT; u += 4) {             // u & 1 == wave & 1: a wave only ever needs one half of the weights
+      const int pidx = (u >> 1) * 32 + (lane & 31);
+      const int py = pidx / PW, px = pidx - py * PW;
+      const int gy = ty0 + py - P, gx = tx0 + px - P;
+      const bool inpatch = pidx < NPIX;
+      const bool pvalid = inpatch && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const int tb = inpatch ? py * FC + px : 0;
+      float tap[5];
+#pragma unroll
+      for (int st = 0; st < 5; ++st) {
+        float v = (float)u8p[tb + koff[st]] * scale;
+        if (st == 0) v = hh ? v : 1.0f;
+        tap[st] = pvalid ? v : 0.f;
+      }
+      f32x16 d = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[0], tap[0], zero, 0, 0, 0);
+#pragma unroll
+      for (int st = 1; st < 5; ++st) d = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[st], tap[st], d, 0, 0, 0);
+      if (inpatch) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                       // rows (channels) 8 q + 4 hh + (0..3) of half nt
+          f16x4 h4, l4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float o = d[4 * q + e] > 0.f ? d[4 * q + e] : 0.f;
+            const float x = fminf(o * sa, 65000.f);
+            const _Float16 h = (_Float16)x;
+            h4[e] = h;
+            l4[e] = (_Float16)(x - (float)h);
+          }
+          const int off = pidx * CPH + nt * 32 + 8 * q + 4 * hh;
+          *reinterpret_cast<f16x4*>(hi + off) = h4;
+          *reinterpret_cast<f16x4*>(lo + off) = l4;
         }
       }
     }
@@ -220,8 +253,8 @@ static hipError_t launch_f16(bool pool, bool relu, int cout_pad, const ConvArgs&
 
 static hipError_t launch_f16_fused1b(int cout_pad, const ConvArgs& a, hipStream_t s) {
   constexpr int TH = 4, TW = 32;
-  constexpr size_t lds = (size_t)(TH + 2) * (TW + 2) * 72 * sizeof(_Float16) * 2;
-  if (cout_pad != 64) return hipErrorInvalidValue;
+  constexpr size_t lds = (size_t)(TH + 2) * (TW + 2) * 72 * sizeof(_Float16) * 2 + (TH + 4) * (TW + 4);      // hi/lo patch planes + the frame bytes
+  if (cout_pad != 64 || !a.img || !a.w1a || !a.b1a) return hipErrorInvalidValue;
   auto k = conv_f16x2_kernel<64, 3, TH, TW, 2, 2, 2, 1, true, true, true>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
