@@ -49,23 +49,52 @@ __global__ __launch_bounds__(WM * WN * 64, f32_min_waves(CIN, KS, TH, TW)) void 
 
   // ---- stage the input patch -------------------------------------------------------------------------
   if constexpr (FUSE1A) {
-    // conv1a is evaluated on the fly for the (TH+2)x(TW+2) patch: the 78.6 MB/image conv1a activation never exists
-    static_assert(CIN == 64 && KS == 3, "fused prologue is conv1a -> conv1b");
+    // conv1a is evaluated on the fly for the (TH+2)x(TW+2) patch: the 78.6 MB/image conv1a activation never exists.  Same staging as
+    // the Winograd and fp16x2 kernels: frame bytes through LDS, a unit = 32 patch pixels x 32 channels as a chain of five
+    // v_mfma_f32_32x32x2_f32 with the weights as the A operand (k = 0: bias against 1.0, then the taps in (ky,kx) order = the fmaf chain
+    // of conv1a_octet, bit for bit); a patch pixel outside the image gets all taps and the bias slot zeroed, i.e. +0.
+    static_assert(CIN == 64 && KS == 3 && NTHREADS == 256, "fused prologue is conv1a -> conv1b, four waves");
+    constexpr int NPIX = PH * PW, FR = PH + 2, FC = PW + 2, NMT = (NPIX + 31) / 32;
+    unsigned char* u8p = reinterpret_cast<unsigned char*>(patch + NPIX * CP);
     const uint8_t* ip = a.img + (size_t)img * a.img_istride;
-    for (int pix = tid; pix < ((PH * PW + 63) / 64) * 64; pix += NTHREADS) {
-      const int gy = ty0 + pix / PW - P, gx = tx0 + pix % PW - P;
-      const bool inpatch = pix < PH * PW;
-      const bool valid = inpatch && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      float v[9];
-      conv1a_load_taps(ip, a.img_stride, a.H, a.W, valid ? gy : 0, valid ? gx : 0, v);
-#pragma unroll 1
-      for (int oct = 0; oct < 8; ++oct) {
-        float o[8];
-        conv1a_octet(v, a.w1a, a.b1a, oct, valid, o);
-        if (inpatch) {
+    for (int i = tid; i < FR * FC; i += NTHREADS) {
+      const int r = i / FC, c = i - r * FC;
+      const int gy = ty0 - P - 1 + r, gx = tx0 - P - 1 + c;
+      u8p[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? ip[(size_t)gy * a.img_stride + gx] : (unsigned char)0;
+    }
+    const int hh = lane >> 5, nt = wave & 1;
+    float c1a[5];
+    int koff[5];
 #pragma unroll
-          for (int c = 0; c < 8; ++c) patch[pix * CP + oct * 8 + c] = o[c];
-        }
+    for (int st = 0; st < 5; ++st) {
+      const int k = 2 * st + hh;
+      c1a[st] = k == 0 ? a.b1a[nt * 32 + (lane & 31)] : a.w1a[(k - 1) * 64 + nt * 32 + (lane & 31)];
+      koff[st] = k == 0 ? 0 : ((k - 1) / 3) * FC + (k - 1) % 3;
+    }
+    const float scale = (float)(1.0 / 255.0);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int u = wave; u < 2 * NMT; u += 4) {             // u & 1 == wave & 1: a wave only ever needs one half of the weights
+      const int pidx = (u >> 1) * 32 + (lane & 31);
+      const int py = pidx / PW, px = pidx - py * PW;
+      const int gy = ty0 + py - P, gx = tx0 + px - P;
+      const bool inpatch = pidx < NPIX;
+      const bool pvalid = inpatch && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const int tb = inpatch ? py * FC + px : 0;
+      float tap[5];
+#pragma unroll
+      for (int st = 0; st < 5; ++st) {
+        float v = (float)u8p[tb + koff[st]] * scale;
+        if (st == 0) v = hh ? v : 1.0f;
+        tap[st] = pvalid ? v : 0.f;
+      }
+      f32x16 d = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[0], tap[0], zero, 0, 0, 0);
+#pragma unroll
+      for (int st = 1; st < 5; ++st) d = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[st], tap[st], d, 0, 0, 0);
+      if (inpatch) {
+        float* dst = patch + pidx * CP + nt * 32 + 4 * hh;      // rows (channels) 8 q + 4 hh + (0..3) of half nt; odd pixel stride: scalar stores
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[8 * (r >> 2) + (r & 3)] = d[r] > 0.f ? d[r] : 0.f;
       }
     }
   } else {
@@ -205,7 +234,7 @@ static hipError_t launch_f32(bool pool, bool relu, int cout_pad, const ConvArgs&
 
 static hipError_t launch_f32_fused1b(int cout_pad, const ConvArgs& a, hipStream_t s) {
   constexpr int TH = 4, TW = 32;
-  constexpr size_t lds = (size_t)(TH + 2) * (TW + 2) * 65 * sizeof(float);
+  constexpr size_t lds = (size_t)(TH + 2) * (TW + 2) * 65 * sizeof(float) + (TH + 4) * (TW + 4);      // the patch + the frame bytes
   if (cout_pad != 64) return hipErrorInvalidValue;
   auto k = conv_f32_kernel<64, 3, TH, TW, 2, 2, 2, 1, true, true, true>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
