@@ -183,6 +183,9 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
         acc[nt * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], ub[slot][nt][j], first ? zero : acc[nt * 4 + j], 0, 0, 0);
   };
 
+  const bool tracing = (ABL & 256) && blockIdx.x == 0 && tid == 0;
+  auto mark = [&](int item, int ch, int slot) { if constexpr ((ABL & 256) != 0) { if (tracing && item < 4) g_wino_trace[item][ch][slot] = clock64(); } };
+  int trace_item = 0;
   // FUSE: the frame bytes of the next item (see the staging below)
   unsigned char* u8p = reinterpret_cast<unsigned char*>(wlds + 8 * CHF);     // [12][20] bytes behind the patch
   const int fr = tid / 20, fc = tid - fr * 20;
@@ -209,6 +212,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     const int vo0 = (lane & 31) * 4 + hh * rowpair, vo1 = (lane & 31) * 4 + (1 - hh) * rowpair;
     const int obase = ((POOL ? T.by * 4 * Wo + T.bx * 8 : T.by * 8 * Wo + T.bx * 16)) * cs4 + n32 * 128;
     if constexpr (FUSE) { store_frame(); __syncthreads(); }   // the next item's frame bytes; every wave is through with the patch before the exchange overwrites it
+    mark(trace_item, 8, 0);
     f32x4 sk[4];           // kept tiles (registers r = 4I .. 4I+3): (s_nt0_b0, s_nt0_b1, s_nt1_b0, s_nt1_b1) of row I
     f32x4* xw = reinterpret_cast<f32x4*>(xch) + (I * 12) * 64 + lane;
 #pragma unroll
@@ -223,7 +227,9 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
       const int o = r >> 2;                               // the wave that finishes this tile
       if (o == I) sk[r & 3] = sv; else xw[((o < I ? o : o - 1) * 4 + (r & 3)) * 64] = sv;
     }
+    mark(trace_item, 8, 1);
     __syncthreads();
+    mark(trace_item, 8, 2);
     auto finish_tile = [&](auto k_c) {
       constexpr int k = decltype(k_c)::value;
       constexpr int r = 4 * I + k;
@@ -285,6 +291,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
       }
     };
     finish_tile(IC<0>{}); finish_tile(IC<1>{}); finish_tile(IC<2>{}); finish_tile(IC<3>{});
+    mark(trace_item, 8, 3);
     // FUSE: the next item's staging overwrites the patch = the exchange area, so every wave must be through with it.  Otherwise the
     // next writer of the exchange area is the next item's epilogue, eight chunk barriers away: no barrier needed here.
     if constexpr (FUSE) __syncthreads();
@@ -392,8 +399,6 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     read_d(0);
   }
 
-  const bool tracing = (ABL & 256) && blockIdx.x == 0 && tid == 0;
-  auto mark = [&](int item, int ch, int slot) { if constexpr ((ABL & 256) != 0) { if (tracing && item < 4) g_wino_trace[item][ch][slot] = clock64(); } };
 
   // ---- walk: items x chunks; g counts chunks across items (ring position) ---------------------------------------------------
   int g = 0;
@@ -459,6 +464,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
 #pragma unroll 1
     for (int ch = 1; ch < NCH; ++ch) chunk(IC<0>{}, item, ch);
     mark(item, 0, 4);
+    trace_item = item;
     if constexpr (!(ABL & 32)) epilogue(cur);
     mark(item, 0, 5);
     cur = nxt; dcur = dnxt; ucur = unxt;
@@ -522,7 +528,9 @@ hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const C
               fprintf(stderr, "item %d chunk %d: 3 k-steps+transform %5lld | vmcnt wait %5lld | barrier %5lld | to next chunk start %5lld\n", it, c,
                       tr[it][c][1] - tr[it][c][0], tr[it][c][2] - tr[it][c][1], tr[it][c][3] - tr[it][c][2],
                       (c < 7 ? tr[it][c + 1][0] : tr[it][0][4]) - tr[it][c][3]);
-            fprintf(stderr, "item %d epilogue %5lld, item period %5lld\n", it, tr[it][0][5] - tr[it][0][4], tr[it + 1][0][0] - tr[it][0][0]);
+            fprintf(stderr, "item %d epilogue %5lld (s-transform + exchange writes %5lld | barrier %5lld | finish + stores %5lld), item period %5lld\n", it,
+                    tr[it][0][5] - tr[it][0][4], tr[it][8][1] - tr[it][8][0], tr[it][8][2] - tr[it][8][1], tr[it][8][3] - tr[it][8][2],
+                    tr[it + 1][0][0] - tr[it][0][0]);
           }
         }
         return hipGetLastError();
