@@ -213,84 +213,94 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     const int obase = ((POOL ? T.by * 4 * Wo + T.bx * 8 : T.by * 8 * Wo + T.bx * 16)) * cs4 + n32 * 128;
     if constexpr (FUSE) { store_frame(); __syncthreads(); }   // the next item's frame bytes; every wave is through with the patch before the exchange overwrites it
     mark(trace_item, 8, 0);
-    f32x4 sk[4];           // kept tiles (registers r = 4I .. 4I+3): (s_nt0_b0, s_nt0_b1, s_nt1_b0, s_nt1_b1) of row I
+    // Everything below works on PAIRS of tiles (accumulator registers r, r + 1: neighbours in x) as the halves of v_pk_add_f32 -- the
+    // epilogue runs while this wave has no MFMAs in flight, so every VALU instruction saved is time.  The compiler scalarises
+    // <2 x float> subtractions, hence the instruction is asked for by name.  Same additions in the same order as one tile at a time.
+    auto padd = [](f32x2 x, f32x2 y) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
+    auto psub = [](f32x2 x, f32x2 y) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y)); return d; };
+    // kept pairs: sk[p * 2 + nt] = (s_b0(r), s_b0(r+1), s_b1(r), s_b1(r+1)) of row I for the tile pair r = 4I + 2p and channel half nt
+    f32x4 sk[4];
     f32x4* xw = reinterpret_cast<f32x4*>(xch) + (I * 12) * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      f32x4 sv;
+    for (int rp = 0; rp < 8; ++rp) {
+      const int r = 2 * rp, o = rp >> 1, p = rp & 1;        // o: the wave that finishes these two tiles
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        const float m0 = acc[nt * 4 + 0][r], m1 = acc[nt * 4 + 1][r], m2 = acc[nt * 4 + 2][r], m3 = acc[nt * 4 + 3][r];
-        sv[nt * 2 + 0] = (m0 + m1) + m2;
-        sv[nt * 2 + 1] = (m1 - m2) - m3;
+        const f32x2 m0 = {acc[nt * 4 + 0][r], acc[nt * 4 + 0][r + 1]}, m1 = {acc[nt * 4 + 1][r], acc[nt * 4 + 1][r + 1]};
+        const f32x2 m2 = {acc[nt * 4 + 2][r], acc[nt * 4 + 2][r + 1]}, m3 = {acc[nt * 4 + 3][r], acc[nt * 4 + 3][r + 1]};
+        const f32x2 b0 = padd(padd(m0, m1), m2), b1 = psub(psub(m1, m2), m3);
+        const f32x4 q = {b0[0], b0[1], b1[0], b1[1]};
+        if (o == I) sk[p * 2 + nt] = q; else xw[((o < I ? o : o - 1) * 4 + p * 2 + nt) * 64] = q;
       }
-      const int o = r >> 2;                               // the wave that finishes this tile
-      if (o == I) sk[r & 3] = sv; else xw[((o < I ? o : o - 1) * 4 + (r & 3)) * 64] = sv;
     }
     mark(trace_item, 8, 1);
     __syncthreads();
     mark(trace_item, 8, 2);
-    auto finish_tile = [&](auto k_c) {
-      constexpr int k = decltype(k_c)::value;
-      constexpr int r = 4 * I + k;
-      f32x4 srow[4];       // rows 0..3 of s for this tile: (nt0 b0, nt0 b1, nt1 b0, nt1 b1)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        if (w == I) srow[w] = sk[k];
-        else srow[w] = (reinterpret_cast<const f32x4*>(xch) + (w * 12 + (I < w ? I : I - 1) * 4 + k) * 64)[lane];
-      }
+    // bias, ReLU, pool and the stores of one tile (register r) and channel half nt; y[pp][b] = output pixel (2 ty + pp, 2 tx + b)
+    auto emit_tile = [&](auto r_c, int nt, float (&y)[2][2]) {
+      constexpr int r = decltype(r_c)::value;
       constexpr int par = ((r >> 2) ^ (r >> 3)) & 1;
       const int txr = 4 * ((r >> 2) & 1) + (r & 3);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        float y[2][2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const float s0 = srow[0][nt * 2 + b], s1 = srow[1][nt * 2 + b], s2 = srow[2][nt * 2 + b], s3 = srow[3][nt * 2 + b];
-          y[0][b] = (s0 + s1) + s2;
-          y[1][b] = (s1 - s2) - s3;
-        }
-        const float bias = nt ? bias1 : bias0;
+      if constexpr (RELU) {
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            float v = y[pp][b] + bias;
-            if (RELU) v = v > 0.f ? v : 0.f;
-            y[pp][b] = v;
-          }
-        if (full) {
-          // interior item: uniform byte offset (SALU) + one of two per-lane offsets (channel, and the tile row this lane half holds)
-          const int vo = par ? vo1 : vo0;
-          if constexpr (POOL) {
-            const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
-            buf_store_f32(v, orsrc, vo, obase + ((2 * (r >> 3)) * (aW >> 1) + txr) * cs4 + nt * 128);
-          } else {
-#pragma unroll
-            for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-              for (int b = 0; b < 2; ++b)
-                buf_store_f32(y[pp][b], orsrc, vo, obase + ((4 * (r >> 3) + pp) * aW + 2 * txr + b) * cs4 + nt * 128);
-          }
+          for (int b = 0; b < 2; ++b) y[pp][b] = y[pp][b] > 0.f ? y[pp][b] : 0.f;
+      }
+      if (full) {
+        // interior item: uniform byte offset (SALU) + one of two per-lane offsets (channel, and the tile row this lane half holds)
+        const int vo = par ? vo1 : vo0;
+        if constexpr (POOL) {
+          const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+          buf_store_f32(v, orsrc, vo, obase + ((2 * (r >> 3)) * (aW >> 1) + txr) * cs4 + nt * 128);
         } else {
-          const int co = co0 + nt * 32;
-          const bool cok = co < a.cout_real && !(ABL & 4);
-          const int tyr = 2 * (r >> 3) + (par ^ hh);
-          const int oy = T.by * 8 + 2 * tyr, ox = T.bx * 16 + 2 * txr;
-          if constexpr (POOL) {
-            const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
-            if (cok && oy + 1 < aH && ox + 1 < aW) out[((size_t)(oy >> 1) * (aW >> 1) + (ox >> 1)) * cs + co] = v;
-          } else {
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp)
+          for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-              for (int b = 0; b < 2; ++b)
-                if (cok && oy + pp < aH && ox + b < aW) out[((size_t)(oy + pp) * aW + ox + b) * cs + co] = y[pp][b];
-          }
+            for (int b = 0; b < 2; ++b)
+              buf_store_f32(y[pp][b], orsrc, vo, obase + ((4 * (r >> 3) + pp) * aW + 2 * txr + b) * cs4 + nt * 128);
+        }
+      } else {
+        const int co = co0 + nt * 32;
+        const bool cok = co < a.cout_real && !(ABL & 4);
+        const int tyr = 2 * (r >> 3) + (par ^ hh);
+        const int oy = T.by * 8 + 2 * tyr, ox = T.bx * 16 + 2 * txr;
+        if constexpr (POOL) {
+          const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+          if (cok && oy + 1 < aH && ox + 1 < aW) out[((size_t)(oy >> 1) * (aW >> 1) + (ox >> 1)) * cs + co] = v;
+        } else {
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              if (cok && oy + pp < aH && ox + b < aW) out[((size_t)(oy + pp) * aW + ox + b) * cs + co] = y[pp][b];
         }
       }
     };
-    finish_tile(IC<0>{}); finish_tile(IC<1>{}); finish_tile(IC<2>{}); finish_tile(IC<3>{});
+    auto finish_pair = [&](auto p_c) {
+      constexpr int p = decltype(p_c)::value;
+      constexpr int r = 4 * I + 2 * p;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x2 lo[4], hi[4];      // rows 0..3 of s: lo = (b0(r), b0(r+1)), hi = (b1(r), b1(r+1))
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          f32x4 sv;
+          if (w == I) sv = sk[p * 2 + nt];
+          else sv = (reinterpret_cast<const f32x4*>(xch) + (w * 12 + (I < w ? I : I - 1) * 4 + p * 2 + nt) * 64)[lane];
+          lo[w] = f32x2{sv[0], sv[1]}; hi[w] = f32x2{sv[2], sv[3]};
+        }
+        const float bias = nt ? bias1 : bias0;
+        const f32x2 bb = {bias, bias};
+        // y[pp][b] of tile r in element 0, of tile r + 1 in element 1
+        const f32x2 y00 = padd(padd(padd(lo[0], lo[1]), lo[2]), bb), y01 = padd(padd(padd(hi[0], hi[1]), hi[2]), bb);
+        const f32x2 y10 = padd(psub(psub(lo[1], lo[2]), lo[3]), bb), y11 = padd(psub(psub(hi[1], hi[2]), hi[3]), bb);
+        float ya[2][2] = {{y00[0], y01[0]}, {y10[0], y11[0]}}, yb[2][2] = {{y00[1], y01[1]}, {y10[1], y11[1]}};
+        emit_tile(IC<r>{}, nt, ya);
+        emit_tile(IC<r + 1>{}, nt, yb);
+      }
+    };
+    finish_pair(IC<0>{}); finish_pair(IC<1>{});
     mark(trace_item, 8, 3);
     // FUSE: the next item's staging overwrites the patch = the exchange area, so every wave must be through with it.  Otherwise the
     // next writer of the exchange area is the next item's epilogue, eight chunk barriers away: no barrier needed here.
