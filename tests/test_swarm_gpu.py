@@ -91,3 +91,11 @@ def test_pack_blocks_and_gate_kernels():
     assert np.array_equal(pas.cpu().numpy(), exp_pass) and int(gn.item()) == exp_pass.sum()
     assert np.array_equal(cnt.cpu().numpy(), np.where(exp_pass == 1, 9, 0))
     fe.close()
+
+
+def test_rccl_single_rank_collectives():
+    """The nccl (= RCCL) calls of bench.py's --gpus N path -- init with device_id, the exchange all-gather on a side stream, barrier,
+    all-reduce MAX -- on the one GPU this box has (the world-2 tests above run the same path over gloo)."""
+    env = dict(os.environ); env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_rccl_1rank.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL 1-rank OK" in r.stdout, (r.stdout + r.stderr)[-2000:]
