@@ -115,47 +115,69 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
   for (int k = 0; k < 4; ++k) { top[k].d = __builtin_inff(); top[k].i = 0x7FFFFFFF; }
 
   const int nkc = (dim + KCH - 1) / KCH;
-  for (int t0 = 0; t0 < nt; t0 += TB) {
-    f32x16 acc;
+  // train chunks (TB rows x KCH columns) go global -> registers -> LDS; the loads of chunk c + 1 are in flight during the norms and the
+  // MFMAs of chunk c (the kernel is latency-bound: staged synchronously, every chunk exposed one L2 round trip)
+  constexpr int NLD = TB * (KCH / 4) / 256;
+  static_assert(TB * (KCH / 4) % 256 == 0, "staging assumes whole passes");
+  f32x4 stg[NLD];
+  auto gload = [&](int c) {
+    const int t0 = (c / nkc) * TB, kc = c % nkc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float tnorm = 0.f;
-    for (int kc = 0; kc < nkc; ++kc) {
-      __syncthreads();
-      for (int i = tid; i < TB * (KCH / 4); i += 256) {
-        const int r = i / (KCH / 4), c4 = i % (KCH / 4);
-        const int col = kc * KCH + c4 * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (t0 + r < nt && col < dim) v = *reinterpret_cast<const f32x4*>(T + (size_t)(t0 + r) * dim + col);
-        float* d = Ts + r * TS + c4 * 4;
-        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-      }
-      __syncthreads();
-      {   // |t|^2 of the staged chunk, 2 threads per row
-        const int r = tid >> 1, part = tid & 1;
-        float s = 0.f;
-        for (int k = part; k < KCH; k += 2) s = __builtin_fmaf(Ts[r * TS + k], Ts[r * TS + k], s);
-        s += __shfl_xor(s, 1, 64);
-        tnorm += s;
-      }
-      // A = train rows of this wave (row = lane&31), B = queries (col = lane&31); k = 2*step + (lane>>5)
-      const float* ap = Ts + (wave * 32 + (lane & 31)) * TS + (lane >> 5);
-      const float* bp = Qs + (lane & 31) * QS + kc * KCH + (lane >> 5);
-#pragma unroll 8
-      for (int ks = 0; ks < KCH / 2; ++ks)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
+    for (int u = 0; u < NLD; ++u) {
+      const int i = tid + 256 * u;
+      const int r = i / (KCH / 4), c4 = i % (KCH / 4);
+      const int col = kc * KCH + c4 * 4;
+      stg[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t0 + r < nt && col < dim) stg[u] = *reinterpret_cast<const f32x4*>(T + (size_t)(t0 + r) * dim + col);
     }
-    if ((tid & 1) == 0) tn[tid >> 1] = tnorm;
-    __syncthreads();
-    // acc[r]: train row i = (r&3) + 8*(r>>2) + 4*(lane>>5) of this wave's 32, query j = lane&31
-    const float qq = qn[lane & 31];
+  };
+  const int nchunks = ((nt + TB - 1) / TB) * nkc;
+  if (nchunks > 0) gload(0);
+  f32x16 acc;
+  float tnorm = 0.f;
+  for (int c = 0; c < nchunks; ++c) {
+    const int t0 = (c / nkc) * TB, kc = c % nkc;
+    if (kc == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int li = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int gi = t0 + li;
-      if (gi < nt) {
-        const float d2 = (tn[li] + qq) - 2.0f * acc[r];
-        cand_insert(top, d2, gi);
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      tnorm = 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int i = tid + 256 * u;
+      const int r = i / (KCH / 4), c4 = i % (KCH / 4);
+      float* d = Ts + r * TS + c4 * 4;
+      d[0] = stg[u][0]; d[1] = stg[u][1]; d[2] = stg[u][2]; d[3] = stg[u][3];
+    }
+    __syncthreads();
+    if (c + 1 < nchunks) gload(c + 1);
+    {   // |t|^2 of the staged chunk, 2 threads per row
+      const int r = tid >> 1, part = tid & 1;
+      float s = 0.f;
+      for (int k = part; k < KCH; k += 2) s = __builtin_fmaf(Ts[r * TS + k], Ts[r * TS + k], s);
+      s += __shfl_xor(s, 1, 64);
+      tnorm += s;
+    }
+    // A = train rows of this wave (row = lane&31), B = queries (col = lane&31); k = 2*step + (lane>>5)
+    const float* ap = Ts + (wave * 32 + (lane & 31)) * TS + (lane >> 5);
+    const float* bp = Qs + (lane & 31) * QS + kc * KCH + (lane >> 5);
+#pragma unroll 8
+    for (int ks = 0; ks < KCH / 2; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
+    if (kc == nkc - 1) {
+      if ((tid & 1) == 0) tn[tid >> 1] = tnorm;
+      __syncthreads();
+      // acc[r]: train row i = (r&3) + 8*(r>>2) + 4*(lane>>5) of this wave's 32, query j = lane&31
+      const float qq = qn[lane & 31];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int li = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int gi = t0 + li;
+        if (gi < nt) {
+          const float d2 = (tn[li] + qq) - 2.0f * acc[r];
+          cand_insert(top, d2, gi);
+        }
       }
     }
   }
@@ -189,14 +211,53 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
     for (int k = 0; k < 4; ++k) mcand[lane * 4 + k] = top[k].i == 0x7FFFFFFF ? -1 : top[k].i;
   }
   __syncthreads();
-  // exact re-rank: every (query, candidate) distance re-evaluated in the oracle's order, 16 lanes per pair
-  for (int r = 0; r < (MQ * 4 * 16) / 256; ++r) {
-    const int pr = r * 16 + (tid >> 4);
-    const int q = pr >> 2;
-    const int ci = mcand[pr];
-    const float* trow = T + (size_t)(ci >= 0 ? ci : 0) * dim;
-    const float dd = exact_dist16(Qs + q * QS, trow, dim, tid & 15, lane);
-    if ((tid & 15) == 0) mdist[pr] = ci >= 0 ? dd : __builtin_inff();
+  // exact re-rank: every (query, candidate) distance re-evaluated in the oracle's order, 16 lanes per pair.  A 16-lane group owns 8 of
+  // the 128 (query, candidate) pairs; for dim = 256 the train-row elements of FOUR pairs (4 x 16 loads per lane) are requested before
+  // the first is used, so the loop costs two L2 round trips instead of sixteen (this kernel is latency-bound: ~60 cycles per instruction)
+  if (dim == 256) {
+    const int slot = tid & 15;
+#pragma unroll 1
+    for (int r0 = 0; r0 < (MQ * 4 * 16) / 256; r0 += 4) {
+      float tv[4][16];
+      int cis[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pr = (r0 + u) * 16 + (tid >> 4);
+        cis[u] = mcand[pr];
+        const float* trow = T + (size_t)(cis[u] >= 0 ? cis[u] : 0) * 256 + slot;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tv[u][i] = trow[16 * i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pr = (r0 + u) * 16 + (tid >> 4);
+        const float* q = Qs + (pr >> 2) * QS + slot;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {              // ascending j = slot + 16 i: the oracle's order within an accumulator lane
+          const float d = q[16 * i] - tv[u][i];
+          const float dd = d * d;
+          acc = acc + dd;
+        }
+        const int base = lane & ~15, l = slot & 3;
+        const float a0 = __shfl(acc, base + 0 + l, 64), a1 = __shfl(acc, base + 4 + l, 64);
+        const float a2 = __shfl(acc, base + 8 + l, 64), a3 = __shfl(acc, base + 12 + l, 64);
+        const float rr = ((a0 + a1) + a2) + a3;
+        const float r0v = __shfl(rr, base + 0, 64), r1v = __shfl(rr, base + 1, 64);
+        const float r2v = __shfl(rr, base + 2, 64), r3v = __shfl(rr, base + 3, 64);
+        const float dd = __builtin_sqrtf((r0v + r2v) + (r1v + r3v));
+        if (slot == 0) mdist[pr] = cis[u] >= 0 ? dd : __builtin_inff();
+      }
+    }
+  } else {
+    for (int r = 0; r < (MQ * 4 * 16) / 256; ++r) {
+      const int pr = r * 16 + (tid >> 4);
+      const int q = pr >> 2;
+      const int ci = mcand[pr];
+      const float* trow = T + (size_t)(ci >= 0 ? ci : 0) * dim;
+      const float dd = exact_dist16(Qs + q * QS, trow, dim, tid & 15, lane);
+      if ((tid & 15) == 0) mdist[pr] = ci >= 0 ? dd : __builtin_inff();
+    }
   }
   __syncthreads();
   if (tid < MQ && q0 + tid < nq) {
