@@ -83,6 +83,8 @@ __device__ __forceinline__ void buf_load_lds16(__amdgpu_buffer_rsrc_t r, float* 
 
 // ABL 256: workgroup 0 / wave 0 records shader-clock marks (s_memtime) for its first 4 items
 __device__ long long g_wino_trace[4][16][6];
+__device__ long long g_wino_pair[2][64][3];       // ABL 256: the two workgroups of ONE CU: [wave slot parity][item][K start, epilogue start, epilogue end]
+__device__ unsigned g_wino_hw[1024][2];      // ABL 256: HW_ID / XCC_ID of wave 0 of every workgroup (which two share a CU?)
 
 // Tile <-> MFMA row.  Row t (= lane & 31 of the A operand, = (r&3) + 8*(r>>2) + 4*(lane>>5) of an accumulator register r)
 // holds tile  ty = 2*(q>>2) + parity(q),  tx = 4*((q>>1)&1) + (t&3),  q = t>>2.  ds_read_b128 serves a wave in the lane groups
@@ -184,7 +186,23 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   };
 
   const bool tracing = (ABL & 256) && blockIdx.x == 0 && tid == 0;
-  auto mark = [&](int item, int ch, int slot) { if constexpr ((ABL & 256) != 0) { if (tracing && item < 4) g_wino_trace[item][ch][slot] = clock64(); } };
+  int pair_slot = -1;       // ABL 256: this workgroup sits on (xcc 0, se 0, sh 0, cu 0): record its item timeline beside its CU partner's
+  if constexpr ((ABL & 256) != 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (tid == 0 && (hwid & 0xff00) == 0 && (xcc & 15) == 0) pair_slot = hwid & 1;
+  }
+  auto mark = [&](int item, int ch, int slot) {
+    if constexpr ((ABL & 256) != 0) {
+      if (tracing && item < 4) g_wino_trace[item][ch][slot] = clock64();
+      if (pair_slot >= 0 && item < 64) {
+        if (ch == 0 && slot == 0) g_wino_pair[pair_slot][item][0] = clock64();
+        if (ch == 0 && slot == 4) g_wino_pair[pair_slot][item][1] = clock64();
+        if (ch == 0 && slot == 5) g_wino_pair[pair_slot][item][2] = clock64();
+      }
+    }
+  };
   int trace_item = 0;
   // FUSE: the frame bytes of the next item (see the staging below)
   unsigned char* u8p = reinterpret_cast<unsigned char*>(wlds + 8 * CHF);     // [12][20] bytes behind the patch
@@ -490,6 +508,14 @@ template <int CIN, bool POOL, bool RELU, int ABL = 0, int TAG = 0, bool FUSE = f
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a, int nbx, int nby, int ncb, int total) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   if ((int)blockIdx.x >= total) return;
+  if constexpr ((ABL & 256) != 0) {
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+      unsigned hwid, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_wino_hw[blockIdx.x][0] = hwid; g_wino_hw[blockIdx.x][1] = xcc;
+    }
+  }
   // the four rows of the transform domain run different (compile-time) row arithmetic; the branch is wave-uniform
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
     case 0: wino_body<CIN, POOL, RELU, ABL, 0, FUSE>(a, nbx, nby, ncb, total, wlds); break;
@@ -532,6 +558,28 @@ hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const C
         D2FE_WINO_K((conv_wino_kernel<64, false, true, 256>));
         static int dumped = 0;
         long long tr[4][16][6];
+        static unsigned hw[1024][2];
+        if (!dumped && hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_wino_hw), sizeof(hw)) == hipSuccess) {
+          for (int b = 0; b < grid && b < 1024; b += (b < 8 || (b >= 256 && b < 264)) ? 1 : 37)
+            fprintf(stderr, "wg %4d: hw_id %08x wave_id %u simd %u cu %u sh %u se %u | xcc_id %08x\n", b, hw[b][0], hw[b][0] & 15, (hw[b][0] >> 4) & 3,
+                    (hw[b][0] >> 8) & 15, (hw[b][0] >> 12) & 1, (hw[b][0] >> 13) & 7, hw[b][1]);
+          // how many workgroups share (xcc, se, sh, cu), and do partners differ in wave_id parity?
+          int pairs = 0, parity_ok = 0, half_ok = 0;
+          for (int b = 0; b < grid && b < 1024; ++b)
+            for (int c = b + 1; c < grid && c < 1024; ++c)
+              if ((hw[b][0] & 0xff00) == (hw[c][0] & 0xff00) && (hw[b][1] & 15) == (hw[c][1] & 15)) {
+                ++pairs; parity_ok += ((hw[b][0] ^ hw[c][0]) & 1); half_ok += (b < grid / 2) != (c < grid / 2);
+              }
+          fprintf(stderr, "co-resident workgroup pairs: %d; wave_id parity differs in %d; in different halves of the grid in %d\n", pairs, parity_ok, half_ok);
+        }
+        static long long pr[2][64][3];
+        if (!dumped && hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_wino_pair), sizeof(pr)) == hipSuccess) {
+          const long long base = pr[0][0][0] < pr[1][0][0] ? pr[0][0][0] : pr[1][0][0];
+          for (int it = 20; it < 28; ++it)
+            fprintf(stderr, "CU (0,0,0,0) item %2d: wg A  K %8lld  epilogue %8lld..%8lld | wg B  K %8lld  epilogue %8lld..%8lld | B.epi - A.epi = %6lld\n", it,
+                    pr[0][it][0] - base, pr[0][it][1] - base, pr[0][it][2] - base, pr[1][it][0] - base, pr[1][it][1] - base, pr[1][it][2] - base,
+                    pr[1][it][1] - pr[0][it][1]);
+        }
         if (!dumped++ && hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_wino_trace), sizeof(tr)) == hipSuccess) {
           for (int it = 0; it < 3; ++it) {
             for (int c = 0; c < 8; ++c)
