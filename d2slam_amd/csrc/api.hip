@@ -78,6 +78,8 @@ struct d2fe_context {
   const uint8_t* last_gray = nullptr; int last_stride = 0; size_t last_istride = 0;
   float* aconf = nullptr; int* clist = nullptr; int* a_ncand = nullptr;     // variant A scratch
   float* zeros = nullptr;      // 1 KiB of zeros (ConvArgs::zeros)
+  int* work_ctrs = nullptr;    // one work-item counter per Winograd layer, zeroed at the start of every network pass (ConvArgs::work_ctr)
+  bool wino_dynamic = true;    // D2FE_WINO_DYNAMIC=0: static round-robin split of the work items
   // sparse descriptor head (variant B unless cfg.dense_descriptors): cell flags, cell -> slot map, slot -> cell list, counts, descriptors
   bool sparse_desc = false; int sp_slots = 0; int sp_min_batch = 4;
   uint8_t* sp_flags = nullptr; int32_t* sp_slotmap = nullptr; int32_t* sp_cells = nullptr; int32_t* sp_count = nullptr; float* sp_desc = nullptr;
@@ -224,6 +226,7 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
   Tensor& draw = bs ? h->draw2 : h->draw;
   h->last_set = bs;
   const int prec = h->cfg.precision;
+  if (prec == D2FE_PREC_F32_WINO && h->wino_dynamic) HIP_TRY(hipMemsetAsync(h->work_ctrs, 0, 64 * sizeof(int), s));
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8;
   auto conv = [&](ConvShape shape, const Layer& L, const float* in, int ics, int ico, long iis, float* out, int ocs,
                   long ois, int hh, int ww, bool pool, bool relu) -> hipError_t {
@@ -234,6 +237,7 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     a.img = d_gray; a.img_stride = stride; a.img_istride = (long)image_stride; a.w1a = h->w1a; a.b1a = h->b1a;
     a.H = hh; a.W = ww; a.n_img = n; a.in_img_stride = iis; a.out_img_stride = ois; a.zeros = h->zeros;
     a.tag = (&L == &h->L[L_1B]) ? 1 : 0;
+    a.work_ctr = (prec == D2FE_PREC_F32_WINO && h->wino_dynamic) ? h->work_ctrs + (int)(&L - &h->L[0]) : nullptr;
     { static int ab = -1; if (ab < 0) { const char* e = getenv("D2FE_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
     if (prec == D2FE_PREC_F32_WINO)   // 3x3 layers: Winograd kernels; the 1x1 heads: the exact fp32 kernels
       return shape == CONV1B_FUSED ? launch_conv_wino_fused1b(L.cout_pad, a, s)
@@ -419,6 +423,9 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     }
     HIP_TRY(hipMalloc(&h->zeros, 1024));
     HIP_TRY(hipMemset(h->zeros, 0, 1024));
+    HIP_TRY(hipMalloc(&h->work_ctrs, 64 * sizeof(int)));
+    HIP_TRY(hipMemset(h->work_ctrs, 0, 64 * sizeof(int)));
+    { const char* e = getenv("D2FE_WINO_DYNAMIC"); if (e) h->wino_dynamic = atoi(e) != 0; }
     if (cfg->postproc == D2FE_POSTPROC_A) {
       HIP_TRY(hipMalloc(&h->aconf, sizeof(float) * H * W * B));
       HIP_TRY(hipMalloc(&h->clist, sizeof(int) * H * W * B));
@@ -455,7 +462,7 @@ void d2fe_destroy(d2fe_handle h) {
     if (t->p) hipFree(t->p);
   for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
   for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->cand_count, (void*)h->s_img, (void*)h->s_kps,
-                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc,
+                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->work_ctrs, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc,
                   (void*)h->pca_comp_t, (void*)h->pca_mean})
     if (p) hipFree(p);
   nv_free(h);

@@ -31,8 +31,8 @@
 //
 // Data movement.  Persistent workgroups walk a list of work items; the K loop runs over chunks of 8 input channels.  A chunk of
 // the 10 x 18 input patch is brought in by LDS-DMA (buffer_load_dwordx4 ... lds: 16 bytes = 4 channels of one pixel per lane,
-// no VGPR round trip; out-of-image pixels are out-of-range buffer offsets, which read as 0) into a ring of four 8 KiB
-// buffers that runs on across work items (with the 48 KiB exchange area: 80 KiB, exactly two workgroups per CU; three buffers measure the same within 0.2 %).  LDS layout of a chunk: [channel quad 2][pixel parity plane 4][5 rows x 12 (9 used)]
+// no VGPR round trip; out-of-image pixels are out-of-range buffer offsets, which read as 0) into a ring of three 8 KiB
+// buffers that runs on across work items.  LDS layout of a chunk: [channel quad 2][pixel parity plane 4][5 rows x 12 (9 used)]
 // [4 channels]: the 32 tiles of a wave read the same (dy,dx) of their 4x4 input window from ONE parity plane at positions
 // 12*ty + tx, and the tile -> MFMA-row assignment (below) makes that conflict-free for ds_read_b128's lane groups.  U streams
 // from L2 in MFMA lane order (8 values per lane per k-step, requested three k-steps ahead, running on across work items).
@@ -46,7 +46,7 @@ namespace d2fe {
 
 namespace {
 
-constexpr int WR = 4;                       // ring depth
+constexpr int WR = 3;                       // ring depth (four buffers measure the same and would fill the LDS to the last byte)
 constexpr int WCHUNK = 2 * 4 * 64 * 4;      // floats per chunk buffer (8 KiB): [quad 2][plane 4][64 slots][4 channels]
 constexpr int WROW = 12;                    // plane row stride in positions (9 used)
 constexpr int WXCH = 4 * 12 * 64 * 4;       // floats of the epilogue exchange area: [wave 4][12 float4][64 lanes]
@@ -103,9 +103,14 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int aH = a.H, aW = a.W, in_cs = a.in_cstride;
 
-  const int t0 = blockIdx.x, tstride = gridDim.x;
-  const int n_my = (total - t0 + tstride - 1) / tstride;
-  const int G = n_my * NCH;                  // chunks this workgroup walks through
+  // Work items: a workgroup starts with items blockIdx and blockIdx + gridDim and then either strides on (a.work_ctr == null) or CLAIMS
+  // the next index from a device counter.  Claiming matters: of the two workgroups of a CU the one with the older waves gets ~20 % more
+  // of the matrix pipe (issue arbitration is by age; measured with D2FE_ABLATE=256), so with an equal split it is done early and its
+  // partner runs the tail alone, every MFMA-free phase exposed.
+  const int tstride = gridDim.x;
+  const bool dyn = a.work_ctr != nullptr && total >= 48 * tstride;      // short walks (10-40 items per workgroup) gain nothing from claiming (measured)
+  int icur = blockIdx.x, inxt = icur + tstride;                  // indices >= total: no such item
+  int* claim_slot = reinterpret_cast<int*>(FUSE ? wlds + 8 * (2 * 4 * (FUSE ? 272 : 256)) + 64 : wlds + WR * WCHUNK + WXCH);
 
   // ---- LDS-DMA: wave w copies channel quad (w>>1), parity planes 2(w&1), 2(w&1)+1 (64 slots = one instruction each) ---------
   struct DmaItem { __amdgpu_buffer_rsrc_t rsrc; int off[2]; };
@@ -204,6 +209,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     }
   };
   int trace_item = 0;
+  int inn = 0, inn_claim = 0;            // the item after `nxt`: its index, and thread 0's claim in flight
   // FUSE: the frame bytes of the next item (see the staging below)
   unsigned char* u8p = reinterpret_cast<unsigned char*>(wlds + 8 * CHF);     // [12][20] bytes behind the patch
   const int fr = tid / 20, fc = tid - fr * 20;
@@ -252,7 +258,9 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
       }
     }
     mark(trace_item, 8, 1);
+    if (dyn && tid == 0) *claim_slot = inn_claim;          // the index claimed at the start of this item (one barrier serves both)
     __syncthreads();
+    if (dyn) inn = *claim_slot;
     mark(trace_item, 8, 2);
     // bias, ReLU, pool and the stores of one tile (register r) and channel half nt; y[pp][b] = output pixel (2 ty + pp, 2 tx + b)
     auto emit_tile = [&](auto r_c, int nt, float (&y)[2][2]) {
@@ -405,15 +413,14 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   };
 
   // ---- prologue ---------------------------------------------------------------------------------------------------------------
-  WItem cur = w_decode(t0, nbx, nby, ncb);
-  WItem nxt = n_my > 1 ? w_decode(t0 + tstride, nbx, nby, ncb) : cur;
+  WItem cur = w_decode(icur, nbx, nby, ncb);
+  WItem nxt = inxt < total ? w_decode(inxt, nbx, nby, ncb) : cur;
   DmaItem dcur{}, dnxt{};
   if constexpr (!FUSE) {
     dcur = dma_prepare(cur); dnxt = dma_prepare(nxt);
     // chunk c of the walk belongs to item c / NCH: the DMA cursor is at most WR chunks (< NCH) ahead, i.e. in `cur` or `nxt`
 #pragma unroll
-    for (int c = 0; c < WR; ++c)
-      if (c < G) dma_issue(c < NCH ? dcur : dnxt, c % NCH, c);
+    for (int c = 0; c < WR; ++c) dma_issue(dcur, c, c);      // WR < NCH: all in the first item
   }
   if constexpr (FUSE) { load_frame(cur); store_frame(); __syncthreads(); }
   int ucur = u_ptr(cur), unxt = u_ptr(nxt);
@@ -421,8 +428,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   load_u(1, ucur, 1);
   load_u(2, ucur, 2);
   if constexpr (!FUSE) {
-    if (G > 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // chunk 0 landed (younger: 3 x 2 copies + 6 U loads)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // chunk 0 landed (younger: 2 x 2 copies + 6 U loads)
     __syncthreads();
     read_d(0);
   }
@@ -460,19 +466,20 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
       // the whole patch is in LDS: read the next chunk (after the last one: a harmless re-read of chunk 0)
       read_d((ch + 1) & (NCH - 1));
     } else {
-      if (g + 1 < G) {
-        // chunk g+1 (copied WR-1 iterations ago) must have landed: allowed outstanding are this and the last iteration's 8 U loads
-        // (the latter long consumed) and the copies of chunks g+2 and g+3 -- loads complete in order, so "at most 20 outstanding"
-        // implies chunk g+1 is complete
-        if (g + 3 < G) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      const bool has_next = inxt < total;
+      if (ch + 1 < NCH || has_next) {
+        // chunk g+1 (copied WR-1 iterations ago) must have landed: the loads younger than it are this iteration's 8 U loads
+        // and the 2 copies of chunk g+2 -- loads complete in order, so "at most 10 outstanding" implies it is complete (a claim
+        // in flight in wave 0 only makes the wait stricter)
+        if (ch + 2 < NCH || has_next) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       mark(item, ch, 2);
       if constexpr (!(ABL & 8)) __syncthreads();   // every wave's part of chunk g+1 is in LDS; every wave has read chunk g out of its buffer
       mark(item, ch, 3);
-      if (g + WR < G) {
+      {
         const int c3 = ch + WR;      // chunk g+WR of the walk, relative to the current item
-        if (c3 < NCH) dma_issue(dcur, c3, g % WR); else dma_issue(dnxt, c3 - NCH, g % WR);
+        if (c3 < NCH) dma_issue(dcur, c3, g % WR); else if (has_next) dma_issue(dnxt, c3 - NCH, g % WR);
       }
       if constexpr (!(ABL & 16)) read_d((g + 1) % WR);        // unconditional (a stale buffer after the very last chunk): no phi copies
     }
@@ -481,12 +488,14 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     ++g;
   };
 #pragma unroll 1
-  for (int item = 0; item < n_my; ++item) {
+  for (int item = 0; icur < total; ++item) {
+    inn = inxt + tstride;
+    if (dyn && tid == 0) inn_claim = 2 * tstride + atomicAdd(a.work_ctr, 1);      // in flight during the K loop, published in the epilogue
     if constexpr (FUSE) {
       if (!(a.ablate & 64) || item == 0) stage_fused(cur);     // D2FE_ABLATE=64: timing experiment, the staging runs for the first item only
       __syncthreads();
       read_d(0);
-      if (item + 1 < n_my && !(a.ablate & 64)) load_frame(nxt);     // the next item's frame bytes, in flight during this item's K loop
+      if (inxt < total && !(a.ablate & 64)) load_frame(nxt);     // the next item's frame bytes, in flight during this item's K loop
     }
     chunk(IC<1>{}, item, 0);       // the first k-step multiplies into C = 0: no accumulator clearing
 #pragma unroll 1
@@ -496,8 +505,9 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     if constexpr (!(ABL & 32)) epilogue(cur);
     mark(item, 0, 5);
     cur = nxt; dcur = dnxt; ucur = unxt;
-    if (item + 2 < n_my) {
-      nxt = w_decode(t0 + (item + 2) * tstride, nbx, nby, ncb);
+    icur = inxt; inxt = inn;
+    if (inxt < total) {
+      nxt = w_decode(inxt, nbx, nby, ncb);
       if constexpr (!FUSE) dnxt = dma_prepare(nxt);
       unxt = u_ptr(nxt);
     }
@@ -539,7 +549,7 @@ hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const C
     ncu = p.multiProcessorCount;
   }
   const int grid = total < 2 * ncu ? total : 2 * ncu;      // two workgroups per CU (2 waves per SIMD)
-  constexpr size_t lds = (size_t)(WR * WCHUNK + WXCH) * sizeof(float);
+  constexpr size_t lds = (size_t)(WR * WCHUNK + WXCH) * sizeof(float) + 16;      // ring + exchange area + the claim slot
 #define D2FE_WINO_K(K)                                                                                       \
   do {                                                                                                      \
     auto k = K;                                                                                             \
@@ -618,7 +628,7 @@ hipError_t launch_conv_wino_fused1b(int cout_pad, const ConvArgs& a, hipStream_t
     ncu = p.multiProcessorCount;
   }
   const int grid = total < 2 * ncu ? total : 2 * ncu;
-  constexpr size_t lds = (size_t)8 * 2 * 4 * 272 * sizeof(float) + 256;      // the 64-channel patch (the exchange area, 48 KiB, reuses it) + the 12 x 20 frame bytes
+  constexpr size_t lds = (size_t)8 * 2 * 4 * 272 * sizeof(float) + 256 + 16;      // the 64-channel patch (the exchange area, 48 KiB, reuses it) + the 12 x 20 frame bytes
   static_assert(lds >= (size_t)WXCH * sizeof(float), "exchange area must fit into the patch buffer");
   auto k = conv_wino_kernel<64, true, true, 0, 1, true>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

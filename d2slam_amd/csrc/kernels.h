@@ -22,6 +22,7 @@ struct ConvArgs {
   const float* zeros;       // >= 256 zero floats in HBM (source of the LDS-DMA copies of out-of-image patch pixels)
   int tag;                  // 1: conv1b (the dominant launch gets its own kernel instantiation so that rocprofv3 --stats lists it by itself)
   int ablate;               // experiment knob (D2FE_ABLATE): 1 skip patch loads, 2 skip B reloads, 4 skip stores
+  int* work_ctr = nullptr;  // Winograd kernels: zeroed device counter -> work items are claimed dynamically (null: static round-robin split)
 };
 
 enum ConvShape {
