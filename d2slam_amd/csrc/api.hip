@@ -239,6 +239,11 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     a.tag = (&L == &h->L[L_1B]) ? 1 : 0;
     a.work_ctr = (prec == D2FE_PREC_F32_WINO && h->wino_dynamic) ? h->work_ctrs + (int)(&L - &h->L[0]) : nullptr;
     { static int ab = -1; if (ab < 0) { const char* e = getenv("D2FE_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
+    if (prec != D2FE_PREC_F16X2 && shape == CONV_256_1x1_T4x16 && L.cout == 65 && !pool && !relu) {      // convPb
+      static int on = -1;
+      if (on < 0) { const char* e = getenv("D2FE_CONV1X1"); on = e ? atoi(e) : 1; }
+      if (on) { const hipError_t e = launch_conv1x1_256_65(a, s); if (e != hipErrorNotSupported) return e; }
+    }
     if (prec == D2FE_PREC_F32_WINO)   // 3x3 layers: Winograd kernels; the 1x1 heads: the exact fp32 kernels
       return shape == CONV1B_FUSED ? launch_conv_wino_fused1b(L.cout_pad, a, s)
              : L.ks == 3 ? launch_conv_wino(L.cin, pool, relu, L.cout_pad, a, s) : launch_conv(shape, D2FE_PREC_F32, pool, relu, L.cout_pad, a, s);

@@ -37,6 +37,10 @@ enum ConvShape {
 hipError_t launch_conv(ConvShape shape, int precision, bool pool, bool relu, int cout_pad, const ConvArgs& a,
                        hipStream_t s);
 
+// convPb (1x1, 256 -> 65) in the fp32 modes: 64 cell channels on the matrix pipe + the dustbin on the vector pipe (conv1x1.hip); same bits as
+// the generic kernels; hipErrorNotSupported when the tensors are not flat pixel lists
+hipError_t launch_conv1x1_256_65(const ConvArgs& a, hipStream_t s);
+
 // persistent producer/consumer kernels (conv_pc.hip); same arithmetic, selected by D2FE_CONV_PC (default 2: every layer but the fused conv1a+conv1b)
 hipError_t launch_conv_pc(ConvShape shape, int precision, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s);
 
