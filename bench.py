@@ -59,6 +59,11 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event breakdown to stderr")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a bare `python bench.py --gpus N`: re-launch this command line as N ranks (one process per GPU) under torch.distributed.run;
+        # rank 0's JSON line passes through on stdout and the exit code is the launcher's
+        raise SystemExit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     from d2slam_amd import api, swarm
@@ -69,13 +74,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or run `python bench.py --gpus %d` bare)"
+                         % (args.gpus, world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     ndev = torch.cuda.device_count()
     backend = os.environ.get("D2FE_BENCH_BACKEND", "nccl")   # "gloo" only to exercise the N>1 code path on a 1-GPU box
-    if local_rank >= ndev and backend != "nccl":
+    if local_rank >= ndev:
+        if backend == "nccl":
+            raise SystemExit("rank %d needs GPU %d but only %d are visible (RCCL does not put two ranks on one device; "
+                             "D2FE_BENCH_BACKEND=gloo exercises the N>1 path on fewer GPUs)" % (rank, local_rank, ndev))
         local_rank = local_rank % ndev      # debug only: several ranks share one GPU under gloo
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -86,11 +94,17 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    rccl = collective_evidence(torch, dist, dev, backend, rank, world) if world > 1 else None
+
     weights = synthetic_superpoint_weights(dustbin_bias=7.5)
     if args.workload == "quadcam":
-        out = run_quadcam(args, torch, api, weights, dev, local_rank, world)
+        out = run_quadcam(args, torch, api, weights, dev, local_rank, world, rank)
         if rank == 0:
+            if rccl:
+                out["rccl"] = rccl
             print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
         return
 
     from d2slam_amd import netvlad as nvm
@@ -328,6 +342,8 @@ def main():
         }
         if primary["gated"]:
             out["netvlad_gate"] = primary["gated"]
+        if rccl:
+            out["rccl"] = rccl
         names = {"configs1": "configs1", "f32": "exact_mode", "f16x2": "fast_mode", "wino": "wino_mode"}
         for k, o in legs.items():
             e = {"value": round(o["value"], 2), "unit": "stereo_frames/s", "ms_per_step": round(o["ms_per_step"], 3), "roofline": o["roofline"]}
@@ -354,6 +370,42 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` from a bare shell: the same command line as N ranks on this node (torch.distributed.run, rendezvous on
+    127.0.0.1 and a free port).  The ranks' stdout/stderr pass through; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def collective_evidence(torch, dist, dev, backend, rank, world):
+    """What the N>1 record needs to prove N ranks on N devices: the backend and world size as the process group reports them, every
+    rank's device identity gathered with all_gather_object, and one all-reduce over the group on the device (sum of ranks)."""
+    p = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "pid": os.getpid(), "device_index": dev.index, "name": p.name,
+            "uuid": str(getattr(p, "uuid", "")), "pci_bus_id": getattr(p, "pci_bus_id", None), "pci_device_id": getattr(p, "pci_device_id", None),
+            "cus": p.multi_processor_count}
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    t = torch.tensor([float(rank)], device=dev)
+    dist.all_reduce(t)
+    ver = None
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        pass
+    ids = {(r["uuid"], r["pci_bus_id"], r["device_index"]) for r in allr}
+    return {"backend": dist.get_backend(), "is_rccl": dist.get_backend() == "nccl", "rccl_version": ver, "world_size": dist.get_world_size(),
+            "allreduce_sum_of_ranks": float(t.item()), "expected_sum": float(world * (world - 1) // 2),
+            "distinct_devices": len(ids), "ranks": allr}
 
 
 def conv1b_roofline(precision, avg_ms, launches, NI, fused):
@@ -386,15 +438,14 @@ def conv1b_roofline(precision, avg_ms, launches, NI, fused):
             "note": "f16x2 executes 3 MFMA FLOPs (hi*hi + hi*lo + lo*hi) per algorithmic FLOP" if precision == "f16x2" else "one MFMA FLOP per algorithmic FLOP"}
 
 
-def run_quadcam(args, torch, api, weights, dev, local_rank, world):
+def run_quadcam(args, torch, api, weights, dev, local_rank, world, rank=0):
     """BASELINE configs[2] on one GPU: quadcam FOURCORNER_FISHEYE, 4 raw 1280x800 frames -> FisheyeUndist (800x400, photometric
     gain) -> SuperPoint (100 keypoints, threshold 0.15: config/quadcam/quadcam_single.yaml:83,117) + NetVLAD on every view ->
     neighbour matching as D2FeatureTracker::matchLocalFeatures does it for quadcam (d2featuretracker.cpp:1144-1182: half-image filter on
     both views, a-side x shifted by +-move_cols, matchKNN with the search radius, index remap) + temporal matchKNN per view."""
-    from d2slam_amd import netvlad as nvm, quadcam
+    import torch.distributed as dist
+    from d2slam_amd import netvlad as nvm, quadcam, swarm
     from d2slam_amd.synth import synth_image
-    if world != 1:
-        raise SystemExit("--workload quadcam is a single-GPU configuration")
     RH, RW, UH, UW, CAPQ = 800, 1280, 400, 800, 100
     Q = max(1, args.frames // 4)          # quad frames per step
     NI = 4 * Q
@@ -406,22 +457,42 @@ def run_quadcam(args, torch, api, weights, dev, local_rank, world):
     main = torch.cuda.Stream(device=dev); torch.cuda.set_stream(main)
     st = main.cuda_stream
     # raw frames camera-major: [c0: q0..q(Q-1) | c1: ... ] so that one undistort launch per camera writes a contiguous slab
-    raw = torch.from_numpy(np.stack([synth_image(RH, RW, 7000 + i) for i in range(NI)])).to(dev)
+    # every agent flies through the same scenes (seed 7000 + i) with its own sensor noise, so that cross-agent matches exist
+    def frame(i):
+        im = synth_image(RH, RW, 7000 + i)
+        if world > 1:
+            rng = np.random.RandomState(977 * rank + i)
+            im = np.clip(im.astype(np.int16) + rng.randint(-2, 3, im.shape), 0, 255).astype(np.uint8)
+        return im
+    raw = torch.from_numpy(np.stack([frame(i) for i in range(NI)])).to(dev)
     maps = [tuple(torch.from_numpy(m).to(dev) for m in quadcam.synthetic_maps(c, RH, RW, UH, UW)) for c in range(4)]
     chain = quadcam.QuadcamChain(fe, torch, dev, Q, UH, UW, CAPQ, undistort_fov=200.0, knn_ratio=0.8, search_local_max_dist=0.2)
+    qs = swarm.QuadSwarm(chain, torch, dev, world, rank, fe.netvlad_dim, NETVLAD_GATE, mode=os.environ.get("D2FE_QUAD_SWARM_MODE", "all2all")) if world > 1 else None
 
     def step():
         chain.step(raw, RH, RW, maps, st)
+        if qs:
+            qs.step(st)        # configs[4]: one block per view, ONE all-gather, the quadcam NetVLAD gate, view x view cross-agent matchKNN
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(dev)
+    barrier()
     fe.profile_enable(1)
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize(dev)
+    barrier()
     el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
     prof = fe.profile_read(); fe.profile_enable(0)
     c1b_ms, c1b_n = prof["conv1b"]
     avg_ms = c1b_ms / max(c1b_n, 1)
@@ -430,12 +501,15 @@ def run_quadcam(args, torch, api, weights, dev, local_rank, world):
     items = NI * (UH // 8) * (UW // 16)
     executed = items * 1084 * 4096.0 if args.precision == "wino" else flop * (3.0 if args.precision == "f16x2" else 1.0)
     ach = executed / (avg_ms * 1e-3) / 1e12 if avg_ms else 0.0
-    out = {"metric": "quad frames/sec undistort+SuperPoint+NetVLAD+match, 4x(1280x800->800x400)", "value": round(Q * args.steps / el, 2),
-           "unit": "quad_frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
+    out = {"metric": "quad frames/sec undistort+SuperPoint+NetVLAD+match, 4x(1280x800->800x400)", "value": round(Q * world * args.steps / el, 2),
+           "unit": "quad_frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision != "f16x2" else "f16x2(hi+lo split)/f32-acc", "data": "synthetic",
-           "config": {"workload": "configs[2]: quadcam FOURCORNER_FISHEYE 1280x800 x4 virtual cams, undistort + SuperPoint + NetVLAD + "
-                                  "neighbour matching (half-image filter, +-move_cols shift, radius gate, index remap) + temporal matchKNN, 1 MI355X",
-                      "quad_frames_per_step": Q, "max_keypoints": CAPQ, "threshold": 0.15, "undistort_fov": 200.0, "search_radius_px": 0.2 * UW,
+           "config": {"workload": ("configs[2]: quadcam FOURCORNER_FISHEYE 1280x800 x4 virtual cams, undistort + SuperPoint + NetVLAD + "
+                                   "neighbour matching (half-image filter, +-move_cols shift, radius gate, index remap) + temporal matchKNN, 1 MI355X") if world == 1 else
+                                  ("configs[4]: %d-agent quadcam swarm, one agent per GPU: the configs[2] chain per agent + one exchange block per view "
+                                   "(4 per quad frame), ONE all-gather, the quadcam NetVLAD gate (getMatchedPrevKeyframe, FOURCORNER_FISHEYE branch) on the "
+                                   "device and view x view cross-agent matchKNN against every remote agent (%s)" % (world, qs.mode)),
+                      "quad_frames_per_step_per_gpu": Q, "max_keypoints": CAPQ, "threshold": 0.15, "undistort_fov": 200.0, "search_radius_px": 0.2 * UW,
                       "precision": args.precision},
            "avg_keypoints_per_image": round(chain.cnt[:NI].float().mean().item(), 1),
            "avg_matches_per_pair": round(chain.mn.float().mean().item(), 1),
@@ -443,6 +517,14 @@ def run_quadcam(args, torch, api, weights, dev, local_rank, world):
                         "frac": round(ach / peak, 4), "frac_executed": round(ach / peak, 4), "frac_algorithmic": round(flop / (avg_ms * 1e-3) / 1e12 / peak, 4) if avg_ms else 0,
                         "traffic": None},
            "cpu_baseline": None}
+    if qs:
+        dp = qs.dir_prev.cpu().numpy()
+        out["cross_agent"] = {"jobs_per_step_per_gpu": qs.njobs, "view_pairs_per_step_per_gpu": qs.NP, "mode": qs.mode,
+                              "avg_matches_per_view_pair": round(qs.mn.float().mean().item(), 2),
+                              "block_bytes": 4 * qs.BLK, "all_gather_bytes_received_per_step": 4 * qs.BLK * NI * (world - 1)}
+        out["netvlad_gate"] = {"jobs": qs.njobs, "passing_netvlad_gate": int(qs.n_pass.item()), "threshold": NETVLAD_GATE,
+                               "rotation_histogram_dir_prev": {str(k): int((dp == k).sum()) for k in (-1, 0, 1, 2, 3)},
+                               "rule": "remote view 2 vs local views 2,3,0,1 in order, first similarity >= threshold (d2featuretracker.cpp:212-233)"}
     fe.close()
     return out
 

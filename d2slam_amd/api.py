@@ -25,6 +25,8 @@ if os.environ.get("D2FE_LIB"):      # developer knob: same-box A/B of two builds
 
 POSTPROC_B, POSTPROC_A = 0, 1
 PREC_F32, PREC_F16X2, PREC_F32_WINO = 0, 1, 2
+ERR_TRUNCATED = -4            # d2fe_status: output capacity too small, n_out holds what was written
+KEEP_ALL_CAP = 1024           # host-pointer staging capacity of a keep-all handle (max_keypoints = -1)
 PROF_STAGES = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPaDa",
                "convPb", "convDb", "softmax_cand", "select", "sample", "match", "netvlad"]
 
@@ -76,8 +78,8 @@ _lib = None
 EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_create", "d2fe_destroy",
            "d2fe_load_superpoint", "d2fe_set_superpoint_pca", "d2fe_desc_dim", "d2fe_superpoint_extract", "d2fe_superpoint_extract_batch",
            "d2fe_superpoint_extract_device", "d2fe_tail_stream", "d2fe_superpoint_wait_tail", "d2fe_load_netvlad", "d2fe_set_netvlad_pca", "d2fe_netvlad_dim",
-           "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device",
-           "d2fe_block_words", "d2fe_block_field_offset", "d2fe_pack_blocks_device", "d2fe_gate_pairs_device",
+           "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device", "d2fe_match_fallback_rows",
+           "d2fe_block_words", "d2fe_block_field_offset", "d2fe_pack_blocks_device", "d2fe_gate_pairs_device", "d2fe_quad_gate_device",
            "d2fe_half_move_cols", "d2fe_half_image_compact_device", "d2fe_remap_matches_device",
            "d2fe_half_image_filter", "d2fe_undistort", "d2fe_undistort_device", "d2fe_db_create", "d2fe_db_destroy",
            "d2fe_db_ntotal", "d2fe_db_add", "d2fe_db_search", "d2fe_db_query_gated", "d2fe_quantize_int8", "d2fe_dequantize_int8",
@@ -143,6 +145,8 @@ def load_library():
         lib.d2fe_destroy.argtypes = [C.c_void_p]
         lib.d2fe_load_superpoint.argtypes = [C.c_void_p, C.c_void_p]
         lib.d2fe_sync.argtypes = [C.c_void_p]
+        lib.d2fe_match_fallback_rows.argtypes = [C.c_void_p, C.c_int]
+        lib.d2fe_match_fallback_rows.restype = C.c_long
         lib.d2fe_tail_stream.argtypes = [C.c_void_p]
         lib.d2fe_tail_stream.restype = C.c_void_p
         lib.d2fe_superpoint_wait_tail.argtypes = [C.c_void_p, C.c_void_p]
@@ -307,12 +311,24 @@ class FrontEnd:
         if images.ndim == 2:
             images = images[None]
         n, H, W = images.shape
-        cap = cap or self.cfg.max_keypoints
+        if not cap:      # keep-all handles (max_keypoints = -1) have no configured cap: the library's staging capacity applies
+            cap = self.cfg.max_keypoints if self.cfg.max_keypoints > 0 else KEEP_ALL_CAP
         kps = np.zeros((n, cap, 2), np.float32); sc = np.zeros((n, cap), np.float32)
         desc = np.zeros((n, cap, self.desc_dim), np.float32); cnt = np.zeros(n, np.int32)
-        _check(self._lib.d2fe_superpoint_extract_batch(self._h, _ptr(images), n, W, H, W, H * W, _ptr(kps), _ptr(sc),
-                                                       _ptr(desc), cap, _ptr(cnt)))
+        rc = self._lib.d2fe_superpoint_extract_batch(self._h, _ptr(images), n, W, H, W, H * W, _ptr(kps), _ptr(sc),
+                                                     _ptr(desc), cap, _ptr(cnt))
+        # D2FE_ERR_TRUNCATED: the strongest `cap` keypoints were written and n_out is valid -- report it, keep the results
+        self.last_truncated = rc == ERR_TRUNCATED
+        if rc != 0 and rc != ERR_TRUNCATED:
+            _check(rc)
         return [(kps[i, :cnt[i]].copy(), sc[i, :cnt[i]].copy(), desc[i, :cnt[i]].copy()) for i in range(n)]
+
+    def match_fallback_rows(self, reset=True):
+        """Queries whose 2-NN came from the matcher's exact fallback scan since the last reset (include/d2fe.h)."""
+        r = int(self._lib.d2fe_match_fallback_rows(self._h, int(bool(reset))))
+        if r < 0:
+            _check(r)
+        return r
 
     def extract_device(self, d_gray, n, W, H, d_kps, d_scores, d_desc, d_idx, cap, d_n, stream=None, stride=None,
                        image_stride=None):
@@ -520,6 +536,15 @@ class FrontEnd:
                                                 C.c_void_p(d_pair_q), C.c_void_p(d_pair_db), int(npairs), C.c_double(thres),
                                                 C.c_void_p(d_cnt_inout or 0), C.c_void_p(d_pass or 0), C.c_void_p(d_sims or 0),
                                                 C.c_void_p(d_n_pass or 0), C.c_void_p(stream or 0)))
+
+    def quad_gate_device(self, d_local, local_stride, d_remote, remote_stride, dim, d_job_local_row0, d_job_remote_row0, local_view_step,
+                         remote_view_step, njobs, thres, d_dir_prev=None, d_sims=None, d_cnt_inout=None, d_n_pass=None, stream=None):
+        """The FOURCORNER_FISHEYE gate of getMatchedPrevKeyframe + the view pairing of trackRemoteFrames (include/d2fe.h)."""
+        V = C.c_void_p
+        _check(self._lib.d2fe_quad_gate_device(self._h, V(d_local), C.c_size_t(local_stride), V(d_remote), C.c_size_t(remote_stride), int(dim),
+                                               V(d_job_local_row0), V(d_job_remote_row0), int(local_view_step), int(remote_view_step),
+                                               int(njobs), C.c_double(thres), V(d_dir_prev or 0), V(d_sims or 0), V(d_cnt_inout or 0),
+                                               V(d_n_pass or 0), V(stream or 0)))
 
     def half_image_compact_device(self, d_desc, d_pts, d_n, d_job_row, d_job_left, d_job_shift, njobs, cap, dim, width_undistort, undistort_fov,
                                   d_out_desc, d_out_pts, d_out_map, d_out_n, stream=None):

@@ -78,6 +78,7 @@ struct d2fe_context {
   const uint8_t* last_gray = nullptr; int last_stride = 0; size_t last_istride = 0;
   float* aconf = nullptr; int* clist = nullptr; int* a_ncand = nullptr;     // variant A scratch
   float* zeros = nullptr;      // 1 KiB of zeros (ConvArgs::zeros)
+  int32_t* match_stats = nullptr;   // [4] matcher counters: [0] queries that took the exact fallback scan (MatchArgs::stats)
   int* work_ctrs = nullptr;    // one work-item counter per Winograd layer, zeroed at the start of every network pass (ConvArgs::work_ctr)
   bool wino_dynamic = true;    // D2FE_WINO_DYNAMIC=0: static round-robin split of the work items
   // sparse descriptor head (variant B unless cfg.dense_descriptors): cell flags, cell -> slot map, slot -> cell list, counts, descriptors
@@ -428,6 +429,8 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     }
     HIP_TRY(hipMalloc(&h->zeros, 1024));
     HIP_TRY(hipMemset(h->zeros, 0, 1024));
+    HIP_TRY(hipMalloc(&h->match_stats, 4 * sizeof(int32_t)));
+    HIP_TRY(hipMemset(h->match_stats, 0, 4 * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&h->work_ctrs, 64 * sizeof(int)));
     HIP_TRY(hipMemset(h->work_ctrs, 0, 64 * sizeof(int)));
     { const char* e = getenv("D2FE_WINO_DYNAMIC"); if (e) h->wino_dynamic = atoi(e) != 0; }
@@ -467,7 +470,7 @@ void d2fe_destroy(d2fe_handle h) {
     if (t->p) hipFree(t->p);
   for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
   for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->cand_count, (void*)h->s_img, (void*)h->s_kps,
-                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->work_ctrs, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc,
+                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->work_ctrs, (void*)h->match_stats, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc,
                   (void*)h->pca_comp_t, (void*)h->pca_mean})
     if (p) hipFree(p);
   nv_free(h);
@@ -1259,10 +1262,23 @@ int d2fe_gate_pairs_device(d2fe_handle h, const float* d_q, size_t q_stride, con
                            const int32_t* d_pair_q, const int32_t* d_pair_db, int npairs, double thres, int32_t* d_cnt_inout,
                            int32_t* d_pass, float* d_sims, int32_t* d_n_pass, void* stream) {
   if (!h || !d_q || !d_db || !d_pair_q || !d_pair_db) return fail(D2FE_ERR_INVALID, "null argument");
-  if (npairs < 1 || dim < 4 || (dim & 3) || (q_stride & 3) || (db_stride & 3)) return fail(D2FE_ERR_INVALID, "dim and strides must be multiples of 4");
+  if (npairs < 1 || dim < 4 || (dim & 3)) return fail(D2FE_ERR_INVALID, "dim must be a multiple of 4");
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   HIP_TRY(launch_gate_pairs(d_q, (long)q_stride, d_db, (long)db_stride, dim, d_pair_q, d_pair_db, npairs, thres, d_cnt_inout, d_pass,
                             d_sims, d_n_pass, stream ? (hipStream_t)stream : h->stream));
+  return D2FE_OK;
+}
+
+int d2fe_quad_gate_device(d2fe_handle h, const float* d_local, size_t local_stride, const float* d_remote, size_t remote_stride, int dim,
+                          const int32_t* d_job_local_row0, const int32_t* d_job_remote_row0, int local_view_step, int remote_view_step,
+                          int njobs, double thres, int32_t* d_dir_prev, float* d_sims, int32_t* d_cnt_inout, int32_t* d_n_pass,
+                          void* stream) {
+  if (!h || !d_local || !d_remote || !d_job_local_row0 || !d_job_remote_row0) return fail(D2FE_ERR_INVALID, "null argument");
+  if (njobs < 1 || dim < 4 || (dim & 3) || local_view_step < 1 || remote_view_step < 1) return fail(D2FE_ERR_INVALID, "bad geometry");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(launch_quad_gate(d_local, (long)local_stride, d_remote, (long)remote_stride, dim, d_job_local_row0, d_job_remote_row0,
+                           local_view_step, remote_view_step, njobs, thres, d_dir_prev, d_sims, d_cnt_inout, d_n_pass,
+                           stream ? (hipStream_t)stream : h->stream));
   return D2FE_OK;
 }
 
@@ -1317,7 +1333,7 @@ int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* str
   m.npairs = mb->npairs; m.dim = mb->dim; m.max_n = mb->max_n; m.mode = mb->mode;
   m.ratio = mb->ratio; m.radius = mb->radius;
   m.q_idx = mb->d_q_idx; m.t_idx = mb->d_t_idx; m.dist = mb->d_dist; m.n_out = mb->d_n_out;
-  m.cand4 = sc->cand4;
+  m.cand4 = sc->cand4; m.stats = h->match_stats;
   { ProfScope ps(h, D2FE_PROF_MATCH, s); HIP_TRY(launch_match(m, s)); }
   return D2FE_OK;
 }
@@ -1381,7 +1397,7 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
   m.a = d_a; m.b = d_b; m.pts_a = use_pts ? d_pa : nullptr; m.pts_b = use_pts ? d_pb : nullptr;
   m.a_off = d_meta; m.b_off = d_meta + 1; m.a_cnt = d_meta + 2; m.b_cnt = d_meta + 3;
   m.npairs = 1; m.dim = dim; m.max_n = max_n; m.mode = mode; m.ratio = ratio; m.radius = use_pts ? radius : -1.0;
-  m.q_idx = d_q; m.t_idx = d_t; m.dist = d_dist; m.n_out = d_meta + 4; m.cand4 = d_c4;
+  m.q_idx = d_q; m.t_idx = d_t; m.dist = d_dist; m.n_out = d_meta + 4; m.cand4 = d_c4; m.stats = h->match_stats;
   if (rc == D2FE_OK) chk(launch_match(m, s), "launch_match");
   int32_t cnt = 0;
   if (rc == D2FE_OK) chk(hipMemcpyAsync(&cnt, d_meta + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s), "D2H n");
@@ -1545,6 +1561,16 @@ int d2fe_profile_read(d2fe_handle h, float* ms, int32_t* launches) {
   h->prof_used = 0;
   h->prof_recs.clear();
   return D2FE_OK;
+}
+
+long d2fe_match_fallback_rows(d2fe_handle h, int reset) {
+  if (!h) return fail(D2FE_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  int32_t v = 0;
+  HIP_TRY(hipMemcpy(&v, h->match_stats, sizeof(v), hipMemcpyDeviceToHost));
+  if (reset) HIP_TRY(hipMemset(h->match_stats, 0, sizeof(int32_t)));
+  return v;
 }
 
 int d2fe_sync(d2fe_handle h) {

@@ -158,6 +158,9 @@ hipError_t launch_pack_blocks(const float* desc, const float* kps, const float* 
 hipError_t launch_gate_pairs(const float* q, long q_stride, const float* db, long db_stride, int dim, const int32_t* pair_q,
                              const int32_t* pair_db, int npairs, double thres, int32_t* cnt_inout, int32_t* pass, float* sims,
                              int32_t* n_pass, hipStream_t s);
+hipError_t launch_quad_gate(const float* loc, long loc_stride, const float* rem, long rem_stride, int dim, const int32_t* job_loc_row0,
+                            const int32_t* job_rem_row0, int loc_view_step, int rem_view_step, int njobs, double thres, int32_t* dir_prev,
+                            float* sims, int32_t* cnt_inout, int32_t* n_pass, hipStream_t s);
 
 hipError_t launch_half_compact(const float* desc, const float* pts, const int32_t* n_kp, const int32_t* job_row, const int32_t* job_left,
                                const float* job_shift, int njobs, int cap, int dim, float width_undistort, float move_cols,
@@ -174,6 +177,7 @@ struct MatchArgs {
   int32_t* q_idx; int32_t* t_idx; float* dist; int32_t* n_out;
   // scratch: per pair, per direction, per row: 4 candidate indices
   int32_t* cand4;   // [npairs][2][max_n][4]
+  int32_t* stats = nullptr;   // optional: [0] += queries whose 2-NN came from the exact fallback scan (match.hip)
 };
 hipError_t launch_match(const MatchArgs& m, hipStream_t s);
 

@@ -12,8 +12,12 @@
 //  (2) match_finalize: per pair, re-evaluates the <= 4 candidates of every row of both directions with the
 //      ORACLE's arithmetic (orc_l2_dist: OpenCV normL2Sqr_ accumulation order, then sqrt), takes the exact
 //      2-NN, applies ratio / mutual / radius tests in double exactly as feature_matcher.cpp:16-37, and emits
-//      matches in ascending query order.  Indices and distances therefore equal the oracle's bit for bit
-//      unless more than four train rows lie within fp32 round-off (~1e-6) of the nearest distance.
+//      matches in ascending query order.
+// Exact by construction: the top-4 is chosen on the Gram-trick distance, whose error against the exact one is bounded by
+// GRAM_ERR * (|q|^2 + |t|^2).  A row excluded from the top-4 has an approximate d2 >= the 4th candidate's; if that bound cannot rule
+// out that such a row beats the exact 2nd neighbour (more than four rows within round-off of each other: repeated texture, a frame
+// matched against a near-copy, all-equal sets), the query is SATURATED and its 2-NN is recomputed by an exact scan of every train
+// row in the oracle's arithmetic.  Indices and distances therefore equal the oracle's bit for bit for any input.
 #include "kernels.h"
 
 namespace d2fe {
@@ -27,6 +31,9 @@ constexpr int KCH = 64;        // K chunk staged per pass (64: 67 KB of LDS per 
 constexpr int QS = 257;        // LDS row stride of the query tile (odd -> conflict-free column reads)
 constexpr int TS = KCH + 1;    // LDS row stride of the train chunk
 constexpr int MAXDIM = 256;
+// |d2_gram - d2_exact| <= GRAM_ERR * (|q|^2 + |t|^2): three fp32 sums of <= 256 products (gamma_257 = 257 * 2^-24 = 1.53e-5 each, and
+// sum |t_k q_k| <= (|q|^2 + |t|^2) / 2) give 2 * gamma_257 = 3.1e-5; 4e-5 leaves room for the final subtraction's rounding
+constexpr float GRAM_ERR = 4.0e-5f;
 
 struct Cand { float d; int i; };
 __device__ __forceinline__ bool cand_less(float d, int i, const Cand& c) { return d < c.d || (d == c.d && i < c.i); }
@@ -81,6 +88,11 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
   float* qn = Ts + TB * TS;               // [MQ]
   float* tn = qn + MQ;                    // [TB]
   Cand* merge = reinterpret_cast<Cand*>(tn + TB);  // [4 waves][MQ][4]
+  float* aux = reinterpret_cast<float*>(merge + 4 * MQ * 4);   // [4] per-wave max |t|^2
+  float* m4th = aux + 4;                                        // [MQ] approximate d2 of the 4th candidate
+  int* satn = reinterpret_cast<int*>(m4th + MQ);                // number of saturated queries of this tile
+  int* sat = satn + 1;                                          // [MQ] their tile-local rows
+  Cand* scan = reinterpret_cast<Cand*>(sat + MQ + 1);           // [16 groups][2] partial 2-NN of the exact scan (8-byte aligned)
 
   const int pair = blockIdx.z, dir = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,6 +147,7 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
   if (nchunks > 0) gload(0);
   f32x16 acc;
   float tnorm = 0.f;
+  float tnmax = 0.f;                     // largest |t|^2 this lane has seen (the error bound of the rows it dropped)
   for (int c = 0; c < nchunks; ++c) {
     const int t0 = (c / nkc) * TB, kc = c % nkc;
     if (kc == 0) {
@@ -176,6 +189,7 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
         const int gi = t0 + li;
         if (gi < nt) {
           const float d2 = (tn[li] + qq) - 2.0f * acc[r];
+          tnmax = fmaxf(tnmax, tn[li]);
           cand_insert(top, d2, gi);
         }
       }
@@ -192,11 +206,14 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) cand_insert(top, other[k].d, other[k].i);
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tnmax = fmaxf(tnmax, __shfl_xor(tnmax, o, 64));
   __syncthreads();
   if (lane < 32) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) merge[(wave * MQ + lane) * 4 + k] = top[k];
   }
+  if (lane == 0) aux[wave] = tnmax;
   __syncthreads();
   int* mcand = reinterpret_cast<int*>(Ts);          // [MQ][4] candidate indices (the train chunk buffer is free now)
   float* mdist = reinterpret_cast<float*>(Ts) + MQ * 4;  // [MQ][4] exact distances
@@ -209,7 +226,9 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
       }
 #pragma unroll
     for (int k = 0; k < 4; ++k) mcand[lane * 4 + k] = top[k].i == 0x7FFFFFFF ? -1 : top[k].i;
+    m4th[lane] = top[3].d;                          // approximate d2 of the weakest candidate kept: every dropped row has at least this
   }
+  if (tid == 0) *satn = 0;
   __syncthreads();
   // exact re-rank: every (query, candidate) distance re-evaluated in the oracle's order, 16 lanes per pair.  A 16-lane group owns 8 of
   // the 128 (query, candidate) pairs; for dim = 256 the train-row elements of FOUR pairs (4 x 16 loads per lane) are requested before
@@ -271,8 +290,44 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
       if (dk < bd0 || (dk == bd0 && ik < bi0)) { bd1 = bd0; bi1 = bi0; bd0 = dk; bi0 = ik; }
       else if (dk < bd1 || (dk == bd1 && ik < bi1)) { bd1 = dk; bi1 = ik; }
     }
-    int32_t* out = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + q0 + tid) * 4;   // {nn index, d0 bits, d1 bits, -}
-    out[0] = bi0; out[1] = __float_as_int(bd0); out[2] = __float_as_int(bd1);
+    // saturation test (header): can a row that was dropped from the top-4 still beat the exact 2nd neighbour?
+    const float slack = GRAM_ERR * (qn[tid] + fmaxf(fmaxf(aux[0], aux[1]), fmaxf(aux[2], aux[3])));
+    const bool saturated = nt > 4 && !(m4th[tid] - slack > bd1 * bd1 * 1.00001f);
+    if (saturated) {
+      sat[atomicAdd(satn, 1)] = tid;
+    } else {
+      int32_t* out = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + q0 + tid) * 4;   // {nn index, d0 bits, d1 bits, fallback flag}
+      out[0] = bi0; out[1] = __float_as_int(bd0); out[2] = __float_as_int(bd1); out[3] = 0;
+    }
+  }
+  __syncthreads();
+  // exact scan of the saturated queries (normally none): 16 lanes per train row, 16 rows in flight, every row of the pair's train set;
+  // (distance, index) compared lexicographically = the oracle's "strictly smaller replaces" insertion in ascending index
+  const int ns = *satn;
+  for (int si = 0; si < ns; ++si) {
+    const int sq = sat[si];
+    const int grp = tid >> 4, slot = tid & 15;
+    Cand b0{__builtin_inff(), 0x7FFFFFFF}, b1{__builtin_inff(), 0x7FFFFFFF};
+    for (int j = grp; j < nt; j += 16) {
+      const float dj = exact_dist16(Qs + sq * QS, T + (size_t)j * dim, dim, slot, lane);
+      if (cand_less(dj, j, b0)) { b1 = b0; b0.d = dj; b0.i = j; }
+      else if (cand_less(dj, j, b1)) { b1.d = dj; b1.i = j; }
+    }
+    if (slot == 0) { scan[grp * 2] = b0; scan[grp * 2 + 1] = b1; }
+    __syncthreads();
+    if (tid == 0) {
+      Cand r0{__builtin_inff(), 0x7FFFFFFF}, r1{__builtin_inff(), 0x7FFFFFFF};
+      for (int g = 0; g < 32; ++g) {
+        const Cand c = scan[g];
+        if (c.i == 0x7FFFFFFF) continue;
+        if (cand_less(c.d, c.i, r0)) { r1 = r0; r0 = c; }
+        else if (cand_less(c.d, c.i, r1)) { r1 = c; }
+      }
+      int32_t* out = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + q0 + sq) * 4;
+      out[0] = r0.i == 0x7FFFFFFF ? -1 : r0.i; out[1] = __float_as_int(r0.d); out[2] = __float_as_int(r1.d); out[3] = 1;
+      if (m.stats) atomicAdd(m.stats, 1);
+    }
+    __syncthreads();
   }
 }
 
@@ -350,7 +405,8 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(MatchArgs m
 
 hipError_t launch_match(const MatchArgs& m, hipStream_t s) {
   if (m.dim > MAXDIM || (m.dim & 3) || m.max_n > FIN_MAXN || m.max_n < 1) return hipErrorInvalidValue;
-  const size_t lds = sizeof(float) * (MQ * QS + TB * TS + MQ + TB) + sizeof(Cand) * 4 * MQ * 4;
+  const size_t lds = sizeof(float) * (MQ * QS + TB * TS + MQ + TB) + sizeof(Cand) * 4 * MQ * 4 + sizeof(float) * (4 + MQ) +
+                     sizeof(int) * (MQ + 2) + sizeof(Cand) * 32;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(match_prefilter_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

@@ -266,7 +266,8 @@ __global__ __launch_bounds__(1024) void dequant_int8_kernel(const int8_t* __rest
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
       const bool full = (seg + 1) * 32 <= n;
-      out[i] = (seg < landmark_num && full) ? v / __builtin_sqrtf(s) : v;
+      // Eigen's normalize(): z = squaredNorm(); if (z > 0) derived() /= sqrt(z) -- an all-zero segment stays zero
+      out[i] = (seg < landmark_num && full && s > 0.f) ? v / __builtin_sqrtf(s) : v;
     }
   } else {
     float s = 0.f;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(1024) void dequant_int8_kernel(const int8_t* __rest
     float t = 0.f;
     for (int w = 0; w < 16; ++w) t += red[w];
     const float nr = __builtin_sqrtf(t);
-    for (int i = tid; i < n; i += 1024) out[i] = (float)((double)q[i] / 127.0) / nr;
+    for (int i = tid; i < n; i += 1024) { const float v = (float)((double)q[i] / 127.0); out[i] = t > 0.f ? v / nr : v; }
   }
 }
 

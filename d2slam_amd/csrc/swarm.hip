@@ -14,6 +14,12 @@
 namespace d2fe {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// NetVLAD rows inside a block start at word cap*259, 16-byte aligned only when cap is a multiple of 4: the gate kernels take a flag and
+// fall back to four scalar loads when a base pointer or a stride is not (the C ABI computes it)
+__device__ __forceinline__ f32x4 ld4(const float* p, bool vec) {
+  if (vec) return *reinterpret_cast<const f32x4*>(p);
+  return f32x4{p[0], p[1], p[2], p[3]};
+}
 
 // one workgroup per frame; `row0 + f * row_step` is the frame's row in the dense extract outputs ([rows][cap][...]),
 // f its row in the NetVLAD output [F][G] (null: the block's NetVLAD part is zero-filled)
@@ -49,14 +55,14 @@ __global__ __launch_bounds__(256) void gate_pairs_kernel(const float* __restrict
                                                          long db_stride, int dim, const int32_t* __restrict__ pair_q,
                                                          const int32_t* __restrict__ pair_db, int npairs, double thres,
                                                          int32_t* __restrict__ cnt_inout, int32_t* __restrict__ pass,
-                                                         float* __restrict__ sims, int32_t* __restrict__ n_pass) {
+                                                         float* __restrict__ sims, int32_t* __restrict__ n_pass, bool vec) {
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (p >= npairs) return;
   const float* a = q + (size_t)pair_q[p] * q_stride;
   const float* b = db + (size_t)pair_db[p] * db_stride;
   float s = 0.f;
   for (int j = lane * 4; j < dim; j += 256) {
-    const f32x4 x = *reinterpret_cast<const f32x4*>(a + j), y = *reinterpret_cast<const f32x4*>(b + j);
+    const f32x4 x = ld4(a + j, vec), y = ld4(b + j, vec);
 #pragma unroll
     for (int e = 0; e < 4; ++e) s = __builtin_fmaf(x[e], y[e], s);
   }
@@ -71,6 +77,61 @@ __global__ __launch_bounds__(256) void gate_pairs_kernel(const float* __restrict
   }
 }
 
+// FOURCORNER_FISHEYE form of the gate: D2FeatureTracker::getMatchedPrevKeyframe (d2frontend/src/d2featuretracker.cpp:212-233) compares
+// view 2 of the REMOTE quad frame (dir_a = 2) with the views dirs = {2, 3, 0, 1} of the local keyframe, in that order, and stops at the
+// first whose NetVLAD similarity is not below the threshold: dir_b = dirs[j].  trackRemoteFrames (:282-297) then tracks the four view
+// pairs (remote view dir_a = (2 + k) % 4, local view (dir_b - 2 + dir_a) % 4), k = 0..3 -- the relative yaw between the two drones, in
+// quarter turns.  One wave per job = (local quad frame, remote quad frame): the four dot products (fp32, as Eigen's VectorXf::dot;
+// compared in double), dir_prev[job] = dir_b or -1, sims[job][j] for dirs[j], and -- view pairs laid out as 16 consecutive matcher
+// problems per job, index local_view * 4 + remote_view -- cnt_inout[job*16 + p] = 0 for every pair the reference would not track.
+__global__ __launch_bounds__(256) void quad_gate_kernel(const float* __restrict__ loc, long loc_stride, const float* __restrict__ rem,
+                                                        long rem_stride, int dim, const int32_t* __restrict__ job_loc_row0,
+                                                        const int32_t* __restrict__ job_rem_row0, int loc_view_step, int rem_view_step,
+                                                        int njobs, double thres, int32_t* __restrict__ dir_prev,
+                                                        float* __restrict__ sims, int32_t* __restrict__ cnt_inout,
+                                                        int32_t* __restrict__ n_pass, bool vec) {
+  const int job = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (job >= njobs) return;
+  const float* r2 = rem + ((size_t)job_rem_row0[job] + 2 * (size_t)rem_view_step) * rem_stride;
+  const float* l0 = loc + (size_t)job_loc_row0[job] * loc_stride;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};      // s[j]: local view dirs[j] = (2 + j) & 3
+  for (int e = lane * 4; e < dim; e += 256) {
+    const f32x4 y = ld4(r2 + e, vec);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 x = ld4(l0 + (size_t)((2 + j) & 3) * loc_view_step * loc_stride + e, vec);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s[j] = __builtin_fmaf(x[c], y[c], s[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o, 64);
+  int db = -1;
+#pragma unroll
+  for (int j = 3; j >= 0; --j) if (!((double)s[j] < thres)) db = (2 + j) & 3;     // the FIRST j that passes wins
+  if (lane == 0) {
+    if (dir_prev) dir_prev[job] = db;
+    if (sims) { sims[job * 4 + 0] = s[0]; sims[job * 4 + 1] = s[1]; sims[job * 4 + 2] = s[2]; sims[job * 4 + 3] = s[3]; }
+    if (db >= 0 && n_pass) atomicAdd(n_pass, 1);
+  }
+  if (cnt_inout && lane < 16) {
+    const int lv = lane >> 2, rv = lane & 3;
+    const bool tracked = db >= 0 && lv == ((db - 2 + rv + 4) & 3);
+    if (!tracked) cnt_inout[(size_t)job * 16 + lane] = 0;
+  }
+}
+
+hipError_t launch_quad_gate(const float* loc, long loc_stride, const float* rem, long rem_stride, int dim, const int32_t* job_loc_row0,
+                            const int32_t* job_rem_row0, int loc_view_step, int rem_view_step, int njobs, double thres, int32_t* dir_prev,
+                            float* sims, int32_t* cnt_inout, int32_t* n_pass, hipStream_t s) {
+  const bool vec = !(((uintptr_t)loc | (uintptr_t)rem) & 15) && !((loc_stride | rem_stride) & 3);
+  hipLaunchKernelGGL(quad_gate_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, loc, loc_stride, rem, rem_stride, dim, job_loc_row0,
+                     job_rem_row0, loc_view_step, rem_view_step, njobs, thres, dir_prev, sims, cnt_inout, n_pass, vec);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_blocks(const float* desc, const float* kps, const float* scores, const int32_t* n_kp, const float* gdesc,
                               int row0, int row_step, int nframes, int cap, int G, int blk_words, float* blocks, hipStream_t s) {
   hipLaunchKernelGGL(pack_blocks_kernel, dim3(nframes), dim3(256), 0, s, desc, kps, scores, n_kp, gdesc, row0, row_step, cap, G, blk_words, blocks);
@@ -79,8 +140,9 @@ hipError_t launch_pack_blocks(const float* desc, const float* kps, const float* 
 hipError_t launch_gate_pairs(const float* q, long q_stride, const float* db, long db_stride, int dim, const int32_t* pair_q,
                              const int32_t* pair_db, int npairs, double thres, int32_t* cnt_inout, int32_t* pass, float* sims,
                              int32_t* n_pass, hipStream_t s) {
+  const bool vec = !(((uintptr_t)q | (uintptr_t)db) & 15) && !((q_stride | db_stride) & 3);
   hipLaunchKernelGGL(gate_pairs_kernel, dim3((npairs + 3) / 4), dim3(256), 0, s, q, q_stride, db, db_stride, dim, pair_q, pair_db, npairs,
-                     thres, cnt_inout, pass, sims, n_pass);
+                     thres, cnt_inout, pass, sims, n_pass, vec);
   return hipGetLastError();
 }
 

@@ -76,3 +76,74 @@ def all_gather_blocks(gath: torch.Tensor, blocks: torch.Tensor, group=None) -> N
         gath.copy_(g)
     else:
         dist.all_gather_into_tensor(gath.view(-1), blocks.view(-1), group=group)
+
+
+class QuadSwarm:
+    """BASELINE configs[4]: one quadcam (FOURCORNER_FISHEYE) agent per rank.  After the per-agent chain (d2slam_amd.quadcam.QuadcamChain:
+    undistort, SuperPoint + NetVLAD on the 4 views, neighbour + temporal matching) every rank packs ONE block per VIEW (4 per quad
+    frame, each with its own NetVLAD vector -- the reference broadcasts the whole VisualImageDescArray, loop_net.cpp:24-87), ONE
+    all-gather ships them, and each rank matches its own views against every remote agent's views of the same time index: the 16 view
+    pairs (local view lv, remote view rv) of a job (local quad frame q, remote agent r) are 16 consecutive matcher problems, index
+    lv*4 + rv, whose b-side descriptors are read in place inside the gathered blocks (row-block decomposition, no second exchange).
+
+    The reference's gate for this camera configuration (getMatchedPrevKeyframe, d2featuretracker.cpp:212-233, and the view pairing of
+    trackRemoteFrames, :282-297) is evaluated on the device by d2fe_quad_gate_device: mode "all2all" matches all 16 view pairs and
+    reports how many jobs pass the gate and which rotation the reference would pick; mode "gated" zeroes the a-side count of the 12
+    (or 16) view pairs the reference would not track, so that exactly its four pairs are matched.  WHOLE_IMG_MATCH, no radius gate
+    (trackRemote passes search_radius*2 but matchLocalFeatures only uses it with motion prediction, :1100-1115)."""
+
+    def __init__(self, chain, torch, dev, world, rank, netvlad_dim, thres, mode="all2all", knn_ratio=0.8):
+        assert mode in ("all2all", "gated")
+        self.chain, self.torch, self.world, self.rank, self.G, self.thres, self.mode, self.ratio = chain, torch, world, rank, netvlad_dim, thres, mode, knn_ratio
+        Q, NI, cap = chain.Q, chain.NI, chain.cap
+        self.BLK = block_words(cap, netvlad_dim)
+        rows_per_block = self.BLK // 256
+        f32, i32 = torch.float32, torch.int32
+        self.blocks = torch.zeros((NI, self.BLK), dtype=f32, device=dev)
+        self.gath = torch.zeros((world, NI, self.BLK), dtype=f32, device=dev)
+        self.gath_i32 = self.gath.view(i32).view(world * NI, self.BLK)
+        job_loc, job_rem, a_off, b_off, a_row, rem_blk = [], [], [], [], [], []
+        self.jobs = []                                       # (remote rank, quad frame)
+        for r in range(world):
+            if r == rank:
+                continue
+            for q in range(Q):
+                self.jobs.append((r, q))
+                job_loc.append(q); job_rem.append(r * NI + q)
+                for lv in range(4):
+                    for rv in range(4):
+                        a_off.append((lv * Q + q) * cap); a_row.append(lv * Q + q)
+                        blk = r * NI + rv * Q + q
+                        b_off.append(blk * rows_per_block); rem_blk.append(blk)
+        self.njobs, self.NP = len(self.jobs), len(a_off)
+        t = lambda x, dt: torch.tensor(x, dtype=dt, device=dev)
+        self.job_loc, self.job_rem = t(job_loc, i32), t(job_rem, i32)
+        self.a_off, self.b_off = t(a_off, i32), t(b_off, i32)
+        self.a_row, self.rem_blk = t(a_row, torch.int64), t(rem_blk, torch.int64)
+        n = max(self.NP, 1)
+        self.a_cnt = torch.zeros(n, dtype=i32, device=dev); self.b_cnt = torch.zeros(n, dtype=i32, device=dev)
+        self.mq = torch.zeros((n, cap), dtype=i32, device=dev); self.mt = torch.zeros((n, cap), dtype=i32, device=dev)
+        self.md = torch.zeros((n, cap), dtype=f32, device=dev); self.mn = torch.zeros(n, dtype=i32, device=dev)
+        nj = max(self.njobs, 1)
+        self.dir_prev = torch.full((nj,), -1, dtype=i32, device=dev); self.sims = torch.zeros((nj, 4), dtype=f32, device=dev)
+        self.n_pass = torch.zeros(1, dtype=i32, device=dev)
+        self.n_off = block_field_offset(cap, netvlad_dim, "n"); self.g_off = block_field_offset(cap, netvlad_dim, "netvlad")
+
+    def step(self, st, group=None):
+        """pack -> ONE all-gather -> gate -> cross-agent matching, all ordered on the current torch stream (raw handle `st`)."""
+        c, fe, torch = self.chain, self.chain.fe, self.torch
+        Q, NI, cap, G = c.Q, c.NI, c.cap, self.G
+        fe.pack_blocks_device(c.desc.data_ptr(), c.pts.data_ptr(), c.scores.data_ptr(), c.cnt.data_ptr(), c.gdesc.data_ptr(), 0, 1, NI, cap, G,
+                              self.blocks.data_ptr(), stream=st)
+        all_gather_blocks(self.gath, self.blocks, group)
+        if self.NP == 0:
+            return
+        torch.index_select(c.cnt, 0, self.a_row, out=self.a_cnt)
+        self.b_cnt.copy_(self.gath_i32[self.rem_blk, self.n_off])
+        self.n_pass.zero_()
+        fe.quad_gate_device(c.gdesc.data_ptr(), G, self.gath.data_ptr() + 4 * self.g_off, self.BLK, G, self.job_loc.data_ptr(),
+                            self.job_rem.data_ptr(), Q, Q, self.njobs, self.thres, d_dir_prev=self.dir_prev.data_ptr(), d_sims=self.sims.data_ptr(),
+                            d_cnt_inout=self.a_cnt.data_ptr() if self.mode == "gated" else None, d_n_pass=self.n_pass.data_ptr(), stream=st)
+        fe.match_batch_device(c.desc.data_ptr(), self.gath.data_ptr(), self.a_off.data_ptr(), self.b_off.data_ptr(), self.a_cnt.data_ptr(),
+                              self.b_cnt.data_ptr(), self.NP, 256, cap, self.mq.data_ptr(), self.mt.data_ptr(), self.md.data_ptr(), self.mn.data_ptr(),
+                              mode=0, ratio=self.ratio, radius=-1.0, stream=st)

@@ -190,6 +190,13 @@ D2FE_API int d2fe_match_knn(d2fe_handle h, const float* a, int na, const float* 
 D2FE_API int d2fe_match_crosscheck(d2fe_handle h, const float* a, int na, const float* b, int nb, int dim,
                                    int32_t* q_idx, int32_t* t_idx, float* dist, int cap, int* n_out);
 
+/* Both matchers pick their candidates with a Gram-trick prefilter and re-rank them in the reference's (OpenCV's) arithmetic; a query
+ * whose candidate list cannot be proven to contain the true two nearest neighbours (more than four train rows within fp32 round-off of
+ * each other: repeated texture, near-duplicate frames) is re-evaluated by an exact scan of all train rows, so the result equals the
+ * reference's for any input.  d2fe_match_fallback_rows returns how many queries took that scan since the last reset (diagnostic;
+ * synchronises the device). */
+D2FE_API long d2fe_match_fallback_rows(d2fe_handle h, int reset);
+
 /* Batched, device-resident matcher: npairs problems; pair p matches rows [a_off[p], a_off[p]+a_cnt[p]) of
  * d_a against rows [b_off[p], ...) of d_b.  Counts may live on the device (d_a_cnt/d_b_cnt, e.g. the d_n_out
  * of an extract call) -- pass max_n as the upper bound of any count.  mode: 0 = matchKNN, 1 = cross-check.
@@ -332,6 +339,19 @@ D2FE_API int d2fe_pack_blocks_device(d2fe_handle h, const float* d_desc, const f
 D2FE_API int d2fe_gate_pairs_device(d2fe_handle h, const float* d_q, size_t q_stride, const float* d_db, size_t db_stride, int dim,
                                     const int32_t* d_pair_q, const int32_t* d_pair_db, int npairs, double thres,
                                     int32_t* d_cnt_inout, int32_t* d_pass, float* d_sims, int32_t* d_n_pass, void* stream);
+
+/* The same gate for a FOURCORNER_FISHEYE (quadcam) agent: getMatchedPrevKeyframe's second branch (d2featuretracker.cpp:212-233) compares
+ * view 2 of the REMOTE quad frame with the local keyframe's views in the order dirs = {2, 3, 0, 1} and stops at the first whose similarity
+ * is not below thres (dir_b = dirs[j]); trackRemoteFrames (:282-297) then tracks the four view pairs (remote view a = (2+k)%4, local view
+ * (dir_b - 2 + a) % 4).  Job j = (local quad frame, remote quad frame): the NetVLAD vector of local view v is row d_job_local_row0[j] +
+ * v*local_view_step of d_local (rows local_stride words apart), of remote view v row d_job_remote_row0[j] + v*remote_view_step of d_remote.
+ * Outputs (each may be NULL): d_dir_prev[j] = dir_b or -1; d_sims[j][4] = the similarities for dirs[0..3]; *d_n_pass += passing jobs;
+ * d_cnt_inout[j*16 + local_view*4 + remote_view] = 0 for every view pair the reference would NOT track (the 16 view pairs of a job laid
+ * out as 16 consecutive matcher problems: with the matcher's a_cnt there, only the reference's four pairs are matched). */
+D2FE_API int d2fe_quad_gate_device(d2fe_handle h, const float* d_local, size_t local_stride, const float* d_remote, size_t remote_stride,
+                                   int dim, const int32_t* d_job_local_row0, const int32_t* d_job_remote_row0, int local_view_step,
+                                   int remote_view_step, int njobs, double thres, int32_t* d_dir_prev, float* d_sims,
+                                   int32_t* d_cnt_inout, int32_t* d_n_pass, void* stream);
 
 /* ---- quadcam neighbour matching on the device (A12) -------------------------------------------------------------------------------
  * d2fe_half_image_compact_device = getFeatureHalfImg (d2frontend/src/d2featuretracker.cpp:1051-1075) for a batch of jobs, plus the

@@ -30,6 +30,14 @@ RANGES = {
     "SPREF_GEN_MATCHER": ("d2frontend/src/feature_matcher.cpp", 3, 43, "namespace D2FrontEnd {", "}"),
     "SPREF_GEN_HALFIMG": ("d2frontend/src/d2featuretracker.cpp", 1051, 1075, "getFeatureHalfImg(", "}"),
     "SPREF_GEN_NEIGHBOUR": ("d2frontend/src/d2featuretracker.cpp", 1146, 1181, "std::map<int, int> tmp_to_idx_a, tmp_to_idx_b;", "}"),
+    # round 3 (ref_shim/spref_api2.cpp): the reference-owned code either side of the hot path
+    "SPREF_GEN_CODEC_Q_LM": ("d2common/include/d2common/d2frontend_types.h", 230, 237, "Eigen::Map<const VectorXf> desc0(landmark_descriptor.data()", "}"),
+    "SPREF_GEN_CODEC_Q_NV": ("d2common/include/d2common/d2frontend_types.h", 262, 268, "img_desc.header.image_desc_size_int8 = image_desc.size();", "}"),
+    "SPREF_GEN_CODEC_DEQ": ("d2common/include/d2common/d2frontend_types.h", 319, 341, "if (desc.landmark_descriptor_int8.size() > 0) {", "}"),
+    "SPREF_GEN_DB_QUERY": ("d2frontend/src/loop_detector.cpp", 300, 350, "int LoopDetector::queryIndexFromDatabase(", "}"),
+    "SPREF_GEN_TRACKER_GATE": ("d2frontend/src/d2featuretracker.cpp", 166, 235, "bool D2FeatureTracker::getMatchedPrevKeyframe(", "}"),
+    "SPREF_GEN_TRACKER_DIRS": ("d2frontend/src/d2featuretracker.cpp", 270, 284, "int max_dirs = 4;", "}"),
+    "SPREF_GEN_LOOPCAM_MATCH": ("d2frontend/src/loop_cam.cpp", 156, 191, "void matchLocalFeatures(", "}"),
 }
 
 
@@ -72,7 +80,7 @@ def build(force=False, verbose=False):
             defs.append('-D%s="%s"' % (macro, inc))
         cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-w",
                "-I" + SHIM, "-I" + os.path.join(REF, "d2frontend", "include")] + defs + \
-              [os.path.join(SHIM, "spref_api.cpp"), "-o", LIB]
+              [os.path.join(SHIM, "spref_api.cpp"), os.path.join(SHIM, "spref_api2.cpp"), "-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

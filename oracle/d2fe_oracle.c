@@ -784,15 +784,62 @@ ORC_API void orc_dequant_int8(const int8_t* q, int n, int landmark_num, float* o
     for (int i = 0; i < landmark_num && (i + 1) * 32 <= n; ++i) {
       float s = 0.f;
       for (int j = 0; j < 32; ++j) s += out[i * 32 + j] * out[i * 32 + j];
+      if (!(s > 0.f)) continue;            /* Eigen's normalize(): z = squaredNorm(); if (z > 0) derived() /= sqrt(z)  (Dot.h) */
       const float nr = sqrtf(s);
       for (int j = 0; j < 32; ++j) out[i * 32 + j] = out[i * 32 + j] / nr;
     }
   } else {
     float s = 0.f;
     for (int i = 0; i < n; ++i) s += out[i] * out[i];
+    if (!(s > 0.f)) return;
     const float nr = sqrtf(s);
     for (int i = 0; i < n; ++i) out[i] = out[i] / nr;
   }
+}
+
+/* NetVLAD gate of the feature tracker: D2FeatureTracker::getMatchedPrevKeyframe (d2frontend/src/d2featuretracker.cpp:166-235) and, for
+ * FOURCORNER_FISHEYE, the view pairing of trackRemoteFrames (:270-284).
+ *   quadcam == 0 (STEREO_PINHOLE / PINHOLE_DEPTH / MONOCULAR, :173-205): keyframes newest first; view 0 of the remote frame against view 0
+ *     of the keyframe; the first keyframe with !(sim < thres) wins, dir_a = dir_b = 0.
+ *   quadcam != 0 (:206-233): dir_a = 2; remote view 2 against the keyframe's views dirs = {2,3,0,1} in that order; first pass wins,
+ *     dir_b = dirs[j]; then the pairs (dir_a = (2+k)%4, dir_b = ((dir_b0 - 2 + 4)%4 + 2 + k)%4), k = 0..3, kept when both views have
+ *     SuperPoint landmarks (sp counts may be NULL = all non-empty).
+ * remote [n_views][dim], keyframes [n_kf][n_views][dim] (oldest first, as current_keyframes).  The similarity is an fp32 dot product
+ * (Eigen::VectorXf::dot; sequential sum here, Eigen reduces in packets) compared in double.  Returns 1 when a keyframe matched. */
+ORC_API int orc_tracker_gate(int quadcam, const float* remote, const int* sp_remote, const float* keyframes, const int* sp_kf, int n_kf,
+                             int n_views, int dim, double thres, int* kf_idx, int* dir_a, int* dir_b, int* pairs_cur, int* pairs_prev,
+                             int* n_pairs, float* sims4) {
+  static const int dirs[4] = {2, 3, 0, 1};
+  *n_pairs = 0; *kf_idx = -1; *dir_a = 0; *dir_b = 0;
+  if (n_kf == 0) return 0;
+  for (int k = n_kf - 1; k >= 0; --k) {
+    const float* kf = keyframes + (size_t)k * n_views * dim;
+    if (!quadcam) {
+      float s = 0.f;
+      for (int j = 0; j < dim; ++j) s += kf[j] * remote[j];
+      if (sims4) sims4[0] = s;
+      if (!((double)s < thres)) { *kf_idx = k; return 1; }
+    } else {
+      const float* r2 = remote + (size_t)2 * dim;
+      for (int j = 0; j < n_views && j < 4; ++j) {
+        const float* v = kf + (size_t)dirs[j] * dim;
+        float s = 0.f;
+        for (int e = 0; e < dim; ++e) s += v[e] * r2[e];
+        if (sims4) sims4[j] = s;
+        if (!((double)s < thres)) {
+          *kf_idx = k; *dir_a = 2; *dir_b = dirs[j];
+          for (int _a = 2; _a < 6; ++_a) {
+            const int a = _a % 4, b = ((dirs[j] - 2 + 4) % 4 + _a) % 4;
+            if (a < n_views && b < n_views && (!sp_kf || sp_kf[k * n_views + b] > 0) && (!sp_remote || sp_remote[a] > 0)) {
+              pairs_cur[*n_pairs] = a; pairs_prev[*n_pairs] = b; ++*n_pairs;
+            }
+          }
+          return 1;
+        }
+      }
+    }
+  }
+  return 0;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -308,6 +308,24 @@ def dequant_int8(q, landmark_num=-1):
     return out
 
 
+def tracker_gate(remote, keyframes, thres, quadcam, sp_remote=None, sp_kf=None):
+    """getMatchedPrevKeyframe (+ the FOURCORNER_FISHEYE view pairing of trackRemoteFrames), d2featuretracker.cpp:166-235,270-284.
+    remote [n_views, dim]; keyframes [n_kf, n_views, dim] oldest first.  Returns None or dict(kf, dir_a, dir_b, pairs, sims)."""
+    remote = _f(remote); keyframes = _f(keyframes)
+    n_kf, n_views, dim = keyframes.shape
+    kf = C.c_int(); da = C.c_int(); db = C.c_int(); npairs = C.c_int()
+    pc = np.zeros(4, np.int32); pp = np.zeros(4, np.int32); sims = np.zeros(4, np.float32)
+    spr = np.ascontiguousarray(sp_remote, np.int32) if sp_remote is not None else None
+    spk = np.ascontiguousarray(sp_kf, np.int32) if sp_kf is not None else None
+    lib().orc_tracker_gate.restype = C.c_int
+    r = lib().orc_tracker_gate(int(bool(quadcam)), _p(remote), _p(spr) if spr is not None else None, _p(keyframes),
+                               _p(spk) if spk is not None else None, n_kf, n_views, dim, C.c_double(thres), C.byref(kf), C.byref(da),
+                               C.byref(db), _p(pc), _p(pp), C.byref(npairs), _p(sims))
+    if not r:
+        return None
+    return dict(kf=kf.value, dir_a=da.value, dir_b=db.value, pairs=list(zip(pc[:npairs.value].tolist(), pp[:npairs.value].tolist())), sims=sims)
+
+
 # ---- section 8(f)-4: LK optical-flow tracker (oracle/d2fe_oracle_lk.c) ---------------------------------------------------------
 def pyr_layout(w, h, levels):
     off = (C.c_int * 16)(); ws = (C.c_int * 16)(); hs = (C.c_int * 16)()

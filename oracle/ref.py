@@ -25,7 +25,8 @@ def lib():
         if so is None:
             raise RuntimeError("oracle/_ref/libspref.so is absent and /root/reference is not available to build it")
         _LIB = C.CDLL(so)
-        for f in ("spref_superpoint_post", "spref_get_keypoints", "spref_match_knn", "spref_half_image", "spref_match_neighbour"):
+        for f in ("spref_superpoint_post", "spref_get_keypoints", "spref_match_knn", "spref_half_image", "spref_match_neighbour",
+                  "spref_db_query", "spref_tracker_gate", "spref_loopcam_match"):
             getattr(_LIB, f).restype = C.c_int
     return _LIB
 
@@ -98,3 +99,59 @@ def match_neighbour(pts_a, desc_a, pts_b, desc_b, type_lr, ratio, enable_search_
         return None
     assert n >= 0, n
     return q[:n].copy(), t[:n].copy(), d[:n].copy()
+
+
+# ---- round 3: the reference-owned code either side of the hot path (oracle/ref_shim/spref_api2.cpp) ---------------------------------
+def quant_landmarks(x):
+    """VisualImageDesc::toLCM, landmark descriptors -> int8 (d2frontend_types.h:230-237: float max)."""
+    x = _f(x).reshape(-1); out = np.empty(x.shape[0], np.int8)
+    lib().spref_quant_landmarks(_p(x), x.shape[0], _p(out))
+    return out
+
+
+def quant_netvlad(x):
+    """VisualImageDesc::toLCM, NetVLAD descriptor -> int8 (d2frontend_types.h:262-268: double max)."""
+    x = _f(x).reshape(-1); out = np.empty(x.shape[0], np.int8)
+    lib().spref_quant_netvlad(_p(x), x.shape[0], _p(out))
+    return out
+
+
+def dequant(lm_q, landmark_num, nv_q):
+    """VisualImageDesc(const ImageDescriptor_t&), d2frontend_types.h:319-341.  Returns (landmark_descriptor, image_desc)."""
+    lm_q = np.ascontiguousarray(lm_q, np.int8).reshape(-1); nv_q = np.ascontiguousarray(nv_q, np.int8).reshape(-1)
+    lo = np.zeros(max(len(lm_q), 1), np.float32); no = np.zeros(max(len(nv_q), 1), np.float32)
+    lib().spref_dequant(_p(lm_q), len(lm_q), int(landmark_num), _p(nv_q), len(nv_q), _p(lo), _p(no))
+    return lo[:len(lm_q)].copy(), no[:len(nv_q)].copy()
+
+
+def db_query(db, q, max_index, thres):
+    """LoopDetector::queryIndexFromDatabase (loop_detector.cpp:300-350) over a stand-in faiss::IndexFlatIP.  Returns (label, similarity)."""
+    db = _f(db); q = _f(q)
+    sim = C.c_float(0)
+    r = lib().spref_db_query(_p(db), db.shape[0], db.shape[1], _p(q), int(max_index), C.c_double(thres), C.byref(sim))
+    return int(r), float(sim.value)
+
+
+def tracker_gate(remote, keyframes, thres, quadcam, sp_remote=None, sp_kf=None):
+    """getMatchedPrevKeyframe + trackRemoteFrames' view pairing (d2featuretracker.cpp:166-235,270-284); same return as oracle.tracker_gate."""
+    remote = _f(remote); keyframes = _f(keyframes)
+    n_kf, n_views, dim = keyframes.shape
+    kf = C.c_int(); da = C.c_int(); db = C.c_int(); npairs = C.c_int()
+    pc = np.zeros(4, np.int32); pp = np.zeros(4, np.int32)
+    spr = np.ascontiguousarray(sp_remote, np.int32) if sp_remote is not None else None
+    spk = np.ascontiguousarray(sp_kf, np.int32) if sp_kf is not None else None
+    r = lib().spref_tracker_gate(3 if quadcam else 0, _p(remote), _p(spr) if spr is not None else None, _p(keyframes),
+                                 _p(spk) if spk is not None else None, n_kf, n_views, dim, C.c_double(thres), C.byref(kf), C.byref(da),
+                                 C.byref(db), _p(pc), _p(pp), C.byref(npairs))
+    if not r:
+        return None
+    return dict(kf=kf.value, dir_a=da.value, dir_b=db.value, pairs=list(zip(pc[:npairs.value].tolist(), pp[:npairs.value].tolist())))
+
+
+def loopcam_match(pts_up, desc_up, pts_down, desc_down):
+    """matchLocalFeatures of loop_cam.cpp:156-191 (cross-check BFMatcher, ids and the compacted point lists)."""
+    pu = _f(pts_up).reshape(-1, 2); pd = _f(pts_down).reshape(-1, 2); du = _f(desc_up); dd = _f(desc_down)
+    n = max(len(pu), 1)
+    iu = np.empty(n, np.int32); idn = np.empty(n, np.int32); po = np.empty((n, 2), np.float32); pdo = np.empty((n, 2), np.float32)
+    k = lib().spref_loopcam_match(_p(pu), _p(du), len(pu), _p(pd), _p(dd), len(pd), du.shape[1], _p(iu), _p(idn), _p(po), _p(pdo))
+    return iu[:k].copy(), idn[:k].copy(), po[:k].copy(), pdo[:k].copy()

@@ -1,0 +1,124 @@
+"""One rank of the world-2 QUADCAM cross-agent test (BASELINE configs[4]; tests/test_swarm_gpu.py launches two of these on ONE GPU over
+gloo).  Each rank runs the quadcam chain on its own 4 views with the HIP path, packs one exchange block per view, all-gathers them,
+evaluates the FOURCORNER_FISHEYE NetVLAD gate (d2fe_quad_gate_device) and matches view x view against the other agent -- every block,
+every gate decision, the view pairing and every match list is compared with the CPU oracle (and, when present, the reference's own
+getMatchedPrevKeyframe / trackRemoteFrames compiled in place) run on the SAME seeded frames of both ranks.
+Rank 1's cameras are mounted one quarter turn further round (its view v looks at scene (v+1)%4), so the gate has to find a rotation.
+Exit code 0 = all assertions held."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from d2slam_amd import api, netvlad as nvm, quadcam, swarm
+    from d2slam_amd.synth import synth_image
+    from d2slam_amd.weights import synthetic_superpoint_weights
+    from oracle import oracle as orc, ref as spref
+
+    rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+    mode = os.environ.get("QUAD_SWARM_MODE", "gated")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+    RH, RW, UH, UW, CAP, Q = 160, 256, 96, 160, 60, 1
+    NI = 4 * Q
+    w = synthetic_superpoint_weights(dustbin_bias=7.5)
+    nv = nvm.synthetic_netvlad_weights()
+    maps_np = [quadcam.synthetic_maps(c, RH, RW, UH, UW) for c in range(4)]
+
+    def raw_views(r):
+        out = []
+        for v in range(4):
+            scene = (v + r) % 4                                   # rank r's rig is turned by r quarter turns
+            im = synth_image(RH, RW, 300 + scene)
+            rng = np.random.RandomState(50 * r + v)
+            out.append(np.clip(im.astype(np.int16) + rng.randint(-2, 3, im.shape), 0, 255).astype(np.uint8))
+        return out
+
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=UW, input_height=UH, max_batch=NI, precision=api.PREC_F32))
+    fe.load_superpoint(w); fe.load_netvlad(nv)
+    G = fe.netvlad_dim
+    st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st); s = st.cuda_stream
+    raw = torch.from_numpy(np.stack(raw_views(rank))).to(dev)                 # camera-major, Q = 1
+    maps = [tuple(torch.from_numpy(m).to(dev) for m in maps_np[c]) for c in range(4)]
+    chain = quadcam.QuadcamChain(fe, torch, dev, Q, UH, UW, CAP, undistort_fov=200.0, knn_ratio=0.8, search_local_max_dist=0.2)
+
+    # ---- the oracle's view of BOTH agents ------------------------------------------------------------------------------------------
+    ref = {}
+    for r in range(world):
+        for v, im in enumerate(raw_views(r)):
+            und = orc.undistort(im, *maps_np[v])
+            rk, rs, rd, _, _ = orc.extract_b(und, w, 0.015, 1, CAP)
+            ref[(r, v)] = (rk, rs, rd, orc.netvlad_forward(und, nv))
+    other = 1 - rank
+    loc_g = np.stack([ref[(rank, v)][3] for v in range(4)]); rem_g = np.stack([ref[(other, v)][3] for v in range(4)])
+    sims_all = loc_g @ rem_g[2]
+    srt = np.sort(sims_all)
+    assert srt[-1] - srt[-2] > 5e-3, "the scene must single out one local view for the remote view 2 (%s)" % srt
+    thres = float(0.5 * (srt[-1] + srt[-2]))
+    qs = swarm.QuadSwarm(chain, torch, dev, world, rank, G, thres, mode=mode)
+
+    chain.step(raw, RH, RW, maps, s)
+    qs.step(s)
+    torch.cuda.synchronize()
+
+    # ---- blocks ------------------------------------------------------------------------------------------------------------------------
+    off = {f: api.block_field_offset(CAP, G, f) for f in ("desc", "kps", "scores", "netvlad", "n")}
+    gh = qs.gath.cpu().numpy()
+    for r in range(world):
+        for v in range(4):
+            rk, rs, rd, rg = ref[(r, v)]
+            b = gh[r, v * Q]
+            n = int(b.view(np.int32)[off["n"]])
+            assert n == len(rk), (r, v, n, len(rk))
+            assert np.array_equal(b[off["kps"]:off["kps"] + 2 * n].reshape(n, 2), rk) and np.array_equal(b[off["scores"]:off["scores"] + n], rs)
+            assert np.abs(b[off["desc"]:off["desc"] + 256 * n].reshape(n, 256) - rd).max() <= 1e-6
+            assert np.abs(b[off["netvlad"]:off["netvlad"] + G] - rg).max() <= 1e-4
+
+    # ---- the gate and the view pairing ---------------------------------------------------------------------------------------------
+    assert qs.njobs == Q and qs.NP == 16 * Q
+    o = orc.tracker_gate(rem_g, loc_g[None], thres, True)
+    assert o is not None and int(qs.n_pass.item()) == 1
+    dir_b = int(qs.dir_prev[0].item())
+    assert dir_b == o["dir_b"] == (2 + other - rank) % 4, (dir_b, o)
+    if spref.available():
+        f = spref.tracker_gate(rem_g, loc_g[None], thres, True)
+        assert f is not None and f["dir_b"] == dir_b and f["pairs"] == o["pairs"]
+    tracked = {(b_view, a_view) for a_view, b_view in o["pairs"]}             # (local view, remote view)
+    assert len(tracked) == 4
+
+    # ---- cross-agent matches: 16 view pairs ----------------------------------------------------------------------------------------
+    mn = qs.mn.cpu().numpy(); mq = qs.mq.cpu().numpy(); mt = qs.mt.cpu().numpy(); md = qs.md.cpu().numpy()
+    n_tracked = 0
+    for lv in range(4):
+        for rv in range(4):
+            p = lv * 4 + rv
+            if mode == "gated" and (lv, rv) not in tracked:
+                assert mn[p] == 0, "a view pair the reference would not track must not be matched"
+                continue
+            rq, rt, rdist = orc.match_knn(ref[(rank, lv)][2], ref[(other, rv)][2], 0.8)
+            n = int(mn[p])
+            # GPU descriptors differ from the oracle's by <= 1e-6: the match LISTS are compared through the GPU's own descriptors
+            da = chain.desc[lv * Q, :int(chain.cnt[lv * Q].item())].cpu().numpy()
+            nb = int(gh[other, rv * Q].view(np.int32)[off["n"]])
+            db = gh[other, rv * Q][off["desc"]:off["desc"] + 256 * nb].reshape(nb, 256)
+            gq, gt, gd = orc.match_knn(da, db, 0.8)
+            assert n == len(gq) and np.array_equal(mq[p, :n], gq) and np.array_equal(mt[p, :n], gt) and np.array_equal(md[p, :n], gd), (lv, rv)
+            assert abs(n - len(rq)) <= 2
+            if (lv, rv) in tracked:
+                n_tracked += n
+    assert n_tracked >= 8, "the views that look at the same scene must produce cross-agent matches (%d)" % n_tracked
+    fe.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d OK: mode %s, rotation dir_b %d, %d matches on the 4 tracked view pairs" % (rank, mode, dir_b, n_tracked))
+
+
+if __name__ == "__main__":
+    main()

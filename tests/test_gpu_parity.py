@@ -222,6 +222,63 @@ def test_match_edge_cases(api, orc):
     fe.close()
 
 
+def _unit(x):
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+SATURATED = ["eight_identical_train_rows", "all_equal_train_set", "self_plus_noise_1e-7", "six_near_copies_of_every_row",
+             "both_sets_all_equal"]
+
+
+@pytest.mark.parametrize("case", SATURATED)
+def test_match_saturated_candidate_lists_are_exact(api, orc, case):
+    """More than four train rows within fp32 round-off of the nearest distance (repeated texture, a frame against a near-copy):
+    the Gram-trick top-4 cannot be trusted there, the kernel must notice and fall back to the exact scan (match.hip header).
+    Indices AND distances bitwise against the oracle and, when present, the reference's own matchKNN (oracle/_ref)."""
+    from oracle import ref
+    rng = np.random.RandomState(11)
+    a = _unit(rng.randn(150, 256)); b = _unit(rng.randn(180, 256))
+    if case == "eight_identical_train_rows":
+        b[20:28] = b[20]; a[5] = _unit(b[20:21] + 1e-3 * rng.randn(1, 256))[0]; a[6] = b[20]
+    elif case == "all_equal_train_set":
+        b[:] = b[0]
+    elif case == "self_plus_noise_1e-7":
+        b = (a + np.float32(1e-7) * rng.randn(*a.shape).astype(np.float32)).astype(np.float32)
+        b = np.concatenate([b, b[::-1][:40]])            # and 40 rows twice, at other indices
+    elif case == "six_near_copies_of_every_row":
+        base = _unit(rng.randn(30, 256))
+        b = np.concatenate([base + np.float32(3e-8) * rng.randn(30, 256).astype(np.float32) for _ in range(6)]).astype(np.float32)
+        a = _unit(base[rng.randint(0, 30, 150)] + 0.05 * rng.randn(150, 256))
+    elif case == "both_sets_all_equal":
+        a[:] = a[0]; b[:] = a[0]
+    fe = _fe(api, 64, 64, 1, api.PREC_F32)
+    fe.match_fallback_rows(reset=True)
+    for ratio in (0.8, 1.5):          # 1.5: ties pass the ratio test, so a wrong index among equals would surface as a wrong match
+        q, t, d = fe.match_knn(a, b, ratio)
+        rq, rt, rd = orc.match_knn(a, b, ratio)
+        assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd), case
+        if ref.available():
+            fq, ft, fd = ref.match_knn(a, b, ratio)
+            assert np.array_equal(q, fq) and np.array_equal(t, ft) and np.array_equal(d, fd), case + " vs reference matchKNN"
+        q, t, d = fe.match_crosscheck(a, b)
+        rq, rt, rd = orc.match_crosscheck(a, b)
+        assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd), case
+    assert fe.match_fallback_rows() > 0, "the saturated rows of %s did not take the exact scan" % case
+    fe.close()
+
+
+def test_match_fallback_is_rare_on_ordinary_descriptors(api, orc):
+    """The fallback is a safety net: on well-separated descriptor sets only a few queries may need it."""
+    fe = _fe(api, 64, 64, 1, api.PREC_F32)
+    fe.match_fallback_rows(reset=True)
+    a, b, _, _ = synth_descriptor_pair(200, 200, 256, seed=5)
+    q, t, d = fe.match_knn(a, b, 0.8)
+    rq, rt, rd = orc.match_knn(a, b, 0.8)
+    assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd)
+    assert fe.match_fallback_rows() <= 40          # of 400 queries
+    fe.close()
+
+
 def test_match_batch_device_equals_host_calls(api, orc):
     """The batched device-resident entry point (what bench.py times) == per-pair host calls == oracle."""
     torch = pytest.importorskip("torch")

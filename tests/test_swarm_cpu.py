@@ -98,3 +98,55 @@ def test_block_layout_matches_the_abi():
         assert api.block_words(cap, G) == swarm.block_words(cap, G)
         for f in ("desc", "kps", "scores", "netvlad", "n"):
             assert api.block_field_offset(cap, G, f) == swarm.block_field_offset(cap, G, f)
+
+
+def _quad_worker(rank, world, port, q):
+    """QuadSwarm's pair layout and exchange on CPU tensors (world 2, gloo): block (r, view, q) addressing inside the gathered buffer."""
+    sys.path.insert(0, ROOT)
+    from d2slam_amd import swarm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Chain:      # the fields QuadSwarm reads of a QuadcamChain
+        Q, NI, cap = 2, 8, 4
+    G = 8
+    qs = swarm.QuadSwarm(Chain, torch, torch.device("cpu"), world, rank, G, 0.5)
+    BLK = qs.BLK
+    blocks = torch.zeros((Chain.NI, BLK))
+    for i in range(Chain.NI):
+        blocks[i, 0] = 1000 * rank + i                       # first descriptor word identifies (rank, view*Q + q)
+        blocks[i].view(torch.int32)[qs.n_off] = 1 + i % Chain.cap
+    swarm.all_gather_blocks(qs.gath, blocks)
+    rows = qs.gath.view(-1, 256)
+    first = [float(rows[int(o)][0]) for o in qs.b_off]
+    ncnt = [int(x) for x in qs.gath_i32[qs.rem_blk, qs.n_off]]
+    q.put((rank, qs.jobs, qs.a_off.tolist(), first, ncnt, qs.job_loc.tolist(), qs.job_rem.tolist()))
+    dist.destroy_process_group()
+
+
+def test_quad_swarm_pairs_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_quad_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=120)
+        res[r[0]] = r[1:]
+    [p.join(60) for p in ps]
+    Q, cap = 2, 4
+    for rank in range(world):
+        other = 1 - rank
+        jobs, a_off, first, ncnt, job_loc, job_rem = res[rank]
+        assert jobs == [(other, 0), (other, 1)] and job_loc == [0, 1] and job_rem == [other * 8 + 0, other * 8 + 1]
+        i = 0
+        for (r, qq) in jobs:
+            for lv in range(4):
+                for rv in range(4):
+                    assert a_off[i] == (lv * Q + qq) * cap                     # local view lv of quad frame qq
+                    assert first[i] == 1000 * r + rv * Q + qq                  # remote view rv of the same time index, in place
+                    assert ncnt[i] == 1 + (rv * Q + qq) % cap
+                    i += 1
+        assert i == 32

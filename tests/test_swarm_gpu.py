@@ -37,6 +37,31 @@ def test_world2_cross_agent_matches_equal_oracle():
     assert r.stdout.count(" OK: ") == 2, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("mode", ["gated", "all2all"])
+def test_world2_quadcam_swarm_equals_oracle(mode):
+    """BASELINE configs[4] on one GPU: two quadcam agents, one block per view, the FOURCORNER_FISHEYE gate, view x view matching."""
+    r = _torchrun([os.path.join(ROOT, "tests", "helpers", "quad_swarm_worker.py")], {"QUAD_SWARM_MODE": mode})
+    assert r.returncode == 0, _rank_errors(r)
+    assert r.stdout.count(" OK: ") == 2, r.stdout[-2000:]
+
+
+def test_bench_self_launches_n_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the driver calls it) re-launches itself as 2 ranks; the record
+    carries the process group's own evidence.  gloo: RCCL does not put two ranks on one device."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["D2FE_BENCH_BACKEND"] = "gloo"
+    for extra, key in ((["--frames", "2"], "netvlad_gate"), (["--workload", "quadcam", "--frames", "4"], "cross_agent")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--single-mode",
+                            "--no-cpu-baseline"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, _rank_errors(r)
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert j["n_gpus"] == 2 and j["value"] > 0 and key in j
+        e = j["rccl"]
+        assert e["backend"] == "gloo" and e["world_size"] == 2 and e["allreduce_sum_of_ranks"] == 1.0 and len(e["ranks"]) == 2
+        assert {x["rank"] for x in e["ranks"]} == {0, 1} and len({x["pid"] for x in e["ranks"]}) == 2
+    assert j["cross_agent"]["view_pairs_per_step_per_gpu"] == 16 and j["netvlad_gate"]["jobs"] == 1
+
+
 def test_bench_gpus2_path_runs_under_gloo():
     r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "2", "--single-mode", "--no-cpu-baseline"],
                   {"D2FE_BENCH_BACKEND": "gloo"})
