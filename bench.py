@@ -57,6 +57,9 @@ def main():
                          "latency-bound tail on the handle's tail stream.  Measured slower than plain stream order (2214 vs 2258 stereo fps: the two "
                          "sequences stretch each other, NetVLAD 0.94 -> 1.28 ms), hence off by default")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event breakdown to stderr")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency leg (host-pointer C ABI, one frame per call)")
+    ap.add_argument("--latency-calls", type=int, default=300)
+    ap.add_argument("--latency-only", action="store_true", help="print only the single-call latency leg (A/B runs: D2FE_GRAPH=0, D2FE_PINNED=0)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -95,6 +98,12 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     rccl = collective_evidence(torch, dist, dev, backend, rank, world) if world > 1 else None
+    if args.latency_only:
+        from d2slam_amd import netvlad as nvm
+        print(json.dumps({"latency": run_latency(api, synthetic_superpoint_weights(dustbin_bias=7.5), nvm.synthetic_netvlad_weights(), local_rank,
+                                                 args.precision, args.latency_calls),
+                          "env": {k: os.environ.get(k) for k in ("D2FE_GRAPH", "D2FE_PINNED")}}), flush=True)
+        return
 
     weights = synthetic_superpoint_weights(dustbin_bias=7.5)
     if args.workload == "quadcam":
@@ -307,6 +316,10 @@ def main():
         cpu_baseline = run_cpu_baseline(weights, nv_weights if use_nv else None, args.cpu_seconds)
         parity = run_parity_check(primary, weights, nv_weights if use_nv else None, args.precision)
 
+    latency = None
+    if rank == 0 and world == 1 and not args.single_mode and not args.no_latency:
+        latency = run_latency(api, weights, nv_weights, local_rank, args.precision, args.latency_calls)
+
     quad = None
     if rank == 0 and world == 1 and not args.single_mode:
         qa = argparse.Namespace(**vars(args)); qa.steps = 8; qa.warmup = 2
@@ -352,6 +365,8 @@ def main():
             else:
                 e["precision"] = k; e["parity"] = PAR[k]
             out[names[k]] = e
+        if latency:
+            out["latency"] = latency
         if quad:
             out["quadcam"] = {k: quad[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "avg_keypoints_per_image", "avg_matches_per_pair", "roofline")}
         b = primary["breakdown"]
@@ -526,6 +541,82 @@ def run_quadcam(args, torch, api, weights, dev, local_rank, world, rank=0):
                                "rotation_histogram_dir_prev": {str(k): int((dp == k).sum()) for k in (-1, 0, 1, 2, 3)},
                                "rule": "remote view 2 vs local views 2,3,0,1 in order, first similarity >= threshold (d2featuretracker.cpp:212-233)"}
     fe.close()
+    return out
+
+
+def run_latency(api, weights, nv_weights, device_id, precision, calls):
+    """Single-call latency through the boundary AS THE REFERENCE CALLS IT: one image per SuperPoint::infer / MobileNetVLADONNX::inference
+    call (loop_cam.cpp:609-616), one matchKNN per pair, host pointers in and out (the H2D / D2H copies and the synchronisation are inside).
+    Raw ctypes calls into the C ABI with preallocated buffers; p50 / p99 over `calls` calls after 20 warm-up calls."""
+    import ctypes as C
+    from d2slam_amd.synth import synth_descriptor_pair, synth_image, synth_stereo
+    prec = {"f32": api.PREC_F32, "f16x2": api.PREC_F16X2, "wino": api.PREC_F32_WINO}[precision]
+    lib = api.load_library()
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def stats(fn):
+        for _ in range(20):
+            fn()
+        t = np.empty(calls)
+        for i in range(calls):
+            t0 = time.perf_counter(); fn(); t[i] = time.perf_counter() - t0
+        t *= 1e3
+        return {"p50_ms": round(float(np.percentile(t, 50)), 4), "p99_ms": round(float(np.percentile(t, 99)), 4), "mean_ms": round(float(t.mean()), 4)}
+
+    out = {"calls": calls, "precision": precision, "api": "host-pointer C ABI (sync H2D + kernels + D2H per call), python ctypes with preallocated buffers",
+           "reference_call_sites": "loop_cam.cpp:609-616 (infer / inference, one image per call), d2featuretracker.cpp:1134-1138 (matchKNN)"}
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2, precision=prec, device_id=device_id))
+    fe.load_superpoint(weights)
+    if nv_weights is not None:
+        fe.load_netvlad(nv_weights)
+    h = fe._h
+    l, r = synth_stereo(H, W, seed=3)
+    pair = np.ascontiguousarray(np.stack([l, r]))
+    kps = np.zeros((2, CAP, 2), np.float32); sc = np.zeros((2, CAP), np.float32); desc = np.zeros((2, CAP, 256), np.float32)
+    cnt = np.zeros(2, np.int32)
+    one = lambda: lib.d2fe_superpoint_extract(h, P(pair), W, H, W, P(kps), P(sc), P(desc), CAP, P(cnt))
+    two = lambda: lib.d2fe_superpoint_extract_batch(h, P(pair), 2, W, H, W, H * W, P(kps), P(sc), P(desc), CAP, P(cnt))
+    assert one() == 0 and two() == 0
+    out["d2fe_superpoint_extract_1_image"] = stats(one)
+    out["d2fe_superpoint_extract_batch_2_images"] = stats(two)
+    if nv_weights is not None:
+        g = np.zeros(fe.netvlad_dim, np.float32)
+        nvc = lambda: lib.d2fe_netvlad(h, P(l), W, H, W, P(g))
+        assert nvc() == 0
+        out["d2fe_netvlad_1_image"] = stats(nvc)
+    two()
+    na, nb = int(cnt[0]), int(cnt[1])
+    da, db = desc[0, :na].copy(), desc[1, :nb].copy()
+    q = np.zeros(CAP, np.int32); t = np.zeros(CAP, np.int32); d = np.zeros(CAP, np.float32); nm = C.c_int(0)
+    mk = lambda: lib.d2fe_match_knn(h, P(da), na, P(db), nb, 256, C.c_double(0.8), None, None, C.c_double(-1.0), P(q), P(t), P(d), CAP, C.byref(nm))
+    assert mk() == 0
+    out["d2fe_match_knn_%dx%dx256" % (na, nb)] = stats(mk)
+
+    def stereo():            # what trackLocalFrames costs per stereo frame without NetVLAD: 2 images + L<->R + L<->prevL
+        two(); mk(); mk()
+    out["stereo_frame_2_images_2_matches_host_to_host"] = stats(stereo)
+    if nv_weights is not None:
+        def stereo_nv():
+            two(); nvc(); mk(); mk()
+        out["stereo_frame_with_netvlad_host_to_host"] = stats(stereo_nv)
+    fe.close()
+    # one quadcam frame (configs[2] geometry): 4 undistorted 800x400 views through extract_batch + netvlad_batch
+    UH, UW, CAPQ = 400, 800, 100
+    fq = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAPQ, input_width=UW, input_height=UH, max_batch=4, precision=prec, keypoint_threshold=0.15,
+                                           device_id=device_id))
+    fq.load_superpoint(synthetic_sp_for_threshold(weights))
+    views = np.ascontiguousarray(np.stack([synth_image(UH, UW, 7100 + i) for i in range(4)]))
+    k4 = np.zeros((4, CAPQ, 2), np.float32); s4 = np.zeros((4, CAPQ), np.float32); d4 = np.zeros((4, CAPQ, 256), np.float32); c4 = np.zeros(4, np.int32)
+    quad = lambda: lib.d2fe_superpoint_extract_batch(fq._h, P(views), 4, UW, UH, UW, UH * UW, P(k4), P(s4), P(d4), CAPQ, P(c4))
+    assert quad() == 0
+    out["quadcam_frame_4_views_800x400_extract_batch"] = stats(quad)
+    if nv_weights is not None:
+        fq.load_netvlad(nv_weights)
+        g4 = np.zeros((4, fq.netvlad_dim), np.float32)
+        qnv = lambda: lib.d2fe_netvlad_batch(fq._h, P(views), 4, UW, UH, UW, UH * UW, P(g4))
+        assert qnv() == 0
+        out["quadcam_frame_4_views_netvlad_batch"] = stats(qnv)
+    fq.close()
     return out
 
 

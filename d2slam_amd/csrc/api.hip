@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <array>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -78,6 +80,16 @@ struct d2fe_context {
   const uint8_t* last_gray = nullptr; int last_stride = 0; size_t last_istride = 0;
   float* aconf = nullptr; int* clist = nullptr; int* a_ncand = nullptr;     // variant A scratch
   float* zeros = nullptr;      // 1 KiB of zeros (ConvArgs::zeros)
+  // host-pointer calls: pinned host staging (one DMA in, one DMA out per call) and cached hipGraphs of the launch sequences.
+  // The reference calls infer / inference with ONE image at 15-30 Hz (loop_cam.cpp:609-616): at that batch the ~10 us the command
+  // processor spends between two dependent launches and the per-copy latency of pageable D2H copies are a third of a call.
+  uint8_t* pin_in = nullptr; size_t pin_in_bytes = 0;
+  float* pin_out = nullptr; size_t pin_out_bytes = 0;
+  float* s_out = nullptr;      // device: [kps | scores | desc | n] of a host-pointer extract call, contiguous -> ONE D2H
+  bool use_graphs = true, use_pinned = true;       // D2FE_GRAPH=0 / D2FE_PINNED=0 switch them off (A/B measurements)
+  struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; bool bad = false; };
+  std::map<std::array<long, 6>, GraphEntry> graphs;
+  int ncu = 256;               // compute units of cfg.device_id, read once by d2fe_create (ConvArgs::ncu)
   int32_t* match_stats = nullptr;   // [4] matcher counters: [0] queries that took the exact fallback scan (MatchArgs::stats)
   int* work_ctrs = nullptr;    // one work-item counter per Winograd layer, zeroed at the start of every network pass (ConvArgs::work_ctr)
   bool wino_dynamic = true;    // D2FE_WINO_DYNAMIC=0: static round-robin split of the work items
@@ -110,7 +122,7 @@ struct d2fe_context {
   bool fuse1a = true;      // conv1a fused into conv1b's staging (D2FE_FUSE1A=0 keeps the stand-alone conv1a kernel)
   // host-pointer matcher: pool of (stream, scratch) slots so that concurrent callers (the reference calls matchKNN from three
   // threads) neither share state nor pay hipStreamCreate / hipMalloc / hipFree (a device-wide sync) per call
-  struct MatchSlot { hipStream_t stream = nullptr; char* buf = nullptr; bool busy = false; };
+  struct MatchSlot { hipStream_t stream = nullptr; char* buf = nullptr; char* pin = nullptr; bool busy = false; };
   std::deque<MatchSlot> match_slots;     // deque: growing it never relocates the slots other threads are using
   std::mutex match_mu;
   // device-API matcher scratch (cand4), one per caller stream: calls on different streams may overlap on the GPU
@@ -217,6 +229,43 @@ struct ProfScope {
   }
 };
 
+// weights / PCA matrices were (re)loaded: the captured launch sequences hold the old device pointers
+void graphs_clear(d2fe_context* h) {
+  if (h->graphs.empty()) return;
+  (void)hipStreamSynchronize(h->stream);
+  for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  h->graphs.clear();
+}
+
+// Runs `fn(s)` -- a launch sequence on `s` whose arguments are a pure function of `key` (handle-owned buffers only) -- directly the
+// first time a key is seen (module loads, function attributes, lazy allocations happen there), captures it into a hipGraph the second
+// time and replays the instantiated graph from then on.  Anything that cannot be captured marks the key bad and runs directly.
+template <class F>
+int run_cached(d2fe_context* h, const std::array<long, 6>& key, hipStream_t s, F&& fn) {
+  if (!h->use_graphs || h->prof_mode != 0) return fn(s);
+  auto& e = h->graphs[key];
+  if (e.bad) return fn(s);
+  if (e.exec) { HIP_TRY(hipGraphLaunch(e.exec, s)); return D2FE_OK; }
+  if (e.seen++ < 1) return fn(s);
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); e.bad = true; return fn(s); }
+  const int rc = fn(s);
+  hipGraph_t g = nullptr;
+  const hipError_t er = hipStreamEndCapture(s, &g);
+  if (rc != D2FE_OK || er != hipSuccess || !g) {
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    e.bad = true;
+    return rc != D2FE_OK ? rc : fn(s);
+  }
+  hipGraphExec_t ex = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (ei != hipSuccess || !ex) { (void)hipGetLastError(); e.bad = true; return fn(s); }
+  e.exec = ex;
+  HIP_TRY(hipGraphLaunch(e.exec, s));
+  return D2FE_OK;
+}
+
 // the launch sequence == one TensorRT executeV2 + processOutput of the reference
 int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int stride, size_t image_stride,
                    float* d_kps, float* d_scores, float* d_desc, int32_t* d_idx, int cap, int32_t* d_n, hipStream_t s,
@@ -236,7 +285,7 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     a.out = out; a.out_cstride = ocs; a.out_coff = 0;
     a.cout_real = L.cout; a.wpack = L.wpack; a.bias = L.bias;
     a.img = d_gray; a.img_stride = stride; a.img_istride = (long)image_stride; a.w1a = h->w1a; a.b1a = h->b1a;
-    a.H = hh; a.W = ww; a.n_img = n; a.in_img_stride = iis; a.out_img_stride = ois; a.zeros = h->zeros;
+    a.H = hh; a.W = ww; a.n_img = n; a.in_img_stride = iis; a.out_img_stride = ois; a.zeros = h->zeros; a.ncu = h->ncu;
     a.tag = (&L == &h->L[L_1B]) ? 1 : 0;
     a.work_ctr = (prec == D2FE_PREC_F32_WINO && h->wino_dynamic) ? h->work_ctrs + (int)(&L - &h->L[0]) : nullptr;
     { static int ab = -1; if (ab < 0) { const char* e = getenv("D2FE_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
@@ -294,7 +343,7 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, W, h->cfg.max_keypoints, cap, 1, d_kps, d_scores, d_idx,
                             d_n, s));
     if ((long)H * W > 65536)     // the reference's CV_16UC1 index map wraps above 65 536 candidates; reproduced (no-op below that)
-      HIP_TRY(launch_nms2_wrap_fix(h->clist, h->a_ncand, H, W, n, d_kps, d_n, cap, s));
+      HIP_TRY(launch_nms2_wrap_fix(h->clist, h->a_ncand, H, W, n, d_kps, d_idx, d_n, cap, s));
   } else {
     ProfScope ps(h, D2FE_PROF_SELECT, s);
     HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, Wc * 8, h->cfg.max_keypoints, cap, 0, d_kps, d_scores, d_idx,
@@ -369,6 +418,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   if (!cfg || !out) return fail(D2FE_ERR_INVALID, "null argument");
   *out = nullptr;
   if (cfg->struct_size != (int32_t)sizeof(d2fe_config)) return fail(D2FE_ERR_INVALID, "d2fe_config size mismatch");
+  if (!(cfg->keypoint_threshold >= 0.f)) return fail(D2FE_ERR_INVALID, "keypoint_threshold must be >= 0 (scores are probabilities)");
   if (cfg->max_width < 16 || cfg->max_height < 16) return fail(D2FE_ERR_INVALID, "max_width/max_height must be at least 16");
   if (cfg->max_batch < 1) return fail(D2FE_ERR_INVALID, "max_batch < 1");
   // -1 = keep every keypoint above the threshold (SuperPoint::topKeypoints only truncates when k != -1, superpoint_tensorrt.cpp:241-253;
@@ -429,6 +479,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     }
     HIP_TRY(hipMalloc(&h->zeros, 1024));
     HIP_TRY(hipMemset(h->zeros, 0, 1024));
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device_id) == hipSuccess && v > 0) h->ncu = v; }
     HIP_TRY(hipMalloc(&h->match_stats, 4 * sizeof(int32_t)));
     HIP_TRY(hipMemset(h->match_stats, 0, 4 * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&h->work_ctrs, 64 * sizeof(int)));
@@ -449,6 +500,20 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     HIP_TRY(hipMalloc(&h->s_desc, sizeof(float) * 256 * h->s_cap * B));
     HIP_TRY(hipMalloc(&h->s_idx, sizeof(int32_t) * h->s_cap * B));
     HIP_TRY(hipMalloc(&h->s_n, sizeof(int32_t) * B));
+    HIP_TRY(hipMalloc(&h->s_out, (sizeof(float) * (size_t)h->s_cap * 259 + sizeof(int32_t)) * B));
+    { const char* e = getenv("D2FE_GRAPH"); if (e) h->use_graphs = atoi(e) != 0; }
+    { const char* e = getenv("D2FE_PINNED"); if (e) h->use_pinned = atoi(e) != 0; }
+    if (h->use_pinned) {
+      h->pin_in_bytes = (size_t)H * W * B;
+      h->pin_out_bytes = (sizeof(float) * (size_t)h->s_cap * 259 + sizeof(int32_t)) * B;
+      if (h->pin_out_bytes < sizeof(float) * 8192 * (size_t)B) h->pin_out_bytes = sizeof(float) * 8192 * (size_t)B;      // NetVLAD descriptors
+      if (hipHostMalloc(&h->pin_in, h->pin_in_bytes, hipHostMallocDefault) != hipSuccess ||
+          hipHostMalloc(&h->pin_out, h->pin_out_bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        if (h->pin_in) { (void)hipHostFree(h->pin_in); h->pin_in = nullptr; }
+        h->pin_out = nullptr; h->use_pinned = false;        // not fatal: the pageable path remains
+      }
+    }
     return D2FE_OK;
   }();
   if (rc_alloc != D2FE_OK) { d2fe_destroy(h); return rc_alloc; }   // everything allocated so far is released
@@ -475,14 +540,19 @@ void d2fe_destroy(d2fe_handle h) {
     if (p) hipFree(p);
   nv_free(h);
   for (void* p : {(void*)h->nv_pca_comp, (void*)h->nv_pca_mean, (void*)h->nv_s_img, (void*)h->nv_s_out}) if (p) hipFree(p);
+  for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  if (h->pin_in) (void)hipHostFree(h->pin_in);
+  if (h->pin_out) (void)hipHostFree(h->pin_out);
+  if (h->s_out) hipFree(h->s_out);
   for (auto& sc : h->m_scratch) if (sc.cand4) hipFree(sc.cand4);
-  for (auto& ms : h->match_slots) { if (ms.stream) { hipStreamSynchronize(ms.stream); (void)hipStreamDestroy(ms.stream); } if (ms.buf) hipFree(ms.buf); }
+  for (auto& ms : h->match_slots) { if (ms.stream) { hipStreamSynchronize(ms.stream); (void)hipStreamDestroy(ms.stream); } if (ms.buf) hipFree(ms.buf); if (ms.pin) (void)hipHostFree(ms.pin); }
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
 int d2fe_load_superpoint(d2fe_handle h, const d2fe_superpoint_weights* w) {
+  if (h) graphs_clear(h);
   if (!h || !w) return fail(D2FE_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   static const struct { const char* name; int cout, cin, ks; } spec[D2FE_SP_NUM_LAYERS] = {
@@ -529,6 +599,7 @@ int d2fe_load_superpoint(d2fe_handle h, const d2fe_superpoint_weights* w) {
 }
 
 int d2fe_set_superpoint_pca(d2fe_handle h, const float* comp, const float* mean, int pca_dims) {
+  if (h) graphs_clear(h);
   if (!h) return fail(D2FE_ERR_INVALID, "null handle");
   if (pca_dims < 0 || pca_dims > 256 || (pca_dims > 0 && (!comp || !mean))) return fail(D2FE_ERR_INVALID, "bad PCA arguments");
   if (pca_dims > 0 && h->cfg.postproc != D2FE_POSTPROC_A)
@@ -588,6 +659,32 @@ int d2fe_superpoint_wait_tail(d2fe_handle h, void* stream) {
   return D2FE_OK;
 }
 
+// host image(s) -> the handle's device staging, tight rows: through the pinned staging buffer (CPU row copy + ONE DMA) or, when that
+// is off, with pageable 2D copies
+static int upload_frames(d2fe_context* h, uint8_t* d_dst, const uint8_t* gray, int n, int width, int height, int stride, size_t image_stride,
+                         hipStream_t s) {
+  const size_t bytes = (size_t)width * height * n;
+  if (h->use_pinned && bytes <= h->pin_in_bytes) {
+    HIP_TRY(hipStreamSynchronize(s));            // the previous call's DMA out of pin_in has completed (calls are synchronous: a no-op)
+    for (int i = 0; i < n; ++i) {
+      const uint8_t* src = gray + i * image_stride;
+      uint8_t* dst = h->pin_in + (size_t)i * width * height;
+      if (stride == width) memcpy(dst, src, (size_t)width * height);
+      else for (int y = 0; y < height; ++y) memcpy(dst + (size_t)y * width, src + (size_t)y * stride, width);
+    }
+    HIP_TRY(hipMemcpyAsync(d_dst, h->pin_in, bytes, hipMemcpyHostToDevice, s));
+    return D2FE_OK;
+  }
+  if (image_stride == (size_t)stride * height) {
+    HIP_TRY(hipMemcpy2DAsync(d_dst, width, gray, stride, width, (size_t)height * n, hipMemcpyHostToDevice, s));
+  } else {
+    for (int i = 0; i < n; ++i)
+      HIP_TRY(hipMemcpy2DAsync(d_dst + (size_t)i * width * height, width, gray + i * image_stride, stride, width, height,
+                               hipMemcpyHostToDevice, s));
+  }
+  return D2FE_OK;
+}
+
 int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int height, int stride,
                                   size_t image_stride, float* kps_xy, float* scores, float* desc, int cap, int* n_out) {
   if (n_out) for (int i = 0; i < (n > 0 ? n : 0); ++i) n_out[i] = 0;
@@ -597,37 +694,57 @@ int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   const int dcap = cap < h->s_cap ? cap : h->s_cap;
   hipStream_t s = h->stream;
-  // tightly pack rows on upload (stride -> width)
-  if (image_stride == (size_t)stride * height) {
-    HIP_TRY(hipMemcpy2DAsync(h->s_img, width, gray, stride, width, (size_t)height * n, hipMemcpyHostToDevice, s));
-  } else {
-    for (int i = 0; i < n; ++i)
-      HIP_TRY(hipMemcpy2DAsync(h->s_img + (size_t)i * width * height, width, gray + i * image_stride, stride, width, height,
-                               hipMemcpyHostToDevice, s));
-  }
+  rc = upload_frames(h, h->s_img, gray, n, width, height, stride, image_stride, s);
+  if (rc) return rc;
   // async_tail handles: a preceding d2fe_superpoint_extract_device call may still have its post-processing running on the tail
   // stream against the single-buffered scratch (candidates, score map, sparse-head slots) that this run uses too
   if (h->cfg.async_tail)
     for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(s, h->ev_tail[i], 0));
-  rc = run_superpoint(h, h->s_img, n, width, height, width, (size_t)width * height, h->s_kps, h->s_scores, h->s_desc,
-                      h->s_idx, dcap, h->s_n, s);
-  if (rc) return rc;
-  std::vector<int32_t> cnt(n);
+  // outputs of the call, contiguous in one device block: kps [n][dcap][2] | scores [n][dcap] | desc [n][dcap][D] | counts [n]
   const size_t D = (h->cfg.postproc == D2FE_POSTPROC_A && h->pca_dims) ? (size_t)h->pca_dims : 256;
-  HIP_TRY(hipMemcpyAsync(cnt.data(), h->s_n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+  float* o_kps = h->s_out;
+  float* o_sc = o_kps + (size_t)n * dcap * 2;
+  float* o_desc = o_sc + (size_t)n * dcap;
+  int32_t* o_n = reinterpret_cast<int32_t*>(o_desc + (size_t)n * dcap * D);
+  const size_t out_bytes = sizeof(float) * (size_t)n * dcap * (3 + D) + sizeof(int32_t) * n;
+  rc = run_cached(h, {1, n, width, height, dcap, (long)D}, s, [&](hipStream_t st) {
+    return run_superpoint(h, h->s_img, n, width, height, width, (size_t)width * height, o_kps, o_sc, o_desc, h->s_idx, dcap, o_n, st);
+  });
+  if (rc) return rc;
   std::vector<int32_t> ncand(h->cfg.max_keypoints < 0 ? n : 0);
   if (!ncand.empty()) HIP_TRY(hipMemcpyAsync(ncand.data(), h->cand_count, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  for (int i = 0; i < n; ++i) {
-    const int k = cnt[i];
-    n_out[i] = k;
-    if (k > 0) {
-      HIP_TRY(hipMemcpyAsync(kps_xy + (size_t)i * cap * 2, h->s_kps + (size_t)i * dcap * 2, sizeof(float) * 2 * k, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipMemcpyAsync(scores + (size_t)i * cap, h->s_scores + (size_t)i * dcap, sizeof(float) * k, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipMemcpyAsync(desc + (size_t)i * cap * D, h->s_desc + (size_t)i * dcap * D, sizeof(float) * D * k, hipMemcpyDeviceToHost, s));
+  if (h->use_pinned && out_bytes <= h->pin_out_bytes) {
+    // ONE D2H of the whole block into pinned memory, one synchronisation, then the rows that exist go to the caller's arrays
+    HIP_TRY(hipMemcpyAsync(h->pin_out, h->s_out, out_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const float* p_kps = h->pin_out;
+    const float* p_sc = p_kps + (size_t)n * dcap * 2;
+    const float* p_desc = p_sc + (size_t)n * dcap;
+    const int32_t* p_n = reinterpret_cast<const int32_t*>(p_desc + (size_t)n * dcap * D);
+    for (int i = 0; i < n; ++i) {
+      const int k = p_n[i] < dcap ? p_n[i] : dcap;
+      n_out[i] = k;
+      if (k > 0) {
+        memcpy(kps_xy + (size_t)i * cap * 2, p_kps + (size_t)i * dcap * 2, sizeof(float) * 2 * k);
+        memcpy(scores + (size_t)i * cap, p_sc + (size_t)i * dcap, sizeof(float) * k);
+        memcpy(desc + (size_t)i * cap * D, p_desc + (size_t)i * dcap * D, sizeof(float) * D * k);
+      }
     }
+  } else {
+    std::vector<int32_t> cnt(n);
+    HIP_TRY(hipMemcpyAsync(cnt.data(), o_n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) {
+      const int k = cnt[i];
+      n_out[i] = k;
+      if (k > 0) {
+        HIP_TRY(hipMemcpyAsync(kps_xy + (size_t)i * cap * 2, o_kps + (size_t)i * dcap * 2, sizeof(float) * 2 * k, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(scores + (size_t)i * cap, o_sc + (size_t)i * dcap, sizeof(float) * k, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(desc + (size_t)i * cap * D, o_desc + (size_t)i * dcap * D, sizeof(float) * D * k, hipMemcpyDeviceToHost, s));
+      }
+    }
+    HIP_TRY(hipStreamSynchronize(s));
   }
-  HIP_TRY(hipStreamSynchronize(s));
   for (int32_t c : ncand)
     if (c > dcap) return fail(D2FE_ERR_TRUNCATED, "max_keypoints = -1: an image has more keypoints than the call's capacity; the strongest were kept");
   return D2FE_OK;
@@ -756,6 +873,7 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
 }  // namespace
 
 int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
+  if (h) graphs_clear(h);
   if (!h || !w || !w->layers || w->n_layers < 1) return fail(D2FE_ERR_INVALID, "null argument");
   if (!w->pre_w || !w->pre_b || !w->assign_w || !w->assign_b || !w->centroids) return fail(D2FE_ERR_INVALID, "null head weights");
   if (w->n_clusters < 1 || w->n_clusters > 64 || w->proj_dim < 4 || w->proj_dim > 256 || (w->proj_dim & 3) ||
@@ -945,6 +1063,7 @@ long d2fe_debug_netvlad_layer(d2fe_handle h, int layer, int n_images, void* dst,
 }
 
 int d2fe_set_netvlad_pca(d2fe_handle h, const float* comp, const float* mean, int m) {
+  if (h) graphs_clear(h);
   if (!h) return fail(D2FE_ERR_INVALID, "null handle");
   if (!h->nv_loaded) return fail(D2FE_ERR_NOT_READY, "netvlad weights not loaded");
   const int G = h->nv_k * h->nv_proj;
@@ -992,14 +1111,22 @@ int d2fe_netvlad_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int
   if (!gray || !out) return fail(D2FE_ERR_INVALID, "null pointer");
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   hipStream_t s = h->stream;
-  for (int i = 0; i < n; ++i)
-    HIP_TRY(hipMemcpy2DAsync(h->nv_s_img + (size_t)i * width * height, width, gray + i * image_stride, stride, width, height,
-                             hipMemcpyHostToDevice, s));
-  rc = run_netvlad(h, h->nv_s_img, n, width, height, width, (size_t)width * height, h->nv_s_out, s);
+  rc = upload_frames(h, h->nv_s_img, gray, n, width, height, stride, image_stride, s);
+  if (rc) return rc;
+  rc = run_cached(h, {2, n, width, height, (long)h->nv_pca_m, 0}, s, [&](hipStream_t st) {
+    return run_netvlad(h, h->nv_s_img, n, width, height, width, (size_t)width * height, h->nv_s_out, st);
+  });
   if (rc) return rc;
   const int G = d2fe_netvlad_dim(h);
-  HIP_TRY(hipMemcpyAsync(out, h->nv_s_out, sizeof(float) * (size_t)G * n, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  const size_t bytes = sizeof(float) * (size_t)G * n;
+  if (h->use_pinned && bytes <= h->pin_out_bytes) {
+    HIP_TRY(hipMemcpyAsync(h->pin_out, h->nv_s_out, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    memcpy(out, h->pin_out, bytes);
+  } else {
+    HIP_TRY(hipMemcpyAsync(out, h->nv_s_out, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
   return D2FE_OK;
 }
 
@@ -1354,10 +1481,11 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
   if (dim < 4 || dim > 256 || (dim & 3)) return fail(D2FE_ERR_INVALID, "dim must be a multiple of 4 in 4..256");
   // a private (stream, scratch) slot per call in flight: re-entrant; slots are created on demand and reused
   constexpr size_t MAXN = 1024, MAXD = 256;
-  constexpr size_t SLOT_BYTES = sizeof(float) * (2 * MAXN * MAXD + 4 * MAXN + MAXN) + sizeof(int32_t) * (2 * MAXN + 5 + 8 * MAXN) + 64;
+  constexpr size_t SLOT_BYTES = sizeof(float) * (2 * MAXN * MAXD + 4 * MAXN + MAXN) + sizeof(int32_t) * (2 * MAXN + 8 + 8 * MAXN) + 64;
   int slot = -1;
   hipStream_t s = nullptr;
   char* buf = nullptr;
+  char* pin = nullptr;
   {
     std::lock_guard<std::mutex> lk(h->match_mu);
     for (size_t i = 0; i < h->match_slots.size(); ++i)
@@ -1366,41 +1494,75 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
       d2fe_context::MatchSlot ms;
       if (hipStreamCreateWithFlags(&ms.stream, hipStreamNonBlocking) != hipSuccess) return fail(D2FE_ERR_HIP, "hipStreamCreate (match slot)");
       if (hipMalloc(&ms.buf, SLOT_BYTES) != hipSuccess) { hipStreamDestroy(ms.stream); return fail(D2FE_ERR_HIP, "hipMalloc match scratch"); }
+      if (h->use_pinned && hipHostMalloc(&ms.pin, SLOT_BYTES, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ms.pin = nullptr; }
       h->match_slots.push_back(ms);
       slot = (int)h->match_slots.size() - 1;
     }
     h->match_slots[slot].busy = true;
     s = h->match_slots[slot].stream;      // read under the lock: another thread may be appending a slot right now
     buf = h->match_slots[slot].buf;
+    pin = h->match_slots[slot].pin;
   }
   struct Release { d2fe_context* h; int slot; ~Release() { std::lock_guard<std::mutex> lk(h->match_mu); h->match_slots[slot].busy = false; } } release{h, slot};
+  // device layout (words): a | b | pts_a | pts_b | meta {a_off, b_off, a_cnt, b_cnt, pad x4} | n_out, pad x7 | dist | q | t | cand4
+  // -- the inputs are one contiguous run (ONE H2D from the slot's pinned mirror), the outputs another (ONE D2H, one synchronisation)
+  const size_t w_in = fa + fb + (use_pts ? 2 * (size_t)(na + nb) : 0) + 8;
   float* d_a = reinterpret_cast<float*>(buf);
   float* d_b = d_a + fa;
   float* d_pa = d_b + fb;
-  float* d_pb = d_pa + 2 * (size_t)na;
-  float* d_dist = d_pb + 2 * (size_t)nb;
+  float* d_pb = d_pa + (use_pts ? 2 * (size_t)na : 0);
+  int32_t* d_meta = reinterpret_cast<int32_t*>(d_pb + (use_pts ? 2 * (size_t)nb : 0));
+  int32_t* d_nout = d_meta + 8;
+  float* d_dist = reinterpret_cast<float*>(d_nout + 8);
   int32_t* d_q = reinterpret_cast<int32_t*>(d_dist + max_n);
   int32_t* d_t = d_q + max_n;
-  int32_t* d_meta = d_t + max_n;  // a_off, b_off, a_cnt, b_cnt, n_out
-  int32_t* d_c4 = d_meta + 5;
-  const int32_t meta[5] = {0, 0, na, nb, 0};
+  int32_t* d_c4 = d_t + max_n;
+  const size_t w_out = 8 + 3 * (size_t)max_n;
+  const int32_t meta[8] = {0, 0, na, nb, 0, 0, 0, 0};
   int rc = D2FE_OK;
   auto chk = [&](hipError_t er, const char* what) { if (er != hipSuccess && rc == D2FE_OK) rc = fail(D2FE_ERR_HIP, std::string(what) + ": " + hipGetErrorString(er)); };
-  chk(hipMemcpyAsync(d_a, a, sizeof(float) * fa, hipMemcpyHostToDevice, s), "H2D a");
-  chk(hipMemcpyAsync(d_b, b, sizeof(float) * fb, hipMemcpyHostToDevice, s), "H2D b");
-  if (use_pts) {
-    chk(hipMemcpyAsync(d_pa, pts_a, sizeof(float) * 2 * na, hipMemcpyHostToDevice, s), "H2D pts_a");
-    chk(hipMemcpyAsync(d_pb, pts_b, sizeof(float) * 2 * nb, hipMemcpyHostToDevice, s), "H2D pts_b");
+  if (pin) {
+    float* p = reinterpret_cast<float*>(pin);
+    memcpy(p, a, sizeof(float) * fa); memcpy(p + fa, b, sizeof(float) * fb);
+    float* pm = p + fa + fb;
+    if (use_pts) { memcpy(pm, pts_a, sizeof(float) * 2 * na); memcpy(pm + 2 * (size_t)na, pts_b, sizeof(float) * 2 * nb); pm += 2 * (size_t)(na + nb); }
+    memcpy(pm, meta, sizeof(meta));
+    chk(hipMemcpyAsync(d_a, pin, sizeof(float) * w_in, hipMemcpyHostToDevice, s), "H2D inputs");
+  } else {
+    chk(hipMemcpyAsync(d_a, a, sizeof(float) * fa, hipMemcpyHostToDevice, s), "H2D a");
+    chk(hipMemcpyAsync(d_b, b, sizeof(float) * fb, hipMemcpyHostToDevice, s), "H2D b");
+    if (use_pts) {
+      chk(hipMemcpyAsync(d_pa, pts_a, sizeof(float) * 2 * na, hipMemcpyHostToDevice, s), "H2D pts_a");
+      chk(hipMemcpyAsync(d_pb, pts_b, sizeof(float) * 2 * nb, hipMemcpyHostToDevice, s), "H2D pts_b");
+    }
+    chk(hipMemcpyAsync(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice, s), "H2D meta");
   }
-  chk(hipMemcpyAsync(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice, s), "H2D meta");
   MatchArgs m;
   m.a = d_a; m.b = d_b; m.pts_a = use_pts ? d_pa : nullptr; m.pts_b = use_pts ? d_pb : nullptr;
   m.a_off = d_meta; m.b_off = d_meta + 1; m.a_cnt = d_meta + 2; m.b_cnt = d_meta + 3;
   m.npairs = 1; m.dim = dim; m.max_n = max_n; m.mode = mode; m.ratio = ratio; m.radius = use_pts ? radius : -1.0;
-  m.q_idx = d_q; m.t_idx = d_t; m.dist = d_dist; m.n_out = d_meta + 4; m.cand4 = d_c4; m.stats = h->match_stats;
+  m.q_idx = d_q; m.t_idx = d_t; m.dist = d_dist; m.n_out = d_nout; m.cand4 = d_c4; m.stats = h->match_stats;
   if (rc == D2FE_OK) chk(launch_match(m, s), "launch_match");
+  if (pin) {
+    // pinned mirror of the output run, behind the inputs' mirror
+    int32_t* po = reinterpret_cast<int32_t*>(pin) + ((w_in + 15) & ~(size_t)15);
+    if (rc == D2FE_OK) chk(hipMemcpyAsync(po, d_nout, sizeof(int32_t) * w_out, hipMemcpyDeviceToHost, s), "D2H results");
+    if (rc == D2FE_OK) chk(hipStreamSynchronize(s), "sync");
+    if (rc == D2FE_OK) {
+      const int cnt = po[0];
+      const int k = cnt < cap ? cnt : cap;
+      if (k > 0) {
+        memcpy(dist, po + 8, sizeof(float) * k);
+        memcpy(q_idx, po + 8 + max_n, sizeof(int32_t) * k);
+        memcpy(t_idx, po + 8 + 2 * (size_t)max_n, sizeof(int32_t) * k);
+      }
+      *n_out = k;
+      if (cnt > cap) rc = fail(D2FE_ERR_TRUNCATED, "match output capacity too small");
+    }
+    return rc;
+  }
   int32_t cnt = 0;
-  if (rc == D2FE_OK) chk(hipMemcpyAsync(&cnt, d_meta + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s), "D2H n");
+  if (rc == D2FE_OK) chk(hipMemcpyAsync(&cnt, d_nout, sizeof(int32_t), hipMemcpyDeviceToHost, s), "D2H n");
   if (rc == D2FE_OK) chk(hipStreamSynchronize(s), "sync");
   if (rc == D2FE_OK) {
     const int k = cnt < cap ? cnt : cap;
@@ -1513,7 +1675,7 @@ int d2fe_debug_conv3x3_wino(d2fe_handle h, const float* in, int n, int H, int W,
     ConvArgs a{};
     a.in = d_in; a.in_cstride = cin; a.in_coff = 0; a.out = d_out; a.out_cstride = cout; a.out_coff = 0;
     a.cout_real = cout; a.wpack = d_w; a.bias = d_b; a.H = H; a.W = W; a.n_img = n;
-    a.in_img_stride = (long)H * W * cin; a.out_img_stride = (long)Ho * Wo * cout; a.zeros = h->zeros;
+    a.in_img_stride = (long)H * W * cin; a.out_img_stride = (long)Ho * Wo * cout; a.zeros = h->zeros; a.ncu = h->ncu;
     { const char* e = getenv("D2FE_ABLATE"); a.ablate = e ? atoi(e) : 0; }
     HIP_TRY(launch_conv_wino(cin, pool != 0, relu != 0, cout_pad, a, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));

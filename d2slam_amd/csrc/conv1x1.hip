@@ -100,12 +100,7 @@ hipError_t launch_conv1x1_256_65(const ConvArgs& a, hipStream_t s) {
   if (a.cout_real != 65 || a.in_img_stride != hw * a.in_cstride || a.out_img_stride != hw * a.out_cstride || a.out_cstride < 65 ||
       (a.in_cstride & 3) || (a.in_coff & 3) || a.in_coff + 256 > a.in_cstride)
     return hipErrorNotSupported;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0; hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return hipErrorUnknown;
-    ncu = p.multiProcessorCount;
-  }
+  const int ncu = a.ncu > 0 ? a.ncu : 256;     // ConvArgs::ncu: the handle's device (no process-wide cache: one process may drive several GPUs)
   const long npix = hw * a.n_img;
   const long n_wg = (npix + 127) / 128;
   const int grid = (int)(n_wg < 2 * ncu ? n_wg : 2 * ncu);

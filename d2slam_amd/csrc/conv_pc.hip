@@ -389,12 +389,7 @@ static hipError_t launch_pc_one(int cout_pad, const ConvArgs& a, hipStream_t s) 
   if (cout_pad % BN) return hipErrorInvalidValue;
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH, ncg = cout_pad / BN;
   const int total = tiles_x * tiles_y * ncg * a.n_img;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0; hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return hipErrorUnknown;
-    ncu = p.multiProcessorCount;
-  }
+  const int ncu = a.ncu > 0 ? a.ncu : 256;     // ConvArgs::ncu: the handle's device (no process-wide cache: one process may drive several GPUs)
   auto k = conv_pc_kernel<MODE, CIN, KS, TH, TW, WM, WN, MT, NT, POOL, RELU, FUSE1A>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

@@ -542,12 +542,7 @@ hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const C
   if ((long)a.H * a.W * a.in_cstride * 4 >= (1l << 31) || (long)a.H * a.W * a.out_cstride * 4 >= (1l << 31)) return hipErrorInvalidValue;
   const int nbx = (a.W + 15) / 16, nby = (a.H + 7) / 8, ncb = cout_pad / 64;
   const int total = nbx * nby * ncb * a.n_img;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0; hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return hipErrorUnknown;
-    ncu = p.multiProcessorCount;
-  }
+  const int ncu = a.ncu > 0 ? a.ncu : 256;     // ConvArgs::ncu: the handle's device (no process-wide cache: one process may drive several GPUs)
   const int grid = total < 2 * ncu ? total : 2 * ncu;      // two workgroups per CU (2 waves per SIMD)
   constexpr size_t lds = (size_t)(WR * WCHUNK + WXCH) * sizeof(float) + 16;      // ring + exchange area + the claim slot
 #define D2FE_WINO_K(K)                                                                                       \
@@ -621,12 +616,7 @@ hipError_t launch_conv_wino_fused1b(int cout_pad, const ConvArgs& a, hipStream_t
   if ((long)a.H * a.W * a.out_cstride >= (1l << 29)) return hipErrorInvalidValue;
   const int nbx = (a.W + 15) / 16, nby = (a.H + 7) / 8, ncb = 1;
   const int total = nbx * nby * a.n_img;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0; hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return hipErrorUnknown;
-    ncu = p.multiProcessorCount;
-  }
+  const int ncu = a.ncu > 0 ? a.ncu : 256;     // ConvArgs::ncu: the handle's device (no process-wide cache: one process may drive several GPUs)
   const int grid = total < 2 * ncu ? total : 2 * ncu;
   constexpr size_t lds = (size_t)8 * 2 * 4 * 272 * sizeof(float) + 256 + 16;      // the 64-channel patch (the exchange area, 48 KiB, reuses it) + the 12 x 20 frame bytes
   static_assert(lds >= (size_t)WXCH * sizeof(float), "exchange area must fit into the patch buffer");

@@ -23,6 +23,7 @@ struct ConvArgs {
   int tag;                  // 1: conv1b (the dominant launch gets its own kernel instantiation so that rocprofv3 --stats lists it by itself)
   int ablate;               // experiment knob (D2FE_ABLATE): 1 skip patch loads, 2 skip B reloads, 4 skip stores
   int* work_ctr = nullptr;  // Winograd kernels: zeroed device counter -> work items are claimed dynamically (null: static round-robin split)
+  int ncu = 0;              // compute units of the handle's device (d2fe_create reads it once): the persistent kernels size their grids on it
 };
 
 enum ConvShape {
@@ -82,8 +83,8 @@ hipError_t launch_desc_head_sparse(const float* kps_xy, const int32_t* n_kp, int
 // variant A (SuperPointONNX path): NMS2-exact and grid_sampler(align_corners=false) sampling with optional PCA
 hipError_t launch_nms2_a(const float* semi, int H, int W, int n_img, float thr, int dist, float* aconf, int* clist,
                          unsigned long long* cand, int* cand_count, long cand_cap, int* ncand, hipStream_t s);
-hipError_t launch_nms2_wrap_fix(const int* clist, const int* ncand, int H, int W, int n_img, float* kps_xy, const int32_t* n_kp,
-                                int cap, hipStream_t s);
+hipError_t launch_nms2_wrap_fix(const int* clist, const int* ncand, int H, int W, int n_img, float* kps_xy, int32_t* kps_idx,
+                                const int32_t* n_kp, int cap, hipStream_t s);
 hipError_t launch_sample_a(const float* desc_raw, int dstride, int dcoff, int Hc, int Wc, int img_w, int img_h, int n_img,
                            const float* kps_xy, const int32_t* n_kp, int cap, const float* comp_t, const float* mean,
                            int pca_dims, float* samp, int scap, float* cn, const int32_t* slotmap, int max_slots, float* desc_out,

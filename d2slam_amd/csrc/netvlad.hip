@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256) void nv_vlad_mfma_kernel(const float* __restri
 __global__ __launch_bounds__(1024) void nv_vlad_final_mfma_kernel(const float* __restrict__ part, int nchunk, const float* __restrict__ cen,
                                                                   float* __restrict__ out) {
   __shared__ float red[34];
+  __shared__ float red2[16];
   __shared__ float S[32];
   const int img = blockIdx.x, tid = threadIdx.x;
   const float* pp = part + (size_t)img * nchunk * 32 * VM_PP;
@@ -374,9 +375,13 @@ __global__ __launch_bounds__(1024) void nv_vlad_final_mfma_kernel(const float* _
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-  if ((tid & 63) == 0) atomicAdd(&red[32], tot);
+  // 16 wave partials summed in wave order by every thread: no float atomic, the descriptor is reproducible run to run
+  if ((tid & 63) == 0) red2[tid >> 6] = tot;
   __syncthreads();
-  const float nt = __builtin_sqrtf(red[32]);
+  float gsum = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) gsum += red2[w];
+  const float nt = __builtin_sqrtf(gsum);
 #pragma unroll
   for (int r = 0; r < 4; ++r) out[(size_t)img * 4096 + tid + 1024 * r] = v[r] / (nt > 1e-12f ? nt : 1e-12f);
 }

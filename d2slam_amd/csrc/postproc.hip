@@ -598,7 +598,7 @@ __global__ __launch_bounds__(1024) void nms2_a_kernel(const float* __restrict__ 
   for (int w = 0; w < 16; ++w) { if (w < wv) wbase += s_wcnt[w]; n += s_wcnt[w]; }
   for (size_t i0 = seg0; i0 < seg1; i0 += 64) {
     const size_t i = i0 + lane;
-    const bool c = i < seg1 && ac[i] != 0.f;
+    const bool c = i < seg1 && sm[i] > thr;          // the SAME predicate as pass 1 (a negative threshold admits p == 0, whose aconf is 0)
     const unsigned long long m = __ballot(c);
     if (c) cl[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (int)i;
     wbase += __popcll(m);
@@ -659,7 +659,8 @@ hipError_t launch_nms2_a(const float* semi, int H, int W, int n_img, float thr, 
 // CV_16UC1 wrap of NMS2's index map (superpoint_common.cpp:115,128,160-163), applied to the selected keypoints of an image
 // with more than 65 536 candidates: keypoint at pixel i (rank r in the raster-ordered candidate list) -> pixel clist[r & 0xFFFF].
 __global__ __launch_bounds__(256) void nms2_wrap_fix_kernel(const int* __restrict__ clist, const int* __restrict__ ncand, int H, int W,
-                                                            float* __restrict__ kps_xy, const int32_t* __restrict__ n_kp, int cap) {
+                                                            float* __restrict__ kps_xy, int32_t* __restrict__ kps_idx,
+                                                            const int32_t* __restrict__ n_kp, int cap) {
   const int img = blockIdx.y;
   const int n = ncand[img];
   if (n <= 65536) return;
@@ -672,10 +673,11 @@ __global__ __launch_bounds__(256) void nms2_wrap_fix_kernel(const int* __restric
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (cl[mid] < i) lo = mid + 1; else hi = mid; }
   const int j = cl[lo & 0xFFFF];
   kp[0] = (float)(j % W); kp[1] = (float)(j / W);
+  if (kps_idx) kps_idx[(size_t)img * cap + k] = j;       // the raster index output follows the reported coordinates
 }
-hipError_t launch_nms2_wrap_fix(const int* clist, const int* ncand, int H, int W, int n_img, float* kps_xy, const int32_t* n_kp,
-                                int cap, hipStream_t s) {
-  hipLaunchKernelGGL(nms2_wrap_fix_kernel, dim3((cap + 255) / 256, n_img), dim3(256), 0, s, clist, ncand, H, W, kps_xy, n_kp, cap);
+hipError_t launch_nms2_wrap_fix(const int* clist, const int* ncand, int H, int W, int n_img, float* kps_xy, int32_t* kps_idx,
+                                const int32_t* n_kp, int cap, hipStream_t s) {
+  hipLaunchKernelGGL(nms2_wrap_fix_kernel, dim3((cap + 255) / 256, n_img), dim3(256), 0, s, clist, ncand, H, W, kps_xy, kps_idx, n_kp, cap);
   return hipGetLastError();
 }
 

