@@ -152,22 +152,24 @@ def test_score_ties_use_raster_tiebreak(api, orc, sp_weights):
     fe.close()
 
 
-@pytest.mark.parametrize("H,W", [(96, 128), (480, 640)])
-def test_fast_mode_tolerances(api, orc, sp_weights, H, W):
+# every BASELINE geometry: d435 640x480 N=200, quadcam 800x400 N=100 (threshold 0.15 there; the tolerance test keeps 0.015 so that the
+# top-K boundary is exercised), TUM 512x512 N=150
+@pytest.mark.parametrize("H,W,N", [(96, 128, 200), (480, 640, 200), (400, 800, 100), (512, 512, 150)])
+def test_fast_mode_tolerances(api, orc, sp_weights, H, W, N):
     imgs = np.stack(synth_stereo(H, W, seed=3))
-    fe = _fe(api, H, W, 2, api.PREC_F16X2, dense=True)
+    fe = _fe(api, H, W, 2, api.PREC_F16X2, dense=True, max_kp=N)
     fe.load_superpoint(sp_weights)
-    res = fe.extract_batch(imgs, cap=200)
+    res = fe.extract_batch(imgs, cap=N)
     for i in range(2):
         f = orc.superpoint_forward(imgs[i], sp_weights)
         semi = fe.debug_read("semi", (2, H, W))[i]
         assert np.abs(semi - f["semi"]).max() <= 1e-5
         assert np.abs(fe.debug_read("desc_raw", (2, H // 8, W // 8, 256))[i] - f["desc_raw"]).max() <= 1e-4
-        rk, rs, ri = orc.select_b(f["semi"], 0.015, 1, 200)
+        rk, rs, ri = orc.select_b(f["semi"], 0.015, 1, N)
         kps, sc, desc = res[i]
         gi = (kps[:, 1] * W + kps[:, 0]).astype(np.int64)
         common = np.intersect1d(gi, ri)
-        assert len(common) >= 150, "fast mode keypoint set diverged: %d common" % len(common)
+        assert len(common) >= 0.75 * N, "fast mode keypoint set diverged: %d common" % len(common)
         # a keypoint can only enter/leave the top-K if its score is within 2*eps of the K-th score, eps = max score error
         eps = float(np.abs(semi - f["semi"]).max())
         kth = rs[-1]
