@@ -296,9 +296,13 @@ def main():
 
         k0 = int(cnt[0].item())
         first = (kps[0, :k0].cpu().numpy(), scores[0, :k0].cpu().numpy(), desc[0, :k0].cpu().numpy())
+        # what this mode selected and matched on the step's frames (compared across modes below: `mode_disagreement`)
+        sel = {"kidx": kidx[:NI].cpu().numpy().copy(), "cnt": cnt[:NI].cpu().numpy().copy(), "mq": mq[:pl.n_local].cpu().numpy().copy(),
+               "mt": mt[:pl.n_local].cpu().numpy().copy(), "mn": mn[:pl.n_local].cpu().numpy().copy(),
+               "a_row": list(pl.a_cnt_row[:pl.n_local]), "b_row": list(pl.b_cnt_row[:pl.n_local])}
         gfirst = gdesc[0].cpu().numpy().copy() if netvlad else None
         fe.close()
-        return dict(first=first, gfirst=gfirst, value=value, ms_per_step=ms_per_step, roofline=roofline, roofline_nv=roofline_nv, n_kp=n_kp,
+        return dict(sel=sel, first=first, gfirst=gfirst, value=value, ms_per_step=ms_per_step, roofline=roofline, roofline_nv=roofline_nv, n_kp=n_kp,
                     n_match=n_match, breakdown=breakdown, NI=NI, NP=NP, F=F, gated=gated)
 
     use_nv = not args.no_netvlad
@@ -315,6 +319,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(weights, nv_weights if use_nv else None, args.cpu_seconds)
         parity = run_parity_check(primary, weights, nv_weights if use_nv else None, args.precision)
+
+    disagreement = None
+    if rank == 0 and world == 1 and "f32" in legs and args.precision == "wino":
+        disagreement = mode_disagreement(primary["sel"], legs["f32"]["sel"], primary["F"])
 
     latency = None
     if rank == 0 and world == 1 and not args.single_mode and not args.no_latency:
@@ -365,6 +373,8 @@ def main():
             else:
                 e["precision"] = k; e["parity"] = PAR[k]
             out[names[k]] = e
+        if disagreement:
+            out["wino_vs_exact_on_bench_frames"] = disagreement
         if latency:
             out["latency"] = latency
         if quad:
@@ -385,6 +395,38 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def mode_disagreement(a, b, F):
+    """MEASURED difference between the headline mode (Winograd fp32, `a`) and the bitwise-exact direct-convolution mode (`b`) on the very
+    frames the bench times: keypoints that one mode selects and the other does not (raster indices, per image), and matches
+    (as pairs of raster indices, so independent of the order inside a keypoint list) that one mode reports and the other does not.
+    Both modes are fp32 evaluations of the same network; they can only differ where two scores are closer than their ~1e-6 round-off."""
+    NI = a["kidx"].shape[0]
+    kp_tot = kp_diff = img_diff = 0
+    for i in range(NI):
+        sa = set(a["kidx"][i, :a["cnt"][i]].tolist()); sb = set(b["kidx"][i, :b["cnt"][i]].tolist())
+        d = len(sa ^ sb)
+        kp_tot += len(sb); kp_diff += d; img_diff += d > 0
+    m_tot = m_diff = lr_tot = lr_diff = 0
+    for p in range(len(a["mn"])):
+        ra, rb = a["a_row"][p], a["b_row"][p]
+        # the previous-keyframe rows [2F, 3F) hold the left images' keypoints of the step before: the same frames, row - 2F
+        ia, ib = ra, (rb - 2 * F if rb >= 2 * F else rb)
+
+        def pairs(m):
+            n = int(m["mn"][p])
+            return {(int(m["kidx"][ia][q]), int(m["kidx"][ib][t])) for q, t in zip(m["mq"][p, :n].tolist(), m["mt"][p, :n].tolist())}
+        pa, pb = pairs(a), pairs(b)
+        d = len(pa ^ pb)
+        m_tot += len(pb); m_diff += d
+        if rb < 2 * F:
+            lr_tot += len(pb); lr_diff += d
+    return {"images": NI, "keypoints_exact_mode": kp_tot, "keypoints_in_one_mode_only": kp_diff, "images_with_any_keypoint_difference": int(img_diff),
+            "match_pairs": len(a["mn"]), "matches_exact_mode": m_tot, "matches_in_one_mode_only": m_diff,
+            "left_right_matches_exact_mode": lr_tot, "left_right_matches_in_one_mode_only": lr_diff,
+            "note": "symmetric differences; seeded random-init weights compress the score distribution, so near-ties at the top-K cut are far "
+                    "more frequent than with a trained network (DESIGN.md section 2)"}
 
 
 def self_launch(n):
@@ -649,68 +691,105 @@ def _torch_superpoint(torch, F, x, w):
 
 
 def run_cpu_baseline(weights, nv_weights, budget_s):
-    """The same step on the host cores.  The reference has no runnable CPU extractor, so this is
-    kind "port": the network in PyTorch (oneDNN convolutions) + the C oracle's variant-B post-processing, NetVLAD and matchKNN.
-    (i) one thread -- the reference pins every host library to one thread (d2frontend.cpp:303, onnx_generic.h:32) -- and (ii) all
-    cores; (iii) the scalar fmaf-chain oracle that the parity tests use (the slowest possible honest CPU form) as a labelled extra."""
+    """The same step on the host cores, BASELINE.md section 3 / SURVEY.md section 8d.  The reference has no runnable CPU extractor,
+    so this is kind "port": the network in PyTorch (oneDNN convolutions) + the C oracle's variant-B post-processing, NetVLAD and matchKNN.
+    Inputs are generated BEFORE timing; every iteration is timed per stage (prep u8 -> f32/255, conv stack, post-processing, NetVLAD,
+    matching: L<->R and L<->previous L); median and p95 per stage and end to end.  (i) ONE thread -- what the reference pins every host
+    library to (d2frontend.cpp:303, onnx_generic.h:32, superpoint_onnx.cpp:26); (ii) the best of several thread counts, with the C stages
+    threaded over frames (ctypes releases the GIL) and OpenMP inside the NetVLAD convolutions.  The protocol's 5 + >= 50 iterations do not fit
+    bench.py's bounded CPU sample at ~1 s per single-thread frame: iterations are time-bounded and the counts are stated."""
+    import ctypes
     import torch
     import torch.nn.functional as F
+    from concurrent.futures import ThreadPoolExecutor
     from d2slam_amd.synth import synth_stereo
     from oracle import oracle as orc
     orc.build()
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+    except OSError:
+        gomp = None
     tw = {k: (torch.from_numpy(np.ascontiguousarray(v[0])), torch.from_numpy(np.ascontiguousarray(v[1]))) for k, v in weights.items()}
     ncores = os.cpu_count() or 1
+    NF = 8
+    frames = [synth_stereo(H, W, seed=i) for i in range(NF)]          # before any timing
+    STAGES = ["prep", "conv_stack", "postproc"] + (["netvlad"] if nv_weights is not None else []) + ["match"]
 
-    def stereo_frames(nthreads, nframes, batch):
-        torch.set_num_threads(nthreads)
-        os.environ["OMP_NUM_THREADS"] = str(nthreads)
-        prev = None
-        done = 0
+    def iteration(B, first, pool, state):
+        """one batch of B stereo frames; returns seconds per stage"""
+        t = {}
+        fr = [frames[(first + i) % NF] for i in range(B)]
         t0 = time.perf_counter()
+        x = torch.from_numpy(np.stack([p[0] for p in fr] + [p[1] for p in fr]).astype(np.float32) * np.float32(1.0 / 255.0))[:, None]
+        t["prep"] = time.perf_counter() - t0; t0 = time.perf_counter()
         with torch.no_grad():
-            while done < nframes:
-                fb = min(batch, nframes - done)
-                pairs = [synth_stereo(H, W, seed=done + i) for i in range(fb)]
-                x = torch.from_numpy(np.stack([p[0] for p in pairs] + [p[1] for p in pairs]).astype(np.float32) * np.float32(1.0 / 255.0))[:, None]
-                semi, desc = _torch_superpoint(torch, F, x, tw)
-                semi = semi.numpy(); desc = desc.permute(0, 2, 3, 1).contiguous().numpy()
-                for i in range(fb):
-                    kl, sl, _ = orc.select_b(semi[i], 0.015, 1, CAP); dl = orc.sample_b(desc[i], kl)
-                    kr, sr, _ = orc.select_b(semi[fb + i], 0.015, 1, CAP); dr = orc.sample_b(desc[fb + i], kr)
-                    if nv_weights is not None:
-                        orc.netvlad_forward(pairs[i][0], nv_weights)
-                    orc.match_knn(dl, dr, 0.8)
-                    orc.match_knn(dl, prev if prev is not None else dl, 0.8)
-                    prev = dl
-                done += fb
-        return done / (time.perf_counter() - t0)
+            semi, desc = _torch_superpoint(torch, F, x, tw)
+            semi = semi.numpy(); desc = desc.permute(0, 2, 3, 1).contiguous().numpy()
+        t["conv_stack"] = time.perf_counter() - t0; t0 = time.perf_counter()
+
+        def post(i):
+            k, _, _ = orc.select_b(semi[i], 0.015, 1, CAP)
+            return orc.sample_b(desc[i], k)
+        d = list(pool.map(post, range(2 * B))) if pool else [post(i) for i in range(2 * B)]
+        t["postproc"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        if nv_weights is not None:
+            for i in range(B):
+                orc.netvlad_forward(fr[i][0], nv_weights)        # OpenMP inside
+            t["netvlad"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        prev = state.get("prev") or d[:B]
+        jobs = [(d[i], d[B + i]) for i in range(B)] + [(d[i], prev[i % len(prev)]) for i in range(B)]
+        mm = (lambda ab: orc.match_knn(ab[0], ab[1], 0.8))
+        _ = list(pool.map(mm, jobs)) if pool else [mm(j) for j in jobs]
+        state["prev"] = d[:B]
+        t["match"] = time.perf_counter() - t0
+        return t
+
+    def measure(nthreads, B, warm, min_iters, max_iters, seconds):
+        torch.set_num_threads(nthreads)
+        if gomp is not None:
+            gomp.omp_set_num_threads(int(nthreads))
+        pool = ThreadPoolExecutor(max_workers=min(nthreads, 2 * B)) if nthreads > 1 else None
+        state = {}
+        for w_ in range(warm):
+            iteration(B, w_ * B, pool, state)
+        rows = []
+        t_start = time.perf_counter()
+        while len(rows) < max_iters and (len(rows) < min_iters or time.perf_counter() - t_start < seconds):
+            rows.append(iteration(B, len(rows) * B, pool, state))
+        if pool:
+            pool.shutdown()
+        per = {k: np.array([r[k] for r in rows]) / B * 1e3 for k in STAGES}          # ms per stereo frame
+        tot = sum(per.values())
+        return {"threads": nthreads, "stereo_frames_per_iteration": B, "warmup_iterations": warm, "timed_iterations": len(rows),
+                "stereo_frames_per_s_median": round(1e3 / float(np.median(tot)), 4), "stereo_frames_per_s_p95_slowest": round(1e3 / float(np.percentile(tot, 95)), 4),
+                "ms_per_stereo_frame": {k: {"median": round(float(np.median(v)), 3), "p95": round(float(np.percentile(v, 95)), 3)} for k, v in per.items()}}
 
     t_all0 = time.perf_counter()
-    # "all cores": oneDNN's convolutions stop scaling (and on a 256-thread host collapse: 0.12 stereo frames/s measured with 256 intra-op
-    # threads) long before the core count; the figure quoted is the best of 32 and 64 intra-op threads on a batch of 8 stereo frames
-    fps_all, thr_all = 0.0, 0
-    for nthr in sorted({min(ncores, 32), min(ncores, 64)}):
-        stereo_frames(nthr, 2, 2)                                 # warm-up (oneDNN primitive creation for this thread count)
-        f = stereo_frames(nthr, 8, 8)
-        if f > fps_all:
-            fps_all, thr_all = f, nthr
-        if time.perf_counter() - t_all0 > 0.6 * budget_s:
-            break
-    fps_one = stereo_frames(1, 1, 1) if budget_s >= 10 else None
+    one = measure(1, 1, 1, 3, 50, 0.35 * budget_s)
+    best = None
+    cands = sorted({min(ncores, c) for c in (16, 32, 64)})
+    for nthr in cands:
+        r = measure(nthr, 4, 2, 5, 50, 0.3 * budget_s / len(cands))
+        if best is None or r["stereo_frames_per_s_median"] > best["stereo_frames_per_s_median"]:
+            best = r
     torch.set_num_threads(min(ncores, 32))
-    # (iii) the fmaf-chain oracle (OpenMP over all cores)
+    if gomp is not None:
+        gomp.omp_set_num_threads(int(ncores))
+    # the scalar fmaf-chain oracle the parity tests use (OpenMP over all cores): a labelled extra, not a tuned CPU path
     t0 = time.perf_counter()
-    l, r = synth_stereo(H, W, seed=0)
+    l, r = frames[0]
     kl, sl, dl, _, _ = orc.extract_b(l, weights, 0.015, 1, CAP)
     kr, sr, dr, _, _ = orc.extract_b(r, weights, 0.015, 1, CAP)
     orc.match_knn(dl, dr, 0.8); orc.match_knn(dl, dl, 0.8)
     fps_orc = 1.0 / (time.perf_counter() - t0)
     el = time.perf_counter() - t_all0
     what = "SuperPoint (L+R) + " + ("NetVLAD (L) + " if nv_weights is not None else "") + "2 matchKNN per stereo frame, 640x480"
-    return {"value": round(fps_all, 3), "unit": "stereo_frames/s", "cores": thr_all, "kind": "port", "host_cores": ncores,
-            "sample": "8 stereo frames in one batch: %s; network in PyTorch-CPU (oneDNN, %d intra-op threads: the best of 32/64 on this %d-core host), post-processing / NetVLAD / matching in the C oracle; %.1f s for all three lines" % (what, thr_all, ncores, el),
-            "single_thread": {"value": round(fps_one, 4) if fps_one else None, "unit": "stereo_frames/s", "cores": 1,
-                              "sample": "1 stereo frame, torch.set_num_threads(1) / OMP_NUM_THREADS=1 (the reference pins its host libraries to one thread, d2frontend.cpp:303)"},
+    return {"value": best["stereo_frames_per_s_median"], "unit": "stereo_frames/s", "cores": best["threads"], "kind": "port", "host_cores": ncores,
+            "sample": "%s; %d pre-generated stereo frames cycled; network in PyTorch-CPU (oneDNN), post-processing / NetVLAD / matching in the C oracle (threaded over "
+                      "frames); best of %s threads on this %d-core host (more intra-op threads than ~64 collapse oneDNN's convolutions); protocol of BASELINE.md section 3 with "
+                      "time-bounded iteration counts (stated per line); %.1f s for everything" % (what, NF, cands, ncores, el),
+            "protocol": "inputs generated before timing; per-stage wall time per iteration; median / p95 over the timed iterations",
+            "all_cores": best, "single_thread": dict(one, note="the reference pins its host libraries to one thread (d2frontend.cpp:303)"),
             "fmaf_oracle": {"value": round(fps_orc, 4), "unit": "stereo_frames/s", "cores": ncores,
                             "sample": "1 stereo frame through oracle/d2fe_oracle.c (one fp32 fmaf chain per output, OpenMP): the parity checker, not a tuned CPU path"}}
 
