@@ -57,6 +57,9 @@ def main():
                          "latency-bound tail on the handle's tail stream.  Measured slower than plain stream order (2214 vs 2258 stereo fps: the two "
                          "sequences stretch each other, NetVLAD 0.94 -> 1.28 ms), hence off by default")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event breakdown to stderr")
+    ap.add_argument("--exchange", choices=["fp32", "int8"], default=os.environ.get("D2FE_BENCH_EXCHANGE", "fp32"),
+                    help="N>1: precision of the exchange blocks on the wire.  int8 = the reference's LCM wire format (VisualImageDesc::toLCM quantisation, "
+                         "decoded with its 32-float renormalisation before the gate and the matcher): 3.9x fewer all-gather bytes")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency leg (host-pointer C ABI, one frame per call)")
     ap.add_argument("--latency-calls", type=int, default=300)
     ap.add_argument("--latency-only", action="store_true", help="print only the single-call latency leg (A/B runs: D2FE_GRAPH=0, D2FE_PINNED=0)")
@@ -153,6 +156,10 @@ def main():
         kidx = torch.zeros((NI, CAP), dtype=torch.int32, device=dev)
         gdesc = torch.zeros((max(F, 1), max(G, 4)), dtype=torch.float32, device=dev)
         blocks = torch.zeros((F, BLK), dtype=torch.float32, device=dev) if world > 1 else None
+        int8x = world > 1 and args.exchange == "int8"
+        if int8x:
+            BLKB = api.block_bytes_int8(CAP, G)
+            blocks_q = torch.zeros((F, BLKB), dtype=torch.int8, device=dev); gath_q = torch.zeros((world, F, BLKB), dtype=torch.int8, device=dev)
 
         # pairs: (L_f, R_f), (L_f, prevL_f) and, for N>1, (L_f, every left frame block of every other rank)
         pl = swarm.PairList(F, CAP, world, rank, BLK)
@@ -216,9 +223,16 @@ def main():
                     if netvlad and overlap:
                         tail.wait_event(ev_nv)        # the blocks carry this step's NetVLAD descriptors
                     # cross-agent exchange: one block per left frame, ONE all-gather (RCCL over xGMI), the NetVLAD gate on the device
-                    fe.pack_blocks_device(desc.data_ptr(), kps.data_ptr(), scores.data_ptr(), cnt.data_ptr(), gdesc.data_ptr() if netvlad else 0,
-                                          0, 1, F, CAP, G, blocks.data_ptr(), stream=tstream)
-                    swarm.all_gather_blocks(gath, blocks)
+                    if int8x:
+                        # the reference's wire precision: quantise on the sender, ONE all-gather of int8 blocks, decode on the receiver
+                        fe.pack_blocks_int8_device(desc.data_ptr(), kps.data_ptr(), cnt.data_ptr(), gdesc.data_ptr() if netvlad else 0, 0, 1, F, CAP, G,
+                                                   blocks_q.data_ptr(), stream=tstream)
+                        swarm.all_gather_blocks(gath_q, blocks_q)
+                        fe.unpack_blocks_int8_device(gath_q.data_ptr(), world * F, CAP, G, gath.data_ptr(), renorm=0, stream=tstream)
+                    else:
+                        fe.pack_blocks_device(desc.data_ptr(), kps.data_ptr(), scores.data_ptr(), cnt.data_ptr(), gdesc.data_ptr() if netvlad else 0,
+                                              0, 1, F, CAP, G, blocks.data_ptr(), stream=tstream)
+                        swarm.all_gather_blocks(gath, blocks)
                     b_cnt[pl.n_local:] = gath_i32[rem_blk, n_off]
                     if netvlad:
                         gate_n.zero_()
@@ -268,6 +282,11 @@ def main():
         gated = None
         if world > 1 and netvlad:
             gated = {"pairs": pl.n_remote, "passing_netvlad_gate": int(gate_n.item()), "threshold": NETVLAD_GATE}
+        exch = None
+        if world > 1:
+            per_block = api.block_bytes_int8(CAP, G) if int8x else 4 * BLK
+            exch = {"wire_precision": args.exchange, "block_bytes": per_block, "all_gather_bytes_received_per_step_per_gpu": per_block * F * (world - 1),
+                    "avg_cross_agent_matches_per_pair": round(mn[pl.n_local:].float().mean().item(), 2)}
 
         breakdown = None
         if want_breakdown and rank == 0 and world == 1:
@@ -303,7 +322,7 @@ def main():
         gfirst = gdesc[0].cpu().numpy().copy() if netvlad else None
         fe.close()
         return dict(sel=sel, first=first, gfirst=gfirst, value=value, ms_per_step=ms_per_step, roofline=roofline, roofline_nv=roofline_nv, n_kp=n_kp,
-                    n_match=n_match, breakdown=breakdown, NI=NI, NP=NP, F=F, gated=gated)
+                    n_match=n_match, breakdown=breakdown, NI=NI, NP=NP, F=F, gated=gated, exch=exch)
 
     use_nv = not args.no_netvlad
     primary = run_mode(args.precision, True, netvlad=use_nv)
@@ -363,6 +382,8 @@ def main():
         }
         if primary["gated"]:
             out["netvlad_gate"] = primary["gated"]
+        if primary["exch"]:
+            out["exchange"] = primary["exch"]
         if rccl:
             out["rccl"] = rccl
         names = {"configs1": "configs1", "f32": "exact_mode", "f16x2": "fast_mode", "wino": "wino_mode"}
@@ -524,7 +545,8 @@ def run_quadcam(args, torch, api, weights, dev, local_rank, world, rank=0):
     raw = torch.from_numpy(np.stack([frame(i) for i in range(NI)])).to(dev)
     maps = [tuple(torch.from_numpy(m).to(dev) for m in quadcam.synthetic_maps(c, RH, RW, UH, UW)) for c in range(4)]
     chain = quadcam.QuadcamChain(fe, torch, dev, Q, UH, UW, CAPQ, undistort_fov=200.0, knn_ratio=0.8, search_local_max_dist=0.2)
-    qs = swarm.QuadSwarm(chain, torch, dev, world, rank, fe.netvlad_dim, NETVLAD_GATE, mode=os.environ.get("D2FE_QUAD_SWARM_MODE", "all2all")) if world > 1 else None
+    qs = swarm.QuadSwarm(chain, torch, dev, world, rank, fe.netvlad_dim, NETVLAD_GATE, mode=os.environ.get("D2FE_QUAD_SWARM_MODE", "all2all"),
+                         exchange=args.exchange) if world > 1 else None
 
     def step():
         chain.step(raw, RH, RW, maps, st)
@@ -578,7 +600,7 @@ def run_quadcam(args, torch, api, weights, dev, local_rank, world, rank=0):
         dp = qs.dir_prev.cpu().numpy()
         out["cross_agent"] = {"jobs_per_step_per_gpu": qs.njobs, "view_pairs_per_step_per_gpu": qs.NP, "mode": qs.mode,
                               "avg_matches_per_view_pair": round(qs.mn.float().mean().item(), 2),
-                              "block_bytes": 4 * qs.BLK, "all_gather_bytes_received_per_step": 4 * qs.BLK * NI * (world - 1)}
+                              "wire_precision": qs.exchange, "block_bytes": qs.block_bytes, "all_gather_bytes_received_per_step": qs.block_bytes * NI * (world - 1)}
         out["netvlad_gate"] = {"jobs": qs.njobs, "passing_netvlad_gate": int(qs.n_pass.item()), "threshold": NETVLAD_GATE,
                                "rotation_histogram_dir_prev": {str(k): int((dp == k).sum()) for k in (-1, 0, 1, 2, 3)},
                                "rule": "remote view 2 vs local views 2,3,0,1 in order, first similarity >= threshold (d2featuretracker.cpp:212-233)"}

@@ -79,7 +79,7 @@ EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_creat
            "d2fe_load_superpoint", "d2fe_set_superpoint_pca", "d2fe_desc_dim", "d2fe_superpoint_extract", "d2fe_superpoint_extract_batch",
            "d2fe_superpoint_extract_device", "d2fe_tail_stream", "d2fe_superpoint_wait_tail", "d2fe_load_netvlad", "d2fe_set_netvlad_pca", "d2fe_netvlad_dim",
            "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device", "d2fe_match_fallback_rows",
-           "d2fe_block_words", "d2fe_block_field_offset", "d2fe_pack_blocks_device", "d2fe_gate_pairs_device", "d2fe_quad_gate_device",
+           "d2fe_block_words", "d2fe_block_field_offset", "d2fe_pack_blocks_device", "d2fe_gate_pairs_device", "d2fe_quad_gate_device", "d2fe_block_bytes_int8", "d2fe_pack_blocks_int8_device", "d2fe_unpack_blocks_int8_device",
            "d2fe_half_move_cols", "d2fe_half_image_compact_device", "d2fe_remap_matches_device",
            "d2fe_half_image_filter", "d2fe_undistort", "d2fe_undistort_device", "d2fe_db_create", "d2fe_db_destroy",
            "d2fe_db_ntotal", "d2fe_db_add", "d2fe_db_search", "d2fe_db_query_gated", "d2fe_quantize_int8", "d2fe_dequantize_int8",
@@ -529,6 +529,18 @@ class FrontEnd:
                                                  C.c_void_p(d_netvlad or 0), int(row0), int(row_step), int(nframes), int(cap), int(netvlad_dim),
                                                  C.c_void_p(d_blocks), C.c_void_p(stream or 0)))
 
+    def pack_blocks_int8_device(self, d_desc, d_kps, d_n, d_netvlad, row0, row_step, nframes, cap, netvlad_dim, d_blocks, stream=None):
+        """Exchange blocks in the reference's int8 wire precision (VisualImageDesc::toLCM); raw device addresses."""
+        V = C.c_void_p
+        _check(self._lib.d2fe_pack_blocks_int8_device(self._h, V(d_desc), V(d_kps), V(d_n), V(d_netvlad or 0), int(row0), int(row_step), int(nframes),
+                                                      int(cap), int(netvlad_dim), V(d_blocks), V(stream or 0)))
+
+    def unpack_blocks_int8_device(self, d_blocks_int8, nblocks, cap, netvlad_dim, d_blocks, renorm=0, stream=None):
+        """Gathered int8 blocks -> fp32 block layout with the reference's decode (renorm 0) or per-descriptor re-normalisation (1)."""
+        V = C.c_void_p
+        _check(self._lib.d2fe_unpack_blocks_int8_device(self._h, V(d_blocks_int8), int(nblocks), int(cap), int(netvlad_dim), int(renorm), V(d_blocks),
+                                                        V(stream or 0)))
+
     def gate_pairs_device(self, d_q, q_stride, d_db, db_stride, dim, d_pair_q, d_pair_db, npairs, thres, d_cnt_inout=None, d_pass=None,
                           d_sims=None, d_n_pass=None, stream=None):
         """NetVLAD gate of a pair list (getMatchedPrevKeyframe's similarity test), raw device addresses."""
@@ -574,6 +586,11 @@ class FrontEnd:
 def block_words(cap, netvlad_dim):
     """Float words of one exchange block (include/d2fe.h, d2fe_block_words); callable without a GPU."""
     return int(load_library().d2fe_block_words(int(cap), int(netvlad_dim)))
+
+
+def block_bytes_int8(cap, netvlad_dim):
+    """Bytes of one int8 exchange block (include/d2fe.h, d2fe_block_bytes_int8)."""
+    return int(load_library().d2fe_block_bytes_int8(int(cap), int(netvlad_dim)))
 
 
 def block_field_offset(cap, netvlad_dim, field):

@@ -72,8 +72,6 @@ struct d2fe_context {
   long cand_cap = 0;
   // staging for the host-pointer API
   uint8_t* s_img = nullptr;
-  float *s_kps = nullptr, *s_scores = nullptr, *s_desc = nullptr;
-  int32_t *s_idx = nullptr, *s_n = nullptr;
   int s_cap = 0;
   // last call geometry (for debug reads)
   int last_w = 0, last_h = 0, last_n = 0;
@@ -85,7 +83,8 @@ struct d2fe_context {
   // processor spends between two dependent launches and the per-copy latency of pageable D2H copies are a third of a call.
   uint8_t* pin_in = nullptr; size_t pin_in_bytes = 0;
   float* pin_out = nullptr; size_t pin_out_bytes = 0;
-  float* s_out = nullptr;      // device: [kps | scores | desc | n] of a host-pointer extract call, contiguous -> ONE D2H
+  float* s_out = nullptr;      // device: [kps | scores | desc | n | idx] of a host-pointer extract call, contiguous -> ONE D2H of the first four
+  size_t s_out_bytes = 0;
   bool use_graphs = true, use_pinned = true;       // D2FE_GRAPH=0 / D2FE_PINNED=0 switch them off (A/B measurements)
   struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; bool bad = false; };
   std::map<std::array<long, 6>, GraphEntry> graphs;
@@ -122,7 +121,7 @@ struct d2fe_context {
   bool fuse1a = true;      // conv1a fused into conv1b's staging (D2FE_FUSE1A=0 keeps the stand-alone conv1a kernel)
   // host-pointer matcher: pool of (stream, scratch) slots so that concurrent callers (the reference calls matchKNN from three
   // threads) neither share state nor pay hipStreamCreate / hipMalloc / hipFree (a device-wide sync) per call
-  struct MatchSlot { hipStream_t stream = nullptr; char* buf = nullptr; char* pin = nullptr; bool busy = false; };
+  struct MatchSlot { hipStream_t stream = nullptr; char* buf = nullptr; char* pin = nullptr; size_t bytes = 0; bool busy = false; };
   std::deque<MatchSlot> match_slots;     // deque: growing it never relocates the slots other threads are using
   std::mutex match_mu;
   // device-API matcher scratch (cand4), one per caller stream: calls on different streams may overlap on the GPU
@@ -315,7 +314,7 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
   // both paths give identical bits; with fewer than 4 images per call the dense head is quicker (the sparse kernels are
   // latency-bound with so few 32-cell workgroups in flight; measured per step, exact mode: 2 images 1.079 ms dense / 1.096 sparse,
   // 4 images 1.877 / 1.862, 8 images 3.42 / 3.28, 16 images 6.48 / 6.20)
-  const bool sparse = h->sparse_desc && n >= h->sp_min_batch;
+  const bool sparse = h->sparse_desc && n >= h->sp_min_batch && 4 * (long)cap <= h->sp_slots;      // a larger capacity than the sparse store was sized for: dense head
   if (sparse) {
     // detector head only (convPa 128->256, convPb); the descriptor head is evaluated after keypoint selection, at the needed cells
     { ProfScope ps(h, D2FE_PROF_CONVPADA, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_PA], a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, true)); }
@@ -333,21 +332,25 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
   }
   { ProfScope ps(h, D2FE_PROF_SOFTMAX, s);
   HIP_TRY(launch_softmax_cand(logits.p, 65, Hc, Wc, n, h->cfg.keypoint_threshold, h->cfg.remove_borders,
-                              (h->cfg.keep_score_map || varA) ? h->semi.p : nullptr,
+                              (h->cfg.keep_score_map || varA || h->cfg.max_keypoints < 0) ? h->semi.p : nullptr,
                               h->cand, h->cand_count, varA ? 0 : h->cand_cap, s)); }
   if (varA) {
     // getKeyPoints + NMS2 (superpoint_common.cpp:12-40,107-177): border = 0, sorted by confidence, max_num
     ProfScope ps(h, D2FE_PROF_SELECT, s);
     HIP_TRY(launch_nms2_a(h->semi.p, H, W, n, h->cfg.keypoint_threshold, h->cfg.nms_dist, h->aconf, h->clist, h->cand,
                           h->cand_count, h->cand_cap, h->a_ncand, s));
-    HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, W, h->cfg.max_keypoints, cap, 1, d_kps, d_scores, d_idx,
-                            d_n, s));
+    // variant A's sampling scratch holds a_scap keypoints per image: keep-all (max_keypoints = -1) means "up to a_scap" here
+    HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, W, h->cfg.max_keypoints < 0 ? h->a_scap : h->cfg.max_keypoints, cap, 1, nullptr, H,
+                            h->cfg.keypoint_threshold, 0, d_kps, d_scores, d_idx, d_n, s));
     if ((long)H * W > 65536)     // the reference's CV_16UC1 index map wraps above 65 536 candidates; reproduced (no-op below that)
       HIP_TRY(launch_nms2_wrap_fix(h->clist, h->a_ncand, H, W, n, d_kps, d_idx, d_n, cap, s));
   } else {
     ProfScope ps(h, D2FE_PROF_SELECT, s);
-    HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, Wc * 8, h->cfg.max_keypoints, cap, 0, d_kps, d_scores, d_idx,
-                            d_n, s));      // raster indices and keypoints are in score-map coordinates: (W/8)*8 wide
+    // raster indices and keypoints are in score-map coordinates: (W/8)*8 wide.  Keep-all handles also hand over the dense score map:
+    // more keypoints than the in-LDS sort takes are compacted from it in raster order (any count up to the call's capacity)
+    HIP_TRY(launch_select_b(h->cand, h->cand_count, h->cand_cap, n, Wc * 8, h->cfg.max_keypoints, cap, 0,
+                            (h->cfg.keep_score_map || h->cfg.max_keypoints < 0) ? h->semi.p : nullptr, Hc * 8, h->cfg.keypoint_threshold,
+                            h->cfg.remove_borders, d_kps, d_scores, d_idx, d_n, s));
   }
   if (!sparse) {
     ProfScope ps(h, D2FE_PROF_SAMPLE, s);
@@ -422,9 +425,11 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   if (cfg->max_width < 16 || cfg->max_height < 16) return fail(D2FE_ERR_INVALID, "max_width/max_height must be at least 16");
   if (cfg->max_batch < 1) return fail(D2FE_ERR_INVALID, "max_batch < 1");
   // -1 = keep every keypoint above the threshold (SuperPoint::topKeypoints only truncates when k != -1, superpoint_tensorrt.cpp:241-253;
-  // NMS2's `i < max_num` is an unsigned compare, superpoint_common.cpp:173): the calls then return up to min(cap, 1024) keypoints, in raster
-  // order for variant B, and D2FE_ERR_TRUNCATED from the host-pointer entry points if an image had more
-  if ((cfg->max_keypoints < 1 && cfg->max_keypoints != -1) || cfg->max_keypoints > 1024) return fail(D2FE_ERR_INVALID, "max_keypoints must be -1 (keep all) or in 1..1024");
+  // NMS2's `i < max_num` is an unsigned compare, superpoint_common.cpp:173): variant B then returns EVERY keypoint above the threshold, in
+  // raster order, up to the call's capacity (any capacity up to H*W; D2FE_ERR_TRUNCATED with the strongest kept if an image had more);
+  // variant A up to 1024.  A sorted top-K selection takes K <= 16384 (one workgroup's in-LDS bitonic sort); the reference's TensorRT
+  // profile (1500 x 1500, superpoint_tensorrt.cpp:50-55) with max_keypoints in the thousands is inside that.
+  if ((cfg->max_keypoints < 1 && cfg->max_keypoints != -1) || cfg->max_keypoints > 16384) return fail(D2FE_ERR_INVALID, "max_keypoints must be -1 (keep all) or in 1..16384");
   if (cfg->precision != D2FE_PREC_F32 && cfg->precision != D2FE_PREC_F16X2 && cfg->precision != D2FE_PREC_F32_WINO) return fail(D2FE_ERR_INVALID, "bad precision");
   if (cfg->postproc != D2FE_POSTPROC_B && cfg->postproc != D2FE_POSTPROC_A) return fail(D2FE_ERR_INVALID, "bad postproc");
   int ndev = 0;
@@ -470,7 +475,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     { const char* e = getenv("D2FE_SPARSE_MIN_BATCH"); if (e) h->sp_min_batch = atoi(e); }
     if (h->sparse_desc) {
       const size_t ncell = (H / 8) * (W / 8);
-      h->sp_slots = 4 * (cfg->max_keypoints < 0 ? 1024 : cfg->max_keypoints);            // <= 4 corner cells per keypoint
+      h->sp_slots = 4 * (cfg->max_keypoints < 0 || cfg->max_keypoints > 1024 ? 1024 : cfg->max_keypoints);   // <= 4 corner cells per keypoint; larger calls take the dense head
       HIP_TRY(hipMalloc(&h->sp_flags, ncell * B));
       HIP_TRY(hipMalloc(&h->sp_slotmap, sizeof(int32_t) * ncell * B));
       HIP_TRY(hipMalloc(&h->sp_cells, sizeof(int32_t) * (size_t)h->sp_slots * B));
@@ -489,23 +494,19 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
       HIP_TRY(hipMalloc(&h->aconf, sizeof(float) * H * W * B));
       HIP_TRY(hipMalloc(&h->clist, sizeof(int) * H * W * B));
       HIP_TRY(hipMalloc(&h->a_ncand, sizeof(int) * B));
-      h->a_scap = (h->cfg.max_keypoints > 0 && h->cfg.max_keypoints < 1024) ? h->cfg.max_keypoints : 1024;   // select keeps at most min(max_keypoints, 1024)
+      h->a_scap = h->cfg.max_keypoints > 0 ? h->cfg.max_keypoints : 1024;   // variant A: select keeps at most min(max_keypoints, call capacity); keep-all: 1024
       HIP_TRY(hipMalloc(&h->a_samp, sizeof(float) * 256 * (size_t)h->a_scap * B));
       HIP_TRY(hipMalloc(&h->a_cn, sizeof(float) * 256 * B));
     }
-    h->s_cap = 1024;
+    h->s_cap = h->cfg.max_keypoints > 1024 ? h->cfg.max_keypoints : 1024;      // initial staging capacity per image; grows with the calls (ensure_staging)
     HIP_TRY(hipMalloc(&h->s_img, H * W * B));
-    HIP_TRY(hipMalloc(&h->s_kps, sizeof(float) * 2 * h->s_cap * B));
-    HIP_TRY(hipMalloc(&h->s_scores, sizeof(float) * h->s_cap * B));
-    HIP_TRY(hipMalloc(&h->s_desc, sizeof(float) * 256 * h->s_cap * B));
-    HIP_TRY(hipMalloc(&h->s_idx, sizeof(int32_t) * h->s_cap * B));
-    HIP_TRY(hipMalloc(&h->s_n, sizeof(int32_t) * B));
-    HIP_TRY(hipMalloc(&h->s_out, (sizeof(float) * (size_t)h->s_cap * 259 + sizeof(int32_t)) * B));
+    h->s_out_bytes = (sizeof(float) * (size_t)h->s_cap * 260 + sizeof(int32_t)) * B;
+    HIP_TRY(hipMalloc(&h->s_out, h->s_out_bytes));
     { const char* e = getenv("D2FE_GRAPH"); if (e) h->use_graphs = atoi(e) != 0; }
     { const char* e = getenv("D2FE_PINNED"); if (e) h->use_pinned = atoi(e) != 0; }
     if (h->use_pinned) {
       h->pin_in_bytes = (size_t)H * W * B;
-      h->pin_out_bytes = (sizeof(float) * (size_t)h->s_cap * 259 + sizeof(int32_t)) * B;
+      h->pin_out_bytes = h->s_out_bytes;
       if (h->pin_out_bytes < sizeof(float) * 8192 * (size_t)B) h->pin_out_bytes = sizeof(float) * 8192 * (size_t)B;      // NetVLAD descriptors
       if (hipHostMalloc(&h->pin_in, h->pin_in_bytes, hipHostMallocDefault) != hipSuccess ||
           hipHostMalloc(&h->pin_out, h->pin_out_bytes, hipHostMallocDefault) != hipSuccess) {
@@ -534,8 +535,7 @@ void d2fe_destroy(d2fe_handle h) {
   for (Tensor* t : {&h->a1a, &h->a1b, &h->a2a, &h->a2b, &h->a3a, &h->a3b, &h->a4a, &h->a4b, &h->aPD, &h->logits, &h->draw, &h->semi, &h->a4b2, &h->logits2, &h->draw2})
     if (t->p) hipFree(t->p);
   for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
-  for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->cand_count, (void*)h->s_img, (void*)h->s_kps,
-                  (void*)h->s_scores, (void*)h->s_desc, (void*)h->s_idx, (void*)h->s_n, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->work_ctrs, (void*)h->match_stats, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc,
+  for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->cand_count, (void*)h->s_img, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->work_ctrs, (void*)h->match_stats, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc,
                   (void*)h->pca_comp_t, (void*)h->pca_mean})
     if (p) hipFree(p);
   nv_free(h);
@@ -692,28 +692,44 @@ int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int
   if (rc) return rc;
   if (!gray || !kps_xy || !scores || !desc || !n_out) return fail(D2FE_ERR_INVALID, "null pointer");
   HIP_TRY(hipSetDevice(h->cfg.device_id));
-  const int dcap = cap < h->s_cap ? cap : h->s_cap;
   hipStream_t s = h->stream;
+  // the call's capacity, bounded by what can exist: H*W candidates (keep-all) or the configured maximum
+  const long most = h->cfg.max_keypoints > 0 ? h->cfg.max_keypoints : (long)height * width;
+  const int dcap = cap < most ? cap : (int)most;
+  const size_t D = (h->cfg.postproc == D2FE_POSTPROC_A && h->pca_dims) ? (size_t)h->pca_dims : 256;
+  // outputs of the call, contiguous in one device block: kps [n][dcap][2] | scores [n][dcap] | desc [n][dcap][D] | counts [n] | idx [n][dcap]
+  const size_t out_bytes = sizeof(float) * (size_t)n * dcap * (3 + D) + sizeof(int32_t) * n;
+  const size_t need = out_bytes + sizeof(int32_t) * (size_t)n * dcap;
+  if (need > h->s_out_bytes) {       // grow-only staging: a keep-all call may ask for far more than the initial 1024 per image
+    HIP_TRY(hipStreamSynchronize(s));
+    graphs_clear(h);                 // captured launch sequences hold the old staging pointers
+    if (h->s_out) { hipFree(h->s_out); h->s_out = nullptr; h->s_out_bytes = 0; }
+    HIP_TRY(hipMalloc(&h->s_out, need));
+    h->s_out_bytes = need;
+    if (h->use_pinned && out_bytes > h->pin_out_bytes) {
+      if (h->pin_out) { (void)hipHostFree(h->pin_out); h->pin_out = nullptr; h->pin_out_bytes = 0; }
+      if (hipHostMalloc(&h->pin_out, out_bytes, hipHostMallocDefault) == hipSuccess) h->pin_out_bytes = out_bytes;
+      else { (void)hipGetLastError(); h->pin_out = nullptr; }     // the pageable path below serves calls the pinned buffer cannot
+    }
+  }
   rc = upload_frames(h, h->s_img, gray, n, width, height, stride, image_stride, s);
   if (rc) return rc;
   // async_tail handles: a preceding d2fe_superpoint_extract_device call may still have its post-processing running on the tail
   // stream against the single-buffered scratch (candidates, score map, sparse-head slots) that this run uses too
   if (h->cfg.async_tail)
     for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(s, h->ev_tail[i], 0));
-  // outputs of the call, contiguous in one device block: kps [n][dcap][2] | scores [n][dcap] | desc [n][dcap][D] | counts [n]
-  const size_t D = (h->cfg.postproc == D2FE_POSTPROC_A && h->pca_dims) ? (size_t)h->pca_dims : 256;
   float* o_kps = h->s_out;
   float* o_sc = o_kps + (size_t)n * dcap * 2;
   float* o_desc = o_sc + (size_t)n * dcap;
   int32_t* o_n = reinterpret_cast<int32_t*>(o_desc + (size_t)n * dcap * D);
-  const size_t out_bytes = sizeof(float) * (size_t)n * dcap * (3 + D) + sizeof(int32_t) * n;
+  int32_t* o_idx = o_n + n;
   rc = run_cached(h, {1, n, width, height, dcap, (long)D}, s, [&](hipStream_t st) {
-    return run_superpoint(h, h->s_img, n, width, height, width, (size_t)width * height, o_kps, o_sc, o_desc, h->s_idx, dcap, o_n, st);
+    return run_superpoint(h, h->s_img, n, width, height, width, (size_t)width * height, o_kps, o_sc, o_desc, o_idx, dcap, o_n, st);
   });
   if (rc) return rc;
   std::vector<int32_t> ncand(h->cfg.max_keypoints < 0 ? n : 0);
   if (!ncand.empty()) HIP_TRY(hipMemcpyAsync(ncand.data(), h->cand_count, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
-  if (h->use_pinned && out_bytes <= h->pin_out_bytes) {
+  if (h->use_pinned && h->pin_out && out_bytes <= h->pin_out_bytes) {
     // ONE D2H of the whole block into pinned memory, one synchronisation, then the rows that exist go to the caller's arrays
     HIP_TRY(hipMemcpyAsync(h->pin_out, h->s_out, out_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1119,7 +1135,7 @@ int d2fe_netvlad_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int
   if (rc) return rc;
   const int G = d2fe_netvlad_dim(h);
   const size_t bytes = sizeof(float) * (size_t)G * n;
-  if (h->use_pinned && bytes <= h->pin_out_bytes) {
+  if (h->use_pinned && h->pin_out && bytes <= h->pin_out_bytes) {
     HIP_TRY(hipMemcpyAsync(h->pin_out, h->nv_s_out, bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     memcpy(out, h->pin_out, bytes);
@@ -1396,6 +1412,31 @@ int d2fe_gate_pairs_device(d2fe_handle h, const float* d_q, size_t q_stride, con
   return D2FE_OK;
 }
 
+int d2fe_block_bytes_int8(int cap, int netvlad_dim) {
+  if (cap < 1 || netvlad_dim < 0 || (netvlad_dim & 3)) return fail(D2FE_ERR_INVALID, "bad argument");
+  return (cap * 256 + netvlad_dim + cap * 8 + 4 + 63) / 64 * 64;
+}
+int d2fe_pack_blocks_int8_device(d2fe_handle h, const float* d_desc, const float* d_kps_xy, const int32_t* d_n, const float* d_netvlad,
+                                 int row0, int row_step, int nframes, int cap, int netvlad_dim, int8_t* d_blocks, void* stream) {
+  if (!h || !d_desc || !d_kps_xy || !d_n || !d_blocks) return fail(D2FE_ERR_INVALID, "null argument");
+  if (nframes < 1 || cap < 1 || row0 < 0 || row_step < 1 || netvlad_dim < 0 || (netvlad_dim & 3)) return fail(D2FE_ERR_INVALID, "bad geometry");
+  if (((uintptr_t)d_desc & 15) || ((uintptr_t)d_blocks & 3)) return fail(D2FE_ERR_INVALID, "d_desc must be 16-byte aligned, d_blocks 4-byte aligned");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(launch_pack_blocks_int8(d_desc, d_kps_xy, d_n, d_netvlad, row0, row_step, nframes, cap, netvlad_dim,
+                                  d2fe_block_bytes_int8(cap, netvlad_dim), d_blocks, stream ? (hipStream_t)stream : h->stream));
+  return D2FE_OK;
+}
+int d2fe_unpack_blocks_int8_device(d2fe_handle h, const int8_t* d_blocks_int8, int nblocks, int cap, int netvlad_dim, int renorm,
+                                   float* d_blocks, void* stream) {
+  if (!h || !d_blocks_int8 || !d_blocks) return fail(D2FE_ERR_INVALID, "null argument");
+  if (nblocks < 1 || cap < 1 || netvlad_dim < 0 || (netvlad_dim & 3) || (renorm != 0 && renorm != 1)) return fail(D2FE_ERR_INVALID, "bad geometry");
+  if (((uintptr_t)d_blocks & 15) || ((uintptr_t)d_blocks_int8 & 3)) return fail(D2FE_ERR_INVALID, "d_blocks must be 16-byte aligned, d_blocks_int8 4-byte aligned");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  HIP_TRY(launch_unpack_blocks_int8(d_blocks_int8, nblocks, cap, netvlad_dim, d2fe_block_bytes_int8(cap, netvlad_dim),
+                                    d2fe_block_words(cap, netvlad_dim), renorm, d_blocks, stream ? (hipStream_t)stream : h->stream));
+  return D2FE_OK;
+}
+
 int d2fe_quad_gate_device(d2fe_handle h, const float* d_local, size_t local_stride, const float* d_remote, size_t remote_stride, int dim,
                           const int32_t* d_job_local_row0, const int32_t* d_job_remote_row0, int local_view_step, int remote_view_step,
                           int njobs, double thres, int32_t* d_dir_prev, float* d_sims, int32_t* d_cnt_inout, int32_t* d_n_pass,
@@ -1435,7 +1476,7 @@ int d2fe_remap_matches_device(d2fe_handle h, int32_t* d_q_idx, int32_t* d_t_idx,
 
 int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* stream) {
   if (!h || !mb) return fail(D2FE_ERR_INVALID, "null argument");
-  if (mb->npairs < 1 || mb->max_n < 1 || mb->max_n > 1024) return fail(D2FE_ERR_INVALID, "npairs/max_n out of range (max_n <= 1024)");
+  if (mb->npairs < 1 || mb->max_n < 1 || mb->max_n > 16384) return fail(D2FE_ERR_INVALID, "npairs/max_n out of range (max_n <= 16384)");
   if (mb->dim < 4 || mb->dim > 256 || (mb->dim & 3)) return fail(D2FE_ERR_INVALID, "dim must be a multiple of 4 in 4..256");
   if (mb->mode != 0 && mb->mode != 1) return fail(D2FE_ERR_INVALID, "bad mode");
   HIP_TRY(hipSetDevice(h->cfg.device_id));
@@ -1474,14 +1515,15 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
   if (na == 0 || nb == 0) return D2FE_OK;
   if (!a || !b || !q_idx || !t_idx || !dist) return fail(D2FE_ERR_INVALID, "null pointer");
   const int max_n = na > nb ? na : nb;
-  if (max_n > 1024) return fail(D2FE_ERR_UNSUPPORTED, "more than 1024 descriptors per side");
+  if (max_n > 16384) return fail(D2FE_ERR_UNSUPPORTED, "more than 16384 descriptors per side");
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   const bool use_pts = mode == 0 && radius > 0 && pts_a && pts_b;
   const size_t fa = (size_t)na * dim, fb = (size_t)nb * dim;
   if (dim < 4 || dim > 256 || (dim & 3)) return fail(D2FE_ERR_INVALID, "dim must be a multiple of 4 in 4..256");
   // a private (stream, scratch) slot per call in flight: re-entrant; slots are created on demand and reused
-  constexpr size_t MAXN = 1024, MAXD = 256;
-  constexpr size_t SLOT_BYTES = sizeof(float) * (2 * MAXN * MAXD + 4 * MAXN + MAXN) + sizeof(int32_t) * (2 * MAXN + 8 + 8 * MAXN) + 64;
+  // a slot's buffers are sized for 1024 rows per side at first (every shipped configuration) and grow with the calls
+  const size_t rows = (size_t)(max_n > 1024 ? max_n : 1024);
+  const size_t slot_bytes = sizeof(float) * (2 * rows * 256 + 4 * rows + rows) + sizeof(int32_t) * (2 * rows + 16 + 8 * rows) + 128;
   int slot = -1;
   hipStream_t s = nullptr;
   char* buf = nullptr;
@@ -1493,15 +1535,22 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
     if (slot < 0) {
       d2fe_context::MatchSlot ms;
       if (hipStreamCreateWithFlags(&ms.stream, hipStreamNonBlocking) != hipSuccess) return fail(D2FE_ERR_HIP, "hipStreamCreate (match slot)");
-      if (hipMalloc(&ms.buf, SLOT_BYTES) != hipSuccess) { hipStreamDestroy(ms.stream); return fail(D2FE_ERR_HIP, "hipMalloc match scratch"); }
-      if (h->use_pinned && hipHostMalloc(&ms.pin, SLOT_BYTES, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ms.pin = nullptr; }
       h->match_slots.push_back(ms);
       slot = (int)h->match_slots.size() - 1;
     }
-    h->match_slots[slot].busy = true;
-    s = h->match_slots[slot].stream;      // read under the lock: another thread may be appending a slot right now
-    buf = h->match_slots[slot].buf;
-    pin = h->match_slots[slot].pin;
+    d2fe_context::MatchSlot& ms = h->match_slots[slot];
+    if (ms.bytes < slot_bytes) {          // the slot is idle (not busy): nothing of it is in flight
+      if (ms.buf) { hipFree(ms.buf); ms.buf = nullptr; }
+      if (ms.pin) { (void)hipHostFree(ms.pin); ms.pin = nullptr; }
+      ms.bytes = 0;
+      if (hipMalloc(&ms.buf, slot_bytes) != hipSuccess) return fail(D2FE_ERR_HIP, "hipMalloc match scratch");
+      if (h->use_pinned && hipHostMalloc(&ms.pin, slot_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ms.pin = nullptr; }
+      ms.bytes = slot_bytes;
+    }
+    ms.busy = true;
+    s = ms.stream;      // read under the lock: another thread may be appending a slot right now
+    buf = ms.buf;
+    pin = ms.pin;
   }
   struct Release { d2fe_context* h; int slot; ~Release() { std::lock_guard<std::mutex> lk(h->match_mu); h->match_slots[slot].busy = false; } } release{h, slot};
   // device layout (words): a | b | pts_a | pts_b | meta {a_off, b_off, a_cnt, b_cnt, pad x4} | n_out, pad x7 | dist | q | t | cand4

@@ -69,8 +69,8 @@ hipError_t launch_softmax_cand(const float* logits, int lstride, int Hc, int Wc,
                                hipStream_t s);
 // exact top-K (score desc, raster asc) / raster-ordered pass-through when count <= K (variant B).
 hipError_t launch_select_b(const unsigned long long* cand, const int* cand_count, long cand_cap, int n_img, int W,
-                           int max_kp, int cap, int always_sort, float* kps_xy, float* scores, int32_t* kps_idx,
-                           int32_t* n_out, hipStream_t s);
+                           int max_kp, int cap, int always_sort, const float* semi, int H, float thr, int border, float* kps_xy,
+                           float* scores, int32_t* kps_idx, int32_t* n_out, hipStream_t s);
 // variant-B descriptor sampling (normalize_keypoints + grid_sample + normalize_descriptors).
 hipError_t launch_sample_b(const float* desc_raw, int dstride, int dcoff, int Hc, int Wc, int n_img, const float* kps_xy,
                            const int32_t* n_kp, int cap, const int32_t* slotmap, int max_slots, float* desc_out, hipStream_t s);
@@ -159,6 +159,10 @@ hipError_t launch_pack_blocks(const float* desc, const float* kps, const float* 
 hipError_t launch_gate_pairs(const float* q, long q_stride, const float* db, long db_stride, int dim, const int32_t* pair_q,
                              const int32_t* pair_db, int npairs, double thres, int32_t* cnt_inout, int32_t* pass, float* sims,
                              int32_t* n_pass, hipStream_t s);
+hipError_t launch_pack_blocks_int8(const float* desc, const float* kps, const int32_t* n_kp, const float* gdesc, int row0, int row_step,
+                                   int nframes, int cap, int G, int blk_bytes, int8_t* blocks, hipStream_t s);
+hipError_t launch_unpack_blocks_int8(const int8_t* blocks, int nblocks, int cap, int G, int blk_bytes, int blk_words, int renorm, float* out,
+                                     hipStream_t s);
 hipError_t launch_quad_gate(const float* loc, long loc_stride, const float* rem, long rem_stride, int dim, const int32_t* job_loc_row0,
                             const int32_t* job_rem_row0, int loc_view_step, int rem_view_step, int njobs, double thres, int32_t* dir_prev,
                             float* sims, int32_t* cnt_inout, int32_t* n_pass, hipStream_t s);

@@ -296,8 +296,8 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
     if (saturated) {
       sat[atomicAdd(satn, 1)] = tid;
     } else {
-      int32_t* out = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + q0 + tid) * 4;   // {nn index, d0 bits, d1 bits, fallback flag}
-      out[0] = bi0; out[1] = __float_as_int(bd0); out[2] = __float_as_int(bd1); out[3] = 0;
+      int32_t* out = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + q0 + tid) * 4;   // {nn index, d0 bits, d1 bits, (finalize: inverse dictionary)}
+      out[0] = bi0; out[1] = __float_as_int(bd0); out[2] = __float_as_int(bd1);
     }
   }
   __syncthreads();
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
         else if (cand_less(c.d, c.i, r1)) { r1 = c; }
       }
       int32_t* out = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + q0 + sq) * 4;
-      out[0] = r0.i == 0x7FFFFFFF ? -1 : r0.i; out[1] = __float_as_int(r0.d); out[2] = __float_as_int(r1.d); out[3] = 1;
+      out[0] = r0.i == 0x7FFFFFFF ? -1 : r0.i; out[1] = __float_as_int(r0.d); out[2] = __float_as_int(r1.d);
       if (m.stats) atomicAdd(m.stats, 1);
     }
     __syncthreads();
@@ -332,46 +332,43 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
 }
 
 constexpr int FIN_THREADS = 1024;
-constexpr int FIN_MAXN = 1024;
+constexpr int MATCH_MAXN = 16384;       // rows per side (the candidate scratch is 2 x max_n x 16 bytes per pair)
 
+// One workgroup per pair.  The exact 2-NN records {nn index, d0, d1, -} of every row of both directions sit in the candidate scratch
+// (written by the prefilter blocks); nothing here is sized by the row count: the inverse dictionary goes into the records' fourth
+// word, the forward test walks the queries in chunks of 1024 with an ordered compaction.
 __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(MatchArgs m) {
-  __shared__ int f0[FIN_MAXN];
-  __shared__ float fd0[FIN_MAXN], fd1[FIN_MAXN];
-  __shared__ int g0[FIN_MAXN];
-  __shared__ float gd0[FIN_MAXN], gd1[FIN_MAXN];
   __shared__ int wsum[FIN_THREADS / 64];
   const int pair = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int na = min(m.a_cnt[pair], m.max_n), nb = min(m.b_cnt[pair], m.max_n);
-  // phase 1: exact 2-NN (index, d0, d1) of every row of both directions, computed by the prefilter blocks
-  for (int task = tid; task < na + nb; task += FIN_THREADS) {
-    const int dir = task < na ? 0 : 1;
-    const int row = dir == 0 ? task : task - na;
-    const int32_t* c4 = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + row) * 4;
-    if (dir == 0) { f0[row] = c4[0]; fd0[row] = __int_as_float(c4[1]); fd1[row] = __int_as_float(c4[2]); }
-    else { g0[row] = c4[0]; gd0[row] = __int_as_float(c4[1]); gd1[row] = __int_as_float(c4[2]); }
-  }
-  __syncthreads();
-  // phase 2: inverse dictionary (feature_matcher.cpp:16-25)
+  int32_t* fwd = m.cand4 + ((size_t)pair * 2 + 0) * m.max_n * 4;
+  int32_t* inv = m.cand4 + ((size_t)pair * 2 + 1) * m.max_n * 4;
+  // phase 1: inverse dictionary (feature_matcher.cpp:16-25): inv[j][3] = the a-row b-row j names, or -1
   for (int j = tid; j < nb; j += FIN_THREADS) {
-    int inv = -1;
+    int v = -1;
+    const int g0 = inv[4 * j];
     if (m.mode == 0) {
-      if (na >= 2 && (double)gd0[j] < m.ratio * (double)gd1[j]) inv = g0[j];
+      if (na >= 2 && (double)__int_as_float(inv[4 * j + 1]) < m.ratio * (double)__int_as_float(inv[4 * j + 2])) v = g0;
     } else {
-      inv = g0[j];
+      v = g0;
     }
-    g0[j] = inv;
+    inv[4 * j + 3] = v;
   }
-  __syncthreads();
-  // phase 3: forward test + ordered compaction (ascending query index)
+  __syncthreads();       // workgroup-scope release/acquire: the records are read back below by other threads of this workgroup
+  // phase 2: forward test + ordered compaction (ascending query index)
   int base = 0;
   for (int i0 = 0; i0 < na; i0 += FIN_THREADS) {
     const int i = i0 + tid;
     bool ok = false;
+    int j = -1;
+    float d0 = 0.f;
     if (i < na) {
-      const int j = f0[i];
+      j = fwd[4 * i];
+      d0 = __int_as_float(fwd[4 * i + 1]);
+      const float d1 = __int_as_float(fwd[4 * i + 2]);
       if (m.mode == 0) {
-        ok = nb >= 2 && j >= 0 && (double)fd0[i] < m.ratio * (double)fd1[i] && g0[j] == i;
+        ok = nb >= 2 && j >= 0 && (double)d0 < m.ratio * (double)d1 && inv[4 * j + 3] == i;
         if (ok && m.radius > 0 && m.pts_a && m.pts_b) {
           const float* pa = m.pts_a + 2 * ((size_t)m.a_off[pair] + i);
           const float* pb = m.pts_b + 2 * ((size_t)m.b_off[pair] + j);
@@ -380,7 +377,7 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(MatchArgs m
           if (nr > m.radius) ok = false;
         }
       } else {
-        ok = j >= 0 && g0[j] == i;
+        ok = j >= 0 && inv[4 * j + 3] == i;
       }
     }
     const unsigned long long bal = __ballot(ok);
@@ -394,7 +391,7 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(MatchArgs m
       const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
       if (pos < m.max_n) {
         const size_t o = (size_t)pair * m.max_n + pos;
-        m.q_idx[o] = i; m.t_idx[o] = f0[i]; m.dist[o] = fd0[i];
+        m.q_idx[o] = i; m.t_idx[o] = j; m.dist[o] = d0;
       }
     }
     base += total;
@@ -404,7 +401,7 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(MatchArgs m
 }
 
 hipError_t launch_match(const MatchArgs& m, hipStream_t s) {
-  if (m.dim > MAXDIM || (m.dim & 3) || m.max_n > FIN_MAXN || m.max_n < 1) return hipErrorInvalidValue;
+  if (m.dim > MAXDIM || (m.dim & 3) || m.max_n > MATCH_MAXN || m.max_n < 1) return hipErrorInvalidValue;
   const size_t lds = sizeof(float) * (MQ * QS + TB * TS + MQ + TB) + sizeof(Cand) * 4 * MQ * 4 + sizeof(float) * (4 + MQ) +
                      sizeof(int) * (MQ + 2) + sizeof(Cand) * 32;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(match_prefilter_kernel),

@@ -159,30 +159,70 @@ hipError_t launch_softmax_cand(const float* logits, int lstride, int Hc, int Wc,
 // Exact selection by MSB-first radix select on the unique 64-bit keys, then an in-LDS bitonic sort.
 // -----------------------------------------------------------------------------------------------------
 constexpr int SEL_THREADS = 1024;
-constexpr int SEL_MAXK = 1024;
+constexpr int SEL_MAXSORT = 16384;     // keys the in-LDS bitonic sort takes (128 KiB of the 160 KiB LDS)
 
+// sort_n: power of two in [1024, SEL_MAXSORT], >= min(K, SEL_MAXSORT) -- the size of the LDS key array (dynamic shared memory).
+// semi/H/thr/border: the dense score map and the candidate predicate of softmax_cand_kernel; only read when everything is kept
+// (count <= K, raster order) and the count exceeds sort_n: the keypoints then come from an ordered compaction of the map itself.
 __global__ __launch_bounds__(SEL_THREADS) void select_b_kernel(const unsigned long long* __restrict__ cand,
                                                                const int* __restrict__ cand_count, long cand_cap,
-                                                               int W, int max_kp, int cap, int always_sort,
+                                                               int W, int max_kp, int cap, int always_sort, int sort_n,
+                                                               const float* __restrict__ semi, int H, float thr, int border,
                                                                float* __restrict__ kps_xy,
                                                                float* __restrict__ scores, int32_t* __restrict__ kps_idx,
                                                                int32_t* __restrict__ n_out) {
-  __shared__ unsigned long long keys[SEL_MAXK];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];      // [sort_n]
   __shared__ int hist[256];
   __shared__ int s_digit, s_need, s_cnt;
+  __shared__ int s_wcnt[SEL_THREADS / 64];
   const int img = blockIdx.x;
   const int tid = threadIdx.x;
   const unsigned long long* c = cand + (size_t)img * cand_cap;
   long n = cand_count[img];
   if (n > cand_cap) n = cand_cap;
   int K = (max_kp < 0) ? cap : min(max_kp, cap);
-  if (K > SEL_MAXK) K = SEL_MAXK;
   const bool take_all = (n <= K) && !always_sort;   // variant A sorts by confidence even when everything is kept
+  if (take_all && n > sort_n && semi) {
+    // keep-all with more keypoints than the LDS sort takes: raster order straight from the dense score map (same predicate as the
+    // candidate list: score > thr, inside the borders), ordered compaction by ballot + prefix
+    const float* sm = semi + (size_t)img * H * W;
+    const int lane = tid & 63, wv = tid >> 6;
+    int base = 0;
+    for (long i0 = 0; i0 < (long)H * W; i0 += SEL_THREADS) {
+      const long i = i0 + tid;
+      bool ok = false;
+      float p = 0.f;
+      if (i < (long)H * W) {
+        p = sm[i];
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        ok = p > thr && y >= border && y < H - border && x >= border && x < W - border;
+      }
+      const unsigned long long m = __ballot(ok);
+      if (lane == 0) s_wcnt[wv] = __popcll(m);
+      __syncthreads();
+      int off = base, tot = 0;
+      for (int w = 0; w < SEL_THREADS / 64; ++w) { if (w < wv) off += s_wcnt[w]; tot += s_wcnt[w]; }
+      if (ok) {
+        const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (slot < cap) {
+          const size_t o = (size_t)img * cap + slot;
+          kps_xy[2 * o] = (float)(i % W); kps_xy[2 * o + 1] = (float)(i / W);
+          scores[o] = p;
+          if (kps_idx) kps_idx[o] = (int32_t)i;
+        }
+      }
+      base += tot;
+      __syncthreads();
+    }
+    if (tid == 0) n_out[img] = base < cap ? base : cap;
+    return;
+  }
+  if (K > sort_n) K = sort_n;
   // When everything is kept the output order is raster (the reference does not sort): sort on the low word
   // (0xFFFFFFFF - idx, descending == idx ascending) and let the score bits ride along in the low half.
   unsigned long long thresh = 0;  // keep keys >= thresh
   int nk = (int)(n < K ? n : K);
-  if (!take_all && n > K) {
+  if (!(take_all && n <= sort_n) && n > K) {
     // radix select: find the K-th largest key
     unsigned long long prefix = 0, mask = 0;
     int need = K;
@@ -211,40 +251,46 @@ __global__ __launch_bounds__(SEL_THREADS) void select_b_kernel(const unsigned lo
       need = s_need;
       const int above = s_cnt;
       __syncthreads();
-      if (above <= SEL_MAXK) break;   // all of them fit in LDS: sort them there and keep the first K
+      if (above <= sort_n) break;   // all of them fit in LDS: sort them there and keep the first K
     }
-    thresh = prefix;  // at least K (and <= SEL_MAXK) keys are >= thresh; the sort below keeps the first K
+    thresh = prefix;  // at least K (and <= sort_n) keys are >= thresh; the sort below keeps the first K
   }
+  const bool by_index = take_all && n <= sort_n;
   // gather survivors into LDS
   if (tid == 0) s_cnt = 0;
-  for (int i = tid; i < SEL_MAXK; i += SEL_THREADS) keys[i] = 0;
+  for (int i = tid; i < sort_n; i += SEL_THREADS) keys[i] = 0;
   __syncthreads();
   for (long i = tid; i < n; i += SEL_THREADS) {
     const unsigned long long k = c[i];
     if (k >= thresh) {
       const int slot = atomicAdd(&s_cnt, 1);
-      if (slot < SEL_MAXK) keys[slot] = take_all ? ((k << 32) | (k >> 32)) : k;
+      if (slot < sort_n) keys[slot] = by_index ? ((k << 32) | (k >> 32)) : k;
     }
   }
   __syncthreads();
-  // bitonic sort, descending, SEL_MAXK elements (zeros sink to the end)
-  for (int k2 = 2; k2 <= SEL_MAXK; k2 <<= 1)
+  // bitonic sort, descending, sort_n elements (zeros sink to the end); only as many stages as the occupied power of two needs
+  int used = s_cnt < sort_n ? s_cnt : sort_n;
+  int sn = 1024;
+  while (sn < used) sn <<= 1;
+  for (int k2 = 2; k2 <= sn; k2 <<= 1)
     for (int j = k2 >> 1; j > 0; j >>= 1) {
-      const int i = tid, ixj = i ^ j;
-      if (ixj > i) {
-        const unsigned long long x = keys[i], y = keys[ixj];
-        const bool desc = ((i & k2) == 0);
-        if (desc ? (x < y) : (x > y)) { keys[i] = y; keys[ixj] = x; }
+      for (int i = tid; i < sn; i += SEL_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long x = keys[i], y = keys[ixj];
+          const bool desc = ((i & k2) == 0);
+          if (desc ? (x < y) : (x > y)) { keys[i] = y; keys[ixj] = x; }
+        }
       }
       __syncthreads();
     }
   if (tid == 0) n_out[img] = nk;
-  if (tid < nk) {
-    unsigned long long k = keys[tid];
-    if (take_all) k = (k << 32) | (k >> 32);
+  for (int t = tid; t < nk; t += SEL_THREADS) {
+    unsigned long long k = keys[t];
+    if (by_index) k = (k << 32) | (k >> 32);
     const unsigned idx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
     const float sc = __uint_as_float((unsigned)(k >> 32));
-    const size_t o = (size_t)img * cap + tid;
+    const size_t o = (size_t)img * cap + t;
     kps_xy[2 * o] = (float)(idx % (unsigned)W);
     kps_xy[2 * o + 1] = (float)(idx / (unsigned)W);
     scores[o] = sc;
@@ -253,10 +299,17 @@ __global__ __launch_bounds__(SEL_THREADS) void select_b_kernel(const unsigned lo
 }
 
 hipError_t launch_select_b(const unsigned long long* cand, const int* cand_count, long cand_cap, int n_img, int W,
-                           int max_kp, int cap, int always_sort, float* kps_xy, float* scores, int32_t* kps_idx, int32_t* n_out,
-                           hipStream_t s) {
-  hipLaunchKernelGGL(select_b_kernel, dim3(n_img), dim3(SEL_THREADS), 0, s, cand, cand_count, cand_cap, W, max_kp, cap,
-                     always_sort, kps_xy, scores, kps_idx, n_out);
+                           int max_kp, int cap, int always_sort, const float* semi, int H, float thr, int border, float* kps_xy,
+                           float* scores, int32_t* kps_idx, int32_t* n_out, hipStream_t s) {
+  int K = max_kp < 0 ? cap : (max_kp < cap ? max_kp : cap);
+  if (K > SEL_MAXSORT) K = SEL_MAXSORT;
+  int sort_n = 1024;
+  while (sort_n < K) sort_n <<= 1;
+  const size_t lds = sizeof(unsigned long long) * (size_t)sort_n;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * SEL_MAXSORT));
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(select_b_kernel, dim3(n_img), dim3(SEL_THREADS), lds, s, cand, cand_count, cand_cap, W, max_kp, cap,
+                     always_sort, sort_n, semi, H, thr, border, kps_xy, scores, kps_idx, n_out);
   return hipGetLastError();
 }
 

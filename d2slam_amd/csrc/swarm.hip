@@ -132,6 +132,118 @@ hipError_t launch_quad_gate(const float* loc, long loc_stride, const float* rem,
   return hipGetLastError();
 }
 
+// ---- int8 wire format of the exchange block ------------------------------------------------------------------------------------------
+// The reference ships descriptors as int8 (VisualImageDesc::toLCM, d2common/include/d2common/d2frontend_types.h:228-237: q = (int8)(x / max|x| * 127)
+// with ONE float maximum over the frame's whole landmark_descriptor vector; :260-268 the NetVLAD vector with a double maximum; scores are not
+// sent) and decodes them in the LCM constructor (:319-338: x = q / 127.0, then `desc0.segment(i*32, 32).normalize()` for i < landmark_num --
+// the hard-coded 32: only the first landmark_num*32 floats are re-normalised, in 32-float pieces -- and the NetVLAD vector normalised as a whole).
+// int8 block (bytes) = desc_q[cap][256] | netvlad_q[G] | kps f32[cap][2] | n int32 | zero padding to a multiple of 64: 3.9x smaller than the fp32
+// block.  pack = the reference's quantisation; unpack expands a gathered int8 block into the fp32 block layout (scores = 0) with the
+// reference's decode arithmetic, so that the gate and the matcher see exactly the descriptors a receiving agent of the reference would hold.
+__global__ __launch_bounds__(256) void pack_blocks_int8_kernel(const float* __restrict__ desc, const float* __restrict__ kps,
+                                                               const int32_t* __restrict__ n_kp, const float* __restrict__ gdesc, int row0,
+                                                               int row_step, int cap, int G, int blk_bytes, int8_t* __restrict__ blocks) {
+  __shared__ float red[4];
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int row = row0 + f * row_step;
+  int8_t* b = blocks + (size_t)f * blk_bytes;
+  const int n = max(0, min(n_kp[row], cap));
+  const f32x4* src = reinterpret_cast<const f32x4*>(desc + (size_t)row * cap * 256);
+  float m = 0.f;
+  for (int i = tid; i < n * 64; i += 256) { const f32x4 v = src[i]; m = fmaxf(fmaxf(m, __builtin_fabsf(v[0])), fmaxf(__builtin_fabsf(v[1]), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])))); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) red[wv] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  uint32_t* dq = reinterpret_cast<uint32_t*>(b);
+  for (int i = tid; i < cap * 64; i += 256) {
+    uint32_t w = 0;
+    if (i < n * 64) {
+      const f32x4 v = src[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w |= (uint32_t)(uint8_t)(int8_t)(int)(v[e] / m * 127.0f) << (8 * e);      // C cast: truncation toward zero
+    }
+    dq[i] = w;
+  }
+  __syncthreads();
+  // NetVLAD: `double max` (d2frontend_types.h:265): x / max * 127 evaluated in double
+  float gm = 0.f;
+  if (gdesc) for (int i = tid; i < G; i += 256) gm = fmaxf(gm, __builtin_fabsf(gdesc[(size_t)f * G + i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
+  if (lane == 0) red[wv] = gm;
+  __syncthreads();
+  const double gmd = (double)fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  int8_t* gq = b + (size_t)cap * 256;
+  for (int i = tid; i < G; i += 256) gq[i] = gdesc ? (int8_t)(int)((double)gdesc[(size_t)f * G + i] / gmd * 127.0) : (int8_t)0;
+  float* bk = reinterpret_cast<float*>(gq + G);
+  for (int i = tid; i < cap * 2; i += 256) bk[i] = (i >> 1) < n ? kps[(size_t)row * cap * 2 + i] : 0.f;
+  int32_t* bn = reinterpret_cast<int32_t*>(bk + cap * 2);
+  if (tid == 0) *bn = n;
+  const int used = cap * 256 + G + cap * 8 + 4;
+  for (int i = used + tid; i < blk_bytes; i += 256) b[i] = 0;
+}
+
+// renorm 0 = the reference's decode (32-float segments, the first n of them); 1 = every descriptor row re-normalised over its 256 floats
+__global__ __launch_bounds__(256) void unpack_blocks_int8_kernel(const int8_t* __restrict__ blocks, int cap, int G, int blk_bytes, int blk_words,
+                                                                 int renorm, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int8_t* b = blocks + (size_t)f * blk_bytes;
+  float* o = out + (size_t)f * blk_words;
+  const int8_t* gq = b + (size_t)cap * 256;
+  const float* bk = reinterpret_cast<const float*>(gq + G);
+  const int n = max(0, min(*reinterpret_cast<const int32_t*>(bk + cap * 2), cap));
+  const uint32_t* dq = reinterpret_cast<const uint32_t*>(b);
+  f32x4* od = reinterpret_cast<f32x4*>(o);
+  // thread i holds 4 consecutive values; 8 consecutive threads = one 32-float segment, 64 = one descriptor row
+  for (int i0 = 0; i0 < cap * 64; i0 += 256) {
+    const int i = i0 + tid;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < n * 64) {
+      const uint32_t w = dq[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (float)((double)(int8_t)(w >> (8 * e)) / 127.0);
+    }
+    float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    const int nsh = renorm ? 32 : 4;
+#pragma unroll
+    for (int sh = 1; sh <= 32; sh <<= 1) if (sh <= nsh) s += __shfl_xor(s, sh, 64);
+    const bool norm = renorm ? (i < n * 64) : ((i >> 3) < n);        // reference: segment index < landmark_num (= n)
+    if (norm && s > 0.f) { const float r = __builtin_sqrtf(s); v[0] = v[0] / r; v[1] = v[1] / r; v[2] = v[2] / r; v[3] = v[3] / r; }
+    if (i < cap * 64) od[i] = v;
+  }
+  float* ok = o + (size_t)cap * 256;
+  for (int i = tid; i < cap * 2; i += 256) ok[i] = bk[i];
+  float* os = ok + cap * 2;
+  for (int i = tid; i < cap; i += 256) os[i] = 0.f;                  // scores are not on the wire (d2frontend_types.h:229 "Not send scores currently")
+  float* og = os + cap;
+  float s = 0.f;
+  for (int i = tid; i < G; i += 256) { const float v = (float)((double)gq[i] / 127.0); s += v * v; }
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh, 64);
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  const float z = (red[0] + red[1]) + (red[2] + red[3]);
+  const float r = __builtin_sqrtf(z);
+  for (int i = tid; i < G; i += 256) { const float v = (float)((double)gq[i] / 127.0); og[i] = z > 0.f ? v / r : v; }
+  const int used = cap * 259 + G;
+  if (tid == 0) reinterpret_cast<int32_t*>(o)[used] = n;
+  for (int i = used + 1 + tid; i < blk_words; i += 256) o[i] = 0.f;
+}
+
+hipError_t launch_pack_blocks_int8(const float* desc, const float* kps, const int32_t* n_kp, const float* gdesc, int row0, int row_step,
+                                   int nframes, int cap, int G, int blk_bytes, int8_t* blocks, hipStream_t s) {
+  hipLaunchKernelGGL(pack_blocks_int8_kernel, dim3(nframes), dim3(256), 0, s, desc, kps, n_kp, gdesc, row0, row_step, cap, G, blk_bytes, blocks);
+  return hipGetLastError();
+}
+hipError_t launch_unpack_blocks_int8(const int8_t* blocks, int nblocks, int cap, int G, int blk_bytes, int blk_words, int renorm, float* out,
+                                     hipStream_t s) {
+  hipLaunchKernelGGL(unpack_blocks_int8_kernel, dim3(nblocks), dim3(256), 0, s, blocks, cap, G, blk_bytes, blk_words, renorm, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_blocks(const float* desc, const float* kps, const float* scores, const int32_t* n_kp, const float* gdesc,
                               int row0, int row_step, int nframes, int cap, int G, int blk_words, float* blocks, hipStream_t s) {
   hipLaunchKernelGGL(pack_blocks_kernel, dim3(nframes), dim3(256), 0, s, desc, kps, scores, n_kp, gdesc, row0, row_step, cap, G, blk_words, blocks);

@@ -26,6 +26,11 @@ def block_words(cap: int, netvlad_dim: int) -> int:
     return (cap * 259 + netvlad_dim + 1 + 255) // 256 * 256
 
 
+def block_bytes_int8(cap: int, netvlad_dim: int) -> int:
+    """Mirror of d2fe_block_bytes_int8: desc_q[cap][256] | netvlad_q[G] | kps f32[cap][2] | n int32, padded to 64 bytes."""
+    return (cap * 256 + netvlad_dim + cap * 8 + 4 + 63) // 64 * 64
+
+
 def block_field_offset(cap: int, netvlad_dim: int, field: str) -> int:
     return {"desc": 0, "kps": cap * 256, "scores": cap * 258, "netvlad": cap * 259, "n": cap * 259 + netvlad_dim}[field]
 
@@ -92,11 +97,17 @@ class QuadSwarm:
     (or 16) view pairs the reference would not track, so that exactly its four pairs are matched.  WHOLE_IMG_MATCH, no radius gate
     (trackRemote passes search_radius*2 but matchLocalFeatures only uses it with motion prediction, :1100-1115)."""
 
-    def __init__(self, chain, torch, dev, world, rank, netvlad_dim, thres, mode="all2all", knn_ratio=0.8):
-        assert mode in ("all2all", "gated")
+    def __init__(self, chain, torch, dev, world, rank, netvlad_dim, thres, mode="all2all", knn_ratio=0.8, exchange="fp32"):
+        assert mode in ("all2all", "gated") and exchange in ("fp32", "int8")
         self.chain, self.torch, self.world, self.rank, self.G, self.thres, self.mode, self.ratio = chain, torch, world, rank, netvlad_dim, thres, mode, knn_ratio
+        self.exchange = exchange
         Q, NI, cap = chain.Q, chain.NI, chain.cap
         self.BLK = block_words(cap, netvlad_dim)
+        self.block_bytes = 4 * self.BLK
+        if exchange == "int8":      # the reference's wire precision (include/d2fe.h): quantise, ONE all-gather of int8 blocks, decode into `gath`
+            self.block_bytes = block_bytes_int8(cap, netvlad_dim)
+            self.blocks_q = torch.zeros((NI, self.block_bytes), dtype=torch.int8, device=dev)
+            self.gath_q = torch.zeros((world, NI, self.block_bytes), dtype=torch.int8, device=dev)
         rows_per_block = self.BLK // 256
         f32, i32 = torch.float32, torch.int32
         self.blocks = torch.zeros((NI, self.BLK), dtype=f32, device=dev)
@@ -133,9 +144,15 @@ class QuadSwarm:
         """pack -> ONE all-gather -> gate -> cross-agent matching, all ordered on the current torch stream (raw handle `st`)."""
         c, fe, torch = self.chain, self.chain.fe, self.torch
         Q, NI, cap, G = c.Q, c.NI, c.cap, self.G
-        fe.pack_blocks_device(c.desc.data_ptr(), c.pts.data_ptr(), c.scores.data_ptr(), c.cnt.data_ptr(), c.gdesc.data_ptr(), 0, 1, NI, cap, G,
-                              self.blocks.data_ptr(), stream=st)
-        all_gather_blocks(self.gath, self.blocks, group)
+        if self.exchange == "int8":
+            fe.pack_blocks_int8_device(c.desc.data_ptr(), c.pts.data_ptr(), c.cnt.data_ptr(), c.gdesc.data_ptr(), 0, 1, NI, cap, G,
+                                       self.blocks_q.data_ptr(), stream=st)
+            all_gather_blocks(self.gath_q, self.blocks_q, group)
+            fe.unpack_blocks_int8_device(self.gath_q.data_ptr(), self.world * NI, cap, G, self.gath.data_ptr(), renorm=0, stream=st)
+        else:
+            fe.pack_blocks_device(c.desc.data_ptr(), c.pts.data_ptr(), c.scores.data_ptr(), c.cnt.data_ptr(), c.gdesc.data_ptr(), 0, 1, NI, cap, G,
+                                  self.blocks.data_ptr(), stream=st)
+            all_gather_blocks(self.gath, self.blocks, group)
         if self.NP == 0:
             return
         torch.index_select(c.cnt, 0, self.a_row, out=self.a_cnt)

@@ -330,6 +330,20 @@ D2FE_API int d2fe_block_field_offset(int cap, int netvlad_dim, int field);   /* 
 D2FE_API int d2fe_pack_blocks_device(d2fe_handle h, const float* d_desc, const float* d_kps_xy, const float* d_scores,
                                      const int32_t* d_n, const float* d_netvlad, int row0, int row_step, int nframes, int cap,
                                      int netvlad_dim, float* d_blocks, void* stream);
+/* The same block in the reference's WIRE precision.  VisualImageDesc::toLCM quantises the descriptors to int8 before the broadcast
+ * (d2common/include/d2common/d2frontend_types.h:228-237: one float maximum over the frame's landmark descriptors; :260-268: the NetVLAD
+ * vector with a double maximum; scores are not sent) and the receiving constructor decodes them (:319-338: q / 127.0, the first
+ * landmark_num 32-float segments re-normalised -- the reference's hard-coded 32 --, the NetVLAD vector normalised as a whole).
+ *   int8 block (bytes) = desc_q[cap][256] | netvlad_q[G] | kps f32[cap][2] | n int32 | zero padding to a multiple of 64   (3.9x smaller)
+ * d2fe_pack_blocks_int8_device = the quantisation, on the sender; d2fe_unpack_blocks_int8_device expands gathered int8 blocks into the
+ * fp32 block layout above (scores = 0) with the decode arithmetic: renorm 0 = as the reference (landmark_num = n), 1 = every descriptor
+ * re-normalised over its 256 floats.  Gate and matcher then read exactly what a receiving agent of the reference would hold. */
+D2FE_API int d2fe_block_bytes_int8(int cap, int netvlad_dim);
+D2FE_API int d2fe_pack_blocks_int8_device(d2fe_handle h, const float* d_desc, const float* d_kps_xy, const int32_t* d_n,
+                                          const float* d_netvlad, int row0, int row_step, int nframes, int cap, int netvlad_dim,
+                                          int8_t* d_blocks, void* stream);
+D2FE_API int d2fe_unpack_blocks_int8_device(d2fe_handle h, const int8_t* d_blocks_int8, int nblocks, int cap, int netvlad_dim, int renorm,
+                                            float* d_blocks, void* stream);
 /* NetVLAD gate of a pair list.  Replaces the similarity test of D2FeatureTracker::getMatchedPrevKeyframe
  * (d2frontend/src/d2featuretracker.cpp:185-203: `vlad_desc.dot(vlad_desc_remote) < track_remote_netvlad_thres` rejects) and of
  * LoopDetector::queryIndexFromDatabase (loop_detector.cpp:339).  Pair p compares row d_pair_q[p] of d_q (rows q_stride words apart)

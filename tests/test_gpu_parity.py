@@ -220,7 +220,23 @@ def test_match_edge_cases(api, orc):
     assert np.array_equal(q, np.arange(50)) and np.array_equal(t, np.arange(50)) and np.all(d == 0)
     # too many rows -> loud error, not silence
     with pytest.raises(api.D2FEError):
-        fe.match_knn(np.zeros((1025, 256), np.float32), b, 0.8)
+        fe.match_knn(np.zeros((16385, 256), np.float32), b, 0.8)
+    fe.close()
+
+
+@pytest.mark.parametrize("na,nb,dim", [(1025, 1500, 256), (3000, 2000, 128), (5000, 700, 64)])
+def test_match_more_than_1024_rows(api, orc, na, nb, dim):
+    """The matcher takes up to 16384 rows per side (the reference's matchKNN is unbounded; keep-all extractions produce thousands of
+    keypoints): exact against the oracle, as for small sets."""
+    fe = _fe(api, 64, 64, 1, api.PREC_F32)
+    a, b, pa, pb = synth_descriptor_pair(na, nb, dim, seed=na + nb, sigma=0.1)
+    for radius in (-1.0, 60.0):
+        q, t, d = fe.match_knn(a, b, 0.8, pa, pb, radius)
+        rq, rt, rd = orc.match_knn(a, b, 0.8, pa, pb, radius)
+        assert len(rq) > 100 and np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd)
+    q, t, d = fe.match_crosscheck(a, b)
+    rq, rt, rd = orc.match_crosscheck(a, b)
+    assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd)
     fe.close()
 
 
@@ -595,7 +611,9 @@ def test_matcher_fuzz(api, orc):
 
 @pytest.mark.parametrize("H,W,maxkp,thr", [(512, 512, 150, 0.015),      # C1: TUM 512x512 (config/tum/tum_single.yaml:20-21)
                                            (400, 800, 100, 0.015),      # C3: one undistorted quadcam view, 100 keypoints
-                                           (480, 640, 1024, 0.015),     # the largest keypoint budget the ABI accepts
+                                           (480, 640, 1024, 0.015),     # the former limit of the ABI
+                                           (480, 640, 3000, 0.015),     # above it: 4096-key in-LDS sort (TensorRT profile 1500 x 1500, thousands of points)
+                                           (240, 320, 16384, 0.002),    # the largest sorted budget the ABI accepts (25 611 candidates)
                                            (480, 640, 200, 0.9999)])    # a threshold nothing passes: zero keypoints, no failure
 def test_other_configs_and_limits(api, orc, sp_weights, H, W, maxkp, thr):
     img = synth_image(H, W, 91)
@@ -603,7 +621,7 @@ def test_other_configs_and_limits(api, orc, sp_weights, H, W, maxkp, thr):
     fe.load_superpoint(sp_weights)
     kps, sc, desc = fe.extract_batch(img[None], cap=maxkp)[0][:3]
     rk, rs, rd, ri, f = orc.extract_b(img, sp_weights, thr, 1, maxkp)
-    assert len(kps) == len(rk) and (thr < 0.9 or len(kps) == 0) and (thr > 0.9 or len(kps) == maxkp)
+    assert len(kps) == len(rk) and (thr < 0.9 or len(kps) == 0) and (thr > 0.9 or len(kps) == maxkp), (len(kps), len(rk))
     assert np.array_equal(kps, rk) and np.array_equal(sc, rs)
     if len(kps):
         assert np.abs(desc - rd).max() <= 1e-6

@@ -266,6 +266,34 @@ def test_hip_keep_all_vs_reference_cpp(api, orc, sp_weights):
     fe.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "wino"])
+def test_hip_keep_all_thousands_of_keypoints_vs_reference_cpp(api, orc, sp_weights, prec):
+    """Keep-all (topKeypoints with k = -1, superpoint_tensorrt.cpp:241-253) is unbounded in the reference: with a low threshold a 240x320 image
+    yields tens of thousands of keypoints, all of which come back, in raster order, with their descriptors -- far beyond the 1024 the
+    interface used to stop at, and beyond the 16384 the in-LDS sort takes (the raster compaction of the dense score map serves those)."""
+    H, W = 240, 320
+    img = synth_image(H, W, 15)
+    for target in (5000, 30000):
+        fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=-1, input_width=W, input_height=H, max_batch=1, keypoint_threshold=0.0,
+                                               precision=api.PREC_F32 if prec == "f32" else api.PREC_F32_WINO, keep_score_map=True, dense_descriptors=True))
+        fe.load_superpoint(sp_weights)
+        fe.extract_batch(img[None], cap=16)
+        semi = fe.debug_read("semi", (1, H, W))[0]
+        fe.close()
+        thr = float(np.sort(semi.reshape(-1))[-target])
+        fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=-1, input_width=W, input_height=H, max_batch=1, keypoint_threshold=thr,
+                                               precision=api.PREC_F32 if prec == "f32" else api.PREC_F32_WINO, keep_score_map=True, dense_descriptors=True))
+        fe.load_superpoint(sp_weights)
+        (kps, sc, desc), = fe.extract_batch(img[None], cap=H * W)
+        draw = fe.debug_read("desc_raw", (1, H // 8, W // 8, 256))[0]
+        rk, rs, rd = spref.superpoint_post(semi, orc.l2norm_rows(draw), thr, 1, -1)
+        assert not fe.last_truncated and 0.8 * target < len(rk) < target
+        assert np.array_equal(kps, rk) and np.array_equal(sc, rs)
+        assert np.abs(desc - rd).max() <= 1e-6
+        fe.close()
+
+
 # ---- round 3: the reference-owned code either side of the hot path (oracle/ref_shim/spref_api2.cpp) ---------------------------------
 def _unit_rows(x):
     return (x / np.linalg.norm(x, axis=-1, keepdims=True)).astype(np.float32)

@@ -124,3 +124,65 @@ def test_rccl_single_rank_collectives():
     env = dict(os.environ); env["MASTER_PORT"] = str(_free_port())
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_rccl_1rank.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL 1-rank OK" in r.stdout, (r.stdout + r.stderr)[-2000:]
+
+
+def test_int8_exchange_blocks_vs_reference_codec():
+    """The int8 wire format of the exchange block: bytes equal the reference's own toLCM quantisation (oracle/_ref, compiled in place) on the
+    frame's n x 256 descriptor vector and on the NetVLAD vector; the decoded fp32 block equals the reference's LCM-constructor decode
+    (q/127.0, the first n 32-float segments re-normalised, whole-vector NetVLAD normalisation)."""
+    import torch
+    from d2slam_amd import api, swarm
+    from oracle import oracle as orc, ref as spref
+    orc.build()
+    dev = torch.device("cuda", 0)
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=50, input_width=64, input_height=64, max_batch=1))
+    cap, G, rows = 48, 128, 5
+    rng = np.random.RandomState(2)
+    desc = rng.randn(rows, cap, 256).astype(np.float32); desc /= np.linalg.norm(desc, axis=2, keepdims=True)
+    kps = (rng.rand(rows, cap, 2) * 100).astype(np.float32); n = np.array([48, 0, 7, 33, 90], np.int32)      # 90 > cap: clamped
+    g = rng.randn(rows, G).astype(np.float32); g /= np.linalg.norm(g, axis=1, keepdims=True)
+    BB = api.block_bytes_int8(cap, G); BLK = api.block_words(cap, G)
+    assert BB == swarm.block_bytes_int8(cap, G) and BB * 3.5 < 4 * BLK
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_desc, d_kps, d_n, d_g = t(desc), t(kps), t(n), t(g)
+    bq = torch.full((rows, BB), 7, dtype=torch.int8, device=dev)
+    fe.pack_blocks_int8_device(d_desc.data_ptr(), d_kps.data_ptr(), d_n.data_ptr(), d_g.data_ptr(), 0, 1, rows, cap, G, bq.data_ptr())
+    for renorm in (0, 1):
+        out = torch.full((rows, BLK), 7.0, device=dev)
+        fe.unpack_blocks_int8_device(bq.data_ptr(), rows, cap, G, out.data_ptr(), renorm=renorm)
+        fe.sync(); torch.cuda.synchronize()
+        q = bq.cpu().numpy(); o = out.cpu().numpy()
+        off = {f: api.block_field_offset(cap, G, f) for f in ("desc", "kps", "scores", "netvlad", "n")}
+        for f in range(rows):
+            k = min(int(n[f]), cap)
+            have_ref = spref.available()
+            ql = (spref.quant_landmarks if have_ref else orc.quant_int8)(desc[f, :k].reshape(-1)) if k else np.zeros(0, np.int8)
+            qn = spref.quant_netvlad(g[f]) if have_ref else orc.quant_int8(g[f], double_max=True)
+            assert np.array_equal(q[f, :k * 256], ql) and not q[f, k * 256:cap * 256].any()
+            assert np.array_equal(q[f, cap * 256:cap * 256 + G], qn)
+            assert np.array_equal(q[f, cap * 256 + G:cap * 256 + G + cap * 8].view(np.float32)[:2 * k], kps[f, :k].reshape(-1))
+            assert int(q[f, cap * 256 + G + cap * 8:cap * 256 + G + cap * 8 + 4].view(np.int32)[0]) == k
+            if renorm == 0:
+                rl, rn = (spref.dequant(ql, k, qn) if have_ref else (orc.dequant_int8(ql, k) if k else np.zeros(0, np.float32), orc.dequant_int8(qn, -1)))
+            else:
+                x = (ql.astype(np.float64) / 127.0).astype(np.float32).reshape(k, 256)
+                rl = (x / np.linalg.norm(x, axis=1, keepdims=True)).reshape(-1) if k else np.zeros(0, np.float32)
+                rn = orc.dequant_int8(qn, -1)
+            assert np.abs(o[f, :k * 256] - rl).max(initial=0) <= 1e-6 and not o[f, k * 256:off["kps"]].any()
+            assert np.abs(o[f, off["netvlad"]:off["netvlad"] + G] - rn).max() <= 1e-6
+            assert np.array_equal(o[f, off["kps"]:off["kps"] + 2 * k], kps[f, :k].reshape(-1)) and not o[f, off["scores"]:off["netvlad"]].any()
+            assert int(o[f].view(np.int32)[off["n"]]) == k
+            if renorm == 0 and k >= 16:
+                # the reference's decode: rows < k/8 are unit per 32-float segment (norm sqrt(8)), the rest stay scaled by 1/max|x|
+                nr = np.linalg.norm(o[f, :k * 256].reshape(k, 256), axis=1)
+                assert np.abs(nr[:k // 8] - np.sqrt(8.0)).max() < 1e-4 and nr[k // 8 + 1:].min() > 1.5
+    fe.close()
+
+
+def test_bench_int8_exchange_runs_under_gloo():
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "2", "--single-mode", "--no-cpu-baseline",
+                   "--exchange", "int8"], {"D2FE_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, _rank_errors(r)
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["exchange"]["wire_precision"] == "int8" and j["exchange"]["block_bytes"] * 3.5 < 4 * 56064
+    assert j["exchange"]["avg_cross_agent_matches_per_pair"] >= 0
