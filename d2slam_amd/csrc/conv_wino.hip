@@ -90,8 +90,17 @@ __device__ unsigned g_wino_hw[1024][2];      // ABL 256: HW_ID / XCC_ID of wave 
 // holds tile  ty = 2*(q>>2) + parity(q),  tx = 4*((q>>1)&1) + (t&3),  q = t>>2.  ds_read_b128 serves a wave in the lane groups
 // {0-3,12-15,20-27} and {4-11,16-19,28-31} (+32): with this assignment a group holds tile rows {0,2} or {1,3}, whose
 // positions 12*ty + tx cover every residue mod 16 exactly once -- one 16-byte slot per lane, no bank conflict.
-template <int CIN, bool POOL, bool RELU, int ABL, int I, bool FUSE>
+// NT: 32-channel halves of the output channels a wave carries.  NT = 2 (default): the 8 x 16 pixel x 64 channel items described above (128
+// accumulators, two workgroups per CU).  NT = 1 (ring kernels only, D2FE_WINO_NT=1): 8 x 16 pixels x 32 channels per item -- 64 accumulators,
+// 138 registers and 48 KB of LDS per workgroup, so THREE workgroups share a CU and two waves of a SIMD are in their K loops while the third is
+// in its MFMA-free epilogue.  The price is the input transform, the LDS window reads and the patch copies once per 32 instead of per 64
+// output channels -- measured (round 3, profiles/r03_wino_nt_ab.txt): 6-8 % slower on every layer, bit-identical.  Kept as the record of
+// the structural experiment VERDICT r02 asked for; same arithmetic per output, so the oracle does not change.
+template <int CIN, bool POOL, bool RELU, int ABL, int I, bool FUSE, int NT>
 __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, int ncb, int total, float* wlds) {
+  static_assert(NT == 1 || NT == 2, "a wave carries one or two 32-channel halves");
+  static_assert(!FUSE || NT == 2, "the fused conv1b kernel keeps 64 channels per item (its LDS patch allows two workgroups per CU either way)");
+  constexpr int WXCHN = 4 * 6 * NT * 64 * 4;  // floats of the exchange area: [wave 4][3 other waves x 2 tile pairs x NT float4][64 lanes]
   constexpr int NCH = CIN / 8;               // chunks per work item
   constexpr int KSTEPS = CIN / 2;
   // FUSE (conv1b): the whole 64-channel patch is produced in LDS by conv1a on the matrix pipe instead of being copied in; its
@@ -110,7 +119,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   const int tstride = gridDim.x;
   const bool dyn = a.work_ctr != nullptr && total >= 48 * tstride;      // short walks (10-40 items per workgroup) gain nothing from claiming (measured)
   int icur = blockIdx.x, inxt = icur + tstride;                  // indices >= total: no such item
-  int* claim_slot = reinterpret_cast<int*>(FUSE ? wlds + 8 * (2 * 4 * (FUSE ? 272 : 256)) + 64 : wlds + WR * WCHUNK + WXCH);
+  int* claim_slot = reinterpret_cast<int*>(FUSE ? wlds + 8 * (2 * 4 * (FUSE ? 272 : 256)) + 64 : wlds + WR * WCHUNK + WXCHN);
 
   // ---- LDS-DMA: wave w copies channel quad (w>>1), parity planes 2(w&1), 2(w&1)+1 (64 slots = one instruction each) ---------
   struct DmaItem { __amdgpu_buffer_rsrc_t rsrc; int off[2]; };
@@ -141,13 +150,13 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   const int ty = 2 * (q8 >> 2) + (__builtin_popcount(q8) & 1), tx = 4 * ((q8 >> 1) & 1) + (trow & 3);
   const int rd_off = hh * 4 * PL + (ty * WROW + tx) * 4;     // floats: quad hh, plane 0, this lane's tile origin
   // U: one buffer resource over the packed weights; wave-uniform byte offset of a 32-channel group's stream + lane * 16
-  const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, ncb * 2 * KSTEPS * 4096, 0x00020000);
-  auto u_ptr = [&](const WItem& T) { return T.cb * 2 * KSTEPS * 4096; };      // first of the item's two 32-channel streams
+  const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, ncb * NT * KSTEPS * 4096, 0x00020000);
+  auto u_ptr = [&](const WItem& T) { return T.cb * NT * KSTEPS * 4096; };      // first of the item's NT 32-channel streams
   const int lane16 = lane * 16 + I * 1024;       // xi quad I (row I) of the 4 KiB k-step record
 
-  f32x16 acc[8];           // acc[nt*4 + j]: position (I, j), 32-channel half nt
+  f32x16 acc[4 * NT];      // acc[nt*4 + j]: position (I, j), 32-channel half nt
   f32x4 dq[8];             // dq[r*4+dx] = the 4 channels of this lane's quad at window position (dy = DY[r], dx)
-  f32x4 ub[4][2];          // [k-step of the chunk][nt]: the fragments of k-step k+3 are requested before the MFMAs of k-step k
+  f32x4 ub[4][NT];         // [k-step of the chunk][nt]: the fragments of k-step k+3 are requested before the MFMAs of k-step k
   // the two window rows row I of B^T d B is made of:  t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3
   constexpr int DYA = I == 0 ? 0 : 1, DYB = I == 3 ? 3 : 2;
 
@@ -164,7 +173,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   auto load_u = [&](int slot, int up, int ks) {
     if constexpr ((ABL & 2) != 0) return;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) ub[slot][nt] = buf_load_f32x4(u_rsrc, lane16, up + (nt * KSTEPS + ks) * 4096);
+    for (int nt = 0; nt < NT; ++nt) ub[slot][nt] = buf_load_f32x4(u_rsrc, lane16, up + (nt * KSTEPS + ks) * 4096);
   };
   // row I of B^T d B for channel j of the quad, then the row transform
   auto transform = [&](auto j_c, float (&v)[4]) {
@@ -184,7 +193,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     constexpr bool first = decltype(first_c)::value != 0;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[nt * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], ub[slot][nt][j], first ? zero : acc[nt * 4 + j], 0, 0, 0);
@@ -225,11 +234,11 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   auto epilogue = [&](const WItem& T) {
     float* out = a.out + (size_t)T.img * a.out_img_stride + a.out_coff;
     const int cs = a.out_cstride, cs4 = cs * 4;
-    const int n32 = T.cb * 2;
+    const int n32 = T.cb * NT;
     const int co0 = n32 * 32 + (lane & 31);
-    const float bias0 = a.bias[co0], bias1 = a.bias[co0 + 32];
-    // fast path (item inside the image, all 64 channels real): buffer stores, wave-uniform offsets on the SALU
-    const bool full = T.by * 8 + 8 <= aH && T.bx * 16 + 16 <= aW && (n32 + 2) * 32 <= a.cout_real && !(ABL & 4);
+    const float bias0 = a.bias[co0], bias1 = NT == 2 ? a.bias[co0 + 32] : 0.f;
+    // fast path (item inside the image, all of its channels real): buffer stores, wave-uniform offsets on the SALU
+    const bool full = T.by * 8 + 8 <= aH && T.bx * 16 + 16 <= aW && (n32 + NT) * 32 <= a.cout_real && !(ABL & 4);
     const int Wo = POOL ? (aW >> 1) : aW, Ho = POOL ? (aH >> 1) : aH;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, Ho * Wo * cs4, 0x00020000);
     const int rowpair = (POOL ? Wo : 2 * Wo) * cs4;               // bytes between tile rows ty and ty + 1
@@ -243,18 +252,18 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     auto padd = [](f32x2 x, f32x2 y) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
     auto psub = [](f32x2 x, f32x2 y) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y)); return d; };
     // kept pairs: sk[p * 2 + nt] = (s_b0(r), s_b0(r+1), s_b1(r), s_b1(r+1)) of row I for the tile pair r = 4I + 2p and channel half nt
-    f32x4 sk[4];
-    f32x4* xw = reinterpret_cast<f32x4*>(xch) + (I * 12) * 64 + lane;
+    f32x4 sk[2 * NT];
+    f32x4* xw = reinterpret_cast<f32x4*>(xch) + (I * 6 * NT) * 64 + lane;
 #pragma unroll
     for (int rp = 0; rp < 8; ++rp) {
       const int r = 2 * rp, o = rp >> 1, p = rp & 1;        // o: the wave that finishes these two tiles
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
+      for (int nt = 0; nt < NT; ++nt) {
         const f32x2 m0 = {acc[nt * 4 + 0][r], acc[nt * 4 + 0][r + 1]}, m1 = {acc[nt * 4 + 1][r], acc[nt * 4 + 1][r + 1]};
         const f32x2 m2 = {acc[nt * 4 + 2][r], acc[nt * 4 + 2][r + 1]}, m3 = {acc[nt * 4 + 3][r], acc[nt * 4 + 3][r + 1]};
         const f32x2 b0 = padd(padd(m0, m1), m2), b1 = psub(psub(m1, m2), m3);
         const f32x4 q = {b0[0], b0[1], b1[0], b1[1]};
-        if (o == I) sk[p * 2 + nt] = q; else xw[((o < I ? o : o - 1) * 4 + p * 2 + nt) * 64] = q;
+        if (o == I) sk[p * NT + nt] = q; else xw[((o < I ? o : o - 1) * 2 * NT + p * NT + nt) * 64] = q;
       }
     }
     mark(trace_item, 8, 1);
@@ -307,13 +316,13 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
       constexpr int p = decltype(p_c)::value;
       constexpr int r = 4 * I + 2 * p;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
+      for (int nt = 0; nt < NT; ++nt) {
         f32x2 lo[4], hi[4];      // rows 0..3 of s: lo = (b0(r), b0(r+1)), hi = (b1(r), b1(r+1))
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           f32x4 sv;
-          if (w == I) sv = sk[p * 2 + nt];
-          else sv = (reinterpret_cast<const f32x4*>(xch) + (w * 12 + (I < w ? I : I - 1) * 4 + p * 2 + nt) * 64)[lane];
+          if (w == I) sv = sk[p * NT + nt];
+          else sv = (reinterpret_cast<const f32x4*>(xch) + (w * 6 * NT + (I < w ? I : I - 1) * 2 * NT + p * NT + nt) * 64)[lane];
           lo[w] = f32x2{sv[0], sv[1]}; hi[w] = f32x2{sv[2], sv[3]};
         }
         const float bias = nt ? bias1 : bias0;
@@ -428,7 +437,8 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   load_u(1, ucur, 1);
   load_u(2, ucur, 2);
   if constexpr (!FUSE) {
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // chunk 0 landed (younger: 2 x 2 copies + 6 U loads)
+    // chunk 0 landed (younger: 2 x 2 copies + 3 x NT U loads)
+    if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     __syncthreads();
     read_d(0);
   }
@@ -468,10 +478,10 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     } else {
       const bool has_next = inxt < total;
       if (ch + 1 < NCH || has_next) {
-        // chunk g+1 (copied WR-1 iterations ago) must have landed: the loads younger than it are this iteration's 8 U loads
-        // and the 2 copies of chunk g+2 -- loads complete in order, so "at most 10 outstanding" implies it is complete (a claim
+        // chunk g+1 (copied WR-1 iterations ago) must have landed: the loads younger than it are this iteration's 4 x NT U loads
+        // and the 2 copies of chunk g+2 -- loads complete in order, so "at most 4 NT + 2 outstanding" implies it is complete (a claim
         // in flight in wave 0 only makes the wait stricter)
-        if (ch + 2 < NCH || has_next) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        if (ch + 2 < NCH || has_next) { if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       mark(item, ch, 2);
@@ -514,8 +524,8 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   }
 }
 
-template <int CIN, bool POOL, bool RELU, int ABL = 0, int TAG = 0, bool FUSE = false>
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a, int nbx, int nby, int ncb, int total) {
+template <int CIN, bool POOL, bool RELU, int ABL = 0, int TAG = 0, bool FUSE = false, int NT = 2>
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(ConvArgs a, int nbx, int nby, int ncb, int total) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   if ((int)blockIdx.x >= total) return;
   if constexpr ((ABL & 256) != 0) {
@@ -528,10 +538,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a, int nbx, 
   }
   // the four rows of the transform domain run different (compile-time) row arithmetic; the branch is wave-uniform
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-    case 0: wino_body<CIN, POOL, RELU, ABL, 0, FUSE>(a, nbx, nby, ncb, total, wlds); break;
-    case 1: wino_body<CIN, POOL, RELU, ABL, 1, FUSE>(a, nbx, nby, ncb, total, wlds); break;
-    case 2: wino_body<CIN, POOL, RELU, ABL, 2, FUSE>(a, nbx, nby, ncb, total, wlds); break;
-    default: wino_body<CIN, POOL, RELU, ABL, 3, FUSE>(a, nbx, nby, ncb, total, wlds); break;
+    case 0: wino_body<CIN, POOL, RELU, ABL, 0, FUSE, NT>(a, nbx, nby, ncb, total, wlds); break;
+    case 1: wino_body<CIN, POOL, RELU, ABL, 1, FUSE, NT>(a, nbx, nby, ncb, total, wlds); break;
+    case 2: wino_body<CIN, POOL, RELU, ABL, 2, FUSE, NT>(a, nbx, nby, ncb, total, wlds); break;
+    default: wino_body<CIN, POOL, RELU, ABL, 3, FUSE, NT>(a, nbx, nby, ncb, total, wlds); break;
   }
 }
 
@@ -540,11 +550,17 @@ hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const C
   if (cout_pad % 64 || (a.in_cstride & 3) || (a.in_coff & 3)) return hipErrorInvalidValue;
   // buffer addressing: 32-bit byte offsets inside one image's tensor, 0x80000000 must stay out of range
   if ((long)a.H * a.W * a.in_cstride * 4 >= (1l << 31) || (long)a.H * a.W * a.out_cstride * 4 >= (1l << 31)) return hipErrorInvalidValue;
-  const int nbx = (a.W + 15) / 16, nby = (a.H + 7) / 8, ncb = cout_pad / 64;
+  // D2FE_WINO_NT=1 selects the 32-channel items (three workgroups per CU, round 3's structural experiment: every layer 6-8 % SLOWER
+  // than the 64-channel items, profiles/r03_wino_nt_ab.txt -- the doubled input transform / LDS reads / patch copies cost more than the
+  // third wave per SIMD hides); default: 64-channel items, two workgroups per CU
+  static const int nt_env = [] { const char* e = getenv("D2FE_WINO_NT"); return e ? atoi(e) : 2; }();
+  const int NTsel = (nt_env == 1 && !a.ablate) ? 1 : 2;
+  const int nbx = (a.W + 15) / 16, nby = (a.H + 7) / 8, ncb = cout_pad / (32 * NTsel);
   const int total = nbx * nby * ncb * a.n_img;
   const int ncu = a.ncu > 0 ? a.ncu : 256;     // ConvArgs::ncu: the handle's device (no process-wide cache: one process may drive several GPUs)
-  const int grid = total < 2 * ncu ? total : 2 * ncu;      // two workgroups per CU (2 waves per SIMD)
-  constexpr size_t lds = (size_t)(WR * WCHUNK + WXCH) * sizeof(float) + 16;      // ring + exchange area + the claim slot
+  const int wg_per_cu = NTsel == 1 ? 3 : 2;
+  const int grid = total < wg_per_cu * ncu ? total : wg_per_cu * ncu;
+  const size_t lds = (size_t)(WR * WCHUNK + (NTsel == 1 ? WXCH / 2 : WXCH)) * sizeof(float) + 16;      // ring + exchange area + the claim slot
 #define D2FE_WINO_K(K)                                                                                       \
   do {                                                                                                      \
     auto k = K;                                                                                             \
@@ -552,6 +568,13 @@ hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const C
     if (e != hipSuccess) return e;                                                                          \
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a, nbx, nby, ncb, total);                          \
   } while (0)
+  if (NTsel == 1) {
+    if (cin == 64 && pool && relu) { D2FE_WINO_K((conv_wino_kernel<64, true, true, 0, 0, false, 1>)); return hipGetLastError(); }
+    if (cin == 64 && !pool && relu) { D2FE_WINO_K((conv_wino_kernel<64, false, true, 0, 0, false, 1>)); return hipGetLastError(); }
+    if (cin == 128 && pool && relu) { D2FE_WINO_K((conv_wino_kernel<128, true, true, 0, 0, false, 1>)); return hipGetLastError(); }
+    if (cin == 128 && !pool && relu) { D2FE_WINO_K((conv_wino_kernel<128, false, true, 0, 0, false, 1>)); return hipGetLastError(); }
+    return hipErrorInvalidValue;
+  }
   if (a.ablate && cin == 64 && !pool && relu) {     // timing experiments through d2fe_debug_conv3x3_wino (D2FE_ABLATE)
     switch (a.ablate) {
       case 1: D2FE_WINO_K((conv_wino_kernel<64, false, true, 1>)); return hipGetLastError();
