@@ -270,6 +270,8 @@ def main():
         t1 = time.perf_counter()
         prof = fe.profile_read()
         fe.profile_enable(0)
+        fb = fe.match_fallback_rows(reset=True, full=True)
+        fallback_rows = (fb[0] / float(steps + args.warmup), fb[1] / float(steps + args.warmup))
         elapsed = t1 - t0
         if world > 1:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -322,7 +324,7 @@ def main():
         gfirst = gdesc[0].cpu().numpy().copy() if netvlad else None
         fe.close()
         return dict(sel=sel, first=first, gfirst=gfirst, value=value, ms_per_step=ms_per_step, roofline=roofline, roofline_nv=roofline_nv, n_kp=n_kp,
-                    n_match=n_match, breakdown=breakdown, NI=NI, NP=NP, F=F, gated=gated, exch=exch)
+                    n_match=n_match, breakdown=breakdown, NI=NI, NP=NP, F=F, gated=gated, exch=exch, fallback_rows=fallback_rows)
 
     use_nv = not args.no_netvlad
     primary = run_mode(args.precision, True, netvlad=use_nv)
@@ -377,6 +379,8 @@ def main():
                        "weights": "seeded random-init SuperPoint / MobileNetVLAD stand-in (no checkpoints in the reference tree)"},
             "sp_tflops_algorithmic": round(SP_FLOP_PER_IMG * 2 * value / 1e12, 2),
             "avg_keypoints_per_image": round(primary["n_kp"], 1), "avg_matches_per_pair": round(primary["n_match"], 1),
+            "matcher_queries_past_first_4_candidates_per_step": round(primary["fallback_rows"][0], 2),
+            "matcher_exact_scan_rows_per_step": round(primary["fallback_rows"][1], 2),
             "roofline": primary["roofline"], "roofline_netvlad": primary["roofline_nv"], "cpu_baseline": cpu_baseline, "parity": parity,
             "mode_parity": PAR[args.precision],
         }

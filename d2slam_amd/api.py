@@ -145,7 +145,7 @@ def load_library():
         lib.d2fe_destroy.argtypes = [C.c_void_p]
         lib.d2fe_load_superpoint.argtypes = [C.c_void_p, C.c_void_p]
         lib.d2fe_sync.argtypes = [C.c_void_p]
-        lib.d2fe_match_fallback_rows.argtypes = [C.c_void_p, C.c_int]
+        lib.d2fe_match_fallback_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.d2fe_match_fallback_rows.restype = C.c_long
         lib.d2fe_tail_stream.argtypes = [C.c_void_p]
         lib.d2fe_tail_stream.restype = C.c_void_p
@@ -323,12 +323,14 @@ class FrontEnd:
             _check(rc)
         return [(kps[i, :cnt[i]].copy(), sc[i, :cnt[i]].copy(), desc[i, :cnt[i]].copy()) for i in range(n)]
 
-    def match_fallback_rows(self, reset=True):
-        """Queries whose 2-NN came from the matcher's exact fallback scan since the last reset (include/d2fe.h)."""
-        r = int(self._lib.d2fe_match_fallback_rows(self._h, int(bool(reset))))
+    def match_fallback_rows(self, reset=True, full=False):
+        """Queries that needed more than the matcher's first four candidates since the last reset (include/d2fe.h); full=True returns
+        (that count, the number that took the exact scan of all train rows)."""
+        fs = C.c_long(0)
+        r = int(self._lib.d2fe_match_fallback_rows(self._h, int(bool(reset)), C.byref(fs)))
         if r < 0:
             _check(r)
-        return r
+        return (r, int(fs.value)) if full else r
 
     def extract_device(self, d_gray, n, W, H, d_kps, d_scores, d_desc, d_idx, cap, d_n, stream=None, stride=None,
                        image_stride=None):

@@ -1774,14 +1774,15 @@ int d2fe_profile_read(d2fe_handle h, float* ms, int32_t* launches) {
   return D2FE_OK;
 }
 
-long d2fe_match_fallback_rows(d2fe_handle h, int reset) {
+long d2fe_match_fallback_rows(d2fe_handle h, int reset, long* full_scans) {
   if (!h) return fail(D2FE_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   HIP_TRY(hipDeviceSynchronize());
-  int32_t v = 0;
-  HIP_TRY(hipMemcpy(&v, h->match_stats, sizeof(v), hipMemcpyDeviceToHost));
-  if (reset) HIP_TRY(hipMemset(h->match_stats, 0, sizeof(int32_t)));
-  return v;
+  int32_t v[2] = {0, 0};
+  HIP_TRY(hipMemcpy(v, h->match_stats, sizeof(v), hipMemcpyDeviceToHost));
+  if (reset) HIP_TRY(hipMemset(h->match_stats, 0, sizeof(v)));
+  if (full_scans) *full_scans = v[0];
+  return v[1];
 }
 
 int d2fe_sync(d2fe_handle h) {

@@ -183,6 +183,7 @@ struct MatchArgs {
   // scratch: per pair, per direction, per row: 4 candidate indices
   int32_t* cand4;   // [npairs][2][max_n][4]
   int32_t* stats = nullptr;   // optional: [0] += queries whose 2-NN came from the exact fallback scan (match.hip)
+  int no_fallback = 0;        // D2FE_MATCH_NOFALLBACK=1 (timing experiments only): skip the saturation test
 };
 hipError_t launch_match(const MatchArgs& m, hipStream_t s);
 

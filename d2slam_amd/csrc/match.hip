@@ -13,11 +13,13 @@
 //      ORACLE's arithmetic (orc_l2_dist: OpenCV normL2Sqr_ accumulation order, then sqrt), takes the exact
 //      2-NN, applies ratio / mutual / radius tests in double exactly as feature_matcher.cpp:16-37, and emits
 //      matches in ascending query order.
-// Exact by construction: the top-4 is chosen on the Gram-trick distance, whose error against the exact one is bounded by
-// GRAM_ERR * (|q|^2 + |t|^2).  A row excluded from the top-4 has an approximate d2 >= the 4th candidate's; if that bound cannot rule
-// out that such a row beats the exact 2nd neighbour (more than four rows within round-off of each other: repeated texture, a frame
-// matched against a near-copy, all-equal sets), the query is SATURATED and its 2-NN is recomputed by an exact scan of every train
-// row in the oracle's arithmetic.  Indices and distances therefore equal the oracle's bit for bit for any input.
+// Exact by construction: candidates are chosen on the Gram-trick distance, whose error against the exact one is bounded by
+// GRAM_ERR * (|q|^2 + |t|^2).  Eight candidates per query are tracked; the first four are re-ranked exactly.  A row outside the
+// first four has an approximate d2 >= the 4th candidate's: if that bound cannot rule out that such a row beats the exact 2nd
+// neighbour, the query is SATURATED at level 1 (about 1 % of the queries on SuperPoint descriptors, whose 2nd..4th neighbours lie
+// ~3e-3 apart in d2) and candidates 5..8 are re-ranked exactly as well, now against the 8th candidate's bound; only if that fails
+// too (more than eight rows within round-off of each other: repeated texture, a frame matched against a near-copy, all-equal sets)
+// is the 2-NN recomputed by an exact scan of every train row.  Indices and distances equal the oracle's bit for bit for any input.
 #include "kernels.h"
 
 namespace d2fe {
@@ -37,11 +39,12 @@ constexpr float GRAM_ERR = 4.0e-5f;
 
 struct Cand { float d; int i; };
 __device__ __forceinline__ bool cand_less(float d, int i, const Cand& c) { return d < c.d || (d == c.d && i < c.i); }
-__device__ __forceinline__ void cand_insert(Cand (&top)[4], float d, int i) {
-  if (!cand_less(d, i, top[3])) return;
-  top[3].d = d; top[3].i = i;
+constexpr int NC = 8;          // candidates tracked per query (the first four are always re-ranked, the rest on demand)
+__device__ __forceinline__ void cand_insert(Cand (&top)[NC], float d, int i) {
+  if (!cand_less(d, i, top[NC - 1])) return;
+  top[NC - 1].d = d; top[NC - 1].i = i;
 #pragma unroll
-  for (int k = 3; k > 0; --k) {
+  for (int k = NC - 1; k > 0; --k) {
     if (cand_less(top[k].d, top[k].i, top[k - 1])) {
       const Cand t = top[k]; top[k] = top[k - 1]; top[k - 1] = t;
     }
@@ -87,12 +90,16 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
   float* Ts = Qs + MQ * QS;               // [TB][TS]
   float* qn = Ts + TB * TS;               // [MQ]
   float* tn = qn + MQ;                    // [TB]
-  Cand* merge = reinterpret_cast<Cand*>(tn + TB);  // [4 waves][MQ][4]
-  float* aux = reinterpret_cast<float*>(merge + 4 * MQ * 4);   // [4] per-wave max |t|^2
+  Cand* merge = reinterpret_cast<Cand*>(tn + TB);  // [4 waves][MQ][NC]
+  float* aux = reinterpret_cast<float*>(merge + 4 * MQ * NC);  // [4] per-wave max |t|^2
   float* m4th = aux + 4;                                        // [MQ] approximate d2 of the 4th candidate
-  int* satn = reinterpret_cast<int*>(m4th + MQ);                // number of saturated queries of this tile
-  int* sat = satn + 1;                                          // [MQ] their tile-local rows
-  Cand* scan = reinterpret_cast<Cand*>(sat + MQ + 1);           // [16 groups][2] partial 2-NN of the exact scan (8-byte aligned)
+  float* m8th = m4th + MQ;                                      // [MQ] ... of the 8th
+  int* mcand2 = reinterpret_cast<int*>(m8th + MQ);              // [MQ][4] candidates 5..8
+  float* mdist2 = reinterpret_cast<float*>(mcand2 + MQ * 4);    // [MQ][4] their exact distances (computed for saturated queries only)
+  int* satn = reinterpret_cast<int*>(mdist2 + MQ * 4);          // [2]: saturated at level 1 / still saturated after level 2
+  int* sat = satn + 2;                                          // [MQ] tile-local rows saturated at level 1
+  int* sat2 = sat + MQ;                                         // [MQ] ... at level 2: exact scan
+  Cand* scan = reinterpret_cast<Cand*>(sat2 + MQ + 2);          // [16 groups][2] partial 2-NN of the exact scan (8-byte aligned)
 
   const int pair = blockIdx.z, dir = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -122,9 +129,9 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
     if (part == 0) qn[r] = s;
   }
 
-  Cand top[4];
+  Cand top[NC];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { top[k].d = __builtin_inff(); top[k].i = 0x7FFFFFFF; }
+  for (int k = 0; k < NC; ++k) { top[k].d = __builtin_inff(); top[k].i = 0x7FFFFFFF; }
 
   const int nkc = (dim + KCH - 1) / KCH;
   // train chunks (TB rows x KCH columns) go global -> registers -> LDS; the loads of chunk c + 1 are in flight during the norms and the
@@ -197,21 +204,21 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
   }
   // merge the two lane halves (same query, different train rows)
   {
-    Cand other[4];
+    Cand other[NC];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NC; ++k) {
       other[k].d = __shfl_xor(top[k].d, 32, 64);
       other[k].i = __shfl_xor(top[k].i, 32, 64);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cand_insert(top, other[k].d, other[k].i);
+    for (int k = 0; k < NC; ++k) cand_insert(top, other[k].d, other[k].i);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) tnmax = fmaxf(tnmax, __shfl_xor(tnmax, o, 64));
   __syncthreads();
   if (lane < 32) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) merge[(wave * MQ + lane) * 4 + k] = top[k];
+    for (int k = 0; k < NC; ++k) merge[(wave * MQ + lane) * NC + k] = top[k];
   }
   if (lane == 0) aux[wave] = tnmax;
   __syncthreads();
@@ -220,15 +227,19 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
   if (wave == 0 && lane < 32) {
     for (int w = 1; w < 4; ++w)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const Cand c = merge[(w * MQ + lane) * 4 + k];
+      for (int k = 0; k < NC; ++k) {
+        const Cand c = merge[(w * MQ + lane) * NC + k];
         cand_insert(top, c.d, c.i);
       }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) mcand[lane * 4 + k] = top[k].i == 0x7FFFFFFF ? -1 : top[k].i;
-    m4th[lane] = top[3].d;                          // approximate d2 of the weakest candidate kept: every dropped row has at least this
+    for (int k = 0; k < 4; ++k) {
+      mcand[lane * 4 + k] = top[k].i == 0x7FFFFFFF ? -1 : top[k].i;
+      mcand2[lane * 4 + k] = top[4 + k].i == 0x7FFFFFFF ? -1 : top[4 + k].i;
+    }
+    m4th[lane] = top[3].d;                          // every row outside the first four has an approximate d2 of at least this
+    m8th[lane] = top[NC - 1].d;                     // ... and every row outside the eight of at least this
   }
-  if (tid == 0) *satn = 0;
+  if (tid < 2) satn[tid] = 0;
   __syncthreads();
   // exact re-rank: every (query, candidate) distance re-evaluated in the oracle's order, 16 lanes per pair.  A 16-lane group owns 8 of
   // the 128 (query, candidate) pairs; for dim = 256 the train-row elements of FOUR pairs (4 x 16 loads per lane) are requested before
@@ -279,33 +290,60 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
     }
   }
   __syncthreads();
-  if (tid < MQ && q0 + tid < nq) {
-    float bd0 = __builtin_inff(), bd1 = __builtin_inff();
-    int bi0 = -1, bi1 = -1;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float dk = mdist[tid * 4 + k];
-      const int ik = mcand[tid * 4 + k];
+  // the exact 2-NN among a query's re-ranked candidates: (distance, index) lexicographic = the oracle's insertion order
+  auto best2 = [&](int q, int ncand, float& bd0, int& bi0, float& bd1, int& bi1) {
+    bd0 = __builtin_inff(); bd1 = __builtin_inff(); bi0 = -1; bi1 = -1;
+    for (int k = 0; k < ncand; ++k) {
+      const float dk = k < 4 ? mdist[q * 4 + k] : mdist2[q * 4 + k - 4];
+      const int ik = k < 4 ? mcand[q * 4 + k] : mcand2[q * 4 + k - 4];
       if (ik < 0) continue;
       if (dk < bd0 || (dk == bd0 && ik < bi0)) { bd1 = bd0; bi1 = bi0; bd0 = dk; bi0 = ik; }
       else if (dk < bd1 || (dk == bd1 && ik < bi1)) { bd1 = dk; bi1 = ik; }
     }
-    // saturation test (header): can a row that was dropped from the top-4 still beat the exact 2nd neighbour?
-    const float slack = GRAM_ERR * (qn[tid] + fmaxf(fmaxf(aux[0], aux[1]), fmaxf(aux[2], aux[3])));
-    const bool saturated = nt > 4 && !(m4th[tid] - slack > bd1 * bd1 * 1.00001f);
-    if (saturated) {
-      sat[atomicAdd(satn, 1)] = tid;
-    } else {
-      int32_t* out = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + q0 + tid) * 4;   // {nn index, d0 bits, d1 bits, (finalize: inverse dictionary)}
-      out[0] = bi0; out[1] = __float_as_int(bd0); out[2] = __float_as_int(bd1);
-    }
+  };
+  auto emit = [&](int q, int bi0, float bd0, float bd1) {
+    int32_t* out = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + q0 + q) * 4;   // {nn index, d0 bits, d1 bits, (finalize: inverse dictionary)}
+    out[0] = bi0; out[1] = __float_as_int(bd0); out[2] = __float_as_int(bd1);
+  };
+  const float tn_all = fmaxf(fmaxf(aux[0], aux[1]), fmaxf(aux[2], aux[3]));
+  if (tid < MQ && q0 + tid < nq) {
+    float bd0, bd1; int bi0, bi1;
+    best2(tid, 4, bd0, bi0, bd1, bi1);
+    // saturation test (header): can a row outside the first four still beat the exact 2nd neighbour?
+    const float slack = GRAM_ERR * (qn[tid] + tn_all);
+    const bool saturated = !m.no_fallback && nt > 4 && !(m4th[tid] - slack > bd1 * bd1 * 1.00001f);
+    if (saturated) sat[atomicAdd(&satn[0], 1)] = tid; else emit(tid, bi0, bd0, bd1);
   }
   __syncthreads();
-  // exact scan of the saturated queries (normally none): 16 lanes per train row, 16 rows in flight, every row of the pair's train set;
-  // (distance, index) compared lexicographically = the oracle's "strictly smaller replaces" insertion in ascending index
-  const int ns = *satn;
-  for (int si = 0; si < ns; ++si) {
-    const int sq = sat[si];
+  const int ns = satn[0];
+  if (ns > 0) {
+    // level 2: candidates 5..8 of the saturated queries, 16 lanes per (query, candidate)
+    for (int p0 = 0; p0 < ns * 4; p0 += 16) {
+      const int pr = p0 + (tid >> 4);
+      if (pr < ns * 4) {
+        const int q = sat[pr >> 2], k = pr & 3;
+        const int ci = mcand2[q * 4 + k];
+        const float dd = exact_dist16(Qs + q * QS, T + (size_t)(ci >= 0 ? ci : 0) * dim, dim, tid & 15, lane);
+        if ((tid & 15) == 0) mdist2[q * 4 + k] = ci >= 0 ? dd : __builtin_inff();
+      }
+    }
+    __syncthreads();
+    if (tid < ns) {
+      const int q = sat[tid];
+      float bd0, bd1; int bi0, bi1;
+      best2(q, 8, bd0, bi0, bd1, bi1);
+      const float slack = GRAM_ERR * (qn[q] + tn_all);
+      const bool still = nt > NC && !(m8th[q] - slack > bd1 * bd1 * 1.00001f);
+      if (still) sat2[atomicAdd(&satn[1], 1)] = q; else emit(q, bi0, bd0, bd1);
+      if (m.stats) atomicAdd(m.stats + 1, 1);
+    }
+    __syncthreads();
+  }
+  // exact scan of the queries that are saturated even with eight candidates (degenerate inputs): 16 lanes per train row, 16 rows in
+  // flight, every row of the pair's train set
+  const int ns2 = ns > 0 ? satn[1] : 0;
+  for (int si = 0; si < ns2; ++si) {
+    const int sq = sat2[si];
     const int grp = tid >> 4, slot = tid & 15;
     Cand b0{__builtin_inff(), 0x7FFFFFFF}, b1{__builtin_inff(), 0x7FFFFFFF};
     for (int j = grp; j < nt; j += 16) {
@@ -323,8 +361,7 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(MatchArgs m) {
         if (cand_less(c.d, c.i, r0)) { r1 = r0; r0 = c; }
         else if (cand_less(c.d, c.i, r1)) { r1 = c; }
       }
-      int32_t* out = m.cand4 + (((size_t)pair * 2 + dir) * m.max_n + q0 + sq) * 4;
-      out[0] = r0.i == 0x7FFFFFFF ? -1 : r0.i; out[1] = __float_as_int(r0.d); out[2] = __float_as_int(r1.d);
+      emit(sq, r0.i == 0x7FFFFFFF ? -1 : r0.i, r0.d, r1.d);
       if (m.stats) atomicAdd(m.stats, 1);
     }
     __syncthreads();
@@ -400,10 +437,12 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(MatchArgs m
   if (tid == 0) m.n_out[pair] = base < m.max_n ? base : m.max_n;
 }
 
-hipError_t launch_match(const MatchArgs& m, hipStream_t s) {
+hipError_t launch_match(const MatchArgs& m_in, hipStream_t s) {
+  MatchArgs m = m_in;
+  { static const int nf = [] { const char* e = getenv("D2FE_MATCH_NOFALLBACK"); return e ? atoi(e) : 0; }(); m.no_fallback = nf; }
   if (m.dim > MAXDIM || (m.dim & 3) || m.max_n > MATCH_MAXN || m.max_n < 1) return hipErrorInvalidValue;
-  const size_t lds = sizeof(float) * (MQ * QS + TB * TS + MQ + TB) + sizeof(Cand) * 4 * MQ * 4 + sizeof(float) * (4 + MQ) +
-                     sizeof(int) * (MQ + 2) + sizeof(Cand) * 32;
+  const size_t lds = sizeof(float) * (MQ * QS + TB * TS + MQ + TB) + sizeof(Cand) * 4 * MQ * NC + sizeof(float) * (4 + 2 * MQ + 8 * MQ) +
+                     sizeof(int) * (2 * MQ + 4) + sizeof(Cand) * 32;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(match_prefilter_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

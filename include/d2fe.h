@@ -190,12 +190,14 @@ D2FE_API int d2fe_match_knn(d2fe_handle h, const float* a, int na, const float* 
 D2FE_API int d2fe_match_crosscheck(d2fe_handle h, const float* a, int na, const float* b, int nb, int dim,
                                    int32_t* q_idx, int32_t* t_idx, float* dist, int cap, int* n_out);
 
-/* Both matchers pick their candidates with a Gram-trick prefilter and re-rank them in the reference's (OpenCV's) arithmetic; a query
- * whose candidate list cannot be proven to contain the true two nearest neighbours (more than four train rows within fp32 round-off of
- * each other: repeated texture, near-duplicate frames) is re-evaluated by an exact scan of all train rows, so the result equals the
- * reference's for any input.  d2fe_match_fallback_rows returns how many queries took that scan since the last reset (diagnostic;
- * synchronises the device). */
-D2FE_API long d2fe_match_fallback_rows(d2fe_handle h, int reset);
+/* Both matchers pick eight candidates per query with a Gram-trick prefilter and re-rank the first four in the reference's (OpenCV's)
+ * arithmetic.  A query whose first four cannot be PROVEN to contain the true two nearest neighbours (the prefilter's rigorous error
+ * bound; about 1 % of the queries on SuperPoint descriptors) has candidates 5..8 re-ranked as well; if eight cannot be proven either
+ * (more than eight train rows within fp32 round-off of each other: repeated texture, near-duplicate frames, degenerate sets) the
+ * query is re-evaluated by an exact scan of all train rows.  The result equals the reference's for any input.
+ * d2fe_match_fallback_rows returns how many queries went past the first four candidates since the last reset and, in *full_scans
+ * (may be NULL), how many of them took the exact scan (diagnostic; synchronises the device). */
+D2FE_API long d2fe_match_fallback_rows(d2fe_handle h, int reset, long* full_scans);
 
 /* Batched, device-resident matcher: npairs problems; pair p matches rows [a_off[p], a_off[p]+a_cnt[p]) of
  * d_a against rows [b_off[p], ...) of d_b.  Counts may live on the device (d_a_cnt/d_b_cnt, e.g. the d_n_out

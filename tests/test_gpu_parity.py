@@ -281,8 +281,11 @@ def test_match_saturated_candidate_lists_are_exact(api, orc, case):
         q, t, d = fe.match_crosscheck(a, b)
         rq, rt, rd = orc.match_crosscheck(a, b)
         assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd), case
-    if case != "self_plus_noise_1e-7":       # there every row has three near-equal partners at most: the top-4 provably suffices
-        assert fe.match_fallback_rows() > 0, "the saturated rows of %s did not take the exact scan" % case
+    past4, scans = fe.match_fallback_rows(full=True)
+    if case != "self_plus_noise_1e-7":       # there every row has three near-equal partners at most: the first four provably suffice
+        assert past4 > 0, "the saturated rows of %s did not go past the first four candidates" % case
+    if "all_equal" in case or case == "eight_identical_train_rows":
+        assert scans > 0, "more than eight rows within round-off (%s): the exact scan must have run" % case
     fe.close()
 
 
@@ -294,7 +297,8 @@ def test_match_fallback_is_rare_on_ordinary_descriptors(api, orc):
     q, t, d = fe.match_knn(a, b, 0.8)
     rq, rt, rd = orc.match_knn(a, b, 0.8)
     assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd)
-    assert fe.match_fallback_rows() <= 40          # of 400 queries
+    past4, scans = fe.match_fallback_rows(full=True)
+    assert past4 <= 40 and scans == 0               # of 400 queries
     fe.close()
 
 
