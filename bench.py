@@ -490,6 +490,30 @@ def collective_evidence(torch, dist, dev, backend, rank, world):
             "distinct_devices": len(ids), "ranks": allr}
 
 
+def profiled_traffic(kernel_tag):
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes of this command (profiles/r03_wino_rocprofv3_summary.txt:
+    separate --pmc FETCH_SIZE and WRITE_SIZE passes, tools/profile.sh; KiB per dispatch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950's wide reads).  bench.py itself does not collect counters: null when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r03_wino_rocprofv3_summary.txt")
+    if not os.path.exists(path):
+        return None, None
+    fetch = write = None
+    lines = open(path).read().split("\n")
+    sect = ""
+    for i, l in enumerate(lines):
+        if l.startswith("== "):
+            sect = l
+        if kernel_tag in l and i + 1 < len(lines):
+            nxt = lines[i + 1]
+            if "pmc_fetch" in sect and "FETCH_SIZE=" in nxt:
+                fetch = float(nxt.split("FETCH_SIZE=")[1].split()[0])
+            if "pmc_write" in sect and "WRITE_SIZE=" in nxt:
+                write = float(nxt.split("WRITE_SIZE=")[1].split()[0])
+    if fetch is None or write is None:
+        return None, None
+    return int((2.0 * fetch + write) * 1024), "profiles/r03_wino_rocprofv3_summary.txt: 2 x FETCH_SIZE %.4g KiB + WRITE_SIZE %.4g KiB per dispatch (rocprofv3 --pmc passes of `python bench.py`, same build; not collected inside this run)" % (fetch, write)
+
+
 def conv1b_roofline(precision, avg_ms, launches, NI, fused):
     peak = PEAK_TFLOPS[precision]
     alg = CONV1B_FLOP_PER_IMG * NI
@@ -500,11 +524,13 @@ def conv1b_roofline(precision, avg_ms, launches, NI, fused):
         executed = items * (1024 + (60 if fused is not False else 0)) * 4096.0
         ach_e = executed / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         ach_a = alg / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic, tnote = profiled_traffic("conv_wino_kernel<64, true, true, 0, 1, true") if (fused is not False and NI == 64) else (None, None)
         return {"kernel": "conv_wino_kernel<64,POOL,RELU,FUSE> (conv1a from the u8 frame fused into conv1b as Winograd F(2x2,3x3), + ReLU + 2x2 max-pool)",
                 "bound": "mfma", "achieved": round(ach_e, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach_e / peak, 4),
                 "frac_executed": round(ach_e / peak, 4), "frac_algorithmic": round(ach_a / peak, 4),
                 "achieved_algorithmic": round(ach_a, 2),
-                "traffic": None, "traffic_note": "HBM bytes per launch are in profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, r02_*); not collected inside this run",
+                "traffic": traffic, "traffic_note": tnote or "HBM bytes per launch are in profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes); not collected inside this run",
+                "compulsory_bytes_per_launch": int(NI * (H * W + (H // 2) * (W // 2) * 64 * 4)),
                 "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                 "algorithmic_flop_per_launch": alg, "executed_mfma_flop_per_launch": executed,
                 "note": "frac = frac_executed = MFMA FLOPs the kernel executes / HIP-event time / 157.3 TF (the matrix pipe's roofline fraction); "

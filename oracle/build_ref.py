@@ -38,6 +38,13 @@ RANGES = {
     "SPREF_GEN_TRACKER_GATE": ("d2frontend/src/d2featuretracker.cpp", 166, 235, "bool D2FeatureTracker::getMatchedPrevKeyframe(", "}"),
     "SPREF_GEN_TRACKER_DIRS": ("d2frontend/src/d2featuretracker.cpp", 270, 284, "int max_dirs = 4;", "}"),
     "SPREF_GEN_LOOPCAM_MATCH": ("d2frontend/src/loop_cam.cpp", 156, 191, "void matchLocalFeatures(", "}"),
+    # round 3 (ref_shim/spref_api3.cpp): undistortion map generation = camodocal (vendored camera_models/) + FisheyeUndist::genOneUndistMap
+    "SPREF_GEN_CATA_SPACE": ("camera_models/src/camera_models/CataCamera.cc", 495, 515, "void CataCamera::spaceToPlane(const Eigen::Vector3d& P,", "}"),
+    "SPREF_GEN_CATA_DIST": ("camera_models/src/camera_models/CataCamera.cc", 617, 633, "void CataCamera::distortion(const Eigen::Vector2d& p_u,", "}"),
+    "SPREF_GEN_CYL_INVK": ("camera_models/src/camera_models/CylindricalCamera.cc", 144, 147, "m_inv_K11 = 1.0 / mParameters.fx();", "m_inv_K23 = -mParameters.cy() / mParameters.fy();"),
+    "SPREF_GEN_CYL_LIFT": ("camera_models/src/camera_models/CylindricalCamera.cc", 207, 220, "void CylindricalCamera::liftProjective(const Eigen::Vector2d& p,", "}"),
+    "SPREF_GEN_MAP_LOOP_VCAM": ("d2common/include/d2common/fisheye_undistort.h", 571, 579, "for (unsigned int x = 0; x < imgWidth; x++)", "cv::Vec2f(imgPoint.x(), imgPoint.y());"),
+    "SPREF_GEN_MAP_LOOP_PINHOLE": ("d2common/include/d2common/fisheye_undistort.h", 627, 638, "for (unsigned int x = 0; x < imgWidth; x++)", "cv::Vec2f(imgPoint.x(), imgPoint.y());"),
 }
 
 
@@ -80,7 +87,7 @@ def build(force=False, verbose=False):
             defs.append('-D%s="%s"' % (macro, inc))
         cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-w",
                "-I" + SHIM, "-I" + os.path.join(REF, "d2frontend", "include")] + defs + \
-              [os.path.join(SHIM, "spref_api.cpp"), os.path.join(SHIM, "spref_api2.cpp"), "-o", LIB]
+              [os.path.join(SHIM, "spref_api.cpp"), os.path.join(SHIM, "spref_api2.cpp"), os.path.join(SHIM, "spref_api3.cpp"), "-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -155,3 +155,20 @@ def loopcam_match(pts_up, desc_up, pts_down, desc_down):
     iu = np.empty(n, np.int32); idn = np.empty(n, np.int32); po = np.empty((n, 2), np.float32); pdo = np.empty((n, 2), np.float32)
     k = lib().spref_loopcam_match(_p(pu), _p(du), len(pu), _p(pd), _p(dd), len(pd), du.shape[1], _p(iu), _p(idn), _p(po), _p(pdo))
     return iu[:k].copy(), idn[:k].copy(), po[:k].copy(), pdo[:k].copy()
+
+
+def gen_cylinder_map(cam9, width, height, fov_deg):
+    """FisheyeUndist::generateCylinderMap + genOneUndistMap (fisheye_undistort.h:458-500,559-613) over camodocal's CataCamera / CylindricalCamera
+    (vendored camera_models/), compiled in place.  cam9 = (xi, k1, k2, p1, p2, gamma1, gamma2, u0, v0).  Returns (mapx, mapy) float32 [h, w]."""
+    c = np.ascontiguousarray(cam9, np.float64)
+    mx = np.empty((height, width), np.float32); my = np.empty((height, width), np.float32)
+    lib().spref_gen_cylinder_map(_p(c), int(width), int(height), C.c_double(fov_deg), _p(mx), _p(my))
+    return mx, my
+
+
+def gen_pinhole_map(cam9, q_wxyz, width, height, f):
+    """The rotated-pinhole genOneUndistMap (fisheye_undistort.h:615-660)."""
+    c = np.ascontiguousarray(cam9, np.float64); q = np.ascontiguousarray(q_wxyz, np.float64)
+    mx = np.empty((height, width), np.float32); my = np.empty((height, width), np.float32)
+    lib().spref_gen_pinhole_map(_p(c), _p(q), int(width), int(height), C.c_double(f), _p(mx), _p(my))
+    return mx, my

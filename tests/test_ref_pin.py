@@ -464,3 +464,47 @@ def test_hip_crosscheck_vs_reference_loopcam_match(api):
         q, t, _ = fe.match_crosscheck(a, b)
         assert np.array_equal(iu, q) and np.array_equal(idn, t)
     fe.close()
+
+
+# ---- (f)-1 map generation: camodocal (vendored camera_models/) + FisheyeUndist::genOneUndistMap compiled in place ---------------------
+# cam0 of config/quadcam/quad_cam_calib-camchain-imucam-7-inch-n3.yaml (camera_model omni, distortion radtan)
+_MEI9 = [2.2176903753419963, -0.17703529535292872, 0.7517933338735744, -0.0008911425891703079, 2.1653595535258756e-05,
+         1162.5434300524314, 1161.839362615319, 660.6393183718625, 386.1663300322095]
+_MAP_CASES = [(800, 400, 200.0), (640, 480, 190.0), (401, 203, 235.0)]      # the quadcam geometry, another one, odd sizes (unsigned width / 2)
+
+
+@pytest.mark.parametrize("W,H,fov", _MAP_CASES)
+def test_cylinder_map_vs_reference_cpp(orc, W, H, fov):
+    """generateCylinderMap / genOneUndistMap (fisheye_undistort.h:458-500,559-613) with CataCamera::spaceToPlane / distortion and
+    CylindricalCamera::liftProjective (camera_models/, CataCamera.cc:495-515,617-633, CylindricalCamera.cc:144-147,207-220) compiled where they lie:
+    the oracle's restatement is bitwise equal (fp64 evaluation, float store)."""
+    mx, my = orc.gen_cylinder_map(_MEI9, W, H, fov)
+    rx, ry = spref.gen_cylinder_map(_MEI9, W, H, fov)
+    assert np.array_equal(mx, rx) and np.array_equal(my, ry)
+
+
+@pytest.mark.parametrize("angle,axis", [(-np.pi / 4, 1), (np.pi / 4, 1), (0.3, 0), (0.0, 1)])
+def test_pinhole_map_vs_reference_cpp(orc, angle, axis):
+    """The rotated-pinhole genOneUndistMap (fisheye_undistort.h:615-660) incl. Eigen's Quaternion * Vector3 order."""
+    q = [np.cos(angle / 2), 0.0, 0.0, 0.0]; q[1 + axis] = np.sin(angle / 2)
+    px, py = orc.gen_pinhole_map(_MEI9, q, 600, 300, 300.0)
+    rx, ry = spref.gen_pinhole_map(_MEI9, q, 600, 300, 300.0)
+    assert np.array_equal(px, rx) and np.array_equal(py, ry)
+
+
+@pytest.mark.gpu
+def test_hip_maps_vs_reference_cpp(api):
+    """d2fe_gen_cylinder_map / d2fe_gen_pinhole_map against the reference's own map generation: fp64 on the device, where tan()/sqrt() may
+    differ from glibc's in the last fp64 bit -> at most one fp32 ulp on a handful of entries."""
+    fe = api.FrontEnd(api.SuperPointConfig(input_width=64, input_height=64, max_batch=1))
+    cam = dict(zip(("xi", "k1", "k2", "p1", "p2", "gamma1", "gamma2", "u0", "v0"), _MEI9))
+    for W, H, fov in _MAP_CASES[:2]:
+        gx, gy = fe.gen_cylinder_map(cam, W, H, fov)
+        rx, ry = spref.gen_cylinder_map(_MEI9, W, H, fov)
+        assert np.abs(gx - rx).max() <= 1.3e-4 and np.abs(gy - ry).max() <= 1.3e-4
+        assert (gx == rx).mean() > 0.999 and (gy == ry).mean() > 0.999
+    q = [np.cos(np.pi / 8), 0.0, np.sin(np.pi / 8), 0.0]
+    px, py = fe.gen_pinhole_map(_MEI9, q, 600, 300, 300.0)
+    rx, ry = spref.gen_pinhole_map(_MEI9, q, 600, 300, 300.0)
+    assert np.abs(px - rx).max() <= 1.3e-4 and np.abs(py - ry).max() <= 1.3e-4 and (px == rx).mean() > 0.999
+    fe.close()
