@@ -137,11 +137,14 @@ def main():
             fe.load_netvlad(nv_weights)
             G = fe.netvlad_dim
         # frame order within a step: [L0 .. L(F-1), R0 .. R(F-1)] -- the left images are one contiguous batch for NetVLAD
-        host = np.empty((NI, H, W), np.uint8)
+        # two alternating frame sets: even steps see the frames, odd steps the same scenes after a small camera motion (shifted by 3 x 2
+        # pixels), so that L <-> previous-L is a real temporal match between DIFFERENT keypoint sets, not a frame against itself
+        host = np.empty((2, NI, H, W), np.uint8)
         for f in range(F):
             l, r = synth_stereo(H, W, seed=rank * 1000 + f)
-            host[f], host[F + f] = l, r
-        host_pin = torch.from_numpy(host).pin_memory()
+            host[0, f], host[0, F + f] = l, r
+            host[1, f], host[1, F + f] = np.roll(l, (2, 3), (0, 1)), np.roll(r, (2, 3), (0, 1))
+        host_pins = [torch.from_numpy(host[i]).pin_memory() for i in range(2)]
         imgs = [torch.empty((NI, H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
 
         # one pool of 256-float rows: [0, 2F*CAP) current L|R descriptors, [2F*CAP, 3F*CAP) previous L, then the gathered blocks
@@ -153,7 +156,7 @@ def main():
         kps = torch.zeros((3 * F, CAP, 2), dtype=torch.float32, device=dev)
         cnt = torch.zeros((3 * F,), dtype=torch.int32, device=dev)
         scores = torch.zeros((NI, CAP), dtype=torch.float32, device=dev)
-        kidx = torch.zeros((NI, CAP), dtype=torch.int32, device=dev)
+        kidx = torch.zeros((NI + F, CAP), dtype=torch.int32, device=dev)       # rows [NI, NI + F): the previous step's left images
         gdesc = torch.zeros((max(F, 1), max(G, 4)), dtype=torch.float32, device=dev)
         blocks = torch.zeros((F, BLK), dtype=torch.float32, device=dev) if world > 1 else None
         int8x = world > 1 and args.exchange == "int8"
@@ -196,7 +199,7 @@ def main():
             """frames of the next step: pinned host -> HBM on the copy stream (19.7 MB per 32 stereo frames)"""
             with torch.cuda.stream(copy_s):
                 copy_s.wait_event(ev_free[b])
-                imgs[b].copy_(host_pin, non_blocking=True)
+                imgs[b].copy_(host_pins[b], non_blocking=True)
                 ev_copy[b].record(copy_s)
 
         def step():
@@ -245,6 +248,7 @@ def main():
                 # this step's left descriptors become the "previous keyframe" of the next step
                 desc[NI:NI + F].copy_(desc[:F])
                 cnt[NI:NI + F].copy_(cnt[:F])
+                kidx[NI:NI + F].copy_(kidx[:F])
 
         def barrier():
             if world > 1:
@@ -256,8 +260,8 @@ def main():
                 e.record(main)
             upload(0)
         else:
-            for im in imgs:
-                im.copy_(host_pin)
+            for b, im in enumerate(imgs):
+                im.copy_(host_pins[b])
         for _ in range(args.warmup):
             step()
         barrier()
@@ -290,6 +294,18 @@ def main():
             exch = {"wire_precision": args.exchange, "block_bytes": per_block, "all_gather_bytes_received_per_step_per_gpu": per_block * F * (world - 1),
                     "avg_cross_agent_matches_per_pair": round(mn[pl.n_local:].float().mean().item(), 2)}
 
+        # what this mode selected and matched (compared across modes: `mode_disagreement`, `parity`): taken after a step on frame set 0
+        # (the previous-left rows then hold frame set 1), whatever --steps / --warmup were
+        if (state["k"] - 1) & 1:
+            step()
+        torch.cuda.synchronize(dev)
+        k0 = int(cnt[0].item())
+        first = (kps[0, :k0].cpu().numpy(), scores[0, :k0].cpu().numpy(), desc[0, :k0].cpu().numpy())
+        # what this mode selected and matched on the step's frames (compared across modes below: `mode_disagreement`)
+        sel = {"kidx": kidx.cpu().numpy().copy(), "cnt": cnt.cpu().numpy().copy(), "mq": mq[:pl.n_local].cpu().numpy().copy(),
+               "mt": mt[:pl.n_local].cpu().numpy().copy(), "mn": mn[:pl.n_local].cpu().numpy().copy(),
+               "a_row": list(pl.a_cnt_row[:pl.n_local]), "b_row": list(pl.b_cnt_row[:pl.n_local])}
+        gfirst = gdesc[0].cpu().numpy().copy() if netvlad else None
         breakdown = None
         if want_breakdown and rank == 0 and world == 1:
             fe.profile_enable(2)
@@ -315,13 +331,6 @@ def main():
                            "note": "fp32 MFMA (v_mfma_f32_16x16x4_f32) + VALU depthwise; instruction/latency-bound small layers (DESIGN.md section 4); "
                                    "HIP events around the whole sequence on the launch stream"}
 
-        k0 = int(cnt[0].item())
-        first = (kps[0, :k0].cpu().numpy(), scores[0, :k0].cpu().numpy(), desc[0, :k0].cpu().numpy())
-        # what this mode selected and matched on the step's frames (compared across modes below: `mode_disagreement`)
-        sel = {"kidx": kidx[:NI].cpu().numpy().copy(), "cnt": cnt[:NI].cpu().numpy().copy(), "mq": mq[:pl.n_local].cpu().numpy().copy(),
-               "mt": mt[:pl.n_local].cpu().numpy().copy(), "mn": mn[:pl.n_local].cpu().numpy().copy(),
-               "a_row": list(pl.a_cnt_row[:pl.n_local]), "b_row": list(pl.b_cnt_row[:pl.n_local])}
-        gfirst = gdesc[0].cpu().numpy().copy() if netvlad else None
         fe.close()
         return dict(sel=sel, first=first, gfirst=gfirst, value=value, ms_per_step=ms_per_step, roofline=roofline, roofline_nv=roofline_nv, n_kp=n_kp,
                     n_match=n_match, breakdown=breakdown, NI=NI, NP=NP, F=F, gated=gated, exch=exch, fallback_rows=fallback_rows)
@@ -427,7 +436,7 @@ def mode_disagreement(a, b, F):
     frames the bench times: keypoints that one mode selects and the other does not (raster indices, per image), and matches
     (as pairs of raster indices, so independent of the order inside a keypoint list) that one mode reports and the other does not.
     Both modes are fp32 evaluations of the same network; they can only differ where two scores are closer than their ~1e-6 round-off."""
-    NI = a["kidx"].shape[0]
+    NI = 2 * F
     kp_tot = kp_diff = img_diff = 0
     for i in range(NI):
         sa = set(a["kidx"][i, :a["cnt"][i]].tolist()); sb = set(b["kidx"][i, :b["cnt"][i]].tolist())
@@ -435,9 +444,7 @@ def mode_disagreement(a, b, F):
         kp_tot += len(sb); kp_diff += d; img_diff += d > 0
     m_tot = m_diff = lr_tot = lr_diff = 0
     for p in range(len(a["mn"])):
-        ra, rb = a["a_row"][p], a["b_row"][p]
-        # the previous-keyframe rows [2F, 3F) hold the left images' keypoints of the step before: the same frames, row - 2F
-        ia, ib = ra, (rb - 2 * F if rb >= 2 * F else rb)
+        ia, ib = a["a_row"][p], a["b_row"][p]        # rows of the count / raster-index arrays; [2F, 3F) = the previous step's left images
 
         def pairs(m):
             n = int(m["mn"][p])
@@ -445,12 +452,12 @@ def mode_disagreement(a, b, F):
         pa, pb = pairs(a), pairs(b)
         d = len(pa ^ pb)
         m_tot += len(pb); m_diff += d
-        if rb < 2 * F:
+        if ib < 2 * F:
             lr_tot += len(pb); lr_diff += d
     return {"images": NI, "keypoints_exact_mode": kp_tot, "keypoints_in_one_mode_only": kp_diff, "images_with_any_keypoint_difference": int(img_diff),
             "match_pairs": len(a["mn"]), "matches_exact_mode": m_tot, "matches_in_one_mode_only": m_diff,
             "left_right_matches_exact_mode": lr_tot, "left_right_matches_in_one_mode_only": lr_diff,
-            "note": "symmetric differences; seeded random-init weights compress the score distribution, so near-ties at the top-K cut are far "
+            "note": "symmetric differences over the last step's frames (current L, R and the previous step's L); seeded random-init weights compress the score distribution, so near-ties at the top-K cut are far "
                     "more frequent than with a trained network (DESIGN.md section 2)"}
 
 

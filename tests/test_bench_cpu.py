@@ -1,0 +1,46 @@
+"""bench.py's host-side helpers (no GPU): the cross-mode disagreement count, the traffic figure read from the committed PMC summary,
+the roofline arithmetic of the dominant kernel."""
+import os
+
+import numpy as np
+
+import bench
+
+
+def _sel(F, CAP):
+    NI = 2 * F
+    kidx = np.arange((NI + F) * CAP).reshape(NI + F, CAP).astype(np.int32)
+    return dict(kidx=kidx, cnt=np.full(3 * F, CAP, np.int32), mq=np.tile(np.arange(CAP), (2 * F, 1)), mt=np.tile(np.arange(CAP), (2 * F, 1)),
+                mn=np.full(2 * F, CAP), a_row=[0, 0, 1, 1], b_row=[2, 4, 3, 5])
+
+
+def test_mode_disagreement_counts_symmetric_differences():
+    F, CAP = 2, 5
+    a = _sel(F, CAP)
+    b = {k: (v.copy() if hasattr(v, "copy") else list(v)) for k, v in a.items()}
+    d = bench.mode_disagreement(a, b, F)
+    assert d["keypoints_in_one_mode_only"] == 0 and d["matches_in_one_mode_only"] == 0 and d["keypoints_exact_mode"] == 20
+    b["kidx"][0, 0] = 999            # image 0: one keypoint differs -> 2 in the symmetric difference; its matches change in both pairs of frame 0
+    b["mt"][1, 0] = 3                # pair 1 (L0 <-> prev L0): one more match differs
+    d = bench.mode_disagreement(a, b, F)
+    assert d["keypoints_in_one_mode_only"] == 2 and d["images_with_any_keypoint_difference"] == 1
+    assert d["matches_in_one_mode_only"] == 4 and d["left_right_matches_in_one_mode_only"] == 2
+    # order inside a keypoint list does not matter: matches are compared as raster-index pairs
+    c = {k: (v.copy() if hasattr(v, "copy") else list(v)) for k, v in a.items()}
+    perm = np.array([4, 3, 2, 1, 0])
+    c["kidx"][0] = a["kidx"][0][perm]; c["mq"][0] = perm.argsort()[a["mq"][0]]; c["mq"][1] = perm.argsort()[a["mq"][1]]
+    d = bench.mode_disagreement(a, c, F)
+    assert d["keypoints_in_one_mode_only"] == 0 and d["matches_in_one_mode_only"] == 0
+
+
+def test_roofline_arithmetic_and_profiled_traffic():
+    r = bench.conv1b_roofline("wino", 5.65, 20, 64, True)
+    items = 64 * 60 * 40
+    assert r["executed_mfma_flop_per_launch"] == items * 1084 * 4096.0 and abs(r["frac"] - r["achieved"] / 157.3) < 1e-3
+    assert abs(r["algorithmic_flop_per_launch"] - 64 * 2.0 * 480 * 640 * 64 * 576) < 1 and r["frac_algorithmic"] > 1.0
+    assert r["compulsory_bytes_per_launch"] == 64 * (480 * 640 + 240 * 320 * 64 * 4)
+    path = os.path.join(bench.ROOT, "profiles", "r03_wino_rocprofv3_summary.txt")
+    if os.path.exists(path):
+        assert 1.0 < r["traffic"] / r["compulsory_bytes_per_launch"] < 1.3 and "FETCH_SIZE" in r["traffic_note"]
+    e = bench.conv1b_roofline("f32", 10.6, 20, 64, True)
+    assert abs(e["frac"] - e["algorithmic_flop_per_launch"] / 10.6e-3 / 1e12 / 157.3) < 1e-3
