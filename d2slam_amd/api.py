@@ -78,7 +78,7 @@ _lib = None
 EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_create", "d2fe_destroy",
            "d2fe_load_superpoint", "d2fe_set_superpoint_pca", "d2fe_desc_dim", "d2fe_superpoint_extract", "d2fe_superpoint_extract_batch",
            "d2fe_superpoint_extract_device", "d2fe_tail_stream", "d2fe_superpoint_wait_tail", "d2fe_load_netvlad", "d2fe_set_netvlad_pca", "d2fe_netvlad_dim",
-           "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device", "d2fe_match_fallback_rows",
+           "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device", "d2fe_match_fallback_rows", "d2fe_debug_graph_count",
            "d2fe_block_words", "d2fe_block_field_offset", "d2fe_pack_blocks_device", "d2fe_gate_pairs_device", "d2fe_quad_gate_device", "d2fe_block_bytes_int8", "d2fe_pack_blocks_int8_device", "d2fe_unpack_blocks_int8_device",
            "d2fe_half_move_cols", "d2fe_half_image_compact_device", "d2fe_remap_matches_device",
            "d2fe_half_image_filter", "d2fe_undistort", "d2fe_undistort_device", "d2fe_db_create", "d2fe_db_destroy",
@@ -322,6 +322,13 @@ class FrontEnd:
         if rc != 0 and rc != ERR_TRUNCATED:
             _check(rc)
         return [(kps[i, :cnt[i]].copy(), sc[i, :cnt[i]].copy(), desc[i, :cnt[i]].copy()) for i in range(n)]
+
+    def graph_count(self):
+        """(cached hipGraphs of host-pointer launch sequences, geometries whose capture was rejected) -- include/d2fe.h."""
+        bad = C.c_int(0)
+        self._lib.d2fe_debug_graph_count.argtypes = [C.c_void_p, C.c_void_p]
+        n = int(self._lib.d2fe_debug_graph_count(self._h, C.byref(bad)))
+        return n, int(bad.value)
 
     def match_fallback_rows(self, reset=True, full=False):
         """Queries that needed more than the matcher's first four candidates since the last reset (include/d2fe.h); full=True returns

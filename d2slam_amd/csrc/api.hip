@@ -1774,6 +1774,14 @@ int d2fe_profile_read(d2fe_handle h, float* ms, int32_t* launches) {
   return D2FE_OK;
 }
 
+int d2fe_debug_graph_count(d2fe_handle h, int* rejected) {
+  if (!h) return fail(D2FE_ERR_INVALID, "null handle");
+  int n = 0, bad = 0;
+  for (auto& kv : h->graphs) { n += kv.second.exec != nullptr; bad += kv.second.bad; }
+  if (rejected) *rejected = bad;
+  return n;
+}
+
 long d2fe_match_fallback_rows(d2fe_handle h, int reset, long* full_scans) {
   if (!h) return fail(D2FE_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(h->cfg.device_id));

@@ -415,6 +415,11 @@ enum {
 D2FE_API int d2fe_profile_enable(d2fe_handle h, int mode);
 D2FE_API int d2fe_profile_read(d2fe_handle h, float* ms /*[D2FE_PROF_COUNT]*/, int32_t* launches /*[D2FE_PROF_COUNT]*/);
 
+/* Host-pointer calls replay cached hipGraphs of their launch sequences from the third call with the same geometry on (D2FE_GRAPH=0 in the
+ * environment turns that off).  Returns how many graphs the handle holds; *rejected (may be NULL) = geometries whose capture failed and which
+ * therefore keep launching kernel by kernel (diagnostic). */
+D2FE_API int d2fe_debug_graph_count(d2fe_handle h, int* rejected);
+
 /* Synchronise the handle's stream (for timing with device-resident calls). */
 D2FE_API int d2fe_sync(d2fe_handle h);
 

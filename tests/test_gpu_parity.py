@@ -4,6 +4,8 @@
    at score near-ties (checked as: the symmetric difference of the keypoint sets only contains near-boundary scores)
  * matcher: indices and distances bit-exact
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -629,6 +631,37 @@ def test_other_configs_and_limits(api, orc, sp_weights, H, W, maxkp, thr):
     assert np.array_equal(kps, rk) and np.array_equal(sc, rs)
     if len(kps):
         assert np.abs(desc - rd).max() <= 1e-6
+    fe.close()
+
+
+def test_host_calls_replay_cached_graphs_with_identical_results(api, orc, sp_weights):
+    """The host-pointer extract / NetVLAD calls capture their launch sequence into a hipGraph on the second call of a geometry and replay it
+    afterwards (one pinned DMA in, one out): results of the plain, the capturing and the replayed calls are identical bit for bit, for two
+    geometries on one handle, and a weight reload drops the graphs."""
+    from d2slam_amd import netvlad as nvm
+    if os.environ.get("D2FE_GRAPH", "1") == "0":
+        pytest.skip("graphs switched off")
+    H, W = 120, 160
+    fe = _fe(api, H, W, 2, api.PREC_F32_WINO, max_kp=100)
+    fe.load_superpoint(sp_weights); fe.load_netvlad(nvm.synthetic_netvlad_weights())
+    a = np.stack(synth_stereo(H, W, seed=5)); b = np.stack(synth_stereo(H, W, seed=6))
+    outs = [fe.extract_batch(a, cap=100) for _ in range(4)]          # plain, capture, replay, replay
+    for o in outs[1:]:
+        for (k0, s0, d0), (k1, s1, d1) in zip(outs[0], o):
+            assert np.array_equal(k0, k1) and np.array_equal(s0, s1) and np.array_equal(d0, d1)
+    rk, rs, rd, _, _ = orc.extract_b(a[0], sp_weights, 0.015, 1, 100, wino=True)
+    assert np.array_equal(outs[3][0][0], rk) and np.array_equal(outs[3][0][1], rs)
+    ob = [fe.extract_batch(b[:1], cap=100) for _ in range(3)]         # another geometry (1 image) on the same handle, other frames
+    rk, rs, rd, _, _ = orc.extract_b(b[0], sp_weights, 0.015, 1, 100, wino=True)
+    assert np.array_equal(ob[2][0][0], rk) and np.array_equal(ob[2][0][1], rs) and np.abs(ob[2][0][2] - rd).max() <= 1e-6
+    g = [fe.netvlad(a) for _ in range(3)]
+    assert np.array_equal(g[0], g[1]) and np.array_equal(g[0], g[2])
+    n, bad = fe.graph_count()
+    assert n == 3 and bad == 0, (n, bad)                               # extract x 2 geometries + netvlad
+    fe.load_superpoint(sp_weights)
+    assert fe.graph_count()[0] == 0
+    again = fe.extract_batch(a, cap=100)
+    assert np.array_equal(again[0][2], outs[0][0][2])
     fe.close()
 
 
