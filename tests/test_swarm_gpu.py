@@ -186,3 +186,9 @@ def test_bench_int8_exchange_runs_under_gloo():
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["exchange"]["wire_precision"] == "int8" and j["exchange"]["block_bytes"] * 3.5 < 4 * 56064
     assert j["exchange"]["avg_cross_agent_matches_per_pair"] >= 0
+    # the quadcam swarm over int8 blocks (one per view)
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "4", "--workload", "quadcam",
+                   "--exchange", "int8"], {"D2FE_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, _rank_errors(r)
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["cross_agent"]["wire_precision"] == "int8" and j["cross_agent"]["view_pairs_per_step_per_gpu"] == 16 and j["n_gpus"] == 2
