@@ -275,7 +275,12 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
   Tensor& draw = bs ? h->draw2 : h->draw;
   h->last_set = bs;
   const int prec = h->cfg.precision;
-  if (prec == D2FE_PREC_F32_WINO && h->wino_dynamic) HIP_TRY(hipMemsetAsync(h->work_ctrs, 0, 64 * sizeof(int), s));
+  // One memset per pass: the Winograd work counters and (when the post-processing runs on this same stream) the per-image candidate
+  // counters behind them.  async_tail: the previous call's tail may still be reading ITS counts, so the tail zeroes them itself, in stream order.
+  const bool tail_elsewhere = s_tail && s_tail != s;
+  const bool wctr = prec == D2FE_PREC_F32_WINO && h->wino_dynamic;
+  if (wctr || !tail_elsewhere)
+    HIP_TRY(hipMemsetAsync(wctr ? h->work_ctrs : h->cand_count, 0, ((wctr ? 64 : 0) + (tail_elsewhere ? 0 : n)) * sizeof(int), s));
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8;
   auto conv = [&](ConvShape shape, const Layer& L, const float* in, int ics, int ico, long iis, float* out, int ocs,
                   long ois, int hh, int ww, bool pool, bool relu) -> hipError_t {
@@ -333,7 +338,7 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
   { ProfScope ps(h, D2FE_PROF_SOFTMAX, s);
   HIP_TRY(launch_softmax_cand(logits.p, 65, Hc, Wc, n, h->cfg.keypoint_threshold, h->cfg.remove_borders,
                               (h->cfg.keep_score_map || varA || h->cfg.max_keypoints < 0) ? h->semi.p : nullptr,
-                              h->cand, h->cand_count, varA ? 0 : h->cand_cap, s)); }
+                              h->cand, h->cand_count, varA ? 0 : h->cand_cap, /*zero_counts=*/tail_elsewhere, s)); }
   if (varA) {
     // getKeyPoints + NMS2 (superpoint_common.cpp:12-40,107-177): border = 0, sorted by confidence, max_num
     ProfScope ps(h, D2FE_PROF_SELECT, s);
@@ -462,7 +467,10 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     if (rc) return D2FE_ERR_HIP;
     h->cand_cap = (long)(H * W);
     HIP_TRY(hipMalloc(&h->cand, sizeof(unsigned long long) * h->cand_cap * B));
-    HIP_TRY(hipMalloc(&h->cand_count, sizeof(int) * B));
+    // the per-image candidate counters sit directly behind the 64 Winograd work counters: ONE memset clears both at the start of a pass
+    HIP_TRY(hipMalloc(&h->work_ctrs, (64 + (size_t)B) * sizeof(int)));
+    HIP_TRY(hipMemset(h->work_ctrs, 0, (64 + (size_t)B) * sizeof(int)));
+    h->cand_count = h->work_ctrs + 64;
     if (cfg->async_tail) {
       HIP_TRY(hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
       for (int i = 0; i < 2; ++i) {
@@ -487,8 +495,6 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device_id) == hipSuccess && v > 0) h->ncu = v; }
     HIP_TRY(hipMalloc(&h->match_stats, 4 * sizeof(int32_t)));
     HIP_TRY(hipMemset(h->match_stats, 0, 4 * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&h->work_ctrs, 64 * sizeof(int)));
-    HIP_TRY(hipMemset(h->work_ctrs, 0, 64 * sizeof(int)));
     { const char* e = getenv("D2FE_WINO_DYNAMIC"); if (e) h->wino_dynamic = atoi(e) != 0; }
     if (cfg->postproc == D2FE_POSTPROC_A) {
       HIP_TRY(hipMalloc(&h->aconf, sizeof(float) * H * W * B));
@@ -535,7 +541,7 @@ void d2fe_destroy(d2fe_handle h) {
   for (Tensor* t : {&h->a1a, &h->a1b, &h->a2a, &h->a2b, &h->a3a, &h->a3b, &h->a4a, &h->a4b, &h->aPD, &h->logits, &h->draw, &h->semi, &h->a4b2, &h->logits2, &h->draw2})
     if (t->p) hipFree(t->p);
   for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
-  for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->cand_count, (void*)h->s_img, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->work_ctrs, (void*)h->match_stats, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc,
+  for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->s_img, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->work_ctrs, (void*)h->match_stats, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc,
                   (void*)h->pca_comp_t, (void*)h->pca_mean})
     if (p) hipFree(p);
   nv_free(h);

@@ -550,11 +550,24 @@ hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const C
   if (cout_pad % 64 || (a.in_cstride & 3) || (a.in_coff & 3)) return hipErrorInvalidValue;
   // buffer addressing: 32-bit byte offsets inside one image's tensor, 0x80000000 must stay out of range
   if ((long)a.H * a.W * a.in_cstride * 4 >= (1l << 31) || (long)a.H * a.W * a.out_cstride * 4 >= (1l << 31)) return hipErrorInvalidValue;
-  // D2FE_WINO_NT=1 selects the 32-channel items (three workgroups per CU, round 3's structural experiment: every layer 6-8 % SLOWER
-  // than the 64-channel items, profiles/r03_wino_nt_ab.txt -- the doubled input transform / LDS reads / patch copies cost more than the
-  // third wave per SIMD hides); default: 64-channel items, two workgroups per CU
-  static const int nt_env = [] { const char* e = getenv("D2FE_WINO_NT"); return e ? atoi(e) : 2; }();
-  const int NTsel = (nt_env == 1 && !a.ablate) ? 1 : 2;
+  // 64-channel items (NT = 2, two workgroups per CU) are 6-8 % faster per unit of work than 32-channel items (NT = 1, three per CU;
+  // profiles/r03_wino_nt_ab.txt), so every launch that keeps the chip busy for several rounds of workgroups uses them.  A SMALL launch -- the
+  // 60 x 80 and 120 x 160 layers of a one- or two-image call, how the reference calls infer (loop_cam.cpp:609-616) -- is a handful of items
+  // per CU at most: its duration is (rounds of resident workgroups) x (one item's latency), and halving the item while raising the resident
+  // workgroups from 2 to 3 per CU wins there (conv4a at two images: 160 items -> 320 half-items in ONE round of 768 slots).
+  // D2FE_WINO_NT=1 / 2 forces one form (A/B measurements); bit-identical either way.
+  static const int nt_env = [] { const char* e = getenv("D2FE_WINO_NT"); return e ? atoi(e) : 0; }();
+  int NTsel = 2;
+  {
+    const int ncu0 = a.ncu > 0 ? a.ncu : 256;
+    const long total2 = (long)((a.W + 15) / 16) * ((a.H + 7) / 8) * (cout_pad / 64) * a.n_img;
+    if (total2 <= 4l * 2 * ncu0) {
+      const long rounds2 = (total2 + 2 * ncu0 - 1) / (2 * ncu0), rounds1 = (2 * total2 + 3 * ncu0 - 1) / (3 * ncu0);
+      if (rounds1 * 0.5 * 1.07 < (double)rounds2) NTsel = 1;
+    }
+    if (nt_env == 1) NTsel = 1;
+    if (nt_env == 2 || a.ablate) NTsel = 2;
+  }
   const int nbx = (a.W + 15) / 16, nby = (a.H + 7) / 8, ncb = cout_pad / (32 * NTsel);
   const int total = nbx * nby * ncb * a.n_img;
   const int ncu = a.ncu > 0 ? a.ncu : 256;     // ConvArgs::ncu: the handle's device (no process-wide cache: one process may drive several GPUs)

@@ -65,8 +65,7 @@ void pack_weights_f16x2(const float* w, int cout, int cin, int ks, int cout_pad,
 // softmax(65) -> drop dustbin -> 8x8 unfold; writes dense semi (optional) and appends variant-B candidates
 // (score > thr, inside borders) as u64 keys (score_bits << 32 | ~raster_idx) with one counter per image.
 hipError_t launch_softmax_cand(const float* logits, int lstride, int Hc, int Wc, int n_img, float thr, int border,
-                               float* semi /*nullable*/, unsigned long long* cand, int* cand_count, long cand_cap,
-                               hipStream_t s);
+                               float* semi, unsigned long long* cand, int* cand_count, long cand_cap, bool zero_counts, hipStream_t s);
 // exact top-K (score desc, raster asc) / raster-ordered pass-through when count <= K (variant B).
 hipError_t launch_select_b(const unsigned long long* cand, const int* cand_count, long cand_cap, int n_img, int W,
                            int max_kp, int cap, int always_sort, const float* semi, int H, float thr, int border, float* kps_xy,

@@ -143,9 +143,11 @@ __global__ __launch_bounds__(256) void softmax_cand_kernel(const float* __restri
 }
 
 hipError_t launch_softmax_cand(const float* logits, int lstride, int Hc, int Wc, int n_img, float thr, int border,
-                               float* semi, unsigned long long* cand, int* cand_count, long cand_cap, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(cand_count, 0, sizeof(int) * n_img, s);
-  if (e != hipSuccess) return e;
+                               float* semi, unsigned long long* cand, int* cand_count, long cand_cap, bool zero_counts, hipStream_t s) {
+  if (zero_counts) {      // false: the caller zeroed the counters together with the work counters at the start of the network pass
+    hipError_t e = hipMemsetAsync(cand_count, 0, sizeof(int) * n_img, s);
+    if (e != hipSuccess) return e;
+  }
   dim3 grid((Hc * Wc + 63) / 64, n_img), block(256);
   hipLaunchKernelGGL(softmax_cand_kernel, grid, block, 0, s, logits, lstride, Hc, Wc, thr, border, semi, cand,
                      cand_count, cand_cap);
@@ -235,15 +237,31 @@ __global__ __launch_bounds__(SEL_THREADS) void select_b_kernel(const unsigned lo
         if ((k & mask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 0xFF)], 1);
       }
       __syncthreads();
-      if (tid == 0) {
-        int acc = 0, d = 255;
-        for (; d > 0; --d) {
-          if (acc + hist[d] >= need) break;
-          acc += hist[d];
+      if (tid < 64) {
+        // the digit d = the largest one whose suffix count S(d) = sum_{x >= d} hist[x] reaches `need` (0 if none does): lane l owns digits
+        // 4l .. 4l+3, suffix sums by a 6-step shuffle scan -- what used to be a 256-iteration serial loop of one thread per pass
+        const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+        int above = h0 + h1 + h2 + h3;              // becomes the sum over the lanes ABOVE this one
+        int incl = above;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(incl, o, 64); if (tid + o < 64) incl += t; }
+        above = incl - above;
+        const int S3 = above + h3, S2 = S3 + h2, S1 = S2 + h1, S0 = S1 + h0;
+        int best = -1;                              // the largest digit of this lane with S >= need
+        if (S3 >= need) best = 4 * tid + 3; else if (S2 >= need) best = 4 * tid + 2; else if (S1 >= need) best = 4 * tid + 1; else if (S0 >= need) best = 4 * tid;
+        int gb = best;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gb = max(gb, __shfl_xor(gb, o, 64));
+        const int d = gb < 0 ? 0 : gb;
+        if (4 * tid <= d && d < 4 * tid + 4) {      // the lane that owns d publishes
+          const int k = d - 4 * tid;
+          const int Sd = k == 3 ? S3 : k == 2 ? S2 : k == 1 ? S1 : S0;      // S(d)
+          const int hd = k == 3 ? h3 : k == 2 ? h2 : k == 1 ? h1 : h0;
+          const int acc = Sd - hd;                  // S(d + 1): keys with a larger digit
+          s_digit = d;
+          s_need = need - acc;
+          s_cnt = (K - need) + acc + hd;            // keys >= the prefix chosen so far
         }
-        s_digit = d;
-        s_need = need - acc;
-        s_cnt = (K - need) + acc + hist[d];   // keys >= the prefix chosen so far
       }
       __syncthreads();
       prefix |= ((unsigned long long)s_digit) << shift;

@@ -57,7 +57,8 @@ typedef struct {
   int32_t max_width;          /* largest input width (>= 16)   -- SuperPointConfig::input_width  */
   int32_t max_height;         /* largest input height (>= 16)  -- SuperPointConfig::input_height */
   int32_t max_batch;          /* images per batched call (>= 1) */
-  int32_t max_keypoints;      /* SuperPointConfig::max_keypoints (1..1024)  [params->max_superpoint_cnt] */
+  int32_t max_keypoints;      /* SuperPointConfig::max_keypoints: 1..16384 (sorted top-K), or -1 = keep every keypoint above the threshold in raster
+                                 order like topKeypoints with k == -1 (superpoint_tensorrt.cpp:241-253)  [params->max_superpoint_cnt] */
   int32_t remove_borders;     /* SuperPointConfig::remove_borders (variant B), default 1 */
   float   keypoint_threshold; /* SuperPointConfig::keypoint_threshold, default 0.015 */
   int32_t postproc;           /* d2fe_postproc */
@@ -181,6 +182,7 @@ D2FE_API int d2fe_netvlad_device(d2fe_handle h, const uint8_t* d_gray, int n, in
  * feature_matcher.cpp:4-42).  a: na x dim row-major, b: nb x dim.  pts_*: n x 2 floats or NULL.
  * radius <= 0 disables the pixel gate.  Outputs ascending in query index; *n_out matches written.
  * Re-entrant (the reference calls it from three threads). */
+/* Up to 16384 rows per side (the reference is unbounded; D2FE_ERR_UNSUPPORTED above that). */
 D2FE_API int d2fe_match_knn(d2fe_handle h, const float* a, int na, const float* b, int nb, int dim, double ratio,
                             const float* pts_a, const float* pts_b, double radius, int32_t* q_idx,
                             int32_t* t_idx, float* dist, int cap, int* n_out);
