@@ -229,9 +229,89 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     if (tid < 240 && gy >= 0 && gy < aH && gx >= 0 && gx < aW) fbyte = a.img[(size_t)T.img * a.img_istride + (size_t)gy * a.img_stride + gx];
   };
   auto store_frame = [&]() { if (tid < 240) u8p[tid] = (unsigned char)fbyte; };
+  // ---- FUSE: conv1a for the 10 x 18 patch on the matrix pipe, straight into the chunk layout ------------------------------------
+  // D[channel][pixel] = sum_k W[channel][k] * tap[k][pixel]: the weights are the A operand, so that a lane (= pixel) holds 4
+  // consecutive channels in registers 4q..4q+3 -- one 16-byte LDS write per channel quad.  K = 10: k = 0 carries the bias against a
+  // tap of 1.0 (fmaf(1, b, +0) = b exactly), k = 1..9 the taps in (ky,kx) order -- the same chain as conv1a_kernel, bit for bit.
+  // unit u = wave + 4*uu covers m-tile u >> 1 and channel half u & 1 = wave & 1: a wave only ever needs one half of the weights
+  float c1a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      const int k = 2 * st + (lane >> 5);
+      c1a[st] = k == 0 ? a.b1a[(wave & 1) * 32 + (lane & 31)] : a.w1a[(k - 1) * 64 + (wave & 1) * 32 + (lane & 31)];
+    }
+  }
+  // The frame bytes under the patch (12 x 20: the 10 x 18 patch plus conv1a's own ring) are staged through LDS: thread t < 240 fetches
+  // ONE byte per item, one item ahead (out-of-image bytes are 0 = conv1a's zero padding), and writes it at the start of the running
+  // item's epilogue, in front of a barrier that is there anyway.  Every address below is a per-lane constant of the kernel, so what is
+  // left per item and unit is 5 byte reads + conversions, the in-image test of the patch pixel and the MFMA chain.
+  int tb[3], dsto[3], pyx[3];            // unit uu: byte index of tap (0,0), float index of the patch pixel in the chunk layout, (py, px)
+  int koff[5];                           // k-step st: this lane half's tap (ky, kx) as a byte offset
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int uu = 0; uu < 3; ++uu) {
+      const int pidx = ((wave >> 1) + 2 * uu) * 32 + (lane & 31);
+      const int py = pidx / 18, px = pidx - py * 18;
+      tb[uu] = pidx < 180 ? py * 20 + px : 0;
+      pyx[uu] = pidx < 180 ? (py << 8) | px : (int)0x8080;         // 0x8080 marks the 12 lanes of the last m-tile beyond the patch: computed, not stored
+      dsto[uu] = ((py & 1) * 2 + (px & 1)) * PL + ((py >> 1) * WROW + (px >> 1)) * 4;
+    }
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      const int t = 2 * st + (lane >> 5) - 1;                      // tap index; -1 is the bias slot (k = 0)
+      koff[st] = t < 0 ? 0 : (t / 3) * 20 + t % 3;
+    }
+  }
+  // The staging is split: stage_taps (byte reads + conversions), stage_step (one k-step of the three conv1a MFMA chains) and stage_store (ReLU +
+  // the patch writes).  A wave issues in order, so its MFMAs only run under its own VALU / LDS / store work when they are INTERLEAVED with it:
+  // the epilogue issues the next item's taps and the five chain steps between the four quarters of its finish phase (exchange reads, A^T s, bias,
+  // ReLU, pool, stores), which touch neither the frame bytes nor the chain registers; stage_store follows the barrier that ends the epilogue.
+  auto stage_taps = [&](const WItem& T, float (&tap)[3][5]) {
+    const float scale = (float)(1.0 / 255.0);
+    const int gy0 = T.by * 8 - 1, gx0 = T.bx * 16 - 1;
+#pragma unroll
+    for (int uu = 0; uu < 3; ++uu) {
+      // a patch pixel outside the image is conv1b's zero padding: all its taps AND the bias slot are 0, so the chain gives +0
+      const bool pvalid = (unsigned)(gy0 + (pyx[uu] >> 8)) < (unsigned)aH && (unsigned)(gx0 + (pyx[uu] & 255)) < (unsigned)aW;
+#pragma unroll
+      for (int st = 0; st < 5; ++st) {
+        float v = (float)u8p[tb[uu] + koff[st]] * scale;
+        if (st == 0) v = hh ? v : 1.0f;                           // k = 0 (lanes 0-31 of the first step) carries the bias against 1.0
+        tap[uu][st] = pvalid ? v : 0.f;
+      }
+    }
+  };
+  // 12 units = 6 m-tiles of 32 patch pixels x 2 halves of the channels; unit u = wave + 4*uu covers m-tile u >> 1, half wave & 1
+  auto stage_step = [&](auto st_c, const float (&tap)[3][5], f32x16 (&d)[3]) {
+    constexpr int st = decltype(st_c)::value;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int uu = 0; uu < 3; ++uu) d[uu] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[st], tap[uu][st], st == 0 ? zero : d[uu], 0, 0, 0);
+  };
+  auto stage_store = [&](const f32x16 (&d)[3]) {
+    const int nt = wave & 1;
+#pragma unroll
+    for (int uu = 0; uu < 3; ++uu) {
+      // rows (channels) of this lane: 8*q + 4*hh + (0..3) of half nt -> channel quad Q = nt*8 + 2*q + hh; column = patch pixel
+      if (pyx[uu] != (int)0x8080) {
+        float* dst = wlds + dsto[uu];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int Q = nt * 8 + 2 * q + hh;
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)      // ReLU as one v_max (the chain never yields -0 or a NaN; the builtins add a canonicalising second one)
+            asm("v_max_f32 %0, 0, %1" : "=v"(o[e]) : "v"(d[uu][4 * q + e]));
+          *reinterpret_cast<f32x4*>(dst + (Q >> 1) * CHF + (Q & 1) * 4 * PL) = o;
+        }
+      }
+    }
+  };
+
   // ---- epilogue: s = M A for this wave's row, swap rows between the four waves, A^T s, bias, ReLU, pool, store ----------------
   float* xch = FUSE ? wlds : wlds + WR * WCHUNK;      // FUSE: the patch is dead once the K loop is through, the exchange area reuses it
-  auto epilogue = [&](const WItem& T) {
+  auto epilogue = [&](const WItem& T, bool stage_next, const WItem& TN) {
     float* out = a.out + (size_t)T.img * a.out_img_stride + a.out_coff;
     const int cs = a.out_cstride, cs4 = cs * 4;
     const int n32 = T.cb * NT;
@@ -312,11 +392,11 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
         }
       }
     };
-    auto finish_pair = [&](auto p_c) {
+    auto finish_q = [&](auto p_c, auto nt_c) {
       constexpr int p = decltype(p_c)::value;
+      constexpr int nt = decltype(nt_c)::value;
       constexpr int r = 4 * I + 2 * p;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
+      if constexpr (nt < NT) {
         f32x2 lo[4], hi[4];      // rows 0..3 of s: lo = (b0(r), b0(r+1)), hi = (b1(r), b1(r+1))
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -335,90 +415,38 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
         emit_tile(IC<r + 1>{}, nt, yb);
       }
     };
-    finish_pair(IC<0>{}); finish_pair(IC<1>{});
+    if constexpr (FUSE) {
+      // the next item's conv1a chains, one k-step between two quarters of the finish phase (see stage_step); the fences pin the interleaving
+      float tap[3][5];
+      f32x16 dstage[3];          // local to the epilogue: no value is carried around the item loop
+      if (stage_next) { stage_taps(TN, tap); stage_step(IC<0>{}, tap, dstage); }
+      __builtin_amdgcn_sched_barrier(0);
+      finish_q(IC<0>{}, IC<0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (stage_next) stage_step(IC<1>{}, tap, dstage);
+      __builtin_amdgcn_sched_barrier(0);
+      finish_q(IC<0>{}, IC<1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (stage_next) stage_step(IC<2>{}, tap, dstage);
+      __builtin_amdgcn_sched_barrier(0);
+      finish_q(IC<1>{}, IC<0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (stage_next) stage_step(IC<3>{}, tap, dstage);
+      __builtin_amdgcn_sched_barrier(0);
+      finish_q(IC<1>{}, IC<1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (stage_next) stage_step(IC<4>{}, tap, dstage);
+      mark(trace_item, 8, 3);
+      // the staging overwrites the patch = the exchange area: every wave must be through with it
+      __syncthreads();
+      if (stage_next) stage_store(dstage);
+      return;
+    } else {
+      finish_q(IC<0>{}, IC<0>{}); finish_q(IC<0>{}, IC<1>{}); finish_q(IC<1>{}, IC<0>{}); finish_q(IC<1>{}, IC<1>{});
+    }
     mark(trace_item, 8, 3);
     // FUSE: the next item's staging overwrites the patch = the exchange area, so every wave must be through with it.  Otherwise the
     // next writer of the exchange area is the next item's epilogue, eight chunk barriers away: no barrier needed here.
-    if constexpr (FUSE) __syncthreads();
-  };
-
-  // ---- FUSE: conv1a for the 10 x 18 patch on the matrix pipe, straight into the chunk layout ------------------------------------
-  // D[channel][pixel] = sum_k W[channel][k] * tap[k][pixel]: the weights are the A operand, so that a lane (= pixel) holds 4
-  // consecutive channels in registers 4q..4q+3 -- one 16-byte LDS write per channel quad.  K = 10: k = 0 carries the bias against a
-  // tap of 1.0 (fmaf(1, b, +0) = b exactly), k = 1..9 the taps in (ky,kx) order -- the same chain as conv1a_kernel, bit for bit.
-  // unit u = wave + 4*uu covers m-tile u >> 1 and channel half u & 1 = wave & 1: a wave only ever needs one half of the weights
-  float c1a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  if constexpr (FUSE) {
-#pragma unroll
-    for (int st = 0; st < 5; ++st) {
-      const int k = 2 * st + (lane >> 5);
-      c1a[st] = k == 0 ? a.b1a[(wave & 1) * 32 + (lane & 31)] : a.w1a[(k - 1) * 64 + (wave & 1) * 32 + (lane & 31)];
-    }
-  }
-  // The frame bytes under the patch (12 x 20: the 10 x 18 patch plus conv1a's own ring) are staged through LDS: thread t < 240 fetches
-  // ONE byte per item, one item ahead (out-of-image bytes are 0 = conv1a's zero padding), and writes it at the start of the running
-  // item's epilogue, in front of a barrier that is there anyway.  Every address below is a per-lane constant of the kernel, so what is
-  // left per item and unit is 5 byte reads + conversions, the in-image test of the patch pixel and the MFMA chain.
-  int tb[3], dsto[3], pyx[3];            // unit uu: byte index of tap (0,0), float index of the patch pixel in the chunk layout, (py, px)
-  int koff[5];                           // k-step st: this lane half's tap (ky, kx) as a byte offset
-  if constexpr (FUSE) {
-#pragma unroll
-    for (int uu = 0; uu < 3; ++uu) {
-      const int pidx = ((wave >> 1) + 2 * uu) * 32 + (lane & 31);
-      const int py = pidx / 18, px = pidx - py * 18;
-      tb[uu] = pidx < 180 ? py * 20 + px : 0;
-      pyx[uu] = pidx < 180 ? (py << 8) | px : (int)0x8080;         // 0x8080 marks the 12 lanes of the last m-tile beyond the patch: computed, not stored
-      dsto[uu] = ((py & 1) * 2 + (px & 1)) * PL + ((py >> 1) * WROW + (px >> 1)) * 4;
-    }
-#pragma unroll
-    for (int st = 0; st < 5; ++st) {
-      const int t = 2 * st + (lane >> 5) - 1;                      // tap index; -1 is the bias slot (k = 0)
-      koff[st] = t < 0 ? 0 : (t / 3) * 20 + t % 3;
-    }
-  }
-  auto stage_fused = [&](const WItem& T) {
-    const float scale = (float)(1.0 / 255.0);
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int gy0 = T.by * 8 - 1, gx0 = T.bx * 16 - 1;
-    // 12 units = 6 m-tiles of 32 patch pixels x 2 halves of the channels; unit u = wave + 4*uu covers m-tile u >> 1, half wave & 1.
-    // The three chains of a wave are independent: all 15 bytes are read first and the MFMAs issue round-robin, so that the
-    // conversions, the ReLU and the LDS writes of one unit run under the MFMAs of the others (the accumulators are idle here).
-    float tap[3][5];
-#pragma unroll
-    for (int uu = 0; uu < 3; ++uu) {
-      // a patch pixel outside the image is conv1b's zero padding: all its taps AND the bias slot are 0, so the chain gives +0
-      const bool pvalid = (unsigned)(gy0 + (pyx[uu] >> 8)) < (unsigned)aH && (unsigned)(gx0 + (pyx[uu] & 255)) < (unsigned)aW;
-#pragma unroll
-      for (int st = 0; st < 5; ++st) {
-        float v = (float)u8p[tb[uu] + koff[st]] * scale;
-        if (st == 0) v = hh ? v : 1.0f;                           // k = 0 (lanes 0-31 of the first step) carries the bias against 1.0
-        tap[uu][st] = pvalid ? v : 0.f;
-      }
-    }
-    f32x16 d[3];
-#pragma unroll
-    for (int uu = 0; uu < 3; ++uu) d[uu] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[0], tap[uu][0], zero, 0, 0, 0);
-#pragma unroll
-    for (int st = 1; st < 5; ++st)
-#pragma unroll
-      for (int uu = 0; uu < 3; ++uu) d[uu] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a[st], tap[uu][st], d[uu], 0, 0, 0);
-    const int nt = wave & 1;
-#pragma unroll
-    for (int uu = 0; uu < 3; ++uu) {
-      // rows (channels) of this lane: 8*q + 4*hh + (0..3) of half nt -> channel quad Q = nt*8 + 2*q + hh; column = patch pixel
-      if (pyx[uu] != (int)0x8080) {
-        float* dst = wlds + dsto[uu];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int Q = nt * 8 + 2 * q + hh;
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)      // ReLU as one v_max (the chain never yields -0 or a NaN; the builtins add a canonicalising second one)
-            asm("v_max_f32 %0, 0, %1" : "=v"(o[e]) : "v"(d[uu][4 * q + e]));
-          *reinterpret_cast<f32x4*>(dst + (Q >> 1) * CHF + (Q & 1) * 4 * PL) = o;
-        }
-      }
-    }
   };
 
   // ---- prologue ---------------------------------------------------------------------------------------------------------------
@@ -431,7 +459,13 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
 #pragma unroll
     for (int c = 0; c < WR; ++c) dma_issue(dcur, c, c);      // WR < NCH: all in the first item
   }
-  if constexpr (FUSE) { load_frame(cur); store_frame(); __syncthreads(); }
+  if constexpr (FUSE) {
+    float tap0[3][5]; f32x16 d0[3];
+    load_frame(cur); store_frame(); __syncthreads();
+    stage_taps(cur, tap0);
+    stage_step(IC<0>{}, tap0, d0); stage_step(IC<1>{}, tap0, d0); stage_step(IC<2>{}, tap0, d0); stage_step(IC<3>{}, tap0, d0); stage_step(IC<4>{}, tap0, d0);
+    stage_store(d0);
+  }
   int ucur = u_ptr(cur), unxt = u_ptr(nxt);
   load_u(0, ucur, 0);
   load_u(1, ucur, 1);
@@ -502,8 +536,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     inn = inxt + tstride;
     if (dyn && tid == 0) inn_claim = 2 * tstride + atomicAdd(a.work_ctr, 1);      // in flight during the K loop, published in the epilogue
     if constexpr (FUSE) {
-      if (!(a.ablate & 64) || item == 0) stage_fused(cur);     // D2FE_ABLATE=64: timing experiment, the staging runs for the first item only
-      __syncthreads();
+      __syncthreads();                                           // the patch (staged by the prologue / the previous epilogue) is complete
       read_d(0);
       if (inxt < total && !(a.ablate & 64)) load_frame(nxt);     // the next item's frame bytes, in flight during this item's K loop
     }
@@ -512,7 +545,8 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     for (int ch = 1; ch < NCH; ++ch) chunk(IC<0>{}, item, ch);
     mark(item, 0, 4);
     trace_item = item;
-    if constexpr (!(ABL & 32)) epilogue(cur);
+    // D2FE_ABLATE=64: timing experiment, the staging runs for the first item only
+    if constexpr (!(ABL & 32)) epilogue(cur, FUSE && inxt < total && !(a.ablate & 64), nxt);
     mark(item, 0, 5);
     cur = nxt; dcur = dnxt; ucur = unxt;
     icur = inxt; inxt = inn;
