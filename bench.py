@@ -57,9 +57,11 @@ def main():
                          "latency-bound tail on the handle's tail stream.  Measured slower than plain stream order (2214 vs 2258 stereo fps: the two "
                          "sequences stretch each other, NetVLAD 0.94 -> 1.28 ms), hence off by default")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event breakdown to stderr")
-    ap.add_argument("--exchange", choices=["fp32", "int8"], default=os.environ.get("D2FE_BENCH_EXCHANGE", "fp32"),
+    ap.add_argument("--exchange", choices=["fp32", "int8", "int8-renorm256"], default=os.environ.get("D2FE_BENCH_EXCHANGE", "fp32"),
                     help="N>1: precision of the exchange blocks on the wire.  int8 = the reference's LCM wire format (VisualImageDesc::toLCM quantisation, "
-                         "decoded with its 32-float renormalisation before the gate and the matcher): 3.9x fewer all-gather bytes")
+                         "decoded exactly as its LCM constructor does: q/127 and the hard-coded 32-float renormalisation of the first n segments, which with "
+                         "256-D descriptors leaves most rows un-normalised -- the reference's own cross-agent numerics); int8-renorm256 = the same bytes, every "
+                         "descriptor re-normalised over its 256 floats on decode.  Either way 3.9x fewer all-gather bytes")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency leg (host-pointer C ABI, one frame per call)")
     ap.add_argument("--latency-calls", type=int, default=300)
     ap.add_argument("--latency-only", action="store_true", help="print only the single-call latency leg (A/B runs: D2FE_GRAPH=0, D2FE_PINNED=0)")
@@ -159,7 +161,8 @@ def main():
         kidx = torch.zeros((NI + F, CAP), dtype=torch.int32, device=dev)       # rows [NI, NI + F): the previous step's left images
         gdesc = torch.zeros((max(F, 1), max(G, 4)), dtype=torch.float32, device=dev)
         blocks = torch.zeros((F, BLK), dtype=torch.float32, device=dev) if world > 1 else None
-        int8x = world > 1 and args.exchange == "int8"
+        int8x = world > 1 and args.exchange.startswith("int8")
+        renorm = 1 if args.exchange == "int8-renorm256" else 0
         if int8x:
             BLKB = api.block_bytes_int8(CAP, G)
             blocks_q = torch.zeros((F, BLKB), dtype=torch.int8, device=dev); gath_q = torch.zeros((world, F, BLKB), dtype=torch.int8, device=dev)
@@ -231,7 +234,7 @@ def main():
                         fe.pack_blocks_int8_device(desc.data_ptr(), kps.data_ptr(), cnt.data_ptr(), gdesc.data_ptr() if netvlad else 0, 0, 1, F, CAP, G,
                                                    blocks_q.data_ptr(), stream=tstream)
                         swarm.all_gather_blocks(gath_q, blocks_q)
-                        fe.unpack_blocks_int8_device(gath_q.data_ptr(), world * F, CAP, G, gath.data_ptr(), renorm=0, stream=tstream)
+                        fe.unpack_blocks_int8_device(gath_q.data_ptr(), world * F, CAP, G, gath.data_ptr(), renorm=renorm, stream=tstream)
                     else:
                         fe.pack_blocks_device(desc.data_ptr(), kps.data_ptr(), scores.data_ptr(), cnt.data_ptr(), gdesc.data_ptr() if netvlad else 0,
                                               0, 1, F, CAP, G, blocks.data_ptr(), stream=tstream)

@@ -98,13 +98,14 @@ class QuadSwarm:
     (trackRemote passes search_radius*2 but matchLocalFeatures only uses it with motion prediction, :1100-1115)."""
 
     def __init__(self, chain, torch, dev, world, rank, netvlad_dim, thres, mode="all2all", knn_ratio=0.8, exchange="fp32"):
-        assert mode in ("all2all", "gated") and exchange in ("fp32", "int8")
+        assert mode in ("all2all", "gated") and exchange in ("fp32", "int8", "int8-renorm256")
         self.chain, self.torch, self.world, self.rank, self.G, self.thres, self.mode, self.ratio = chain, torch, world, rank, netvlad_dim, thres, mode, knn_ratio
         self.exchange = exchange
         Q, NI, cap = chain.Q, chain.NI, chain.cap
         self.BLK = block_words(cap, netvlad_dim)
         self.block_bytes = 4 * self.BLK
-        if exchange == "int8":      # the reference's wire precision (include/d2fe.h): quantise, ONE all-gather of int8 blocks, decode into `gath`
+        self.renorm = 1 if exchange == "int8-renorm256" else 0      # decode: 0 = as the reference's LCM constructor, 1 = every descriptor over its 256 floats
+        if exchange.startswith("int8"):      # the reference's wire precision (include/d2fe.h): quantise, ONE all-gather of int8 blocks, decode into `gath`
             self.block_bytes = block_bytes_int8(cap, netvlad_dim)
             self.blocks_q = torch.zeros((NI, self.block_bytes), dtype=torch.int8, device=dev)
             self.gath_q = torch.zeros((world, NI, self.block_bytes), dtype=torch.int8, device=dev)
@@ -144,11 +145,11 @@ class QuadSwarm:
         """pack -> ONE all-gather -> gate -> cross-agent matching, all ordered on the current torch stream (raw handle `st`)."""
         c, fe, torch = self.chain, self.chain.fe, self.torch
         Q, NI, cap, G = c.Q, c.NI, c.cap, self.G
-        if self.exchange == "int8":
+        if self.exchange.startswith("int8"):
             fe.pack_blocks_int8_device(c.desc.data_ptr(), c.pts.data_ptr(), c.cnt.data_ptr(), c.gdesc.data_ptr(), 0, 1, NI, cap, G,
                                        self.blocks_q.data_ptr(), stream=st)
             all_gather_blocks(self.gath_q, self.blocks_q, group)
-            fe.unpack_blocks_int8_device(self.gath_q.data_ptr(), self.world * NI, cap, G, self.gath.data_ptr(), renorm=0, stream=st)
+            fe.unpack_blocks_int8_device(self.gath_q.data_ptr(), self.world * NI, cap, G, self.gath.data_ptr(), renorm=self.renorm, stream=st)
         else:
             fe.pack_blocks_device(c.desc.data_ptr(), c.pts.data_ptr(), c.scores.data_ptr(), c.cnt.data_ptr(), c.gdesc.data_ptr(), 0, 1, NI, cap, G,
                                   self.blocks.data_ptr(), stream=st)
