@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void pack_blocks_int8_kernel(const float* __re
     if (i < n * 64) {
       const f32x4 v = src[i];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w |= (uint32_t)(uint8_t)(int8_t)(int)(v[e] / m * 127.0f) << (8 * e);      // C cast: truncation toward zero
+      for (int e = 0; e < 4; ++e) w |= (uint32_t)(uint8_t)(int8_t)(int)(m > 0.f ? v[e] / m * 127.0f : 0.f) << (8 * e);      // C cast: truncation toward zero
+                                                                                                         // (an all-zero frame: 0/0 in the reference; zeros here)
     }
     dq[i] = w;
   }
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void pack_blocks_int8_kernel(const float* __re
   __syncthreads();
   const double gmd = (double)fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   int8_t* gq = b + (size_t)cap * 256;
-  for (int i = tid; i < G; i += 256) gq[i] = gdesc ? (int8_t)(int)((double)gdesc[(size_t)f * G + i] / gmd * 127.0) : (int8_t)0;
+  for (int i = tid; i < G; i += 256) gq[i] = (gdesc && gmd > 0.0) ? (int8_t)(int)((double)gdesc[(size_t)f * G + i] / gmd * 127.0) : (int8_t)0;
   float* bk = reinterpret_cast<float*>(gq + G);
   for (int i = tid; i < cap * 2; i += 256) bk[i] = (i >> 1) < n ? kps[(size_t)row * cap * 2 + i] : 0.f;
   int32_t* bn = reinterpret_cast<int32_t*>(bk + cap * 2);

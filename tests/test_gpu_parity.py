@@ -291,6 +291,38 @@ def test_match_saturated_candidate_lists_are_exact(api, orc, case):
     fe.close()
 
 
+def test_match_random_shapes_with_injected_duplicates(api, orc):
+    """40 seeded random problems (1..600 rows per side, dim 32..256, ratio 0.6..1.2, with and without a radius gate; copies, near-copies at 1e-7 and
+    groups of up to 12 identical rows injected on both sides): matchKNN and the cross-check matcher bitwise against the oracle every time."""
+    fe = _fe(api, 64, 64, 1, api.PREC_F32)
+    rng = np.random.RandomState(2026)
+    for it in range(40):
+        na, nb = int(rng.randint(1, 601)), int(rng.randint(1, 601))
+        dim = int(rng.choice([32, 64, 128, 256]))
+        a = _unit(rng.randn(na, dim)); b = _unit(rng.randn(nb, dim))
+        k = min(na, nb) // 2
+        if k:                                   # shared content so that matches exist
+            b[:k] = _unit(a[rng.permutation(na)[:k]] + 0.08 * rng.randn(k, dim))
+        for side in (a, b):                      # degenerate structure
+            n = len(side)
+            if n >= 4 and rng.rand() < 0.7:
+                g = int(rng.randint(2, min(n, 13)))
+                side[rng.choice(n, g, replace=False)] = side[int(rng.randint(0, n))]
+            if n >= 4 and rng.rand() < 0.5:
+                i, j = rng.choice(n, 2, replace=False)
+                side[i] = (side[j] + np.float32(1e-7) * rng.randn(dim)).astype(np.float32)
+        ratio = float(rng.uniform(0.6, 1.2))
+        pa = (rng.rand(na, 2) * 640).astype(np.float32); pb = (rng.rand(nb, 2) * 640).astype(np.float32)
+        radius = float(rng.choice([-1.0, 80.0, 300.0]))
+        q, t, d = fe.match_knn(a, b, ratio, pa, pb, radius)
+        rq, rt, rd = orc.match_knn(a, b, ratio, pa, pb, radius)
+        assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd), (it, na, nb, dim, ratio, radius)
+        q, t, d = fe.match_crosscheck(a, b)
+        rq, rt, rd = orc.match_crosscheck(a, b)
+        assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd), (it, na, nb, dim)
+    fe.close()
+
+
 def test_match_fallback_is_rare_on_ordinary_descriptors(api, orc):
     """The fallback is a safety net: on well-separated descriptor sets only a few queries may need it."""
     fe = _fe(api, 64, 64, 1, api.PREC_F32)
