@@ -44,6 +44,11 @@ RANGES = {
     "SPREF_GEN_CYL_INVK": ("camera_models/src/camera_models/CylindricalCamera.cc", 144, 147, "m_inv_K11 = 1.0 / mParameters.fx();", "m_inv_K23 = -mParameters.cy() / mParameters.fy();"),
     "SPREF_GEN_CYL_LIFT": ("camera_models/src/camera_models/CylindricalCamera.cc", 207, 220, "void CylindricalCamera::liftProjective(const Eigen::Vector2d& p,", "}"),
     "SPREF_GEN_MAP_LOOP_VCAM": ("d2common/include/d2common/fisheye_undistort.h", 571, 579, "for (unsigned int x = 0; x < imgWidth; x++)", "cv::Vec2f(imgPoint.x(), imgPoint.y());"),
+    # round 3 (ref_shim/spref_api4.cpp): the LK tracker's glue around the (absent) OpenCV-CUDA optical flow
+    "SPREF_GEN_LK_INFO": ("d2frontend/include/d2frontend/opticaltrack_utils.h", 16, 26, "template <typename T> struct LKImageInfo {", "using LKImageInfoGPU = LKImageInfo<cv::cuda::GpuMat>;"),
+    "SPREF_GEN_REDUCE_VECTOR": ("d2frontend/include/d2frontend/utils.h", 21, 28, "template <typename T, typename B>", "}"),
+    "SPREF_GEN_LK_INBORDER": ("d2frontend/src/opticaltrack_utils.cpp", 35, 41, "bool inBorder(const cv::Point2f &pt, cv::Size shape) {", "}"),
+    "SPREF_GEN_LK_TRACKPYR": ("d2frontend/src/opticaltrack_utils.cpp", 173, 278, "LKImageInfoGPU opticalflowTrackPyr(const cv::Mat &cur_img,", "}"),
     "SPREF_GEN_MAP_LOOP_PINHOLE": ("d2common/include/d2common/fisheye_undistort.h", 627, 638, "for (unsigned int x = 0; x < imgWidth; x++)", "cv::Vec2f(imgPoint.x(), imgPoint.y());"),
 }
 
@@ -87,7 +92,7 @@ def build(force=False, verbose=False):
             defs.append('-D%s="%s"' % (macro, inc))
         cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-w",
                "-I" + SHIM, "-I" + os.path.join(REF, "d2frontend", "include")] + defs + \
-              [os.path.join(SHIM, "spref_api.cpp"), os.path.join(SHIM, "spref_api2.cpp"), os.path.join(SHIM, "spref_api3.cpp"), "-o", LIB]
+              [os.path.join(SHIM, "spref_api.cpp"), os.path.join(SHIM, "spref_api2.cpp"), os.path.join(SHIM, "spref_api3.cpp"), os.path.join(SHIM, "spref_api4.cpp"), "-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -189,6 +189,17 @@ static void lk_calc(const uint8_t* Ipyr, const uint8_t* Jpyr, const int* off, co
     lk_level(Ipyr + off[l], Jpyr + off[l], ws[l], hs[l], l, win, iters, ppx, ppy, npx, npy, status);
 }
 
+/* cv::cuda::SparsePyrLKOpticalFlow(win, levels, iters, useInitialFlow = true)->calc(prevPyr, nextPyr, prevPts, nextPts, status): ONE direction,
+ * next_pts holds the initial flow on entry.  Exposed for oracle/ref_shim/spref_api4.cpp, where the reference's own opticalflowTrackPyr calls it
+ * through a stand-in cv::cuda class. */
+ORC_API void orc_lk_calc(const uint8_t* prev_pyr, const uint8_t* next_pyr, int w, int h, int levels, const float* prev_pts, float* next_pts, int n,
+                         int win, int iters, uint8_t* status) {
+  int off[16], ws[16], hs[16];
+  orc_pyr_layout(w, h, levels, off, ws, hs);
+  for (int i = 0; i < n; ++i)
+    lk_calc(prev_pyr, next_pyr, off, ws, hs, levels, win, iters, prev_pts[2 * i], prev_pts[2 * i + 1], &next_pts[2 * i], &next_pts[2 * i + 1], &status[i]);
+}
+
 /* the tracking block of opticalflowTrackPyr (opticaltrack_utils.cpp:236-272): forward LK prev->cur from cur_init, reverse
  * LK cur->prev from the (shifted) forward result, accept iff both succeed, |prev - reverse| <= 0.5 and inBorder(cur).
  * type: 0 WHOLE_IMG_MATCH, 1 LEFT_RIGHT_IMG_MATCH, 2 RIGHT_LEFT_IMG_MATCH.  Outputs cur_pts[n][2], status[n]. */

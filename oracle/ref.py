@@ -172,3 +172,29 @@ def gen_pinhole_map(cam9, q_wxyz, width, height, f):
     mx = np.empty((height, width), np.float32); my = np.empty((height, width), np.float32)
     lib().spref_gen_pinhole_map(_p(c), _p(q), int(width), int(height), C.c_double(f), _p(mx), _p(my))
     return mx, my
+
+
+_LK_CB = []      # the ctypes callbacks must outlive the calls
+
+
+def lk_track_pyr(prev_img, cur_img, prev_pts, track_type, undistort_fov):
+    """The reference's opticalflowTrackPyr (GPU form, opticaltrack_utils.cpp:173-278) + inBorder (:35-41) compiled in place, over a stand-in
+    cv::cuda::SparsePyrLKOpticalFlow / buildImagePyramid that call the oracle's restatement (oracle/d2fe_oracle_lk.c).  Returns (cur_pts of the
+    surviving points, their ids = indices into prev_pts)."""
+    from . import oracle as orc
+    L = lib()
+    if not _LK_CB:
+        ol = orc.lib()
+        PB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
+        PL = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+        LC = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p)
+        _LK_CB.extend([C.cast(ol.orc_pyr_build, PB), C.cast(ol.orc_pyr_layout, PL), C.cast(ol.orc_lk_calc, LC)])
+        L.spref_set_lk_backend(*_LK_CB)
+    prev = np.ascontiguousarray(prev_img, np.uint8); cur = np.ascontiguousarray(cur_img, np.uint8)
+    h, w = prev.shape
+    pp = _f(prev_pts).reshape(-1, 2)
+    n = len(pp)
+    out = np.zeros((max(n, 1), 2), np.float32); ids = np.zeros(max(n, 1), np.int32)
+    L.spref_lk_track_pyr.restype = C.c_int
+    k = L.spref_lk_track_pyr(_p(prev), _p(cur), w, h, _p(pp), n, int(track_type), C.c_double(undistort_fov), _p(out), _p(ids))
+    return out[:k].copy(), ids[:k].copy()

@@ -54,6 +54,7 @@ class Mat {
   template <class T> const T& at(int r, int c) const { return *reinterpret_cast<const T*>(data + (size_t)r * step + (size_t)c * sizeof(T)); }
   template <class T> const T* ptr(int r) const { return reinterpret_cast<const T*>(data + (size_t)r * step); }
   void setTo(int v) { if (data) std::memset(data, v, (size_t)rows * step); }   // only ever called with 0
+  Size size() const { return Size(cols, rows); }
 };
 // (prob > threshold): CV_8U mask, 255 where true (cv::compare CMP_GT with a scalar, single precision)
 inline Mat operator>(const Mat& m, float thr) {

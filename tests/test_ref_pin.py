@@ -508,3 +508,72 @@ def test_hip_maps_vs_reference_cpp(api):
     rx, ry = spref.gen_pinhole_map(_MEI9, q, 600, 300, 300.0)
     assert np.abs(px - rx).max() <= 1.3e-4 and np.abs(py - ry).max() <= 1.3e-4 and (px == rx).mean() > 0.999
     fe.close()
+
+
+# ---- (f)-4 LK tracker glue: the reference's opticalflowTrackPyr compiled in place over the oracle's SparsePyrLK restatement ------------------
+def _shift(img, dx, dy):
+    """bilinear shift of a u8 image (content moves by +dx, +dy), borders replicated"""
+    h, w = img.shape
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    sx = np.clip(xx - dx, 0, w - 1); sy = np.clip(yy - dy, 0, h - 1)
+    x0 = np.floor(sx).astype(int); y0 = np.floor(sy).astype(int); x1 = np.minimum(x0 + 1, w - 1); y1 = np.minimum(y0 + 1, h - 1)
+    fx = sx - x0; fy = sy - y0
+    f = img.astype(np.float32)
+    v = (f[y0, x0] * (1 - fx) + f[y0, x1] * fx) * (1 - fy) + (f[y1, x0] * (1 - fx) + f[y1, x1] * fx) * fy
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
+def _track_like_the_mirror(track, prev_pts, W, track_type, fov):
+    """include/d2fe.hpp's opticalflowTrackPyr on top of a bidirectional track function (orc.lk_track / the HIP d2fe_lk_track)"""
+    move = np.float32(W * 90.0 / fov)
+    p = np.asarray(prev_pts, np.float32).reshape(-1, 2)
+    ids = np.arange(len(p))
+    init = p.copy()
+    if track_type == 1:
+        keep = p[:, 0] < W - move; p, ids = p[keep], ids[keep]; init = p.copy(); init[:, 0] += move
+    elif track_type == 2:
+        keep = p[:, 0] >= move; p, ids = p[keep], ids[keep]; init = p.copy(); init[:, 0] -= move
+    if not len(p):
+        return np.zeros((0, 2), np.float32), ids[:0]
+    out, st = track(p, init, float(move))
+    return out[st > 0], ids[st > 0]
+
+
+_LK_CASES = [(0, 3.5, -2.25, 640, 480), (1, 2.0, 0.5, 800, 400), (2, -1.5, 1.0, 800, 400)]
+
+
+@pytest.mark.parametrize("ttype,dx,dy,W,H", _LK_CASES)
+def test_lk_glue_vs_reference_cpp(orc, ttype, dx, dy, W, H):
+    """(f)-4: opticalflowTrackPyr (opticaltrack_utils.cpp:173-278: the half-image pre-filter and +-move_cols shift, the reverse track from the shifted
+    result, the 0.5 px forward/backward test, inBorder, reduceVector) compiled where it lies, calling the oracle's SparsePyrLK through a stand-in
+    cv::cuda class: the oracle's one-call bidirectional track + the mirror's pre-filter give the same surviving points, ids and coordinates."""
+    fov = 200.0
+    move = float(np.float32(W * 90.0 / fov))
+    img = synth_image(H, W, 21 + ttype)
+    shift = dx + (move if ttype == 1 else -move if ttype == 2 else 0.0)
+    cur = _shift(img, shift, dy)
+    pts, _ = orc.fast_by_region(img, 150)
+    pts = np.concatenate([pts, [[0.4, 0.4], [W - 1.2, H - 1.3], [W / 2, H / 2]]]).astype(np.float32)       # border cases for inBorder
+    rp, rid = spref.lk_track_pyr(img, cur, pts, ttype, fov)
+    p0, p1 = orc.pyr_build(img), orc.pyr_build(cur)
+    op, oid = _track_like_the_mirror(lambda p, init, mv: orc.lk_track(p0, p1, W, H, p, init, track_type=ttype, move_cols=mv), pts, W, ttype, fov)
+    assert len(rid) > 20 and np.array_equal(rid, oid) and np.array_equal(rp, op)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ttype,dx,dy,W,H", _LK_CASES)
+def test_hip_lk_glue_vs_reference_cpp(api, ttype, dx, dy, W, H):
+    fov = 200.0
+    move = float(np.float32(W * 90.0 / fov))
+    img = synth_image(H, W, 21 + ttype)
+    cur = _shift(img, dx + (move if ttype == 1 else -move if ttype == 2 else 0.0), dy)
+    from oracle import oracle as orc
+    orc.build()
+    pts, _ = orc.fast_by_region(img, 150)
+    pts = np.concatenate([pts, [[0.4, 0.4], [W - 1.2, H - 1.3], [W / 2, H / 2]]]).astype(np.float32)
+    rp, rid = spref.lk_track_pyr(img, cur, pts, ttype, fov)
+    fe = api.FrontEnd(api.SuperPointConfig(input_width=64, input_height=64, max_batch=1))
+    f0, f1 = api.LKFrame(fe, img), api.LKFrame(fe, cur)
+    gp, gid = _track_like_the_mirror(lambda p, init, mv: api.lk_track(fe, f0, f1, p, init, track_type=ttype, move_cols=mv), pts, W, ttype, fov)
+    assert np.array_equal(rid, gid) and np.array_equal(rp, gp)
+    f0.close(); f1.close(); fe.close()
