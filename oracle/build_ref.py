@@ -39,6 +39,8 @@ RANGES = {
     "SPREF_GEN_TRACKER_DIRS": ("d2frontend/src/d2featuretracker.cpp", 270, 284, "int max_dirs = 4;", "}"),
     "SPREF_GEN_LOOPCAM_MATCH": ("d2frontend/src/loop_cam.cpp", 156, 191, "void matchLocalFeatures(", "}"),
     # round 3 (ref_shim/spref_api3.cpp): undistortion map generation = camodocal (vendored camera_models/) + FisheyeUndist::genOneUndistMap
+    "SPREF_GEN_CATA_INVK": ("camera_models/src/camera_models/CataCamera.cc", 221, 224, "m_inv_K11 = 1.0 / mParameters.gamma1();", "m_inv_K23 = -mParameters.v0() / mParameters.gamma2();"),
+    "SPREF_GEN_CATA_LIFT": ("camera_models/src/camera_models/CataCamera.cc", 425, 487, "void CataCamera::liftProjective(const Eigen::Vector2d& p,", "}"),
     "SPREF_GEN_CATA_SPACE": ("camera_models/src/camera_models/CataCamera.cc", 495, 515, "void CataCamera::spaceToPlane(const Eigen::Vector3d& P,", "}"),
     "SPREF_GEN_CATA_DIST": ("camera_models/src/camera_models/CataCamera.cc", 617, 633, "void CataCamera::distortion(const Eigen::Vector2d& p_u,", "}"),
     "SPREF_GEN_CYL_INVK": ("camera_models/src/camera_models/CylindricalCamera.cc", 144, 147, "m_inv_K11 = 1.0 / mParameters.fx();", "m_inv_K23 = -mParameters.cy() / mParameters.fy();"),

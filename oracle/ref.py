@@ -198,3 +198,11 @@ def lk_track_pyr(prev_img, cur_img, prev_pts, track_type, undistort_fov):
     L.spref_lk_track_pyr.restype = C.c_int
     k = L.spref_lk_track_pyr(_p(prev), _p(cur), w, h, _p(pp), n, int(track_type), C.c_double(undistort_fov), _p(out), _p(ids))
     return out[:k].copy(), ids[:k].copy()
+
+
+def cata_lift(cam9, pts):
+    """camodocal CataCamera::liftProjective (camera_models/, CataCamera.cc:425-487) compiled in place: [n, 3] float64 rays."""
+    c = np.ascontiguousarray(cam9, np.float64); p = _f(pts).reshape(-1, 2)
+    out = np.zeros((len(p), 3), np.float64)
+    lib().spref_cata_lift(_p(c), _p(p), len(p), _p(out))
+    return out

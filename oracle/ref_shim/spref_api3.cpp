@@ -29,8 +29,10 @@ struct Vector2d {
   Comma2 operator<<(double a) { v[0] = a; return Comma2{v, 1}; }
   Vector2d operator+(const Vector2d& o) const { return Vector2d(v[0] + o.v[0], v[1] + o.v[1]); }
 };
+struct Comma3 { double* v; int i; Comma3& operator,(double x) { v[i++] = x; return *this; } };
 struct Vector3d {
   double v[3];
+  Comma3 operator<<(double a) { v[0] = a; return Comma3{v, 1}; }
   Vector3d() : v{0, 0, 0} {}
   Vector3d(double a, double b, double c) : v{a, b, c} {}
   double& operator()(int i) { return v[i]; }
@@ -67,10 +69,15 @@ class CataCamera : public Camera {
   };
   Parameters mParameters;
   bool m_noDistortion = false;
-  void liftProjective(const Eigen::Vector2d&, Eigen::Vector3d&) const override {}
+  double m_inv_K11 = 1, m_inv_K13 = 0, m_inv_K22 = 1, m_inv_K23 = 0;
+  void set_inverse_K() {
+#include SPREF_GEN_CATA_INVK           /* CataCamera.cc:221-224 */
+  }
+  void liftProjective(const Eigen::Vector2d& p, Eigen::Vector3d& P) const override;
   void spaceToPlane(const Eigen::Vector3d& P, Eigen::Vector2d& p) const override;
   void distortion(const Eigen::Vector2d& p_u, Eigen::Vector2d& d_u) const;
 };
+#include SPREF_GEN_CATA_LIFT           /* CataCamera.cc:425-487  liftProjective: inverse K, 8-step recursive distortion removal, the MEI ray */
 #include SPREF_GEN_CATA_SPACE          /* CataCamera.cc:495-515 */
 #include SPREF_GEN_CATA_DIST           /* CataCamera.cc:617-633 */
 
@@ -102,13 +109,23 @@ struct MapMat {
 
 #define DEG_TO_RAD (M_PI / 180.0)      /* fisheye_undistort.h:27 */
 
-static camodocal::CameraPtr make_cata(const double* c) {
+static std::shared_ptr<camodocal::CataCamera> make_cata(const double* c) {
   auto cam = std::make_shared<camodocal::CataCamera>();
   cam->mParameters = camodocal::CataCamera::Parameters{c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]};
+  cam->set_inverse_K();
   return cam;
 }
 
 extern "C" {
+// CataCamera::liftProjective for n image points (what LoopCam::extractorImgDescDeepnet calls per keypoint, loop_cam.cpp:619-623): out[n][3]
+SPREF_API void spref_cata_lift(const double* cam9, const float* pts, int n, double* out) {
+  auto cam = make_cata(cam9);
+  for (int i = 0; i < n; ++i) {
+    Eigen::Vector3d P;
+    cam->liftProjective(Eigen::Vector2d(pts[2 * i], pts[2 * i + 1]), P);
+    out[3 * i] = P(0); out[3 * i + 1] = P(1); out[3 * i + 2] = P(2);
+  }
+}
 // generateCylinderMap (fisheye_undistort.h:458-500): cylinderFov = fov * DEG_TO_RAD (:465), f_center = imgWidth / cylinderFov (:469),
 // CylindricalCamera("cylindrical", imgWidth, imgHeight, f_center, f_center, imgWidth / 2, imgHeight / 2) (:489-493, unsigned divisions),
 // then genOneUndistMap's loop.  cam9 = {xi, k1, k2, p1, p2, gamma1, gamma2, u0, v0}.

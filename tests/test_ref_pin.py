@@ -577,3 +577,31 @@ def test_hip_lk_glue_vs_reference_cpp(api, ttype, dx, dy, W, H):
     gp, gid = _track_like_the_mirror(lambda p, init, mv: api.lk_track(fe, f0, f1, p, init, track_type=ttype, move_cols=mv), pts, W, ttype, fov)
     assert np.array_equal(rid, gid) and np.array_equal(rp, gp)
     f0.close(); f1.close(); fe.close()
+
+
+def test_mirror_lift_vs_camodocal(tmp_path):
+    """A8 (host): include/d2fe.hpp's liftProjectiveMEI -- what an adapter without camodocal calls where the reference calls camera->liftProjective
+    (loop_cam.cpp:619-623) -- against camodocal's CataCamera::liftProjective (vendored camera_models/, CataCamera.cc:425-487: inverse K, the 8-step
+    recursive distortion removal, the MEI ray) compiled in place: same fp64 operations in the same order, bitwise equal."""
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "liblift.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "lift_wrap.cpp"), "-o", so])
+    L = C.CDLL(so)
+    rng = np.random.RandomState(4)
+    pts = np.concatenate([rng.rand(500, 2) * [1280, 800], [[660.64, 386.17], [0, 0], [1279, 799], [-50, 900]]]).astype(np.float32)
+    cam = np.array(_MEI9, np.float64)
+    out = np.zeros((len(pts), 3), np.float64)
+    L.lift_mei(cam.ctypes.data_as(C.c_void_p), pts.ctypes.data_as(C.c_void_p), len(pts), out.ctypes.data_as(C.c_void_p))
+    ref = spref.cata_lift(_MEI9, pts)
+    # far from the principal point the MEI ray does not exist (sqrt of a negative number): NaN in both -- the case extractorImgDescDeepnet skips
+    assert np.array_equal(out, ref, equal_nan=True) and 0.2 < np.isfinite(ref).all(1).mean() < 1.0
+    # no distortion (k1 = k2 = p1 = p2 = 0: m_noDistortion in camodocal) and xi = 1 (the parabolic branch)
+    for cam2 in ([2.2, 0, 0, 0, 0, 1100.0, 1100.0, 640.0, 400.0], [1.0, -0.1, 0.05, 1e-3, -1e-3, 900.0, 905.0, 630.0, 410.0]):
+        c2 = np.array(cam2, np.float64)
+        L.lift_mei(c2.ctypes.data_as(C.c_void_p), pts.ctypes.data_as(C.c_void_p), len(pts), out.ctypes.data_as(C.c_void_p))
+        r2 = spref.cata_lift(cam2, pts)
+        assert np.array_equal(np.isnan(out), np.isnan(r2)) and np.nanmax(np.abs(out - r2)) <= 1e-12, cam2
