@@ -55,6 +55,48 @@ RANGES = {
 }
 
 
+TORCH_LIB = os.path.join(OUT_DIR, "libspref_torch.so")
+TORCH_RANGE = ("SPREF_GEN_COMPUTE_DESC", "d2frontend/src/CNN/superpoint_common.cpp", 42, 99, "void computeDescriptors(const torch::Tensor& mProb, const torch::Tensor& mDesc,", "}")
+
+
+def build_torch(force=False, verbose=False):
+    """oracle/_ref/libspref_torch.so: computeDescriptors (superpoint_common.cpp:42-99) against the image's libtorch.  Returns the path or None
+    (no reference tree and no prebuilt library, or no torch C++ headers)."""
+    if not available():
+        return TORCH_LIB if os.path.exists(TORCH_LIB) else None
+    src = os.path.join(SHIM, "spref_torch.cpp")
+    deps = [src, os.path.join(SHIM, "torch_eigen", "Eigen", "Eigen"), os.path.join(REF, TORCH_RANGE[1]), os.path.abspath(__file__)]
+    if not force and os.path.exists(TORCH_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(TORCH_LIB) for d in deps):
+        return TORCH_LIB
+    try:
+        import torch
+        from torch.utils import cpp_extension as ce
+    except Exception:
+        return None
+    os.makedirs(OUT_DIR, exist_ok=True)
+    macro, rel, a, b, anchor_a, anchor_b = TORCH_RANGE
+    with open(os.path.join(REF, rel), encoding="utf-8") as f:
+        lines = f.read().split("\n")
+    if anchor_a not in lines[a - 1] or anchor_b not in lines[b - 1]:
+        raise RuntimeError("%s:%d-%d does not look like the surveyed reference" % (rel, a, b))
+    with tempfile.TemporaryDirectory(prefix="spref_t_") as tmp:
+        inc = os.path.join(tmp, "compute_desc.inc")
+        with open(inc, "w", encoding="utf-8") as f:
+            f.write('#line %d "%s"\n' % (a, os.path.join(REF, rel)))
+            f.write("\n".join(lines[a - 1:b]) + "\n")
+        libdir = ce.library_paths()[0]
+        cmd = ["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-w",
+               "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), '-D%s="%s"' % (macro, inc),
+               "-I" + os.path.join(SHIM, "torch_eigen"), "-I" + SHIM] + ["-I" + p for p in ce.include_paths()] + \
+              [src, "-L" + libdir, "-ltorch_cpu", "-lc10", "-ltorch", "-Wl,-rpath," + libdir, "-o", TORCH_LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building oracle/_ref/libspref_torch.so failed:\n" + r.stdout[-3000:] + r.stderr[-6000:])
+    return TORCH_LIB
+
+
 def available():
     return os.path.isdir(os.path.join(REF, "d2frontend", "src"))
 
@@ -105,3 +147,5 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force="-f" in sys.argv, verbose=True))
+    if "--torch" in sys.argv:
+        print(build_torch(force="-f" in sys.argv, verbose=True))

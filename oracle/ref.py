@@ -206,3 +206,39 @@ def cata_lift(cam9, pts):
     out = np.zeros((len(p), 3), np.float64)
     lib().spref_cata_lift(_p(c), _p(p), len(p), _p(out))
     return out
+
+
+_TLIB = None
+
+
+def torch_available():
+    return os.path.exists(build_ref.TORCH_LIB) or build_ref.available()
+
+
+def compute_descriptors(desc_hwc, kps, img_w, img_h, pca_comp=None, pca_mean=None):
+    """The reference's variant-A descriptor sampling, computeDescriptors (superpoint_common.cpp:42-99), compiled in place against the image's
+    REAL libtorch (torch::grid_sampler, norm, div).  desc_hwc [hc, wc, 256] channel-normalised (the ONNX graph's `desc` output, transposed here
+    to CHW); kps [n, 2] (x, y); pca_comp [pd, 256] (the CSV layout; the reference multiplies by its transpose).  Returns [n, pd or 256]."""
+    global _TLIB
+    if _TLIB is None:
+        import torch  # noqa: F401  (libtorch_cpu / libc10 loaded first)
+        so = build_ref.build_torch()
+        if so is None:
+            raise RuntimeError("oracle/_ref/libspref_torch.so is absent and cannot be built here")
+        _TLIB = C.CDLL(so)
+        _TLIB.spref_compute_descriptors.restype = C.c_int
+    hc, wc, dim = desc_hwc.shape
+    chw = _f(np.transpose(desc_hwc, (2, 0, 1)))
+    k = _f(kps).reshape(-1, 2)
+    n = len(k)
+    pd = 0; ct = mean = None
+    if pca_comp is not None:
+        pc = _f(pca_comp); pd = pc.shape[0]
+        ct = np.asfortranarray(pc.T)                 # pca_comp_T = comp^T, [dim, pd], column-major like Eigen::MatrixXf
+        ct = np.ascontiguousarray(ct.T.reshape(-1))   # column-major storage of [dim, pd] == row-major storage of [pd, dim]
+        mean = _f(pca_mean)
+    out = np.zeros((max(n, 1), pd or dim), np.float32)
+    m = _TLIB.spref_compute_descriptors(_p(chw), dim, hc, wc, _p(k), n, int(img_w), int(img_h), _p(ct) if ct is not None else None,
+                                        _p(mean) if mean is not None else None, pd, _p(out))
+    assert m == n * (pd or dim), (m, n)
+    return out[:n].copy()

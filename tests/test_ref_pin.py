@@ -605,3 +605,55 @@ def test_mirror_lift_vs_camodocal(tmp_path):
         L.lift_mei(c2.ctypes.data_as(C.c_void_p), pts.ctypes.data_as(C.c_void_p), len(pts), out.ctypes.data_as(C.c_void_p))
         r2 = spref.cata_lift(cam2, pts)
         assert np.array_equal(np.isnan(out), np.isnan(r2)) and np.nanmax(np.abs(out - r2)) <= 1e-12, cam2
+
+
+# ---- A7: the reference's computeDescriptors compiled against the image's real libtorch -------------------------------------------------------
+@pytest.mark.skipif(not spref.torch_available(), reason="oracle/_ref/libspref_torch.so absent and not buildable here")
+@pytest.mark.parametrize("H,W,N,thr,seed", CONFIGS[:3])
+def test_variant_a_sampling_vs_reference_cpp_libtorch(orc, forwards, H, W, N, thr, seed):
+    """computeDescriptors (superpoint_common.cpp:42-99: the (y, x) keypoint matrix, the grid 2x/W - 1, torch::grid_sampler(bilinear, zeros,
+    align_corners = false), torch::norm over the KEYPOINT axis, the row normalisation, the optional PCA) compiled where it lies and run on ATen's own
+    kernels: the oracle's restatement agrees to fp32 round-off, with and without PCA, at the BASELINE geometries."""
+    f = forwards(H, W, seed, 3.5 if thr > 0.1 else 0.0)
+    kps, _ = spref.get_keypoints(f["semi"], thr, 10, N)              # variant A's own keypoints (NMS2)
+    assert len(kps) > 20
+    ref = spref.compute_descriptors(f["desc"], kps, W, H)
+    got = orc.sample_a(f["desc"], kps, W, H)
+    assert ref.shape == got.shape == (len(kps), 256) and np.abs(got - ref).max() <= 2e-6
+    rng = np.random.RandomState(seed)
+    comp = np.linalg.qr(rng.randn(256, 64))[0].T.astype(np.float32); mean = (0.01 * rng.randn(256)).astype(np.float32)
+    refp = spref.compute_descriptors(f["desc"], kps, W, H, comp, mean)
+    gotp = orc.sample_a(f["desc"], kps, W, H, comp, mean)
+    assert refp.shape == gotp.shape == (len(kps), 64) and np.abs(gotp - refp).max() <= 3e-6
+    # keypoints on the image border sample outside the map (zeros padding)
+    edge = np.array([[0, 0], [W - 1, 0], [0, H - 1], [W - 1, H - 1], [3, 5]], np.float32)
+    assert np.abs(orc.sample_a(f["desc"], edge, W, H) - spref.compute_descriptors(f["desc"], edge, W, H)).max() <= 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not spref.torch_available(), reason="oracle/_ref/libspref_torch.so absent and not buildable here")
+@pytest.mark.parametrize("H,W,N,thr,seed", CONFIGS[:3])
+@pytest.mark.parametrize("pca", [False, True])
+def test_hip_variant_a_descriptors_vs_reference_cpp_libtorch(api, orc, sp_weights, H, W, N, thr, seed, pca):
+    """HIP variant A (NMS2 + sampling + PCA) against the reference's getKeyPoints AND computeDescriptors (real ATen grid_sampler), both applied to
+    the HIP path's own network outputs."""
+    w = sp_weights
+    if thr > 0.1:
+        w = dict(w); Wt, b = w["convPb"]; b = b.copy(); b[64] -= np.float32(3.5); w["convPb"] = (Wt, b)
+    img = synth_image(H, W, seed)
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=N, input_width=W, input_height=H, max_batch=1, keypoint_threshold=thr,
+                                           postproc=api.POSTPROC_A, nms_dist=10, keep_score_map=True, dense_descriptors=True))
+    fe.load_superpoint(w)
+    comp = mean = None
+    if pca:
+        rng = np.random.RandomState(seed)
+        comp = np.linalg.qr(rng.randn(256, 64))[0].T.astype(np.float32); mean = (0.01 * rng.randn(256)).astype(np.float32)
+        fe.set_pca(comp, mean)
+    (kps, sc, desc), = fe.extract_batch(img[None], cap=N)
+    semi = fe.debug_read("semi", (1, H, W))[0]
+    dmap = orc.l2norm_rows(fe.debug_read("desc_raw", (1, H // 8, W // 8, 256))[0])
+    rk, rs = spref.get_keypoints(semi, thr, 10, N)
+    assert_same_selection(kps, sc, rk, rs, "HIP NMS2")
+    ref = spref.compute_descriptors(dmap, kps, W, H, comp, mean)          # on the HIP path's own keypoint list (the channel norms depend on it)
+    assert desc.shape == ref.shape and np.abs(desc - ref).max() <= 3e-6
+    fe.close()
