@@ -703,6 +703,18 @@ def run_latency(api, weights, nv_weights, device_id, precision, calls):
         def stereo_nv():
             two(); nvc(); mk(); mk()
         out["stereo_frame_with_netvlad_host_to_host"] = stats(stereo_nv)
+        # the fused entry point: ONE upload, SuperPoint (L+R) and NetVLAD (L) side by side on two streams (loop_cam.cpp:609-616 makes the two calls
+        # back to back for the same image)
+        g1 = np.zeros((1, fe.netvlad_dim), np.float32)
+        all1 = lambda: lib.d2fe_extract_all(h, P(pair), W, H, W, P(kps), P(sc), P(desc), CAP, P(cnt), P(g1))
+        all2 = lambda: lib.d2fe_extract_all_batch(h, P(pair), 2, W, H, W, H * W, P(kps), P(sc), P(desc), CAP, P(cnt), 1, P(g1))
+        assert all1() == 0 and all2() == 0
+        out["d2fe_extract_all_1_image_superpoint_and_netvlad"] = stats(all1)
+        out["d2fe_extract_all_batch_stereo_pair_netvlad_left"] = stats(all2)
+
+        def stereo_all():
+            all2(); mk(); mk()
+        out["stereo_frame_with_netvlad_fused_host_to_host"] = stats(stereo_all)
     fe.close()
     # one quadcam frame (configs[2] geometry): 4 undistorted 800x400 views through extract_batch + netvlad_batch
     UH, UW, CAPQ = 400, 800, 100
@@ -720,6 +732,9 @@ def run_latency(api, weights, nv_weights, device_id, precision, calls):
         qnv = lambda: lib.d2fe_netvlad_batch(fq._h, P(views), 4, UW, UH, UW, UH * UW, P(g4))
         assert qnv() == 0
         out["quadcam_frame_4_views_netvlad_batch"] = stats(qnv)
+        qall = lambda: lib.d2fe_extract_all_batch(fq._h, P(views), 4, UW, UH, UW, UH * UW, P(k4), P(s4), P(d4), CAPQ, P(c4), 4, P(g4))
+        assert qall() == 0
+        out["quadcam_frame_4_views_extract_all_batch"] = stats(qall)
     fq.close()
     return out
 

@@ -77,7 +77,7 @@ _lib = None
 
 EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_create", "d2fe_destroy",
            "d2fe_load_superpoint", "d2fe_set_superpoint_pca", "d2fe_desc_dim", "d2fe_superpoint_extract", "d2fe_superpoint_extract_batch",
-           "d2fe_superpoint_extract_device", "d2fe_tail_stream", "d2fe_superpoint_wait_tail", "d2fe_load_netvlad", "d2fe_set_netvlad_pca", "d2fe_netvlad_dim",
+           "d2fe_superpoint_extract_device", "d2fe_extract_all", "d2fe_extract_all_batch", "d2fe_tail_stream", "d2fe_superpoint_wait_tail", "d2fe_load_netvlad", "d2fe_set_netvlad_pca", "d2fe_netvlad_dim",
            "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device", "d2fe_match_fallback_rows", "d2fe_debug_graph_count",
            "d2fe_block_words", "d2fe_block_field_offset", "d2fe_pack_blocks_device", "d2fe_gate_pairs_device", "d2fe_quad_gate_device", "d2fe_block_bytes_int8", "d2fe_pack_blocks_int8_device", "d2fe_unpack_blocks_int8_device",
            "d2fe_half_move_cols", "d2fe_half_image_compact_device", "d2fe_remap_matches_device",
@@ -131,6 +131,10 @@ def load_library():
         lib.d2fe_superpoint_extract_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                        C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                        C.c_int, C.c_void_p, C.c_void_p]
+        lib.d2fe_extract_all_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        lib.d2fe_extract_all.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p]
         lib.d2fe_superpoint_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.d2fe_match_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double,
@@ -322,6 +326,25 @@ class FrontEnd:
         if rc != 0 and rc != ERR_TRUNCATED:
             _check(rc)
         return [(kps[i, :cnt[i]].copy(), sc[i, :cnt[i]].copy(), desc[i, :cnt[i]].copy()) for i in range(n)]
+
+    def extract_all_batch(self, images, n_netvlad, cap=None):
+        """d2fe_extract_all_batch: SuperPoint on all images + NetVLAD on the first n_netvlad, one upload, two streams.
+        Returns (list of (kps, scores, desc), netvlad [n_netvlad, G])."""
+        images = np.ascontiguousarray(images, np.uint8)
+        if images.ndim == 2:
+            images = images[None]
+        n, H, W = images.shape
+        if not cap:
+            cap = self.cfg.max_keypoints if self.cfg.max_keypoints > 0 else KEEP_ALL_CAP
+        kps = np.zeros((n, cap, 2), np.float32); sc = np.zeros((n, cap), np.float32)
+        desc = np.zeros((n, cap, self.desc_dim), np.float32); cnt = np.zeros(n, np.int32)
+        g = np.zeros((max(n_netvlad, 1), self.netvlad_dim), np.float32)
+        rc = self._lib.d2fe_extract_all_batch(self._h, _ptr(images), n, W, H, W, H * W, _ptr(kps), _ptr(sc), _ptr(desc), cap, _ptr(cnt),
+                                              int(n_netvlad), _ptr(g))
+        self.last_truncated = rc == ERR_TRUNCATED
+        if rc != 0 and rc != ERR_TRUNCATED:
+            _check(rc)
+        return [(kps[i, :cnt[i]].copy(), sc[i, :cnt[i]].copy(), desc[i, :cnt[i]].copy()) for i in range(n)], g[:n_netvlad].copy()
 
     def graph_count(self):
         """(cached hipGraphs of host-pointer launch sequences, geometries whose capture was rejected) -- include/d2fe.h."""

@@ -86,6 +86,8 @@ struct d2fe_context {
   float* s_out = nullptr;      // device: [kps | scores | desc | n | idx] of a host-pointer extract call, contiguous -> ONE D2H of the first four
   size_t s_out_bytes = 0;
   bool use_graphs = true, use_pinned = true;       // D2FE_GRAPH=0 / D2FE_PINNED=0 switch them off (A/B measurements)
+  // d2fe_extract_all*: NetVLAD of the same uploaded frame(s) on a second stream, beside SuperPoint
+  hipStream_t nv_stream = nullptr; hipEvent_t ev_up = nullptr; float* pin_nv = nullptr; size_t pin_nv_bytes = 0;
   struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; bool bad = false; };
   std::map<std::array<long, 6>, GraphEntry> graphs;
   int ncu = 256;               // compute units of cfg.device_id, read once by d2fe_create (ConvArgs::ncu)
@@ -547,6 +549,9 @@ void d2fe_destroy(d2fe_handle h) {
   nv_free(h);
   for (void* p : {(void*)h->nv_pca_comp, (void*)h->nv_pca_mean, (void*)h->nv_s_img, (void*)h->nv_s_out}) if (p) hipFree(p);
   for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  if (h->nv_stream) { hipStreamSynchronize(h->nv_stream); (void)hipStreamDestroy(h->nv_stream); }
+  if (h->ev_up) (void)hipEventDestroy(h->ev_up);
+  if (h->pin_nv) (void)hipHostFree(h->pin_nv);
   if (h->pin_in) (void)hipHostFree(h->pin_in);
   if (h->pin_out) (void)hipHostFree(h->pin_out);
   if (h->s_out) hipFree(h->s_out);
@@ -691,12 +696,19 @@ static int upload_frames(d2fe_context* h, uint8_t* d_dst, const uint8_t* gray, i
   return D2FE_OK;
 }
 
-int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int height, int stride,
-                                  size_t image_stride, float* kps_xy, float* scores, float* desc, int cap, int* n_out) {
+static int nv_check(d2fe_context* h, int n, int W, int H, int stride);
+int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int stride, size_t image_stride, float* d_out, hipStream_t s);
+
+// host-pointer extract of n images; n_netvlad > 0: the NetVLAD descriptors of the first n_netvlad of them as well, from the SAME uploaded frames,
+// on a second stream beside SuperPoint (d2fe_extract_all*)
+static int extract_host(d2fe_handle h, const uint8_t* gray, int n, int width, int height, int stride, size_t image_stride, float* kps_xy,
+                        float* scores, float* desc, int cap, int* n_out, int n_netvlad, float* netvlad_out) {
   if (n_out) for (int i = 0; i < (n > 0 ? n : 0); ++i) n_out[i] = 0;
   int rc = check_geometry(h, n, width, height, stride, cap);
   if (rc) return rc;
   if (!gray || !kps_xy || !scores || !desc || !n_out) return fail(D2FE_ERR_INVALID, "null pointer");
+  if (n_netvlad < 0 || n_netvlad > n || (n_netvlad > 0 && !netvlad_out)) return fail(D2FE_ERR_INVALID, "bad NetVLAD image count / null output");
+  if (n_netvlad > 0) { rc = nv_check(h, n_netvlad, width, height, stride); if (rc) return rc; }
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   hipStream_t s = h->stream;
   // the call's capacity, bounded by what can exist: H*W candidates (keep-all) or the configured maximum
@@ -720,6 +732,28 @@ int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int
   }
   rc = upload_frames(h, h->s_img, gray, n, width, height, stride, image_stride, s);
   if (rc) return rc;
+  size_t nv_bytes = 0;
+  if (n_netvlad > 0) {
+    // NetVLAD reads the frames SuperPoint reads (one upload), on its own stream: at one or two images per call both launch sequences are
+    // latency-bound and leave most of the chip idle, so they overlap almost completely (the reference calls infer and then inference
+    // for the same image, loop_cam.cpp:609-616)
+    if (!h->nv_stream) { HIP_TRY(hipStreamCreateWithFlags(&h->nv_stream, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming)); }
+    const int G = d2fe_netvlad_dim(h);
+    nv_bytes = sizeof(float) * (size_t)G * n_netvlad;
+    if (h->use_pinned && nv_bytes > h->pin_nv_bytes) {
+      if (h->pin_nv) { (void)hipHostFree(h->pin_nv); h->pin_nv = nullptr; h->pin_nv_bytes = 0; }
+      const size_t want = sizeof(float) * 8192 * (size_t)h->cfg.max_batch;
+      if (hipHostMalloc(&h->pin_nv, want > nv_bytes ? want : nv_bytes, hipHostMallocDefault) == hipSuccess) h->pin_nv_bytes = want > nv_bytes ? want : nv_bytes;
+      else { (void)hipGetLastError(); h->pin_nv = nullptr; }
+    }
+    HIP_TRY(hipEventRecord(h->ev_up, s));
+    HIP_TRY(hipStreamWaitEvent(h->nv_stream, h->ev_up, 0));
+    rc = run_cached(h, {3, n_netvlad, width, height, (long)h->nv_pca_m, 0}, h->nv_stream, [&](hipStream_t st) {
+      return run_netvlad(h, h->s_img, n_netvlad, width, height, width, (size_t)width * height, h->nv_s_out, st);
+    });
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->pin_nv ? (void*)h->pin_nv : (void*)netvlad_out, h->nv_s_out, nv_bytes, hipMemcpyDeviceToHost, h->nv_stream));
+  }
   // async_tail handles: a preceding d2fe_superpoint_extract_device call may still have its post-processing running on the tail
   // stream against the single-buffered scratch (candidates, score map, sparse-head slots) that this run uses too
   if (h->cfg.async_tail)
@@ -767,9 +801,28 @@ int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int
     }
     HIP_TRY(hipStreamSynchronize(s));
   }
+  if (n_netvlad > 0) {
+    HIP_TRY(hipStreamSynchronize(h->nv_stream));
+    if (h->pin_nv) memcpy(netvlad_out, h->pin_nv, nv_bytes);
+  }
   for (int32_t c : ncand)
     if (c > dcap) return fail(D2FE_ERR_TRUNCATED, "max_keypoints = -1: an image has more keypoints than the call's capacity; the strongest were kept");
   return D2FE_OK;
+}
+
+int d2fe_superpoint_extract_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int height, int stride,
+                                  size_t image_stride, float* kps_xy, float* scores, float* desc, int cap, int* n_out) {
+  return extract_host(h, gray, n, width, height, stride, image_stride, kps_xy, scores, desc, cap, n_out, 0, nullptr);
+}
+
+int d2fe_extract_all_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int height, int stride, size_t image_stride, float* kps_xy,
+                           float* scores, float* desc, int cap, int* n_out, int n_netvlad, float* netvlad_out) {
+  return extract_host(h, gray, n, width, height, stride, image_stride, kps_xy, scores, desc, cap, n_out, n_netvlad, netvlad_out);
+}
+
+int d2fe_extract_all(d2fe_handle h, const uint8_t* gray, int width, int height, int stride, float* kps_xy, float* scores, float* desc, int cap,
+                     int* n_out, float* netvlad_out) {
+  return extract_host(h, gray, 1, width, height, stride, (size_t)stride * height, kps_xy, scores, desc, cap, n_out, 1, netvlad_out);
 }
 
 int d2fe_superpoint_extract(d2fe_handle h, const uint8_t* gray, int width, int height, int stride, float* kps_xy,

@@ -177,6 +177,16 @@ D2FE_API int d2fe_netvlad_batch(d2fe_handle h, const uint8_t* gray, int n, int w
 D2FE_API int d2fe_netvlad_device(d2fe_handle h, const uint8_t* d_gray, int n, int width, int height, int stride,
                                  size_t image_stride, float* d_out, void* stream);
 
+/* Fused form of the two calls LoopCam::extractorImgDescDeepnet makes for one image (loop_cam.cpp:609-616: superpoint_net->infer(...) and then
+ * netvlad_onnx->inference(...) on the same frame): ONE upload, SuperPoint and NetVLAD on two streams side by side (at one or two images per call
+ * both are latency-bound and leave most of the chip idle), one synchronisation.  Same outputs, bit for bit, as d2fe_superpoint_extract(_batch)
+ * followed by d2fe_netvlad(_batch) on the first n_netvlad images (stereo: the left image, loop_cam.cpp:446-451).  netvlad_out: n_netvlad x
+ * d2fe_netvlad_dim() floats.  Needs both networks loaded and an image size both accept. */
+D2FE_API int d2fe_extract_all(d2fe_handle h, const uint8_t* gray, int width, int height, int stride, float* kps_xy, float* scores, float* desc,
+                              int cap, int* n_out, float* netvlad_out);
+D2FE_API int d2fe_extract_all_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int height, int stride, size_t image_stride,
+                                    float* kps_xy, float* scores, float* desc, int cap, int* n_out, int n_netvlad, float* netvlad_out);
+
 /* Matcher.  Replaces: std::vector<cv::DMatch> matchKNN(const cv::Mat& desc_a, const cv::Mat& desc_b,
  * double knn_match_ratio, pts_a, pts_b, double search_local_dist) (feature_matcher.h:6-11,
  * feature_matcher.cpp:4-42).  a: na x dim row-major, b: nb x dim.  pts_*: n x 2 floats or NULL.

@@ -697,6 +697,32 @@ def test_host_calls_replay_cached_graphs_with_identical_results(api, orc, sp_wei
     fe.close()
 
 
+def test_extract_all_equals_the_two_separate_calls(api, sp_weights):
+    """d2fe_extract_all(_batch) = SuperPoint::infer + MobileNetVLADONNX::inference of loop_cam.cpp:609-616 from one upload on two streams:
+    bit-identical to the separate calls, for one image and for a stereo pair with NetVLAD on the left image only, call after call
+    (plain, graph capture, graph replay)."""
+    from d2slam_amd import netvlad as nvm
+    H, W = 240, 320
+    fe = _fe(api, H, W, 2, api.PREC_F32_WINO, max_kp=150)
+    fe.load_superpoint(sp_weights); fe.load_netvlad(nvm.synthetic_netvlad_weights())
+    pair = np.stack(synth_stereo(H, W, seed=12))
+    sep = fe.extract_batch(pair, cap=150); gsep = fe.netvlad(pair[:1])
+    for it in range(4):
+        outs, g = fe.extract_all_batch(pair, 1, cap=150)
+        assert g.shape == (1, fe.netvlad_dim) and np.array_equal(g, gsep), it
+        for (k0, s0, d0), (k1, s1, d1) in zip(sep, outs):
+            assert np.array_equal(k0, k1) and np.array_equal(s0, s1) and np.array_equal(d0, d1), it
+    one = fe.extract_batch(pair[1:], cap=150); gone = fe.netvlad(pair[1:])
+    for it in range(3):
+        outs, g = fe.extract_all_batch(pair[1:], 1, cap=150)
+        assert np.array_equal(g, gone) and np.array_equal(outs[0][0], one[0][0]) and np.array_equal(outs[0][2], one[0][2])
+    outs, g = fe.extract_all_batch(pair, 2, cap=150)                 # NetVLAD on both
+    assert np.array_equal(g, fe.netvlad(pair))
+    with pytest.raises(api.D2FEError):
+        fe.extract_all_batch(pair, 3, cap=150)                       # more NetVLAD images than images
+    fe.close()
+
+
 def test_matcher_is_reentrant(api, orc):
     """The reference calls matchKNN from three threads (D2FeatureTracker, LoopDetector, remote tracking).
     Four threads hammer d2fe_match_knn / d2fe_match_crosscheck on one handle (ctypes releases the GIL): every result must equal
