@@ -107,11 +107,12 @@ struct d2fe_context {
   std::vector<NvLayer> nv;
   // execution plan over the flat layer list: fused MobileNetV2 blocks (netvlad_fused.hip) where the pattern matches, single layers otherwise;
   // only the LAST layer of a step is materialised in HBM (NvLayer::out), everything inside a fused block lives in LDS
-  struct NvStep { int l0 = 0, l1 = 0; bool fused = false, expand = false, front = false, tail = false, xblock = false; float* we = nullptr; float* wp = nullptr; float* bp = nullptr; float* w0 = nullptr; };
+  struct NvStep { int l0 = 0, l1 = 0; bool fused = false, expand = false, front = false, tail = false, xblock = false, pblock = false; float* we = nullptr; float* wp = nullptr; float* bp = nullptr; float* w0 = nullptr; };
   int nv_feat_gmax = 1, nv_feat_slabs = 1; long nv_feat_slab_stride = 0;
   // scheduling knobs of the fused plan, read from the environment by d2fe_load_netvlad (A/B measurements; defaults measured best):
   // workgroups per launch the hidden-channel split aims at (D2FE_NV_BLOCKS), the same for the tail kernel (D2FE_NV_TAIL_BLOCKS),
   // and the number of partial slabs from which they are summed once instead of by every consumer (D2FE_NV_SLABSUM, 0 = never)
+  int nv_stamp_step = -1; unsigned long long* nv_stamps = nullptr; int nv_stamp_wgs = 0;     // D2FE_NV_STAMP_STEP (diagnostics)
   int nv_blocks_target = 512, nv_tail_blocks = 768, nv_slabsum = 3;      // the pre-projected features (input of the VLAD stage), same slab scheme
   std::vector<NvStep> nv_plan;
   bool nv_loaded = false;
@@ -840,6 +841,7 @@ void nv_free(d2fe_context* h) {
   h->nv_plan.clear();
   for (float** p : {&h->nv_pre_w, &h->nv_pre_b, &h->nv_aw, &h->nv_aw_pack, &h->nv_ab, &h->nv_cen, &h->nv_feat_buf, &h->nv_raw, &h->nv_pca_out, &h->nv_part})
     if (*p) { hipFree(*p); *p = nullptr; }
+  if (h->nv_stamps) { hipFree(h->nv_stamps); h->nv_stamps = nullptr; }
   h->nv_loaded = false;
 }
 inline int same_out(int in, int stride) { return (in + stride - 1) / stride; }
@@ -847,8 +849,9 @@ inline int same_pad_begin(int in, int stride, int out) { const int t = (out - 1)
 
 // hidden-channel groups for a fused step: enough workgroups to fill the chip (2 per CU), at least 4 chunks of 16 per group (every
 // group stages the whole input patch again, and its consumer reads one more partial slab)
-inline void nv_groups(long base_blocks, int nchunk, int gmax, int* groups, int* cpg, int target) {
+inline void nv_groups(long base_blocks, int nchunk, int gmax, int* groups, int* cpg, int target, long cap = 0) {
   int g = (int)((target + base_blocks - 1) / base_blocks);
+  if (cap > 0 && g > 1 && g * base_blocks > cap) --g;      // a second round of workgroups costs more than one more chunk per group
   if (g > gmax) g = gmax;
   if (g > nchunk / 4) g = nchunk / 4;
   if (g < 1) g = 1;
@@ -864,6 +867,8 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
   for (size_t si = 0; si < h->nv_plan.size(); ++si) {
     const auto& st = h->nv_plan[si];
     const bool next_fused = si + 1 < h->nv_plan.size() && h->nv_plan[si + 1].fused;
+    // nv_xblock_kernel (stride-2 blocks) and nv_tail_kernel read ONE input slab: their producer's partial slabs are summed first
+    const bool next_single = next_fused && ((h->nv_plan[si + 1].xblock && !h->nv_plan[si + 1].pblock) || h->nv_plan[si + 1].tail);
     if (!st.fused) {
       auto& l = h->nv[st.l0];
       const float* in = st.l0 ? h->nv[st.l0 - 1].out : nullptr;
@@ -921,16 +926,25 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     a.wp = st.wp; a.bp = st.bp; a.act_p = pj.act;
     if (pj.res >= 0) { const auto& r = h->nv[pj.res]; a.res = r.out; a.res_slabs = r.slabs; a.res_slab_stride = r.slab_stride; }
     a.th = 8; a.tw = 16;
-    if (st.xblock) nv_xblock_tile(a.Ho, a.Wo, a.stride, &a.th, &a.tw);
+    if (st.pblock) nv_pblock_tile(a.Ho, a.Wo, &a.th, &a.tw);
+    else if (st.xblock) nv_xblock_tile(a.Ho, a.Wo, a.stride, &a.th, &a.tw);
     const long tiles = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th) * n;
     // partial slabs are summed by the consumer's staging: only when that consumer is a fused step
-    nv_groups(tiles, a.Chid / 16, next_fused ? pj.gmax : 1, &groups, &cpg, h->nv_blocks_target);
+    // pixel-pair kernel: no more workgroups than 85 % of what the device holds at once (registers / LDS of that block shape)
+    nv_groups(tiles, a.Chid / 16, next_fused ? pj.gmax : 1, &groups, &cpg, h->nv_blocks_target,
+              st.pblock ? nv_pblock_slots(a.Cin, a.Cout, h->ncu, 1) * 85 / 100 : 0);
     a.cpg = cpg; a.out = pj.out; a.out_slab_stride = (long)n * a.Ho * a.Wo * a.Cout;
     pj.slabs = groups; pj.slab_stride = a.out_slab_stride;
-    if (st.xblock) HIP_TRY(launch_nv_xblock(a, n, groups, s));
+    a.ncu = h->ncu;
+    if ((int)si == h->nv_stamp_step && h->nv_stamps && tiles * groups <= 8192) {
+      HIP_TRY(hipMemsetAsync(h->nv_stamps, 0, sizeof(unsigned long long) * 32 * 8192, s));
+      a.stamps = h->nv_stamps; h->nv_stamp_wgs = (int)(tiles * groups);
+    }
+    if (st.pblock) HIP_TRY(launch_nv_pblock(a, n, groups, s));
+    else if (st.xblock) HIP_TRY(launch_nv_xblock(a, n, groups, s));
     else HIP_TRY(launch_nv_block(a, st.expand, st.front ? 1 : 0, n, groups, s));
     // three or more partial slabs: sum them once instead of in every consumer workgroup (and in every residual read)
-    if (h->nv_slabsum > 0 && groups >= h->nv_slabsum) { HIP_TRY(launch_nv_slab_sum(pj.out, groups, pj.slab_stride, pj.slab_stride, s)); pj.slabs = 1; }
+    if ((h->nv_slabsum > 0 && groups >= h->nv_slabsum) || (next_single && groups > 1)) { HIP_TRY(launch_nv_slab_sum(pj.out, groups, pj.slab_stride, pj.slab_stride, s)); pj.slabs = 1; }
     ch = a.Ho; cw = a.Wo;
   }
   const int np = ch * cw;
@@ -1011,6 +1025,10 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
     if (const char* v = getenv("D2FE_NV_BLOCKS")) { if (atoi(v) > 0) h->nv_blocks_target = atoi(v); }
     if (const char* v = getenv("D2FE_NV_TAIL_BLOCKS")) { if (atoi(v) > 0) h->nv_tail_blocks = atoi(v); }
     if (const char* v = getenv("D2FE_NV_SLABSUM")) h->nv_slabsum = atoi(v);
+    if (const char* v = getenv("D2FE_NV_STAMP_STEP")) {
+      h->nv_stamp_step = atoi(v);
+      if (!h->nv_stamps) HIP_TRY(hipMalloc(&h->nv_stamps, sizeof(unsigned long long) * 32 * 8192));
+    }
     const int nl = w->n_layers;
     auto K = [&](int i) { return i < nl ? h->nv[i].kind : -1; };
     std::vector<char> materialised(nl, 0);
@@ -1026,7 +1044,10 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
                    nv_block_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride, true, 0)) {
           st.fused = true; st.expand = true; st.l1 = i + 2;
           { const char* x = getenv("D2FE_NV_XBLOCK");      // input-in-registers form of the block (default on; 0: the LDS-resident form)
-            st.xblock = !(x && atoi(x) == 0) && nv_xblock_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride); }
+            st.xblock = !(x && atoi(x) == 0) && nv_xblock_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride);
+            // stride 1: the pixel-pair form of the same block (netvlad_pair.hip; D2FE_NV_PAIR=0: nv_xblock_kernel)
+            const char* pq = getenv("D2FE_NV_PAIR");
+            st.pblock = st.xblock && !(pq && atoi(pq) == 0) && nv_pblock_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride); }
         } else if (i > 0 && K(i) == D2FE_NV_DW && K(i + 1) == D2FE_NV_PW &&
                    nv_block_supported(h->nv[i].cin, h->nv[i].cin, h->nv[i + 1].cout, h->nv[i].stride, false, 0)) {
           st.fused = true; st.l1 = i + 1;
@@ -1051,6 +1072,7 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
           const d2fe_nv_layer& E = w->layers[li++];
           std::vector<float> pk(pack_nv_expand_floats(E.cout, E.cin));
           if (st.tail && nv_tail_supported(E.cin, w->proj_dim)) pack_nv_expand_tail(E.weight, E.bias, E.cout, E.cin, pk.data());
+          else if (st.pblock) { pk.assign(pack_nv_expand_pair_floats(E.cout, E.cin), 0.f); pack_nv_expand_pair(E.weight, E.bias, E.cout, E.cin, pk.data()); }
           else if (st.xblock) { pk.assign(pack_nv_expand_perm_floats(E.cout, E.cin), 0.f); pack_nv_expand_perm(E.weight, E.bias, E.cout, E.cin, pk.data()); }
           else pack_nv_expand(E.weight, E.bias, E.cout, E.cin, pk.data());
           const int rc = upload(pk.data(), pk.size() * sizeof(float), reinterpret_cast<void**>(&st.we));
@@ -1061,8 +1083,9 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
         const float* pbs = st.tail ? w->pre_b : w->layers[li + 1].bias;
         const int pco = st.tail ? w->proj_dim : w->layers[li + 1].cout, pci = st.tail ? w->feat_dim : w->layers[li + 1].cin;
         const int nt = nv_block_ntiles(pco);
-        std::vector<float> pk(pack_nv_dwproj_floats(pci, nt)), pb(nt * 16, 0.f);
-        pack_nv_dwproj(st.tail ? nullptr : w->layers[li].weight, st.tail ? nullptr : w->layers[li].bias, pwt, pco, pci, nt, pk.data());
+        std::vector<float> pk(st.pblock ? pack_nv_dwproj_pair_floats(pci, nt) : pack_nv_dwproj_floats(pci, nt)), pb(nt * 16, 0.f);
+        if (st.pblock) pack_nv_dwproj_pair(w->layers[li].weight, w->layers[li].bias, pwt, pco, pci, nt, pk.data());
+        else pack_nv_dwproj(st.tail ? nullptr : w->layers[li].weight, st.tail ? nullptr : w->layers[li].bias, pwt, pco, pci, nt, pk.data());
         for (int co = 0; co < pco; ++co) pb[co] = pbs[co];
         h->nv_plan.push_back(st);
         auto& ds = h->nv_plan.back();
@@ -1111,6 +1134,17 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
   h->nv_loaded = true;
   guard.ok = true;
   return D2FE_OK;
+}
+
+/* diagnostics: with D2FE_NV_STAMP_STEP=<plan step> set at d2fe_load_netvlad() time, the wall_clock64() phase stamps [workgroup][32] that step's
+ * nv_xblock_kernel wrote during the last d2fe_netvlad* call; returns the number of workgroups (tools/nv_stamps.py). */
+long d2fe_debug_netvlad_stamps(d2fe_handle h, unsigned long long* dst, long max_wgs) {
+  if (!h || !dst || !h->nv_stamps) return fail(D2FE_ERR_NOT_READY, "D2FE_NV_STAMP_STEP was not set when the network was loaded");
+  hipSetDevice(h->cfg.device_id);
+  const long nw = std::min<long>(max_wgs, h->nv_stamp_wgs);
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(dst, h->nv_stamps, sizeof(unsigned long long) * 32 * nw, hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(D2FE_ERR_HIP, "D2H");
+  return nw;
 }
 
 /* test hook: the output of layer `layer` of the loaded network for the last d2fe_netvlad* call (NHWC fp32), if the execution plan

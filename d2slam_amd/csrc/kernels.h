@@ -120,6 +120,8 @@ struct NvBlockArgs {
   const float* wp;                    // depthwise weights + bias + project weights, one record per chunk (pack_nv_dwproj)
   const float* bp;                    // project bias [Cout padded to the n-tiles]
   int act_e, act_d, act_p;
+  int ncu;                            // compute units of the device (launch heuristics; 0: 256)
+  unsigned long long* stamps;         // diagnostics (D2FE_NV_STAMP_STEP): [workgroup][32] wall_clock64() phase stamps, or null
 };
 bool nv_block_supported(int cin, int chid, int cout, int stride, bool expand, int mode);
 int nv_block_ntiles(int cout);
@@ -137,6 +139,15 @@ void nv_xblock_tile(int Ho, int Wo, int stride, int* th, int* tw);
 size_t pack_nv_expand_perm_floats(int chid, int cin);
 void pack_nv_expand_perm(const float* w, const float* b, int chid, int cin, float* dst);
 hipError_t launch_nv_xblock(const NvBlockArgs& a, int n, int groups, hipStream_t s);
+// stride-1 expand blocks, depthwise stage on horizontal pixel pairs (netvlad_pair.hip)
+bool nv_pblock_supported(int cin, int chid, int cout, int stride);
+void nv_pblock_tile(int Ho, int Wo, int* th, int* tw);
+size_t pack_nv_expand_pair_floats(int chid, int cin);
+void pack_nv_expand_pair(const float* w, const float* b, int chid, int cin, float* dst);
+size_t pack_nv_dwproj_pair_floats(int chid, int nt);
+void pack_nv_dwproj_pair(const float* wd, const float* bd, const float* wp, int cout, int chid, int nt, float* dst);
+hipError_t launch_nv_pblock(const NvBlockArgs& a, int n, int groups, hipStream_t s);
+long nv_pblock_slots(int cin, int cout, int ncu, int nbuf);     // resident workgroups of that block shape on the whole device
 hipError_t launch_nv_slab_sum(float* t, int slabs, long slab_stride, long count, hipStream_t s);   // slab 0 += slabs 1..
 void pack_nv_conv0(const float* w /*[cout][9]*/, const float* b, int cout, float* dst /*[384]*/);
 

@@ -393,6 +393,45 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
   const int iy0 = oy0 * S - a.pt, ix0 = ox0 * S - a.pl;
   const int nchunk = a.Chid >> 4;
   const int ch0 = blockIdx.z * a.cpg, ch1 = min(nchunk, ch0 + a.cpg);
+  unsigned long long* stamp = a.stamps ? a.stamps + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 : nullptr;
+  int stamp_i = 0;
+  auto STAMP = [&]() { if (stamp && tid == 0 && stamp_i < 32) stamp[stamp_i] = wall_clock64(); ++stamp_i; };
+  STAMP();
+  // the project bias and the residual, first thing in the kernel instead of in the epilogue where their latency has nothing to hide behind
+  // (NT = 8: no registers for it)
+  const bool lead = blockIdx.z == 0;
+  const int Cout = a.Cout;
+  const float* rp = (a.res && lead) ? a.res + (size_t)n * a.Ho * a.Wo * Cout : nullptr;
+  constexpr bool RES_EARLY = NT <= 4 && S == 1;        // a stride-2 block has no residual (shapes differ)
+  float resv[2][4][RES_EARLY ? NT : 1], res1[2][4][RES_EARLY ? NT : 1], bvv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bvv[t] = a.bp[t * 16 + lp];           // padded to the n-tiles by the host
+  if (RES_EARLY && rp) {
+    int rb[2][4];
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = (wave * 2 + m2) * 16 + lq * 4 + r;
+        const int oy = (int)(((unsigned)q * a.inv_tw) >> 20), ox = q - oy * tw;
+        const int gy = oy0 + oy, gx = ox0 + ox;
+        rb[m2][r] = (q < th * tw && gy < a.Ho && gx < a.Wo) ? (gy * a.Wo + gx) * Cout + lp : -1;
+      }
+    auto batch = [&](float (&dst)[2][4][RES_EARLY ? NT : 1], int sl, bool add) {
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int t = 0; t < (RES_EARLY ? NT : 1); ++t) {
+            const float v = rp[(size_t)sl * a.res_slab_stride + ((rb[m2][r] >= 0 && t * 16 + lp < Cout) ? rb[m2][r] + t * 16 : 0)];
+            dst[m2][r][t] = add ? dst[m2][r][t] + v : v;
+          }
+    };
+    batch(resv, 0, false);
+    if (a.res_slabs > 1) batch(res1, 1, false);
+    for (int sl = 2; sl < a.res_slabs; ++sl) batch(res1, sl, true);
+  }
   float wes[WER], wds[WDR];
   // weight records travel global -> registers -> LDS; the loads for chunk ch + 2 are issued right after the registers holding chunk
   // ch + 1 have been written to LDS, so a full chunk of work covers their L2 latency (a chunk's MFMA time is ~0.5 us, a miss ~1-2 us)
@@ -419,10 +458,12 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
   if (ch0 < ch1) { fetch_we(ch0); fetch_wd(ch0); }
 
   // ---- the wave's MPW patch m-tiles: pixel mt*16 + lp, channels (lq + 4 j) * 4 .. + 3, summed over the producer's partial slabs ----
+  // Every global load of the prologue is issued before anything waits on one, in batches per slab: a run-time loop over the partial slabs
+  // around each load costs one memory round trip per iteration (tools/nv_stamps.py: 3 us of prologue, 3 us of epilogue per workgroup).
   f32x4 xr[MPW][NJ];
   float one[MPW];
   {
-    const float* ip = a.in + (size_t)n * a.H * a.W * Cin;
+    const float* ip = a.in + (size_t)n * a.H * a.W * Cin;        // one slab (the launcher rejects a split input: run_netvlad sums the slabs first)
 #pragma unroll
     for (int m = 0; m < MPW; ++m) {
       const int p = (wave + 4 * m) * 16 + lp;
@@ -430,16 +471,9 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
       const int gy = iy0 + iy, gx = ix0 + ix;
       const bool ok = p < npx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       one[m] = ok ? 1.f : 0.f;
-      const float* src = ip + (ok ? (gy * a.W + gx) * Cin : 0) + lq * 4;
+      const float* src = ip + (ok ? (gy * a.W + gx) * Cin : 0);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok && (lq + 4 * j) * 4 < Cin) {
-          v = *reinterpret_cast<const f32x4*>(src + j * 16);
-          for (int sl = 1; sl < a.in_slabs; ++sl) v += *reinterpret_cast<const f32x4*>(src + (size_t)sl * a.in_slab_stride + j * 16);
-        }
-        xr[m][j] = v;
-      }
+      for (int j = 0; j < NJ; ++j) xr[m][j] = *reinterpret_cast<const f32x4*>(src + ((lq + 4 * j) * 4 < Cin ? (lq + 4 * j) * 4 : 0));
     }
   }
   // ---- the wave's two output m-tiles (flat index q = (2 wave + m2) * 16 + lp over the th x tw tile) -> patch pixel of tap (0,0) ----
@@ -450,9 +484,12 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
     const int oy = (int)(((unsigned)q * a.inv_tw) >> 20), ox = q - oy * tw;
     ebase[m2] = q < th * tw ? (oy * S) * iw + ox * S : 0;
   }
+  STAMP();
   if (ch0 < ch1) { store_we(0); store_wd(0); }
   if (ch0 + 1 < ch1) { fetch_we(ch0 + 1); fetch_wd(ch0 + 1); }
+  STAMP();
   __syncthreads();
+  STAMP();
 
   f32x4 acc[2][NT];
 #pragma unroll
@@ -460,6 +497,19 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float lo_e = nvf_lo(a.act_e), hi_e = nvf_hi(a.act_e), lo_d = nvf_lo(a.act_d), hi_d = nvf_hi(a.act_d);
+  if (RES_EARLY && rp && a.res_slabs > 1) {
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < (RES_EARLY ? NT : 1); ++t) resv[m2][r][t] += res1[m2][r][t];
+  }
+#pragma unroll
+  for (int m = 0; m < MPW; ++m)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (!(one[m] != 0.f && (lq + 4 * j) * 4 < Cin)) xr[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int ch = ch0; ch < ch1; ++ch) {
     const int wb_i = (ch - ch0) & 1;
@@ -495,9 +545,12 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
         else { e[0] = o[0]; e[1] = o[1]; e[2] = o[2]; e[3] = o[3]; }
       }
     }
+    STAMP();
     if (ch + 1 < ch1) store_we(wb_i ^ 1);              // WE[wb_i ^ 1] was last read by the previous chunk's expand stage
     if (ch + 2 < ch1) fetch_we(ch + 2);
+    STAMP();
     __syncthreads();
+    STAMP();
     const float* wd = WD + wb_i * WD_N;
     const float* wpl = wd + 256 + lane;
     // depthwise: two hidden channels (k-steps 2 kp, 2 kp + 1) of one pixel as the halves of v_pk_fma_f32 (see nv_block_kernel); three row
@@ -529,15 +582,14 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
           acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1[h], wv, acc[1][t], 0, 0, 0);
         }
     }
+    STAMP();
     if (ch + 1 < ch1) store_wd(wb_i ^ 1);              // WD[wb_i ^ 1]: everybody passed this chunk's barrier, so chunk ch - 1 is done with it
     if (ch + 2 < ch1) fetch_wd(ch + 2);
+    STAMP();
   }
 
   // ---- epilogue: C row = pixel q = (2 wave + m2) * 16 + 4 lq + r of the flat tile, col = channel lp of n-tile t ----------------------
-  const bool lead = blockIdx.z == 0;
-  const int Cout = a.Cout;
   float* op = a.out + (size_t)blockIdx.z * a.out_slab_stride + (size_t)n * a.Ho * a.Wo * Cout;
-  const float* rp = (a.res && lead) ? a.res + (size_t)n * a.Ho * a.Wo * Cout : nullptr;
   const float lo_p = nvf_lo(a.act_p), hi_p = nvf_hi(a.act_p);
 #pragma unroll
   for (int m2 = 0; m2 < 2; ++m2) {
@@ -552,12 +604,14 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
       for (int t = 0; t < NT; ++t) {
         if (t * 16 + lp >= Cout) continue;
         const int o = base + t * 16;
-        float v = acc[m2][t][r] + (lead ? a.bp[t * 16 + lp] : 0.f);
-        if (rp) { for (int sl = 0; sl < a.res_slabs; ++sl) v += rp[(size_t)sl * a.res_slab_stride + o]; }
+        float v = acc[m2][t][r] + (lead ? bvv[t] : 0.f);
+        if constexpr (RES_EARLY) { if (rp) v += resv[m2][r][t]; }
+        else if (rp) { for (int sl = 0; sl < a.res_slabs; ++sl) v += rp[(size_t)sl * a.res_slab_stride + o]; }
         op[o] = nvf_clamp(v, lo_p, hi_p);
       }
     }
   }
+  STAMP();
 }
 
 // tile shape for a th x tw <= 128 pixel output tile whose patch fits the kernel's m-tiles: maximise the useful fraction of the MFMA rows
@@ -621,7 +675,7 @@ static hipError_t launch_xblock_nt(const NvBlockArgs& a, int n, int groups, hipS
 hipError_t launch_nv_xblock(const NvBlockArgs& a_in, int n, int groups, hipStream_t s) {
   NvBlockArgs a = a_in;
   const int iw = (a.tw - 1) * a.stride + 3;
-  if (a.tw < 1 || a.tw > 128 || iw > 1024) return hipErrorInvalidValue;
+  if (a.tw < 1 || a.tw > 128 || iw > 1024 || a.in_slabs > 1) return hipErrorInvalidValue;
   a.inv_iw = ((1u << 20) + iw - 1) / iw; a.inv_tw = ((1u << 20) + a.tw - 1) / a.tw;     // exact for n < 2^20 / d: n < 1024 here
   if ((long)a.H * a.W * a.Cin >= (1l << 31) || (long)a.Ho * a.Wo * a.Cout >= (1l << 31)) return hipErrorInvalidValue;
   const int nj = nv_xblock_nj(a.Cin);
@@ -686,8 +740,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float* src = a.in + (ok ? p * CIN : 0) + lq * 4;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(src + j * 16);
-      for (int sl = 1; sl < a.in_slabs; ++sl) v += *reinterpret_cast<const f32x4*>(src + (size_t)sl * a.in_slab_stride + j * 16);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + j * 16);        // one slab (launch_nv_tail rejects a split input)
       xr[mt][j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
@@ -771,7 +824,7 @@ void pack_nv_expand_tail(const float* w /*[chid][cin]*/, const float* b, int chi
 }
 bool nv_tail_supported(int cin, int cout) { return (cin == 112 || cin == 128) && nv_block_ntiles(cout) == 8; }
 hipError_t launch_nv_tail(const NvBlockArgs& a, int groups, hipStream_t s) {
-  if (a.P * (long)std::max(a.Cin, a.Cout) >= (1l << 31)) return hipErrorInvalidValue;
+  if (a.P * (long)std::max(a.Cin, a.Cout) >= (1l << 31) || a.in_slabs > 1) return hipErrorInvalidValue;
   const size_t lds = sizeof(float) * (2 * (size_t)nvb_we_rec(a.Cin) + 2 * (size_t)nvb_wd_rec(8) + 4 * 16 * 48);
   auto k = a.Cin == 112 ? nv_tail_kernel<7, 8> : nv_tail_kernel<8, 8>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1,0 +1,448 @@
+// netvlad_pair.hip -- stride-1 MobileNetV2 inverted-residual block (pw expand -> dw 3x3 -> pw project (+ residual)) of the NetVLAD trunk, one kernel
+// per block, organised around the LDS traffic of the depthwise stage (gfx950).  Reference boundary: MobileNetVLADONNX::inference,
+// d2frontend/include/d2frontend/CNN/mobilenetvlad_onnx.h:49-74 (one ONNX Runtime session run); the layer list is whatever d2fe_load_netvlad() got.
+//
+// Same data flow as nv_xblock_kernel (netvlad_fused.hip): block input in registers, the expanded tensor 16 hidden channels at a time through LDS,
+// project accumulators in registers.  What the phase stamps of that kernel showed (tools/nv_stamps.py, profiles/r03_netvlad_stamps.txt): a chunk costs
+// 3.1 us, 2.0 of them in depthwise + project, where every wave issues 128 ds_read_b32 (72 for the 3x3 windows, 40 depthwise weights, 16 project
+// B fragments) with a third of the LDS cycles lost to bank conflicts -- the LDS pipe of the CU, shared by ~10 waves, is the limit, not the matrix
+// or vector pipes.  Here:
+//   * a lane owns two horizontally adjacent output pixels (2 px, 2 px + 1) of one hidden channel: the 4 input columns both windows cover are two
+//     aligned ds_read_b64 per window row (24 per chunk and wave instead of 72 ds_read_b32), and the pair is the two halves of v_pk_fma_f32;
+//     even pixels feed the wave's first project m-tile, odd pixels the second
+//   * E rows (one per hidden channel of the chunk, 256-float pitch) start at bank 4 (c & 7) + 32 (c >> 3): the expand stage's ds_write_b128 (8-lane
+//     groups = 8 channels) lands on 8 distinct 16-byte slots, and the two channels c, c + 8 that the lane groups of one 32-lane half read
+//     are exactly half a bank row (32 of 64 banks) apart -- hidden channel of k-step ks for lane group lq: ks + 4 (lq >> 1) + 8 (lq & 1)
+//   * depthwise weights [lane group][k-step][12] and project B fragments [k-step][lane][n-tiles] are read as ds_read_b128 / b64
+//   * the expand GEMM walks exactly Cin / 4 k-steps (lane group lq holds input channels lq Cin/4 ..): no zero rows for Cin = 8, 24, 56; its bias
+//     is the accumulator's initial value (bias x in-image mask in the C layout) instead of one more k-step
+//   * the residual is read first thing in the kernel, not in the epilogue
+#include <algorithm>
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace d2fe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+__device__ __forceinline__ float nvp_lo(int act) { return act >= 1 ? 0.f : -__builtin_inff(); }
+__device__ __forceinline__ float nvp_hi(int act) { return act == 2 ? 6.f : __builtin_inff(); }
+__device__ __forceinline__ float nvp_clamp(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+}  // namespace
+
+constexpr int NVP_EROW = 256, NVP_EBUF = 16 * NVP_EROW, NVP_PATCH = 192;      // patch pixels = 12 m-tiles, 3 per wave
+__host__ __device__ constexpr int nvp_we_rec(int nk) { return (nk * 64 + 16 + 255) / 256 * 256; }      // [nk/4][lane][4] (+ [lane][2]) + bias[16]
+__host__ __device__ constexpr int nvp_wd_rec(int nt) { return 256 + nt * 256; }                         // [lq][ks][12] + pad, [ks][nt/ntv][lane][ntv]
+__host__ __device__ constexpr int nvp_row(int c) { return c * NVP_EROW + 4 * (c & 7) + 32 * (c >> 3); }
+
+// waves per SIMD the register allocation must leave room for (unified VGPR + AGPR file, 512 per lane): what the launches of this network need to be
+// resident in ONE round -- 640 workgroups of <2, 8> on 256 CUs need 3 per CU, 1280 of <1, 4> need 5; left alone the compiler settles for 2 and 4
+__host__ __device__ constexpr int nvp_min_waves(int nt, int nk) { return nt == 1 ? 5 : nt == 2 ? 3 : 2; }
+template <int NT, int NK, int NBUF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_waves(NT, NK)))) void nv_pblock_kernel(NvBlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WE_N = nvp_we_rec(NK), WD_N = nvp_wd_rec(NT), WER = WE_N / 256, WDR = WD_N / 256;
+  constexpr int NK4 = NK / 4, NK2 = (NK % 4) / 2;
+  constexpr int NTV = NT < 4 ? NT : 4, NTH = NT / NTV;
+  static_assert(NK % 2 == 0, "Cin must be a multiple of 8");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane >> 4, lp = lane & 15;
+  float* E = lds;                         // [NBUF][16 rows, NVP_EROW pitch, swizzled starts]
+  float* WE = E + NBUF * NVP_EBUF;        // [2][WE_N]
+  float* WD = WE + 2 * WE_N;              // [2][WD_N]
+  const int Cin = a.Cin, Cout = a.Cout, th = a.th, tw = a.tw, pw = tw >> 1;
+  const int iw = tw + 2, npx = (th + 2) * iw;
+  const int tiles_x = (a.Wo + tw - 1) / tw;
+  const int n = blockIdx.y;
+  const int ty = (int)blockIdx.x / tiles_x;
+  const int oy0 = ty * th, ox0 = ((int)blockIdx.x - ty * tiles_x) * tw;
+  const int iy0 = oy0 - a.pt, ix0 = ox0 - a.pl;
+  const int nchunk = a.Chid >> 4;
+  const int ch0 = blockIdx.z * a.cpg, ch1 = min(nchunk, ch0 + a.cpg);
+  const bool lead = blockIdx.z == 0;
+  unsigned long long* stamp = a.stamps ? a.stamps + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 : nullptr;
+  int stamp_i = 0;
+  auto STAMP = [&]() { if (stamp && tid == 0 && stamp_i < 32) stamp[stamp_i] = wall_clock64(); ++stamp_i; };
+  STAMP();
+
+  // ---- residual (hidden-channel group 0 only): C layout of the project accumulators, row = pair 16 wave + 4 lq + r, pixel 2 px + m2 ----------
+  const float* rp = (a.res && lead) ? a.res + (size_t)n * a.Ho * a.Wo * Cout : nullptr;
+  constexpr bool RES_EARLY = NT <= 4;
+  float resv[2][4][RES_EARLY ? NT : 1];
+  int obase[4];                 // element offset of (pixel of pair r, m2 = 0, channel lp), or -1
+  bool ok2[4];                  // the pair's odd pixel is inside the output too
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int P = wave * 16 + lq * 4 + r;
+    const int oy = (int)(((unsigned)P * a.inv_tw) >> 20), px = P - oy * pw;
+    const int gy = oy0 + oy, gx = ox0 + 2 * px;
+    const bool okp = P < th * pw && gy < a.Ho && gx < a.Wo;
+    obase[r] = okp ? (gy * a.Wo + gx) * Cout + lp : -1;
+    ok2[r] = okp && gx + 1 < a.Wo;
+  }
+  // every global load of the prologue is issued before anything waits on one: batches per slab, no load inside a run-time loop (a loop over the
+  // slabs around each load costs one memory round trip per iteration -- 6 us of the old kernel's prologue + epilogue)
+  float bvv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bvv[t] = a.bp[t * 16 + lp];           // padded to the n-tiles by the host
+  float r1[2][4][RES_EARLY ? NT : 1];
+  if (RES_EARLY && rp) {
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < (RES_EARLY ? NT : 1); ++t) {
+          const bool okr = obase[r] >= 0 && (m2 == 0 || ok2[r]) && t * 16 + lp < Cout;
+          resv[m2][r][t] = rp[okr ? (unsigned)(obase[r] + m2 * Cout + t * 16) : 0u];
+        }
+    if (a.res_slabs > 1) {
+      const float* rp1 = rp + a.res_slab_stride;          // uniform bases + 32-bit lane offsets: no 64-bit address pair per load
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int t = 0; t < (RES_EARLY ? NT : 1); ++t) {
+            const bool okr = obase[r] >= 0 && (m2 == 0 || ok2[r]) && t * 16 + lp < Cout;
+            r1[m2][r][t] = rp1[okr ? (unsigned)(obase[r] + m2 * Cout + t * 16) : 0u];
+          }
+      for (int sl = 2; sl < a.res_slabs; ++sl)
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < (RES_EARLY ? NT : 1); ++t) {
+              const bool okr = obase[r] >= 0 && (m2 == 0 || ok2[r]) && t * 16 + lp < Cout;
+              r1[m2][r][t] += (rp + (size_t)sl * a.res_slab_stride)[okr ? (unsigned)(obase[r] + m2 * Cout + t * 16) : 0u];
+            }
+    }
+  }
+
+  // ---- weights: global -> registers -> LDS double buffers, two chunks ahead (as nv_xblock_kernel) ---------------------------------------
+  float wes[WER], wds[WDR];
+  auto fetch_we = [&](int ch) {
+    const float* wb = a.we + (size_t)ch * WE_N + tid;
+#pragma unroll
+    for (int i = 0; i < WER; ++i) wes[i] = wb[256 * i];
+  };
+  auto fetch_wd = [&](int ch) {
+    const float* wc = a.wp + (size_t)ch * WD_N + tid;
+#pragma unroll
+    for (int i = 0; i < WDR; ++i) wds[i] = wc[256 * i];
+  };
+  auto store_we = [&](int buf) {
+    float* wl = WE + buf * WE_N + tid;
+#pragma unroll
+    for (int i = 0; i < WER; ++i) wl[256 * i] = wes[i];
+  };
+  auto store_wd = [&](int buf) {
+    float* wm = WD + buf * WD_N + tid;
+#pragma unroll
+    for (int i = 0; i < WDR; ++i) wm[256 * i] = wds[i];
+  };
+  if (ch0 < ch1) { fetch_we(ch0); fetch_wd(ch0); }
+
+  // ---- input: the wave's 3 patch m-tiles, pixel mt*16 + lp, channels lq*NK .. lq*NK + NK - 1, summed over the producer's partial slabs ------
+  float xr[3][NK];
+  f32x4 maskc[3];               // C layout: pixel mt*16 + 4 lq + r is inside the image
+  constexpr int LW = NK % 4 == 0 ? 4 : 2;          // lq * NK floats is 16-byte aligned only when NK is a multiple of 4
+  auto ldx = [&](float* dst, const float* base, unsigned off) {        // uniform base + 32-bit lane offset
+    if constexpr (LW == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(base + off); dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
+    else { const f32x2 v = *reinterpret_cast<const f32x2*>(base + off); dst[0] = v[0]; dst[1] = v[1]; }
+  };
+  bool okm[3]; unsigned offm[3];
+  const float* ip = a.in + (size_t)n * a.H * a.W * Cin;
+  float x1[3][NK];
+  {
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int p = (wave + 4 * m) * 16 + lp;
+      const int iy = (int)(((unsigned)p * a.inv_iw) >> 20), ix = p - iy * iw;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      const bool ok = p < npx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      okm[m] = ok; offm[m] = (unsigned)((ok ? (gy * a.W + gx) * Cin : 0) + lq * NK);
+#pragma unroll
+      for (int s = 0; s < NK; s += LW) ldx(xr[m] + s, ip, offm[m] + s);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int pc = (wave + 4 * m) * 16 + lq * 4 + r;
+        const int cy = (int)(((unsigned)pc * a.inv_iw) >> 20), cx = pc - cy * iw;
+        const int hy = iy0 + cy, hx = ix0 + cx;
+        maskc[m][r] = (pc < npx && hy >= 0 && hy < a.H && hx >= 0 && hx < a.W) ? 1.f : 0.f;
+      }
+    }
+    if (a.in_slabs > 1) {
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int s = 0; s < NK; s += LW) ldx(x1[m] + s, ip + a.in_slab_stride, offm[m] + s);
+      for (int sl = 2; sl < a.in_slabs; ++sl)
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+          for (int s = 0; s < NK; s += LW) { float t[LW]; ldx(t, ip + (size_t)sl * a.in_slab_stride, offm[m] + s); for (int e = 0; e < LW; ++e) x1[m][s + e] += t[e]; }
+    }
+  }
+  // ---- depthwise: pair P = 16 wave + lp of the th x (tw / 2) pair grid -> patch pixel of tap (0, 0) of its even pixel --------------------------
+  int ebase;
+  {
+    const int P = wave * 16 + lp;
+    const int oy = (int)(((unsigned)P * a.inv_tw) >> 20), px = P - oy * pw;
+    ebase = P < th * pw ? oy * iw + 2 * px : 0;
+  }
+  const int c0 = 4 * (lq >> 1) + 8 * (lq & 1);           // hidden channel of k-step 0 for this lane group; k-step ks: c0 + ks, row start + 260 ks
+  const int rd0 = nvp_row(0) + c0 * NVP_EROW + 16 * (lq >> 1) + 32 * (lq & 1) + ebase;
+  const int wr0 = lp * NVP_EROW + 4 * (lp & 7) + 32 * (lp >> 3) + lq * 4;
+  STAMP();
+  if (ch0 < ch1) { store_we(0); store_wd(0); }
+  if (ch0 + 1 < ch1) { fetch_we(ch0 + 1); fetch_wd(ch0 + 1); }
+  STAMP();
+  __syncthreads();
+  STAMP();
+  // the sums over the partial slabs, now that every load has been issued (loads return in order: nothing here waits longer than the input would)
+  if (RES_EARLY && rp && a.res_slabs > 1) {
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < (RES_EARLY ? NT : 1); ++t) resv[m2][r][t] += r1[m2][r][t];
+  }
+  if (a.in_slabs > 1) {
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int s = 0; s < NK; ++s) xr[m][s] += x1[m][s];
+  }
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int s = 0; s < NK; ++s) xr[m][s] = okm[m] ? xr[m][s] : 0.f;
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float lo_e = nvp_lo(a.act_e), hi_e = nvp_hi(a.act_e), lo_d = nvp_lo(a.act_d), hi_d = nvp_hi(a.act_d);
+
+  for (int ch = ch0; ch < ch1; ++ch) {
+    const int wb_i = (ch - ch0) & 1;
+    float* Eb = E + (NBUF == 2 ? wb_i : 0) * NVP_EBUF;
+    if (NBUF == 1 && ch > ch0) __syncthreads();            // one E buffer (more workgroups per CU): everybody is done reading the previous chunk
+    {
+      const float* wl = WE + wb_i * WE_N;
+      float wk[NK];
+#pragma unroll
+      for (int j = 0; j < NK4; ++j) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wl + (j * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wk[j * 4 + e] = v[e];
+      }
+      if (NK2) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(wl + NK4 * 256 + lane * 2);
+        wk[NK4 * 4] = v[0]; wk[NK4 * 4 + 1] = v[1];
+      }
+      const float bias = wl[NK * 64 + lp];
+      f32x4 c[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) c[m] = maskc[m] * bias;
+#pragma unroll
+      for (int s = 0; s < NK; ++s)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[m][s], wk[s], c[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = nvp_clamp(c[m][r], lo_e, hi_e);
+        *reinterpret_cast<f32x4*>(Eb + wr0 + (wave + 4 * m) * 16) = o;
+      }
+    }
+    STAMP();
+    if (ch + 1 < ch1) store_we(wb_i ^ 1);              // WE[wb_i ^ 1] was last read by the previous chunk's expand stage
+    if (ch + 2 < ch1) fetch_we(ch + 2);
+    STAMP();
+    __syncthreads();
+    STAMP();
+    const float* wd = WD + wb_i * WD_N;
+    const float* r0 = Eb + rd0;
+    const float* r1 = r0 + iw;
+    const float* r2 = r1 + iw;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 wa = *reinterpret_cast<const f32x4*>(wd + (lq * 4 + ks) * 12);
+      const f32x4 wb = *reinterpret_cast<const f32x4*>(wd + (lq * 4 + ks) * 12 + 4);
+      const f32x4 wc = *reinterpret_cast<const f32x4*>(wd + (lq * 4 + ks) * 12 + 8);       // tap 8, bias, 0, 0
+      const float tap[9] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3], wc[0]};
+      f32x2 d = {wc[1], wc[1]};
+      const float* rr[3] = {r0, r1, r2};
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const f32x2 A = *reinterpret_cast<const f32x2*>(rr[ky] + ks * 260);
+        const f32x2 B = *reinterpret_cast<const f32x2*>(rr[ky] + ks * 260 + 2);
+        d = __builtin_elementwise_fma(A, f32x2{tap[ky * 3], tap[ky * 3]}, d);
+        d = __builtin_elementwise_fma(f32x2{A[1], B[0]}, f32x2{tap[ky * 3 + 1], tap[ky * 3 + 1]}, d);
+        d = __builtin_elementwise_fma(B, f32x2{tap[ky * 3 + 2], tap[ky * 3 + 2]}, d);
+      }
+      d[0] = nvp_clamp(d[0], lo_d, hi_d); d[1] = nvp_clamp(d[1], lo_d, hi_d);
+      const float* wpl = wd + 256 + (ks * NTH * 64 + lane) * NTV;
+#pragma unroll
+      for (int hf = 0; hf < NTH; ++hf) {
+        float wv[NTV];
+        if constexpr (NTV == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(wpl + hf * 256); wv[0] = v[0]; wv[1] = v[1]; wv[2] = v[2]; wv[3] = v[3]; }
+        else if constexpr (NTV == 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(wpl); wv[0] = v[0]; wv[1] = v[1]; }
+        else wv[0] = wpl[0];
+#pragma unroll
+        for (int e = 0; e < NTV; ++e) {
+          acc[0][hf * NTV + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[0], wv[e], acc[0][hf * NTV + e], 0, 0, 0);
+          acc[1][hf * NTV + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[1], wv[e], acc[1][hf * NTV + e], 0, 0, 0);
+        }
+      }
+    }
+    STAMP();
+    if (ch + 1 < ch1) store_wd(wb_i ^ 1);              // everybody passed this chunk's barrier, so chunk ch - 1 is done with WD[wb_i ^ 1]
+    if (ch + 2 < ch1) fetch_wd(ch + 2);
+    STAMP();
+  }
+
+  // ---- epilogue: hidden-channel group g > 0 stores its bare partial sum into slab g; group 0 adds the bias and the residual -------------------
+  float* op = a.out + (size_t)blockIdx.z * a.out_slab_stride + (size_t)n * a.Ho * a.Wo * Cout;
+  const float lo_p = nvp_lo(a.act_p), hi_p = nvp_hi(a.act_p);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t * 16 + lp >= Cout) continue;
+    const float bv = lead ? bvv[t] : 0.f;
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (obase[r] < 0 || (m2 == 1 && !ok2[r])) continue;
+        const int o = obase[r] + m2 * Cout + t * 16;
+        float v = acc[m2][t][r] + bv;
+        if constexpr (RES_EARLY) { if (rp) v += resv[m2][r][t]; }
+        else if (rp) { for (int sl = 0; sl < a.res_slabs; ++sl) v += rp[(size_t)sl * a.res_slab_stride + o]; }
+        op[o] = nvp_clamp(v, lo_p, hi_p);
+      }
+  }
+  STAMP();
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------------------
+bool nv_pblock_supported(int cin, int chid, int cout, int stride) {
+  const int nk = cin / 4;
+  return stride == 1 && !(cin & 7) && !(chid & 15) && (nk == 2 || nk == 4 || nk == 6 || nk == 8 || nk == 14) && nv_block_ntiles(cout) > 0;
+}
+// tile: th x tw output pixels, tw even, th * tw / 2 <= 64 pairs, (th + 2)(tw + 2) <= 192 patch pixels; maximise the useful fraction of the MFMA rows
+void nv_pblock_tile(int Ho, int Wo, int* th_out, int* tw_out) {
+  double best = -1; int bth = 8, btw = 16;
+  for (int th = 1; th <= 32; ++th)
+    for (int tw = 4; tw <= 64; tw += 2) {
+      if (th * tw > 128 || (th + 2) * (tw + 2) > NVP_PATCH) continue;
+      const long tiles = (long)((Ho + th - 1) / th) * ((Wo + tw - 1) / tw);
+      const double eff = (double)Ho * Wo / (double)(tiles * 128);
+      const double halo = (double)(th * tw) / (double)((th + 2) * (tw + 2));
+      const double score = eff * (0.75 + 0.25 * halo);
+      if (score > best + 1e-9) { best = score; bth = th; btw = tw; }
+    }
+  *th_out = bth; *tw_out = btw;
+}
+size_t pack_nv_expand_pair_floats(int chid, int cin) { return (size_t)(chid / 16) * nvp_we_rec(cin / 4); }
+// expand record: lane (n = lane & 15, lq = lane >> 4) holds W[chunk*16 + n][lq*nk + s] for k-step s: [s / 4][lane][4], a [lane][2] remainder, bias[16]
+void pack_nv_expand_pair(const float* w /*[chid][cin]*/, const float* b, int chid, int cin, float* dst) {
+  const int nk = cin / 4, rec = nvp_we_rec(nk), nk4 = nk / 4;
+  for (int ch = 0; ch < chid / 16; ++ch) {
+    float* d = dst + (size_t)ch * rec;
+    for (int i = 0; i < rec; ++i) d[i] = 0.f;
+    for (int l = 0; l < 64; ++l) {
+      const float* wr = w + (size_t)(ch * 16 + (l & 15)) * cin + (l >> 4) * nk;
+      for (int s = 0; s < nk4 * 4; ++s) d[((s >> 2) * 64 + l) * 4 + (s & 3)] = wr[s];
+      for (int s = nk4 * 4; s < nk; ++s) d[nk4 * 256 + l * 2 + (s - nk4 * 4)] = wr[s];
+    }
+    for (int c = 0; c < 16; ++c) d[nk * 64 + c] = b[ch * 16 + c];
+  }
+}
+size_t pack_nv_dwproj_pair_floats(int chid, int nt) { return (size_t)(chid / 16) * nvp_wd_rec(nt); }
+// depthwise + project record: [lq][ks][12] = 9 taps, bias, 0, 0 of hidden channel c(ks, lq) = ks + 4 (lq >> 1) + 8 (lq & 1); then at 256:
+// [ks][nt / ntv][lane][ntv] = Wp[t*16 + (lane & 15)][chunk*16 + c(ks, lane >> 4)]
+void pack_nv_dwproj_pair(const float* wd /*[chid][9]*/, const float* bd, const float* wp /*[cout][chid]*/, int cout, int chid, int nt, float* dst) {
+  const int rec = nvp_wd_rec(nt), ntv = nt < 4 ? nt : 4, nth = nt / ntv;
+  for (int ch = 0; ch < chid / 16; ++ch) {
+    float* d = dst + (size_t)ch * rec;
+    for (int i = 0; i < rec; ++i) d[i] = 0.f;
+    for (int lq = 0; lq < 4; ++lq)
+      for (int ks = 0; ks < 4; ++ks) {
+        const int c = ch * 16 + ks + 4 * (lq >> 1) + 8 * (lq & 1);
+        for (int t = 0; t < 9; ++t) d[(lq * 4 + ks) * 12 + t] = wd[(size_t)c * 9 + t];
+        d[(lq * 4 + ks) * 12 + 9] = bd[c];
+      }
+    for (int ks = 0; ks < 4; ++ks)
+      for (int hf = 0; hf < nth; ++hf)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < ntv; ++e) {
+            const int co = (hf * ntv + e) * 16 + (l & 15), lq = l >> 4, k = ch * 16 + ks + 4 * (lq >> 1) + 8 * (lq & 1);
+            d[256 + ((ks * nth + hf) * 64 + l) * ntv + e] = co < cout ? wp[(size_t)co * chid + k] : 0.f;
+          }
+  }
+}
+
+template <int NT, int NK, int NBUF>
+static hipError_t launch_pblock_b(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
+  const size_t lds = sizeof(float) * (NBUF * (size_t)NVP_EBUF + 2 * nvp_we_rec(NK) + 2 * nvp_wd_rec(NT));
+  auto k = nv_pblock_kernel<NT, NK, NBUF>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const long tiles = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th);
+  hipLaunchKernelGGL(k, dim3((unsigned)tiles, n, groups), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+static size_t nvp_lds_bytes(int nt, int nk, int nbuf) { return sizeof(float) * ((size_t)nbuf * NVP_EBUF + 2 * nvp_we_rec(nk) + 2 * nvp_wd_rec(nt)); }
+// workgroups of this block shape that can be resident at once (registers: nvp_min_waves; LDS with `nbuf` E buffers)
+long nv_pblock_slots(int cin, int cout, int ncu, int nbuf) {
+  const int nt = nv_block_ntiles(cout), nk = cin / 4;
+  const long per_cu = std::min<long>(nvp_min_waves(nt, nk), (long)((160 * 1024) / nvp_lds_bytes(nt, nk, nbuf)));
+  return (long)(ncu > 0 ? ncu : 256) * per_cu;
+}
+// E double-buffered (one barrier per chunk) when every workgroup of the launch is resident at once anyway; one buffer (two barriers per chunk,
+// 16 KB less LDS: 5-6 workgroups per CU instead of 3-4) when the launch would otherwise run in rounds.  The dispatch is never perfectly even:
+// "fits" means 85 % of the slots.  D2FE_NV_NBUF=1|2 forces.
+template <int NT, int NK>
+static hipError_t launch_pblock_t(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("D2FE_NV_NBUF"); force = e ? atoi(e) : 0; }
+  const long wgs = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th) * n * groups;
+  const bool one = force ? force == 1 : wgs * 100 > nv_pblock_slots(a.Cin, a.Cout, a.ncu, 2) * 85;
+  return one ? launch_pblock_b<NT, NK, 1>(a, n, groups, s) : launch_pblock_b<NT, NK, 2>(a, n, groups, s);
+}
+template <int NK>
+static hipError_t launch_pblock_nt(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
+  switch (nv_block_ntiles(a.Cout)) {
+    case 1: return launch_pblock_t<1, NK>(a, n, groups, s);
+    case 2: return launch_pblock_t<2, NK>(a, n, groups, s);
+    case 4: return launch_pblock_t<4, NK>(a, n, groups, s);
+    case 8: return launch_pblock_t<8, NK>(a, n, groups, s);
+  }
+  return hipErrorInvalidValue;
+}
+hipError_t launch_nv_pblock(const NvBlockArgs& a_in, int n, int groups, hipStream_t s) {
+  NvBlockArgs a = a_in;
+  if (a.stride != 1 || a.tw < 2 || (a.tw & 1) || a.th < 1 || a.th * a.tw > 128 || (a.th + 2) * (a.tw + 2) > NVP_PATCH) return hipErrorInvalidValue;
+  const int iw = a.tw + 2, pw = a.tw / 2;
+  a.inv_iw = ((1u << 20) + iw - 1) / iw; a.inv_tw = ((1u << 20) + pw - 1) / pw;       // exact for n < 2^20 / d: n < 256 here
+  if ((long)a.H * a.W * a.Cin >= (1l << 31) || (long)a.Ho * a.Wo * a.Cout >= (1l << 31)) return hipErrorInvalidValue;
+  switch (a.Cin / 4) {
+    case 2: return launch_pblock_nt<2>(a, n, groups, s);
+    case 4: return launch_pblock_nt<4>(a, n, groups, s);
+    case 6: return launch_pblock_nt<6>(a, n, groups, s);
+    case 8: return launch_pblock_nt<8>(a, n, groups, s);
+    case 14: return launch_pblock_nt<14>(a, n, groups, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace d2fe

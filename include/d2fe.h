@@ -406,6 +406,10 @@ D2FE_API long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t
  * execution plan materialises it -- the last layer of every fused MobileNetV2 block and every unfused layer; D2FE_ERR_NOT_READY for a
  * layer that only exists in LDS inside a fused block (D2FE_NV_LEGACY=1 in the environment: one launch per layer, everything readable). */
 D2FE_API long d2fe_debug_netvlad_layer(d2fe_handle h, int layer, int n_images, void* dst, size_t max_bytes);
+/* Kernel diagnostics (tools/nv_stamps.py): with D2FE_NV_STAMP_STEP=<execution-plan step> in the environment when the network was loaded, the
+ * wall_clock64() phase stamps [workgroup][32] (100 MHz ticks) that step's block kernel wrote during the last d2fe_netvlad* call.  Returns the number
+ * of workgroups copied (<= max_wgs) or <0. */
+D2FE_API long d2fe_debug_netvlad_stamps(d2fe_handle h, unsigned long long* dst, long max_wgs);
 /* One 3x3 / pad 1 layer (cin 64 or 128, ReLU, optional 2x2 max-pool) through the Winograd kernels of D2FE_PREC_F32_WINO, host
  * NHWC buffers in and out; iters > 0 also times `iters` back-to-back launches (HIP events on the handle's stream).  For the
  * layer-level parity tests (tests/test_wino.py) and tools/; the product path is d2fe_superpoint_extract*. */

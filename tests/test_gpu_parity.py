@@ -523,16 +523,16 @@ def test_netvlad_fused_blocks_layerwise(api, orc, H, W):
 
 
 def test_netvlad_plans_agree(api, orc, monkeypatch):
-    """The fused plan (default), the LDS-resident block form (D2FE_NV_XBLOCK=0), no slab sums (D2FE_NV_SLABSUM=0) and one launch per
-    layer (D2FE_NV_LEGACY=1) are four schedules of the same arithmetic up to summation order: all within 1e-4 of the oracle, and a batch
+    """The fused plan (default), the per-pixel form of the stride-1 blocks (D2FE_NV_PAIR=0), the LDS-resident block form (D2FE_NV_XBLOCK=0), no slab sums (D2FE_NV_SLABSUM=0) and one launch per
+    layer (D2FE_NV_LEGACY=1) are five schedules of the same arithmetic up to summation order: all within 1e-4 of the oracle, and a batch
     of one image equals the same image inside a batch of five (different group counts, hence different slab layouts)."""
     from d2slam_amd import netvlad as nvm
     nv = nvm.synthetic_netvlad_weights()
     H, W = 240, 320
     imgs = np.stack([synth_image(H, W, 30 + s) for s in range(5)])
     ref = orc.netvlad_forward(imgs[2], nv)
-    for env in ({}, {"D2FE_NV_XBLOCK": "0"}, {"D2FE_NV_SLABSUM": "0"}, {"D2FE_NV_LEGACY": "1"}):
-        for k in ("D2FE_NV_XBLOCK", "D2FE_NV_SLABSUM", "D2FE_NV_LEGACY"):
+    for env in ({}, {"D2FE_NV_PAIR": "0"}, {"D2FE_NV_XBLOCK": "0"}, {"D2FE_NV_SLABSUM": "0"}, {"D2FE_NV_LEGACY": "1"}):
+        for k in ("D2FE_NV_PAIR", "D2FE_NV_XBLOCK", "D2FE_NV_SLABSUM", "D2FE_NV_LEGACY"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
