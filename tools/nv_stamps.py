@@ -18,14 +18,15 @@ st = fe.debug_netvlad_stamps().astype(np.int64)
 st = st[st[:, 0] > 0]
 t0 = st[:, 0].min()
 nst = int((st > 0).sum(axis=1).max())
+n_all = len(st)
+st = st[(st > 0).sum(axis=1) == nst]          # the hidden-channel groups with the most chunks
 rel = (st[:, :nst] - t0) * 0.01           # us (100 MHz)
-print("step %d flags %s: %d workgroups, %d stamps; kernel span (first start -> last end) %.2f us" % (step, os.environ.get("D2FE_NV_FLAGS", "0"), len(st), nst, rel[:, nst - 1].max()))
+print("step %d: %d workgroups (%d with all %d stamps); kernel span (first start -> last end) %.2f us" % (step, n_all, len(st), nst, rel[:, nst - 1].max()))
 print("workgroup start: p50 %.2f p90 %.2f max %.2f us after the first; lifetime p50 %.2f p90 %.2f max %.2f us" % (
     np.median(rel[:, 0]), np.percentile(rel[:, 0], 90), rel[:, 0].max(), np.median(rel[:, nst - 1] - rel[:, 0]), np.percentile(rel[:, nst - 1] - rel[:, 0], 90),
     (rel[:, nst - 1] - rel[:, 0]).max()))
 names = ["start", "inputs issued / w0 arrived", "w0 stored", "barrier0"]
-nch = (nst - 5) // 5
-for c in range(nch):
+for c in range((nst - 5) // 5):
     names += ["ch%d expand done" % c, "ch%d we stored" % c, "ch%d barrier" % c, "ch%d dw+project done" % c, "ch%d wd stored" % c]
 names += ["epilogue done"]
 d = np.diff(rel, axis=1)
