@@ -926,7 +926,7 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     a.wp = st.wp; a.bp = st.bp; a.act_p = pj.act;
     if (pj.res >= 0) { const auto& r = h->nv[pj.res]; a.res = r.out; a.res_slabs = r.slabs; a.res_slab_stride = r.slab_stride; }
     a.th = 8; a.tw = 16;
-    if (st.pblock) nv_pblock_tile(a.Ho, a.Wo, &a.th, &a.tw);
+    if (st.pblock) nv_pblock_tile(a.Ho, a.Wo, &a.th, &a.tw, st.front ? a.c0_stride : 0);
     else if (st.xblock) nv_xblock_tile(a.Ho, a.Wo, a.stride, &a.th, &a.tw);
     const long tiles = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th) * n;
     // partial slabs are summed by the consumer's staging: only when that consumer is a fused step
@@ -940,7 +940,8 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
       HIP_TRY(hipMemsetAsync(h->nv_stamps, 0, sizeof(unsigned long long) * 32 * 8192, s));
       a.stamps = h->nv_stamps; h->nv_stamp_wgs = (int)(tiles * groups);
     }
-    if (st.pblock) HIP_TRY(launch_nv_pblock(a, n, groups, s));
+    if (st.pblock && st.front) HIP_TRY(launch_nv_fpair(a, n, s));
+    else if (st.pblock) HIP_TRY(launch_nv_pblock(a, n, groups, s));
     else if (st.xblock) HIP_TRY(launch_nv_xblock(a, n, groups, s));
     else HIP_TRY(launch_nv_block(a, st.expand, st.front ? 1 : 0, n, groups, s));
     // three or more partial slabs: sum them once instead of in every consumer workgroup (and in every residual read)
@@ -1040,6 +1041,8 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
         if (K(i) == D2FE_NV_CONV && K(i + 1) == D2FE_NV_DW && K(i + 2) == D2FE_NV_PW && h->nv[i + 1].res < 0 && h->nv[i + 2].res < 0 &&
             nv_block_supported(h->nv[i + 1].cin, h->nv[i + 1].cin, h->nv[i + 2].cout, h->nv[i + 1].stride, false, 1)) {
           st.fused = true; st.front = true; st.l1 = i + 2;
+          { const char* pq = getenv("D2FE_NV_PAIR");       // pixel-pair form of the first block too (netvlad_pair.hip)
+            st.pblock = !(pq && atoi(pq) == 0) && nv_fpair_supported(h->nv[i].cout, h->nv[i].stride, h->nv[i + 1].stride, h->nv[i + 2].cout); }
         } else if (i > 0 && K(i) == D2FE_NV_PW && K(i + 1) == D2FE_NV_DW && K(i + 2) == D2FE_NV_PW && h->nv[i].res < 0 &&
                    nv_block_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride, true, 0)) {
           st.fused = true; st.expand = true; st.l1 = i + 2;

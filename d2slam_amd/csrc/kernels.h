@@ -141,12 +141,14 @@ void pack_nv_expand_perm(const float* w, const float* b, int chid, int cin, floa
 hipError_t launch_nv_xblock(const NvBlockArgs& a, int n, int groups, hipStream_t s);
 // stride-1 expand blocks, depthwise stage on horizontal pixel pairs (netvlad_pair.hip)
 bool nv_pblock_supported(int cin, int chid, int cout, int stride);
-void nv_pblock_tile(int Ho, int Wo, int* th, int* tw);
+void nv_pblock_tile(int Ho, int Wo, int* th, int* tw, int c0_stride = 0);
 size_t pack_nv_expand_pair_floats(int chid, int cin);
 void pack_nv_expand_pair(const float* w, const float* b, int chid, int cin, float* dst);
 size_t pack_nv_dwproj_pair_floats(int chid, int nt);
 void pack_nv_dwproj_pair(const float* wd, const float* bd, const float* wp, int cout, int chid, int nt, float* dst);
 hipError_t launch_nv_pblock(const NvBlockArgs& a, int n, int groups, hipStream_t s);
+bool nv_fpair_supported(int c0_cout, int c0_stride, int dw_stride, int cout);      // the first block (conv from u8 -> dw -> pw) in the same form
+hipError_t launch_nv_fpair(const NvBlockArgs& a, int n, hipStream_t s);
 long nv_pblock_slots(int cin, int cout, int ncu, int nbuf);     // resident workgroups of that block shape on the whole device
 hipError_t launch_nv_slab_sum(float* t, int slabs, long slab_stride, long count, hipStream_t s);   // slab 0 += slabs 1..
 void pack_nv_conv0(const float* w /*[cout][9]*/, const float* b, int cout, float* dst /*[384]*/);

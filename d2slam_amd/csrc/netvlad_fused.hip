@@ -378,7 +378,9 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int MT_IN = nvb_mt_in(S, 0), EP = nvb_ep(S, 0), NBUF = S == 1 ? 2 : 1;
   constexpr int MPW = MT_IN / 4, GI = 3;
-  constexpr int KSE1 = NJ * 4 + 1, WE_N = (KSE1 * 64 + 255) / 256 * 256, WD_N = nvb_wd_rec(NT), WER = WE_N / 256, WDR = WD_N / 256;
+  // NJ = 0: Cin = 8, a float2 per lane (channels 2 lq, 2 lq + 1) and two k-steps instead of a float4 with half the lane groups zero and four
+  constexpr int KS = NJ ? NJ * 4 : 2;
+  constexpr int KSE1 = KS + 1, WE_N = (KSE1 * 64 + 255) / 256 * 256, WD_N = nvb_wd_rec(NT), WER = WE_N / 256, WDR = WD_N / 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane >> 4, lp = lane & 15;
   float* E = lds;                         // [NBUF][16][EP]
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
   // ---- the wave's MPW patch m-tiles: pixel mt*16 + lp, channels (lq + 4 j) * 4 .. + 3, summed over the producer's partial slabs ----
   // Every global load of the prologue is issued before anything waits on one, in batches per slab: a run-time loop over the partial slabs
   // around each load costs one memory round trip per iteration (tools/nv_stamps.py: 3 us of prologue, 3 us of epilogue per workgroup).
-  f32x4 xr[MPW][NJ];
+  float xr[MPW][KS];
   float one[MPW];
   {
     const float* ip = a.in + (size_t)n * a.H * a.W * Cin;        // one slab (the launcher rejects a split input: run_netvlad sums the slabs first)
@@ -472,8 +474,16 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
       const bool ok = p < npx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       one[m] = ok ? 1.f : 0.f;
       const float* src = ip + (ok ? (gy * a.W + gx) * Cin : 0);
+      if constexpr (NJ == 0) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(src + lq * 2);
+        xr[m][0] = v[0]; xr[m][1] = v[1];
+      } else {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) xr[m][j] = *reinterpret_cast<const f32x4*>(src + ((lq + 4 * j) * 4 < Cin ? (lq + 4 * j) * 4 : 0));
+        for (int j = 0; j < NJ; ++j) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((lq + 4 * j) * 4 < Cin ? (lq + 4 * j) * 4 : 0));
+          xr[m][j * 4] = v[0]; xr[m][j * 4 + 1] = v[1]; xr[m][j * 4 + 2] = v[2]; xr[m][j * 4 + 3] = v[3];
+        }
+      }
     }
   }
   // ---- the wave's two output m-tiles (flat index q = (2 wave + m2) * 16 + lp over the th x tw tile) -> patch pixel of tap (0,0) ----
@@ -508,8 +518,8 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
 #pragma unroll
   for (int m = 0; m < MPW; ++m)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
-      if (!(one[m] != 0.f && (lq + 4 * j) * 4 < Cin)) xr[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < KS; ++k)
+      if (!(one[m] != 0.f && (NJ == 0 || (lq + 4 * (k >> 2)) * 4 < Cin))) xr[m][k] = 0.f;
 
   for (int ch = ch0; ch < ch1; ++ch) {
     const int wb_i = (ch - ch0) & 1;
@@ -522,13 +532,11 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
 #pragma unroll
       for (int i = 0; i < GI; ++i) c[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+      for (int k = 0; k < KS; ++k) {
+        const float wv = wl[k * 64];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float wv = wl[(j * 4 + e) * 64];
-#pragma unroll
-          for (int i = 0; i < GI; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[g * GI + i][j][e], wv, c[i], 0, 0, 0);
-        }
+        for (int i = 0; i < GI; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[g * GI + i][k], wv, c[i], 0, 0, 0);
+      }
       {
         const float wv = wl[(KSE1 - 1) * 64];          // bias step against the in-image mask
 #pragma unroll
@@ -630,30 +638,33 @@ void nv_xblock_tile(int Ho, int Wo, int stride, int* th_out, int* tw_out) {
     }
   *th_out = bth; *tw_out = btw;
 }
-int nv_xblock_nj(int cin) { const int nj = (cin + 15) / 16; return nj <= 2 ? nj : nj <= 4 ? 4 : nj <= 7 ? 7 : -1; }
+int nv_xblock_nj(int cin) { if (cin == 8) return 0; const int nj = (cin + 15) / 16; return nj <= 2 ? nj : nj <= 4 ? 4 : nj <= 7 ? 7 : -1; }     // 0: the Cin = 8 form
 bool nv_xblock_supported(int cin, int chid, int cout, int stride) {
-  return (stride == 1 || stride == 2) && !(cin & 3) && !(chid & 15) && cin >= 4 && nv_xblock_nj(cin) > 0 && nv_block_ntiles(cout) > 0 &&
+  return (stride == 1 || stride == 2) && !(cin & 3) && !(chid & 15) && cin >= 4 && nv_xblock_nj(cin) >= 0 && nv_block_ntiles(cout) > 0 &&
          (stride == 1 || nv_xblock_nj(cin) <= 2);      // stride 2 keeps 9 m-tiles of input per lane: Cin <= 32
 }
 // expand record for nv_xblock_kernel: k-step (j, e) holds input channel (lq + 4 j) * 4 + e for lane group lq (zero beyond cin); bias step last
-size_t pack_nv_expand_perm_floats(int chid, int cin) { const int nj = nv_xblock_nj(cin); return (size_t)(chid / 16) * (((nj * 4 + 1) * 64 + 255) / 256 * 256); }
+size_t pack_nv_expand_perm_floats(int chid, int cin) { const int nj = nv_xblock_nj(cin), ks = nj ? nj * 4 : 2; return (size_t)(chid / 16) * (((ks + 1) * 64 + 255) / 256 * 256); }
 void pack_nv_expand_perm(const float* w /*[chid][cin]*/, const float* b, int chid, int cin, float* dst) {
-  const int nj = nv_xblock_nj(cin), rec = ((nj * 4 + 1) * 64 + 255) / 256 * 256;
+  const int nj = nv_xblock_nj(cin), ks = nj ? nj * 4 : 2, rec = ((ks + 1) * 64 + 255) / 256 * 256;
   for (int ch = 0; ch < chid / 16; ++ch) {
     float* d = dst + (size_t)ch * rec;
     for (int i = 0; i < rec; ++i) d[i] = 0.f;
+    if (nj == 0)         // Cin = 8: k-step e holds channel 2 lq + e
+      for (int e = 0; e < 2; ++e)
+        for (int l = 0; l < 64; ++l) d[e * 64 + l] = w[(size_t)(ch * 16 + (l & 15)) * cin + (l >> 4) * 2 + e];
     for (int j = 0; j < nj; ++j)
       for (int e = 0; e < 4; ++e)
         for (int l = 0; l < 64; ++l) {
           const int k = ((l >> 4) + 4 * j) * 4 + e;
           d[(j * 4 + e) * 64 + l] = k < cin ? w[(size_t)(ch * 16 + (l & 15)) * cin + k] : 0.f;
         }
-    for (int c = 0; c < 16; ++c) d[nj * 4 * 64 + c] = b[ch * 16 + c];
+    for (int c = 0; c < 16; ++c) d[ks * 64 + c] = b[ch * 16 + c];
   }
 }
 template <int S, int NT, int NJ>
 static hipError_t launch_xblock_t(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
-  constexpr int EP = nvb_ep(S, 0), NBUF = S == 1 ? 2 : 1, WE_N = ((NJ * 4 + 1) * 64 + 255) / 256 * 256;
+  constexpr int EP = nvb_ep(S, 0), NBUF = S == 1 ? 2 : 1, WE_N = (((NJ ? NJ * 4 : 2) + 1) * 64 + 255) / 256 * 256;
   const size_t lds = sizeof(float) * ((size_t)NBUF * 16 * EP + 2 * WE_N + 2 * nvb_wd_rec(NT));
   auto k = nv_xblock_kernel<S, NT, NJ>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -680,11 +691,13 @@ hipError_t launch_nv_xblock(const NvBlockArgs& a_in, int n, int groups, hipStrea
   if ((long)a.H * a.W * a.Cin >= (1l << 31) || (long)a.Ho * a.Wo * a.Cout >= (1l << 31)) return hipErrorInvalidValue;
   const int nj = nv_xblock_nj(a.Cin);
   if (a.stride == 1) {
+    if (nj == 0) return launch_xblock_nt<1, 0>(a, n, groups, s);
     if (nj == 1) return launch_xblock_nt<1, 1>(a, n, groups, s);
     if (nj == 2) return launch_xblock_nt<1, 2>(a, n, groups, s);
     if (nj == 4) return launch_xblock_nt<1, 4>(a, n, groups, s);
     if (nj == 7) return launch_xblock_nt<1, 7>(a, n, groups, s);
   } else {
+    if (nj == 0) return launch_xblock_nt<2, 0>(a, n, groups, s);
     if (nj == 1) return launch_xblock_nt<2, 1>(a, n, groups, s);
     if (nj == 2) return launch_xblock_nt<2, 2>(a, n, groups, s);
   }

@@ -34,6 +34,7 @@ __device__ __forceinline__ float nvp_clamp(float v, float lo, float hi) { return
 }  // namespace
 
 constexpr int NVP_EROW = 256, NVP_EBUF = 16 * NVP_EROW, NVP_PATCH = 192;      // patch pixels = 12 m-tiles, 3 per wave
+constexpr int NVP_U8_PITCH = 40, NVP_U8_ROWS = 24;      // first block: u8 copy of the patch's receptive field, (10 - 1) * 2 + 3 = 21 rows x 37 bytes at stride 2
 __host__ __device__ constexpr int nvp_we_rec(int nk) { return (nk * 64 + 16 + 255) / 256 * 256; }      // [nk/4][lane][4] (+ [lane][2]) + bias[16]
 __host__ __device__ constexpr int nvp_wd_rec(int nt) { return 256 + nt * 256; }                         // [lq][ks][12] + pad, [ks][nt/ntv][lane][ntv]
 __host__ __device__ constexpr int nvp_row(int c) { return c * NVP_EROW + 4 * (c & 7) + 32 * (c >> 3); }
@@ -333,17 +334,186 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
   STAMP();
 }
 
+// ---- the network's first block: conv 3x3 from the u8 frame -> dw 3x3 -> pw project, same depthwise organisation ---------------------------------
+// One chunk (the first conv has 16 output channels = the block's hidden channels), so no weight pipeline: the u8 receptive field of the patch,
+// the conv's B fragments and the depthwise + project record are fetched in ONE batch of loads at the top (the old form, nv_block_kernel MODE 1,
+// walked the u8 patch in a run-time loop: four memory round trips per workgroup, and was bound by the LDS reads of its per-pixel depthwise stage).
+//   conv: M = patch pixels (12 m-tiles), K = 9 taps + 1 bias row (+ 2 zero rows), N = 16; A = (u8 - 128) / 128 read from the u8 copy in LDS; a pixel
+//   outside the conv's output map zeroes its whole A row, bias included, so the depthwise stage sees its zero padding.
+template <int NT>
+__global__ __launch_bounds__(256) void nv_fpair_kernel(NvBlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WD_N = nvp_wd_rec(NT), WDR = WD_N / 256;
+  constexpr int NTV = NT < 4 ? NT : 4, NTH = NT / NTV;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane >> 4, lp = lane & 15;
+  float* E = lds;                                   // [16 rows], as nv_pblock_kernel
+  float* WD = E + NVP_EBUF;                         // [WD_N]
+  float* W0 = WD + WD_N;                            // [3][64] B fragments of the conv (n-tile 0 of pack_nv_conv0's [3][2][64])
+  uint8_t* U8 = reinterpret_cast<uint8_t*>(W0 + 192);      // [NVP_U8_ROWS][NVP_U8_PITCH]
+  const int Cout = a.Cout, th = a.th, tw = a.tw, pw = tw >> 1;
+  const int iw = tw + 2, npx = (th + 2) * iw;
+  const int tiles_x = (a.Wo + tw - 1) / tw;
+  const int n = blockIdx.y;
+  const int ty = (int)blockIdx.x / tiles_x;
+  const int oy0 = ty * th, ox0 = ((int)blockIdx.x - ty * tiles_x) * tw;
+  const int iy0 = oy0 - a.pt, ix0 = ox0 - a.pl;
+  const int cs = a.c0_stride;
+  const int uy0 = iy0 * cs - a.c0_pt, ux0 = ix0 * cs - a.c0_pl;
+  const int UH = (th + 1) * cs + 3, UW = (iw - 1) * cs + 3;
+  // ---- one batch of loads: u8 patch (4 bytes per thread at most), conv fragments, depthwise + project record, project bias --------------------------
+  const uint8_t* ipx = a.img + (size_t)n * a.img_istride;
+  uint8_t ub[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = i * 256 + tid;
+    const int uy = idx / NVP_U8_PITCH, ux = idx - uy * NVP_U8_PITCH;
+    const int yy = uy0 + uy, xx = ux0 + ux;
+    const bool in = idx < NVP_U8_ROWS * NVP_U8_PITCH && uy < UH && ux < UW && yy >= 0 && yy < a.H0 && xx >= 0 && xx < a.W0;
+    ub[i] = ipx[in ? (unsigned)(yy * a.img_stride + xx) : 0u];
+    if (!in) ub[i] = 128;                           // 128 -> exactly 0 after (x - 128) / 128
+  }
+  const float w0v = tid < 192 ? a.w0[(tid >> 6) * 128 + (tid & 63)] : 0.f;
+  float wds[WDR];
+#pragma unroll
+  for (int i = 0; i < WDR; ++i) wds[i] = a.wp[i * 256 + tid];
+  float bvv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bvv[t] = a.bp[t * 16 + lp];
+  // ---- output addresses (C layout of the project accumulators: row = pair 16 wave + 4 lq + r, pixel 2 px + m2) and the depthwise base ------------
+  int obase[4]; bool ok2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int P = wave * 16 + lq * 4 + r;
+    const int oy = (int)(((unsigned)P * a.inv_tw) >> 20), px = P - oy * pw;
+    const int gy = oy0 + oy, gx = ox0 + 2 * px;
+    const bool okp = P < th * pw && gy < a.Ho && gx < a.Wo;
+    obase[r] = okp ? (gy * a.Wo + gx) * Cout + lp : -1;
+    ok2[r] = okp && gx + 1 < a.Wo;
+  }
+  int ebase;
+  {
+    const int P = wave * 16 + lp;
+    const int oy = (int)(((unsigned)P * a.inv_tw) >> 20), px = P - oy * pw;
+    ebase = P < th * pw ? oy * iw + 2 * px : 0;
+  }
+  const int c0 = 4 * (lq >> 1) + 8 * (lq & 1);
+  const int rd0 = nvp_row(0) + c0 * NVP_EROW + 16 * (lq >> 1) + 32 * (lq & 1) + ebase;
+  const int wr0 = lp * NVP_EROW + 4 * (lp & 7) + 32 * (lp >> 3) + lq * 4;
+  // this lane's conv A rows: patch pixel (wave + 4 m) * 16 + lp -> byte offset of its tap (0, 0) in the u8 copy, or -1 outside the conv's output
+  int uoff[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const int p = (wave + 4 * m) * 16 + lp;
+    const int iy = (int)(((unsigned)p * a.inv_iw) >> 20), ix = p - iy * iw;
+    const int gy = iy0 + iy, gx = ix0 + ix;
+    uoff[m] = (p < npx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (iy * cs) * NVP_U8_PITCH + ix * cs : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (i * 256 + tid < NVP_U8_ROWS * NVP_U8_PITCH) U8[i * 256 + tid] = ub[i];
+  if (tid < 192) W0[tid] = w0v;
+#pragma unroll
+  for (int i = 0; i < WDR; ++i) WD[i * 256 + tid] = wds[i];
+  __syncthreads();
+
+  // ---- first conv on the matrix pipe -> E rows (channel lp, pixels 4 lq .. + 3 of m-tile mt) --------------------------------------------------
+  {
+    const float lo0 = nvp_lo(a.act0), hi0 = nvp_hi(a.act0);
+    float wf[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) wf[ks] = W0[ks * 64 + lane];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const bool ok = uoff[m] >= 0;
+      const uint8_t* up = U8 + (ok ? uoff[m] : 0);
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const int k = ks * 4 + lq;                  // tap (k / 3, k % 3) for k < 9, the bias row for k == 9
+        const int toff = k < 9 ? (k / 3) * NVP_U8_PITCH + (k % 3) : 0;
+        const float t = ((float)up[toff] - 128.0f) * 0.0078125f;
+        const float av = ok ? (k < 9 ? t : (k == 9 ? 1.f : 0.f)) : 0.f;
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wf[ks], c, 0, 0, 0);
+      }
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = nvp_clamp(c[r], lo0, hi0);
+      *reinterpret_cast<f32x4*>(E + wr0 + (wave + 4 * m) * 16) = o;
+    }
+  }
+  __syncthreads();
+
+  // ---- depthwise (pixel pairs) + project, as one chunk of nv_pblock_kernel -----------------------------------------------------------------------
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float lo_d = nvp_lo(a.act_d), hi_d = nvp_hi(a.act_d);
+  {
+    const float* r0 = E + rd0;
+    const float* r1 = r0 + iw;
+    const float* r2 = r1 + iw;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 wa = *reinterpret_cast<const f32x4*>(WD + (lq * 4 + ks) * 12);
+      const f32x4 wb = *reinterpret_cast<const f32x4*>(WD + (lq * 4 + ks) * 12 + 4);
+      const f32x4 wc = *reinterpret_cast<const f32x4*>(WD + (lq * 4 + ks) * 12 + 8);
+      const float tap[9] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3], wc[0]};
+      f32x2 d = {wc[1], wc[1]};
+      const float* rr[3] = {r0, r1, r2};
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const f32x2 A = *reinterpret_cast<const f32x2*>(rr[ky] + ks * 260);
+        const f32x2 B = *reinterpret_cast<const f32x2*>(rr[ky] + ks * 260 + 2);
+        d = __builtin_elementwise_fma(A, f32x2{tap[ky * 3], tap[ky * 3]}, d);
+        d = __builtin_elementwise_fma(f32x2{A[1], B[0]}, f32x2{tap[ky * 3 + 1], tap[ky * 3 + 1]}, d);
+        d = __builtin_elementwise_fma(B, f32x2{tap[ky * 3 + 2], tap[ky * 3 + 2]}, d);
+      }
+      d[0] = nvp_clamp(d[0], lo_d, hi_d); d[1] = nvp_clamp(d[1], lo_d, hi_d);
+      const float* wpl = WD + 256 + (ks * NTH * 64 + lane) * NTV;
+#pragma unroll
+      for (int hf = 0; hf < NTH; ++hf) {
+        float wv[NTV];
+        if constexpr (NTV == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(wpl + hf * 256); wv[0] = v[0]; wv[1] = v[1]; wv[2] = v[2]; wv[3] = v[3]; }
+        else if constexpr (NTV == 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(wpl); wv[0] = v[0]; wv[1] = v[1]; }
+        else wv[0] = wpl[0];
+#pragma unroll
+        for (int e = 0; e < NTV; ++e) {
+          acc[0][hf * NTV + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[0], wv[e], acc[0][hf * NTV + e], 0, 0, 0);
+          acc[1][hf * NTV + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[1], wv[e], acc[1][hf * NTV + e], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* op = a.out + (size_t)n * a.Ho * a.Wo * Cout;
+  const float lo_p = nvp_lo(a.act_p), hi_p = nvp_hi(a.act_p);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t * 16 + lp >= Cout) continue;
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (obase[r] < 0 || (m2 == 1 && !ok2[r])) continue;
+        op[(unsigned)(obase[r] + m2 * Cout + t * 16)] = nvp_clamp(acc[m2][t][r] + bvv[t], lo_p, hi_p);
+      }
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------------------------
 bool nv_pblock_supported(int cin, int chid, int cout, int stride) {
   const int nk = cin / 4;
   return stride == 1 && !(cin & 7) && !(chid & 15) && (nk == 2 || nk == 4 || nk == 6 || nk == 8 || nk == 14) && nv_block_ntiles(cout) > 0;
 }
 // tile: th x tw output pixels, tw even, th * tw / 2 <= 64 pairs, (th + 2)(tw + 2) <= 192 patch pixels; maximise the useful fraction of the MFMA rows
-void nv_pblock_tile(int Ho, int Wo, int* th_out, int* tw_out) {
+// (c0_stride > 0: the first block -- the u8 receptive field of the patch must fit its LDS copy)
+void nv_pblock_tile(int Ho, int Wo, int* th_out, int* tw_out, int c0_stride) {
   double best = -1; int bth = 8, btw = 16;
   for (int th = 1; th <= 32; ++th)
     for (int tw = 4; tw <= 64; tw += 2) {
       if (th * tw > 128 || (th + 2) * (tw + 2) > NVP_PATCH) continue;
+      if (c0_stride > 0 && ((th + 1) * c0_stride + 3 > NVP_U8_ROWS || (tw + 1) * c0_stride + 3 > NVP_U8_PITCH)) continue;
       const long tiles = (long)((Ho + th - 1) / th) * ((Wo + tw - 1) / tw);
       const double eff = (double)Ho * Wo / (double)(tiles * 128);
       const double halo = (double)(th * tw) / (double)((th + 2) * (tw + 2));
@@ -426,6 +596,35 @@ static hipError_t launch_pblock_nt(const NvBlockArgs& a, int n, int groups, hipS
     case 2: return launch_pblock_t<2, NK>(a, n, groups, s);
     case 4: return launch_pblock_t<4, NK>(a, n, groups, s);
     case 8: return launch_pblock_t<8, NK>(a, n, groups, s);
+  }
+  return hipErrorInvalidValue;
+}
+bool nv_fpair_supported(int c0_cout, int c0_stride, int dw_stride, int cout) {
+  return c0_cout == 16 && (c0_stride == 1 || c0_stride == 2) && dw_stride == 1 && nv_block_ntiles(cout) > 0;
+}
+template <int NT>
+static hipError_t launch_fpair_t(const NvBlockArgs& a, int n, hipStream_t s) {
+  const size_t lds = sizeof(float) * ((size_t)NVP_EBUF + nvp_wd_rec(NT) + 192) + NVP_U8_ROWS * NVP_U8_PITCH;
+  auto k = nv_fpair_kernel<NT>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const long tiles = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th);
+  hipLaunchKernelGGL(k, dim3((unsigned)tiles, n, 1), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+// the first block (conv from the u8 frame -> dw -> pw): a.we unused, a.wp = one pack_nv_dwproj_pair record, a.w0 = pack_nv_conv0
+hipError_t launch_nv_fpair(const NvBlockArgs& a_in, int n, hipStream_t s) {
+  NvBlockArgs a = a_in;
+  if (a.stride != 1 || a.tw < 2 || (a.tw & 1) || a.th < 1 || a.th * a.tw > 128 || (a.th + 2) * (a.tw + 2) > NVP_PATCH) return hipErrorInvalidValue;
+  if ((a.th + 1) * a.c0_stride + 3 > NVP_U8_ROWS || (a.tw + 1) * a.c0_stride + 3 > NVP_U8_PITCH) return hipErrorInvalidValue;
+  const int iw = a.tw + 2, pw = a.tw / 2;
+  a.inv_iw = ((1u << 20) + iw - 1) / iw; a.inv_tw = ((1u << 20) + pw - 1) / pw;
+  if ((long)a.H0 * a.img_stride >= (1l << 31) || (long)a.Ho * a.Wo * a.Cout >= (1l << 31)) return hipErrorInvalidValue;
+  switch (nv_block_ntiles(a.Cout)) {
+    case 1: return launch_fpair_t<1>(a, n, s);
+    case 2: return launch_fpair_t<2>(a, n, s);
+    case 4: return launch_fpair_t<4>(a, n, s);
+    case 8: return launch_fpair_t<8>(a, n, s);
   }
   return hipErrorInvalidValue;
 }
