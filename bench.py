@@ -333,7 +333,7 @@ def main():
         if netvlad and nv_n:
             t = nv_ms / nv_n
             ach = NV_FLOP_PER_IMG * F / (t * 1e-3) / 1e12
-            roofline_nv = {"kernel": "NetVLAD sequence (26 launches: nv_block_kernel<front>, nv_xblock_kernel x16, nv_slab_sum_kernel x5, nv_tail_kernel, nv_vlad_*): MobileNetV2-0.35 trunk + NetVLAD head",
+            roofline_nv = {"kernel": "NetVLAD sequence (27 launches: nv_fpair_kernel, nv_pblock_kernel x12 (stride 1), nv_xblock_kernel x4 (stride 2), nv_slab_sum_kernel x6, nv_tail_kernel, nv_vlad_* x2 + memset): MobileNetV2-0.35 trunk + NetVLAD head",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
                            "ms_per_call": round(t, 4), "images_per_call": F, "algorithmic_flop_per_call": NV_FLOP_PER_IMG * F,
                            "note": "fp32 MFMA (v_mfma_f32_16x16x4_f32) + VALU depthwise; instruction/latency-bound small layers (DESIGN.md section 4); "

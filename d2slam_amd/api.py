@@ -457,7 +457,7 @@ class FrontEnd:
         assert r == out.nbytes, (r, out.nbytes)
         return out
 
-    def debug_netvlad_stamps(self, max_wgs=8192):
+    def debug_netvlad_stamps(self, max_wgs=32768):
         """[workgroups][32] uint64 phase stamps of the plan step named by D2FE_NV_STAMP_STEP (see include/d2fe.h)."""
         out = np.zeros((max_wgs, 32), np.uint64)
         self._lib.d2fe_debug_netvlad_stamps.restype = C.c_long

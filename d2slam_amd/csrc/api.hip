@@ -847,13 +847,13 @@ void nv_free(d2fe_context* h) {
 inline int same_out(int in, int stride) { return (in + stride - 1) / stride; }
 inline int same_pad_begin(int in, int stride, int out) { const int t = (out - 1) * stride + 3 - in; return t > 0 ? t / 2 : 0; }   // TF "SAME", 3x3
 
-// hidden-channel groups for a fused step: enough workgroups to fill the chip (2 per CU), at least 4 chunks of 16 per group (every
+// hidden-channel groups for a fused step: enough workgroups to fill the chip (2 per CU), at least 3 chunks of 16 per group (every
 // group stages the whole input patch again, and its consumer reads one more partial slab)
 inline void nv_groups(long base_blocks, int nchunk, int gmax, int* groups, int* cpg, int target, long cap = 0) {
   int g = (int)((target + base_blocks - 1) / base_blocks);
   if (cap > 0 && g > 1 && g * base_blocks > cap) --g;      // a second round of workgroups costs more than one more chunk per group
   if (g > gmax) g = gmax;
-  if (g > nchunk / 4) g = nchunk / 4;
+  if (g > nchunk / 3) g = nchunk / 3;
   if (g < 1) g = 1;
   *cpg = (nchunk + g - 1) / g;
   *groups = (nchunk + *cpg - 1) / *cpg;
@@ -936,8 +936,8 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     a.cpg = cpg; a.out = pj.out; a.out_slab_stride = (long)n * a.Ho * a.Wo * a.Cout;
     pj.slabs = groups; pj.slab_stride = a.out_slab_stride;
     a.ncu = h->ncu;
-    if ((int)si == h->nv_stamp_step && h->nv_stamps && tiles * groups <= 8192) {
-      HIP_TRY(hipMemsetAsync(h->nv_stamps, 0, sizeof(unsigned long long) * 32 * 8192, s));
+    if ((int)si == h->nv_stamp_step && h->nv_stamps && (tiles * groups <= 32768)) {
+      HIP_TRY(hipMemsetAsync(h->nv_stamps, 0, sizeof(unsigned long long) * 32 * 32768, s));
       a.stamps = h->nv_stamps; h->nv_stamp_wgs = (int)(tiles * groups);
     }
     if (st.pblock && st.front) HIP_TRY(launch_nv_fpair(a, n, s));
@@ -1028,7 +1028,7 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
     if (const char* v = getenv("D2FE_NV_SLABSUM")) h->nv_slabsum = atoi(v);
     if (const char* v = getenv("D2FE_NV_STAMP_STEP")) {
       h->nv_stamp_step = atoi(v);
-      if (!h->nv_stamps) HIP_TRY(hipMalloc(&h->nv_stamps, sizeof(unsigned long long) * 32 * 8192));
+      if (!h->nv_stamps) HIP_TRY(hipMalloc(&h->nv_stamps, sizeof(unsigned long long) * 32 * 32768));
     }
     const int nl = w->n_layers;
     auto K = [&](int i) { return i < nl ? h->nv[i].kind : -1; };

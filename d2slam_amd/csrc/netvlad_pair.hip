@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
 //   conv: M = patch pixels (12 m-tiles), K = 9 taps + 1 bias row (+ 2 zero rows), N = 16; A = (u8 - 128) / 128 read from the u8 copy in LDS; a pixel
 //   outside the conv's output map zeroes its whole A row, bias included, so the depthwise stage sees its zero padding.
 template <int NT>
-__global__ __launch_bounds__(256) void nv_fpair_kernel(NvBlockArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 7 : NT == 2 ? 5 : NT == 4 ? 4 : 2))) void nv_fpair_kernel(NvBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WD_N = nvp_wd_rec(NT), WDR = WD_N / 256;
   constexpr int NTV = NT < 4 ? NT : 4, NTH = NT / NTV;
@@ -353,43 +353,41 @@ __global__ __launch_bounds__(256) void nv_fpair_kernel(NvBlockArgs a) {
   uint8_t* U8 = reinterpret_cast<uint8_t*>(W0 + 192);      // [NVP_U8_ROWS][NVP_U8_PITCH]
   const int Cout = a.Cout, th = a.th, tw = a.tw, pw = tw >> 1;
   const int iw = tw + 2, npx = (th + 2) * iw;
-  const int tiles_x = (a.Wo + tw - 1) / tw;
+  const int tiles_x = (a.Wo + tw - 1) / tw, ntiles = tiles_x * ((a.Ho + th - 1) / th);
   const int n = blockIdx.y;
-  const int ty = (int)blockIdx.x / tiles_x;
-  const int oy0 = ty * th, ox0 = ((int)blockIdx.x - ty * tiles_x) * tw;
-  const int iy0 = oy0 - a.pt, ix0 = ox0 - a.pl;
   const int cs = a.c0_stride;
-  const int uy0 = iy0 * cs - a.c0_pt, ux0 = ix0 * cs - a.c0_pl;
   const int UH = (th + 1) * cs + 3, UW = (iw - 1) * cs + 3;
-  // ---- one batch of loads: u8 patch (4 bytes per thread at most), conv fragments, depthwise + project record, project bias --------------------------
+  // a workgroup walks a.tpw consecutive tiles: the u8 patch of the next one is in flight while this one is computed (a tile is ~3.5 us of work
+  // behind ~3.3 us of load latency), and the weights are fetched once
+  const int tpw = a.tpw > 0 ? a.tpw : 1;
+  const int t_begin = (int)blockIdx.x * tpw, t_end = min(ntiles, t_begin + tpw);
+  unsigned long long* stamp = a.stamps ? a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
+  int stamp_i = 0;
+  auto STAMP = [&]() { if (stamp && tid == 0 && stamp_i < 32) stamp[stamp_i] = wall_clock64(); ++stamp_i; };
+  STAMP();
   const uint8_t* ipx = a.img + (size_t)n * a.img_istride;
-  uint8_t ub[4];
+  // tile-independent index arithmetic: this thread's 4 bytes of the u8 copy, its 4 output pairs, its 3 conv rows, its depthwise window
+  // (y, x) pairs packed as y << 8 | x, one register each; y = 0xffff (far outside any frame) marks an entry that does not exist
+  int u_yx[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = i * 256 + tid;
     const int uy = idx / NVP_U8_PITCH, ux = idx - uy * NVP_U8_PITCH;
-    const int yy = uy0 + uy, xx = ux0 + ux;
-    const bool in = idx < NVP_U8_ROWS * NVP_U8_PITCH && uy < UH && ux < UW && yy >= 0 && yy < a.H0 && xx >= 0 && xx < a.W0;
-    ub[i] = ipx[in ? (unsigned)(yy * a.img_stride + xx) : 0u];
-    if (!in) ub[i] = 128;                           // 128 -> exactly 0 after (x - 128) / 128
+    u_yx[i] = (idx < NVP_U8_ROWS * NVP_U8_PITCH && uy < UH && ux < UW) ? (uy << 8 | ux) : (0xffff << 8);
   }
-  const float w0v = tid < 192 ? a.w0[(tid >> 6) * 128 + (tid & 63)] : 0.f;
-  float wds[WDR];
-#pragma unroll
-  for (int i = 0; i < WDR; ++i) wds[i] = a.wp[i * 256 + tid];
-  float bvv[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) bvv[t] = a.bp[t * 16 + lp];
-  // ---- output addresses (C layout of the project accumulators: row = pair 16 wave + 4 lq + r, pixel 2 px + m2) and the depthwise base ------------
-  int obase[4]; bool ok2[4];
+  int p_yx[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int P = wave * 16 + lq * 4 + r;
-    const int oy = (int)(((unsigned)P * a.inv_tw) >> 20), px = P - oy * pw;
-    const int gy = oy0 + oy, gx = ox0 + 2 * px;
-    const bool okp = P < th * pw && gy < a.Ho && gx < a.Wo;
-    obase[r] = okp ? (gy * a.Wo + gx) * Cout + lp : -1;
-    ok2[r] = okp && gx + 1 < a.Wo;
+    const int py = (int)(((unsigned)P * a.inv_tw) >> 20);
+    p_yx[r] = P < th * pw ? (py << 8 | 2 * (P - py * pw)) : (0xffff << 8);
+  }
+  int c_yx[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const int p = (wave + 4 * m) * 16 + lp;
+    const int cy = (int)(((unsigned)p * a.inv_iw) >> 20);
+    c_yx[m] = p < npx ? (cy << 8 | (p - cy * iw)) : (0xffff << 8);
   }
   int ebase;
   {
@@ -400,104 +398,131 @@ __global__ __launch_bounds__(256) void nv_fpair_kernel(NvBlockArgs a) {
   const int c0 = 4 * (lq >> 1) + 8 * (lq & 1);
   const int rd0 = nvp_row(0) + c0 * NVP_EROW + 16 * (lq >> 1) + 32 * (lq & 1) + ebase;
   const int wr0 = lp * NVP_EROW + 4 * (lp & 7) + 32 * (lp >> 3) + lq * 4;
-  // this lane's conv A rows: patch pixel (wave + 4 m) * 16 + lp -> byte offset of its tap (0, 0) in the u8 copy, or -1 outside the conv's output
-  int uoff[3];
+  uint8_t ub[4];
+  auto load_u8 = [&](int t) {
+    const int ty = t / tiles_x;
+    const int uy0 = (ty * th - a.pt) * cs - a.c0_pt, ux0 = ((t - ty * tiles_x) * tw - a.pl) * cs - a.c0_pl;
 #pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    const int p = (wave + 4 * m) * 16 + lp;
-    const int iy = (int)(((unsigned)p * a.inv_iw) >> 20), ix = p - iy * iw;
-    const int gy = iy0 + iy, gx = ix0 + ix;
-    uoff[m] = (p < npx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (iy * cs) * NVP_U8_PITCH + ix * cs : -1;
-  }
+    for (int i = 0; i < 4; ++i) {
+      const int yy = uy0 + (u_yx[i] >> 8), xx = ux0 + (u_yx[i] & 255);
+      const bool in = yy >= 0 && yy < a.H0 && xx >= 0 && xx < a.W0;
+      ub[i] = ipx[in ? (unsigned)(yy * a.img_stride + xx) : 0u];
+      if (!in) ub[i] = 128;                         // 128 -> exactly 0 after (x - 128) / 128
+    }
+  };
+  // ---- one batch of loads: first u8 patch, conv fragments, depthwise + project record, project bias ---------------------------------------------
+  if (t_begin < t_end) load_u8(t_begin);
+  const float w0v = tid < 192 ? a.w0[(tid >> 6) * 128 + (tid & 63)] : 0.f;
+  float wds[WDR];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) if (i * 256 + tid < NVP_U8_ROWS * NVP_U8_PITCH) U8[i * 256 + tid] = ub[i];
+  for (int i = 0; i < WDR; ++i) wds[i] = a.wp[i * 256 + tid];
+  float bvv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bvv[t] = a.bp[t * 16 + lp];
   if (tid < 192) W0[tid] = w0v;
 #pragma unroll
   for (int i = 0; i < WDR; ++i) WD[i * 256 + tid] = wds[i];
-  __syncthreads();
+  const float lo0 = nvp_lo(a.act0), hi0 = nvp_hi(a.act0), lo_d = nvp_lo(a.act_d), hi_d = nvp_hi(a.act_d), lo_p = nvp_lo(a.act_p), hi_p = nvp_hi(a.act_p);
+  float* op = a.out + (size_t)n * a.Ho * a.Wo * Cout;
 
-  // ---- first conv on the matrix pipe -> E rows (channel lp, pixels 4 lq .. + 3 of m-tile mt) --------------------------------------------------
-  {
-    const float lo0 = nvp_lo(a.act0), hi0 = nvp_hi(a.act0);
-    float wf[3];
+  for (int t = t_begin; t < t_end; ++t) {
+    const int ty = t / tiles_x;
+    const int oy0 = ty * th, ox0 = (t - ty * tiles_x) * tw;
+    const int iy0 = oy0 - a.pt, ix0 = ox0 - a.pl;
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) wf[ks] = W0[ks * 64 + lane];
+    for (int i = 0; i < 4; ++i) if (i * 256 + tid < NVP_U8_ROWS * NVP_U8_PITCH) U8[i * 256 + tid] = ub[i];
+    STAMP();
+    __syncthreads();          // this tile's u8 copy (and, first time round, the weights) are in LDS; everybody is done with the previous tile's E
+    STAMP();
+    if (t + 1 < t_end) load_u8(t + 1);
+
+    // ---- first conv on the matrix pipe -> E rows (channel lp, pixels 4 lq .. + 3 of m-tile mt) ------------------------------------------------
+    {
+      float wf[3];
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const bool ok = uoff[m] >= 0;
-      const uint8_t* up = U8 + (ok ? uoff[m] : 0);
-      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < 3; ++ks) wf[ks] = W0[ks * 64 + lane];
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        const int k = ks * 4 + lq;                  // tap (k / 3, k % 3) for k < 9, the bias row for k == 9
-        const int toff = k < 9 ? (k / 3) * NVP_U8_PITCH + (k % 3) : 0;
-        const float t = ((float)up[toff] - 128.0f) * 0.0078125f;
-        const float av = ok ? (k < 9 ? t : (k == 9 ? 1.f : 0.f)) : 0.f;
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wf[ks], c, 0, 0, 0);
+      for (int m = 0; m < 3; ++m) {
+        const int cy = c_yx[m] >> 8, cx = c_yx[m] & 255;
+        const int gy = iy0 + cy, gx = ix0 + cx;
+        const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const uint8_t* up = U8 + (ok ? (cy * cs) * NVP_U8_PITCH + cx * cs : 0);
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const int k = ks * 4 + lq;                  // tap (k / 3, k % 3) for k < 9, the bias row for k == 9
+          const int toff = k < 9 ? (k / 3) * NVP_U8_PITCH + (k % 3) : 0;
+          const float tv = ((float)up[toff] - 128.0f) * 0.0078125f;
+          const float av = ok ? (k < 9 ? tv : (k == 9 ? 1.f : 0.f)) : 0.f;
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wf[ks], c, 0, 0, 0);
+        }
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = nvp_clamp(c[r], lo0, hi0);
+        *reinterpret_cast<f32x4*>(E + wr0 + (wave + 4 * m) * 16) = o;
       }
-      f32x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = nvp_clamp(c[r], lo0, hi0);
-      *reinterpret_cast<f32x4*>(E + wr0 + (wave + 4 * m) * 16) = o;
     }
-  }
-  __syncthreads();
+    STAMP();
+    __syncthreads();
+    STAMP();
 
-  // ---- depthwise (pixel pairs) + project, as one chunk of nv_pblock_kernel -----------------------------------------------------------------------
-  f32x4 acc[2][NT];
+    // ---- depthwise (pixel pairs) + project, as one chunk of nv_pblock_kernel ---------------------------------------------------------------------
+    f32x4 acc[2][NT];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float lo_d = nvp_lo(a.act_d), hi_d = nvp_hi(a.act_d);
-  {
-    const float* r0 = E + rd0;
-    const float* r1 = r0 + iw;
-    const float* r2 = r1 + iw;
+      for (int tt = 0; tt < NT; ++tt) acc[m][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      const float* r0 = E + rd0;
+      const float* r1 = r0 + iw;
+      const float* r2 = r1 + iw;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const f32x4 wa = *reinterpret_cast<const f32x4*>(WD + (lq * 4 + ks) * 12);
-      const f32x4 wb = *reinterpret_cast<const f32x4*>(WD + (lq * 4 + ks) * 12 + 4);
-      const f32x4 wc = *reinterpret_cast<const f32x4*>(WD + (lq * 4 + ks) * 12 + 8);
-      const float tap[9] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3], wc[0]};
-      f32x2 d = {wc[1], wc[1]};
-      const float* rr[3] = {r0, r1, r2};
+      for (int ks = 0; ks < 4; ++ks) {
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(WD + (lq * 4 + ks) * 12);
+        const f32x4 wb = *reinterpret_cast<const f32x4*>(WD + (lq * 4 + ks) * 12 + 4);
+        const f32x4 wc = *reinterpret_cast<const f32x4*>(WD + (lq * 4 + ks) * 12 + 8);
+        const float tap[9] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3], wc[0]};
+        f32x2 d = {wc[1], wc[1]};
+        const float* rr[3] = {r0, r1, r2};
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const f32x2 A = *reinterpret_cast<const f32x2*>(rr[ky] + ks * 260);
-        const f32x2 B = *reinterpret_cast<const f32x2*>(rr[ky] + ks * 260 + 2);
-        d = __builtin_elementwise_fma(A, f32x2{tap[ky * 3], tap[ky * 3]}, d);
-        d = __builtin_elementwise_fma(f32x2{A[1], B[0]}, f32x2{tap[ky * 3 + 1], tap[ky * 3 + 1]}, d);
-        d = __builtin_elementwise_fma(B, f32x2{tap[ky * 3 + 2], tap[ky * 3 + 2]}, d);
-      }
-      d[0] = nvp_clamp(d[0], lo_d, hi_d); d[1] = nvp_clamp(d[1], lo_d, hi_d);
-      const float* wpl = WD + 256 + (ks * NTH * 64 + lane) * NTV;
+        for (int ky = 0; ky < 3; ++ky) {
+          const f32x2 A = *reinterpret_cast<const f32x2*>(rr[ky] + ks * 260);
+          const f32x2 B = *reinterpret_cast<const f32x2*>(rr[ky] + ks * 260 + 2);
+          d = __builtin_elementwise_fma(A, f32x2{tap[ky * 3], tap[ky * 3]}, d);
+          d = __builtin_elementwise_fma(f32x2{A[1], B[0]}, f32x2{tap[ky * 3 + 1], tap[ky * 3 + 1]}, d);
+          d = __builtin_elementwise_fma(B, f32x2{tap[ky * 3 + 2], tap[ky * 3 + 2]}, d);
+        }
+        d[0] = nvp_clamp(d[0], lo_d, hi_d); d[1] = nvp_clamp(d[1], lo_d, hi_d);
+        const float* wpl = WD + 256 + (ks * NTH * 64 + lane) * NTV;
 #pragma unroll
-      for (int hf = 0; hf < NTH; ++hf) {
-        float wv[NTV];
-        if constexpr (NTV == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(wpl + hf * 256); wv[0] = v[0]; wv[1] = v[1]; wv[2] = v[2]; wv[3] = v[3]; }
-        else if constexpr (NTV == 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(wpl); wv[0] = v[0]; wv[1] = v[1]; }
-        else wv[0] = wpl[0];
+        for (int hf = 0; hf < NTH; ++hf) {
+          float wv[NTV];
+          if constexpr (NTV == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(wpl + hf * 256); wv[0] = v[0]; wv[1] = v[1]; wv[2] = v[2]; wv[3] = v[3]; }
+          else if constexpr (NTV == 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(wpl); wv[0] = v[0]; wv[1] = v[1]; }
+          else wv[0] = wpl[0];
 #pragma unroll
-        for (int e = 0; e < NTV; ++e) {
-          acc[0][hf * NTV + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[0], wv[e], acc[0][hf * NTV + e], 0, 0, 0);
-          acc[1][hf * NTV + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[1], wv[e], acc[1][hf * NTV + e], 0, 0, 0);
+          for (int e = 0; e < NTV; ++e) {
+            acc[0][hf * NTV + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[0], wv[e], acc[0][hf * NTV + e], 0, 0, 0);
+            acc[1][hf * NTV + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[1], wv[e], acc[1][hf * NTV + e], 0, 0, 0);
+          }
         }
       }
     }
-  }
-  float* op = a.out + (size_t)n * a.Ho * a.Wo * Cout;
-  const float lo_p = nvp_lo(a.act_p), hi_p = nvp_hi(a.act_p);
+    STAMP();
+    // ---- store: C layout row = pair 16 wave + 4 lq + r, pixel 2 px + m2, column = channel lp of n-tile t -------------------------------------------
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (t * 16 + lp >= Cout) continue;
+    for (int r = 0; r < 4; ++r) {
+      const int gy = oy0 + (p_yx[r] >> 8), gx = ox0 + (p_yx[r] & 255);
+      if (gy >= a.Ho || gx >= a.Wo) continue;
+      const unsigned ob = (unsigned)((gy * a.Wo + gx) * Cout + lp);
 #pragma unroll
-    for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (obase[r] < 0 || (m2 == 1 && !ok2[r])) continue;
-        op[(unsigned)(obase[r] + m2 * Cout + t * 16)] = nvp_clamp(acc[m2][t][r] + bvv[t], lo_p, hi_p);
+      for (int tt = 0; tt < NT; ++tt) {
+        if (tt * 16 + lp >= Cout) continue;
+        op[ob + tt * 16] = nvp_clamp(acc[0][tt][r] + bvv[tt], lo_p, hi_p);
+        if (gx + 1 < a.Wo) op[ob + Cout + tt * 16] = nvp_clamp(acc[1][tt][r] + bvv[tt], lo_p, hi_p);
       }
+    }
+    STAMP();
   }
 }
 
@@ -609,12 +634,21 @@ static hipError_t launch_fpair_t(const NvBlockArgs& a, int n, hipStream_t s) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const long tiles = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th);
-  hipLaunchKernelGGL(k, dim3((unsigned)tiles, n, 1), dim3(256), lds, s, a);
+  const int tpw = a.tpw > 0 ? a.tpw : 1;
+  hipLaunchKernelGGL(k, dim3((unsigned)((tiles + tpw - 1) / tpw), n, 1), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 // the first block (conv from the u8 frame -> dw -> pw): a.we unused, a.wp = one pack_nv_dwproj_pair record, a.w0 = pack_nv_conv0
 hipError_t launch_nv_fpair(const NvBlockArgs& a_in, int n, hipStream_t s) {
   NvBlockArgs a = a_in;
+  {
+    // tiles per workgroup: 3 once the launch is several rounds of workgroups deep anyway (measured 1..5: 684, 668, 663, 665, 666 us for the whole
+    // 32-image NetVLAD call; D2FE_NV_FRONT_TPW forces)
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("D2FE_NV_FRONT_TPW"); force = e ? atoi(e) : 0; }
+    const long tiles = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th) * n;
+    a.tpw = force > 0 ? force : (tiles >= 16l * (a.ncu > 0 ? a.ncu : 256) ? 3 : 1);
+  }
   if (a.stride != 1 || a.tw < 2 || (a.tw & 1) || a.th < 1 || a.th * a.tw > 128 || (a.th + 2) * (a.tw + 2) > NVP_PATCH) return hipErrorInvalidValue;
   if ((a.th + 1) * a.c0_stride + 3 > NVP_U8_ROWS || (a.tw + 1) * a.c0_stride + 3 > NVP_U8_PITCH) return hipErrorInvalidValue;
   const int iw = a.tw + 2, pw = a.tw / 2;

@@ -29,6 +29,8 @@ names = ["start", "inputs issued / w0 arrived", "w0 stored", "barrier0"]
 for c in range((nst - 5) // 5):
     names += ["ch%d expand done" % c, "ch%d we stored" % c, "ch%d barrier" % c, "ch%d dw+project done" % c, "ch%d wd stored" % c]
 names += ["epilogue done"]
+if nst == 7:      # the first block (nv_fpair_kernel)
+    names = ["start", "loads arrived and stored", "barrier", "conv done", "barrier", "dw+project done", "epilogue done"]
 d = np.diff(rel, axis=1)
 for i in range(1, nst):
     print("  %-28s +%6.2f us (p10 %5.2f p90 %5.2f)   at %6.2f" % (names[i] if i < len(names) else "?", np.median(d[:, i - 1]), np.percentile(d[:, i - 1], 10),
