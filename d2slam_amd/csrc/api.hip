@@ -112,6 +112,7 @@ struct d2fe_context {
   // scheduling knobs of the fused plan, read from the environment by d2fe_load_netvlad (A/B measurements; defaults measured best):
   // workgroups per launch the hidden-channel split aims at (D2FE_NV_BLOCKS), the same for the tail kernel (D2FE_NV_TAIL_BLOCKS),
   // and the number of partial slabs from which they are summed once instead of by every consumer (D2FE_NV_SLABSUM, 0 = never)
+  int nv_front_tpw = 0, nv_nbuf = 0;       // D2FE_NV_FRONT_TPW, D2FE_NV_NBUF (0: the launchers decide)
   int nv_stamp_step = -1; unsigned long long* nv_stamps = nullptr; int nv_stamp_wgs = 0;     // D2FE_NV_STAMP_STEP (diagnostics)
   int nv_blocks_target = 512, nv_tail_blocks = 768, nv_slabsum = 3;      // the pre-projected features (input of the VLAD stage), same slab scheme
   std::vector<NvStep> nv_plan;
@@ -935,7 +936,7 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
               st.pblock ? nv_pblock_slots(a.Cin, a.Cout, h->ncu, 1) * 85 / 100 : 0);
     a.cpg = cpg; a.out = pj.out; a.out_slab_stride = (long)n * a.Ho * a.Wo * a.Cout;
     pj.slabs = groups; pj.slab_stride = a.out_slab_stride;
-    a.ncu = h->ncu;
+    a.ncu = h->ncu; a.tpw = h->nv_front_tpw; a.nbuf = h->nv_nbuf;
     if ((int)si == h->nv_stamp_step && h->nv_stamps && (tiles * groups <= 32768)) {
       HIP_TRY(hipMemsetAsync(h->nv_stamps, 0, sizeof(unsigned long long) * 32 * 32768, s));
       a.stamps = h->nv_stamps; h->nv_stamp_wgs = (int)(tiles * groups);
@@ -1026,6 +1027,9 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
     if (const char* v = getenv("D2FE_NV_BLOCKS")) { if (atoi(v) > 0) h->nv_blocks_target = atoi(v); }
     if (const char* v = getenv("D2FE_NV_TAIL_BLOCKS")) { if (atoi(v) > 0) h->nv_tail_blocks = atoi(v); }
     if (const char* v = getenv("D2FE_NV_SLABSUM")) h->nv_slabsum = atoi(v);
+    h->nv_front_tpw = 0; h->nv_nbuf = 0;
+    if (const char* v = getenv("D2FE_NV_FRONT_TPW")) h->nv_front_tpw = atoi(v);
+    if (const char* v = getenv("D2FE_NV_NBUF")) h->nv_nbuf = atoi(v);
     if (const char* v = getenv("D2FE_NV_STAMP_STEP")) {
       h->nv_stamp_step = atoi(v);
       if (!h->nv_stamps) HIP_TRY(hipMalloc(&h->nv_stamps, sizeof(unsigned long long) * 32 * 32768));

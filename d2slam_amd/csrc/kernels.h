@@ -121,7 +121,8 @@ struct NvBlockArgs {
   const float* bp;                    // project bias [Cout padded to the n-tiles]
   int act_e, act_d, act_p;
   int ncu;                            // compute units of the device (launch heuristics; 0: 256)
-  int tpw;                            // nv_fpair_kernel: consecutive tiles per workgroup (filled in by the launcher)
+  int tpw;                            // nv_fpair_kernel: consecutive tiles per workgroup (0: the launcher decides)
+  int nbuf;                           // nv_pblock_kernel: E buffers (0: the launcher decides)
   unsigned long long* stamps;         // diagnostics (D2FE_NV_STAMP_STEP): [workgroup][32] wall_clock64() phase stamps, or null
 };
 bool nv_block_supported(int cin, int chid, int cout, int stride, bool expand, int mode);

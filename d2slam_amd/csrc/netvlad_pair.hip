@@ -605,11 +605,10 @@ long nv_pblock_slots(int cin, int cout, int ncu, int nbuf) {
 }
 // E double-buffered (one barrier per chunk) when every workgroup of the launch is resident at once anyway; one buffer (two barriers per chunk,
 // 16 KB less LDS: 5-6 workgroups per CU instead of 3-4) when the launch would otherwise run in rounds.  The dispatch is never perfectly even:
-// "fits" means 85 % of the slots.  D2FE_NV_NBUF=1|2 forces.
+// "fits" means 85 % of the slots.  D2FE_NV_NBUF=1|2 (NvBlockArgs::nbuf) forces.
 template <int NT, int NK>
 static hipError_t launch_pblock_t(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
-  static int force = -1;
-  if (force < 0) { const char* e = getenv("D2FE_NV_NBUF"); force = e ? atoi(e) : 0; }
+  const int force = a.nbuf;            // D2FE_NV_NBUF, read when the network was loaded
   const long wgs = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th) * n * groups;
   const bool one = force ? force == 1 : wgs * 100 > nv_pblock_slots(a.Cin, a.Cout, a.ncu, 2) * 85;
   return one ? launch_pblock_b<NT, NK, 1>(a, n, groups, s) : launch_pblock_b<NT, NK, 2>(a, n, groups, s);
@@ -644,8 +643,7 @@ hipError_t launch_nv_fpair(const NvBlockArgs& a_in, int n, hipStream_t s) {
   {
     // tiles per workgroup: 3 once the launch is several rounds of workgroups deep anyway (measured 1..5: 684, 668, 663, 665, 666 us for the whole
     // 32-image NetVLAD call; D2FE_NV_FRONT_TPW forces)
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("D2FE_NV_FRONT_TPW"); force = e ? atoi(e) : 0; }
+    const int force = a.tpw;           // D2FE_NV_FRONT_TPW, read when the network was loaded
     const long tiles = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th) * n;
     a.tpw = force > 0 ? force : (tiles >= 16l * (a.ncu > 0 ? a.ncu : 256) ? 3 : 1);
   }

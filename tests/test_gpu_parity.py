@@ -522,6 +522,66 @@ def test_netvlad_fused_blocks_layerwise(api, orc, H, W):
     fe.close()
 
 
+@pytest.mark.parametrize("env", [{"D2FE_NV_FRONT_TPW": "3"}, {"D2FE_NV_FRONT_TPW": "4", "D2FE_NV_NBUF": "1"}, {"D2FE_NV_NBUF": "2"}])
+def test_netvlad_pair_kernel_variants(api, orc, monkeypatch, env):
+    """Launch variants of the pixel-pair kernels (netvlad_pair.hip) that the default heuristics only pick at large batches: the first block
+    walking 3 / 4 tiles per workgroup with the next tile's bytes in flight (tile counts that are not multiples of either), one / two E
+    buffers in the stride-1 blocks.  Same arithmetic, same bits as the default plan; every block output within 2e-5 of the oracle."""
+    from d2slam_amd import netvlad as nvm
+    nv = nvm.synthetic_netvlad_weights()
+    H, W = 200, 328                       # first block: 100 x 164 outputs -> tile counts not divisible by 3 or 4, odd sizes further down
+    imgs = np.stack([synth_image(H, W, 70 + s) for s in range(2)])
+    for k in ("D2FE_NV_FRONT_TPW", "D2FE_NV_NBUF"):
+        monkeypatch.delenv(k, raising=False)
+    fe0 = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
+    fe0.load_netvlad(nv)
+    base = fe0.netvlad(imgs)
+    fe0.close()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
+    fe.load_netvlad(nv)
+    got = fe.netvlad(imgs)
+    assert np.array_equal(got, base), np.abs(got - base).max()
+    refs = [orc.netvlad_forward(imgs[i], nv, return_layers=True) for i in range(2)]
+    for li in range(len(nv["layers"])):
+        g = fe.debug_netvlad_layer(li, (2,) + refs[0][1][li].shape)
+        if g is None:
+            continue
+        for i in range(2):
+            r = refs[i][1][li]
+            assert np.abs(g[i] - r).max() <= 2e-5 * max(1.0, np.abs(r).max()), (li, env)
+    fe.close()
+
+
+def test_netvlad_phase_stamps_hook(api, monkeypatch):
+    """D2FE_NV_STAMP_STEP: the block kernel of that execution-plan step writes wall_clock64() stamps per workgroup (tools/nv_stamps.py);
+    they are monotonic per workgroup and the call's result does not change."""
+    from d2slam_amd import netvlad as nvm
+    nv = nvm.synthetic_netvlad_weights()
+    H, W = 240, 320
+    imgs = np.stack([synth_image(H, W, 80 + s) for s in range(2)])
+    monkeypatch.delenv("D2FE_NV_STAMP_STEP", raising=False)
+    fe0 = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
+    fe0.load_netvlad(nv)
+    base = fe0.netvlad(imgs)
+    fe0.close()
+    for step in (0, 2):
+        monkeypatch.setenv("D2FE_NV_STAMP_STEP", str(step))
+        fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
+        fe.load_netvlad(nv)
+        got = fe.netvlad(imgs)
+        assert np.array_equal(got, base)
+        st = fe.debug_netvlad_stamps().astype(np.int64)
+        assert len(st) > 0
+        st = st[st.any(axis=1)]              # (a multi-tile first block launches fewer workgroups than it has tiles)
+        assert len(st) > 0
+        for row in st:
+            t = row[row > 0]
+            assert len(t) >= 5 and np.all(np.diff(t) >= 0), (step, row[:12])
+        fe.close()
+
+
 def test_netvlad_plans_agree(api, orc, monkeypatch):
     """The fused plan (default), the per-pixel form of the stride-1 blocks (D2FE_NV_PAIR=0), the LDS-resident block form (D2FE_NV_XBLOCK=0), no slab sums (D2FE_NV_SLABSUM=0) and one launch per
     layer (D2FE_NV_LEGACY=1) are five schedules of the same arithmetic up to summation order: all within 1e-4 of the oracle, and a batch
