@@ -34,7 +34,7 @@ __device__ __forceinline__ float nvp_clamp(float v, float lo, float hi) { return
 }  // namespace
 
 constexpr int NVP_EROW = 256, NVP_EBUF = 16 * NVP_EROW, NVP_PATCH = 192;      // patch pixels = 12 m-tiles, 3 per wave
-constexpr int NVP_U8_PITCH = 40, NVP_U8_ROWS = 24;      // first block: u8 copy of the patch's receptive field, (10 - 1) * 2 + 3 = 21 rows x 37 bytes at stride 2
+constexpr int NVP_U8_PITCH = 40, NVP_U8_ROWS = 24, NVP_U8_DUMMY = 2 * NVP_U8_PITCH + 8;      // first block: u8 copy of the patch's receptive field, (10 - 1) * 2 + 3 = 21 rows x 37 bytes at stride 2
 __host__ __device__ constexpr int nvp_we_rec(int nk) { return (nk * 64 + 16 + 255) / 256 * 256; }      // [nk/4][lane][4] (+ [lane][2]) + bias[16]
 __host__ __device__ constexpr int nvp_wd_rec(int nt) { return 256 + nt * 256; }                         // [lq][ks][12] + pad, [ks][nt/ntv][lane][ntv]
 __host__ __device__ constexpr int nvp_row(int c) { return c * NVP_EROW + 4 * (c & 7) + 32 * (c >> 3); }
@@ -398,6 +398,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 7
   const int c0 = 4 * (lq >> 1) + 8 * (lq & 1);
   const int rd0 = nvp_row(0) + c0 * NVP_EROW + 16 * (lq >> 1) + 32 * (lq & 1) + ebase;
   const int wr0 = lp * NVP_EROW + 4 * (lp & 7) + 32 * (lp >> 3) + lq * 4;
+  int toff[3];                   // byte offset of this lane group's tap in k-step ks (k = 4 ks + lq; 0 where k is not a tap)
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) { const int k = ks * 4 + lq; toff[ks] = k < 9 ? (k / 3) * NVP_U8_PITCH + (k % 3) : 0; }
   uint8_t ub[4];
   auto load_u8 = [&](int t) {
     const int ty = t / tiles_x;
@@ -419,7 +422,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 7
   float bvv[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) bvv[t] = a.bp[t * 16 + lp];
-  if (tid < 192) W0[tid] = w0v;
+  if (tid < 192) W0[tid] = (tid >> 6) * 4 + ((tid & 63) >> 4) < 9 ? w0v * 0.0078125f : w0v;       // tap rows carry the 1 / 128
+  if (tid < NVP_U8_DUMMY) U8[NVP_U8_ROWS * NVP_U8_PITCH + tid] = 128;                               // the all-128 window of pixels outside the map
 #pragma unroll
   for (int i = 0; i < WDR; ++i) WD[i * 256 + tid] = wds[i];
   const float lo0 = nvp_lo(a.act0), hi0 = nvp_hi(a.act0), lo_d = nvp_lo(a.act_d), hi_d = nvp_hi(a.act_d), lo_p = nvp_lo(a.act_p), hi_p = nvp_hi(a.act_p);
@@ -437,6 +441,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 7
     if (t + 1 < t_end) load_u8(t + 1);
 
     // ---- first conv on the matrix pipe -> E rows (channel lp, pixels 4 lq .. + 3 of m-tile mt) ------------------------------------------------
+    // A = u8 - 128 (the 1/128 of the normalisation sits in the tap rows of B: a power of two, so every product and the result are bit-identical to
+    // ((u8 - 128) / 128) * w); a pixel outside the conv's output reads the all-128 dummy window, i.e. zeros, and gets no bias
     {
       float wf[3];
 #pragma unroll
@@ -446,14 +452,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 7
         const int cy = c_yx[m] >> 8, cx = c_yx[m] & 255;
         const int gy = iy0 + cy, gx = ix0 + cx;
         const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const uint8_t* up = U8 + (ok ? (cy * cs) * NVP_U8_PITCH + cx * cs : 0);
+        const uint8_t* up = U8 + (ok ? (cy * cs) * NVP_U8_PITCH + cx * cs : NVP_U8_ROWS * NVP_U8_PITCH);
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-          const int k = ks * 4 + lq;                  // tap (k / 3, k % 3) for k < 9, the bias row for k == 9
-          const int toff = k < 9 ? (k / 3) * NVP_U8_PITCH + (k % 3) : 0;
-          const float tv = ((float)up[toff] - 128.0f) * 0.0078125f;
-          const float av = ok ? (k < 9 ? tv : (k == 9 ? 1.f : 0.f)) : 0.f;
+          float av = (float)up[toff[ks]] - 128.0f;           // k = 4 ks + lq: a tap for k < 9 (toff), the bias row for k == 9, nothing beyond
+          if (ks == 2) av = lq == 0 ? av : (lq == 1 && ok ? 1.f : 0.f);
           c = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wf[ks], c, 0, 0, 0);
         }
         f32x4 o;
@@ -628,7 +632,7 @@ bool nv_fpair_supported(int c0_cout, int c0_stride, int dw_stride, int cout) {
 }
 template <int NT>
 static hipError_t launch_fpair_t(const NvBlockArgs& a, int n, hipStream_t s) {
-  const size_t lds = sizeof(float) * ((size_t)NVP_EBUF + nvp_wd_rec(NT) + 192) + NVP_U8_ROWS * NVP_U8_PITCH;
+  const size_t lds = sizeof(float) * ((size_t)NVP_EBUF + nvp_wd_rec(NT) + 192) + NVP_U8_ROWS * NVP_U8_PITCH + NVP_U8_DUMMY;
   auto k = nv_fpair_kernel<NT>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
