@@ -1,5 +1,5 @@
-// netvlad_pair.hip -- stride-1 MobileNetV2 inverted-residual block (pw expand -> dw 3x3 -> pw project (+ residual)) of the NetVLAD trunk, one kernel
-// per block, organised around the LDS traffic of the depthwise stage (gfx950).  Reference boundary: MobileNetVLADONNX::inference,
+// netvlad_pair.hip -- the stride-1 MobileNetV2 inverted-residual blocks (pw expand -> dw 3x3 -> pw project (+ residual)) of the NetVLAD trunk and its
+// first block (conv 3x3 from the u8 frame -> dw 3x3 -> pw project), one kernel per block, organised around the LDS traffic of the depthwise stage (gfx950).  Reference boundary: MobileNetVLADONNX::inference,
 // d2frontend/include/d2frontend/CNN/mobilenetvlad_onnx.h:49-74 (one ONNX Runtime session run); the layer list is whatever d2fe_load_netvlad() got.
 //
 // Same data flow as nv_xblock_kernel (netvlad_fused.hip): block input in registers, the expanded tensor 16 hidden channels at a time through LDS,
@@ -18,7 +18,6 @@
 //     is the accumulator's initial value (bias x in-image mask in the C layout) instead of one more k-step
 //   * the residual is read first thing in the kernel, not in the epilogue
 #include <algorithm>
-#include <cstdlib>
 
 #include "kernels.h"
 
