@@ -569,13 +569,19 @@ __global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
     const float* r1[3] = {e1, e1 + iw, e1 + 2 * iw};
 #pragma unroll
     for (int kp = 0; kp < 2; ++kp) {
-      const float* wk = wd + kp * 8 + lq;
-      f32x2 d0 = {wk[144], wk[148]}, d1 = d0;
+      // this lane group's two channels (kp * 8 + lq, + 4): [tap][2] + bias[2] = 20 floats, five ds_read_b128 (pack_nv_dwproj_x) instead of 20 ds_read_b32
+      float wq[20];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wd + (lq * 2 + kp) * 20 + i * 4);
+        wq[i * 4] = v[0]; wq[i * 4 + 1] = v[1]; wq[i * 4 + 2] = v[2]; wq[i * 4 + 3] = v[3];
+      }
+      f32x2 d0 = {wq[18], wq[19]}, d1 = d0;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const f32x2 w = {wk[(ky * 3 + kx) * 16], wk[(ky * 3 + kx) * 16 + 4]};
+          const f32x2 w = {wq[(ky * 3 + kx) * 2], wq[(ky * 3 + kx) * 2 + 1]};
           d0 = __builtin_elementwise_fma(f32x2{r0[ky][kp * 8 * EP + kx], r0[ky][(kp * 8 + 4) * EP + kx]}, w, d0);
           d1 = __builtin_elementwise_fma(f32x2{r1[ky][kp * 8 * EP + kx], r1[ky][(kp * 8 + 4) * EP + kx]}, w, d1);
         }
@@ -926,6 +932,23 @@ void pack_nv_dwproj(const float* wd /*[chid][9]*/, const float* bd, const float*
   }
 }
 size_t pack_nv_dwproj_floats(int chid, int nt) { return (size_t)(chid / 16) * nvb_wd_rec(nt); }
+// the same record for nv_xblock_kernel: the depthwise part as [lane group lq][kp][tap][2] + bias[2] (20 floats per (lq, kp): channels kp*8 + lq and + 4,
+// the two halves of the kernel's v_pk_fma_f32), read as five ds_read_b128; project part unchanged
+void pack_nv_dwproj_x(const float* wd /*[chid][9]*/, const float* bd, const float* wp /*[cout][chid]*/, int cout, int chid, int nt, float* dst) {
+  pack_nv_dwproj(wd, bd, wp, cout, chid, nt, dst);
+  const int rec = nvb_wd_rec(nt);
+  for (int ch = 0; ch < chid / 16; ++ch) {
+    float* d = dst + (size_t)ch * rec;
+    for (int i = 0; i < 256; ++i) d[i] = 0.f;
+    for (int lq = 0; lq < 4; ++lq)
+      for (int kp = 0; kp < 2; ++kp)
+        for (int h = 0; h < 2; ++h) {
+          const int c = ch * 16 + kp * 8 + lq + 4 * h;
+          for (int t = 0; t < 9; ++t) d[(lq * 2 + kp) * 20 + t * 2 + h] = wd[(size_t)c * 9 + t];
+          d[(lq * 2 + kp) * 20 + 18 + h] = bd[c];
+        }
+  }
+}
 // first conv (mode 1) as B fragments [ks = 3][t = 2][lane]: k = ks*4 + (lane >> 4): k < 9 tap weight w[c][k], k == 9 the bias, else 0
 void pack_nv_conv0(const float* w /*[cout][9]*/, const float* b, int cout, float* dst /*[384]*/) {
   for (int ks = 0; ks < 3; ++ks)
