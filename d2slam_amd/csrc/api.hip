@@ -1092,6 +1092,7 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
         const int nt = nv_block_ntiles(pco);
         std::vector<float> pk(st.pblock ? pack_nv_dwproj_pair_floats(pci, nt) : pack_nv_dwproj_floats(pci, nt)), pb(nt * 16, 0.f);
         if (st.pblock) pack_nv_dwproj_pair(w->layers[li].weight, w->layers[li].bias, pwt, pco, pci, nt, pk.data());
+        else if (st.tail && nv_tail_supported(w->layers[st.l0].cin, w->proj_dim)) pack_nv_proj_t(pwt, pco, pci, nt, pk.data());
         else if (st.xblock && !st.tail) pack_nv_dwproj_x(w->layers[li].weight, w->layers[li].bias, pwt, pco, pci, nt, pk.data());
         else pack_nv_dwproj(st.tail ? nullptr : w->layers[li].weight, st.tail ? nullptr : w->layers[li].bias, pwt, pco, pci, nt, pk.data());
         for (int co = 0; co < pco; ++co) pb[co] = pbs[co];

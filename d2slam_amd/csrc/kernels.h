@@ -132,6 +132,7 @@ void pack_nv_expand(const float* w /*[chid][cin]*/, const float* b, int chid, in
 size_t pack_nv_expand_floats(int chid, int cin);
 void pack_nv_dwproj(const float* wd /*[chid][9] or null*/, const float* bd, const float* wp /*[cout][chid]*/, int cout, int chid, int nt, float* dst);
 size_t pack_nv_dwproj_floats(int chid, int nt);
+void pack_nv_proj_t(const float* wp, int cout, int chid, int nt, float* dst);                 // nv_tail_kernel's project fragments (transposed expand GEMM)
 void pack_nv_dwproj_x(const float* wd, const float* bd, const float* wp, int cout, int chid, int nt, float* dst);     // nv_xblock_kernel's layout of the depthwise part
 void pack_nv_expand_tail(const float* w, const float* b, int chid, int cin, float* dst);    // K order of nv_tail_kernel
 bool nv_tail_supported(int cin, int cout);

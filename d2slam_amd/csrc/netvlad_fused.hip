@@ -720,13 +720,12 @@ hipError_t launch_nv_xblock(const NvBlockArgs& a_in, int n, int groups, hipStrea
 template <int NJ, int NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void nv_tail_kernel(NvBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int CIN = NJ * 16, KSE1 = CIN / 4 + 1, WE_N = nvb_we_rec(CIN), WD_N = nvb_wd_rec(NT), EPW = 48;
+  constexpr int CIN = NJ * 16, KSE1 = CIN / 4 + 1, WE_N = nvb_we_rec(CIN), WD_N = nvb_wd_rec(NT);
   constexpr int WER = WE_N / 256, WDR = WD_N / 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane >> 4, lp = lane & 15;
   float* WE = lds;                    // [2][WE_N]
   float* WD = WE + 2 * WE_N;          // [2][WD_N]
-  float* Ew = WD + 2 * WD_N + wave * 16 * EPW;   // [16][EPW] per wave
   const int p0 = (int)blockIdx.x * 128 + wave * 32;
   const int nchunk = a.Chid >> 4;
   const int ch0 = blockIdx.z * a.cpg, ch1 = min(nchunk, ch0 + a.cpg);
@@ -781,23 +780,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float wv = wl[(j * 4 + e) * 64];
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[0][j][e], wv, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[1][j][e], wv, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xr[0][j][e], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xr[1][j][e], c1, 0, 0, 0);
       }
     {
-      const float wv = wl[(KSE1 - 1) * 64];          // bias step
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(one[0], wv, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(one[1], wv, c1, 0, 0, 0);
+      const float wv = wl[(KSE1 - 1) * 64];          // bias step: bias[hidden] (k = 0 row) x mask[pixel]
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, one[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, one[1], c1, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { c0[r] = nvf_clamp(c0[r], lo_e, hi_e); c1[r] = nvf_clamp(c1[r], lo_e, hi_e); }
-    // C layout (channel = lp, pixels lq*4 + r) -> wave-private LDS -> A layout (pixel = lp, channel = 4 ks + lq)
-    *reinterpret_cast<f32x4*>(Ew + lp * EPW + lq * 4) = c0;
-    *reinterpret_cast<f32x4*>(Ew + lp * EPW + 16 + lq * 4) = c1;
+    // The expand GEMM is evaluated TRANSPOSED (A = weights, B = pixels): its C layout -- lane (pixel lp, group lq) holds hidden channels 4 lq + r --
+    // is already the A layout of the project GEMM's k-step r (pack_nv_proj_t orders the project fragments accordingly): no trip through LDS
     const float* wpl = WD + b * WD_N + 256 + lane;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const float d0 = Ew[(ks * 4 + lq) * EPW + lp], d1 = Ew[(ks * 4 + lq) * EPW + 16 + lp];
+      const float d0 = c0[ks], d1 = c1[ks];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const float wv = wpl[(ks * NT + t) * 64];
@@ -844,7 +842,7 @@ void pack_nv_expand_tail(const float* w /*[chid][cin]*/, const float* b, int chi
 bool nv_tail_supported(int cin, int cout) { return (cin == 112 || cin == 128) && nv_block_ntiles(cout) == 8; }
 hipError_t launch_nv_tail(const NvBlockArgs& a, int groups, hipStream_t s) {
   if (a.P * (long)std::max(a.Cin, a.Cout) >= (1l << 31) || a.in_slabs > 1) return hipErrorInvalidValue;
-  const size_t lds = sizeof(float) * (2 * (size_t)nvb_we_rec(a.Cin) + 2 * (size_t)nvb_wd_rec(8) + 4 * 16 * 48);
+  const size_t lds = sizeof(float) * (2 * (size_t)nvb_we_rec(a.Cin) + 2 * (size_t)nvb_wd_rec(8));
   auto k = a.Cin == 112 ? nv_tail_kernel<7, 8> : nv_tail_kernel<8, 8>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -932,6 +930,21 @@ void pack_nv_dwproj(const float* wd /*[chid][9]*/, const float* bd, const float*
   }
 }
 size_t pack_nv_dwproj_floats(int chid, int nt) { return (size_t)(chid / 16) * nvb_wd_rec(nt); }
+// the record of nv_tail_kernel (no depthwise part): project fragments [ks][t][lane] = Wp[t*16 + (lane & 15)][chunk*16 + (lane >> 4) * 4 + ks] -- lane group lq
+// owns hidden channels 4 lq .. 4 lq + 3 of the chunk (the C layout of the transposed expand GEMM), k-step ks takes the ks-th of them
+void pack_nv_proj_t(const float* wp /*[cout][chid]*/, int cout, int chid, int nt, float* dst) {
+  const int rec = nvb_wd_rec(nt);
+  for (int ch = 0; ch < chid / 16; ++ch) {
+    float* d = dst + (size_t)ch * rec;
+    for (int i = 0; i < 256; ++i) d[i] = 0.f;
+    for (int ks = 0; ks < 4; ++ks)
+      for (int t = 0; t < nt; ++t)
+        for (int l = 0; l < 64; ++l) {
+          const int co = t * 16 + (l & 15), k = ch * 16 + (l >> 4) * 4 + ks;
+          d[256 + (ks * nt + t) * 64 + l] = co < cout ? wp[(size_t)co * chid + k] : 0.f;
+        }
+  }
+}
 // the same record for nv_xblock_kernel: the depthwise part as [lane group lq][kp][tap][2] + bias[2] (20 floats per (lq, kp): channels kp*8 + lq and + 4,
 // the two halves of the kernel's v_pk_fma_f32), read as five ds_read_b128; project part unchanged
 void pack_nv_dwproj_x(const float* wd /*[chid][9]*/, const float* bd, const float* wp /*[cout][chid]*/, int cout, int chid, int nt, float* dst) {
