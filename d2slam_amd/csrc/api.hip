@@ -1798,6 +1798,39 @@ long d2fe_debug_pack_wino(const float* weight, int cout, int cin, float* out, lo
   return (long)n;
 }
 
+// Host-side weight packing of the NetVLAD block kernels, callable without a GPU (tests/test_netvlad_pack_cpu.py):
+//   kind 0 expand record of nv_pblock_kernel (pack_nv_expand_pair)      kind 1 depthwise + project record of nv_pblock / nv_fpair (pack_nv_dwproj_pair)
+//   kind 2 expand record of nv_xblock_kernel (pack_nv_expand_perm)      kind 3 depthwise + project record of nv_xblock_kernel (pack_nv_dwproj_x)
+//   kind 4 expand record of nv_tail_kernel (pack_nv_expand_tail)        kind 5 project record of nv_tail_kernel (pack_nv_proj_t)
+// we [chid][cin], be [chid], wd [chid][9], bd [chid], wp [cout][chid]; returns the number of floats written or <0.
+long d2fe_debug_pack_netvlad(int kind, const float* we, const float* be, const float* wd, const float* bd, const float* wp, int cin, int chid,
+                             int cout, float* out, long max_floats) {
+  if (!out || cin < 8 || (cin & 7) || chid < 16 || (chid & 15) || cout < 1) return fail(D2FE_ERR_INVALID, "bad argument");
+  const int nt = nv_block_ntiles(cout);
+  if (nt < 0) return fail(D2FE_ERR_UNSUPPORTED, "cout");
+  size_t n = 0;
+  switch (kind) {
+    case 0: n = pack_nv_expand_pair_floats(chid, cin); break;
+    case 1: n = pack_nv_dwproj_pair_floats(chid, nt); break;
+    case 2: if (!nv_xblock_supported(cin, chid, cout, 1)) return fail(D2FE_ERR_UNSUPPORTED, "shape"); n = pack_nv_expand_perm_floats(chid, cin); break;
+    case 3: case 5: n = pack_nv_dwproj_floats(chid, nt); break;
+    case 4: if (!nv_tail_supported(cin, cout)) return fail(D2FE_ERR_UNSUPPORTED, "shape"); n = pack_nv_expand_floats(chid, cin); break;
+    default: return fail(D2FE_ERR_INVALID, "kind");
+  }
+  if ((long)n > max_floats) return fail(D2FE_ERR_TRUNCATED, "destination too small");
+  if (((kind == 0 || kind == 2 || kind == 4) && (!we || !be)) || ((kind == 1 || kind == 3) && (!wd || !bd || !wp)) || (kind == 5 && !wp))
+    return fail(D2FE_ERR_INVALID, "null weights");
+  switch (kind) {
+    case 0: pack_nv_expand_pair(we, be, chid, cin, out); break;
+    case 1: pack_nv_dwproj_pair(wd, bd, wp, cout, chid, nt, out); break;
+    case 2: pack_nv_expand_perm(we, be, chid, cin, out); break;
+    case 3: pack_nv_dwproj_x(wd, bd, wp, cout, chid, nt, out); break;
+    case 4: pack_nv_expand_tail(we, be, chid, cin, out); break;
+    case 5: pack_nv_proj_t(wp, cout, chid, nt, out); break;
+  }
+  return (long)n;
+}
+
 // One 3x3 layer through the Winograd kernels, host buffers in and out (layer-level parity tests and timing; not a product path).
 int d2fe_debug_conv3x3_wino(d2fe_handle h, const float* in, int n, int H, int W, int cin, const float* weight, const float* bias,
                             int cout, int pool, int relu, float* out, int iters, float* ms_per_launch) {

@@ -415,6 +415,10 @@ D2FE_API long d2fe_debug_netvlad_stamps(d2fe_handle h, unsigned long long* dst, 
  * layer-level parity tests (tests/test_wino.py) and tools/; the product path is d2fe_superpoint_extract*. */
 /* The host-side weight transform of that mode (U = G g G^T, packed [32-channel group][k-step][row i][lane][4]); needs no GPU.
  * Returns the number of floats written (16 * cin * cout rounded up to 64 channels). */
+/* The host-side weight packing of the NetVLAD block kernels (needs no GPU; tests/test_netvlad_pack_cpu.py): kind 0..5 = expand / depthwise + project
+ * records of nv_pblock_kernel, nv_xblock_kernel, nv_tail_kernel (see csrc/api.hip).  Returns the number of floats written or <0. */
+D2FE_API long d2fe_debug_pack_netvlad(int kind, const float* we, const float* be, const float* wd, const float* bd, const float* wp, int cin, int chid,
+                                      int cout, float* out, long max_floats);
 D2FE_API long d2fe_debug_pack_wino(const float* weight /*[cout][cin][3][3]*/, int cout, int cin, float* out, long max_floats);
 D2FE_API int d2fe_debug_conv3x3_wino(d2fe_handle h, const float* in, int n, int H, int W, int cin, const float* weight,
                                      const float* bias, int cout, int pool, int relu, float* out, int iters, float* ms_per_launch);
