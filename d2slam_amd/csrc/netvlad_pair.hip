@@ -401,15 +401,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 7
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) { const int k = ks * 4 + lq; toff[ks] = k < 9 ? (k / 3) * NVP_U8_PITCH + (k % 3) : 0; }
   uint8_t ub[4];
+  unsigned ub_in = 0;            // bit i: byte i lies inside the frame.  The loaded values are not touched before they are stored to LDS one tile later:
+                                 // a select right after the load would wait for it on the spot and expose the latency the prefetch is there to hide
   auto load_u8 = [&](int t) {
     const int ty = t / tiles_x;
     const int uy0 = (ty * th - a.pt) * cs - a.c0_pt, ux0 = ((t - ty * tiles_x) * tw - a.pl) * cs - a.c0_pl;
+    ub_in = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int yy = uy0 + (u_yx[i] >> 8), xx = ux0 + (u_yx[i] & 255);
       const bool in = yy >= 0 && yy < a.H0 && xx >= 0 && xx < a.W0;
       ub[i] = ipx[in ? (unsigned)(yy * a.img_stride + xx) : 0u];
-      if (!in) ub[i] = 128;                         // 128 -> exactly 0 after (x - 128) / 128
+      ub_in |= in ? 1u << i : 0u;
     }
   };
   // ---- one batch of loads: first u8 patch, conv fragments, depthwise + project record, project bias ---------------------------------------------
@@ -425,6 +428,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 7
   if (tid < NVP_U8_DUMMY) U8[NVP_U8_ROWS * NVP_U8_PITCH + tid] = 128;                               // the all-128 window of pixels outside the map
 #pragma unroll
   for (int i = 0; i < WDR; ++i) WD[i * 256 + tid] = wds[i];
+  // the bias counts as arrived from here on: first used inside the tile loop, it would otherwise make the compiler wait for EVERY outstanding memory
+  // operation (vmcnt(0): the prefetched bytes and the previous pair's stores) before each pair of output stores
+#pragma unroll
+  for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(bvv[t]));
+  auto store_u8 = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i * 256 + tid < NVP_U8_ROWS * NVP_U8_PITCH) U8[i * 256 + tid] = (ub_in >> i) & 1 ? ub[i] : (uint8_t)128;       // 128 -> exactly 0 after x - 128
+  };
+  if (t_begin < t_end) store_u8();
   const float lo0 = nvp_lo(a.act0), hi0 = nvp_hi(a.act0), lo_d = nvp_lo(a.act_d), hi_d = nvp_hi(a.act_d), lo_p = nvp_lo(a.act_p), hi_p = nvp_hi(a.act_p);
   float* op = a.out + (size_t)n * a.Ho * a.Wo * Cout;
 
@@ -432,8 +445,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 7
     const int ty = t / tiles_x;
     const int oy0 = ty * th, ox0 = (t - ty * tiles_x) * tw;
     const int iy0 = oy0 - a.pt, ix0 = ox0 - a.pl;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) if (i * 256 + tid < NVP_U8_ROWS * NVP_U8_PITCH) U8[i * 256 + tid] = ub[i];
     STAMP();
     __syncthreads();          // this tile's u8 copy (and, first time round, the weights) are in LDS; everybody is done with the previous tile's E
     STAMP();
@@ -512,6 +523,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 7
       }
     }
     STAMP();
+    // the next tile's bytes go to LDS BEFORE this tile's output stores are issued (the conv stage, the last reader of the u8 copy, is behind every wave's
+    // second barrier): loads and stores share one in-order counter, so a wait for the prefetched bytes placed after the stores would also wait for them
+    store_u8();                                 // (unconditional: behind the last tile it rewrites the same bytes; a condition equal to the loop's own lets the
+    __builtin_amdgcn_sched_barrier(0);          //  compiler sink the LDS writes onto the back edge, behind the global stores)
     // ---- store: C layout row = pair 16 wave + 4 lq + r, pixel 2 px + m2, column = channel lp of n-tile t -------------------------------------------
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
