@@ -316,7 +316,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     const int cs = a.out_cstride, cs4 = cs * 4;
     const int n32 = T.cb * NT;
     const int co0 = n32 * 32 + (lane & 31);
-    const float bias0 = a.bias[co0], bias1 = NT == 2 ? a.bias[co0 + 32] : 0.f;
+    float bias0 = a.bias[co0], bias1 = NT == 2 ? a.bias[co0 + 32] : 0.f;
     // fast path (item inside the image, all of its channels real): buffer stores, wave-uniform offsets on the SALU
     const bool full = T.by * 8 + 8 <= aH && T.bx * 16 + 16 <= aW && (n32 + NT) * 32 <= a.cout_real && !(ABL & 4);
     const int Wo = POOL ? (aW >> 1) : aW, Ho = POOL ? (aH >> 1) : aH;
@@ -350,6 +350,9 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     if (dyn && tid == 0) *claim_slot = inn_claim;          // the index claimed at the start of this item (one barrier serves both)
     __syncthreads();
     if (dyn) inn = *claim_slot;
+    // both biases count as arrived from here on (they were requested before the exchange): first used between the stores of the finish phase, the
+    // second one would otherwise cost a vmcnt(0) there -- loads and stores share one in-order counter, so that wait also sits out the stores just issued
+    asm volatile("" : "+v"(bias0), "+v"(bias1));
     mark(trace_item, 8, 2);
     // bias, ReLU, pool and the stores of one tile (register r) and channel half nt; y[pp][b] = output pixel (2 ty + pp, 2 tx + b)
     auto emit_tile = [&](auto r_c, int nt, float (&y)[2][2]) {
