@@ -16,6 +16,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 
 
+# per-file extras.  conv_wino.hip: the persistent kernels claim their next work item with one returning atomicAdd per item whose result is consumed an
+# item later; the atomic optimizer's wave-wide rewrite would wait for it immediately (see the kernel)
+EXTRA_FLAGS = {"conv_wino.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -41,7 +46,7 @@ def build(force=False, verbose=False):
 
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

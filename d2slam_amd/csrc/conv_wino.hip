@@ -347,7 +347,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
       }
     }
     mark(trace_item, 8, 1);
-    if (dyn && tid == 0) *claim_slot = inn_claim;          // the index claimed at the start of this item (one barrier serves both)
+    if (dyn && tid == 0) *claim_slot = 2 * tstride + inn_claim;          // the index claimed at the start of this item (one barrier serves both)
     __syncthreads();
     if (dyn) inn = *claim_slot;
     // both biases count as arrived from here on (they were requested before the exchange): first used between the stores of the finish phase, the
@@ -537,7 +537,10 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
 #pragma unroll 1
   for (int item = 0; icur < total; ++item) {
     inn = inxt + tstride;
-    if (dyn && tid == 0) inn_claim = 2 * tstride + atomicAdd(a.work_ctr, 1);      // in flight during the K loop, published in the epilogue
+    // in flight during the K loop, published in the epilogue.  The raw return value is not touched before that (an add here would wait for the
+    // round trip on the spot), and this file is compiled with the AMDGPU atomic optimizer off: its wave-wide reduction reads the result back with
+    // v_readfirstlane right behind the atomic -- a 1-2 us stall of wave 0 at the start of every item
+    if (dyn && tid == 0) inn_claim = atomicAdd(a.work_ctr, 1);
     if constexpr (FUSE) {
       __syncthreads();                                           // the patch (staged by the prologue / the previous epilogue) is complete
       read_d(0);
