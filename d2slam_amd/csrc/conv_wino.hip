@@ -219,6 +219,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
   };
   int trace_item = 0;
   int inn = 0, inn_claim = 0;            // the item after `nxt`: its index, and thread 0's claim in flight
+  float bias0 = 0.f, bias1 = 0.f;        // the current item's biases (channel lane & 31 of its one or two 32-channel halves), requested at the item's start
   // FUSE: the frame bytes of the next item (see the staging below)
   unsigned char* u8p = reinterpret_cast<unsigned char*>(wlds + 8 * CHF);     // [12][20] bytes behind the patch
   const int fr = tid / 20, fc = tid - fr * 20;
@@ -316,7 +317,6 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     const int cs = a.out_cstride, cs4 = cs * 4;
     const int n32 = T.cb * NT;
     const int co0 = n32 * 32 + (lane & 31);
-    float bias0 = a.bias[co0], bias1 = NT == 2 ? a.bias[co0 + 32] : 0.f;
     // fast path (item inside the image, all of its channels real): buffer stores, wave-uniform offsets on the SALU
     const bool full = T.by * 8 + 8 <= aH && T.bx * 16 + 16 <= aW && (n32 + NT) * 32 <= a.cout_real && !(ABL & 4);
     const int Wo = POOL ? (aW >> 1) : aW, Ho = POOL ? (aH >> 1) : aH;
@@ -350,8 +350,8 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     if (dyn && tid == 0) *claim_slot = 2 * tstride + inn_claim;          // the index claimed at the start of this item (one barrier serves both)
     __syncthreads();
     if (dyn) inn = *claim_slot;
-    // both biases count as arrived from here on (they were requested before the exchange): first used between the stores of the finish phase, the
-    // second one would otherwise cost a vmcnt(0) there -- loads and stores share one in-order counter, so that wait also sits out the stores just issued
+    // both biases count as arrived from here on: first used between the stores of the finish phase, the second one would otherwise cost a vmcnt(0)
+    // there -- loads and stores share one in-order counter, so that wait also sits out the stores just issued
     asm volatile("" : "+v"(bias0), "+v"(bias1));
     mark(trace_item, 8, 2);
     // bias, ReLU, pool and the stores of one tile (register r) and channel half nt; y[pp][b] = output pixel (2 ty + pp, 2 tx + b)
@@ -541,6 +541,11 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     // round trip on the spot), and this file is compiled with the AMDGPU atomic optimizer off: its wave-wide reduction reads the result back with
     // v_readfirstlane right behind the atomic -- a 1-2 us stall of wave 0 at the start of every item
     if (dyn && tid == 0) inn_claim = atomicAdd(a.work_ctr, 1);
+    {      // the biases of this item: older than every load of the K loop, so they have arrived long before the epilogue asks (requested there, they were
+           // the YOUNGEST loads in flight and their wait also sat out the next item's prefetch)
+      const int co0 = cur.cb * NT * 32 + (lane & 31);
+      bias0 = a.bias[co0]; bias1 = NT == 2 ? a.bias[co0 + 32] : 0.f;
+    }
     if constexpr (FUSE) {
       __syncthreads();                                           // the patch (staged by the prologue / the previous epilogue) is complete
       read_d(0);
