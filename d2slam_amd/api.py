@@ -83,7 +83,7 @@ EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_creat
            "d2fe_half_move_cols", "d2fe_half_image_compact_device", "d2fe_remap_matches_device",
            "d2fe_half_image_filter", "d2fe_undistort", "d2fe_undistort_device", "d2fe_db_create", "d2fe_db_destroy",
            "d2fe_db_ntotal", "d2fe_db_add", "d2fe_db_search", "d2fe_db_query_gated", "d2fe_quantize_int8", "d2fe_dequantize_int8",
-           "d2fe_debug_read", "d2fe_debug_netvlad_layer", "d2fe_debug_netvlad_stamps", "d2fe_debug_pack_wino", "d2fe_debug_pack_netvlad", "d2fe_debug_conv3x3_wino", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read",
+           "d2fe_debug_read", "d2fe_debug_netvlad_layer", "d2fe_debug_netvlad_stamps", "d2fe_debug_pack_wino", "d2fe_debug_pack_netvlad", "d2fe_debug_netvlad_tile", "d2fe_debug_conv3x3_wino", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read",
            "d2fe_prepare_gray", "d2fe_prepare_gray_device", "d2fe_gen_cylinder_map", "d2fe_gen_cylinder_map_device", "d2fe_gen_pinhole_map", "d2fe_gen_pinhole_map_device",
            "d2fe_lk_frame_create", "d2fe_lk_frame_create_device", "d2fe_lk_frame_destroy", "d2fe_lk_frame_read_level",
            "d2fe_lk_track", "d2fe_lk_track_batch", "d2fe_detect_fast_by_region", "d2fe_good_features_to_track"]

@@ -1798,6 +1798,17 @@ long d2fe_debug_pack_wino(const float* weight, int cout, int cin, float* out, lo
   return (long)n;
 }
 
+// Tile shape the NetVLAD block launchers pick for an Ho x Wo output map (no GPU needed; tests/test_netvlad_pack_cpu.py sweeps it against the kernels' limits):
+// kind 0 nv_pblock_kernel (stride 1), kind 1 nv_fpair_kernel (first block; c0_stride = stride of the first conv), kind 2 nv_xblock_kernel (stride = 1 or 2).
+int d2fe_debug_netvlad_tile(int kind, int Ho, int Wo, int stride, int* th, int* tw) {
+  if (!th || !tw || Ho < 1 || Wo < 1 || stride < 1 || stride > 2) return fail(D2FE_ERR_INVALID, "bad argument");
+  if (kind == 0) nv_pblock_tile(Ho, Wo, th, tw, 0);
+  else if (kind == 1) nv_pblock_tile(Ho, Wo, th, tw, stride);
+  else if (kind == 2) nv_xblock_tile(Ho, Wo, stride, th, tw);
+  else return fail(D2FE_ERR_INVALID, "kind");
+  return D2FE_OK;
+}
+
 // Host-side weight packing of the NetVLAD block kernels, callable without a GPU (tests/test_netvlad_pack_cpu.py):
 //   kind 0 expand record of nv_pblock_kernel (pack_nv_expand_pair)      kind 1 depthwise + project record of nv_pblock / nv_fpair (pack_nv_dwproj_pair)
 //   kind 2 expand record of nv_xblock_kernel (pack_nv_expand_perm)      kind 3 depthwise + project record of nv_xblock_kernel (pack_nv_dwproj_x)

@@ -415,6 +415,9 @@ D2FE_API long d2fe_debug_netvlad_stamps(d2fe_handle h, unsigned long long* dst, 
  * layer-level parity tests (tests/test_wino.py) and tools/; the product path is d2fe_superpoint_extract*. */
 /* The host-side weight transform of that mode (U = G g G^T, packed [32-channel group][k-step][row i][lane][4]); needs no GPU.
  * Returns the number of floats written (16 * cin * cout rounded up to 64 channels). */
+/* Tile shape the NetVLAD block launchers pick for an Ho x Wo output map (needs no GPU): kind 0 stride-1 blocks, 1 the first block (stride = the first
+ * conv's), 2 nv_xblock_kernel (stride 1 or 2). */
+D2FE_API int d2fe_debug_netvlad_tile(int kind, int Ho, int Wo, int stride, int* th, int* tw);
 /* The host-side weight packing of the NetVLAD block kernels (needs no GPU; tests/test_netvlad_pack_cpu.py): kind 0..5 = expand / depthwise + project
  * records of nv_pblock_kernel, nv_xblock_kernel, nv_tail_kernel (see csrc/api.hip).  Returns the number of floats written or <0. */
 D2FE_API long d2fe_debug_pack_netvlad(int kind, const float* we, const float* be, const float* wd, const float* bd, const float* wp, int cin, int chid,

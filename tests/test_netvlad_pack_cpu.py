@@ -166,3 +166,24 @@ def test_unsupported_shapes_are_refused(lib):
     assert lib.d2fe_debug_pack_netvlad(0, _p(w), _p(w), None, None, None, 12, 48, 8, _p(out), C.c_long(out.size)) < 0      # cin not a multiple of 8
     assert lib.d2fe_debug_pack_netvlad(9, _p(w), _p(w), None, None, None, 8, 48, 8, _p(out), C.c_long(out.size)) < 0
     assert lib.d2fe_debug_pack_netvlad(4, _p(w), _p(w), None, None, None, 8, 48, 8, _p(out), C.c_long(out.size)) < 0       # not a tail shape
+
+
+def test_tile_shapes_respect_the_kernels_limits(lib):
+    """The launchers' tile choice for every output map from 1 x 1 to 130 x 170 (and the shipped 240 x 320 / 200 x 400 ones): the pixel-pair kernels need
+    an even width, <= 64 pairs and a patch of <= 192 pixels (first block: the u8 receptive field of the patch inside its 24 x 40 byte LDS copy);
+    nv_xblock_kernel <= 128 outputs and a patch of <= 192 (stride 1) / 576 (stride 2) pixels.  A launcher refusing its own tile is an error at run time."""
+    th, tw = C.c_int(), C.c_int()
+    sizes = [(h, w) for h in list(range(1, 41)) + [60, 75, 100, 120, 130] for w in list(range(1, 41)) + [50, 80, 100, 125, 160, 170]] + [(240, 320), (200, 400)]
+    for ho, wo in sizes:
+        assert lib.d2fe_debug_netvlad_tile(0, ho, wo, 1, C.byref(th), C.byref(tw)) == 0
+        assert tw.value % 2 == 0 and tw.value >= 2 and th.value >= 1
+        assert th.value * tw.value <= 128 and (th.value + 2) * (tw.value + 2) <= 192
+        for cs in (1, 2):
+            assert lib.d2fe_debug_netvlad_tile(1, ho, wo, cs, C.byref(th), C.byref(tw)) == 0
+            assert tw.value % 2 == 0 and th.value * tw.value <= 128 and (th.value + 2) * (tw.value + 2) <= 192
+            assert (th.value + 1) * cs + 3 <= 24 and (tw.value + 1) * cs + 3 <= 40
+        for s_ in (1, 2):
+            assert lib.d2fe_debug_netvlad_tile(2, ho, wo, s_, C.byref(th), C.byref(tw)) == 0
+            assert th.value * tw.value <= 128
+            assert ((th.value - 1) * s_ + 3) * ((tw.value - 1) * s_ + 3) <= (192 if s_ == 1 else 576)
+    assert lib.d2fe_debug_netvlad_tile(7, 10, 10, 1, C.byref(th), C.byref(tw)) < 0
