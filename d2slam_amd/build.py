@@ -28,25 +28,36 @@ def _hipcc():
     return "hipcc"
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=None):
+    lib = lib or LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
+DEV_LIB = os.path.join(LIBDIR, "libd2fe_hip_dev.so")     # -DD2FE_DEVTOOLS: phase stamps, ablation switches, d2fe_debug_* exports
+
+
+def build(force=False, verbose=False, dev=False):
+    lib = DEV_LIB if dev else LIB
+    if not force and not needs_build(lib):
+        return lib
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj_dev" if dev else "obj")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
 
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, x)) for x in HEADERS)
+    hdr_t = max(hdr_t, os.path.getmtime(os.path.abspath(__file__)))
+
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        # incremental: an object newer than its source, every header and this script is kept
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(os.path.join(CSRC, src)), hdr_t):
+            return obj
+        cmd = [hipcc] + FLAGS + (["-DD2FE_DEVTOOLS"] if dev else []) + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -58,12 +69,12 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(cc, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="-f" in sys.argv, verbose=True))
+    print(build(force="-f" in sys.argv, verbose=True, dev="--dev" in sys.argv))

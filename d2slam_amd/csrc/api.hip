@@ -91,6 +91,7 @@ struct d2fe_context {
   struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; bool bad = false; };
   std::map<std::array<long, 6>, GraphEntry> graphs;
   int ncu = 256;               // compute units of cfg.device_id, read once by d2fe_create (ConvArgs::ncu)
+  unsigned long long* match_stamps = nullptr;   // development builds: [4096][16] phase stamps of the last d2fe_match_batch_device launch
   int32_t* match_stats = nullptr;   // [4] matcher counters: [0] queries that took the exact fallback scan (MatchArgs::stats)
   int* work_ctrs = nullptr;    // one work-item counter per Winograd layer, zeroed at the start of every network pass (ConvArgs::work_ctr)
   bool wino_dynamic = true;    // D2FE_WINO_DYNAMIC=0: static round-robin split of the work items
@@ -129,7 +130,7 @@ struct d2fe_context {
   std::deque<MatchSlot> match_slots;     // deque: growing it never relocates the slots other threads are using
   std::mutex match_mu;
   // device-API matcher scratch (cand4), one per caller stream: calls on different streams may overlap on the GPU
-  struct MatchScratch { hipStream_t stream = nullptr; int32_t* cand4 = nullptr; size_t bytes = 0; };
+  struct MatchScratch { hipStream_t stream = nullptr; int32_t* cand4 = nullptr; size_t bytes = 0; int npairs = 0; };
   std::deque<MatchScratch> m_scratch;
   // profiling (HIP events on the launch stream)
   int prof_mode = 0;
@@ -545,7 +546,7 @@ void d2fe_destroy(d2fe_handle h) {
   for (Tensor* t : {&h->a1a, &h->a1b, &h->a2a, &h->a2b, &h->a3a, &h->a3b, &h->a4a, &h->a4b, &h->aPD, &h->logits, &h->draw, &h->semi, &h->a4b2, &h->logits2, &h->draw2})
     if (t->p) hipFree(t->p);
   for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
-  for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->s_img, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->work_ctrs, (void*)h->match_stats, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc,
+  for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->s_img, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->work_ctrs, (void*)h->match_stats, (void*)h->match_stamps, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc,
                   (void*)h->pca_comp_t, (void*)h->pca_mean})
     if (p) hipFree(p);
   nv_free(h);
@@ -1589,13 +1590,18 @@ int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* str
   d2fe_context::MatchScratch* sc = nullptr;
   for (auto& e : h->m_scratch) if (e.stream == s) { sc = &e; break; }
   if (!sc) { h->m_scratch.emplace_back(); sc = &h->m_scratch.back(); sc->stream = s; }
-  const size_t need = sizeof(int32_t) * 4 * 2 * (size_t)mb->max_n * mb->npairs;
-  if (need > sc->bytes) {
+  // [arrival tickets | records]; the tickets are zero between launches (the kernel's last workgroup per pair resets its own), so a scratch
+  // sized for more pairs serves any smaller batch
+  const int tp = mb->npairs > sc->npairs ? mb->npairs : sc->npairs;
+  const size_t need = match_scratch_bytes(tp, 0) + sizeof(int32_t) * 8 * (size_t)mb->max_n * mb->npairs;
+  if (need > sc->bytes || mb->npairs > sc->npairs) {
     HIP_TRY(hipStreamSynchronize(s));      // the only work that can still read the old scratch is on this stream
     if (sc->cand4) hipFree(sc->cand4);
-    sc->cand4 = nullptr; sc->bytes = 0;
-    HIP_TRY(hipMalloc(&sc->cand4, need));
-    sc->bytes = need;
+    sc->cand4 = nullptr; sc->bytes = 0; sc->npairs = 0;
+    const size_t want = need > sc->bytes ? need : sc->bytes;
+    HIP_TRY(hipMalloc(&sc->cand4, want));
+    HIP_TRY(hipMemset(sc->cand4, 0, want));
+    sc->bytes = want; sc->npairs = tp;
   }
   MatchArgs m;
   m.a = mb->d_a; m.b = mb->d_b; m.pts_a = mb->d_pts_a; m.pts_b = mb->d_pts_b;
@@ -1603,7 +1609,14 @@ int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* str
   m.npairs = mb->npairs; m.dim = mb->dim; m.max_n = mb->max_n; m.mode = mb->mode;
   m.ratio = mb->ratio; m.radius = mb->radius;
   m.q_idx = mb->d_q_idx; m.t_idx = mb->d_t_idx; m.dist = mb->d_dist; m.n_out = mb->d_n_out;
-  m.cand4 = sc->cand4; m.stats = h->match_stats;
+  match_scratch_carve(sc->cand4, sc->npairs, &m); m.stats = h->match_stats; m.ncu = h->ncu;
+#ifdef D2FE_DEVTOOLS
+  if (getenv("D2FE_MATCH_STAMPS") && (long)((mb->max_n + 31) / 32) * 2 * mb->npairs <= 4096) {
+    if (!h->match_stamps) HIP_TRY(hipMalloc(&h->match_stamps, sizeof(unsigned long long) * 16 * 4096));
+    HIP_TRY(hipMemsetAsync(h->match_stamps, 0, sizeof(unsigned long long) * 16 * 4096, s));
+    m.stamps = h->match_stamps;
+  }
+#endif
   { ProfScope ps(h, D2FE_PROF_MATCH, s); HIP_TRY(launch_match(m, s)); }
   return D2FE_OK;
 }
@@ -1655,7 +1668,7 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
     pin = ms.pin;
   }
   struct Release { d2fe_context* h; int slot; ~Release() { std::lock_guard<std::mutex> lk(h->match_mu); h->match_slots[slot].busy = false; } } release{h, slot};
-  // device layout (words): a | b | pts_a | pts_b | meta {a_off, b_off, a_cnt, b_cnt, pad x4} | n_out, pad x7 | dist | q | t | cand4
+  // device layout (words): a | b | pts_a | pts_b | meta {a_off, b_off, a_cnt, b_cnt, arrival ticket (0), pad x3} | n_out, pad x7 | dist | q | t | cand4
   // -- the inputs are one contiguous run (ONE H2D from the slot's pinned mirror), the outputs another (ONE D2H, one synchronisation)
   const size_t w_in = fa + fb + (use_pts ? 2 * (size_t)(na + nb) : 0) + 8;
   float* d_a = reinterpret_cast<float*>(buf);
@@ -1693,6 +1706,8 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
   m.a_off = d_meta; m.b_off = d_meta + 1; m.a_cnt = d_meta + 2; m.b_cnt = d_meta + 3;
   m.npairs = 1; m.dim = dim; m.max_n = max_n; m.mode = mode; m.ratio = ratio; m.radius = use_pts ? radius : -1.0;
   m.q_idx = d_q; m.t_idx = d_t; m.dist = d_dist; m.n_out = d_nout; m.cand4 = d_c4; m.stats = h->match_stats;
+  m.ncu = h->ncu;
+  m.ticket = d_meta + 4;      // a zero word of the meta block: uploaded with the inputs, so zero at every launch
   if (rc == D2FE_OK) chk(launch_match(m, s), "launch_match");
   if (pin) {
     // pinned mirror of the output run, behind the inputs' mirror
@@ -1927,6 +1942,18 @@ int d2fe_debug_graph_count(d2fe_handle h, int* rejected) {
   if (rejected) *rejected = bad;
   return n;
 }
+
+#ifdef D2FE_DEVTOOLS
+/* development builds: the wall_clock64() phase stamps [workgroup][16] of the last d2fe_match_batch_device launch made with D2FE_MATCH_STAMPS set */
+D2FE_API long d2fe_debug_match_stamps(d2fe_handle h, unsigned long long* dst, long max_wgs) {
+  if (!h || !dst || !h->match_stamps) return fail(D2FE_ERR_NOT_READY, "no stamped launch yet (D2FE_MATCH_STAMPS)");
+  hipSetDevice(h->cfg.device_id);
+  const long nw = max_wgs < 4096 ? max_wgs : 4096;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(dst, h->match_stamps, sizeof(unsigned long long) * 16 * nw, hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(D2FE_ERR_HIP, "D2H");
+  return nw;
+}
+#endif
 
 long d2fe_match_fallback_rows(d2fe_handle h, int reset, long* full_scans) {
   if (!h) return fail(D2FE_ERR_INVALID, "null handle");

@@ -3,6 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Development instrumentation is compiled out of the product library: `python -m d2slam_amd.build --dev` builds
+// lib/libd2fe_hip_dev.so with -DD2FE_DEVTOOLS (phase stamps, ablation switches, the d2fe_debug_* exports of include/d2fe_debug.h).
+#ifdef D2FE_DEVTOOLS
+#define D2FE_STAMP(buf, wg, i) do { if ((buf) && threadIdx.x == 0) (buf)[(size_t)(wg) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define D2FE_STAMP(buf, wg, i) do {} while (0)
+#endif
+
 namespace d2fe {
 
 // ---- conv stack -----------------------------------------------------------------------------------
@@ -196,11 +204,16 @@ struct MatchArgs {
   int npairs, dim, max_n, mode;
   double ratio, radius;
   int32_t* q_idx; int32_t* t_idx; float* dist; int32_t* n_out;
-  // scratch: per pair, per direction, per row: 4 candidate indices
+  // scratch: per pair, per direction, per row one record {nn index, d0 bits, d1 bits, inverse dictionary}
   int32_t* cand4;   // [npairs][2][max_n][4]
-  int32_t* stats = nullptr;   // optional: [0] += queries whose 2-NN came from the exact fallback scan (match.hip)
-  int no_fallback = 0;        // D2FE_MATCH_NOFALLBACK=1 (timing experiments only): skip the saturation test
+  int32_t* ticket;  // [npairs] arrival counters, ZERO before the first launch on this scratch (the kernel leaves them zero)
+  int32_t* stats = nullptr;   // optional: [0] += queries whose 2-NN came from the exact scan of every row, [1] += candidates re-ranked beyond two per query (match.hip)
+  int ncu = 0;                // compute units of the device (0: 256): launch shape
+  unsigned long long* stamps = nullptr;   // development builds (-DD2FE_DEVTOOLS) only: [workgroup][16] wall_clock64() phase stamps
 };
 hipError_t launch_match(const MatchArgs& m, hipStream_t s);
+inline size_t match_scratch_bytes(int npairs, int max_n) { return sizeof(int32_t) * (((size_t)npairs + 15) / 16 * 16 + 8 * (size_t)max_n * npairs); }
+// carves the zero-initialised scratch [tickets | records]
+inline void match_scratch_carve(void* base, int npairs, MatchArgs* m) { m->ticket = static_cast<int32_t*>(base); m->cand4 = m->ticket + ((size_t)npairs + 15) / 16 * 16; }
 
 }  // namespace d2fe
