@@ -25,6 +25,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The frames-in-flight pipe gives every lane two HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
+# streams that share a queue serialise.  Must be set before the HIP runtime initialises; recorded in the JSON line (`env_overrides`).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# lanes in flight per frames-per-submit for the batch curve (measured: tools/pipe_probe.py; more lanes than this do not pay)
+LANES_FOR = {1: 4, 2: 4, 4: 4, 8: 3, 16: 2, 32: 2}
+REFUSED_ENV = ("D2FE_ABLATE", "D2FE_MATCH_NOFALLBACK")     # switches that make results wrong or parity unproven: never inside a benchmark
 
 H, W, CAP = 480, 640, 200
 CONV1B_FLOP_PER_IMG = 2.0 * H * W * 64 * 64 * 9          # 22.65 GFLOP (SURVEY.md section 8a layer table)
@@ -43,6 +49,8 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f16x2", "wino"], default=os.environ.get("D2FE_BENCH_PRECISION", "wino"),
                     help="wino: fp32, 3x3 layers as Winograd F(2x2,3x3) on the fp32 MFMA pipe (headline); f32: direct convolutions, "
                          "bitwise equal to the oracle's fmaf chains; f16x2: fp16 hi/lo split operands")
+    ap.add_argument("--lanes", type=int, default=0, help="submits in flight of the frames-in-flight pipe (0: LANES_FOR[frames])")
+    ap.add_argument("--no-batch-curve", action="store_true", help="skip the batch curve (stereo fps at 1, 2, 4, 8, 16, 32 stereo frames per submit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-netvlad", action="store_true", help="time BASELINE configs[1] (SuperPoint + match only) as `value`")
@@ -66,6 +74,9 @@ def main():
     ap.add_argument("--latency-calls", type=int, default=300)
     ap.add_argument("--latency-only", action="store_true", help="print only the single-call latency leg (A/B runs: D2FE_GRAPH=0, D2FE_PINNED=0)")
     args = ap.parse_args()
+    for k in REFUSED_ENV:
+        if os.environ.get(k):
+            raise SystemExit("%s is set: that switch changes what the kernels compute; bench.py refuses to time it" % k)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # a bare `python bench.py --gpus N`: re-launch this command line as N ranks (one process per GPU) under torch.distributed.run;
@@ -344,13 +355,46 @@ def main():
                     n_match=n_match, breakdown=breakdown, NI=NI, NP=NP, F=F, gated=gated, exch=exch, fallback_rows=fallback_rows)
 
     use_nv = not args.no_netvlad
-    primary = run_mode(args.precision, True, netvlad=use_nv)
-    legs = {}
-    if not args.single_mode:
-        legs["configs1"] = run_mode(args.precision, False, netvlad=False, steps=max(5, args.steps // 2))
-        for om in ("f32", "f16x2", "wino"):
-            if om != args.precision:
-                legs[om] = run_mode(om, False, netvlad=use_nv, steps=max(5, args.steps // 2))
+    solo = None
+    batch_curve = None
+    device_resident = None
+    if world == 1:
+        # N = 1: `value` is timed through the frames-in-flight pipe (include/d2fe.h, d2fe_pipe_*): host frames in, host results out.  The
+        # device-API step above (frames uploaded on a copy stream, results left in HBM) is kept as a labelled extra and for the per-stage breakdown
+        lanes = args.lanes or LANES_FOR.get(args.frames, 2)
+        primary = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, args.steps, args.warmup, local_rank, rank, netvlad=use_nv)
+        legs = {}
+        if not args.single_mode:
+            legs["configs1"] = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, max(5, args.steps // 2), 2, local_rank, rank, netvlad=False)
+            for om in ("f32", "f16x2", "wino"):
+                if om != args.precision:
+                    legs[om] = run_pipe(torch, api, weights, nv_weights, om, args.frames, lanes, max(5, args.steps // 2), 2, local_rank, rank, netvlad=use_nv)
+            dr = run_mode(args.precision, True, netvlad=use_nv, steps=max(5, args.steps // 2))
+            device_resident = {"value": round(dr["value"], 2), "unit": "stereo_frames/s", "ms_per_step": round(dr["ms_per_step"], 3),
+                               "workload": "the same step through the device API on one handle: frames uploaded on a copy stream inside the timed region, keypoints / "
+                                           "descriptors / matches left in HBM (round 3's headline configuration; no D2H)", "breakdown": dr["breakdown"], "n_kp": dr["n_kp"], "NI": dr["NI"], "NP": dr["NP"], "roofline_nv": dr["roofline_nv"]}
+        if not args.no_batch_curve and not args.single_mode:
+            batch_curve = []
+            for Fc in (1, 2, 4, 8, 16, 32):
+                for Kc in sorted({1, LANES_FOR[Fc]}):
+                    if Fc == args.frames and Kc == lanes:
+                        r = primary
+                    else:
+                        alone = Fc == args.frames and Kc == 1      # the step with ONE submit in flight: every kernel has the device to itself
+                        r = run_pipe(torch, api, weights, nv_weights, args.precision, Fc, Kc, max(12, min(400, int(700 / Fc))), max(2 * Kc, 4), local_rank, rank, netvlad=use_nv,
+                                     light=not alone)
+                        if alone:
+                            solo = r
+                    batch_curve.append({"stereo_frames_per_submit": Fc, "submits_in_flight": Kc, "stereo_fps": round(r["value"], 1), "ms_per_submit": round(r["ms_per_step"], 4),
+                                        "host_ms_per_submit_call": round(r["host_submit_ms"], 4)})
+    else:
+        primary = run_mode(args.precision, True, netvlad=use_nv)
+        legs = {}
+        if not args.single_mode:
+            legs["configs1"] = run_mode(args.precision, False, netvlad=False, steps=max(5, args.steps // 2))
+            for om in ("f32", "f16x2", "wino"):
+                if om != args.precision:
+                    legs[om] = run_mode(om, False, netvlad=use_nv, steps=max(5, args.steps // 2))
 
     cpu_baseline = None
     parity = None
@@ -359,8 +403,11 @@ def main():
         parity = run_parity_check(primary, weights, nv_weights if use_nv else None, args.precision)
 
     disagreement = None
+    disagreement_fast = None
     if rank == 0 and world == 1 and "f32" in legs and args.precision == "wino":
         disagreement = mode_disagreement(primary["sel"], legs["f32"]["sel"], primary["F"])
+        if "f16x2" in legs:
+            disagreement_fast = mode_disagreement(legs["f16x2"]["sel"], legs["f32"]["sel"], primary["F"])
 
     latency = None
     if rank == 0 and world == 1 and not args.single_mode and not args.no_latency:
@@ -399,17 +446,42 @@ def main():
                                    + "matchKNN L<->R and L<->prevL"
                                    + ("; + one RCCL all-gather of exchange blocks, device NetVLAD gate, cross-agent matchKNN vs every remote frame" if world > 1 else ""),
                        "frames_per_step_per_gpu": F, "images_per_step_per_gpu": NI, "match_pairs_per_step_per_gpu": NP,
-                       "h2d_in_timed_region": not args.no_h2d, "async_tail": bool(args.async_tail or (use_nv and args.overlap)),
-                       "netvlad_overlaps_superpoint_tail": bool(use_nv and args.overlap), "max_keypoints": CAP, "postproc": "B",
+                       "api": ("d2fe_pipe_submit / d2fe_pipe_wait (include/d2fe.h): host frames in (pinned), host results out (pinned), %d submits in flight"
+                               % primary["lanes"]) if world == 1 else "device API on one handle per rank (d2fe_*_device) + torch.distributed collectives",
+                       "h2d_in_timed_region": True if world == 1 else not args.no_h2d,
+                       "d2h_in_timed_region": world == 1,
+                       "d2h_bytes_per_step": primary.get("d2h_bytes") if world == 1 else 0,
+                       "delivered": "keypoints, scores, descriptors, counts, NetVLAD descriptors and both match lists of every frame land in host memory inside the timed "
+                                    "region (the reference's contract ends in host std::vectors, superpoint_tensorrt.cpp:172-180, loop_cam.cpp:619-645)" if world == 1 else
+                                    "results stay in HBM for the cross-agent step (the N = 1 line times the host-delivered form)",
+                       "submits_in_flight": primary.get("lanes"), "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "async_tail": bool(args.async_tail or (use_nv and args.overlap)) if world > 1 else False,
+                       "netvlad_overlaps_superpoint_tail": bool(use_nv and args.overlap) if world > 1 else "NetVLAD runs on the lane's second stream beside SuperPoint",
+                       "max_keypoints": CAP, "postproc": "B",
                        "precision": args.precision, "netvlad": use_nv,
                        "weights": "seeded random-init SuperPoint / MobileNetVLAD stand-in (no checkpoints in the reference tree)"},
             "sp_tflops_algorithmic": round(SP_FLOP_PER_IMG * 2 * value / 1e12, 2),
             "avg_keypoints_per_image": round(primary["n_kp"], 1), "avg_matches_per_pair": round(primary["n_match"], 1),
-            "matcher_queries_past_first_4_candidates_per_step": round(primary["fallback_rows"][0], 2),
+            "matcher_candidates_reranked_beyond_two_per_query_per_step": round(primary["fallback_rows"][0], 2),
             "matcher_exact_scan_rows_per_step": round(primary["fallback_rows"][1], 2),
+            "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("D2FE_", "GPU_MAX_HW_QUEUES", "HIP_", "HSA_", "ROCR_", "AMD_"))},
             "roofline": primary["roofline"], "roofline_netvlad": primary["roofline_nv"], "cpu_baseline": cpu_baseline, "parity": parity,
             "mode_parity": PAR[args.precision],
         }
+        if solo and solo.get("roofline") and primary.get("lanes", 1) > 1:
+            # the kernel's own roofline fraction: measured with one submit in flight (same step, same frames, HIP events on the launch stream); with several
+            # submits in flight a launch shares the device with the other lanes' launches, so its duration says nothing about the kernel
+            shared = primary["roofline"]
+            out["roofline"] = dict(solo["roofline"], measured="HIP events over a timed region of %d submits of the same step with ONE submit in flight (the `batch_curve` point "
+                                   "%d x 1, %.1f stereo fps): the launch has the device to itself" % (solo["steps"], solo["F"], solo["value"]),
+                                   in_timed_region_of_value={"avg_launch_ms": shared["avg_launch_ms"], "launches": shared["launches"], "frac_executed": shared["frac_executed"],
+                                                             "note": "with %d submits in flight the launch overlaps the other lanes' NetVLAD / post-processing / copy work" % primary["lanes"]})
+        if device_resident and device_resident.get("roofline_nv"):
+            # NetVLAD by itself on the device (the device-API leg queues it in front of SuperPoint on one stream); in the pipe it runs on the lane's second
+            # stream underneath SuperPoint's full-device launches, where its wall time is SuperPoint's
+            out["roofline_netvlad"] = dict(device_resident["roofline_nv"], measured="the device-API leg of this run (`device_resident`): the sequence alone on its stream",
+                                           in_timed_region_of_value={"ms_per_call": (primary.get("roofline_nv") or {}).get("ms_per_call"),
+                                                                     "note": "beside SuperPoint on the lane's second stream: hidden under it"})
         if primary["gated"]:
             out["netvlad_gate"] = primary["gated"]
         if primary["exch"]:
@@ -426,14 +498,24 @@ def main():
             out[names[k]] = e
         if disagreement:
             out["wino_vs_exact_on_bench_frames"] = disagreement
+        if disagreement_fast:
+            out["f16x2_vs_exact_on_bench_frames"] = disagreement_fast
+        if batch_curve:
+            out["batch_curve"] = {"what": "stereo fps of the same step (H2D, SuperPoint L+R, NetVLAD L, matchKNN L<->R and L<->previous L, D2H of everything) against the stereo frames "
+                                          "per submit, through d2fe_pipe_*; submits_in_flight = 1 is the synchronous single-call form (the way the reference calls the path, "
+                                          "loop_cam.cpp:609-616), the other line keeps that many submits in flight on separate streams", "points": batch_curve}
+        if device_resident:
+            out["device_resident"] = {k: device_resident[k] for k in ("value", "unit", "ms_per_step", "workload")}
         if latency:
             out["latency"] = latency
         if quad:
             out["quadcam"] = {k: quad[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "avg_keypoints_per_image", "avg_matches_per_pair", "roofline")}
-        b = primary["breakdown"]
+        b = primary["breakdown"] or (device_resident or {}).get("breakdown")
         if b:
             out["stage_ms"] = b
             n_kp = primary["n_kp"]
+            if not primary["breakdown"]:
+                NI, NP = device_resident["NI"], device_resident["NP"]
 
             def _gbps(nbytes, ms):
                 return {"ms_per_launch": ms, "algorithmic_bytes": int(nbytes), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
@@ -441,11 +523,99 @@ def main():
             out["hbm_kernels"] = {
                 "softmax_cand_kernel": _gbps(65 * (H // 8) * (W // 8) * 4 * NI, b.get("softmax_cand")),
                 "sample_b_kernel": _gbps(n_kp * NI * (4 * 1024 + 1024), b.get("sample")),
-                "match_prefilter+finalize": _gbps(2 * CAP * 256 * 4 * NP, b.get("match")),
+                "match_kernel": dict(_gbps(2 * CAP * 256 * 4 * NP, b.get("match")) or {}, pairs_per_launch=NP,
+                                     mfma_tflops=round(2 * 2.0 * CAP * CAP * 256 * NP / (b.get("match") * 1e-3) / 1e12, 2) if b.get("match") else None,
+                                     note="two distance strips per pair (one per direction): 2 x 2 x na x nb x 256 FLOP on v_mfma_f32_16x16x4_f32"),
             }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pipe_frames(F, rank):
+    """two alternating host frame sets for the pipe, [2 sets][L|R][F][H][W] u8: consecutive frames are pairs (scene, the scene after a small camera
+    motion), so L_f <-> L_(f-1) is a real temporal match for odd f; set 1 = set 0 after a further motion (F = 1: the temporal partner is the other set)"""
+    from d2slam_amd.synth import synth_stereo
+    host = np.empty((2, 2, F, H, W), np.uint8)
+    for f in range(F):
+        l, r = synth_stereo(H, W, seed=rank * 1000 + f // 2)
+        if f & 1:
+            l, r = np.roll(l, (1, 2), (0, 1)), np.roll(r, (1, 2), (0, 1))
+        host[0, 0, f], host[0, 1, f] = l, r
+        host[1, 0, f], host[1, 1, f] = np.roll(l, (2, 3), (0, 1)), np.roll(r, (2, 3), (0, 1))
+    return host
+
+
+def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup, local_rank, rank, netvlad=True, light=False):
+    """`steps` submits of F stereo frames through the frames-in-flight pipe with `lanes` submits in flight: the timed region holds, per submit, the H2D of
+    the 2F frames from pinned memory, SuperPoint on them, NetVLAD of the F left images, ONE matcher launch (L<->R, L<->previous L) and the D2H of every
+    result into pinned memory.  Timing: barrier-free single process (N = 1), perf_counter around exactly `steps` submits + the waits for all of them."""
+    prec = {"f32": api.PREC_F32, "f16x2": api.PREC_F16X2, "wino": api.PREC_F32_WINO}[precision]
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=1, precision=prec, device_id=local_rank))
+    fe.load_superpoint(weights)
+    if netvlad:
+        fe.load_netvlad(nv_weights)
+    host = torch.from_numpy(pipe_frames(F, rank)).pin_memory()
+    pipe = api.StereoPipe(fe, lanes=lanes, frames=F, width=W, height=H, cap=CAP, netvlad=netvlad, ratio=0.8, pinned_input=True)
+    base, per_set, per_side = host.data_ptr(), 2 * F * H * W, F * H * W
+
+    def submit(i):
+        o = base + (i & 1) * per_set
+        return pipe.submit_ptr(o, o + per_side)
+
+    def drive(n, start):
+        tk = []
+        th = 0.0
+        for i in range(n):
+            if i >= lanes:
+                pipe.wait_raw(tk[i - lanes])
+            ta = time.perf_counter(); tk.append(submit(start + i)); th += time.perf_counter() - ta
+        for t in tk[-lanes:]:
+            pipe.wait_raw(t)
+        return tk, th
+    warmup = max(warmup, 2)
+    warmup += warmup & 1                       # an even number of submits: the timed region starts on frame set 0
+    drive(warmup, 0)
+    torch.cuda.synchronize()
+    if not light:
+        pipe.profile_enable(1)
+    t0 = time.perf_counter()
+    tk, th = drive(steps, 0)
+    elapsed = time.perf_counter() - t0
+    prof = pipe.profile_read() if not light else None
+    if not light:
+        pipe.profile_enable(0)
+    fb = fe.match_fallback_rows(reset=True, full=True)
+    NI, NP = 2 * F, 2 * F
+    res = dict(steps=steps, value=F * steps / elapsed, ms_per_step=elapsed / steps * 1e3, host_submit_ms=th / steps * 1e3, lanes=lanes, F=F, NI=NI, NP=NP, gated=None, exch=None,
+               breakdown=None, fallback_rows=(fb[0] / float(steps + warmup), fb[1] / float(steps + warmup)), roofline=None, roofline_nv=None)
+    if not light:
+        # one more submit of frame set 0 right behind one of set 1: what this mode selected and matched (parity / mode comparison)
+        t1 = submit(1); pipe.wait_raw(t1)
+        o = pipe.wait(submit(0))
+        cnt = o["n_kp"].copy()
+        kidx = (o["kps_xy"][:, :, 1].astype(np.int64) * W + o["kps_xy"][:, :, 0].astype(np.int64)).astype(np.int32)
+        k0 = int(cnt[0])
+        res["first"] = (o["kps_xy"][0, :k0].copy(), o["scores"][0, :k0].copy(), o["desc"][0, :k0].copy())
+        res["gfirst"] = o["netvlad"][0].copy() if netvlad else None
+        res["sel"] = {"kidx": kidx, "cnt": cnt, "mq": np.concatenate([o["lr_q"], o["prev_q"]]).copy(), "mt": np.concatenate([o["lr_t"], o["prev_t"]]).copy(),
+                      "mn": np.concatenate([o["lr_n"], o["prev_n"]]).copy(), "a_row": list(range(F)) + list(range(F)),
+                      "b_row": [F + f for f in range(F)] + [None] + list(range(F - 1))}
+        res["n_kp"] = float(cnt.mean()); res["n_match"] = float(res["sel"]["mn"].mean())
+        res["d2h_bytes"] = int(4 * (NI * CAP * 259 + F * (fe.netvlad_dim if netvlad else 0) + NI + 2 * F + 3 * 2 * F * CAP))
+        c1b_ms, c1b_n = prof["conv1b"]
+        res["roofline"] = conv1b_roofline(precision, c1b_ms / max(c1b_n, 1), c1b_n, NI, True)
+        nv_ms, nv_n = prof["netvlad"]
+        if netvlad and nv_n:
+            t = nv_ms / nv_n
+            ach = NV_FLOP_PER_IMG * F / (t * 1e-3) / 1e12
+            res["roofline_nv"] = {"kernel": "NetVLAD launch sequence (MobileNetV2-0.35 trunk + NetVLAD head, d2slam_amd/csrc/netvlad*.hip)",
+                                  "bound": "mfma", "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
+                                  "ms_per_call": round(t, 4), "images_per_call": F, "algorithmic_flop_per_call": NV_FLOP_PER_IMG * F,
+                                  "note": "fp32 MFMA (v_mfma_f32_16x16x4_f32) + VALU depthwise; HIP events around the whole sequence on the lane's NetVLAD stream, "
+                                          "which runs BESIDE that lane's SuperPoint launches (the figure includes what the two sequences cost each other)"}
+    pipe.close(); fe.close()
+    return res
 
 
 def mode_disagreement(a, b, F):
@@ -462,6 +632,8 @@ def mode_disagreement(a, b, F):
     m_tot = m_diff = lr_tot = lr_diff = 0
     for p in range(len(a["mn"])):
         ia, ib = a["a_row"][p], a["b_row"][p]        # rows of the count / raster-index arrays; [2F, 3F) = the previous step's left images
+        if ib is None:                               # pipe: frame 0's temporal partner lives in the previous submit's block
+            continue
 
         def pairs(m):
             n = int(m["mn"][p])

@@ -73,6 +73,19 @@ class _MatchBatch(C.Structure):
                 ("d_q_idx", C.c_void_p), ("d_t_idx", C.c_void_p), ("d_dist", C.c_void_p), ("d_n_out", C.c_void_p)]
 
 
+class _PipeConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("lanes", C.c_int32), ("frames", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("cap", C.c_int32), ("netvlad", C.c_int32), ("match_lr", C.c_int32), ("match_prev", C.c_int32), ("pinned_input", C.c_int32),
+                ("ratio", C.c_double), ("radius_lr", C.c_double), ("radius_prev", C.c_double), ("cu_partition", C.c_int32), ("netvlad_inline", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
+class _PipeResult(C.Structure):
+    _fields_ = [("frames", C.c_int32), ("cap", C.c_int32), ("desc_dim", C.c_int32), ("netvlad_dim", C.c_int32),
+                ("kps_xy", C.c_void_p), ("scores", C.c_void_p), ("desc", C.c_void_p), ("n_kp", C.c_void_p), ("netvlad", C.c_void_p),
+                ("lr_q", C.c_void_p), ("lr_t", C.c_void_p), ("lr_dist", C.c_void_p), ("lr_n", C.c_void_p),
+                ("prev_q", C.c_void_p), ("prev_t", C.c_void_p), ("prev_dist", C.c_void_p), ("prev_n", C.c_void_p)]
+
+
 _lib = None
 
 EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_create", "d2fe_destroy",
@@ -86,7 +99,9 @@ EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_creat
            "d2fe_debug_read", "d2fe_debug_netvlad_layer", "d2fe_debug_netvlad_stamps", "d2fe_debug_pack_wino", "d2fe_debug_pack_netvlad", "d2fe_debug_netvlad_tile", "d2fe_debug_conv3x3_wino", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read",
            "d2fe_prepare_gray", "d2fe_prepare_gray_device", "d2fe_gen_cylinder_map", "d2fe_gen_cylinder_map_device", "d2fe_gen_pinhole_map", "d2fe_gen_pinhole_map_device",
            "d2fe_lk_frame_create", "d2fe_lk_frame_create_device", "d2fe_lk_frame_destroy", "d2fe_lk_frame_read_level",
-           "d2fe_lk_track", "d2fe_lk_track_batch", "d2fe_detect_fast_by_region", "d2fe_good_features_to_track"]
+           "d2fe_lk_track", "d2fe_lk_track_batch", "d2fe_detect_fast_by_region", "d2fe_good_features_to_track",
+           "d2fe_pipe_default_config", "d2fe_pipe_create", "d2fe_pipe_destroy", "d2fe_pipe_lanes", "d2fe_pipe_submit", "d2fe_pipe_wait",
+           "d2fe_pipe_profile_enable", "d2fe_pipe_profile_read"]
 
 
 def _preload_hip_runtime():
@@ -199,6 +214,16 @@ def load_library():
                                                    C.c_void_p, C.c_int, C.c_void_p]
         lib.d2fe_good_features_to_track.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p,
                                                     C.c_int, C.c_void_p]
+        lib.d2fe_pipe_default_config.argtypes = [C.c_void_p]
+        lib.d2fe_pipe_default_config.restype = None
+        lib.d2fe_pipe_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.d2fe_pipe_destroy.argtypes = [C.c_void_p]
+        lib.d2fe_pipe_destroy.restype = None
+        lib.d2fe_pipe_lanes.argtypes = [C.c_void_p]
+        lib.d2fe_pipe_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+        lib.d2fe_pipe_wait.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        lib.d2fe_pipe_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        lib.d2fe_pipe_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -622,6 +647,83 @@ class FrontEnd:
         mb = _MatchBatch(d_a, d_b, d_pts_a, d_pts_b, d_a_off, d_b_off, d_a_cnt, d_b_cnt, npairs, dim, max_n, mode,
                          ratio, radius, d_q, d_t, d_dist, d_n)
         _check(self._lib.d2fe_match_batch_device(self._h, C.byref(mb), stream))
+
+
+class StereoPipe:
+    """Frames in flight (include/d2fe.h, d2fe_pipe_*): the per-frame work of D2Frontend::processStereoframe (SuperPoint on both images, NetVLAD on
+    the left one, matchKNN L<->R and L<->previous L) for `frames` stereo frames per submit with up to `lanes` submits in flight.
+    submit() enqueues and returns a ticket; wait() returns views into the lane's pinned result block (copy what must outlive 2 * lanes submits)."""
+
+    def __init__(self, fe: FrontEnd, lanes=4, frames=1, width=640, height=480, cap=None, netvlad=True, match_lr=True, match_prev=True,
+                 ratio=0.8, radius_lr=-1.0, radius_prev=-1.0, pinned_input=False, cu_partition=False, netvlad_inline=False):
+        self._lib = fe._lib
+        self._fe = fe           # the pipe borrows the handle's weights
+        c = _PipeConfig()
+        self._lib.d2fe_pipe_default_config(C.byref(c))
+        c.lanes, c.frames, c.width, c.height = int(lanes), int(frames), int(width), int(height)
+        c.cap = int(cap or fe.cfg.max_keypoints)
+        c.netvlad, c.match_lr, c.match_prev, c.pinned_input = int(bool(netvlad)), int(bool(match_lr)), int(bool(match_prev)), int(bool(pinned_input))
+        c.ratio, c.radius_lr, c.radius_prev = float(ratio), float(radius_lr), float(radius_prev)
+        c.cu_partition = int(bool(cu_partition)); c.netvlad_inline = int(bool(netvlad_inline))
+        self._p = C.c_void_p()
+        _check(self._lib.d2fe_pipe_create(fe.handle, C.byref(c), C.byref(self._p)))
+        self.lanes, self.frames, self.width, self.height = int(lanes), int(frames), int(width), int(height)
+        self._res = _PipeResult()
+
+    def close(self):
+        if getattr(self, "_p", None) and self._p.value:
+            self._lib.d2fe_pipe_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def profile_enable(self, mode):
+        _check(self._lib.d2fe_pipe_profile_enable(self._p, int(mode)))
+
+    def profile_read(self):
+        ms = (C.c_float * len(PROF_STAGES))(); n = (C.c_int32 * len(PROF_STAGES))()
+        _check(self._lib.d2fe_pipe_profile_read(self._p, ms, n))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(PROF_STAGES)}
+
+    def submit_ptr(self, left_ptr, right_ptr, stride=None, image_stride=None):
+        """raw host addresses (e.g. of pinned torch tensors)"""
+        t = C.c_int64()
+        _check(self._lib.d2fe_pipe_submit(self._p, C.c_void_p(left_ptr), C.c_void_p(right_ptr), int(stride or self.width),
+                                          int(image_stride or self.width * self.height), C.byref(t)))
+        return int(t.value)
+
+    def submit(self, left, right):
+        """left, right: u8 [frames, H, W] (or [H, W] when frames == 1)"""
+        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+        self._keep = (left, right)
+        return self.submit_ptr(left.ctypes.data, right.ctypes.data)
+
+    def wait_raw(self, ticket):
+        _check(self._lib.d2fe_pipe_wait(self._p, C.c_int64(ticket), C.byref(self._res)))
+        return self._res
+
+    def wait(self, ticket):
+        """dict of numpy VIEWS into the pinned result block"""
+        r = self.wait_raw(ticket)
+        F, cap, D, G = r.frames, r.cap, r.desc_dim, r.netvlad_dim
+
+        def view(ptr, shape, dt):
+            if not ptr:
+                return None
+            n = int(np.prod(shape))
+            buf = (C.c_float * n).from_address(ptr) if dt == np.float32 else (C.c_int32 * n).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt).reshape(shape)
+        out = {"kps_xy": view(r.kps_xy, (2 * F, cap, 2), np.float32), "scores": view(r.scores, (2 * F, cap), np.float32),
+               "desc": view(r.desc, (2 * F, cap, D), np.float32), "n_kp": view(r.n_kp, (2 * F,), np.int32),
+               "netvlad": view(r.netvlad, (F, G), np.float32) if G else None}
+        for k in ("lr", "prev"):
+            out[k + "_q"] = view(getattr(r, k + "_q"), (F, cap), np.int32); out[k + "_t"] = view(getattr(r, k + "_t"), (F, cap), np.int32)
+            out[k + "_dist"] = view(getattr(r, k + "_dist"), (F, cap), np.float32); out[k + "_n"] = view(getattr(r, k + "_n"), (F,), np.int32)
+        return out
 
 
 def block_words(cap, netvlad_dim):

@@ -15,8 +15,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/d2fe.h"
-#include "kernels.h"
+#include "context.h"
 
 using namespace d2fe;
 
@@ -29,116 +28,7 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
-#define HIP_TRY(expr)                                                                                       \
-  do {                                                                                                      \
-    hipError_t e_ = (expr);                                                                                 \
-    if (e_ != hipSuccess)                                                                                   \
-      return fail(D2FE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " @" + __FILE__ + ":" + \
-                                    std::to_string(__LINE__));                                              \
-  } while (0)
-
-struct Layer {
-  void* wpack = nullptr;
-  float* bias = nullptr;
-  int cout = 0, cout_pad = 0, cin = 0, ks = 0;
-};
-
-enum { L_1B = 0, L_2A, L_2B, L_3A, L_3B, L_4A, L_4B, L_PADA, L_PB, L_DB, L_PA, L_DA32, L_DB32, L_COUNT };   // the last three: sparse descriptor head
-
-struct Tensor {
-  float* p = nullptr;
-  size_t per_img = 0;  // floats per image at max size
-};
-
 }  // namespace
-
-struct d2fe_context {
-  d2fe_config cfg;
-  hipStream_t stream = nullptr;
-  bool sp_loaded = false;
-  float* w1a = nullptr;  // [9][64]
-  float* b1a = nullptr;
-  Layer L[L_COUNT];
-  // activations (NHWC fp32), separate buffer per layer so that d2fe_debug_read can inspect any of them
-  Tensor a1a, a1b, a2a, a2b, a3a, a3b, a4a, a4b, aPD, logits, draw, semi;
-  // async_tail: the post-processing (softmax .. descriptors) of call k runs on tail_stream under the convolutions of call k+1,
-  // so the three tensors the tail reads exist twice (buffer set = call parity) and events order trunk / tail / reuse
-  Tensor a4b2, logits2, draw2;
-  hipStream_t tail_stream = nullptr;
-  hipEvent_t ev_trunk[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
-  int parity = 0, last_set = 0;
-  unsigned long long* cand = nullptr;
-  int* cand_count = nullptr;
-  long cand_cap = 0;
-  // staging for the host-pointer API
-  uint8_t* s_img = nullptr;
-  int s_cap = 0;
-  // last call geometry (for debug reads)
-  int last_w = 0, last_h = 0, last_n = 0;
-  const uint8_t* last_gray = nullptr; int last_stride = 0; size_t last_istride = 0;
-  float* aconf = nullptr; int* clist = nullptr; int* a_ncand = nullptr;     // variant A scratch
-  float* zeros = nullptr;      // 1 KiB of zeros (ConvArgs::zeros)
-  // host-pointer calls: pinned host staging (one DMA in, one DMA out per call) and cached hipGraphs of the launch sequences.
-  // The reference calls infer / inference with ONE image at 15-30 Hz (loop_cam.cpp:609-616): at that batch the ~10 us the command
-  // processor spends between two dependent launches and the per-copy latency of pageable D2H copies are a third of a call.
-  uint8_t* pin_in = nullptr; size_t pin_in_bytes = 0;
-  float* pin_out = nullptr; size_t pin_out_bytes = 0;
-  float* s_out = nullptr;      // device: [kps | scores | desc | n | idx] of a host-pointer extract call, contiguous -> ONE D2H of the first four
-  size_t s_out_bytes = 0;
-  bool use_graphs = true, use_pinned = true;       // D2FE_GRAPH=0 / D2FE_PINNED=0 switch them off (A/B measurements)
-  // d2fe_extract_all*: NetVLAD of the same uploaded frame(s) on a second stream, beside SuperPoint
-  hipStream_t nv_stream = nullptr; hipEvent_t ev_up = nullptr; float* pin_nv = nullptr; size_t pin_nv_bytes = 0;
-  struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; bool bad = false; };
-  std::map<std::array<long, 6>, GraphEntry> graphs;
-  int ncu = 256;               // compute units of cfg.device_id, read once by d2fe_create (ConvArgs::ncu)
-  unsigned long long* match_stamps = nullptr;   // development builds: [4096][16] phase stamps of the last d2fe_match_batch_device launch
-  int32_t* match_stats = nullptr;   // [4] matcher counters: [0] queries that took the exact fallback scan (MatchArgs::stats)
-  int* work_ctrs = nullptr;    // one work-item counter per Winograd layer, zeroed at the start of every network pass (ConvArgs::work_ctr)
-  bool wino_dynamic = true;    // D2FE_WINO_DYNAMIC=0: static round-robin split of the work items
-  // sparse descriptor head (variant B unless cfg.dense_descriptors): cell flags, cell -> slot map, slot -> cell list, counts, descriptors
-  bool sparse_desc = false; int sp_slots = 0; int sp_min_batch = 4;
-  uint8_t* sp_flags = nullptr; int32_t* sp_slotmap = nullptr; int32_t* sp_cells = nullptr; int32_t* sp_count = nullptr; float* sp_desc = nullptr;
-  void* lk_scratch = nullptr; size_t lk_scratch_bytes = 0;   // grow-only scratch of the LK / detector entry points (lk.hip)
-  float* a_samp = nullptr; float* a_cn = nullptr; int a_scap = 0;   // variant A sampling: [batch][a_scap][256] samples, [batch][256] channel norms
-  float* pca_comp_t = nullptr; float* pca_mean = nullptr; int pca_dims = 0;
-  // NetVLAD
-  struct NvLayer { int kind, cin, cout, cout_pad, stride, act, res; float* w = nullptr; float* b = nullptr; float* out = nullptr; int oh = 0, ow = 0;
-                   int gmax = 1;                 // slabs `out` has room for (a fused block may split its hidden channels over workgroup groups)
-                   int slabs = 1; long slab_stride = 0; };   // of the last call: out = sum of `slabs` partial tensors `slab_stride` floats apart
-  std::vector<NvLayer> nv;
-  // execution plan over the flat layer list: fused MobileNetV2 blocks (netvlad_fused.hip) where the pattern matches, single layers otherwise;
-  // only the LAST layer of a step is materialised in HBM (NvLayer::out), everything inside a fused block lives in LDS
-  struct NvStep { int l0 = 0, l1 = 0; bool fused = false, expand = false, front = false, tail = false, xblock = false, pblock = false; float* we = nullptr; float* wp = nullptr; float* bp = nullptr; float* w0 = nullptr; };
-  int nv_feat_gmax = 1, nv_feat_slabs = 1; long nv_feat_slab_stride = 0;
-  // scheduling knobs of the fused plan, read from the environment by d2fe_load_netvlad (A/B measurements; defaults measured best):
-  // workgroups per launch the hidden-channel split aims at (D2FE_NV_BLOCKS), the same for the tail kernel (D2FE_NV_TAIL_BLOCKS),
-  // and the number of partial slabs from which they are summed once instead of by every consumer (D2FE_NV_SLABSUM, 0 = never)
-  int nv_front_tpw = 0, nv_nbuf = 0;       // D2FE_NV_FRONT_TPW, D2FE_NV_NBUF (0: the launchers decide)
-  int nv_stamp_step = -1; unsigned long long* nv_stamps = nullptr; int nv_stamp_wgs = 0;     // D2FE_NV_STAMP_STEP (diagnostics)
-  int nv_blocks_target = 512, nv_tail_blocks = 768, nv_slabsum = 3;      // the pre-projected features (input of the VLAD stage), same slab scheme
-  std::vector<NvStep> nv_plan;
-  bool nv_loaded = false;
-  int nv_feat = 0, nv_proj = 0, nv_k = 0;
-  float *nv_pre_w = nullptr, *nv_pre_b = nullptr, *nv_aw = nullptr, *nv_aw_pack = nullptr, *nv_ab = nullptr, *nv_cen = nullptr;
-  float *nv_feat_buf = nullptr, *nv_raw = nullptr, *nv_pca_out = nullptr, *nv_part = nullptr;
-  float *nv_pca_comp = nullptr, *nv_pca_mean = nullptr; int nv_pca_m = 0;
-  uint8_t* nv_s_img = nullptr; float* nv_s_out = nullptr;
-  bool fuse1a = true;      // conv1a fused into conv1b's staging (D2FE_FUSE1A=0 keeps the stand-alone conv1a kernel)
-  // host-pointer matcher: pool of (stream, scratch) slots so that concurrent callers (the reference calls matchKNN from three
-  // threads) neither share state nor pay hipStreamCreate / hipMalloc / hipFree (a device-wide sync) per call
-  struct MatchSlot { hipStream_t stream = nullptr; char* buf = nullptr; char* pin = nullptr; size_t bytes = 0; bool busy = false; };
-  std::deque<MatchSlot> match_slots;     // deque: growing it never relocates the slots other threads are using
-  std::mutex match_mu;
-  // device-API matcher scratch (cand4), one per caller stream: calls on different streams may overlap on the GPU
-  struct MatchScratch { hipStream_t stream = nullptr; int32_t* cand4 = nullptr; size_t bytes = 0; int npairs = 0; };
-  std::deque<MatchScratch> m_scratch;
-  // profiling (HIP events on the launch stream)
-  int prof_mode = 0;
-  std::vector<hipEvent_t> prof_pool;
-  size_t prof_used = 0;
-  struct ProfRec { int stage; hipEvent_t a, b; };
-  std::vector<ProfRec> prof_recs;
-};
 
 // accessors for the translation units that keep their own extern "C" entry points (lk.hip)
 namespace d2fe {
@@ -270,10 +160,13 @@ int run_cached(d2fe_context* h, const std::array<long, 6>& key, hipStream_t s, F
   return D2FE_OK;
 }
 
+}  // namespace
+
+namespace d2fe {
 // the launch sequence == one TensorRT executeV2 + processOutput of the reference
 int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int stride, size_t image_stride,
                    float* d_kps, float* d_scores, float* d_desc, int32_t* d_idx, int cap, int32_t* d_n, hipStream_t s,
-                   hipStream_t s_tail = nullptr, int bs = 0) {
+                   hipStream_t s_tail, int bs) {
   // s: the convolutions ("trunk"); s_tail (default: s): softmax, selection, descriptor head, sampling ("tail"); bs: buffer set
   Tensor& a4b = bs ? h->a4b2 : h->a4b;
   Tensor& logits = bs ? h->logits2 : h->logits;
@@ -403,7 +296,7 @@ int check_geometry(d2fe_context* h, int n, int W, int H, int stride, int cap) {
   return D2FE_OK;
 }
 
-}  // namespace
+}  // namespace d2fe
 
 extern "C" {
 
@@ -545,12 +438,14 @@ void d2fe_destroy(d2fe_handle h) {
   for (int i = 0; i < 2; ++i) { if (h->ev_trunk[i]) (void)hipEventDestroy(h->ev_trunk[i]); if (h->ev_tail[i]) (void)hipEventDestroy(h->ev_tail[i]); }
   for (Tensor* t : {&h->a1a, &h->a1b, &h->a2a, &h->a2b, &h->a3a, &h->a3b, &h->a4a, &h->a4b, &h->aPD, &h->logits, &h->draw, &h->semi, &h->a4b2, &h->logits2, &h->draw2})
     if (t->p) hipFree(t->p);
-  for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
-  for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->cand, (void*)h->s_img, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->work_ctrs, (void*)h->match_stats, (void*)h->match_stamps, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc,
-                  (void*)h->pca_comp_t, (void*)h->pca_mean})
+  if (!h->borrowed) {
+    for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
+    for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->pca_comp_t, (void*)h->pca_mean, (void*)h->nv_pca_comp, (void*)h->nv_pca_mean}) if (p) hipFree(p);
+  }
+  for (void* p : {(void*)h->cand, (void*)h->s_img, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->work_ctrs, (void*)h->match_stats, (void*)h->match_stamps, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc})
     if (p) hipFree(p);
   nv_free(h);
-  for (void* p : {(void*)h->nv_pca_comp, (void*)h->nv_pca_mean, (void*)h->nv_s_img, (void*)h->nv_s_out}) if (p) hipFree(p);
+  for (void* p : {(void*)h->nv_s_img, (void*)h->nv_s_out}) if (p) hipFree(p);
   for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
   if (h->nv_stream) { hipStreamSynchronize(h->nv_stream); (void)hipStreamDestroy(h->nv_stream); }
   if (h->ev_up) (void)hipEventDestroy(h->ev_up);
@@ -699,8 +594,6 @@ static int upload_frames(d2fe_context* h, uint8_t* d_dst, const uint8_t* gray, i
   return D2FE_OK;
 }
 
-static int nv_check(d2fe_context* h, int n, int W, int H, int stride);
-int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int stride, size_t image_stride, float* d_out, hipStream_t s);
 
 // host-pointer extract of n images; n_netvlad > 0: the NetVLAD descriptors of the first n_netvlad of them as well, from the SAME uploaded frames,
 // on a second stream beside SuperPoint (d2fe_extract_all*)
@@ -834,14 +727,18 @@ int d2fe_superpoint_extract(d2fe_handle h, const uint8_t* gray, int width, int h
                                        cap, n_out);
 }
 
+}  // extern "C"
 // ---- NetVLAD -----------------------------------------------------------------------------------------------------------
 namespace {
 void nv_free(d2fe_context* h) {
-  for (auto& l : h->nv) { if (l.w) hipFree(l.w); if (l.b) hipFree(l.b); if (l.out) hipFree(l.out); }
+  const bool own = !h->borrowed;      // a pipeline lane owns its activations only
+  for (auto& l : h->nv) { if (own && l.w) hipFree(l.w); if (own && l.b) hipFree(l.b); if (l.out) hipFree(l.out); }
   h->nv.clear();
-  for (auto& st : h->nv_plan) { if (st.we) hipFree(st.we); if (st.wp) hipFree(st.wp); if (st.bp) hipFree(st.bp); if (st.w0) hipFree(st.w0); }
+  if (own) for (auto& st : h->nv_plan) { if (st.we) hipFree(st.we); if (st.wp) hipFree(st.wp); if (st.bp) hipFree(st.bp); if (st.w0) hipFree(st.w0); }
   h->nv_plan.clear();
-  for (float** p : {&h->nv_pre_w, &h->nv_pre_b, &h->nv_aw, &h->nv_aw_pack, &h->nv_ab, &h->nv_cen, &h->nv_feat_buf, &h->nv_raw, &h->nv_pca_out, &h->nv_part})
+  for (float** p : {&h->nv_pre_w, &h->nv_pre_b, &h->nv_aw, &h->nv_aw_pack, &h->nv_ab, &h->nv_cen})
+    if (*p) { if (own) hipFree(*p); *p = nullptr; }
+  for (float** p : {&h->nv_feat_buf, &h->nv_raw, &h->nv_pca_out, &h->nv_part})
     if (*p) { hipFree(*p); *p = nullptr; }
   if (h->nv_stamps) { hipFree(h->nv_stamps); h->nv_stamps = nullptr; }
   h->nv_loaded = false;
@@ -861,6 +758,8 @@ inline void nv_groups(long base_blocks, int nchunk, int gmax, int* groups, int* 
   *groups = (nchunk + *cpg - 1) / *cpg;
 }
 
+}  // namespace
+namespace d2fe {
 int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int stride, size_t image_stride, float* d_out,
                 hipStream_t s) {
   ProfScope ps(h, D2FE_PROF_NETVLAD, s);
@@ -962,7 +861,8 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
   if (h->nv_pca_m) HIP_TRY(launch_nv_pca(raw, h->nv_k * h->nv_proj, h->nv_pca_comp, h->nv_pca_mean, h->nv_pca_m, d_out, n, s));
   return D2FE_OK;
 }
-}  // namespace
+}  // namespace d2fe
+extern "C" {
 
 int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
   if (h) graphs_clear(h);
@@ -1205,7 +1105,9 @@ int d2fe_netvlad_dim(d2fe_handle h) {
   return h->nv_pca_m ? h->nv_pca_m : h->nv_k * h->nv_proj;
 }
 
-static int nv_check(d2fe_context* h, int n, int W, int H, int stride) {
+}  // extern "C"
+namespace d2fe {
+int nv_check(d2fe_context* h, int n, int W, int H, int stride) {
   if (!h) return fail(D2FE_ERR_INVALID, "null handle");
   if (!h->nv_loaded) return fail(D2FE_ERR_NOT_READY, "netvlad weights not loaded");
   if (n < 1 || n > h->cfg.max_batch) return fail(D2FE_ERR_INVALID, "batch size out of range");
@@ -1213,6 +1115,8 @@ static int nv_check(d2fe_context* h, int n, int W, int H, int stride) {
   if (stride < W) return fail(D2FE_ERR_INVALID, "stride < width");
   return D2FE_OK;
 }
+}  // namespace d2fe
+extern "C" {
 
 int d2fe_netvlad_device(d2fe_handle h, const uint8_t* d_gray, int n, int width, int height, int stride, size_t image_stride,
                         float* d_out, void* stream) {
@@ -1252,6 +1156,55 @@ int d2fe_netvlad_batch(d2fe_handle h, const uint8_t* gray, int n, int width, int
 int d2fe_netvlad(d2fe_handle h, const uint8_t* gray, int width, int height, int stride, float* out) {
   return d2fe_netvlad_batch(h, gray, 1, width, height, stride, (size_t)stride * height, out);
 }
+
+}  // extern "C"
+namespace d2fe {
+int clone_lane(d2fe_context* p, int max_batch, d2fe_context** out, hipStream_t stream, int ncu) {
+  *out = nullptr;
+  d2fe_config cfg = p->cfg;
+  cfg.max_batch = max_batch;
+  cfg.async_tail = 0;
+  d2fe_handle c = nullptr;
+  int rc = d2fe_create(&cfg, &c);
+  if (rc) return rc;
+  c->borrowed = true;
+  if (stream) { (void)hipStreamDestroy(c->stream); c->stream = stream; }
+  if (ncu > 0) c->ncu = ncu;
+  c->w1a = p->w1a; c->b1a = p->b1a;
+  for (int i = 0; i < L_COUNT; ++i) c->L[i] = p->L[i];
+  c->sp_loaded = p->sp_loaded;
+  c->pca_comp_t = p->pca_comp_t; c->pca_mean = p->pca_mean; c->pca_dims = p->pca_dims;
+  c->fuse1a = p->fuse1a; c->wino_dynamic = p->wino_dynamic; c->sp_min_batch = p->sp_min_batch;
+  if (p->nv_loaded) {
+    const int B = max_batch;
+    c->nv = p->nv;
+    for (auto& l : c->nv) { l.out = nullptr; l.slabs = 1; l.slab_stride = 0; }
+    c->nv_plan = p->nv_plan;
+    c->nv_feat_gmax = p->nv_feat_gmax; c->nv_blocks_target = p->nv_blocks_target; c->nv_tail_blocks = p->nv_tail_blocks; c->nv_slabsum = p->nv_slabsum;
+    c->nv_front_tpw = p->nv_front_tpw; c->nv_nbuf = p->nv_nbuf;
+    c->nv_feat = p->nv_feat; c->nv_proj = p->nv_proj; c->nv_k = p->nv_k;
+    c->nv_pre_w = p->nv_pre_w; c->nv_pre_b = p->nv_pre_b; c->nv_aw = p->nv_aw; c->nv_aw_pack = p->nv_aw_pack; c->nv_ab = p->nv_ab; c->nv_cen = p->nv_cen;
+    c->nv_pca_comp = p->nv_pca_comp; c->nv_pca_mean = p->nv_pca_mean; c->nv_pca_m = p->nv_pca_m;
+    auto alloc = [&]() -> int {
+      for (size_t li = 0; li < c->nv.size(); ++li)
+        if (p->nv[li].out) HIP_TRY(hipMalloc(&c->nv[li].out, sizeof(float) * (size_t)c->nv[li].gmax * B * c->nv[li].oh * c->nv[li].ow * c->nv[li].cout));
+      const int ch = c->nv.back().oh, cw = c->nv.back().ow;
+      HIP_TRY(hipMalloc(&c->nv_feat_buf, sizeof(float) * (size_t)c->nv_feat_gmax * B * ch * cw * c->nv_proj));
+      HIP_TRY(hipMalloc(&c->nv_raw, sizeof(float) * (size_t)B * c->nv_k * c->nv_proj));
+      HIP_TRY(hipMalloc(&c->nv_part, sizeof(float) * (size_t)B * nv_vlad_part_floats(ch * cw, c->nv_proj, c->nv_k)));
+      HIP_TRY(hipMalloc(&c->nv_s_img, (size_t)cfg.max_width * cfg.max_height * B));
+      HIP_TRY(hipMalloc(&c->nv_s_out, sizeof(float) * 8192 * B));
+      return D2FE_OK;
+    };
+    rc = alloc();
+    if (rc) { d2fe_destroy(c); return rc; }
+    c->nv_loaded = true;
+  }
+  *out = c;
+  return D2FE_OK;
+}
+}  // namespace d2fe
+extern "C" {
 
 // ---- SURVEY 8(f) next rows -------------------------------------------------------------------------------------------------
 struct d2fe_db {

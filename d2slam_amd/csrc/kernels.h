@@ -198,7 +198,10 @@ hipError_t launch_remap_matches(int32_t* q_idx, int32_t* t_idx, const int32_t* n
                                 const int32_t* maps, int npairs, int cap_match, int cap_map, hipStream_t s);
 
 // ---- matcher --------------------------------------------------------------------------------------
+// optional per-pair view (pipe.hip): absolute device pointers instead of pool + row offset, counts anywhere, a radius per pair
+struct MatchPairDesc { const float* a; const float* b; const float* pts_a; const float* pts_b; const int32_t* na; const int32_t* nb; double radius; };
 struct MatchArgs {
+  const MatchPairDesc* pairs = nullptr;     // [npairs] in device memory; null: the pool form below
   const float* a; const float* b; const float* pts_a; const float* pts_b;
   const int32_t* a_off; const int32_t* b_off; const int32_t* a_cnt; const int32_t* b_cnt;
   int npairs, dim, max_n, mode;

@@ -17,7 +17,7 @@
 //      2-NN (distance, then index: the reference's insertion order) is taken among them.  Every other row has an exact squared
 //      distance > tau - slack, which is checked against the exact second neighbour found (always true by construction for one pass;
 //      the check also covers multi-pass train sets with unequal norms).  A query with more than CMAX candidates in a pass (more than
-//      eight rows within round-off of each other: repeated texture, a frame matched against a near-copy, all-equal sets) or a failed
+//      sixteen rows within round-off of each other: repeated texture, a frame matched against a near-copy, all-equal sets) or a failed
 //      check takes an exact scan of every train row.  Indices and distances equal the oracle's bit for bit for any input.
 //  (3) the workgroup that finishes LAST for a pair (one device counter per pair) applies ratio / mutual / radius tests in double exactly
 //      as feature_matcher.cpp:16-37 and emits the matches in ascending query order: no second launch.  Hand-off between workgroups
@@ -34,7 +34,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int MQ = 32;           // queries per workgroup (two 16-wide MFMA column tiles)
 constexpr int SC = 256;          // train rows per pass (width of the LDS strip)
 constexpr int SPITCH = SC + 4;   // strip row pitch (floats): the 4-threads-per-query scan below is bank-conflict-free
-constexpr int CMAX = 8;          // candidate slots per query and pass
+constexpr int CMAX = 16;         // candidate slots per query and pass
+constexpr int SHMAX = 8;         // ... of which one scan thread's share of the strip row may hold
 constexpr int MAXDIM = 256;
 constexpr int KST = MAXDIM / 16; // k-steps of 16 floats (4 k-groups x float4)
 // |d2_gram - d2_exact| <= GRAM_ERR * (|q|^2 + |t|^2): three fp32 sums of <= 256 products (gamma_257 = 257 * 2^-24 = 1.53e-5 each, and
@@ -50,7 +51,7 @@ struct MatchSmem {
   float S[MQ * SPITCH];
   float qn[MQ], rm1[MQ], rm2[MQ], lb[MQ], bd0[MQ], bd1[MQ];
   int bi0[MQ], bi1[MQ], ccnt[MQ], ctot[MQ], over[MQ], fb[MQ];
-  int wslot[MQ * CMAX];          // work lists, one region per wave: q * CMAX + slot of every candidate of the pass
+  unsigned short wslot[MQ * CMAX];   // work lists, one region per wave: q * CMAX + slot of every candidate of the pass (4 workgroups per CU: <= 40 KiB each)
   int ct[MQ * CMAX];             // [q][slot] train row
   float cd[MQ * CMAX];           // [q][slot] exact distance
   float tnmax_w[NW];
@@ -95,6 +96,20 @@ __device__ __forceinline__ float exact_dist16(const float* __restrict__ q, const
   return __builtin_sqrtf(d);
 }
 
+struct PairView { const float* a; const float* b; const float* pa; const float* pb; int na, nb; double radius; };
+__device__ __forceinline__ PairView pair_view(const MatchArgs& m, int pair) {
+  PairView v;
+  if (m.pairs) {
+    const MatchPairDesc d = m.pairs[pair];
+    v.a = d.a; v.b = d.b; v.pa = d.pts_a; v.pb = d.pts_b; v.na = min(*d.na, m.max_n); v.nb = min(*d.nb, m.max_n); v.radius = d.radius;
+  } else {
+    v.a = m.a + (size_t)m.a_off[pair] * m.dim; v.b = m.b + (size_t)m.b_off[pair] * m.dim;
+    v.pa = m.pts_a ? m.pts_a + 2 * (size_t)m.a_off[pair] : nullptr; v.pb = m.pts_b ? m.pts_b + 2 * (size_t)m.b_off[pair] : nullptr;
+    v.na = min(m.a_cnt[pair], m.max_n); v.nb = min(m.b_cnt[pair], m.max_n); v.radius = m.radius;
+  }
+  return v;
+}
+
 __device__ __forceinline__ void best2_insert(float d, int i, float& bd0, int& bi0, float& bd1, int& bi1) {
   if (cand_less(d, i, bd0, bi0)) { bd1 = bd0; bi1 = bi0; bd0 = d; bi0 = i; }
   else if (cand_less(d, i, bd1, bi1)) { bd1 = d; bi1 = i; }
@@ -107,7 +122,8 @@ template <int NW>
 __device__ void match_finalize_pair(const MatchArgs& m, int pair, MatchSmem<NW>& sm) {
   constexpr int NTHR = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int na = min(m.a_cnt[pair], m.max_n), nb = min(m.b_cnt[pair], m.max_n);
+  const PairView pv = pair_view(m, pair);
+  const int na = pv.na, nb = pv.nb;
   int32_t* fwd = m.cand4 + ((size_t)pair * 2 + 0) * m.max_n * 4;
   int32_t* inv = m.cand4 + ((size_t)pair * 2 + 1) * m.max_n * 4;
   // phase 1: inverse dictionary (feature_matcher.cpp:16-25): inv[j][3] = the a-row b-row j names, or -1
@@ -137,12 +153,12 @@ __device__ void match_finalize_pair(const MatchArgs& m, int pair, MatchSmem<NW>&
       if (m.mode == 0) {
         ok = nb >= 2 && j >= 0 && (double)d0 < m.ratio * (double)d1 &&
              __hip_atomic_load(inv + 4 * j + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == i;
-        if (ok && m.radius > 0 && m.pts_a && m.pts_b) {
-          const float* pa = m.pts_a + 2 * ((size_t)m.a_off[pair] + i);
-          const float* pb = m.pts_b + 2 * ((size_t)m.b_off[pair] + j);
+        if (ok && pv.radius > 0 && pv.pa && pv.pb) {
+          const float* pa = pv.pa + 2 * (size_t)i;
+          const float* pb = pv.pb + 2 * (size_t)j;
           const float dx = pa[0] - pb[0], dy = pa[1] - pb[1];
           const double nr = __builtin_sqrt((double)dx * dx + (double)dy * dy);
-          if (nr > m.radius) ok = false;
+          if (nr > pv.radius) ok = false;
         }
       } else {
         ok = j >= 0 && __hip_atomic_load(inv + 4 * j + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == i;
@@ -186,12 +202,12 @@ __global__ __launch_bounds__(64 * NW, 2) void match_kernel(MatchArgs m, int tile
   }
   const int per_pair = 2 * tiles;
   const int pair = item / per_pair, dir = (item % per_pair) / tiles, tile = item % tiles;
-  const int na = min(m.a_cnt[pair], m.max_n), nb = min(m.b_cnt[pair], m.max_n);
-  const int nq = dir == 0 ? na : nb, nt = dir == 0 ? nb : na;
+  const PairView pv = pair_view(m, pair);
+  const int nq = dir == 0 ? pv.na : pv.nb, nt = dir == 0 ? pv.nb : pv.na;
   const int q0 = tile * MQ;
   const int dim = m.dim;
-  const float* Q = dir == 0 ? m.a + (size_t)m.a_off[pair] * dim : m.b + (size_t)m.b_off[pair] * dim;
-  const float* T = dir == 0 ? m.b + (size_t)m.b_off[pair] * dim : m.a + (size_t)m.a_off[pair] * dim;
+  const float* Q = dir == 0 ? pv.a : pv.b;
+  const float* T = dir == 0 ? pv.b : pv.a;
 
   D2FE_STAMP(m.stamps, blockIdx.x, 0);
   if (q0 < nq) {
@@ -357,10 +373,10 @@ __global__ __launch_bounds__(64 * NW, 2) void match_kernel(MatchArgs m, int tile
         for (int i = 0; i < VPT; ++i) hits |= (v[i] <= tau && v[i] < __builtin_inff()) ? (1ull << i) : 0ull;
         if (!qvalid) hits = 0;
         const int cnt = __popcll(hits);
-        // slots of the query: exclusive prefix of its lanes' stored counts; more than four hits in one share or more than CMAX in the row:
+        // slots of the query: exclusive prefix of its lanes' stored counts; more than SHMAX hits in one share or more than CMAX in the row:
         // the query takes the exact scan (ccnt > CMAX -> sm.over)
-        const int sc = cnt < 4 ? cnt : 4;
-        int ofq = cnt > 4 ? 1 : 0;
+        const int sc = cnt < SHMAX ? cnt : SHMAX;
+        int ofq = cnt > SHMAX ? 1 : 0;
         int incq = sc;
 #pragma unroll
         for (int o = 1; o < TPQ; o <<= 1) {
@@ -378,12 +394,12 @@ __global__ __launch_bounds__(64 * NW, 2) void match_kernel(MatchArgs m, int tile
         const int woff = __shfl(incl, lane & ~(TPQ - 1), 64) - kept;       // entries of the wave's queries before this one
         if (p == 0) sm.ccnt[q] = ofq ? CMAX + 1 : total;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < SHMAX; ++k) {
           if (k < sc && base + k < CMAX) {
             const int j = __ffsll((long long)hits) - 1;
             hits &= hits - 1;
             sm.ct[q * CMAX + base + k] = t_base + tq0 + j;
-            sm.wslot[wave * WREG + woff + base + k] = q * CMAX + base + k;
+            sm.wslot[wave * WREG + woff + base + k] = (unsigned short)(q * CMAX + base + k);
           }
         }
         if (lane == 63) sm.nwork_w[wave] = incl;
@@ -481,9 +497,41 @@ __global__ __launch_bounds__(64 * NW, 2) void match_kernel(MatchArgs m, int tile
       const int grp = tid >> 4, slot = tid & 15;
       float b0d = __builtin_inff(), b1d = __builtin_inff();
       int b0i = 0x7FFFFFFF, b1i = 0x7FFFFFFF;
-      for (int j = grp; j < nt; j += NTHR / 16) {
-        const float dj = exact_dist16(Q + (size_t)(q0 + sq) * dim, T + (size_t)j * dim, dim, slot, lane);
-        best2_insert(dj, j, b0d, b0i, b1d, b1i);
+      if (FULL) {
+        // the query row once, four train rows per 16-lane group in flight: 4 * NTHR / 16 rows per L2 round trip
+        constexpr int EU = 4;
+        float qv[16];
+        { const float* qrow = Q + (size_t)(q0 + sq) * MAXDIM + slot;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) qv[i] = qrow[16 * i]; }
+        for (int j0 = 0; j0 < nt; j0 += EU * (NTHR / 16)) {
+          float tv[EU][16];
+#pragma unroll
+          for (int u = 0; u < EU; ++u) {
+            const int j = j0 + EU * grp + u;
+            const float* trow = T + (size_t)(j < nt ? j : 0) * MAXDIM + slot;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tv[u][i] = trow[16 * i];
+          }
+#pragma unroll
+          for (int u = 0; u < EU; ++u) {
+            const int j = j0 + EU * grp + u;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const float d = qv[i] - tv[u][i];
+              const float dd = d * d;
+              acc = acc + dd;
+            }
+            const float dj = __builtin_sqrtf(exact_reduce16(acc, slot, lane));
+            if (j < nt) best2_insert(dj, j, b0d, b0i, b1d, b1i);
+          }
+        }
+      } else {
+        for (int j = grp; j < nt; j += NTHR / 16) {
+          const float dj = exact_dist16(Q + (size_t)(q0 + sq) * dim, T + (size_t)j * dim, dim, slot, lane);
+          best2_insert(dj, j, b0d, b0i, b1d, b1i);
+        }
       }
       if (slot == 0) { sm.scan[grp * 2] = Cand{b0d, b0i}; sm.scan[grp * 2 + 1] = Cand{b1d, b1i}; }
       __syncthreads();

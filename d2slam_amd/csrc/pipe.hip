@@ -1,0 +1,334 @@
+// pipe.hip -- frames in flight: the stereo-frame front end of include/d2fe.h (d2fe_pipe_*) as K lanes.
+//
+// The reference processes ONE stereo frame at a time on one thread (D2Frontend::processStereoframe, d2frontend.cpp:155-169): per
+// image SuperPoint::infer and, for the main camera, MobileNetVLADONNX::inference (LoopCam::extractorImgDescDeepnet,
+// loop_cam.cpp:589-648, called for both cameras by generateStereoImageDescriptor :440-470), then the two matchKNN calls of
+// D2FeatureTracker::trackLocalFrames (left <-> right, d2featuretracker.cpp:658-695; left <-> previous left, :403-456).  A one- or
+// two-image pass leaves most of a 256-CU device idle (latency-bound launches, 60 x 80 layers with a few hundred work items), so the
+// throughput form of the same work keeps K frames in flight: submit() only enqueues, wait() returns the frame's results.
+//
+// A lane = its own context (clone_lane: activations, counters, scratch, streams of its own; the packed weights are the parent's),
+// a device input buffer and TWO output blocks (alternating, so the block the NEXT frame's temporal match reads is not the one this
+// lane writes on its next turn).  Per submit, on the lane's stream:
+//     H2D (one DMA from pinned memory) -> [NetVLAD of the left images on the lane's second stream] -> SuperPoint of the 2F images
+//     -> ONE matcher launch over {L_f <-> R_f, L_f <-> L_(f-1)} (the pair table addresses the previous frame's block directly; the
+//        launch waits for the previous submit's extraction event, nothing else of it) -> ONE D2H of the block into pinned memory.
+// Outputs are bit-identical to the single-call entry points (same kernels, same launch shapes for the same image count).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "context.h"
+
+using namespace d2fe;
+
+struct d2fe_pipe_s {
+  d2fe_context* parent = nullptr;
+  d2fe_pipe_config cfg{};
+  int K = 0, F = 0, NI = 0, W = 0, H = 0, cap = 0, D = 256, G = 0, npairs = 0;
+  // block layout (float words from the block base; every array starts on a 64-word boundary)
+  size_t o_desc = 0, o_kps = 0, o_scores = 0, o_nv = 0, o_cnt = 0, o_mn = 0, o_mq = 0, o_mt = 0, o_md = 0, o_idx = 0, blk_words = 0, d2h_words = 0;
+  float* d_all = nullptr;            // [zero word block | K lanes x 2 sets x block]
+  MatchPairDesc* d_pairs = nullptr;  // [K][2][npairs]
+  int32_t* d_match_scratch = nullptr; size_t match_scratch_lane = 0;   // per lane: tickets + records
+  struct Lane {
+    d2fe_context* ctx = nullptr;
+    hipStream_t s = nullptr, nv = nullptr;
+    hipEvent_t ev_up = nullptr, ev_nv = nullptr, ev_ext[2] = {nullptr, nullptr}, ev_done = nullptr;
+    uint8_t* d_img = nullptr;
+    uint8_t* pin_in = nullptr;
+    float* pin_out[2] = {nullptr, nullptr};
+    long long ticket = -1;           // ticket in flight (or last completed) on this lane
+    bool done_synced = true;
+  };
+  std::vector<Lane> lanes;
+  long long next_ticket = 0;
+  float* block(int lane, int set) const { return d_all + 64 + ((size_t)lane * 2 + set) * blk_words; }
+};
+
+namespace {
+
+size_t up64(size_t w) { return (w + 63) / 64 * 64; }
+
+int pipe_fail(int code, const std::string& msg) { return ctx_fail(code, msg); }
+
+int lane_sync(d2fe_pipe_s* p, d2fe_pipe_s::Lane& L) {
+  if (!L.done_synced) {
+    HIP_TRY(hipEventSynchronize(L.ev_done));
+    L.done_synced = true;
+  }
+  (void)p;
+  return D2FE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void d2fe_pipe_destroy(d2fe_pipe p);
+
+void d2fe_pipe_default_config(d2fe_pipe_config* c) {
+  memset(c, 0, sizeof(*c));
+  c->struct_size = (int32_t)sizeof(d2fe_pipe_config);
+  c->lanes = 4; c->frames = 1; c->width = 640; c->height = 480; c->cap = 200;
+  c->netvlad = 1; c->match_lr = 1; c->match_prev = 1; c->pinned_input = 0;
+  c->ratio = 0.8; c->radius_lr = -1.0; c->radius_prev = -1.0;
+}
+
+int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out) {
+  if (!h || !cfg || !out) return pipe_fail(D2FE_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(d2fe_pipe_config)) return pipe_fail(D2FE_ERR_INVALID, "d2fe_pipe_config size mismatch");
+  if (!h->sp_loaded) return pipe_fail(D2FE_ERR_NOT_READY, "superpoint weights not loaded");
+  if (cfg->netvlad && !h->nv_loaded) return pipe_fail(D2FE_ERR_NOT_READY, "netvlad weights not loaded");
+  if (cfg->lanes < 1 || cfg->lanes > 16 || cfg->frames < 1 || cfg->frames > 4096) return pipe_fail(D2FE_ERR_INVALID, "lanes must be 1..16, frames >= 1");
+  if (cfg->cap < 1 || (h->cfg.max_keypoints > 0 && cfg->cap > 16384)) return pipe_fail(D2FE_ERR_INVALID, "cap out of range");
+  if (h->cfg.max_keypoints < 0) return pipe_fail(D2FE_ERR_UNSUPPORTED, "keep-all handles (max_keypoints = -1) are served by the single-call entry points");
+  if (cfg->width > h->cfg.max_width || cfg->height > h->cfg.max_height) return pipe_fail(D2FE_ERR_INVALID, "frame size exceeds the handle's maximum");
+  HIP_TRY(hipSetDevice(h->cfg.device_id));
+  d2fe_pipe_s* p = new d2fe_pipe_s();
+  p->parent = h; p->cfg = *cfg;
+  p->K = cfg->lanes; p->F = cfg->frames; p->NI = 2 * cfg->frames; p->W = cfg->width; p->H = cfg->height;
+  p->cap = cfg->cap < h->cfg.max_keypoints ? cfg->cap : h->cfg.max_keypoints;
+  p->D = d2fe_desc_dim(h);
+  p->G = cfg->netvlad ? d2fe_netvlad_dim(h) : 0;
+  p->npairs = (cfg->match_lr ? p->F : 0) + (cfg->match_prev ? p->F : 0);
+  {
+    int rc = check_geometry(h, 1, p->W, p->H, p->W, p->cap);
+    if (rc) { delete p; return rc; }
+    if (cfg->netvlad) { rc = nv_check(h, 1, p->W, p->H, p->W); if (rc) { delete p; return rc; } }
+  }
+  const size_t NI = p->NI, cap = p->cap, F = p->F;
+  size_t o = 0;
+  p->o_desc = o; o += up64(NI * cap * p->D);
+  p->o_kps = o; o += up64(NI * cap * 2);
+  p->o_scores = o; o += up64(NI * cap);
+  p->o_nv = o; o += up64(F * (size_t)p->G);
+  p->o_cnt = o; o += up64(NI);
+  p->o_mn = o; o += up64(2 * F);
+  p->o_mq = o; o += up64(2 * F * cap);
+  p->o_mt = o; o += up64(2 * F * cap);
+  p->o_md = o; o += up64(2 * F * cap);
+  p->d2h_words = o;
+  p->o_idx = o; o += up64(NI * cap);
+  p->blk_words = o;
+  const int rc = [&]() -> int {
+    const size_t all_words = 64 + (size_t)p->K * 2 * p->blk_words;
+    HIP_TRY(hipMalloc(&p->d_all, sizeof(float) * all_words));
+    HIP_TRY(hipMemset(p->d_all, 0, sizeof(float) * all_words));
+    p->lanes.resize(p->K);
+    for (int k = 0; k < p->K; ++k) {
+      auto& L = p->lanes[k];
+      hipStream_t ms = nullptr;
+      int lane_cus = 0;
+      if (cfg->cu_partition && p->K > 1) {
+        // Disjoint compute units per lane.  Bit i of a HIP CU mask is CU i / 8 of XCD i % 8 on this device, and an XCD without any bit
+        // set is NOT masked at all (tools/ubench/cu_mask_probe.hip), so a lane gets the same rows of CUs in every XCD: rows
+        // [k R / K, (k + 1) R / K) of the R = CUs / 8 rows.  Lanes then run truly side by side (no queue arbitration between their
+        // kernels) and share every XCD's L2 copy of the weights
+        const int rows = h->ncu / 8, r0 = k * rows / p->K, r1 = (k + 1) * rows / p->K;
+        if (r1 > r0) {
+          std::vector<uint32_t> mask((h->ncu + 31) / 32, 0u);
+          for (int b = 8 * r0; b < 8 * r1; ++b) mask[b / 32] |= 1u << (b % 32);
+          HIP_TRY(hipExtStreamCreateWithCUMask(&ms, (uint32_t)mask.size(), mask.data()));
+          HIP_TRY(hipExtStreamCreateWithCUMask(&L.nv, (uint32_t)mask.size(), mask.data()));
+          lane_cus = 8 * (r1 - r0);
+        }
+      }
+      int rc2 = clone_lane(h, p->NI, &L.ctx, ms, lane_cus);
+      if (rc2) { if (ms) (void)hipStreamDestroy(ms); return rc2; }
+      L.s = L.ctx->stream;
+      if (!L.nv) HIP_TRY(hipStreamCreateWithFlags(&L.nv, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&L.ev_up, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&L.ev_nv, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&L.ev_ext[0], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&L.ev_ext[1], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
+      HIP_TRY(hipMalloc(&L.d_img, (size_t)p->W * p->H * p->NI));
+      if (!cfg->pinned_input) HIP_TRY(hipHostMalloc(&L.pin_in, (size_t)p->W * p->H * p->NI, hipHostMallocDefault));
+      for (int set = 0; set < 2; ++set) HIP_TRY(hipHostMalloc(&L.pin_out[set], sizeof(float) * p->d2h_words, hipHostMallocDefault));
+    }
+    if (p->npairs > 0) {
+      // pair tables: [lane][set][pair]; pair f < F (when match_lr): L_f <-> R_f; then L_f <-> L_(f-1), f = 0: the last left frame of the
+      // previous submit's block (lane - 1, that submit's set; the zero word in front of the blocks while no frame has been submitted)
+      std::vector<MatchPairDesc> tab((size_t)p->K * 2 * p->npairs);
+      for (int k = 0; k < p->K; ++k)
+        for (int set = 0; set < 2; ++set) {
+          float* B = p->block(k, set);
+          // the previous submit: ticket t - 1.  With t = j K + k the set is j & 1; t - 1 = j K + k - 1 (k > 0: same j) or (j - 1) K + K - 1
+          const int pk = k > 0 ? k - 1 : p->K - 1;
+          const int pset = k > 0 ? set : set ^ 1;
+          float* PB = p->block(pk, pset);
+          MatchPairDesc* row = tab.data() + ((size_t)k * 2 + set) * p->npairs;
+          int pi = 0;
+          for (size_t f = 0; cfg->match_lr && f < F; ++f, ++pi) {
+            MatchPairDesc& d = row[pi];
+            d.a = B + p->o_desc + f * cap * p->D; d.b = B + p->o_desc + (F + f) * cap * p->D;
+            d.pts_a = B + p->o_kps + f * cap * 2; d.pts_b = B + p->o_kps + (F + f) * cap * 2;
+            d.na = reinterpret_cast<int32_t*>(B + p->o_cnt) + f; d.nb = reinterpret_cast<int32_t*>(B + p->o_cnt) + F + f;
+            d.radius = cfg->radius_lr;
+          }
+          for (size_t f = 0; cfg->match_prev && f < F; ++f, ++pi) {
+            MatchPairDesc& d = row[pi];
+            float* SB = f > 0 ? B : PB;
+            const size_t sf = f > 0 ? f - 1 : F - 1;
+            d.a = B + p->o_desc + f * cap * p->D; d.b = SB + p->o_desc + sf * cap * p->D;
+            d.pts_a = B + p->o_kps + f * cap * 2; d.pts_b = SB + p->o_kps + sf * cap * 2;
+            d.na = reinterpret_cast<int32_t*>(B + p->o_cnt) + f; d.nb = reinterpret_cast<int32_t*>(SB + p->o_cnt) + sf;
+            d.radius = cfg->radius_prev;
+          }
+        }
+      HIP_TRY(hipMalloc(&p->d_pairs, sizeof(MatchPairDesc) * tab.size()));
+      HIP_TRY(hipMemcpy(p->d_pairs, tab.data(), sizeof(MatchPairDesc) * tab.size(), hipMemcpyHostToDevice));
+      p->match_scratch_lane = match_scratch_bytes(p->npairs, p->cap);
+      HIP_TRY(hipMalloc(&p->d_match_scratch, p->match_scratch_lane * p->K));
+      HIP_TRY(hipMemset(p->d_match_scratch, 0, p->match_scratch_lane * p->K));
+    }
+    return D2FE_OK;
+  }();
+  if (rc != D2FE_OK) { d2fe_pipe_destroy(p); return rc; }
+  *out = p;
+  return D2FE_OK;
+}
+
+void d2fe_pipe_destroy(d2fe_pipe p) {
+  if (!p) return;
+  hipSetDevice(p->parent->cfg.device_id);
+  for (auto& L : p->lanes) {
+    if (L.s) (void)hipStreamSynchronize(L.s);
+    if (L.nv) { (void)hipStreamSynchronize(L.nv); (void)hipStreamDestroy(L.nv); }
+    for (hipEvent_t e : {L.ev_up, L.ev_nv, L.ev_ext[0], L.ev_ext[1], L.ev_done}) if (e) (void)hipEventDestroy(e);
+    if (L.d_img) (void)hipFree(L.d_img);
+    if (L.pin_in) (void)hipHostFree(L.pin_in);
+    for (float* q : L.pin_out) if (q) (void)hipHostFree(q);
+    if (L.ctx) d2fe_destroy(L.ctx);
+  }
+  if (p->d_pairs) (void)hipFree(p->d_pairs);
+  if (p->d_match_scratch) (void)hipFree(p->d_match_scratch);
+  if (p->d_all) (void)hipFree(p->d_all);
+  delete p;
+}
+
+int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int stride, size_t image_stride, int64_t* ticket) {
+  if (!p || !left || !right || !ticket) return pipe_fail(D2FE_ERR_INVALID, "null argument");
+  if (stride < p->W) return pipe_fail(D2FE_ERR_INVALID, "stride < width");
+  HIP_TRY(hipSetDevice(p->parent->cfg.device_id));
+  const long long t = p->next_ticket;
+  const int k = (int)(t % p->K), set = (int)((t / p->K) & 1);
+  auto& L = p->lanes[k];
+  // the lane's previous frame (ticket t - K) must be complete before its buffers are reused; with it every ticket <= t - K is (the
+  // invariant that makes the alternating output blocks sufficient, see the header)
+  int rc = lane_sync(p, L);
+  if (rc) return rc;
+  const size_t img = (size_t)p->W * p->H;
+  const int F = p->F, NI = p->NI, W = p->W, H = p->H;
+  hipStream_t s = L.s;
+  if (p->cfg.pinned_input) {
+    for (int side = 0; side < 2; ++side) {
+      const uint8_t* src = side ? right : left;
+      uint8_t* dst = L.d_img + (size_t)side * F * img;
+      if (stride == W && image_stride == img) HIP_TRY(hipMemcpyAsync(dst, src, img * F, hipMemcpyHostToDevice, s));
+      else if (image_stride == (size_t)stride * H) HIP_TRY(hipMemcpy2DAsync(dst, W, src, stride, W, (size_t)H * F, hipMemcpyHostToDevice, s));
+      else for (int f = 0; f < F; ++f) HIP_TRY(hipMemcpy2DAsync(dst + f * img, W, src + f * image_stride, stride, W, H, hipMemcpyHostToDevice, s));
+    }
+  } else {
+    for (int side = 0; side < 2; ++side)
+      for (int f = 0; f < F; ++f) {
+        const uint8_t* src = (side ? right : left) + f * image_stride;
+        uint8_t* dst = L.pin_in + ((size_t)side * F + f) * img;
+        if (stride == W) memcpy(dst, src, img);
+        else for (int y = 0; y < H; ++y) memcpy(dst + (size_t)y * W, src + (size_t)y * stride, W);
+      }
+    HIP_TRY(hipMemcpyAsync(L.d_img, L.pin_in, img * NI, hipMemcpyHostToDevice, s));
+  }
+  float* B = p->block(k, set);
+  const bool nv_side = p->cfg.netvlad && !p->cfg.netvlad_inline;
+  if (nv_side) {
+    HIP_TRY(hipEventRecord(L.ev_up, s));
+    HIP_TRY(hipStreamWaitEvent(L.nv, L.ev_up, 0));
+    rc = run_netvlad(L.ctx, L.d_img, F, W, H, W, img, B + p->o_nv, L.nv);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(L.ev_nv, L.nv));
+  } else if (p->cfg.netvlad) {
+    rc = run_netvlad(L.ctx, L.d_img, F, W, H, W, img, B + p->o_nv, s);
+    if (rc) return rc;
+  }
+  rc = run_superpoint(L.ctx, L.d_img, NI, W, H, W, img, B + p->o_kps, B + p->o_scores, B + p->o_desc, reinterpret_cast<int32_t*>(B + p->o_idx), p->cap,
+                      reinterpret_cast<int32_t*>(B + p->o_cnt), s);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(L.ev_ext[set], s));
+  if (p->npairs > 0) {
+    if (p->cfg.match_prev && t > 0 && p->K > 1) {
+      const int pk = k > 0 ? k - 1 : p->K - 1, pset = k > 0 ? set : set ^ 1;
+      HIP_TRY(hipStreamWaitEvent(s, p->lanes[pk].ev_ext[pset], 0));
+    }
+    MatchArgs m{};
+    m.pairs = p->d_pairs + ((size_t)k * 2 + set) * p->npairs;
+    m.npairs = p->npairs; m.dim = p->D; m.max_n = p->cap; m.mode = 0; m.ratio = p->cfg.ratio; m.radius = -1.0;
+    m.q_idx = reinterpret_cast<int32_t*>(B + p->o_mq); m.t_idx = reinterpret_cast<int32_t*>(B + p->o_mt); m.dist = B + p->o_md;
+    m.n_out = reinterpret_cast<int32_t*>(B + p->o_mn);
+    match_scratch_carve(reinterpret_cast<char*>(p->d_match_scratch) + p->match_scratch_lane * k, p->npairs, &m);
+    m.stats = p->parent->match_stats; m.ncu = L.ctx->ncu;
+    HIP_TRY(launch_match(m, s));
+  }
+  if (nv_side) HIP_TRY(hipStreamWaitEvent(s, L.ev_nv, 0));
+  HIP_TRY(hipMemcpyAsync(L.pin_out[set], B, sizeof(float) * p->d2h_words, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipEventRecord(L.ev_done, s));
+  L.ticket = t; L.done_synced = false;
+  p->next_ticket = t + 1;
+  *ticket = t;
+  return D2FE_OK;
+}
+
+int d2fe_pipe_wait(d2fe_pipe p, int64_t ticket, d2fe_pipe_result* out) {
+  if (!p || !out) return pipe_fail(D2FE_ERR_INVALID, "null argument");
+  memset(out, 0, sizeof(*out));
+  if (ticket < 0 || ticket >= p->next_ticket) return pipe_fail(D2FE_ERR_INVALID, "unknown ticket");
+  if (ticket + 2 * p->K <= p->next_ticket) return pipe_fail(D2FE_ERR_INVALID, "the ticket's result block has been reused: wait for a frame within 2 * lanes submits");
+  HIP_TRY(hipSetDevice(p->parent->cfg.device_id));
+  const int k = (int)(ticket % p->K), set = (int)((ticket / p->K) & 1);
+  auto& L = p->lanes[k];
+  const int rc = lane_sync(p, L);
+  if (rc) return rc;
+  const float* B = L.pin_out[set];
+  const size_t F = p->F, cap = p->cap;
+  out->frames = p->F; out->cap = p->cap; out->desc_dim = p->D; out->netvlad_dim = p->G;
+  out->kps_xy = B + p->o_kps; out->scores = B + p->o_scores; out->desc = B + p->o_desc;
+  out->n_kp = reinterpret_cast<const int32_t*>(B + p->o_cnt);
+  out->netvlad = p->G ? B + p->o_nv : nullptr;
+  size_t pi = 0;
+  if (p->cfg.match_lr) {
+    out->lr_q = reinterpret_cast<const int32_t*>(B + p->o_mq) + pi * cap; out->lr_t = reinterpret_cast<const int32_t*>(B + p->o_mt) + pi * cap;
+    out->lr_dist = B + p->o_md + pi * cap; out->lr_n = reinterpret_cast<const int32_t*>(B + p->o_mn) + pi;
+    pi += F;
+  }
+  if (p->cfg.match_prev) {
+    out->prev_q = reinterpret_cast<const int32_t*>(B + p->o_mq) + pi * cap; out->prev_t = reinterpret_cast<const int32_t*>(B + p->o_mt) + pi * cap;
+    out->prev_dist = B + p->o_md + pi * cap; out->prev_n = reinterpret_cast<const int32_t*>(B + p->o_mn) + pi;
+  }
+  return D2FE_OK;
+}
+
+/* HIP-event timing of the lanes' launch sequences (d2fe_profile_enable / d2fe_profile_read of every lane, summed) */
+int d2fe_pipe_profile_enable(d2fe_pipe p, int mode) {
+  if (!p) return pipe_fail(D2FE_ERR_INVALID, "null pipe");
+  for (auto& L : p->lanes) { const int rc = d2fe_profile_enable(L.ctx, mode); if (rc) return rc; }
+  return D2FE_OK;
+}
+int d2fe_pipe_profile_read(d2fe_pipe p, float* ms, int32_t* launches) {
+  if (!p || !ms || !launches) return pipe_fail(D2FE_ERR_INVALID, "null argument");
+  for (int i = 0; i < D2FE_PROF_COUNT; ++i) { ms[i] = 0.f; launches[i] = 0; }
+  for (auto& L : p->lanes) {
+    float m[D2FE_PROF_COUNT]; int32_t n[D2FE_PROF_COUNT];
+    const int rc = d2fe_profile_read(L.ctx, m, n);
+    if (rc) return rc;
+    for (int i = 0; i < D2FE_PROF_COUNT; ++i) { ms[i] += m[i]; launches[i] += n[i]; }
+  }
+  return D2FE_OK;
+}
+
+int d2fe_pipe_lanes(d2fe_pipe p) { return p ? p->K : pipe_fail(D2FE_ERR_INVALID, "null pipe"); }
+
+}  // extern "C"

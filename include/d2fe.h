@@ -226,6 +226,60 @@ typedef struct {
 } d2fe_match_batch;
 D2FE_API int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* stream);
 
+/* ---- Frames in flight (throughput form of the per-frame work) ------------------------------------------------------------------
+ * The reference handles ONE stereo frame at a time on one thread (D2Frontend::processStereoframe, d2frontend.cpp:155-169): per image
+ * SuperPoint::infer and, for the main camera, MobileNetVLADONNX::inference (LoopCam::extractorImgDescDeepnet, loop_cam.cpp:589-648,
+ * both cameras: generateStereoImageDescriptor :440-470), then matchKNN left<->right and left<->previous left
+ * (D2FeatureTracker::trackLocalFrames, d2featuretracker.cpp:403-456,658-695).  A pipe runs exactly that work for `frames` stereo
+ * frames per submit with up to `lanes` submits in flight: d2fe_pipe_submit only enqueues (H2D, both networks, ONE matcher launch,
+ * ONE D2H, on the lane's own streams), d2fe_pipe_wait returns pointers into the lane's pinned result block.  Results are bit-identical
+ * to d2fe_extract_all_batch + d2fe_match_knn on the same frames.  A pipe borrows the handle's packed weights: keep the handle alive
+ * and do not reload weights while a pipe exists.  One submitting thread per pipe. */
+typedef struct d2fe_pipe_s* d2fe_pipe;
+typedef struct {
+  int32_t struct_size;      /* sizeof(d2fe_pipe_config) */
+  int32_t lanes;            /* submits in flight, 1..16 (each lane owns its activations: ~58 MB per 640x480 image) */
+  int32_t frames;           /* stereo frames per submit (>= 1); consecutive in time */
+  int32_t width, height;    /* frame size, within the handle's maximum */
+  int32_t cap;              /* keypoint capacity per image (rows of the result arrays) */
+  int32_t netvlad;          /* 1: NetVLAD of the left images (the main camera, loop_cam.cpp:446-451) */
+  int32_t match_lr;         /* 1: matchKNN L_f <-> R_f */
+  int32_t match_prev;       /* 1: matchKNN L_f <-> L_(f-1); f = 0: the last left frame of the previous submit (none for the first) */
+  int32_t pinned_input;     /* 1: the frame pointers handed to submit are page-locked and stay valid until the ticket was waited for
+                               (DMA straight from them); 0: submit copies the frames into the lane's pinned staging first */
+  double ratio;             /* knn_match_ratio */
+  double radius_lr;         /* search_local_max_dist_lr * width (<= 0: off), d2featuretracker.cpp:669 */
+  double radius_prev;       /* search_local_max_dist * width (<= 0: off), d2featuretracker.cpp:21-28 */
+  int32_t cu_partition;     /* 1: every lane launches on its own disjoint 1/lanes of the compute units (CU-masked streams): the lanes' kernels run
+                               side by side instead of queueing behind each other's full-device launches.  For small `frames`: a lane then
+                               behaves like a (256 / lanes)-CU device working on its own frame */
+  int32_t netvlad_inline;   /* 0: NetVLAD on the lane's second stream beside SuperPoint (shortest latency of one frame); 1: on the lane's one stream, in
+                               front of SuperPoint (half as many streams: with many lanes the device's hardware queues are the limit) */
+  int32_t reserved[6];
+} d2fe_pipe_config;
+typedef struct {            /* HOST pointers into the lane's pinned block; valid until 2 * lanes further submits */
+  int32_t frames, cap, desc_dim, netvlad_dim;
+  const float* kps_xy;      /* [2 frames][cap][2]   image order L_0 .. L_(F-1), R_0 .. R_(F-1) */
+  const float* scores;      /* [2 frames][cap] */
+  const float* desc;        /* [2 frames][cap][desc_dim] */
+  const int32_t* n_kp;      /* [2 frames] */
+  const float* netvlad;     /* [frames][netvlad_dim] or NULL */
+  const int32_t* lr_q; const int32_t* lr_t; const float* lr_dist; const int32_t* lr_n;            /* [frames][cap] x3, [frames]; NULL when off */
+  const int32_t* prev_q; const int32_t* prev_t; const float* prev_dist; const int32_t* prev_n;    /* prev_t indexes the previous left frame's keypoints */
+} d2fe_pipe_result;
+D2FE_API void d2fe_pipe_default_config(d2fe_pipe_config* cfg);
+D2FE_API int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out);
+D2FE_API void d2fe_pipe_destroy(d2fe_pipe p);
+D2FE_API int d2fe_pipe_lanes(d2fe_pipe p);
+/* d2fe_profile_enable / d2fe_profile_read over all lanes (sums) */
+D2FE_API int d2fe_pipe_profile_enable(d2fe_pipe p, int mode);
+D2FE_API int d2fe_pipe_profile_read(d2fe_pipe p, float* ms /*[D2FE_PROF_COUNT]*/, int32_t* launches /*[D2FE_PROF_COUNT]*/);
+/* left / right: `frames` gray u8 images each, image f at + f * image_stride, rows `stride` bytes apart.  Returns at once with a ticket
+ * (0, 1, 2, ...).  Blocks only when the ticket's lane still holds the frame submitted `lanes` submits ago that nobody waited for. */
+D2FE_API int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int stride, size_t image_stride, int64_t* ticket);
+/* Blocks until the ticket's frame is complete on the host.  Tickets may be waited for in any order, each within 2 * lanes submits. */
+D2FE_API int d2fe_pipe_wait(d2fe_pipe p, int64_t ticket, d2fe_pipe_result* out);
+
 /* Half-image filter for quadcam neighbour matching.  Replaces getFeatureHalfImg
  * (d2featuretracker.cpp:1051-1075): map[c] = source index of the c-th kept keypoint; returns count in *n_out. */
 D2FE_API int d2fe_half_image_filter(const float* pts_xy, int n, int require_left, int width_undistort,

@@ -1,0 +1,103 @@
+"""Frames in flight (d2fe_pipe_*, include/d2fe.h): the pipe's results equal the single-call entry points' bit for bit -- the reference's per-frame
+sequence (loop_cam.cpp:589-648 infer + inference per image, d2featuretracker.cpp:403-456,658-695 matchKNN L<->R and L<->previous L)."""
+import numpy as np
+import pytest
+
+from d2slam_amd.synth import synth_stereo
+
+H, W, CAP = 120, 160, 80
+
+
+def _frames(n):
+    """consecutive frames of one scene under a small camera motion, so that the temporal matches exist"""
+    l0, r0 = synth_stereo(H, W, seed=100)
+    rng = np.random.RandomState(5)
+    out = []
+    for i in range(n):
+        sh = (i % 4, (2 * i) % 5)
+        noise = rng.randint(-2, 3, (2, H, W))
+        out.append((np.clip(np.roll(l0, sh, (0, 1)).astype(np.int16) + noise[0], 0, 255).astype(np.uint8),
+                    np.clip(np.roll(r0, sh, (0, 1)).astype(np.int16) + noise[1], 0, 255).astype(np.uint8)))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes,frames,netvlad,part", [(1, 1, True, False), (3, 1, True, False), (2, 2, True, False), (4, 1, False, False), (2, 3, True, False),
+                                                      (4, 1, True, True), (3, 2, True, True), (8, 1, True, True)])
+def test_pipe_equals_single_calls(lanes, frames, netvlad, part):
+    from d2slam_amd import api, netvlad as nvm
+    from d2slam_amd.weights import synthetic_superpoint_weights
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2 * frames, precision=api.PREC_F32_WINO,
+                                           keypoint_threshold=0.005))
+    fe.load_superpoint(synthetic_superpoint_weights(dustbin_bias=7.5))
+    if netvlad:
+        fe.load_netvlad(nvm.synthetic_netvlad_weights())
+    nsub = 2 * lanes + 3
+    fr = _frames(nsub * frames)
+    radius_lr, radius_prev = 0.2 * W, 0.05 * W
+    pipe = api.StereoPipe(fe, lanes=lanes, frames=frames, width=W, height=H, cap=CAP, netvlad=netvlad, ratio=0.8, radius_lr=radius_lr, radius_prev=radius_prev, cu_partition=part)
+    got = []
+    tickets = []
+    for sidx in range(nsub):
+        L = np.stack([fr[sidx * frames + f][0] for f in range(frames)]); R = np.stack([fr[sidx * frames + f][1] for f in range(frames)])
+        tickets.append(pipe.submit(L, R))
+        if len(tickets) > lanes - 1:                       # keep `lanes` submits in flight
+            t = tickets[len(got)]
+            got.append({k: (None if v is None else v.copy()) for k, v in pipe.wait(t).items()})
+    while len(got) < nsub:
+        got.append({k: (None if v is None else v.copy()) for k, v in pipe.wait(tickets[len(got)]).items()})
+    # single-call reference on the same handle
+    prev = None
+    nmatch = 0
+    for sidx in range(nsub):
+        imgs = np.stack([fr[sidx * frames + f][0] for f in range(frames)] + [fr[sidx * frames + f][1] for f in range(frames)])
+        if netvlad:
+            ext, g = fe.extract_all_batch(imgs, frames, cap=CAP)
+        else:
+            ext, g = fe.extract_batch(imgs, cap=CAP), None
+        o = got[sidx]
+        for i, (kps, sc, desc) in enumerate(ext):
+            n = int(o["n_kp"][i])
+            assert n == len(kps)
+            np.testing.assert_array_equal(o["kps_xy"][i, :n], kps)
+            np.testing.assert_array_equal(o["scores"][i, :n], sc)
+            np.testing.assert_array_equal(o["desc"][i, :n], desc)
+        if netvlad:
+            np.testing.assert_array_equal(o["netvlad"], g)
+        for f in range(frames):
+            kl, _, dl = ext[f]; kr, _, dr = ext[frames + f]
+            q, t, d = fe.match_knn(dl, dr, 0.8, kl, kr, radius_lr)
+            n = int(o["lr_n"][f]); assert n == len(q)
+            np.testing.assert_array_equal(o["lr_q"][f, :n], q); np.testing.assert_array_equal(o["lr_t"][f, :n], t); np.testing.assert_array_equal(o["lr_dist"][f, :n], d)
+            pv = ext[f - 1] if f > 0 else prev
+            n = int(o["prev_n"][f])
+            if pv is None:
+                assert n == 0
+            else:
+                q, t, d = fe.match_knn(dl, pv[2], 0.8, kl, pv[0], radius_prev)
+                assert n == len(q)
+                np.testing.assert_array_equal(o["prev_q"][f, :n], q); np.testing.assert_array_equal(o["prev_t"][f, :n], t); np.testing.assert_array_equal(o["prev_dist"][f, :n], d)
+                nmatch += n
+        prev = ext[frames - 1]
+    assert nmatch > 0
+    pipe.close(); fe.close()
+
+
+@pytest.mark.gpu
+def test_pipe_argument_errors():
+    from d2slam_amd import api
+    from d2slam_amd.weights import synthetic_superpoint_weights
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2))
+    with pytest.raises(api.D2FEError):
+        api.StereoPipe(fe, lanes=2, width=W, height=H, netvlad=False)          # weights not loaded
+    fe.load_superpoint(synthetic_superpoint_weights())
+    with pytest.raises(api.D2FEError):
+        api.StereoPipe(fe, lanes=2, width=W, height=H, netvlad=True)           # no NetVLAD network
+    with pytest.raises(api.D2FEError):
+        api.StereoPipe(fe, lanes=0, width=W, height=H, netvlad=False)
+    with pytest.raises(api.D2FEError):
+        api.StereoPipe(fe, lanes=2, width=2 * W, height=H, netvlad=False)
+    p = api.StereoPipe(fe, lanes=2, width=W, height=H, netvlad=False)
+    with pytest.raises(api.D2FEError):
+        p.wait(0)                                                               # nothing submitted
+    p.close(); fe.close()
