@@ -500,6 +500,9 @@ def main():
             out["wino_vs_exact_on_bench_frames"] = disagreement
         if disagreement_fast:
             out["f16x2_vs_exact_on_bench_frames"] = disagreement_fast
+        ev = index_parity_evidence()
+        if ev:
+            out["index_parity_evidence"] = ev
         if batch_curve:
             out["batch_curve"] = {"what": "stereo fps of the same step (H2D, SuperPoint L+R, NetVLAD L, matchKNN L<->R and L<->previous L, D2H of everything) against the stereo frames "
                                           "per submit, through d2fe_pipe_*; submits_in_flight = 1 is the synchronous single-call form (the way the reference calls the path, "
@@ -684,6 +687,26 @@ def collective_evidence(torch, dist, dev, backend, rank, world):
     return {"backend": dist.get_backend(), "is_rccl": dist.get_backend() == "nccl", "rccl_version": ver, "world_size": dist.get_world_size(),
             "allreduce_sum_of_ranks": float(t.item()), "expected_sum": float(world * (world - 1) // 2),
             "distinct_devices": len(ids), "ranks": allr}
+
+
+def index_parity_evidence():
+    """The committed run of tools/mode_disagreement.py (profiles/r04_mode_disagreement.json): keypoint / match index differences of the Winograd and
+    fp16 hi/lo modes against the exact fp32 mode over 1056 images (992 synthetic + 64 derived from the real crops of the reference's sample image) at
+    N = 100 / 150 / 200 and thresholds 0.015 / 0.15.  Summarised here as the worst rate over the six configurations; the bench frames of THIS run are
+    compared live in `wino_vs_exact_on_bench_frames` / `f16x2_vs_exact_on_bench_frames`."""
+    path = os.path.join(ROOT, "profiles", "r04_mode_disagreement.json")
+    if not os.path.exists(path):
+        return None
+    j = json.load(open(path))
+    out = {"source": "profiles/r04_mode_disagreement.json (python tools/mode_disagreement.py on MI355X, same kernels; not collected inside this run)",
+           "images": j["images"], "real_derived_images": j["real_derived_images"], "pairs": j["pairs"], "configs": "N in {100, 150, 200} x threshold in {0.015, 0.15}"}
+    for m in ("wino", "f16x2"):
+        rows = [c["%s_vs_f32_all" % m] for c in j["configs"]]
+        out[m + "_vs_f32"] = {"keypoints_compared": sum(r["keypoints"] for r in rows), "keypoints_in_one_mode_only": sum(r["keypoints_in_one_mode_only"] for r in rows),
+                              "worst_per_1e4_keypoints": max(r["per_1e4_keypoints"] for r in rows),
+                              "matches_compared": sum(r["matches"] for r in rows), "matches_in_one_mode_only": sum(r["matches_in_one_mode_only"] for r in rows),
+                              "worst_per_1e4_matches": max(r["per_1e4_matches"] for r in rows)}
+    return out
 
 
 def profiled_traffic(kernel_tag):

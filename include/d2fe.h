@@ -202,13 +202,12 @@ D2FE_API int d2fe_match_knn(d2fe_handle h, const float* a, int na, const float* 
 D2FE_API int d2fe_match_crosscheck(d2fe_handle h, const float* a, int na, const float* b, int nb, int dim,
                                    int32_t* q_idx, int32_t* t_idx, float* dist, int cap, int* n_out);
 
-/* Both matchers pick eight candidates per query with a Gram-trick prefilter and re-rank the first four in the reference's (OpenCV's)
- * arithmetic.  A query whose first four cannot be PROVEN to contain the true two nearest neighbours (the prefilter's rigorous error
- * bound; about 1 % of the queries on SuperPoint descriptors) has candidates 5..8 re-ranked as well; if eight cannot be proven either
- * (more than eight train rows within fp32 round-off of each other: repeated texture, near-duplicate frames, degenerate sets) the
- * query is re-evaluated by an exact scan of all train rows.  The result equals the reference's for any input.
- * d2fe_match_fallback_rows returns how many queries went past the first four candidates since the last reset and, in *full_scans
- * (may be NULL), how many of them took the exact scan (diagnostic; synchronises the device). */
+/* Both matchers select candidates on a Gram-trick distance (fp32 matrix pipe) whose error against the reference's (OpenCV's) arithmetic
+ * is rigorously bounded: every train row that the bound cannot separate from the second-nearest one (2.0-2.3 rows per query on
+ * SuperPoint descriptors) is re-ranked in the reference's arithmetic; a query with more than 16 such rows (repeated texture,
+ * near-duplicate frames, degenerate sets) is re-evaluated by an exact scan of all train rows.  The result equals the reference's for any
+ * input.  d2fe_match_fallback_rows returns how many candidates beyond two per query were re-ranked since the last reset and, in
+ * *full_scans (may be NULL), how many queries took the exact scan (diagnostic; synchronises the device). */
 D2FE_API long d2fe_match_fallback_rows(d2fe_handle h, int reset, long* full_scans);
 
 /* Batched, device-resident matcher: npairs problems; pair p matches rows [a_off[p], a_off[p]+a_cnt[p]) of

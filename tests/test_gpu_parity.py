@@ -246,20 +246,23 @@ def _unit(x):
     return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
 
 
-SATURATED = ["eight_identical_train_rows", "all_equal_train_set", "self_plus_noise_1e-7", "six_near_copies_of_every_row",
+SATURATED = ["eight_identical_train_rows", "twenty_identical_train_rows", "all_equal_train_set", "self_plus_noise_1e-7", "six_near_copies_of_every_row",
              "both_sets_all_equal"]
 
 
 @pytest.mark.parametrize("case", SATURATED)
 def test_match_saturated_candidate_lists_are_exact(api, orc, case):
-    """More than four train rows within fp32 round-off of the nearest distance (repeated texture, a frame against a near-copy):
-    the Gram-trick top-4 cannot be trusted there, the kernel must notice and fall back to the exact scan (match.hip header).
+    """Many train rows within fp32 round-off of the nearest distance (repeated texture, a frame against a near-copy): every row the
+    Gram-trick distance cannot separate from the second neighbour must be re-ranked exactly, and beyond the kernel's 16 candidate slots
+    per query the exact scan of every row must run (match.hip header).
     Indices AND distances bitwise against the oracle and, when present, the reference's own matchKNN (oracle/_ref)."""
     from oracle import ref
     rng = np.random.RandomState(11)
     a = _unit(rng.randn(150, 256)); b = _unit(rng.randn(180, 256))
     if case == "eight_identical_train_rows":
         b[20:28] = b[20]; a[5] = _unit(b[20:21] + 1e-3 * rng.randn(1, 256))[0]; a[6] = b[20]
+    elif case == "twenty_identical_train_rows":
+        b[20:40] = b[20]; a[5] = _unit(b[20:21] + 1e-3 * rng.randn(1, 256))[0]; a[6] = b[20]
     elif case == "all_equal_train_set":
         b[:] = b[0]
     elif case == "self_plus_noise_1e-7":
@@ -283,11 +286,10 @@ def test_match_saturated_candidate_lists_are_exact(api, orc, case):
         q, t, d = fe.match_crosscheck(a, b)
         rq, rt, rd = orc.match_crosscheck(a, b)
         assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd), case
-    past4, scans = fe.match_fallback_rows(full=True)
-    if case != "self_plus_noise_1e-7":       # there every row has three near-equal partners at most: the first four provably suffice
-        assert past4 > 0, "the saturated rows of %s did not go past the first four candidates" % case
-    if "all_equal" in case or case == "eight_identical_train_rows":
-        assert scans > 0, "more than eight rows within round-off (%s): the exact scan must have run" % case
+    extra, scans = fe.match_fallback_rows(full=True)
+    assert extra > 0, "the saturated rows of %s were not re-ranked beyond two candidates" % case
+    if "all_equal" in case or case == "twenty_identical_train_rows":
+        assert scans > 0, "more than sixteen rows within round-off (%s): the exact scan must have run" % case
     fe.close()
 
 
