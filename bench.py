@@ -72,7 +72,7 @@ def main():
                          "descriptor re-normalised over its 256 floats on decode.  Either way 3.9x fewer all-gather bytes")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency leg (host-pointer C ABI, one frame per call)")
     ap.add_argument("--latency-calls", type=int, default=300)
-    ap.add_argument("--latency-only", action="store_true", help="print only the single-call latency leg (A/B runs: D2FE_GRAPH=0, D2FE_PINNED=0)")
+    ap.add_argument("--latency-only", action="store_true", help="print only the single-call latency leg, in a process that does nothing but call the C ABI")
     args = ap.parse_args()
     for k in REFUSED_ENV:
         if os.environ.get(k):
@@ -91,7 +91,7 @@ def main():
         from d2slam_amd.weights import synthetic_superpoint_weights
         print(json.dumps({"latency": run_latency(api, synthetic_superpoint_weights(dustbin_bias=7.5), nvm.synthetic_netvlad_weights(),
                                                  int(os.environ.get("LOCAL_RANK", "0")), args.precision, args.latency_calls),
-                          "env": {k: os.environ.get(k) for k in ("D2FE_GRAPH", "D2FE_PINNED")}}), flush=True)
+                          }), flush=True)
         return
 
     import torch
@@ -338,7 +338,7 @@ def main():
 
         c1b_ms, c1b_n = prof["conv1b"]
         avg_ms = c1b_ms / max(c1b_n, 1)
-        roofline = conv1b_roofline(precision, avg_ms, c1b_n, NI, os.environ.get("D2FE_FUSE1A", "1") != "0")
+        roofline = conv1b_roofline(precision, avg_ms, c1b_n, NI, True)
         nv_ms, nv_n = prof["netvlad"]
         roofline_nv = None
         if netvlad and nv_n:

@@ -20,6 +20,7 @@ from .weights import SP_LAYERS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libd2fe_hip.so")
+DEV_LIB_PATH = os.path.join(_HERE, "lib", "libd2fe_hip_dev.so")      # -DD2FE_DEVTOOLS: d2fe_debug_* test hooks, phase stamps, D2FE_* schedule switches
 if os.environ.get("D2FE_LIB"):      # developer knob: same-box A/B of two builds of the library (tools/gpu_ab_lib.sh)
     LIB_PATH = os.path.abspath(os.environ["D2FE_LIB"])
 
@@ -87,21 +88,26 @@ class _PipeResult(C.Structure):
 
 
 _lib = None
+_dev_lib = None
 
-EXPORTS = ["d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_create", "d2fe_destroy",
-           "d2fe_load_superpoint", "d2fe_set_superpoint_pca", "d2fe_desc_dim", "d2fe_superpoint_extract", "d2fe_superpoint_extract_batch",
-           "d2fe_superpoint_extract_device", "d2fe_extract_all", "d2fe_extract_all_batch", "d2fe_tail_stream", "d2fe_superpoint_wait_tail", "d2fe_load_netvlad", "d2fe_set_netvlad_pca", "d2fe_netvlad_dim",
-           "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device", "d2fe_match_fallback_rows", "d2fe_debug_graph_count",
-           "d2fe_block_words", "d2fe_block_field_offset", "d2fe_pack_blocks_device", "d2fe_gate_pairs_device", "d2fe_quad_gate_device", "d2fe_block_bytes_int8", "d2fe_pack_blocks_int8_device", "d2fe_unpack_blocks_int8_device",
-           "d2fe_half_move_cols", "d2fe_half_image_compact_device", "d2fe_remap_matches_device",
-           "d2fe_half_image_filter", "d2fe_undistort", "d2fe_undistort_device", "d2fe_db_create", "d2fe_db_destroy",
-           "d2fe_db_ntotal", "d2fe_db_add", "d2fe_db_search", "d2fe_db_query_gated", "d2fe_quantize_int8", "d2fe_dequantize_int8",
-           "d2fe_debug_read", "d2fe_debug_netvlad_layer", "d2fe_debug_netvlad_stamps", "d2fe_debug_pack_wino", "d2fe_debug_pack_netvlad", "d2fe_debug_netvlad_tile", "d2fe_debug_conv3x3_wino", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read",
-           "d2fe_prepare_gray", "d2fe_prepare_gray_device", "d2fe_gen_cylinder_map", "d2fe_gen_cylinder_map_device", "d2fe_gen_pinhole_map", "d2fe_gen_pinhole_map_device",
-           "d2fe_lk_frame_create", "d2fe_lk_frame_create_device", "d2fe_lk_frame_destroy", "d2fe_lk_frame_read_level",
-           "d2fe_lk_track", "d2fe_lk_track_batch", "d2fe_detect_fast_by_region", "d2fe_good_features_to_track",
-           "d2fe_pipe_default_config", "d2fe_pipe_create", "d2fe_pipe_destroy", "d2fe_pipe_lanes", "d2fe_pipe_submit", "d2fe_pipe_wait",
-           "d2fe_pipe_profile_enable", "d2fe_pipe_profile_read"]
+EXPORTS = [
+    "d2fe_last_error", "d2fe_version", "d2fe_default_config", "d2fe_create", "d2fe_destroy", "d2fe_load_superpoint", "d2fe_set_superpoint_pca",
+    "d2fe_desc_dim", "d2fe_superpoint_extract", "d2fe_superpoint_extract_batch", "d2fe_superpoint_extract_device", "d2fe_extract_all",
+    "d2fe_extract_all_batch", "d2fe_tail_stream", "d2fe_superpoint_wait_tail", "d2fe_load_netvlad", "d2fe_set_netvlad_pca", "d2fe_netvlad_dim",
+    "d2fe_netvlad", "d2fe_netvlad_batch", "d2fe_netvlad_device", "d2fe_match_knn", "d2fe_match_crosscheck", "d2fe_match_batch_device",
+    "d2fe_match_fallback_rows", "d2fe_block_words", "d2fe_block_field_offset", "d2fe_pack_blocks_device", "d2fe_gate_pairs_device",
+    "d2fe_quad_gate_device", "d2fe_block_bytes_int8", "d2fe_pack_blocks_int8_device", "d2fe_unpack_blocks_int8_device", "d2fe_half_move_cols",
+    "d2fe_half_image_compact_device", "d2fe_remap_matches_device", "d2fe_half_image_filter", "d2fe_undistort", "d2fe_undistort_device",
+    "d2fe_db_create", "d2fe_db_destroy", "d2fe_db_ntotal", "d2fe_db_add", "d2fe_db_search", "d2fe_db_query_gated", "d2fe_quantize_int8",
+    "d2fe_dequantize_int8", "d2fe_sync", "d2fe_profile_enable", "d2fe_profile_read", "d2fe_prepare_gray", "d2fe_prepare_gray_device",
+    "d2fe_gen_cylinder_map", "d2fe_gen_cylinder_map_device", "d2fe_gen_pinhole_map", "d2fe_gen_pinhole_map_device", "d2fe_lk_frame_create",
+    "d2fe_lk_frame_create_device", "d2fe_lk_frame_destroy", "d2fe_lk_frame_read_level", "d2fe_lk_track", "d2fe_lk_track_batch",
+    "d2fe_detect_fast_by_region", "d2fe_good_features_to_track", "d2fe_pipe_default_config", "d2fe_pipe_create", "d2fe_pipe_destroy",
+    "d2fe_pipe_lanes", "d2fe_pipe_submit", "d2fe_pipe_wait", "d2fe_pipe_profile_enable", "d2fe_pipe_profile_read"]
+# the development library (lib/libd2fe_hip_dev.so, include/d2fe_debug.h) exports these on top: test hooks and kernel diagnostics
+DEBUG_EXPORTS = [
+    "d2fe_debug_graph_count", "d2fe_debug_read", "d2fe_debug_netvlad_layer", "d2fe_debug_netvlad_stamps", "d2fe_debug_pack_wino",
+    "d2fe_debug_pack_netvlad", "d2fe_debug_netvlad_tile", "d2fe_debug_conv3x3_wino", "d2fe_debug_match_stamps"]
 
 
 def _preload_hip_runtime():
@@ -125,18 +131,33 @@ def _preload_hip_runtime():
                 pass
 
 
-def load_library():
-    """dlopen the C-ABI library.  Raises if it has not been built (python -m d2slam_amd.build)."""
-    global _lib
+def load_library(dev=False):
+    """dlopen the C-ABI library (dev=True: the development library with the d2fe_debug_* hooks, include/d2fe_debug.h).  Raises if it has not
+    been built (python -m d2slam_amd.build [--dev])."""
+    global _lib, _dev_lib
+    if dev:
+        if _dev_lib is None:
+            _dev_lib = _open_library(DEV_LIB_PATH, True)
+        return _dev_lib
     if _lib is None:
+        _lib = _open_library(LIB_PATH, False)
+    return _lib
+
+
+def _open_library(path, dev):
+    if True:
         _preload_hip_runtime()
-        if not os.path.exists(LIB_PATH):
-            raise D2FEError(-100, "libd2fe_hip.so not built: run `python __graft_entry__.py` or d2slam_amd/build.py "
-                                  "(no CPU fallback exists)")
-        lib = C.CDLL(LIB_PATH)
+        if not os.path.exists(path):
+            raise D2FEError(-100, "%s not built: run `python __graft_entry__.py` or `python -m d2slam_amd.build%s` "
+                                  "(no CPU fallback exists)" % (os.path.basename(path), " --dev" if dev else ""))
+        lib = C.CDLL(path)
         lib.d2fe_last_error.restype = C.c_char_p
         lib.d2fe_version.restype = C.c_char_p
-        lib.d2fe_debug_read.restype = C.c_long
+        if dev:
+            lib.d2fe_debug_read.restype = C.c_long
+            lib.d2fe_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+            for nm in ("d2fe_debug_netvlad_layer", "d2fe_debug_netvlad_stamps", "d2fe_debug_pack_wino", "d2fe_debug_pack_netvlad", "d2fe_debug_match_stamps"):
+                getattr(lib, nm).restype = C.c_long
         lib.d2fe_destroy.restype = None
         lib.d2fe_half_move_cols.restype = C.c_float
         lib.d2fe_half_move_cols.argtypes = [C.c_int, C.c_double]
@@ -159,7 +180,6 @@ def load_library():
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.d2fe_match_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.d2fe_half_image_filter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
-        lib.d2fe_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
         lib.d2fe_create.argtypes = [C.c_void_p, C.c_void_p]
         lib.d2fe_destroy.argtypes = [C.c_void_p]
         lib.d2fe_load_superpoint.argtypes = [C.c_void_p, C.c_void_p]
@@ -224,8 +244,7 @@ def load_library():
         lib.d2fe_pipe_wait.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         lib.d2fe_pipe_profile_enable.argtypes = [C.c_void_p, C.c_int]
         lib.d2fe_pipe_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        _lib = lib
-    return _lib
+    return lib
 
 
 def _check(rc):
@@ -270,8 +289,10 @@ class SuperPointConfig:
 class FrontEnd:
     """One device context (== one LoopCam's networks, loop_cam.cpp:24-70)."""
 
-    def __init__(self, cfg: SuperPointConfig):
-        lib = load_library()
+    def __init__(self, cfg: SuperPointConfig, dev: bool = False):
+        """dev=True: a handle of the development library (d2fe_debug_* hooks, D2FE_* schedule switches); the product library otherwise."""
+        lib = load_library(dev)
+        self.dev = bool(dev)
         c = _Config()
         lib.d2fe_default_config(C.byref(c))
         c.device_id = cfg.device_id
@@ -292,6 +313,11 @@ class FrontEnd:
         _check(lib.d2fe_create(C.byref(c), C.byref(self._h)))
         self._lib = lib
         self._keep = None
+
+    def _need_dev(self, what):
+        if not self.dev:
+            raise D2FEError(-5, "%s is a test hook of the development library: create the handle with FrontEnd(cfg, dev=True) / DevFrontEnd(cfg) "
+                                "(include/d2fe_debug.h; the product library exports no d2fe_debug_* symbol)" % what)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -373,6 +399,7 @@ class FrontEnd:
 
     def graph_count(self):
         """(cached hipGraphs of host-pointer launch sequences, geometries whose capture was rejected) -- include/d2fe.h."""
+        self._need_dev("graph_count")
         bad = C.c_int(0)
         self._lib.d2fe_debug_graph_count.argtypes = [C.c_void_p, C.c_void_p]
         n = int(self._lib.d2fe_debug_graph_count(self._h, C.byref(bad)))
@@ -401,6 +428,7 @@ class FrontEnd:
         _check(self._lib.d2fe_superpoint_wait_tail(self._h, C.c_void_p(stream or 0)))
 
     def debug_read(self, name, shape):
+        self._need_dev("debug_read")
         out = np.empty(shape, np.float32)
         r = self._lib.d2fe_debug_read(self._h, name.encode(), _ptr(out), out.nbytes)
         if r < 0:
@@ -411,6 +439,7 @@ class FrontEnd:
 
     def debug_conv3x3_wino(self, x, weight, bias, pool=False, relu=True, iters=0):
         """One 3x3 layer through the Winograd kernels: x [n,H,W,Cin] NHWC, weight [Cout,Cin,3,3].  Returns (out, ms_per_launch)."""
+        self._need_dev("debug_conv3x3_wino")
         x = np.ascontiguousarray(x, np.float32); weight = np.ascontiguousarray(weight, np.float32)
         bias = np.ascontiguousarray(bias, np.float32)
         n, H, W, cin = x.shape
@@ -472,6 +501,7 @@ class FrontEnd:
 
     def debug_netvlad_layer(self, layer, shape):
         """Output of one layer of the last netvlad call ([n,h,w,c] fp32) or None when it only exists inside a fused block."""
+        self._need_dev("debug_netvlad_layer")
         out = np.empty(shape, np.float32)
         self._lib.d2fe_debug_netvlad_layer.restype = C.c_long
         r = self._lib.d2fe_debug_netvlad_layer(self._h, int(layer), int(shape[0]), _ptr(out), C.c_size_t(out.nbytes))
@@ -484,6 +514,7 @@ class FrontEnd:
 
     def debug_netvlad_stamps(self, max_wgs=32768):
         """[workgroups][32] uint64 phase stamps of the plan step named by D2FE_NV_STAMP_STEP (see include/d2fe.h)."""
+        self._need_dev("debug_netvlad_stamps")
         out = np.zeros((max_wgs, 32), np.uint64)
         self._lib.d2fe_debug_netvlad_stamps.restype = C.c_long
         r = int(self._lib.d2fe_debug_netvlad_stamps(self._h, _ptr(out), C.c_long(max_wgs)))
@@ -647,6 +678,13 @@ class FrontEnd:
         mb = _MatchBatch(d_a, d_b, d_pts_a, d_pts_b, d_a_off, d_b_off, d_a_cnt, d_b_cnt, npairs, dim, max_n, mode,
                          ratio, radius, d_q, d_t, d_dist, d_n)
         _check(self._lib.d2fe_match_batch_device(self._h, C.byref(mb), stream))
+
+
+class DevFrontEnd(FrontEnd):
+    """FrontEnd on the development library (lib/libd2fe_hip_dev.so): the d2fe_debug_* test hooks and the D2FE_* schedule switches exist only there."""
+
+    def __init__(self, cfg: SuperPointConfig):
+        super().__init__(cfg, dev=True)
 
 
 class StereoPipe:

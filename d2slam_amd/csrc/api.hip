@@ -16,6 +16,9 @@
 #include <vector>
 
 #include "context.h"
+#ifdef D2FE_DEVTOOLS
+#include "../../include/d2fe_debug.h"
+#endif
 
 using namespace d2fe;
 
@@ -190,10 +193,9 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     a.H = hh; a.W = ww; a.n_img = n; a.in_img_stride = iis; a.out_img_stride = ois; a.zeros = h->zeros; a.ncu = h->ncu;
     a.tag = (&L == &h->L[L_1B]) ? 1 : 0;
     a.work_ctr = (prec == D2FE_PREC_F32_WINO && h->wino_dynamic) ? h->work_ctrs + (int)(&L - &h->L[0]) : nullptr;
-    { static int ab = -1; if (ab < 0) { const char* e = getenv("D2FE_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
+    { static const int ab = d2fe_dev_env("D2FE_ABLATE", 0); a.ablate = ab; }
     if (prec != D2FE_PREC_F16X2 && shape == CONV_256_1x1_T4x16 && L.cout == 65 && !pool && !relu) {      // convPb
-      static int on = -1;
-      if (on < 0) { const char* e = getenv("D2FE_CONV1X1"); on = e ? atoi(e) : 1; }
+      static const int on = d2fe_dev_env("D2FE_CONV1X1", 1);
       if (on) { const hipError_t e = launch_conv1x1_256_65(a, s); if (e != hipErrorNotSupported) return e; }
     }
     if (prec == D2FE_PREC_F32_WINO)   // 3x3 layers: Winograd kernels; the 1x1 heads: the exact fp32 kernels
@@ -345,7 +347,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   const int rc_alloc = [&]() -> int {
   // conv1a is evaluated inside conv1b's staging in every mode (the Winograd kernel runs it on the matrix pipe): the 78.6 MB/image
   // activation never exists.  D2FE_FUSE1A=0 falls back to a stand-alone conv1a kernel (bit-identical; kept for A/B measurements).
-  { const char* e = getenv("D2FE_FUSE1A"); if (e) h->fuse1a = atoi(e) != 0; }
+  h->fuse1a = d2fe_dev_env("D2FE_FUSE1A", 1) != 0;
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     const size_t H = cfg->max_height, W = cfg->max_width;
     const int B = cfg->max_batch;
@@ -378,7 +380,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
       if (alloc_f(h->a4b2, H * W * 2, B) || alloc_f(h->logits2, (H / 8) * (W / 8) * 65, B) || alloc_f(h->draw2, H * W * 4, B)) return D2FE_ERR_HIP;
     }
     h->sparse_desc = !cfg->dense_descriptors;
-    { const char* e = getenv("D2FE_SPARSE_MIN_BATCH"); if (e) h->sp_min_batch = atoi(e); }
+    h->sp_min_batch = d2fe_dev_env("D2FE_SPARSE_MIN_BATCH", h->sp_min_batch);
     if (h->sparse_desc) {
       const size_t ncell = (H / 8) * (W / 8);
       h->sp_slots = 4 * (cfg->max_keypoints < 0 || cfg->max_keypoints > 1024 ? 1024 : cfg->max_keypoints);   // <= 4 corner cells per keypoint; larger calls take the dense head
@@ -393,7 +395,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device_id) == hipSuccess && v > 0) h->ncu = v; }
     HIP_TRY(hipMalloc(&h->match_stats, 4 * sizeof(int32_t)));
     HIP_TRY(hipMemset(h->match_stats, 0, 4 * sizeof(int32_t)));
-    { const char* e = getenv("D2FE_WINO_DYNAMIC"); if (e) h->wino_dynamic = atoi(e) != 0; }
+    h->wino_dynamic = d2fe_dev_env("D2FE_WINO_DYNAMIC", 1) != 0;
     if (cfg->postproc == D2FE_POSTPROC_A) {
       HIP_TRY(hipMalloc(&h->aconf, sizeof(float) * H * W * B));
       HIP_TRY(hipMalloc(&h->clist, sizeof(int) * H * W * B));
@@ -406,8 +408,8 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     HIP_TRY(hipMalloc(&h->s_img, H * W * B));
     h->s_out_bytes = (sizeof(float) * (size_t)h->s_cap * 260 + sizeof(int32_t)) * B;
     HIP_TRY(hipMalloc(&h->s_out, h->s_out_bytes));
-    { const char* e = getenv("D2FE_GRAPH"); if (e) h->use_graphs = atoi(e) != 0; }
-    { const char* e = getenv("D2FE_PINNED"); if (e) h->use_pinned = atoi(e) != 0; }
+    h->use_graphs = d2fe_dev_env("D2FE_GRAPH", 1) != 0;
+    h->use_pinned = d2fe_dev_env("D2FE_PINNED", 1) != 0;
     if (h->use_pinned) {
       h->pin_in_bytes = (size_t)H * W * B;
       h->pin_out_bytes = h->s_out_bytes;
@@ -923,18 +925,14 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
   }
   // ---- plan: fuse [conv0 ->] [pw expand ->] dw -> pw project where the kernels support the shape (D2FE_NV_LEGACY=1: one launch per layer)
   {
-    const char* e = getenv("D2FE_NV_LEGACY");
-    const bool legacy = e && atoi(e) != 0;
-    if (const char* v = getenv("D2FE_NV_BLOCKS")) { if (atoi(v) > 0) h->nv_blocks_target = atoi(v); }
-    if (const char* v = getenv("D2FE_NV_TAIL_BLOCKS")) { if (atoi(v) > 0) h->nv_tail_blocks = atoi(v); }
-    if (const char* v = getenv("D2FE_NV_SLABSUM")) h->nv_slabsum = atoi(v);
-    h->nv_front_tpw = 0; h->nv_nbuf = 0;
-    if (const char* v = getenv("D2FE_NV_FRONT_TPW")) h->nv_front_tpw = atoi(v);
-    if (const char* v = getenv("D2FE_NV_NBUF")) h->nv_nbuf = atoi(v);
-    if (const char* v = getenv("D2FE_NV_STAMP_STEP")) {
-      h->nv_stamp_step = atoi(v);
-      if (!h->nv_stamps) HIP_TRY(hipMalloc(&h->nv_stamps, sizeof(unsigned long long) * 32 * 32768));
-    }
+    // schedule switches of the development library (A/B measurements; the product library always takes the defaults: the measured best)
+    const bool legacy = d2fe_dev_env("D2FE_NV_LEGACY", 0) != 0;
+    { const int v = d2fe_dev_env("D2FE_NV_BLOCKS", 0); if (v > 0) h->nv_blocks_target = v; }
+    { const int v = d2fe_dev_env("D2FE_NV_TAIL_BLOCKS", 0); if (v > 0) h->nv_tail_blocks = v; }
+    h->nv_slabsum = d2fe_dev_env("D2FE_NV_SLABSUM", h->nv_slabsum);
+    h->nv_front_tpw = d2fe_dev_env("D2FE_NV_FRONT_TPW", 0); h->nv_nbuf = d2fe_dev_env("D2FE_NV_NBUF", 0);
+    h->nv_stamp_step = d2fe_dev_env("D2FE_NV_STAMP_STEP", -1);
+    if (h->nv_stamp_step >= 0 && !h->nv_stamps) HIP_TRY(hipMalloc(&h->nv_stamps, sizeof(unsigned long long) * 32 * 32768));
     const int nl = w->n_layers;
     auto K = [&](int i) { return i < nl ? h->nv[i].kind : -1; };
     std::vector<char> materialised(nl, 0);
@@ -946,16 +944,15 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
         if (K(i) == D2FE_NV_CONV && K(i + 1) == D2FE_NV_DW && K(i + 2) == D2FE_NV_PW && h->nv[i + 1].res < 0 && h->nv[i + 2].res < 0 &&
             nv_block_supported(h->nv[i + 1].cin, h->nv[i + 1].cin, h->nv[i + 2].cout, h->nv[i + 1].stride, false, 1)) {
           st.fused = true; st.front = true; st.l1 = i + 2;
-          { const char* pq = getenv("D2FE_NV_PAIR");       // pixel-pair form of the first block too (netvlad_pair.hip)
-            st.pblock = !(pq && atoi(pq) == 0) && nv_fpair_supported(h->nv[i].cout, h->nv[i].stride, h->nv[i + 1].stride, h->nv[i + 2].cout); }
+          {       // pixel-pair form of the first block too (netvlad_pair.hip)
+            st.pblock = d2fe_dev_env("D2FE_NV_PAIR", 1) != 0 && nv_fpair_supported(h->nv[i].cout, h->nv[i].stride, h->nv[i + 1].stride, h->nv[i + 2].cout); }
         } else if (i > 0 && K(i) == D2FE_NV_PW && K(i + 1) == D2FE_NV_DW && K(i + 2) == D2FE_NV_PW && h->nv[i].res < 0 &&
                    nv_block_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride, true, 0)) {
           st.fused = true; st.expand = true; st.l1 = i + 2;
-          { const char* x = getenv("D2FE_NV_XBLOCK");      // input-in-registers form of the block (default on; 0: the LDS-resident form)
-            st.xblock = !(x && atoi(x) == 0) && nv_xblock_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride);
+          {       // input-in-registers form of the block where the shape allows it (otherwise the LDS-resident form)
+            st.xblock = d2fe_dev_env("D2FE_NV_XBLOCK", 1) != 0 && nv_xblock_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride);
             // stride 1: the pixel-pair form of the same block (netvlad_pair.hip; D2FE_NV_PAIR=0: nv_xblock_kernel)
-            const char* pq = getenv("D2FE_NV_PAIR");
-            st.pblock = st.xblock && !(pq && atoi(pq) == 0) && nv_pblock_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride); }
+            st.pblock = st.xblock && d2fe_dev_env("D2FE_NV_PAIR", 1) != 0 && nv_pblock_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride); }
         } else if (i > 0 && K(i) == D2FE_NV_DW && K(i + 1) == D2FE_NV_PW &&
                    nv_block_supported(h->nv[i].cin, h->nv[i].cin, h->nv[i + 1].cout, h->nv[i].stride, false, 0)) {
           st.fused = true; st.l1 = i + 1;
@@ -1046,6 +1043,7 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
   return D2FE_OK;
 }
 
+#ifdef D2FE_DEVTOOLS      /* development library only: include/d2fe_debug.h */
 /* diagnostics: with D2FE_NV_STAMP_STEP=<plan step> set at d2fe_load_netvlad() time, the wall_clock64() phase stamps [workgroup][32] that step's
  * nv_xblock_kernel wrote during the last d2fe_netvlad* call; returns the number of workgroups (tools/nv_stamps.py). */
 long d2fe_debug_netvlad_stamps(d2fe_handle h, unsigned long long* dst, long max_wgs) {
@@ -1080,6 +1078,8 @@ long d2fe_debug_netvlad_layer(d2fe_handle h, int layer, int n_images, void* dst,
   }
   return (long)bytes;
 }
+
+#endif  // D2FE_DEVTOOLS
 
 int d2fe_set_netvlad_pca(d2fe_handle h, const float* comp, const float* mean, int m) {
   if (h) graphs_clear(h);
@@ -1564,7 +1564,7 @@ int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* str
   m.q_idx = mb->d_q_idx; m.t_idx = mb->d_t_idx; m.dist = mb->d_dist; m.n_out = mb->d_n_out;
   match_scratch_carve(sc->cand4, sc->npairs, &m); m.stats = h->match_stats; m.ncu = h->ncu;
 #ifdef D2FE_DEVTOOLS
-  if (getenv("D2FE_MATCH_STAMPS") && (long)((mb->max_n + 31) / 32) * 2 * mb->npairs <= 4096) {
+  if (d2fe_dev_env("D2FE_MATCH_STAMPS", 0) && (long)((mb->max_n + 31) / 32) * 2 * mb->npairs <= 4096) {
     if (!h->match_stamps) HIP_TRY(hipMalloc(&h->match_stamps, sizeof(unsigned long long) * 16 * 4096));
     HIP_TRY(hipMemsetAsync(h->match_stamps, 0, sizeof(unsigned long long) * 16 * 4096, s));
     m.stamps = h->match_stamps;
@@ -1724,6 +1724,7 @@ int d2fe_half_image_filter(const float* pts_xy, int n, int require_left, int wid
   return D2FE_OK;
 }
 
+#ifdef D2FE_DEVTOOLS      /* development library only: include/d2fe_debug.h */
 long d2fe_debug_read(d2fe_handle h, const char* name, void* dst, size_t max_bytes) {
   if (!h || !name || !dst) return fail(D2FE_ERR_INVALID, "null argument");
   if (h->last_n == 0) return fail(D2FE_ERR_NOT_READY, "no extract call yet");
@@ -1839,7 +1840,7 @@ int d2fe_debug_conv3x3_wino(d2fe_handle h, const float* in, int n, int H, int W,
     a.in = d_in; a.in_cstride = cin; a.in_coff = 0; a.out = d_out; a.out_cstride = cout; a.out_coff = 0;
     a.cout_real = cout; a.wpack = d_w; a.bias = d_b; a.H = H; a.W = W; a.n_img = n;
     a.in_img_stride = (long)H * W * cin; a.out_img_stride = (long)Ho * Wo * cout; a.zeros = h->zeros; a.ncu = h->ncu;
-    { const char* e = getenv("D2FE_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+    a.ablate = d2fe_dev_env("D2FE_ABLATE", 0);
     HIP_TRY(launch_conv_wino(cin, pool != 0, relu != 0, cout_pad, a, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(out, d_out, out_fl * 4, hipMemcpyDeviceToHost));
@@ -1861,6 +1862,8 @@ int d2fe_debug_conv3x3_wino(d2fe_handle h, const float* in, int n, int H, int W,
   if (e1) (void)hipEventDestroy(e1);
   return rc;
 }
+
+#endif  // D2FE_DEVTOOLS
 
 int d2fe_profile_enable(d2fe_handle h, int mode) {
   if (!h || mode < 0 || mode > 2) return fail(D2FE_ERR_INVALID, "bad argument");
@@ -1888,6 +1891,7 @@ int d2fe_profile_read(d2fe_handle h, float* ms, int32_t* launches) {
   return D2FE_OK;
 }
 
+#ifdef D2FE_DEVTOOLS
 int d2fe_debug_graph_count(d2fe_handle h, int* rejected) {
   if (!h) return fail(D2FE_ERR_INVALID, "null handle");
   int n = 0, bad = 0;
@@ -1895,6 +1899,8 @@ int d2fe_debug_graph_count(d2fe_handle h, int* rejected) {
   if (rejected) *rejected = bad;
   return n;
 }
+
+#endif
 
 #ifdef D2FE_DEVTOOLS
 /* development builds: the wall_clock64() phase stamps [workgroup][16] of the last d2fe_match_batch_device launch made with D2FE_MATCH_STAMPS set */

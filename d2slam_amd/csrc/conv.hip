@@ -112,7 +112,7 @@ __global__ __launch_bounds__(WM * WN * 64, f32_min_waves(CIN, KS, TH, TW)) void 
         if (it0 + u < ITERS && idx < TOTAL) {
           const int pix = idx / C4, c4 = idx % C4;
           const int gy = ty0 + pix / PW - P, gx = tx0 + pix % PW - P;
-          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && !(a.ablate & 1))
+          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && !D2FE_ABL(a, 1))
             v[u] = *reinterpret_cast<const f32x4*>(in + ((size_t)gy * a.W + gx) * a.in_cstride + c4 * 4);
         }
       }
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(WM * WN * 64, f32_min_waves(CIN, KS, TH, TW)) void 
   static_assert(C8 % G == 0, "group size must divide the steps per tap");
   f32x4 bq[2][G][NT];
   auto load_grp = [&](int buf, int grp) {
-    if (a.ablate & 2) grp = 0;
+    if (D2FE_ABL(a, 2)) grp = 0;
 #pragma unroll
     for (int j = 0; j < G; ++j)
 #pragma unroll
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void conv1a_mfma_kernel(const uint8_t* __restr
 hipError_t launch_conv1a(const uint8_t* img, int stride, long img_stride_bytes, int H, int W, int n,
                          const float* w9x64, const float* bias, float* out, hipStream_t s) {
   static int valu = -1;
-  if (valu < 0) { const char* e = getenv("D2FE_CONV1A_VALU"); valu = e ? atoi(e) : 0; }   // 1: the VALU kernel (A/B timing)
+  if (valu < 0) valu = d2fe_dev_env("D2FE_CONV1A_VALU", 0);   // 1: the VALU kernel (A/B timing)
   if (valu) {
     dim3 grid((W + 63) / 64, H, n), block(256);
     hipLaunchKernelGGL(conv1a_kernel, grid, block, 0, s, img, stride, img_stride_bytes, H, W, w9x64, bias, out);

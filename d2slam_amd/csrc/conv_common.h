@@ -6,20 +6,20 @@
 
 namespace d2fe {
 
-// experiment knob: D2FE_CONV64_TILE: 1 (default) = 4x32-pixel tile, 2x2 waves, ~53 KB LDS, 3 blocks/CU; 0 = 8x32 tile, 4x1 waves, 1 block/CU
+// development-library switches (d2fe_dev_env: constants in the product library).  D2FE_CONV64_TILE: 1 (default) = 4x32-pixel tile, 2x2 waves, ~53 KB LDS, 3 blocks/CU; 0 = 8x32 tile, 4x1 waves, 1 block/CU
 static inline int tune_ablate() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("D2FE_ABLATE"); v = e ? atoi(e) : 0; }
+  if (v < 0) v = d2fe_dev_env("D2FE_ABLATE", 0);
   return v;
 }
 static inline int tune_conv_pc() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("D2FE_CONV_PC"); v = e ? atoi(e) : 2; }   // 0 off, 1 every layer, 2 every layer but the fused conv1a+conv1b (measured best)
+  if (v < 0) v = d2fe_dev_env("D2FE_CONV_PC", 2);   // 0 off, 1 every layer, 2 every layer but the fused conv1a+conv1b (measured best)
   return v;
 }
 static inline int tune_conv64() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("D2FE_CONV64_TILE"); v = e ? atoi(e) : 1; }
+  if (v < 0) v = d2fe_dev_env("D2FE_CONV64_TILE", 1);
   return v;
 }
 

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f16x2_kernel(ConvArgs a) {
         if (it0 + u < ITERS && idx < TOTAL) {
           const int pix = idx / C4, c4 = idx % C4;
           const int gy = ty0 + pix / PW - P, gx = tx0 + pix % PW - P;
-          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && !(a.ablate & 1))
+          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && !D2FE_ABL(a, 1))
             v[u] = *reinterpret_cast<const f32x4*>(in + ((size_t)gy * a.W + gx) * a.in_cstride + c4 * 4);
         }
       }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f16x2_kernel(ConvArgs a) {
   static_assert(KST % G == 0, "group size must divide the steps per tap");
   f16x8 bq[2][G][NT][2];
   auto load_grp = [&](int buf, int grp) {
-    if (a.ablate & 2) grp = 0;
+    if (D2FE_ABL(a, 2)) grp = 0;
 #pragma unroll
     for (int j = 0; j < G; ++j)
 #pragma unroll

@@ -24,8 +24,10 @@ struct PcTile { int img, ty0, tx0, cg; };
 
 // D2FE_ABLATE bit 256: workgroup 0 records s_memrealtime (100 MHz) marks of its first consumer and producer wave for the
 // first 64 tiles -- [wave kind][tile][0 start, 1 main loop issued, 2 epilogue/staging issued, 3 past the barrier].
+#ifdef D2FE_DEVTOOLS
 __device__ unsigned long long g_pc_trace[2][64][4];
 __device__ unsigned long long g_pc_trace_clk[4];   // (s_memtime, s_memrealtime) at tiles 2 and 10 -> shader clock
+#endif
 
 template <int TH, int TW>
 __device__ __forceinline__ PcTile pc_decode(int t, int tiles_x, int tiles_y, int ncg) {
@@ -122,11 +124,15 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
     if (!consumer) conv1a_mfma_load_weights(w1a, b1a, lane, c1w, c1b);
   }
 
-  const bool tracing = (a.ablate & 256) && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == NC);
   int trace_k = 0;
+#ifdef D2FE_DEVTOOLS
+  const bool tracing = D2FE_ABL(a, 256) && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == NC);
   auto mark = [&](int slot) {
     if (tracing && trace_k < 64) g_pc_trace[wave == 0 ? 0 : 1][trace_k][slot] = wall_clock64();
   };
+#else
+  auto mark = [&](int) {};
+#endif
 
   // ------------------------------------------------------------------------------------------------ producer
   auto stage = [&](const PcTile& T, int buf) {
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
     if constexpr (FUSE1A) {
       conv1a_mfma_stage<MODE, NPIX, PW, CPF, CPH, PC_SA>(img_base + (size_t)T.img * img_istride, img_stride_b, aH, aW, T.ty0, T.tx0,
                                                          c1w, c1b, lane, wave - NC, NC, patch, hi, lo);
-    } else if (MODE == 0 && !(a.ablate & 2048)) {
+    } else if (MODE == 0 && !D2FE_ABL(a, 2048)) {
       // fp32 patch = a plain copy: one LDS-DMA instruction (global_load_lds_dword, 64 lanes x 4 B) per 64 channels of a patch
       // pixel, no VGPR round trip and almost no VALU work -- every producer instruction costs the consumer wave of the same
       // SIMD issue time (measured: ~3.4 us per tile for ~1-2 k instructions).  The LDS destination of an LDS-DMA is
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
           if (it0 + u < ITERS && idx < TOTAL) {
             const int pix = idx / C4, c4 = idx % C4;
             const int gy = T.ty0 + pix / PW - P, gx = T.tx0 + pix % PW - P;
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && !(a.ablate & 1))
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && !D2FE_ABL(a, 1))
               v[u] = *reinterpret_cast<const f32x4*>(in + ((size_t)gy * a.W + gx) * a.in_cstride + c4 * 4);
           }
         }
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
       // B fragments (hi, lo per n-tile) travel through a register ring R k-steps deep that wraps around tile boundaries:
       // the load for step (s+R-1) mod S is issued before the MFMAs of step s; A fragments are read one step ahead.
       auto load_step = [&](int slot, int st) {
-        if (a.ablate & 2) st = 0;
+        if (D2FE_ABL(a, 2)) st = 0;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           ring[slot][n][0] = wbase[n][(size_t)st * 128];
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
 
   // producers outrank consumers at the issue arbiter: their few VALU/VMEM/LDS instructions slot in between the consumer's
   // MFMAs instead of waiting for the consumer wave to stall (D2FE_ABLATE bit 512 switches this off for A/B measurements)
-  if (!consumer && !(a.ablate & 512)) __builtin_amdgcn_s_setprio(3);
+  if (!consumer && !D2FE_ABL(a, 512)) __builtin_amdgcn_s_setprio(3);
 
   // ------------------------------------------------------------------------------------------------ tile loop
   int t = blockIdx.x;
@@ -363,12 +369,14 @@ __global__ __launch_bounds__(WM * WN * 128) void conv_pc_kernel(ConvArgs a, int 
     PcTile nxt = cur;
     if (more) nxt = pc_decode<TH, TW>(tn, tiles_x, tiles_y, ncg);
     mark(0);
+#ifdef D2FE_DEVTOOLS
     if (tracing && wave == 0 && (trace_k == 2 || trace_k == 10)) {
       g_pc_trace_clk[trace_k == 2 ? 0 : 2] = clock64();
       g_pc_trace_clk[trace_k == 2 ? 1 : 3] = wall_clock64();
     }
-    if (consumer) { if (!(a.ablate & 16)) compute(cur, buf); }
-    else if (more && !(a.ablate & 8)) stage(nxt, buf ^ 1);
+#endif
+    if (consumer) { if (!D2FE_ABL(a, 16)) compute(cur, buf); }
+    else if (more && !D2FE_ABL(a, 8)) stage(nxt, buf ^ 1);
     mark(2);
     __syncthreads();
     mark(3);
@@ -395,10 +403,11 @@ static hipError_t launch_pc_one(int cout_pad, const ConvArgs& a, hipStream_t s) 
   if (e != hipSuccess) return e;
   const int grid = total < ncu ? total : ncu;
   hipLaunchKernelGGL(k, dim3(grid), dim3(WM * WN * 128), lds, s, a, tiles_x, tiles_y, ncg, total);
-  if (a.ablate & 256) {
+#ifdef D2FE_DEVTOOLS
+  if (D2FE_ABL(a, 256)) {
     static int dumped = 0;
-    const char* e = getenv("D2FE_PC_TRACE_CIN");
-    if (dumped < 2 && (!e || atoi(e) == CIN * 10 + KS + (FUSE1A ? 100000 : 0)) && a.n_img > 1) {
+    const int sel = d2fe_dev_env("D2FE_PC_TRACE_CIN", 0);
+    if (dumped < 2 && (!sel || sel == CIN * 10 + KS + (FUSE1A ? 100000 : 0)) && a.n_img > 1) {
       ++dumped;
       unsigned long long tr[2][64][4];
       if (hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_pc_trace), sizeof(tr)) == hipSuccess) {
@@ -414,6 +423,7 @@ static hipError_t launch_pc_one(int cout_pad, const ConvArgs& a, hipStream_t s) 
       }
     }
   }
+#endif
   return hipGetLastError();
 }
 

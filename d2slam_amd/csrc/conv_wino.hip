@@ -81,10 +81,12 @@ __device__ __forceinline__ void buf_load_lds16(__amdgpu_buffer_rsrc_t r, float* 
 
 }  // namespace
 
-// ABL 256: workgroup 0 / wave 0 records shader-clock marks (s_memtime) for its first 4 items
+#ifdef D2FE_DEVTOOLS
+// development library, ABL 256: workgroup 0 / wave 0 records shader-clock marks (s_memtime) for its first 4 items
 __device__ long long g_wino_trace[4][16][6];
 __device__ long long g_wino_pair[2][64][3];       // ABL 256: the two workgroups of ONE CU: [wave slot parity][item][K start, epilogue start, epilogue end]
 __device__ unsigned g_wino_hw[1024][2];      // ABL 256: HW_ID / XCC_ID of wave 0 of every workgroup (which two share a CU?)
+#endif
 
 // Tile <-> MFMA row.  Row t (= lane & 31 of the A operand, = (r&3) + 8*(r>>2) + 4*(lane>>5) of an accumulator register r)
 // holds tile  ty = 2*(q>>2) + parity(q),  tx = 4*((q>>1)&1) + (t&3),  q = t>>2.  ds_read_b128 serves a wave in the lane groups
@@ -199,6 +201,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
         acc[nt * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], ub[slot][nt][j], first ? zero : acc[nt * 4 + j], 0, 0, 0);
   };
 
+#ifdef D2FE_DEVTOOLS
   const bool tracing = (ABL & 256) && blockIdx.x == 0 && tid == 0;
   int pair_slot = -1;       // ABL 256: this workgroup sits on (xcc 0, se 0, sh 0, cu 0): record its item timeline beside its CU partner's
   if constexpr ((ABL & 256) != 0) {
@@ -217,6 +220,9 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
       }
     }
   };
+#else
+  auto mark = [&](int, int, int) {};
+#endif
   int trace_item = 0;
   int inn = 0, inn_claim = 0;            // the item after `nxt`: its index, and thread 0's claim in flight
   float bias0 = 0.f, bias1 = 0.f;        // the current item's biases (channel lane & 31 of its one or two 32-channel halves), requested at the item's start
@@ -549,7 +555,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     if constexpr (FUSE) {
       __syncthreads();                                           // the patch (staged by the prologue / the previous epilogue) is complete
       read_d(0);
-      if (inxt < total && !(a.ablate & 64)) load_frame(nxt);     // the next item's frame bytes, in flight during this item's K loop
+      if (inxt < total && !D2FE_ABL(a, 64)) load_frame(nxt);     // the next item's frame bytes, in flight during this item's K loop
     }
     chunk(IC<1>{}, item, 0);       // the first k-step multiplies into C = 0: no accumulator clearing
 #pragma unroll 1
@@ -557,7 +563,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a, int nbx, int nby, i
     mark(item, 0, 4);
     trace_item = item;
     // D2FE_ABLATE=64: timing experiment, the staging runs for the first item only
-    if constexpr (!(ABL & 32)) epilogue(cur, FUSE && inxt < total && !(a.ablate & 64), nxt);
+    if constexpr (!(ABL & 32)) epilogue(cur, FUSE && inxt < total && !D2FE_ABL(a, 64), nxt);
     mark(item, 0, 5);
     cur = nxt; dcur = dnxt; ucur = unxt;
     icur = inxt; inxt = inn;
@@ -573,6 +579,7 @@ template <int CIN, bool POOL, bool RELU, int ABL = 0, int TAG = 0, bool FUSE = f
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(ConvArgs a, int nbx, int nby, int ncb, int total) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   if ((int)blockIdx.x >= total) return;
+#ifdef D2FE_DEVTOOLS
   if constexpr ((ABL & 256) != 0) {
     if (threadIdx.x == 0 && blockIdx.x < 1024) {
       unsigned hwid, xcc;
@@ -581,6 +588,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(ConvArg
       g_wino_hw[blockIdx.x][0] = hwid; g_wino_hw[blockIdx.x][1] = xcc;
     }
   }
+#endif
   // the four rows of the transform domain run different (compile-time) row arithmetic; the branch is wave-uniform
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
     case 0: wino_body<CIN, POOL, RELU, ABL, 0, FUSE, NT>(a, nbx, nby, ncb, total, wlds); break;
@@ -601,7 +609,7 @@ hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const C
   // per CU at most: its duration is (rounds of resident workgroups) x (one item's latency), and halving the item while raising the resident
   // workgroups from 2 to 3 per CU wins there (conv4a at two images: 160 items -> 320 half-items in ONE round of 768 slots).
   // D2FE_WINO_NT=1 / 2 forces one form (A/B measurements); bit-identical either way.
-  static const int nt_env = [] { const char* e = getenv("D2FE_WINO_NT"); return e ? atoi(e) : 0; }();
+  static const int nt_env = d2fe_dev_env("D2FE_WINO_NT", 0);
   int NTsel = 2;
   {
     const int ncu0 = a.ncu > 0 ? a.ncu : 256;
@@ -633,6 +641,7 @@ hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const C
     if (cin == 128 && !pool && relu) { D2FE_WINO_K((conv_wino_kernel<128, false, true, 0, 0, false, 1>)); return hipGetLastError(); }
     return hipErrorInvalidValue;
   }
+#ifdef D2FE_DEVTOOLS
   if (a.ablate && cin == 64 && !pool && relu) {     // timing experiments through d2fe_debug_conv3x3_wino (D2FE_ABLATE)
     switch (a.ablate) {
       case 1: D2FE_WINO_K((conv_wino_kernel<64, false, true, 1>)); return hipGetLastError();
@@ -682,6 +691,7 @@ hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const C
       default: break;
     }
   }
+#endif
   if (cin == 64 && pool && relu && a.tag == 1) { D2FE_WINO_K((conv_wino_kernel<64, true, true, 0, 1>)); return hipGetLastError(); }   // conv1b
   if (cin == 64 && pool && relu) { D2FE_WINO_K((conv_wino_kernel<64, true, true>)); return hipGetLastError(); }
   if (cin == 64 && !pool && relu) { D2FE_WINO_K((conv_wino_kernel<64, false, true>)); return hipGetLastError(); }

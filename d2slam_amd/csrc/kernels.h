@@ -6,8 +6,14 @@
 // Development instrumentation is compiled out of the product library: `python -m d2slam_amd.build --dev` builds
 // lib/libd2fe_hip_dev.so with -DD2FE_DEVTOOLS (phase stamps, ablation switches, the d2fe_debug_* exports of include/d2fe_debug.h).
 #ifdef D2FE_DEVTOOLS
+#include <cstdlib>
+// development switches come from the environment in the development library ONLY; the product library reads no environment variable
+static inline int d2fe_dev_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#define D2FE_ABL(a, bits) ((a).ablate & (bits))    /* timing experiments that switch parts of a kernel off (results are wrong with any bit set) */
 #define D2FE_STAMP(buf, wg, i) do { if ((buf) && threadIdx.x == 0) (buf)[(size_t)(wg) * 16 + (i)] = wall_clock64(); } while (0)
 #else
+static inline int d2fe_dev_env(const char*, int dflt) { return dflt; }
+#define D2FE_ABL(a, bits) (0)
 #define D2FE_STAMP(buf, wg, i) do {} while (0)
 #endif
 
@@ -29,7 +35,7 @@ struct ConvArgs {
   const uint8_t* img; int img_stride; long img_istride; const float* w1a; const float* b1a;
   const float* zeros;       // >= 256 zero floats in HBM (source of the LDS-DMA copies of out-of-image patch pixels)
   int tag;                  // 1: conv1b (the dominant launch gets its own kernel instantiation so that rocprofv3 --stats lists it by itself)
-  int ablate;               // experiment knob (D2FE_ABLATE): 1 skip patch loads, 2 skip B reloads, 4 skip stores
+  int ablate;               // development library only (D2FE_ABL): 1 skip patch loads, 2 skip B reloads, 4 skip stores; always 0 in the product library
   int* work_ctr = nullptr;  // Winograd kernels: zeroed device counter -> work items are claimed dynamically (null: static round-robin split)
   int ncu = 0;              // compute units of the handle's device (d2fe_create reads it once): the persistent kernels size their grids on it
 };

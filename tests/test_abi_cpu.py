@@ -30,6 +30,30 @@ def test_every_declared_symbol_is_exported(lib):
     assert sorted(api.EXPORTS) == names, "api.EXPORTS out of sync with include/d2fe.h"
 
 
+def test_product_library_has_no_debug_exports_and_reads_no_environment(lib):
+    """VERDICT r03 #7: test hooks, ablation switches and trace code live in the development library only."""
+    import subprocess
+    from d2slam_amd import api, build
+    syms = subprocess.run(["nm", "-D", "--defined-only", build.LIB], capture_output=True, text=True).stdout
+    assert "d2fe_debug" not in syms and "g_wino_trace" not in syms and "g_pc_trace" not in syms
+    assert not any(n.startswith("d2fe_debug") for n in api.EXPORTS)
+    und = subprocess.run(["nm", "-D", "--undefined-only", build.LIB], capture_output=True, text=True).stdout
+    assert " getenv" not in und and "secure_getenv" not in und, "the product library must not read the environment"
+    csrc = os.path.join(ROOT, "d2slam_amd", "csrc")
+    hits = [f for f in os.listdir(csrc) for l in open(os.path.join(csrc, f), errors="ignore") if "getenv(" in l]
+    assert len(hits) <= 1, hits          # the one in d2fe_dev_env (kernels.h), compiled only with -DD2FE_DEVTOOLS
+
+
+def test_development_library_exports_the_hooks():
+    from d2slam_amd import api, build
+    dev = C.CDLL(build.build(dev=True))
+    src = open(os.path.join(ROOT, "include", "d2fe_debug.h")).read()
+    names = sorted(set(re.findall(r"D2FE_API\s+[\w\s\*]+?\b(d2fe_\w+)\s*\(", src)))
+    assert names == sorted(api.DEBUG_EXPORTS)
+    for n in names + list(api.EXPORTS):
+        assert hasattr(dev, n), "the development library misses %s" % n
+
+
 def test_version_and_default_config(lib):
     from d2slam_amd.api import _Config
     lib.d2fe_version.restype = C.c_char_p

@@ -21,10 +21,15 @@ def api():
     return a
 
 
-def _fe(api, H, W, n, prec, max_kp=200, thr=0.015, dense=False):
+def _fe(api, H, W, n, prec, max_kp=200, thr=0.015, dense=False, dev=False):
     fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=max_kp, input_width=W, input_height=H, max_batch=n, precision=prec,
-                                           keypoint_threshold=thr, keep_score_map=True, dense_descriptors=dense))
+                                           keypoint_threshold=thr, keep_score_map=True, dense_descriptors=dense), dev=dev)
     return fe
+
+
+def _fe_dev(api, *a, **k):
+    """a handle of the development library: the tests that read intermediate tensors back (d2fe_debug_read, include/d2fe_debug.h)"""
+    return _fe(api, *a, dev=True, **k)
 
 
 LAYERS = [("conv1a", 1, 64), ("conv1b", 2, 64), ("conv2a", 2, 64), ("conv2b", 4, 64), ("conv3a", 4, 128), ("conv3b", 8, 128),
@@ -50,7 +55,7 @@ def test_exact_mode_bitwise_every_layer(api, orc, sp_weights, H, W):
     """fp32 MFMA conv stack == oracle fmaf chains, bit for bit, incl. ragged tiles (sizes not multiples of the tile)."""
     n = 2
     imgs = np.stack([synth_image(H, W, 10 + s) for s in range(n)])
-    fe = _fe(api, H, W, n, api.PREC_F32, dense=True)          # the dense descriptor map is inspected below
+    fe = _fe_dev(api, H, W, n, api.PREC_F32, dense=True)          # the dense descriptor map is inspected below
     fe.load_superpoint(sp_weights)
     res = fe.extract_batch(imgs, cap=200)
     for i in range(n):
@@ -79,7 +84,7 @@ def test_sizes_that_are_not_multiples_of_8(api, orc, sp_weights, H, W, prec):
     imgs = np.stack([synth_image(H, W, 20 + s) for s in range(n)])
     P = {"f32": api.PREC_F32, "wino": api.PREC_F32_WINO, "f16x2": api.PREC_F16X2}[prec]
     for dense in (True, False):
-        fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=150, input_width=W, input_height=H, max_batch=n, precision=P,
+        fe = api.DevFrontEnd(api.SuperPointConfig(max_keypoints=150, input_width=W, input_height=H, max_batch=n, precision=P,
                                                keep_score_map=True, dense_descriptors=dense))
         fe.load_superpoint(sp_weights)
         res = fe.extract_batch(imgs, cap=150)
@@ -159,7 +164,7 @@ def test_score_ties_use_raster_tiebreak(api, orc, sp_weights):
 @pytest.mark.parametrize("H,W,N", [(96, 128, 200), (480, 640, 200), (400, 800, 100), (512, 512, 150)])
 def test_fast_mode_tolerances(api, orc, sp_weights, H, W, N):
     imgs = np.stack(synth_stereo(H, W, seed=3))
-    fe = _fe(api, H, W, 2, api.PREC_F16X2, dense=True, max_kp=N)
+    fe = _fe_dev(api, H, W, 2, api.PREC_F16X2, dense=True, max_kp=N)
     fe.load_superpoint(sp_weights)
     res = fe.extract_batch(imgs, cap=N)
     for i in range(2):
@@ -413,7 +418,7 @@ def test_error_behaviour(api, sp_weights):
 def test_variant_a_nms2_exact(api, orc, sp_weights, H, W, d, maxkp):
     """Variant A (SuperPointONNX path): getKeyPoints + NMS2 + grid_sampler sampling; indices exact vs the sequential oracle."""
     img = synth_image(H, W, 77)
-    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=maxkp, input_width=W, input_height=H, max_batch=1,
+    fe = api.DevFrontEnd(api.SuperPointConfig(max_keypoints=maxkp, input_width=W, input_height=H, max_batch=1,
                                            postproc=api.POSTPROC_A, nms_dist=d, keep_score_map=True))
     fe.load_superpoint(sp_weights)
     (kps, sc, desc), = fe.extract_batch(img[None], cap=maxkp)
@@ -503,7 +508,7 @@ def test_netvlad_fused_blocks_layerwise(api, orc, H, W):
     from d2slam_amd import netvlad as nvm
     nv = nvm.synthetic_netvlad_weights()
     imgs = np.stack([synth_image(H, W, 9 + s) for s in range(2)])
-    fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
+    fe = api.DevFrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
     fe.load_netvlad(nv)
     got = fe.netvlad(imgs)
     fused = 0
@@ -535,13 +540,13 @@ def test_netvlad_pair_kernel_variants(api, orc, monkeypatch, env):
     imgs = np.stack([synth_image(H, W, 70 + s) for s in range(2)])
     for k in ("D2FE_NV_FRONT_TPW", "D2FE_NV_NBUF"):
         monkeypatch.delenv(k, raising=False)
-    fe0 = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
+    fe0 = api.DevFrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
     fe0.load_netvlad(nv)
     base = fe0.netvlad(imgs)
     fe0.close()
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
+    fe = api.DevFrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
     fe.load_netvlad(nv)
     got = fe.netvlad(imgs)
     assert np.array_equal(got, base), np.abs(got - base).max()
@@ -564,13 +569,13 @@ def test_netvlad_phase_stamps_hook(api, monkeypatch):
     H, W = 240, 320
     imgs = np.stack([synth_image(H, W, 80 + s) for s in range(2)])
     monkeypatch.delenv("D2FE_NV_STAMP_STEP", raising=False)
-    fe0 = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
+    fe0 = api.DevFrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
     fe0.load_netvlad(nv)
     base = fe0.netvlad(imgs)
     fe0.close()
     for step in (0, 2):
         monkeypatch.setenv("D2FE_NV_STAMP_STEP", str(step))
-        fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
+        fe = api.DevFrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=2))
         fe.load_netvlad(nv)
         got = fe.netvlad(imgs)
         assert np.array_equal(got, base)
@@ -598,7 +603,7 @@ def test_netvlad_plans_agree(api, orc, monkeypatch):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=5))
+        fe = api.DevFrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=5))
         fe.load_netvlad(nv)
         got5 = fe.netvlad(imgs)
         got1 = fe.netvlad(imgs[2:3])
@@ -736,7 +741,7 @@ def test_host_calls_replay_cached_graphs_with_identical_results(api, orc, sp_wei
     if os.environ.get("D2FE_GRAPH", "1") == "0":
         pytest.skip("graphs switched off")
     H, W = 120, 160
-    fe = _fe(api, H, W, 2, api.PREC_F32_WINO, max_kp=100)
+    fe = _fe_dev(api, H, W, 2, api.PREC_F32_WINO, max_kp=100)
     fe.load_superpoint(sp_weights); fe.load_netvlad(nvm.synthetic_netvlad_weights())
     a = np.stack(synth_stereo(H, W, seed=5)); b = np.stack(synth_stereo(H, W, seed=6))
     outs = [fe.extract_batch(a, cap=100) for _ in range(4)]          # plain, capture, replay, replay
@@ -830,7 +835,7 @@ def test_sparse_descriptor_head_equals_dense(api, orc, sp_weights, prec):
     imgs = np.stack([synth_image(H, W, 71), np.full((H, W), 90, np.uint8), synth_image(H, W, 72)] + [synth_image(H, W, 80 + i) for i in range(6)])
     outs = []
     for dense in (False, True):
-        fe = _fe(api, H, W, 9, p, max_kp=300, dense=dense)      # 9 images per call: above the sparse path's batch threshold (4)
+        fe = _fe_dev(api, H, W, 9, p, max_kp=300, dense=dense)      # 9 images per call: above the sparse path's batch threshold (4)
         fe.load_superpoint(sp_weights)
         outs.append(fe.extract_batch(imgs, cap=300))
         if not dense:

@@ -13,7 +13,7 @@ import pytest
 @pytest.fixture(scope="module")
 def lib():
     from d2slam_amd import build
-    l = C.CDLL(build.build())
+    l = C.CDLL(build.build(dev=True))      # the packing hooks are test hooks of the development library (include/d2fe_debug.h)
     l.d2fe_debug_pack_netvlad.restype = C.c_long
     return l
 

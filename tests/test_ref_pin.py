@@ -192,7 +192,7 @@ def test_hip_variant_b_vs_reference_cpp(api, orc, sp_weights, H, W, N, thr, seed
     if thr > 0.1:
         w = dict(w); Wt, b = w["convPb"]; b = b.copy(); b[64] -= np.float32(3.5); w["convPb"] = (Wt, b)
     img = synth_image(H, W, seed)
-    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=N, input_width=W, input_height=H, max_batch=1, keypoint_threshold=thr,
+    fe = api.DevFrontEnd(api.SuperPointConfig(max_keypoints=N, input_width=W, input_height=H, max_batch=1, keypoint_threshold=thr,
                                            precision=api.PREC_F32 if prec == "f32" else api.PREC_F32_WINO, keep_score_map=True,
                                            dense_descriptors=True))
     fe.load_superpoint(w)
@@ -219,7 +219,7 @@ def test_hip_nms2_vs_reference_cpp(api, sp_weights, H, W, N, thr, seed):
     if thr > 0.1:
         w = dict(w); Wt, b = w["convPb"]; b = b.copy(); b[64] -= np.float32(3.5); w["convPb"] = (Wt, b)
     img = synth_image(H, W, seed)
-    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=N, input_width=W, input_height=H, max_batch=1, keypoint_threshold=thr,
+    fe = api.DevFrontEnd(api.SuperPointConfig(max_keypoints=N, input_width=W, input_height=H, max_batch=1, keypoint_threshold=thr,
                                            postproc=api.POSTPROC_A, nms_dist=10, keep_score_map=True))
     fe.load_superpoint(w)
     (kps, sc, desc), = fe.extract_batch(img[None], cap=N)
@@ -275,14 +275,14 @@ def test_hip_keep_all_thousands_of_keypoints_vs_reference_cpp(api, orc, sp_weigh
     H, W = 240, 320
     img = synth_image(H, W, 15)
     for target in (5000, 30000):
-        fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=-1, input_width=W, input_height=H, max_batch=1, keypoint_threshold=0.0,
+        fe = api.DevFrontEnd(api.SuperPointConfig(max_keypoints=-1, input_width=W, input_height=H, max_batch=1, keypoint_threshold=0.0,
                                                precision=api.PREC_F32 if prec == "f32" else api.PREC_F32_WINO, keep_score_map=True, dense_descriptors=True))
         fe.load_superpoint(sp_weights)
         fe.extract_batch(img[None], cap=16)
         semi = fe.debug_read("semi", (1, H, W))[0]
         fe.close()
         thr = float(np.sort(semi.reshape(-1))[-target])
-        fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=-1, input_width=W, input_height=H, max_batch=1, keypoint_threshold=thr,
+        fe = api.DevFrontEnd(api.SuperPointConfig(max_keypoints=-1, input_width=W, input_height=H, max_batch=1, keypoint_threshold=thr,
                                                precision=api.PREC_F32 if prec == "f32" else api.PREC_F32_WINO, keep_score_map=True, dense_descriptors=True))
         fe.load_superpoint(sp_weights)
         (kps, sc, desc), = fe.extract_batch(img[None], cap=H * W)
@@ -641,7 +641,7 @@ def test_hip_variant_a_descriptors_vs_reference_cpp_libtorch(api, orc, sp_weight
     if thr > 0.1:
         w = dict(w); Wt, b = w["convPb"]; b = b.copy(); b[64] -= np.float32(3.5); w["convPb"] = (Wt, b)
     img = synth_image(H, W, seed)
-    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=N, input_width=W, input_height=H, max_batch=1, keypoint_threshold=thr,
+    fe = api.DevFrontEnd(api.SuperPointConfig(max_keypoints=N, input_width=W, input_height=H, max_batch=1, keypoint_threshold=thr,
                                            postproc=api.POSTPROC_A, nms_dist=10, keep_score_map=True, dense_descriptors=True))
     fe.load_superpoint(w)
     comp = mean = None

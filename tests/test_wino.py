@@ -53,7 +53,7 @@ def test_weight_transform_packing_cpu():
     """pack_weights_wino (host code of the library, no GPU needed): U = G g G^T in double, rounded once, in MFMA fragment order."""
     import ctypes as C
     from d2slam_amd import build
-    lib = C.CDLL(build.LIB)
+    lib = C.CDLL(build.build(dev=True))      # a test hook of the development library (include/d2fe_debug.h)
     lib.d2fe_debug_pack_wino.restype = C.c_long
     rng = np.random.default_rng(3)
     cout, cin = 72, 64                       # 72 -> padded to 128 channels: the padding must come out as zeros
@@ -83,7 +83,7 @@ WINO_LAYERS = [  # n, H, W, Cin, Cout, pool
 @pytest.mark.parametrize("n,H,W,cin,cout,pool", WINO_LAYERS)
 def test_wino_layer_bitwise(api, orc, n, H, W, cin, cout, pool):
     x, wg, b = _layer(np.random.default_rng(H * W + cin + cout), H, W, cin, cout, n)
-    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=16, input_width=64, input_height=64, max_batch=1))
+    fe = api.DevFrontEnd(api.SuperPointConfig(max_keypoints=16, input_width=64, input_height=64, max_batch=1))
     out, _ = fe.debug_conv3x3_wino(x, wg, b, pool=pool)
     fe.close()
     for i in range(n):
@@ -100,7 +100,7 @@ def test_wino_extract_vs_oracles(api, orc, H, W, n):
     w = synthetic_superpoint_weights(dustbin_bias=7.5)
     imgs = np.stack([synth_stereo(H, W, seed=11 + i)[i & 1] for i in range(n)])
     cap = 200
-    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=cap, input_width=W, input_height=H, max_batch=n,
+    fe = api.DevFrontEnd(api.SuperPointConfig(max_keypoints=cap, input_width=W, input_height=H, max_batch=n,
                                            precision=api.PREC_F32_WINO, keep_score_map=True, dense_descriptors=True))
     fe.load_superpoint(w)
     res = fe.extract_batch(imgs, cap=cap)
@@ -180,7 +180,7 @@ def test_wino_fused_conv1a_is_bit_identical(api, monkeypatch):
     outs, trunks = [], []
     for fuse in ("0", "1"):
         monkeypatch.setenv("D2FE_FUSE1A", fuse)
-        fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=cap, input_width=W, input_height=H, max_batch=n, precision=api.PREC_F32_WINO))
+        fe = api.DevFrontEnd(api.SuperPointConfig(max_keypoints=cap, input_width=W, input_height=H, max_batch=n, precision=api.PREC_F32_WINO))
         fe.load_superpoint(w)
         outs.append(fe.extract_batch(imgs, cap=cap))
         trunks.append(fe.debug_read("conv1b", (n, H // 2, W // 2, 64)))
@@ -205,14 +205,14 @@ def test_wino_fused_staging_borders_and_stride(api, monkeypatch, H, W):
     trunks, outs, strided = [], [], []
     for fuse in ("0", "1"):
         monkeypatch.setenv("D2FE_FUSE1A", fuse)
-        fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=cap, input_width=W, input_height=H, max_batch=n, precision=api.PREC_F32_WINO))
+        fe = api.DevFrontEnd(api.SuperPointConfig(max_keypoints=cap, input_width=W, input_height=H, max_batch=n, precision=api.PREC_F32_WINO))
         fe.load_superpoint(w)
         outs.append(fe.extract_batch(imgs, cap=cap))
         trunks.append(fe.debug_read("conv1b", (n, H // 2, W // 2, 64)))
         stride = W + 23
         buf = np.full((H, stride), 255, np.uint8); buf[:, :W] = imgs[1]
         kps = np.zeros((cap, 2), np.float32); sc = np.zeros(cap, np.float32); desc = np.zeros((cap, 256), np.float32); k = C.c_int(0)
-        rc = api.load_library().d2fe_superpoint_extract(fe.handle, buf.ctypes.data, W, H, stride, kps.ctypes.data, sc.ctypes.data,
+        rc = api.load_library(dev=True).d2fe_superpoint_extract(fe.handle, buf.ctypes.data, W, H, stride, kps.ctypes.data, sc.ctypes.data,
                                                         desc.ctypes.data, cap, C.byref(k))
         assert rc == 0
         strided.append((kps[:k.value].copy(), sc[:k.value].copy(), desc[:k.value].copy()))

@@ -13,7 +13,7 @@ modes = ["fused"] if "--fused-only" in sys.argv else ["legacy", "fused"]
 for mode in modes:
     os.environ["D2FE_NV_LEGACY"] = "1" if mode == "legacy" else "0"
     for n in ns:
-        fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=n))
+        fe = api.DevFrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=n))
         fe.load_netvlad(nvm.synthetic_netvlad_weights())
         dev = torch.device("cuda", 0)
         imgs = torch.from_numpy(np.stack([synth_image(H, W, s) for s in range(min(n, 4))] * ((n + 3) // 4))[:n].copy()).to(dev)

@@ -16,7 +16,7 @@ a = ap.parse_args()
 LAYERS = [("conv1b", 480, 640, 64, 64, True), ("conv2a", 240, 320, 64, 64, False), ("conv2b", 240, 320, 64, 64, True),
           ("conv3a", 120, 160, 64, 128, False), ("conv3b", 120, 160, 128, 128, True), ("conv4a", 60, 80, 128, 128, False),
           ("convPa", 60, 80, 128, 256, False)]
-fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=16, input_width=64, input_height=64, max_batch=1))
+fe = api.DevFrontEnd(api.SuperPointConfig(max_keypoints=16, input_width=64, input_height=64, max_batch=1))
 rng = np.random.default_rng(0)
 for name, H, W, cin, cout, pool in LAYERS:
     if a.layers and name not in a.layers.split(","):

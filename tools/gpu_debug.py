@@ -18,7 +18,7 @@ def run(H, W, prec, n=2):
     w = synthetic_superpoint_weights(dustbin_bias=7.5)
     imgs = np.stack([synth_image(H, W, s) for s in range(n)])
     cfg = api.SuperPointConfig(max_keypoints=200, input_width=W, input_height=H, max_batch=n, precision=prec, keep_score_map=True)
-    fe = api.FrontEnd(cfg); fe.load_superpoint(w)
+    fe = api.DevFrontEnd(cfg); fe.load_superpoint(w)
     t = time.time(); res = fe.extract_batch(imgs, cap=200); print("  extract wall %.3fs" % (time.time() - t))
     refs = [orc.superpoint_forward(imgs[i], w, return_trunk=True) for i in range(n)]
     Hc, Wc = H // 8, W // 8
@@ -50,7 +50,7 @@ def run(H, W, prec, n=2):
 def run_match():
     print("== matcher", flush=True)
     cfg = api.SuperPointConfig(max_keypoints=100, input_width=64, input_height=64, max_batch=1)
-    fe = api.FrontEnd(cfg)
+    fe = api.DevFrontEnd(cfg)
     for (na, nb, dim, ratio, radius, sigma) in [(200, 200, 256, 0.8, -1, 0.05), (150, 97, 256, 0.7, 30.0, 0.2), (33, 200, 64, 0.9, -1, 0.05),
                                                  (1, 5, 256, 0.8, -1, 0.05), (5, 1, 256, 0.8, -1, 0.05), (2, 2, 256, 0.8, -1, 0.05)]:
         a, b, pa, pb = synth_descriptor_pair(na, nb, dim, seed=na * 7 + nb, sigma=sigma)

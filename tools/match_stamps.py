@@ -1,18 +1,17 @@
 #!/usr/bin/env python3
 """Phase timing INSIDE match_kernel from its wall_clock64() stamps (development build: python -m d2slam_amd.build --dev;
-run with D2FE_LIB=d2slam_amd/lib/libd2fe_hip_dev.so D2FE_MATCH_STAMPS=1).  Usage: match_stamps.py [pairs ...]"""
+the development library is loaded through api.DevFrontEnd).  Usage: match_stamps.py [pairs ...]"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("D2FE_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "d2slam_amd", "lib", "libd2fe_hip_dev.so"))
 os.environ["D2FE_MATCH_STAMPS"] = "1"
 import torch
 from d2slam_amd import api
 from tools.bench_match import sets
 
 NAMES = ["start->Q frags", "tiles (MFMA)", "barrier", "scan+enumerate", "exact", "merge+emit+fallback", "ticket", "finalize (last only)"]
-fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=200, input_width=64, input_height=64, max_batch=1))
-lib = api.load_library()
+fe = api.DevFrontEnd(api.SuperPointConfig(max_keypoints=200, input_width=64, input_height=64, max_batch=1))
+lib = api.load_library(dev=True)
 lib.d2fe_debug_match_stamps.restype = C.c_long
 dev = torch.device("cuda", 0); n = 200
 for P in [int(x) for x in (sys.argv[1:] or ["1", "64"])]:

@@ -9,7 +9,7 @@ import numpy as np
 from d2slam_amd import api, netvlad as nvm
 from d2slam_amd.synth import synth_image
 H, W = 480, 640
-fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=n))
+fe = api.DevFrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=n))
 fe.load_netvlad(nvm.synthetic_netvlad_weights())
 imgs = np.stack([synth_image(H, W, s % 4) for s in range(n)])
 for _ in range(3):
