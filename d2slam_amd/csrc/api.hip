@@ -137,12 +137,30 @@ void graphs_clear(d2fe_context* h) {
 // Runs `fn(s)` -- a launch sequence on `s` whose arguments are a pure function of `key` (handle-owned buffers only) -- directly the
 // first time a key is seen (module loads, function attributes, lazy allocations happen there), captures it into a hipGraph the second
 // time and replays the instantiated graph from then on.  Anything that cannot be captured marks the key bad and runs directly.
+void host_state_save(const d2fe_context* h, d2fe_context::HostState& st) {
+  st.last_w = h->last_w; st.last_h = h->last_h; st.last_n = h->last_n; st.last_set = h->last_set;
+  st.last_gray = h->last_gray; st.last_stride = h->last_stride; st.last_istride = h->last_istride;
+  st.nv_slabs.clear();
+  for (const auto& l : h->nv) st.nv_slabs.emplace_back(l.slabs, l.slab_stride);
+  st.nv_feat_slabs = h->nv_feat_slabs; st.nv_feat_slab_stride = h->nv_feat_slab_stride; st.nv_stamp_wgs = h->nv_stamp_wgs;
+}
+void host_state_restore(d2fe_context* h, const d2fe_context::HostState& st, bool netvlad) {
+  if (netvlad) {
+    for (size_t i = 0; i < h->nv.size() && i < st.nv_slabs.size(); ++i) { h->nv[i].slabs = st.nv_slabs[i].first; h->nv[i].slab_stride = st.nv_slabs[i].second; }
+    h->nv_feat_slabs = st.nv_feat_slabs; h->nv_feat_slab_stride = st.nv_feat_slab_stride; h->nv_stamp_wgs = st.nv_stamp_wgs;
+  } else {
+    h->last_w = st.last_w; h->last_h = st.last_h; h->last_n = st.last_n; h->last_set = st.last_set;
+    h->last_gray = st.last_gray; h->last_stride = st.last_stride; h->last_istride = st.last_istride;
+  }
+}
+
 template <class F>
 int run_cached(d2fe_context* h, const std::array<long, 6>& key, hipStream_t s, F&& fn) {
   if (!h->use_graphs || h->prof_mode != 0) return fn(s);
   auto& e = h->graphs[key];
   if (e.bad) return fn(s);
-  if (e.exec) { HIP_TRY(hipGraphLaunch(e.exec, s)); return D2FE_OK; }
+  const bool netvlad = key[0] != 1;       // key[0]: 1 = the SuperPoint sequence, 2 / 3 = NetVLAD (own frames / the frames SuperPoint reads)
+  if (e.exec) { HIP_TRY(hipGraphLaunch(e.exec, s)); host_state_restore(h, e.st, netvlad); return D2FE_OK; }
   if (e.seen++ < 1) return fn(s);
   if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); e.bad = true; return fn(s); }
   const int rc = fn(s);
@@ -159,6 +177,7 @@ int run_cached(d2fe_context* h, const std::array<long, 6>& key, hipStream_t s, F
   (void)hipGraphDestroy(g);
   if (ei != hipSuccess || !ex) { (void)hipGetLastError(); e.bad = true; return fn(s); }
   e.exec = ex;
+  host_state_save(h, e.st);               // fn(s) ran its host code during the capture: this is the state a direct run leaves
   HIP_TRY(hipGraphLaunch(e.exec, s));
   return D2FE_OK;
 }
@@ -424,6 +443,8 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     return D2FE_OK;
   }();
   if (rc_alloc != D2FE_OK) { d2fe_destroy(h); return rc_alloc; }   // everything allocated so far is released
+  // the hipMemsets above ran on the null stream; the handle's work runs on non-blocking streams that do not wait for it
+  if (hipDeviceSynchronize() != hipSuccess) { d2fe_destroy(h); return fail(D2FE_ERR_HIP, "hipDeviceSynchronize"); }
   *out = h;
   return D2FE_OK;
 }
@@ -631,6 +652,9 @@ static int extract_host(d2fe_handle h, const uint8_t* gray, int n, int width, in
   rc = upload_frames(h, h->s_img, gray, n, width, height, stride, image_stride, s);
   if (rc) return rc;
   size_t nv_bytes = 0;
+  // once NetVLAD work is queued on nv_stream, EVERY exit waits for it: its D2H may target the caller's netvlad_out, and the next call's upload
+  // overwrites the frames it reads
+  struct NvGuard { d2fe_context* h; bool armed = false; ~NvGuard() { if (armed && h->nv_stream) (void)hipStreamSynchronize(h->nv_stream); } } nv_guard{h};
   if (n_netvlad > 0) {
     // NetVLAD reads the frames SuperPoint reads (one upload), on its own stream: at one or two images per call both launch sequences are
     // latency-bound and leave most of the chip idle, so they overlap almost completely (the reference calls infer and then inference
@@ -646,6 +670,7 @@ static int extract_host(d2fe_handle h, const uint8_t* gray, int n, int width, in
     }
     HIP_TRY(hipEventRecord(h->ev_up, s));
     HIP_TRY(hipStreamWaitEvent(h->nv_stream, h->ev_up, 0));
+    nv_guard.armed = true;
     rc = run_cached(h, {3, n_netvlad, width, height, (long)h->nv_pca_m, 0}, h->nv_stream, [&](hipStream_t st) {
       return run_netvlad(h, h->s_img, n_netvlad, width, height, width, (size_t)width * height, h->nv_s_out, st);
     });
@@ -701,6 +726,7 @@ static int extract_host(d2fe_handle h, const uint8_t* gray, int n, int width, in
   }
   if (n_netvlad > 0) {
     HIP_TRY(hipStreamSynchronize(h->nv_stream));
+    nv_guard.armed = false;
     if (h->pin_nv) memcpy(netvlad_out, h->pin_nv, nv_bytes);
   }
   for (int32_t c : ncand)
@@ -1553,7 +1579,7 @@ int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, void* str
     sc->cand4 = nullptr; sc->bytes = 0; sc->npairs = 0;
     const size_t want = need > sc->bytes ? need : sc->bytes;
     HIP_TRY(hipMalloc(&sc->cand4, want));
-    HIP_TRY(hipMemset(sc->cand4, 0, want));
+    HIP_TRY(hipMemsetAsync(sc->cand4, 0, want, s));      // ON the caller's stream: hipMemset runs on the null stream, which a non-blocking stream does not wait for
     sc->bytes = want; sc->npairs = tp;
   }
   MatchArgs m;
@@ -1596,6 +1622,7 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
   hipStream_t s = nullptr;
   char* buf = nullptr;
   char* pin = nullptr;
+  d2fe_context::MatchSlot* msp = nullptr;       // taken under the lock: a deque never relocates its elements, but indexing it races with an append
   {
     std::lock_guard<std::mutex> lk(h->match_mu);
     for (size_t i = 0; i < h->match_slots.size(); ++i)
@@ -1607,7 +1634,14 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
       slot = (int)h->match_slots.size() - 1;
     }
     d2fe_context::MatchSlot& ms = h->match_slots[slot];
-    if (ms.bytes < slot_bytes) {          // the slot is idle (not busy): nothing of it is in flight
+    ms.busy = true;      // the slot is this call's from here on: the (re)allocation below happens OUTSIDE the lock (hipFree / hipHostFree synchronise the device)
+    s = ms.stream;      // read under the lock: another thread may be appending a slot right now
+    msp = &ms;
+  }
+  struct Release { d2fe_context* h; int slot; ~Release() { std::lock_guard<std::mutex> lk(h->match_mu); h->match_slots[slot].busy = false; } } release{h, slot};
+  {
+    d2fe_context::MatchSlot& ms = *msp;
+    if (ms.bytes < slot_bytes) {
       if (ms.buf) { hipFree(ms.buf); ms.buf = nullptr; }
       if (ms.pin) { (void)hipHostFree(ms.pin); ms.pin = nullptr; }
       ms.bytes = 0;
@@ -1615,12 +1649,9 @@ static int match_host(d2fe_handle h, int mode, const float* a, int na, const flo
       if (h->use_pinned && hipHostMalloc(&ms.pin, slot_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ms.pin = nullptr; }
       ms.bytes = slot_bytes;
     }
-    ms.busy = true;
-    s = ms.stream;      // read under the lock: another thread may be appending a slot right now
     buf = ms.buf;
     pin = ms.pin;
   }
-  struct Release { d2fe_context* h; int slot; ~Release() { std::lock_guard<std::mutex> lk(h->match_mu); h->match_slots[slot].busy = false; } } release{h, slot};
   // device layout (words): a | b | pts_a | pts_b | meta {a_off, b_off, a_cnt, b_cnt, arrival ticket (0), pad x3} | n_out, pad x7 | dist | q | t | cand4
   // -- the inputs are one contiguous run (ONE H2D from the slot's pinned mirror), the outputs another (ONE D2H, one synchronisation)
   const size_t w_in = fa + fb + (use_pts ? 2 * (size_t)(na + nb) : 0) + 8;
@@ -1836,6 +1867,7 @@ int d2fe_debug_conv3x3_wino(d2fe_handle h, const float* in, int n, int H, int W,
     HIP_TRY(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(d_out, 0xff, out_fl * 4));
+    HIP_TRY(hipDeviceSynchronize());      // the null-stream memset is not ordered with the handle's non-blocking stream
     ConvArgs a{};
     a.in = d_in; a.in_cstride = cin; a.in_coff = 0; a.out = d_out; a.out_cstride = cout; a.out_coff = 0;
     a.cout_real = cout; a.wpack = d_w; a.bias = d_b; a.H = H; a.W = W; a.n_img = n;
@@ -1920,7 +1952,7 @@ long d2fe_match_fallback_rows(d2fe_handle h, int reset, long* full_scans) {
   HIP_TRY(hipDeviceSynchronize());
   int32_t v[2] = {0, 0};
   HIP_TRY(hipMemcpy(v, h->match_stats, sizeof(v), hipMemcpyDeviceToHost));
-  if (reset) HIP_TRY(hipMemset(h->match_stats, 0, sizeof(v)));
+  if (reset) { HIP_TRY(hipMemset(h->match_stats, 0, sizeof(v))); HIP_TRY(hipDeviceSynchronize()); }
   if (full_scans) *full_scans = v[0];
   return v[1];
 }

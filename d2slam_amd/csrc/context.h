@@ -79,7 +79,11 @@ struct d2fe_context {
   bool use_graphs = true, use_pinned = true;       // D2FE_GRAPH=0 / D2FE_PINNED=0 switch them off (A/B measurements)
   // d2fe_extract_all*: NetVLAD of the same uploaded frame(s) on a second stream, beside SuperPoint
   hipStream_t nv_stream = nullptr; hipEvent_t ev_up = nullptr; float* pin_nv = nullptr; size_t pin_nv_bytes = 0;
-  struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; bool bad = false; };
+  // host-side bookkeeping a launch sequence leaves behind (what the debug reads and the next NetVLAD step consult): saved when a sequence is
+  // captured, restored on every replay, so that a replay leaves the handle exactly as a direct run of the same geometry would
+  struct HostState { int last_w = 0, last_h = 0, last_n = 0, last_set = 0; const uint8_t* last_gray = nullptr; int last_stride = 0; size_t last_istride = 0;
+                     std::vector<std::pair<int, long>> nv_slabs; int nv_feat_slabs = 1; long nv_feat_slab_stride = 0; int nv_stamp_wgs = 0; };
+  struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; bool bad = false; HostState st; };
   std::map<std::array<long, 6>, GraphEntry> graphs;
   int ncu = 256;               // compute units of cfg.device_id, read once by d2fe_create (ConvArgs::ncu)
   unsigned long long* match_stamps = nullptr;   // development builds: [4096][16] phase stamps of the last d2fe_match_batch_device launch

@@ -189,6 +189,8 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
     return D2FE_OK;
   }();
   if (rc != D2FE_OK) { d2fe_pipe_destroy(p); return rc; }
+  // the hipMemsets above ran on the null stream; the lanes' non-blocking streams do not wait for it
+  if (hipDeviceSynchronize() != hipSuccess) { d2fe_pipe_destroy(p); return pipe_fail(D2FE_ERR_HIP, "hipDeviceSynchronize"); }
   *out = p;
   return D2FE_OK;
 }

@@ -58,7 +58,9 @@ typedef struct {
   int32_t max_height;         /* largest input height (>= 16)  -- SuperPointConfig::input_height */
   int32_t max_batch;          /* images per batched call (>= 1) */
   int32_t max_keypoints;      /* SuperPointConfig::max_keypoints: 1..16384 (sorted top-K), or -1 = keep every keypoint above the threshold in raster
-                                 order like topKeypoints with k == -1 (superpoint_tensorrt.cpp:241-253)  [params->max_superpoint_cnt] */
+                                 order like topKeypoints with k == -1 (superpoint_tensorrt.cpp:241-253)  [params->max_superpoint_cnt].
+                                 Keep-all with MORE keypoints in an image than the call's capacity: D2FE_ERR_TRUNCATED, and the strongest
+                                 min(capacity, 16384) of them are returned in score order (16384 = the in-LDS sort) */
   int32_t remove_borders;     /* SuperPointConfig::remove_borders (variant B), default 1 */
   float   keypoint_threshold; /* SuperPointConfig::keypoint_threshold, default 0.015 */
   int32_t postproc;           /* d2fe_postproc */
