@@ -213,6 +213,8 @@ def main():
         ev_free = [torch.cuda.Event() for _ in range(2)]
         use_h2d = not args.no_h2d
         state = {"k": 0}
+        # N > 1: HIP events around the exchange on the stream it runs on -- pack, ONE all-gather, (int8: decode), count fix-up, gate -- one set per step
+        xev = []
 
         def upload(b):
             """frames of the next step: pinned host -> HBM on the copy stream (19.7 MB per 32 stereo frames)"""
@@ -245,22 +247,30 @@ def main():
                     if netvlad and overlap:
                         tail.wait_event(ev_nv)        # the blocks carry this step's NetVLAD descriptors
                     # cross-agent exchange: one block per left frame, ONE all-gather (RCCL over xGMI), the NetVLAD gate on the device
+                    ev4 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                    xev.append(ev4)
+                    ev4[0].record(tail)
                     if int8x:
                         # the reference's wire precision: quantise on the sender, ONE all-gather of int8 blocks, decode on the receiver
                         fe.pack_blocks_int8_device(desc.data_ptr(), kps.data_ptr(), cnt.data_ptr(), gdesc.data_ptr() if netvlad else 0, 0, 1, F, CAP, G,
                                                    blocks_q.data_ptr(), stream=tstream)
+                        ev4[1].record(tail)
                         swarm.all_gather_blocks(gath_q, blocks_q)
+                        ev4[2].record(tail)
                         fe.unpack_blocks_int8_device(gath_q.data_ptr(), world * F, CAP, G, gath.data_ptr(), renorm=renorm, stream=tstream)
                     else:
                         fe.pack_blocks_device(desc.data_ptr(), kps.data_ptr(), scores.data_ptr(), cnt.data_ptr(), gdesc.data_ptr() if netvlad else 0,
                                               0, 1, F, CAP, G, blocks.data_ptr(), stream=tstream)
+                        ev4[1].record(tail)
                         swarm.all_gather_blocks(gath, blocks)
+                        ev4[2].record(tail)
                     b_cnt[pl.n_local:] = gath_i32[rem_blk, n_off]
                     if netvlad:
                         gate_n.zero_()
                         # all-to-all mode (BASELINE configs[4]): every pair is matched; the reference's gate is evaluated and counted
                         fe.gate_pairs_device(gdesc.data_ptr(), G, gath.data_ptr() + 4 * g_off, BLK, G, gate_q.data_ptr(), gate_db.data_ptr(),
                                              pl.n_remote, NETVLAD_GATE, d_pass=gate_pass.data_ptr(), d_n_pass=gate_n.data_ptr(), stream=tstream)
+                    ev4[3].record(tail)
                 fe.match_batch_device(pool.data_ptr(), pool.data_ptr(), a_off.data_ptr(), b_off.data_ptr(), a_cnt.data_ptr(),
                                       b_cnt.data_ptr(), NP, 256, CAP, mq.data_ptr(), mt.data_ptr(), md.data_ptr(), mn.data_ptr(),
                                       mode=0, ratio=0.8, radius=-1.0, stream=tstream)
@@ -284,6 +294,7 @@ def main():
         for _ in range(args.warmup):
             step()
         barrier()
+        xev.clear()
         fe.profile_enable(1)   # HIP events around the dominant kernel and the NetVLAD sequence only (4 event records per step)
         barrier()
         t0 = time.perf_counter()
@@ -309,9 +320,14 @@ def main():
             gated = {"pairs": pl.n_remote, "passing_netvlad_gate": int(gate_n.item()), "threshold": NETVLAD_GATE}
         exch = None
         if world > 1:
+            xt = np.array([[e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3])] for e in xev[:steps]]) if xev else np.zeros((1, 3))
             per_block = api.block_bytes_int8(CAP, G) if int8x else 4 * BLK
             exch = {"wire_precision": args.exchange, "block_bytes": per_block, "all_gather_bytes_received_per_step_per_gpu": per_block * F * (world - 1),
-                    "avg_cross_agent_matches_per_pair": round(mn[pl.n_local:].float().mean().item(), 2)}
+                    "avg_cross_agent_matches_per_pair": round(mn[pl.n_local:].float().mean().item(), 2),
+                    "step_timeline_ms": {"pack_blocks": round(float(np.median(xt[:, 0])), 4), "all_gather": round(float(np.median(xt[:, 1])), 4),
+                                         "decode_counts_gate": round(float(np.median(xt[:, 2])), 4), "all_gather_max": round(float(xt[:, 1].max()), 4),
+                                         "note": "rank 0, median over the timed steps, HIP events on the stream the exchange is queued on (behind the extraction of the "
+                                                 "same step, in front of the one matcher launch over local and remote pairs); backend %s" % backend}}
 
         # what this mode selected and matched (compared across modes: `mode_disagreement`, `parity`): taken after a step on frame set 0
         # (the previous-left rows then hold frame set 1), whatever --steps / --warmup were
