@@ -401,8 +401,14 @@ def main():
                                      light=not alone)
                         if alone:
                             solo = r
-                    batch_curve.append({"stereo_frames_per_submit": Fc, "submits_in_flight": Kc, "stereo_fps": round(r["value"], 1), "ms_per_submit": round(r["ms_per_step"], 4),
+                    batch_curve.append({"stereo_frames_per_submit": Fc, "submits_in_flight": Kc, "coalesce": 1, "stereo_fps": round(r["value"], 1), "ms_per_submit": round(r["ms_per_step"], 4),
                                         "host_ms_per_submit_call": round(r["host_submit_ms"], 4)})
+                if Fc == 1:
+                    # one stereo frame per submit, up to two consecutive submits per launch sequence (d2fe_pipe_config.coalesce = 2): two passes in flight
+                    r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 2, 400, 8, local_rank, rank, netvlad=use_nv, light=True, coalesce=2)
+                    batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": 4, "coalesce": 2, "stereo_fps": round(r["value"], 1), "ms_per_submit": round(r["ms_per_step"], 4),
+                                        "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
+                                        "note": "submit() stages the frame, every second submit launches ONE sequence over both frames (4 images); per-ticket results are bit-identical"})
     else:
         primary = run_mode(args.precision, True, netvlad=use_nv)
         legs = {}
@@ -565,7 +571,7 @@ def pipe_frames(F, rank):
     return host
 
 
-def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup, local_rank, rank, netvlad=True, light=False):
+def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup, local_rank, rank, netvlad=True, light=False, coalesce=1):
     """`steps` submits of F stereo frames through the frames-in-flight pipe with `lanes` submits in flight: the timed region holds, per submit, the H2D of
     the 2F frames from pinned memory, SuperPoint on them, NetVLAD of the F left images, ONE matcher launch (L<->R, L<->previous L) and the D2H of every
     result into pinned memory.  Timing: barrier-free single process (N = 1), perf_counter around exactly `steps` submits + the waits for all of them."""
@@ -575,7 +581,8 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
     if netvlad:
         fe.load_netvlad(nv_weights)
     host = torch.from_numpy(pipe_frames(F, rank)).pin_memory()
-    pipe = api.StereoPipe(fe, lanes=lanes, frames=F, width=W, height=H, cap=CAP, netvlad=netvlad, ratio=0.8, pinned_input=True)
+    pipe = api.StereoPipe(fe, lanes=lanes, frames=F, width=W, height=H, cap=CAP, netvlad=netvlad, ratio=0.8, pinned_input=True, coalesce=coalesce)
+    inflight = lanes * coalesce
     base, per_set, per_side = host.data_ptr(), 2 * F * H * W, F * H * W
 
     def submit(i):
@@ -586,10 +593,10 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
         tk = []
         th = 0.0
         for i in range(n):
-            if i >= lanes:
-                pipe.wait_raw(tk[i - lanes])
+            if i >= inflight:
+                pipe.wait_raw(tk[i - inflight])
             ta = time.perf_counter(); tk.append(submit(start + i)); th += time.perf_counter() - ta
-        for t in tk[-lanes:]:
+        for t in tk[-inflight:]:
             pipe.wait_raw(t)
         return tk, th
     warmup = max(warmup, 2)
@@ -726,10 +733,10 @@ def index_parity_evidence():
 
 
 def profiled_traffic(kernel_tag):
-    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes of this command (profiles/r03_wino_rocprofv3_summary.txt:
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes of this command (profiles/r04_wino_rocprofv3_summary.txt:
     separate --pmc FETCH_SIZE and WRITE_SIZE passes, tools/profile.sh; KiB per dispatch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
     gfx950's wide reads).  bench.py itself does not collect counters: null when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r03_wino_rocprofv3_summary.txt")
+    path = os.path.join(ROOT, "profiles", "r04_wino_rocprofv3_summary.txt")
     if not os.path.exists(path):
         return None, None
     fetch = write = None
@@ -746,7 +753,7 @@ def profiled_traffic(kernel_tag):
                 write = float(nxt.split("WRITE_SIZE=")[1].split()[0])
     if fetch is None or write is None:
         return None, None
-    return int((2.0 * fetch + write) * 1024), "profiles/r03_wino_rocprofv3_summary.txt: 2 x FETCH_SIZE %.4g KiB + WRITE_SIZE %.4g KiB per dispatch (rocprofv3 --pmc passes of `python bench.py`, same build; not collected inside this run)" % (fetch, write)
+    return int((2.0 * fetch + write) * 1024), "profiles/r04_wino_rocprofv3_summary.txt: 2 x FETCH_SIZE %.4g KiB + WRITE_SIZE %.4g KiB per dispatch (rocprofv3 --pmc passes of `python bench.py`, same build; not collected inside this run)" % (fetch, write)
 
 
 def conv1b_roofline(precision, avg_ms, launches, NI, fused):

@@ -399,6 +399,10 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
       if (alloc_f(h->a4b2, H * W * 2, B) || alloc_f(h->logits2, (H / 8) * (W / 8) * 65, B) || alloc_f(h->draw2, H * W * 4, B)) return D2FE_ERR_HIP;
     }
     h->sparse_desc = !cfg->dense_descriptors;
+    // Winograd mode: the dense head would evaluate convDa as a Winograd layer and the sparse head as direct fp32 chains (bits apart by ~1e-7), so the
+    // head must not depend on the number of images in a call: always sparse there (a frame's descriptors are then the same bits in a 1-image call,
+    // in a 64-image batch and in any pass of the frames-in-flight pipe).  The direct modes give identical bits either way; dense is ~2 % quicker below 4 images
+    if (cfg->precision == D2FE_PREC_F32_WINO) h->sp_min_batch = 1;
     h->sp_min_batch = d2fe_dev_env("D2FE_SPARSE_MIN_BATCH", h->sp_min_batch);
     if (h->sparse_desc) {
       const size_t ncell = (H / 8) * (W / 8);

@@ -27,11 +27,14 @@ using namespace d2fe;
 struct d2fe_pipe_s {
   d2fe_context* parent = nullptr;
   d2fe_pipe_config cfg{};
-  int K = 0, F = 0, NI = 0, W = 0, H = 0, cap = 0, D = 256, G = 0, npairs = 0;
+  // K lanes; a PASS = the g <= C consecutive submits that run as one launch sequence on one lane (C = cfg.coalesce; C > 1 needs F = 1).
+  // Image / output row order of a pass: C == 1: L_0 .. L_(F-1), R_0 .. R_(F-1); C > 1: L, R of submit 0, L, R of submit 1, ... (a pass of g
+  // submits is a prefix, so every address is fixed at creation whatever g turns out to be)
+  int K = 0, F = 0, C = 1, NI = 0, W = 0, H = 0, cap = 0, D = 256, G = 0, npp = 0;      // NI: images per full pass; npp: matcher pairs per submit
   // block layout (float words from the block base; every array starts on a 64-word boundary)
   size_t o_desc = 0, o_kps = 0, o_scores = 0, o_nv = 0, o_cnt = 0, o_mn = 0, o_mq = 0, o_mt = 0, o_md = 0, o_idx = 0, blk_words = 0, d2h_words = 0;
-  float* d_all = nullptr;            // [zero word block | K lanes x 2 sets x block]
-  MatchPairDesc* d_pairs = nullptr;  // [K][2][npairs]
+  float* d_all = nullptr;            // [64 zero words | K lanes x 2 sets x block]
+  MatchPairDesc* d_pairs = nullptr;  // [K][2][C variants: submits of the PREVIOUS pass][C * npp]
   int32_t* d_match_scratch = nullptr; size_t match_scratch_lane = 0;   // per lane: tickets + records
   struct Lane {
     d2fe_context* ctx = nullptr;
@@ -40,12 +43,18 @@ struct d2fe_pipe_s {
     uint8_t* d_img = nullptr;
     uint8_t* pin_in = nullptr;
     float* pin_out[2] = {nullptr, nullptr};
-    long long ticket = -1;           // ticket in flight (or last completed) on this lane
     bool done_synced = true;
   };
   std::vector<Lane> lanes;
   long long next_ticket = 0;
+  long long next_pass = 0;           // passes started so far
+  int pend = 0;                      // submits of the newest pass that are staged but not launched yet (0: no pass open)
+  int prev_g = 1;                    // submits of the last LAUNCHED pass
+  struct TInfo { long long pass = -1; int j = 0; };
+  std::vector<TInfo> tinfo;          // ring over tickets
   float* block(int lane, int set) const { return d_all + 64 + ((size_t)lane * 2 + set) * blk_words; }
+  int left_row(int j, int f) const { return C > 1 ? 2 * j : f; }
+  int right_row(int j, int f) const { return C > 1 ? 2 * j + 1 : F + f; }
 };
 
 namespace {
@@ -54,12 +63,73 @@ size_t up64(size_t w) { return (w + 63) / 64 * 64; }
 
 int pipe_fail(int code, const std::string& msg) { return ctx_fail(code, msg); }
 
-int lane_sync(d2fe_pipe_s* p, d2fe_pipe_s::Lane& L) {
+int lane_sync(d2fe_pipe_s::Lane& L) {
   if (!L.done_synced) {
     HIP_TRY(hipEventSynchronize(L.ev_done));
     L.done_synced = true;
   }
-  (void)p;
+  return D2FE_OK;
+}
+
+// launches the open pass (its `pend` submits are staged in the lane's device input buffer): NetVLAD, SuperPoint, ONE matcher launch, ONE D2H
+int pipe_flush(d2fe_pipe_s* p) {
+  if (p->pend == 0) return D2FE_OK;
+  const long long P = p->next_pass - 1;
+  const int k = (int)(P % p->K), set = (int)((P / p->K) & 1), g = p->pend;
+  auto& L = p->lanes[k];
+  const size_t img = (size_t)p->W * p->H;
+  const int F = p->F, W = p->W, H = p->H;
+  hipStream_t s = L.s;
+  float* B = p->block(k, set);
+  const int n_left = p->C > 1 ? g : F, n_img = p->C > 1 ? 2 * g : 2 * F;
+  const size_t left_stride = p->C > 1 ? 2 * img : img;
+  int rc;
+  const bool nv_side = p->cfg.netvlad && !p->cfg.netvlad_inline;
+  // NetVLAD splits a layer's hidden channels over more workgroup groups the fewer images a call carries, so its fp32 summation order depends on
+  // the batch: a coalesced pass runs it per submit (one image each), which keeps every ticket's descriptor bit-identical to the single call
+  auto netvlad = [&](hipStream_t st) -> int {
+    if (p->C == 1) return run_netvlad(L.ctx, L.d_img, n_left, W, H, W, left_stride, B + p->o_nv, st);
+    for (int j = 0; j < g; ++j) {
+      const int r = run_netvlad(L.ctx, L.d_img + (size_t)p->left_row(j, 0) * img, 1, W, H, W, img, B + p->o_nv + (size_t)j * p->G, st);
+      if (r) return r;
+    }
+    return D2FE_OK;
+  };
+  if (nv_side) {
+    HIP_TRY(hipEventRecord(L.ev_up, s));
+    HIP_TRY(hipStreamWaitEvent(L.nv, L.ev_up, 0));
+    rc = netvlad(L.nv);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(L.ev_nv, L.nv));
+  } else if (p->cfg.netvlad) {
+    rc = netvlad(s);
+    if (rc) return rc;
+  }
+  rc = run_superpoint(L.ctx, L.d_img, n_img, W, H, W, img, B + p->o_kps, B + p->o_scores, B + p->o_desc, reinterpret_cast<int32_t*>(B + p->o_idx), p->cap,
+                      reinterpret_cast<int32_t*>(B + p->o_cnt), s);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(L.ev_ext[set], s));
+  if (p->npp > 0) {
+    if (p->cfg.match_prev && P > 0 && p->K > 1) {      // the first temporal pair reads the previous pass's block: wait for ITS extraction only
+      const int pk = k > 0 ? k - 1 : p->K - 1, pset = k > 0 ? set : set ^ 1;
+      HIP_TRY(hipStreamWaitEvent(s, p->lanes[pk].ev_ext[pset], 0));
+    }
+    const int npairs = g * p->npp, maxp = p->C * p->npp;
+    MatchArgs m{};
+    m.pairs = p->d_pairs + (((size_t)k * 2 + set) * p->C + (p->prev_g - 1)) * maxp;
+    m.npairs = npairs; m.dim = p->D; m.max_n = p->cap; m.mode = 0; m.ratio = p->cfg.ratio; m.radius = -1.0;
+    m.q_idx = reinterpret_cast<int32_t*>(B + p->o_mq); m.t_idx = reinterpret_cast<int32_t*>(B + p->o_mt); m.dist = B + p->o_md;
+    m.n_out = reinterpret_cast<int32_t*>(B + p->o_mn);
+    match_scratch_carve(reinterpret_cast<char*>(p->d_match_scratch) + p->match_scratch_lane * k, maxp, &m);
+    m.stats = p->parent->match_stats; m.ncu = L.ctx->ncu;
+    HIP_TRY(launch_match(m, s));
+  }
+  if (nv_side) HIP_TRY(hipStreamWaitEvent(s, L.ev_nv, 0));
+  HIP_TRY(hipMemcpyAsync(L.pin_out[set], B, sizeof(float) * p->d2h_words, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipEventRecord(L.ev_done, s));
+  L.done_synced = false;
+  p->prev_g = g;
+  p->pend = 0;
   return D2FE_OK;
 }
 
@@ -75,6 +145,7 @@ void d2fe_pipe_default_config(d2fe_pipe_config* c) {
   c->lanes = 4; c->frames = 1; c->width = 640; c->height = 480; c->cap = 200;
   c->netvlad = 1; c->match_lr = 1; c->match_prev = 1; c->pinned_input = 0;
   c->ratio = 0.8; c->radius_lr = -1.0; c->radius_prev = -1.0;
+  c->coalesce = 1;
 }
 
 int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out) {
@@ -84,33 +155,36 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
   if (!h->sp_loaded) return pipe_fail(D2FE_ERR_NOT_READY, "superpoint weights not loaded");
   if (cfg->netvlad && !h->nv_loaded) return pipe_fail(D2FE_ERR_NOT_READY, "netvlad weights not loaded");
   if (cfg->lanes < 1 || cfg->lanes > 16 || cfg->frames < 1 || cfg->frames > 4096) return pipe_fail(D2FE_ERR_INVALID, "lanes must be 1..16, frames >= 1");
-  if (cfg->cap < 1 || (h->cfg.max_keypoints > 0 && cfg->cap > 16384)) return pipe_fail(D2FE_ERR_INVALID, "cap out of range");
+  const int C = cfg->coalesce > 0 ? cfg->coalesce : 1;
+  if (C > 16 || (C > 1 && cfg->frames != 1)) return pipe_fail(D2FE_ERR_INVALID, "coalesce must be 1..16 and needs frames == 1");
+  if (cfg->cap < 1 || cfg->cap > 16384) return pipe_fail(D2FE_ERR_INVALID, "cap out of range");
   if (h->cfg.max_keypoints < 0) return pipe_fail(D2FE_ERR_UNSUPPORTED, "keep-all handles (max_keypoints = -1) are served by the single-call entry points");
   if (cfg->width > h->cfg.max_width || cfg->height > h->cfg.max_height) return pipe_fail(D2FE_ERR_INVALID, "frame size exceeds the handle's maximum");
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   d2fe_pipe_s* p = new d2fe_pipe_s();
   p->parent = h; p->cfg = *cfg;
-  p->K = cfg->lanes; p->F = cfg->frames; p->NI = 2 * cfg->frames; p->W = cfg->width; p->H = cfg->height;
+  p->K = cfg->lanes; p->F = cfg->frames; p->C = C; p->NI = 2 * cfg->frames * C; p->W = cfg->width; p->H = cfg->height;
   p->cap = cfg->cap < h->cfg.max_keypoints ? cfg->cap : h->cfg.max_keypoints;
   p->D = d2fe_desc_dim(h);
   p->G = cfg->netvlad ? d2fe_netvlad_dim(h) : 0;
-  p->npairs = (cfg->match_lr ? p->F : 0) + (cfg->match_prev ? p->F : 0);
+  p->npp = (cfg->match_lr ? p->F : 0) + (cfg->match_prev ? p->F : 0);
+  p->tinfo.resize((size_t)2 * p->K * C + C);
   {
     int rc = check_geometry(h, 1, p->W, p->H, p->W, p->cap);
     if (rc) { delete p; return rc; }
     if (cfg->netvlad) { rc = nv_check(h, 1, p->W, p->H, p->W); if (rc) { delete p; return rc; } }
   }
-  const size_t NI = p->NI, cap = p->cap, F = p->F;
+  const size_t NI = p->NI, cap = p->cap, F = p->F, NL = (size_t)F * C, MP = (size_t)p->npp * C;
   size_t o = 0;
   p->o_desc = o; o += up64(NI * cap * p->D);
   p->o_kps = o; o += up64(NI * cap * 2);
   p->o_scores = o; o += up64(NI * cap);
-  p->o_nv = o; o += up64(F * (size_t)p->G);
+  p->o_nv = o; o += up64(NL * (size_t)p->G);
   p->o_cnt = o; o += up64(NI);
-  p->o_mn = o; o += up64(2 * F);
-  p->o_mq = o; o += up64(2 * F * cap);
-  p->o_mt = o; o += up64(2 * F * cap);
-  p->o_md = o; o += up64(2 * F * cap);
+  p->o_mn = o; o += up64(MP);
+  p->o_mq = o; o += up64(MP * cap);
+  p->o_mt = o; o += up64(MP * cap);
+  p->o_md = o; o += up64(MP * cap);
   p->d2h_words = o;
   p->o_idx = o; o += up64(NI * cap);
   p->blk_words = o;
@@ -126,8 +200,7 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
       if (cfg->cu_partition && p->K > 1) {
         // Disjoint compute units per lane.  Bit i of a HIP CU mask is CU i / 8 of XCD i % 8 on this device, and an XCD without any bit
         // set is NOT masked at all (tools/ubench/cu_mask_probe.hip), so a lane gets the same rows of CUs in every XCD: rows
-        // [k R / K, (k + 1) R / K) of the R = CUs / 8 rows.  Lanes then run truly side by side (no queue arbitration between their
-        // kernels) and share every XCD's L2 copy of the weights
+        // [k R / K, (k + 1) R / K) of the R = CUs / 8 rows
         const int rows = h->ncu / 8, r0 = k * rows / p->K, r1 = (k + 1) * rows / p->K;
         if (r1 > r0) {
           std::vector<uint32_t> mask((h->ncu + 31) / 32, 0u);
@@ -150,39 +223,40 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
       if (!cfg->pinned_input) HIP_TRY(hipHostMalloc(&L.pin_in, (size_t)p->W * p->H * p->NI, hipHostMallocDefault));
       for (int set = 0; set < 2; ++set) HIP_TRY(hipHostMalloc(&L.pin_out[set], sizeof(float) * p->d2h_words, hipHostMallocDefault));
     }
-    if (p->npairs > 0) {
-      // pair tables: [lane][set][pair]; pair f < F (when match_lr): L_f <-> R_f; then L_f <-> L_(f-1), f = 0: the last left frame of the
-      // previous submit's block (lane - 1, that submit's set; the zero word in front of the blocks while no frame has been submitted)
-      std::vector<MatchPairDesc> tab((size_t)p->K * 2 * p->npairs);
+    if (p->npp > 0) {
+      // pair tables [lane][set][variant v = submits of the previous pass - 1][C * npp].  Submit j of a pass contributes npp consecutive pairs:
+      // L_f <-> R_f for its F frames (when match_lr), then L_f <-> L_(f-1); the first left frame of a pass pairs with the LAST left frame
+      // of the previous pass, whose row in the previous pass's block depends on how many submits that pass carried (the variant)
+      const size_t maxp = MP;
+      std::vector<MatchPairDesc> tab((size_t)p->K * 2 * C * maxp);
       for (int k = 0; k < p->K; ++k)
-        for (int set = 0; set < 2; ++set) {
-          float* B = p->block(k, set);
-          // the previous submit: ticket t - 1.  With t = j K + k the set is j & 1; t - 1 = j K + k - 1 (k > 0: same j) or (j - 1) K + K - 1
-          const int pk = k > 0 ? k - 1 : p->K - 1;
-          const int pset = k > 0 ? set : set ^ 1;
-          float* PB = p->block(pk, pset);
-          MatchPairDesc* row = tab.data() + ((size_t)k * 2 + set) * p->npairs;
-          int pi = 0;
-          for (size_t f = 0; cfg->match_lr && f < F; ++f, ++pi) {
-            MatchPairDesc& d = row[pi];
-            d.a = B + p->o_desc + f * cap * p->D; d.b = B + p->o_desc + (F + f) * cap * p->D;
-            d.pts_a = B + p->o_kps + f * cap * 2; d.pts_b = B + p->o_kps + (F + f) * cap * 2;
-            d.na = reinterpret_cast<int32_t*>(B + p->o_cnt) + f; d.nb = reinterpret_cast<int32_t*>(B + p->o_cnt) + F + f;
-            d.radius = cfg->radius_lr;
+        for (int set = 0; set < 2; ++set)
+          for (int v = 0; v < C; ++v) {
+            float* B = p->block(k, set);
+            // the previous pass: P - 1.  With P = i K + k the set is i & 1; P - 1 = i K + k - 1 (k > 0: same i) or (i - 1) K + K - 1
+            const int pk = k > 0 ? k - 1 : p->K - 1;
+            const int pset = k > 0 ? set : set ^ 1;
+            float* PB = p->block(pk, pset);
+            MatchPairDesc* row = tab.data() + (((size_t)k * 2 + set) * C + v) * maxp;
+            int pi = 0;
+            auto fill = [&](MatchPairDesc& d, float* BA, int ra, float* BB, int rb, double radius) {
+              d.a = BA + p->o_desc + (size_t)ra * cap * p->D; d.b = BB + p->o_desc + (size_t)rb * cap * p->D;
+              d.pts_a = BA + p->o_kps + (size_t)ra * cap * 2; d.pts_b = BB + p->o_kps + (size_t)rb * cap * 2;
+              d.na = reinterpret_cast<int32_t*>(BA + p->o_cnt) + ra; d.nb = reinterpret_cast<int32_t*>(BB + p->o_cnt) + rb;
+              d.radius = radius;
+            };
+            for (int j = 0; j < C; ++j) {
+              for (int f = 0; cfg->match_lr && f < (int)F; ++f) fill(row[pi++], B, p->left_row(j, f), B, p->right_row(j, f), cfg->radius_lr);
+              for (int f = 0; cfg->match_prev && f < (int)F; ++f) {
+                if (f > 0) fill(row[pi++], B, p->left_row(j, f), B, p->left_row(j, f - 1), cfg->radius_prev);
+                else if (j > 0) fill(row[pi++], B, p->left_row(j, 0), B, p->left_row(j - 1, (int)F - 1), cfg->radius_prev);
+                else fill(row[pi++], B, p->left_row(0, 0), PB, p->left_row(v, (int)F - 1), cfg->radius_prev);        // previous pass: its last submit is v
+              }
+            }
           }
-          for (size_t f = 0; cfg->match_prev && f < F; ++f, ++pi) {
-            MatchPairDesc& d = row[pi];
-            float* SB = f > 0 ? B : PB;
-            const size_t sf = f > 0 ? f - 1 : F - 1;
-            d.a = B + p->o_desc + f * cap * p->D; d.b = SB + p->o_desc + sf * cap * p->D;
-            d.pts_a = B + p->o_kps + f * cap * 2; d.pts_b = SB + p->o_kps + sf * cap * 2;
-            d.na = reinterpret_cast<int32_t*>(B + p->o_cnt) + f; d.nb = reinterpret_cast<int32_t*>(SB + p->o_cnt) + sf;
-            d.radius = cfg->radius_prev;
-          }
-        }
       HIP_TRY(hipMalloc(&p->d_pairs, sizeof(MatchPairDesc) * tab.size()));
       HIP_TRY(hipMemcpy(p->d_pairs, tab.data(), sizeof(MatchPairDesc) * tab.size(), hipMemcpyHostToDevice));
-      p->match_scratch_lane = match_scratch_bytes(p->npairs, p->cap);
+      p->match_scratch_lane = match_scratch_bytes((int)maxp, p->cap);
       HIP_TRY(hipMalloc(&p->d_match_scratch, p->match_scratch_lane * p->K));
       HIP_TRY(hipMemset(p->d_match_scratch, 0, p->match_scratch_lane * p->K));
     }
@@ -218,69 +292,45 @@ int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int
   if (stride < p->W) return pipe_fail(D2FE_ERR_INVALID, "stride < width");
   HIP_TRY(hipSetDevice(p->parent->cfg.device_id));
   const long long t = p->next_ticket;
-  const int k = (int)(t % p->K), set = (int)((t / p->K) & 1);
+  int rc;
+  if (p->pend == 0) {
+    // a new pass on lane P % K: the lane's previous pass (P - K) must be complete before its buffers are reused; with it every pass <= P - K
+    // is (the invariant that makes the alternating output blocks sufficient, see the header)
+    rc = lane_sync(p->lanes[(size_t)(p->next_pass % p->K)]);
+    if (rc) return rc;
+    ++p->next_pass;
+  }
+  const long long P = p->next_pass - 1;
+  const int k = (int)(P % p->K), j = p->pend;
   auto& L = p->lanes[k];
-  // the lane's previous frame (ticket t - K) must be complete before its buffers are reused; with it every ticket <= t - K is (the
-  // invariant that makes the alternating output blocks sufficient, see the header)
-  int rc = lane_sync(p, L);
-  if (rc) return rc;
   const size_t img = (size_t)p->W * p->H;
-  const int F = p->F, NI = p->NI, W = p->W, H = p->H;
+  const int F = p->F, W = p->W, H = p->H;
   hipStream_t s = L.s;
-  if (p->cfg.pinned_input) {
-    for (int side = 0; side < 2; ++side) {
-      const uint8_t* src = side ? right : left;
-      uint8_t* dst = L.d_img + (size_t)side * F * img;
+  // frames of this submit -> the lane's input buffer at the rows of submit j (H2D is issued at once: it travels while the pass fills)
+  for (int side = 0; side < 2; ++side) {
+    const uint8_t* src = side ? right : left;
+    const size_t row0 = side ? p->right_row(j, 0) : p->left_row(j, 0);       // the F images of a side are consecutive rows (C > 1: F = 1)
+    uint8_t* dst = L.d_img + row0 * img;
+    if (p->cfg.pinned_input) {
       if (stride == W && image_stride == img) HIP_TRY(hipMemcpyAsync(dst, src, img * F, hipMemcpyHostToDevice, s));
       else if (image_stride == (size_t)stride * H) HIP_TRY(hipMemcpy2DAsync(dst, W, src, stride, W, (size_t)H * F, hipMemcpyHostToDevice, s));
       else for (int f = 0; f < F; ++f) HIP_TRY(hipMemcpy2DAsync(dst + f * img, W, src + f * image_stride, stride, W, H, hipMemcpyHostToDevice, s));
-    }
-  } else {
-    for (int side = 0; side < 2; ++side)
+    } else {
+      uint8_t* stage = L.pin_in + row0 * img;
       for (int f = 0; f < F; ++f) {
-        const uint8_t* src = (side ? right : left) + f * image_stride;
-        uint8_t* dst = L.pin_in + ((size_t)side * F + f) * img;
-        if (stride == W) memcpy(dst, src, img);
-        else for (int y = 0; y < H; ++y) memcpy(dst + (size_t)y * W, src + (size_t)y * stride, W);
+        const uint8_t* sf = src + f * image_stride;
+        if (stride == W) memcpy(stage + f * img, sf, img);
+        else for (int y = 0; y < H; ++y) memcpy(stage + f * img + (size_t)y * W, sf + (size_t)y * stride, W);
       }
-    HIP_TRY(hipMemcpyAsync(L.d_img, L.pin_in, img * NI, hipMemcpyHostToDevice, s));
-  }
-  float* B = p->block(k, set);
-  const bool nv_side = p->cfg.netvlad && !p->cfg.netvlad_inline;
-  if (nv_side) {
-    HIP_TRY(hipEventRecord(L.ev_up, s));
-    HIP_TRY(hipStreamWaitEvent(L.nv, L.ev_up, 0));
-    rc = run_netvlad(L.ctx, L.d_img, F, W, H, W, img, B + p->o_nv, L.nv);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(L.ev_nv, L.nv));
-  } else if (p->cfg.netvlad) {
-    rc = run_netvlad(L.ctx, L.d_img, F, W, H, W, img, B + p->o_nv, s);
-    if (rc) return rc;
-  }
-  rc = run_superpoint(L.ctx, L.d_img, NI, W, H, W, img, B + p->o_kps, B + p->o_scores, B + p->o_desc, reinterpret_cast<int32_t*>(B + p->o_idx), p->cap,
-                      reinterpret_cast<int32_t*>(B + p->o_cnt), s);
-  if (rc) return rc;
-  HIP_TRY(hipEventRecord(L.ev_ext[set], s));
-  if (p->npairs > 0) {
-    if (p->cfg.match_prev && t > 0 && p->K > 1) {
-      const int pk = k > 0 ? k - 1 : p->K - 1, pset = k > 0 ? set : set ^ 1;
-      HIP_TRY(hipStreamWaitEvent(s, p->lanes[pk].ev_ext[pset], 0));
+      HIP_TRY(hipMemcpyAsync(dst, stage, img * F, hipMemcpyHostToDevice, s));
     }
-    MatchArgs m{};
-    m.pairs = p->d_pairs + ((size_t)k * 2 + set) * p->npairs;
-    m.npairs = p->npairs; m.dim = p->D; m.max_n = p->cap; m.mode = 0; m.ratio = p->cfg.ratio; m.radius = -1.0;
-    m.q_idx = reinterpret_cast<int32_t*>(B + p->o_mq); m.t_idx = reinterpret_cast<int32_t*>(B + p->o_mt); m.dist = B + p->o_md;
-    m.n_out = reinterpret_cast<int32_t*>(B + p->o_mn);
-    match_scratch_carve(reinterpret_cast<char*>(p->d_match_scratch) + p->match_scratch_lane * k, p->npairs, &m);
-    m.stats = p->parent->match_stats; m.ncu = L.ctx->ncu;
-    HIP_TRY(launch_match(m, s));
   }
-  if (nv_side) HIP_TRY(hipStreamWaitEvent(s, L.ev_nv, 0));
-  HIP_TRY(hipMemcpyAsync(L.pin_out[set], B, sizeof(float) * p->d2h_words, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipEventRecord(L.ev_done, s));
-  L.ticket = t; L.done_synced = false;
+  auto& ti = p->tinfo[(size_t)(t % (long long)p->tinfo.size())];
+  ti.pass = P; ti.j = j;
+  ++p->pend;
   p->next_ticket = t + 1;
   *ticket = t;
+  if (p->pend == p->C) return pipe_flush(p);
   return D2FE_OK;
 }
 
@@ -288,19 +338,27 @@ int d2fe_pipe_wait(d2fe_pipe p, int64_t ticket, d2fe_pipe_result* out) {
   if (!p || !out) return pipe_fail(D2FE_ERR_INVALID, "null argument");
   memset(out, 0, sizeof(*out));
   if (ticket < 0 || ticket >= p->next_ticket) return pipe_fail(D2FE_ERR_INVALID, "unknown ticket");
-  if (ticket + 2 * p->K <= p->next_ticket) return pipe_fail(D2FE_ERR_INVALID, "the ticket's result block has been reused: wait for a frame within 2 * lanes submits");
+  const auto& ti = p->tinfo[(size_t)(ticket % (long long)p->tinfo.size())];
+  // the ticket's result block is written again by the pass 2 K passes later
+  if (ticket + (long long)p->tinfo.size() <= p->next_ticket || ti.pass < 0 || ti.pass + 2 * p->K < p->next_pass)
+    return pipe_fail(D2FE_ERR_INVALID, "the ticket's result block has been reused: wait for a frame within 2 * lanes passes");
   HIP_TRY(hipSetDevice(p->parent->cfg.device_id));
-  const int k = (int)(ticket % p->K), set = (int)((ticket / p->K) & 1);
+  if (p->pend > 0 && ti.pass == p->next_pass - 1) {       // the ticket's pass is still filling: launch it with what it has
+    const int rc = pipe_flush(p);
+    if (rc) return rc;
+  }
+  const int k = (int)(ti.pass % p->K), set = (int)((ti.pass / p->K) & 1), j = ti.j;
   auto& L = p->lanes[k];
-  const int rc = lane_sync(p, L);
+  const int rc = lane_sync(L);
   if (rc) return rc;
   const float* B = L.pin_out[set];
   const size_t F = p->F, cap = p->cap;
+  const size_t r0 = p->left_row(j, 0);          // C == 1: 0; C > 1: the submit's L, R rows are 2 j, 2 j + 1 -- the layout of a frames = 1 result
   out->frames = p->F; out->cap = p->cap; out->desc_dim = p->D; out->netvlad_dim = p->G;
-  out->kps_xy = B + p->o_kps; out->scores = B + p->o_scores; out->desc = B + p->o_desc;
-  out->n_kp = reinterpret_cast<const int32_t*>(B + p->o_cnt);
-  out->netvlad = p->G ? B + p->o_nv : nullptr;
-  size_t pi = 0;
+  out->kps_xy = B + p->o_kps + r0 * cap * 2; out->scores = B + p->o_scores + r0 * cap; out->desc = B + p->o_desc + r0 * cap * p->D;
+  out->n_kp = reinterpret_cast<const int32_t*>(B + p->o_cnt) + r0;
+  out->netvlad = p->G ? B + p->o_nv + (p->C > 1 ? (size_t)j : 0) * p->G : nullptr;
+  size_t pi = (size_t)j * p->npp;
   if (p->cfg.match_lr) {
     out->lr_q = reinterpret_cast<const int32_t*>(B + p->o_mq) + pi * cap; out->lr_t = reinterpret_cast<const int32_t*>(B + p->o_mt) + pi * cap;
     out->lr_dist = B + p->o_md + pi * cap; out->lr_n = reinterpret_cast<const int32_t*>(B + p->o_mn) + pi;

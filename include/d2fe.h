@@ -256,7 +256,11 @@ typedef struct {
                                behaves like a (256 / lanes)-CU device working on its own frame */
   int32_t netvlad_inline;   /* 0: NetVLAD on the lane's second stream beside SuperPoint (shortest latency of one frame); 1: on the lane's one stream, in
                                front of SuperPoint (half as many streams: with many lanes the device's hardware queues are the limit) */
-  int32_t reserved[6];
+  int32_t coalesce;         /* > 1 (needs frames == 1): up to this many consecutive submits run as ONE launch sequence when they are submitted before
+                               anybody waits for them -- submit() stages the frame (its H2D starts at once) and the pass is launched when it is full
+                               or when d2fe_pipe_wait asks for one of its tickets; results per ticket are unchanged (bit-identical).  What a
+                               throughput-oriented caller that receives frames one at a time would otherwise do by hand with frames = 2 */
+  int32_t reserved[5];
 } d2fe_pipe_config;
 typedef struct {            /* HOST pointers into the lane's pinned block; valid until 2 * lanes further submits */
   int32_t frames, cap, desc_dim, netvlad_dim;
@@ -276,9 +280,10 @@ D2FE_API int d2fe_pipe_lanes(d2fe_pipe p);
 D2FE_API int d2fe_pipe_profile_enable(d2fe_pipe p, int mode);
 D2FE_API int d2fe_pipe_profile_read(d2fe_pipe p, float* ms /*[D2FE_PROF_COUNT]*/, int32_t* launches /*[D2FE_PROF_COUNT]*/);
 /* left / right: `frames` gray u8 images each, image f at + f * image_stride, rows `stride` bytes apart.  Returns at once with a ticket
- * (0, 1, 2, ...).  Blocks only when the ticket's lane still holds the frame submitted `lanes` submits ago that nobody waited for. */
+ * (0, 1, 2, ...).  Blocks only when the ticket's lane still holds the pass submitted `lanes` passes ago that nobody waited for. */
 D2FE_API int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int stride, size_t image_stride, int64_t* ticket);
-/* Blocks until the ticket's frame is complete on the host.  Tickets may be waited for in any order, each within 2 * lanes submits. */
+/* Blocks until the ticket's frame is complete on the host (launching its pass first if coalescing still holds it back).  Tickets may be waited
+ * for in any order, each within 2 * lanes passes (a pass = `coalesce` submits). */
 D2FE_API int d2fe_pipe_wait(d2fe_pipe p, int64_t ticket, d2fe_pipe_result* out);
 
 /* Half-image filter for quadcam neighbour matching.  Replaces getFeatureHalfImg

@@ -22,9 +22,10 @@ def _frames(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lanes,frames,netvlad,part", [(1, 1, True, False), (3, 1, True, False), (2, 2, True, False), (4, 1, False, False), (2, 3, True, False),
-                                                      (4, 1, True, True), (3, 2, True, True), (8, 1, True, True)])
-def test_pipe_equals_single_calls(lanes, frames, netvlad, part):
+@pytest.mark.parametrize("lanes,frames,netvlad,part,coal", [(1, 1, True, False, 1), (3, 1, True, False, 1), (2, 2, True, False, 1), (4, 1, False, False, 1),
+                                                           (2, 3, True, False, 1), (4, 1, True, True, 1), (3, 2, True, True, 1), (8, 1, True, True, 1),
+                                                           (2, 1, True, False, 2), (3, 1, True, False, 3), (1, 1, False, False, 4), (2, 1, True, True, 2)])
+def test_pipe_equals_single_calls(lanes, frames, netvlad, part, coal):
     from d2slam_amd import api, netvlad as nvm
     from d2slam_amd.weights import synthetic_superpoint_weights
     fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2 * frames, precision=api.PREC_F32_WINO,
@@ -32,16 +33,17 @@ def test_pipe_equals_single_calls(lanes, frames, netvlad, part):
     fe.load_superpoint(synthetic_superpoint_weights(dustbin_bias=7.5))
     if netvlad:
         fe.load_netvlad(nvm.synthetic_netvlad_weights())
-    nsub = 2 * lanes + 3
+    nsub = 2 * lanes * coal + 3              # an odd tail: the last pass is launched by wait() with fewer submits than `coalesce`
+    inflight = lanes * coal
     fr = _frames(nsub * frames)
     radius_lr, radius_prev = 0.2 * W, 0.05 * W
-    pipe = api.StereoPipe(fe, lanes=lanes, frames=frames, width=W, height=H, cap=CAP, netvlad=netvlad, ratio=0.8, radius_lr=radius_lr, radius_prev=radius_prev, cu_partition=part)
+    pipe = api.StereoPipe(fe, lanes=lanes, frames=frames, width=W, height=H, cap=CAP, netvlad=netvlad, ratio=0.8, radius_lr=radius_lr, radius_prev=radius_prev, cu_partition=part, coalesce=coal)
     got = []
     tickets = []
     for sidx in range(nsub):
         L = np.stack([fr[sidx * frames + f][0] for f in range(frames)]); R = np.stack([fr[sidx * frames + f][1] for f in range(frames)])
         tickets.append(pipe.submit(L, R))
-        if len(tickets) > lanes - 1:                       # keep `lanes` submits in flight
+        if len(tickets) > inflight - 1:                    # keep `lanes` passes in flight
             t = tickets[len(got)]
             got.append({k: (None if v is None else v.copy()) for k, v in pipe.wait(t).items()})
     while len(got) < nsub:

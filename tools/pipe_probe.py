@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=0.5)
     ap.add_argument("--precision", default="wino")
     ap.add_argument("--no-netvlad", action="store_true")
+    ap.add_argument("--coalesce", type=int, default=1, help="d2fe_pipe_config.coalesce (frames per submit must be 1)")
     ap.add_argument("--nv-inline", action="store_true", help="d2fe_pipe_config.netvlad_inline")
     ap.add_argument("--partition", action="store_true", help="d2fe_pipe_config.cu_partition: disjoint compute units per lane")
     args = ap.parse_args()
@@ -38,29 +39,30 @@ def main():
                 l, r = scenes[(s * F + f) % len(scenes)]
                 sh = (s % 3, (2 * s) % 5)
                 hn[s, 0, f] = np.roll(l, sh, (0, 1)); hn[s, 1, f] = np.roll(r, sh, (0, 1))
-        pipe = api.StereoPipe(fe, lanes=K, frames=F, width=W, height=H, cap=CAP, netvlad=not args.no_netvlad, pinned_input=True, cu_partition=args.partition, netvlad_inline=args.nv_inline)
+        pipe = api.StereoPipe(fe, lanes=K, frames=F, width=W, height=H, cap=CAP, netvlad=not args.no_netvlad, pinned_input=True, cu_partition=args.partition, netvlad_inline=args.nv_inline, coalesce=args.coalesce)
         base = host.data_ptr(); per = 2 * F * H * W
         def submit(i):
             s = i % NS
             return pipe.submit_ptr(base + s * per, base + s * per + F * H * W)
-        tickets = [submit(i) for i in range(K)]
-        for i in range(K, 3 * K + 2):
-            pipe.wait_raw(tickets[i - K]); tickets.append(submit(i))
-        for t in tickets[-K:]:
+        KC = K * args.coalesce          # submits in flight = lanes x submits per pass
+        tickets = [submit(i) for i in range(KC)]
+        for i in range(KC, 3 * KC + 2):
+            pipe.wait_raw(tickets[i - KC]); tickets.append(submit(i))
+        for t in tickets[-KC:]:
             pipe.wait_raw(t)
-        steps = max(2 * K, int(args.seconds * 2200 / F))
+        steps = max(2 * KC, int(args.seconds * 2200 / F))
         th = 0.0
         t0 = time.perf_counter()
         tickets = []
         for i in range(steps):
-            if i >= K:
-                pipe.wait_raw(tickets[i - K])
+            if i >= KC:
+                pipe.wait_raw(tickets[i - KC])
             ta = time.perf_counter(); tickets.append(submit(i)); th += time.perf_counter() - ta
-        for t in tickets[-K:]:
+        for t in tickets[-KC:]:
             r = pipe.wait_raw(t)
         dt = time.perf_counter() - t0
         o = pipe.wait(tickets[-1])
-        rec = {"cu_partition": bool(args.partition), "nv_inline": bool(args.nv_inline), "hwq": os.environ.get("GPU_MAX_HW_QUEUES"), "lanes": K, "frames_per_submit": F, "stereo_fps": round(steps * F / dt, 1), "ms_per_submit": round(dt / steps * 1e3, 4),
+        rec = {"coalesce": args.coalesce, "cu_partition": bool(args.partition), "nv_inline": bool(args.nv_inline), "hwq": os.environ.get("GPU_MAX_HW_QUEUES"), "lanes": K, "frames_per_submit": F, "stereo_fps": round(steps * F / dt, 1), "ms_per_submit": round(dt / steps * 1e3, 4),
                "host_submit_ms": round(th / steps * 1e3, 4), "avg_kp": float(o["n_kp"].mean()), "avg_lr": float(o["lr_n"].mean()), "avg_prev": float(o["prev_n"].mean())}
         print(json.dumps(rec), flush=True)
         res.append(rec)

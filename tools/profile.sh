@@ -4,10 +4,11 @@ TAG=${1:-r02}; PREC=${2:-wino}
 OUT=$PWD/gpurun_out/prof_${TAG}_${PREC}
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 5 --warmup 2 --precision $PREC --single-mode --no-cpu-baseline"
+# one submit in flight (--lanes 1): every kernel has the device to itself, as in the `roofline` object of the default bench line
+BENCH="python $PWD/bench.py --steps 5 --warmup 2 --precision $PREC --single-mode --no-cpu-baseline --lanes 1"
 REPO=$PWD; cd /tmp
 # the stats pass runs bench.py with its DEFAULT steps/warmup (the command whose JSON line carries roofline.avg_launch_ms)
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py --precision $PREC --single-mode --no-cpu-baseline > $OUT/bench_trace.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py --precision $PREC --single-mode --no-cpu-baseline --lanes 1 > $OUT/bench_trace.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o p -- $BENCH > $OUT/bench_pmc_sq.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $BENCH > $OUT/bench_pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $BENCH > $OUT/bench_pmc_write.log 2>&1

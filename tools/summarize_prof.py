@@ -32,7 +32,9 @@ def main(root):
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"]); agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
             out.append("== %s per-dispatch averages" % sub)
-            for k in sorted(agg, key=lambda k: -sum(agg[k].values()))[:14]:
+            watch = ("match_kernel", "softmax_cand", "select_b", "sample_b", "desc_head_sparse", "conv1x1_256_65")      # the HBM / latency-bound kernels north_star names
+            top = sorted(agg, key=lambda k: -sum(agg[k].values()))
+            for k in top[:14] + [k for k in top[14:] if any(w in k for w in watch)]:
                 out.append("  " + k)
                 out.append("      " + "  ".join("%s=%.4g" % (c, v / cnt[(k, c)]) for c, v in sorted(agg[k].items())))
     print("\n".join(out))
