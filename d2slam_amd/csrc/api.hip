@@ -415,7 +415,7 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
     }
     HIP_TRY(hipMalloc(&h->zeros, 1024));
     HIP_TRY(hipMemset(h->zeros, 0, 1024));
-    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device_id) == hipSuccess && v > 0) h->ncu = v; }
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device_id) == hipSuccess && v > 0) h->ncu = h->ncu_dev = v; }
     HIP_TRY(hipMalloc(&h->match_stats, 4 * sizeof(int32_t)));
     HIP_TRY(hipMemset(h->match_stats, 0, 4 * sizeof(int32_t)));
     h->wino_dynamic = d2fe_dev_env("D2FE_WINO_DYNAMIC", 1) != 0;
@@ -840,7 +840,8 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
       a.P = (long)n * ch * cw;
       a.wp = st.wp; a.bp = st.bp; a.act_p = 0;
       // three workgroups per CU fit (registers), and the MFMA pipe is the limit: ~768 workgroups of equal length load every SIMD alike
-      nv_groups((a.P + 127) / 128, a.Chid / 16, h->nv_feat_gmax, &groups, &cpg, h->nv_tail_blocks);
+      // (the hidden-channel split is decided on ONE image's pixel count whatever the batch: see the block steps below)
+      nv_groups(((long)ch * cw + 127) / 128, a.Chid / 16, h->nv_feat_gmax, &groups, &cpg, h->nv_tail_blocks);
       a.cpg = cpg; a.out = h->nv_feat_buf; a.out_slab_stride = a.P * a.Cout;
       h->nv_feat_slabs = groups; h->nv_feat_slab_stride = a.out_slab_stride;
       if (nv_tail_supported(a.Cin, a.Cout)) HIP_TRY(launch_nv_tail(a, groups, s));     // st.we was packed in that kernel's K order
@@ -861,11 +862,16 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     a.th = 8; a.tw = 16;
     if (st.pblock) nv_pblock_tile(a.Ho, a.Wo, &a.th, &a.tw, st.front ? a.c0_stride : 0);
     else if (st.xblock) nv_xblock_tile(a.Ho, a.Wo, a.stride, &a.th, &a.tw);
-    const long tiles = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th) * n;
+    const long tiles1 = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th);
+    const long tiles = tiles1 * n;
     // partial slabs are summed by the consumer's staging: only when that consumer is a fused step
-    // pixel-pair kernel: no more workgroups than 85 % of what the device holds at once (registers / LDS of that block shape)
-    nv_groups(tiles, a.Chid / 16, next_fused ? pj.gmax : 1, &groups, &cpg, h->nv_blocks_target,
-              st.pblock ? nv_pblock_slots(a.Cin, a.Cout, h->ncu, 1) * 85 / 100 : 0);
+    // pixel-pair kernel: no more workgroups than 85 % of what the device holds at once (registers / LDS of that block shape).
+    // The split of the hidden channels over workgroup groups fixes the fp32 summation order of the block's output, so it is decided on ONE
+    // image's tile count and the DEVICE's compute units (not the batch, not a pipeline lane's share): an image's descriptor is the same bits
+    // in a 1-image call, a 32-image batch and any pass of the frames-in-flight pipe.  A batch then runs with more groups than it needs to fill
+    // the device (15 x 20 layers at 32 images: 7 slabs instead of 4) -- a few MB of partial-slab traffic
+    nv_groups(tiles1, a.Chid / 16, next_fused ? pj.gmax : 1, &groups, &cpg, h->nv_blocks_target,
+              st.pblock ? nv_pblock_slots(a.Cin, a.Cout, h->ncu_dev, 1) * 85 / 100 : 0);
     a.cpg = cpg; a.out = pj.out; a.out_slab_stride = (long)n * a.Ho * a.Wo * a.Cout;
     pj.slabs = groups; pj.slab_stride = a.out_slab_stride;
     a.ncu = h->ncu; a.tpw = h->nv_front_tpw; a.nbuf = h->nv_nbuf;

@@ -85,7 +85,8 @@ struct d2fe_context {
                      std::vector<std::pair<int, long>> nv_slabs; int nv_feat_slabs = 1; long nv_feat_slab_stride = 0; int nv_stamp_wgs = 0; };
   struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; bool bad = false; HostState st; };
   std::map<std::array<long, 6>, GraphEntry> graphs;
-  int ncu = 256;               // compute units of cfg.device_id, read once by d2fe_create (ConvArgs::ncu)
+  int ncu = 256;               // compute units this context sizes its persistent grids for: the device's (d2fe_create) or a pipeline lane's share
+  int ncu_dev = 256;           // compute units of cfg.device_id: decisions that fix an arithmetic order use this one
   unsigned long long* match_stamps = nullptr;   // development builds: [4096][16] phase stamps of the last d2fe_match_batch_device launch
   int32_t* match_stats = nullptr;   // [4] matcher counters: [0] queries that took the exact fallback scan (MatchArgs::stats)
   int* work_ctrs = nullptr;    // one work-item counter per Winograd layer, zeroed at the start of every network pass (ConvArgs::work_ctr)

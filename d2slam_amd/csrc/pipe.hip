@@ -85,16 +85,9 @@ int pipe_flush(d2fe_pipe_s* p) {
   const size_t left_stride = p->C > 1 ? 2 * img : img;
   int rc;
   const bool nv_side = p->cfg.netvlad && !p->cfg.netvlad_inline;
-  // NetVLAD splits a layer's hidden channels over more workgroup groups the fewer images a call carries, so its fp32 summation order depends on
-  // the batch: a coalesced pass runs it per submit (one image each), which keeps every ticket's descriptor bit-identical to the single call
-  auto netvlad = [&](hipStream_t st) -> int {
-    if (p->C == 1) return run_netvlad(L.ctx, L.d_img, n_left, W, H, W, left_stride, B + p->o_nv, st);
-    for (int j = 0; j < g; ++j) {
-      const int r = run_netvlad(L.ctx, L.d_img + (size_t)p->left_row(j, 0) * img, 1, W, H, W, img, B + p->o_nv + (size_t)j * p->G, st);
-      if (r) return r;
-    }
-    return D2FE_OK;
-  };
+  // NetVLAD of the pass's left images in ONE call (its arithmetic order does not depend on the batch: run_netvlad decides the hidden-channel
+  // split per image), C > 1: the left images are every second image of the lane's input buffer
+  auto netvlad = [&](hipStream_t st) -> int { return run_netvlad(L.ctx, L.d_img, n_left, W, H, W, left_stride, B + p->o_nv, st); };
   if (nv_side) {
     HIP_TRY(hipEventRecord(L.ev_up, s));
     HIP_TRY(hipStreamWaitEvent(L.nv, L.ev_up, 0));
@@ -210,6 +203,10 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
           lane_cus = 8 * (r1 - r0);
         }
       }
+      // lane_cus without a CU mask: the lane's persistent kernels size their grids for that many compute units but may run anywhere -- a
+      // full-device persistent launch holds every CU's LDS until it ends, so another lane's small launches cannot start beside it; grids sized
+      // for a share of the device leave workgroup slots on every CU to the other lanes
+      if (!lane_cus && cfg->lane_cus > 0 && cfg->lane_cus < h->ncu) lane_cus = cfg->lane_cus;
       int rc2 = clone_lane(h, p->NI, &L.ctx, ms, lane_cus);
       if (rc2) { if (ms) (void)hipStreamDestroy(ms); return rc2; }
       L.s = L.ctx->stream;

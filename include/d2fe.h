@@ -260,7 +260,10 @@ typedef struct {
                                anybody waits for them -- submit() stages the frame (its H2D starts at once) and the pass is launched when it is full
                                or when d2fe_pipe_wait asks for one of its tickets; results per ticket are unchanged (bit-identical).  What a
                                throughput-oriented caller that receives frames one at a time would otherwise do by hand with frames = 2 */
-  int32_t reserved[5];
+  int32_t lane_cus;         /* > 0: a lane's persistent kernels size their grids for this many compute units (no CU mask: they may run on any CU).  A
+                               full-device persistent launch occupies every CU's LDS until it ends, so other lanes' small launches wait for it;
+                               with e.g. 128 of 256, two lanes run side by side on every CU.  0: the whole device */
+  int32_t reserved[4];
 } d2fe_pipe_config;
 typedef struct {            /* HOST pointers into the lane's pinned block; valid until 2 * lanes further submits */
   int32_t frames, cap, desc_dim, netvlad_dim;

@@ -923,3 +923,20 @@ def test_variant_a_batch_and_pca(api, orc, sp_weights):
         assert withpca[i][2].shape == (len(rk), 64)
         assert np.abs(withpca[i][2] - orc.sample_a(f["desc"], rk, W, H, comp, mean)).max() <= 1e-5
     fe.close()
+
+
+def test_netvlad_does_not_depend_on_the_batch(api):
+    """The split of a block's hidden channels over workgroup groups fixes the fp32 summation order; it is decided per image, so an image's
+    descriptor is the same bits alone, in a batch of 5 and at any position of it (what lets the frames-in-flight pipe batch frames freely)."""
+    from d2slam_amd import netvlad as nvm
+    from d2slam_amd.synth import synth_image
+    H, W = 240, 320
+    fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=5))
+    fe.load_netvlad(nvm.synthetic_netvlad_weights())
+    imgs = np.stack([synth_image(H, W, 40 + i) for i in range(5)])
+    g5 = fe.netvlad(imgs)
+    for i in (0, 2, 4):
+        assert np.array_equal(fe.netvlad(imgs[i:i + 1])[0], g5[i])
+    assert np.array_equal(fe.netvlad(imgs[1:4]), g5[1:4])
+    fe.close()
+

@@ -13,6 +13,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=0.5)
     ap.add_argument("--precision", default="wino")
     ap.add_argument("--no-netvlad", action="store_true")
+    ap.add_argument("--dev", action="store_true", help="the development library (honours the D2FE_* schedule switches)")
+    ap.add_argument("--lane-cus", type=int, default=0, help="d2fe_pipe_config.lane_cus")
     ap.add_argument("--coalesce", type=int, default=1, help="d2fe_pipe_config.coalesce (frames per submit must be 1)")
     ap.add_argument("--nv-inline", action="store_true", help="d2fe_pipe_config.netvlad_inline")
     ap.add_argument("--partition", action="store_true", help="d2fe_pipe_config.cu_partition: disjoint compute units per lane")
@@ -22,7 +24,7 @@ def main():
     from d2slam_amd.synth import synth_stereo
     from d2slam_amd.weights import synthetic_superpoint_weights
     prec = {"f32": api.PREC_F32, "f16x2": api.PREC_F16X2, "wino": api.PREC_F32_WINO}[args.precision]
-    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=1, precision=prec))
+    fe = (api.DevFrontEnd if args.dev else api.FrontEnd)(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=1, precision=prec))
     fe.load_superpoint(synthetic_superpoint_weights(dustbin_bias=7.5))
     if not args.no_netvlad:
         fe.load_netvlad(nvm.synthetic_netvlad_weights())
@@ -39,7 +41,7 @@ def main():
                 l, r = scenes[(s * F + f) % len(scenes)]
                 sh = (s % 3, (2 * s) % 5)
                 hn[s, 0, f] = np.roll(l, sh, (0, 1)); hn[s, 1, f] = np.roll(r, sh, (0, 1))
-        pipe = api.StereoPipe(fe, lanes=K, frames=F, width=W, height=H, cap=CAP, netvlad=not args.no_netvlad, pinned_input=True, cu_partition=args.partition, netvlad_inline=args.nv_inline, coalesce=args.coalesce)
+        pipe = api.StereoPipe(fe, lanes=K, frames=F, width=W, height=H, cap=CAP, netvlad=not args.no_netvlad, pinned_input=True, cu_partition=args.partition, netvlad_inline=args.nv_inline, coalesce=args.coalesce, lane_cus=args.lane_cus)
         base = host.data_ptr(); per = 2 * F * H * W
         def submit(i):
             s = i % NS
@@ -62,7 +64,7 @@ def main():
             r = pipe.wait_raw(t)
         dt = time.perf_counter() - t0
         o = pipe.wait(tickets[-1])
-        rec = {"coalesce": args.coalesce, "cu_partition": bool(args.partition), "nv_inline": bool(args.nv_inline), "hwq": os.environ.get("GPU_MAX_HW_QUEUES"), "lanes": K, "frames_per_submit": F, "stereo_fps": round(steps * F / dt, 1), "ms_per_submit": round(dt / steps * 1e3, 4),
+        rec = {"lane_cus": args.lane_cus, "coalesce": args.coalesce, "cu_partition": bool(args.partition), "nv_inline": bool(args.nv_inline), "hwq": os.environ.get("GPU_MAX_HW_QUEUES"), "lanes": K, "frames_per_submit": F, "stereo_fps": round(steps * F / dt, 1), "ms_per_submit": round(dt / steps * 1e3, 4),
                "host_submit_ms": round(th / steps * 1e3, 4), "avg_kp": float(o["n_kp"].mean()), "avg_lr": float(o["lr_n"].mean()), "avg_prev": float(o["prev_n"].mean())}
         print(json.dumps(rec), flush=True)
         res.append(rec)
