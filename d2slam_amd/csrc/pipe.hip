@@ -16,6 +16,7 @@
 // Outputs are bit-identical to the single-call entry points (same kernels, same launch shapes for the same image count).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -46,6 +47,16 @@ struct d2fe_pipe_s {
     bool done_synced = true;
   };
   std::vector<Lane> lanes;
+  uint8_t* d_img_all = nullptr;      // the lanes' input buffers, one allocation: lane k at k * NI images (netvlad_group reads several lanes' left images with one stride)
+  // netvlad_group = M > 1 (frames == 1, coalesce == 1, lanes % M == 0): the NetVLAD descriptors of M consecutive submits come from ONE call on the pipe's own
+  // context and stream (NetVLAD at one image is ~20 launches of a few workgroups each: 0.25 ms for one image, 0.28 ms for four), while SuperPoint and the
+  // matches of every submit are launched at once.  Tickets [i M, (i + 1) M) use lanes k0 .. k0 + M - 1; a wait() launches the part that is there
+  int M = 1;
+  d2fe_context* gctx = nullptr; hipStream_t gnv = nullptr;
+  float* d_gnv = nullptr; float* pin_gnv = nullptr;      // [2 sets][K][G]
+  std::vector<hipEvent_t> ev_g;                          // [2 sets][K / M]: the group's descriptors are in pinned memory
+  std::vector<char> g_synced;
+  long long g_first = 0;                                 // first ticket whose NetVLAD has not been launched
   long long next_ticket = 0;
   long long next_pass = 0;           // passes started so far
   int pend = 0;                      // submits of the newest pass that are staged but not launched yet (0: no pass open)
@@ -84,7 +95,8 @@ int pipe_flush(d2fe_pipe_s* p) {
   const int n_left = p->C > 1 ? g : F, n_img = p->C > 1 ? 2 * g : 2 * F;
   const size_t left_stride = p->C > 1 ? 2 * img : img;
   int rc;
-  const bool nv_side = p->cfg.netvlad && !p->cfg.netvlad_inline;
+  const bool nv_side = p->cfg.netvlad && !p->cfg.netvlad_inline && p->M == 1;
+  if (p->cfg.netvlad && p->M > 1) HIP_TRY(hipEventRecord(L.ev_up, s));       // netvlad_group: the pipe's NetVLAD stream waits for this lane's frames
   // NetVLAD of the pass's left images in ONE call (its arithmetic order does not depend on the batch: run_netvlad decides the hidden-channel
   // split per image), C > 1: the left images are every second image of the lane's input buffer
   auto netvlad = [&](hipStream_t st) -> int { return run_netvlad(L.ctx, L.d_img, n_left, W, H, W, left_stride, B + p->o_nv, st); };
@@ -94,7 +106,7 @@ int pipe_flush(d2fe_pipe_s* p) {
     rc = netvlad(L.nv);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(L.ev_nv, L.nv));
-  } else if (p->cfg.netvlad) {
+  } else if (p->cfg.netvlad && p->M == 1) {
     rc = netvlad(s);
     if (rc) return rc;
   }
@@ -126,6 +138,23 @@ int pipe_flush(d2fe_pipe_s* p) {
   return D2FE_OK;
 }
 
+// netvlad_group: NetVLAD of the tickets [g_first, upto) -- all inside one aligned group, i.e. consecutive lanes -- as ONE call
+int pipe_flush_group(d2fe_pipe_s* p, long long upto) {
+  if (p->M <= 1 || upto <= p->g_first) return D2FE_OK;
+  const long long t0 = p->g_first;
+  const int n = (int)(upto - t0), k0 = (int)(t0 % p->K), gset = (int)((t0 / p->K) & 1), slot = gset * (p->K / p->M) + k0 / p->M;
+  const size_t img = (size_t)p->W * p->H;
+  for (int i = 0; i < n; ++i) HIP_TRY(hipStreamWaitEvent(p->gnv, p->lanes[k0 + i].ev_up, 0));
+  float* d_out = p->d_gnv + ((size_t)gset * p->K + k0) * p->G;
+  const int rc = run_netvlad(p->gctx, p->d_img_all + (size_t)k0 * p->NI * img, n, p->W, p->H, p->W, (size_t)p->NI * img, d_out, p->gnv);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(p->pin_gnv + ((size_t)gset * p->K + k0) * p->G, d_out, sizeof(float) * (size_t)n * p->G, hipMemcpyDeviceToHost, p->gnv));
+  HIP_TRY(hipEventRecord(p->ev_g[slot], p->gnv));
+  p->g_synced[slot] = 0;
+  p->g_first = upto;
+  return D2FE_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -150,12 +179,15 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
   if (cfg->lanes < 1 || cfg->lanes > 16 || cfg->frames < 1 || cfg->frames > 4096) return pipe_fail(D2FE_ERR_INVALID, "lanes must be 1..16, frames >= 1");
   const int C = cfg->coalesce > 0 ? cfg->coalesce : 1;
   if (C > 16 || (C > 1 && cfg->frames != 1)) return pipe_fail(D2FE_ERR_INVALID, "coalesce must be 1..16 and needs frames == 1");
+  const int M = cfg->netvlad && cfg->netvlad_group > 1 ? cfg->netvlad_group : 1;
+  if (M > 1 && (cfg->frames != 1 || C != 1 || cfg->lanes % M != 0)) return pipe_fail(D2FE_ERR_INVALID, "netvlad_group needs frames == 1, coalesce == 1 and lanes % netvlad_group == 0");
   if (cfg->cap < 1 || cfg->cap > 16384) return pipe_fail(D2FE_ERR_INVALID, "cap out of range");
   if (h->cfg.max_keypoints < 0) return pipe_fail(D2FE_ERR_UNSUPPORTED, "keep-all handles (max_keypoints = -1) are served by the single-call entry points");
   if (cfg->width > h->cfg.max_width || cfg->height > h->cfg.max_height) return pipe_fail(D2FE_ERR_INVALID, "frame size exceeds the handle's maximum");
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   d2fe_pipe_s* p = new d2fe_pipe_s();
   p->parent = h; p->cfg = *cfg;
+  p->M = M;
   p->K = cfg->lanes; p->F = cfg->frames; p->C = C; p->NI = 2 * cfg->frames * C; p->W = cfg->width; p->H = cfg->height;
   p->cap = cfg->cap < h->cfg.max_keypoints ? cfg->cap : h->cfg.max_keypoints;
   p->D = d2fe_desc_dim(h);
@@ -185,6 +217,16 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
     const size_t all_words = 64 + (size_t)p->K * 2 * p->blk_words;
     HIP_TRY(hipMalloc(&p->d_all, sizeof(float) * all_words));
     HIP_TRY(hipMemset(p->d_all, 0, sizeof(float) * all_words));
+    HIP_TRY(hipMalloc(&p->d_img_all, (size_t)p->W * p->H * p->NI * p->K));
+    if (p->M > 1) {
+      const int rcg = clone_lane(h, p->M, &p->gctx);
+      if (rcg) return rcg;
+      p->gnv = p->gctx->stream;
+      HIP_TRY(hipMalloc(&p->d_gnv, sizeof(float) * 2 * p->K * p->G));
+      HIP_TRY(hipHostMalloc(&p->pin_gnv, sizeof(float) * 2 * p->K * p->G, hipHostMallocDefault));
+      p->ev_g.resize((size_t)2 * (p->K / p->M)); p->g_synced.assign(p->ev_g.size(), 1);
+      for (auto& e : p->ev_g) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     p->lanes.resize(p->K);
     for (int k = 0; k < p->K; ++k) {
       auto& L = p->lanes[k];
@@ -216,7 +258,7 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
       HIP_TRY(hipEventCreateWithFlags(&L.ev_ext[0], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&L.ev_ext[1], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
-      HIP_TRY(hipMalloc(&L.d_img, (size_t)p->W * p->H * p->NI));
+      L.d_img = p->d_img_all + (size_t)k * p->NI * p->W * p->H;
       if (!cfg->pinned_input) HIP_TRY(hipHostMalloc(&L.pin_in, (size_t)p->W * p->H * p->NI, hipHostMallocDefault));
       for (int set = 0; set < 2; ++set) HIP_TRY(hipHostMalloc(&L.pin_out[set], sizeof(float) * p->d2h_words, hipHostMallocDefault));
     }
@@ -273,11 +315,16 @@ void d2fe_pipe_destroy(d2fe_pipe p) {
     if (L.s) (void)hipStreamSynchronize(L.s);
     if (L.nv) { (void)hipStreamSynchronize(L.nv); (void)hipStreamDestroy(L.nv); }
     for (hipEvent_t e : {L.ev_up, L.ev_nv, L.ev_ext[0], L.ev_ext[1], L.ev_done}) if (e) (void)hipEventDestroy(e);
-    if (L.d_img) (void)hipFree(L.d_img);
     if (L.pin_in) (void)hipHostFree(L.pin_in);
     for (float* q : L.pin_out) if (q) (void)hipHostFree(q);
     if (L.ctx) d2fe_destroy(L.ctx);
   }
+  if (p->gnv) (void)hipStreamSynchronize(p->gnv);
+  for (auto e : p->ev_g) if (e) (void)hipEventDestroy(e);
+  if (p->gctx) d2fe_destroy(p->gctx);
+  if (p->d_gnv) (void)hipFree(p->d_gnv);
+  if (p->pin_gnv) (void)hipHostFree(p->pin_gnv);
+  if (p->d_img_all) (void)hipFree(p->d_img_all);
   if (p->d_pairs) (void)hipFree(p->d_pairs);
   if (p->d_match_scratch) (void)hipFree(p->d_match_scratch);
   if (p->d_all) (void)hipFree(p->d_all);
@@ -295,6 +342,14 @@ int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int
     // is (the invariant that makes the alternating output blocks sufficient, see the header)
     rc = lane_sync(p->lanes[(size_t)(p->next_pass % p->K)]);
     if (rc) return rc;
+    if (p->M > 1) {
+      // the NetVLAD call that read this lane's previous frame (K tickets ago; the other set) must be through with it before the H2D below
+      const int k = (int)(p->next_pass % p->K), pset = (int)(((p->next_pass / p->K) & 1) ^ 1), slot = pset * (p->K / p->M) + k / p->M;
+      if (t >= p->K) {
+        if (p->g_first <= t - p->K) { rc = pipe_flush_group(p, std::min<long long>(((t - p->K) / p->M + 1) * p->M, t)); if (rc) return rc; }
+        if (!p->g_synced[slot]) { HIP_TRY(hipEventSynchronize(p->ev_g[slot])); p->g_synced[slot] = 1; }
+      }
+    }
     ++p->next_pass;
   }
   const long long P = p->next_pass - 1;
@@ -327,7 +382,11 @@ int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int
   ++p->pend;
   p->next_ticket = t + 1;
   *ticket = t;
-  if (p->pend == p->C) return pipe_flush(p);
+  if (p->pend == p->C) {
+    rc = pipe_flush(p);
+    if (rc) return rc;
+    if (p->M > 1 && (t + 1) % p->M == 0) return pipe_flush_group(p, t + 1);      // the group is complete
+  }
   return D2FE_OK;
 }
 
@@ -346,15 +405,22 @@ int d2fe_pipe_wait(d2fe_pipe p, int64_t ticket, d2fe_pipe_result* out) {
   }
   const int k = (int)(ti.pass % p->K), set = (int)((ti.pass / p->K) & 1), j = ti.j;
   auto& L = p->lanes[k];
-  const int rc = lane_sync(L);
+  int rc = lane_sync(L);
   if (rc) return rc;
+  const float* gdesc = nullptr;
+  if (p->M > 1) {
+    if (p->g_first <= ticket) { rc = pipe_flush_group(p, std::min<long long>((ticket / p->M + 1) * p->M, p->next_ticket)); if (rc) return rc; }
+    const int slot = set * (p->K / p->M) + k / p->M;
+    if (!p->g_synced[slot]) { HIP_TRY(hipEventSynchronize(p->ev_g[slot])); p->g_synced[slot] = 1; }
+    gdesc = p->pin_gnv + ((size_t)set * p->K + k) * p->G;
+  }
   const float* B = L.pin_out[set];
   const size_t F = p->F, cap = p->cap;
   const size_t r0 = p->left_row(j, 0);          // C == 1: 0; C > 1: the submit's L, R rows are 2 j, 2 j + 1 -- the layout of a frames = 1 result
   out->frames = p->F; out->cap = p->cap; out->desc_dim = p->D; out->netvlad_dim = p->G;
   out->kps_xy = B + p->o_kps + r0 * cap * 2; out->scores = B + p->o_scores + r0 * cap; out->desc = B + p->o_desc + r0 * cap * p->D;
   out->n_kp = reinterpret_cast<const int32_t*>(B + p->o_cnt) + r0;
-  out->netvlad = p->G ? B + p->o_nv + (p->C > 1 ? (size_t)j : 0) * p->G : nullptr;
+  out->netvlad = gdesc ? gdesc : p->G ? B + p->o_nv + (p->C > 1 ? (size_t)j : 0) * p->G : nullptr;
   size_t pi = (size_t)j * p->npp;
   if (p->cfg.match_lr) {
     out->lr_q = reinterpret_cast<const int32_t*>(B + p->o_mq) + pi * cap; out->lr_t = reinterpret_cast<const int32_t*>(B + p->o_mt) + pi * cap;

@@ -263,7 +263,12 @@ typedef struct {
   int32_t lane_cus;         /* > 0: a lane's persistent kernels size their grids for this many compute units (no CU mask: they may run on any CU).  A
                                full-device persistent launch occupies every CU's LDS until it ends, so other lanes' small launches wait for it;
                                with e.g. 128 of 256, two lanes run side by side on every CU.  0: the whole device */
-  int32_t reserved[4];
+  int32_t netvlad_group;    /* > 1 (needs frames == 1, coalesce == 1, lanes % netvlad_group == 0): the NetVLAD descriptors of this many consecutive
+                               submits are computed by ONE call on the pipe's own stream when the last of them has been submitted (or when
+                               d2fe_pipe_wait asks for one of them), while SuperPoint and the matches of every submit start at once.  NetVLAD of a
+                               single image is ~20 launches of a few workgroups each (0.25 ms for one image, 0.28 ms for four); the descriptor feeds
+                               loop detection, not the tracker, so it can trail the keypoints.  Bit-identical results */
+  int32_t reserved[3];
 } d2fe_pipe_config;
 typedef struct {            /* HOST pointers into the lane's pinned block; valid until 2 * lanes further submits */
   int32_t frames, cap, desc_dim, netvlad_dim;

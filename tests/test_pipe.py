@@ -22,6 +22,41 @@ def _frames(n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lanes,group", [(2, 2), (4, 2), (4, 4), (6, 3)])
+def test_pipe_netvlad_group_equals_single_calls(lanes, group):
+    """netvlad_group: NetVLAD of `group` consecutive submits in one call on the pipe's own stream; same bits, whatever the order of the waits
+    (a wait for a ticket whose group is still filling launches the part that is there)."""
+    from d2slam_amd import api, netvlad as nvm
+    from d2slam_amd.weights import synthetic_superpoint_weights
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2, precision=api.PREC_F32_WINO, keypoint_threshold=0.005))
+    fe.load_superpoint(synthetic_superpoint_weights(dustbin_bias=7.5)); fe.load_netvlad(nvm.synthetic_netvlad_weights())
+    nsub = 3 * lanes + 1
+    fr = _frames(nsub)
+    ref = [fe.extract_all_batch(np.stack(f), 1, cap=CAP) for f in fr]
+    for order in ("lagged", "immediate"):
+        pipe = api.StereoPipe(fe, lanes=lanes, frames=1, width=W, height=H, cap=CAP, netvlad=True, netvlad_group=group)
+        got, tickets = {}, []
+        for i in range(nsub):
+            tickets.append(pipe.submit(fr[i][0][None], fr[i][1][None]))
+            if order == "immediate":
+                got[i] = {k: (None if v is None else v.copy()) for k, v in pipe.wait(tickets[i]).items()}
+            elif i >= lanes - 1:
+                j = i - (lanes - 1)
+                got[j] = {k: (None if v is None else v.copy()) for k, v in pipe.wait(tickets[j]).items()}
+        for j in range(nsub):
+            if j not in got:
+                got[j] = {k: (None if v is None else v.copy()) for k, v in pipe.wait(tickets[j]).items()}
+        for i in range(nsub):
+            ext, g = ref[i]
+            np.testing.assert_array_equal(got[i]["netvlad"], g)
+            for im in range(2):
+                n = int(got[i]["n_kp"][im]); assert n == len(ext[im][0])
+                np.testing.assert_array_equal(got[i]["desc"][im, :n], ext[im][2])
+        pipe.close()
+    fe.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("lanes,frames,netvlad,part,coal", [(1, 1, True, False, 1), (3, 1, True, False, 1), (2, 2, True, False, 1), (4, 1, False, False, 1),
                                                            (2, 3, True, False, 1), (4, 1, True, True, 1), (3, 2, True, True, 1), (8, 1, True, True, 1),
                                                            (2, 1, True, False, 2), (3, 1, True, False, 3), (1, 1, False, False, 4), (2, 1, True, True, 2)])
