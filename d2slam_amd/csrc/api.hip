@@ -203,10 +203,10 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     HIP_TRY(hipMemsetAsync(wctr ? h->work_ctrs : h->cand_count, 0, ((wctr ? 64 : 0) + (tail_elsewhere ? 0 : n)) * sizeof(int), s));
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8;
   auto conv = [&](ConvShape shape, const Layer& L, const float* in, int ics, int ico, long iis, float* out, int ocs,
-                  long ois, int hh, int ww, bool pool, bool relu) -> hipError_t {
+                  long ois, int hh, int ww, bool pool, bool relu, int oco = 0, bool direct = false) -> hipError_t {
     ConvArgs a;
     a.in = in; a.in_cstride = ics; a.in_coff = ico;
-    a.out = out; a.out_cstride = ocs; a.out_coff = 0;
+    a.out = out; a.out_cstride = ocs; a.out_coff = oco;
     a.cout_real = L.cout; a.wpack = L.wpack; a.bias = L.bias;
     a.img = d_gray; a.img_stride = stride; a.img_istride = (long)image_stride; a.w1a = h->w1a; a.b1a = h->b1a;
     a.H = hh; a.W = ww; a.n_img = n; a.in_img_stride = iis; a.out_img_stride = ois; a.zeros = h->zeros; a.ncu = h->ncu;
@@ -217,9 +217,9 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
       static const int on = d2fe_dev_env("D2FE_CONV1X1", 1);
       if (on) { const hipError_t e = launch_conv1x1_256_65(a, s); if (e != hipErrorNotSupported) return e; }
     }
-    if (prec == D2FE_PREC_F32_WINO)   // 3x3 layers: Winograd kernels; the 1x1 heads: the exact fp32 kernels
+    if (prec == D2FE_PREC_F32_WINO)   // 3x3 layers: Winograd kernels; the 1x1 heads (and `direct`: convDa of the dense head): the exact fp32 kernels
       return shape == CONV1B_FUSED ? launch_conv_wino_fused1b(L.cout_pad, a, s)
-             : L.ks == 3 ? launch_conv_wino(L.cin, pool, relu, L.cout_pad, a, s) : launch_conv(shape, D2FE_PREC_F32, pool, relu, L.cout_pad, a, s);
+             : (L.ks == 3 && !direct) ? launch_conv_wino(L.cin, pool, relu, L.cout_pad, a, s) : launch_conv(shape, D2FE_PREC_F32, pool, relu, L.cout_pad, a, s);
     return launch_conv(shape, prec, pool, relu, L.cout_pad, a, s);
   };
   if (h->fuse1a) {
@@ -244,6 +244,14 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     { ProfScope ps(h, D2FE_PROF_CONVPADA, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_PA], a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, true)); }
     { ProfScope ps(h, D2FE_PROF_CONVPB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_PB], h->aPD.p, 256, 0, (long)Hc * Wc * 256, logits.p, 65, (long)Hc * Wc * 65, Hc, Wc, false, false)); }
   } else {
+    if (prec == D2FE_PREC_F32_WINO && h->sparse_desc) {
+      // Winograd mode, dense head (calls with fewer images than the sparse head pays for): the detector branch convPa as a Winograd layer, the
+      // descriptor branch convDa as DIRECT fp32 chains -- the arithmetic of the sparse head -- so that a frame's descriptors are the same bits
+      // whichever head a call takes (1-image call, 64-image batch, any pass of the frames-in-flight pipe)
+      ProfScope ps(h, D2FE_PROF_CONVPADA, s);
+      HIP_TRY(conv(CONV_128_T4x16, h->L[L_PA], a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 512, (long)Hc * Wc * 512, Hc, Wc, false, true));
+      HIP_TRY(conv(CONV_128_T4x16, h->L[L_DA32], a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 512, (long)Hc * Wc * 512, Hc, Wc, false, true, 256, true));
+    } else
     { ProfScope ps(h, D2FE_PROF_CONVPADA, s); HIP_TRY(conv(CONV_128_T4x16, h->L[L_PADA], a4b.p, 128, 0, (long)Hc * Wc * 128, h->aPD.p, 512, (long)Hc * Wc * 512, Hc, Wc, false, true)); }
     { ProfScope ps(h, D2FE_PROF_CONVPB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_PB], h->aPD.p, 512, 0, (long)Hc * Wc * 512, logits.p, 65, (long)Hc * Wc * 65, Hc, Wc, false, false)); }
     { ProfScope ps(h, D2FE_PROF_CONVDB, s); HIP_TRY(conv(CONV_256_1x1_T4x16, h->L[L_DB], h->aPD.p, 512, 256, (long)Hc * Wc * 512, draw.p, 256, (long)Hc * Wc * 256, Hc, Wc, false, false)); }
@@ -399,10 +407,9 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
       if (alloc_f(h->a4b2, H * W * 2, B) || alloc_f(h->logits2, (H / 8) * (W / 8) * 65, B) || alloc_f(h->draw2, H * W * 4, B)) return D2FE_ERR_HIP;
     }
     h->sparse_desc = !cfg->dense_descriptors;
-    // Winograd mode: the dense head would evaluate convDa as a Winograd layer and the sparse head as direct fp32 chains (bits apart by ~1e-7), so the
-    // head must not depend on the number of images in a call: always sparse there (a frame's descriptors are then the same bits in a 1-image call,
-    // in a 64-image batch and in any pass of the frames-in-flight pipe).  The direct modes give identical bits either way; dense is ~2 % quicker below 4 images
-    if (cfg->precision == D2FE_PREC_F32_WINO) h->sp_min_batch = 1;
+    // Winograd mode: both heads evaluate the descriptor branch as direct fp32 chains (run_superpoint), so the choice is free of consequences for the
+    // bits; measured per call (host to host, 640x480): 1 image 0.44 ms dense / 0.47 sparse, 2 images 0.69 dense / 0.67 sparse
+    if (cfg->precision == D2FE_PREC_F32_WINO) h->sp_min_batch = 2;
     h->sp_min_batch = d2fe_dev_env("D2FE_SPARSE_MIN_BATCH", h->sp_min_batch);
     if (h->sparse_desc) {
       const size_t ncell = (H / 8) * (W / 8);
