@@ -786,14 +786,21 @@ inline int same_out(int in, int stride) { return (in + stride - 1) / stride; }
 inline int same_pad_begin(int in, int stride, int out) { const int t = (out - 1) * stride + 3 - in; return t > 0 ? t / 2 : 0; }   // TF "SAME", 3x3
 
 // hidden-channel groups for a fused step: enough workgroups to fill the chip (2 per CU), at least 3 chunks of 16 per group (every
-// group stages the whole input patch again, and its consumer reads one more partial slab)
-inline void nv_groups(long base_blocks, int nchunk, int gmax, int* groups, int* cpg, int target, long cap = 0) {
+// group stages the whole input patch again, and its consumer reads one more partial slab).  Three or more groups (two, when the consumer reads a
+// single slab: `sum_at_2`) cost a slab-sum launch of ~6 us behind the block; a chunk costs ~2.3 us of a workgroup's latency (tools/nv_stamps.py):
+// the split goes past two groups only when the chunks it takes off every workgroup are worth more than that launch (30 x 40 layers: 9-12 chunks,
+// two groups; 15 x 20 layers: 60 chunks, seven)
+inline void nv_groups(long base_blocks, int nchunk, int gmax, int* groups, int* cpg, int target, long cap = 0, bool sum_at_2 = false, bool rule = true) {
   int g = (int)((target + base_blocks - 1) / base_blocks);
   if (cap > 0 && g > 1 && g * base_blocks > cap) --g;      // a second round of workgroups costs more than one more chunk per group
   if (g > gmax) g = gmax;
   if (g > nchunk / 3) g = nchunk / 3;
   if (g < 1) g = 1;
-  *cpg = (nchunk + g - 1) / g;
+  auto per = [&](int gg) { return (nchunk + gg - 1) / gg; };
+  const double chunk_us = 2.3, launch_us = 6.0;
+  if (rule && g >= 3 && (per(2) - per(g)) * chunk_us < launch_us) g = 2;
+  if (rule && g == 2 && sum_at_2 && (per(1) - per(2)) * chunk_us < launch_us) g = 1;
+  *cpg = per(g);
   *groups = (nchunk + *cpg - 1) / *cpg;
 }
 
@@ -853,7 +860,7 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
       h->nv_feat_slabs = groups; h->nv_feat_slab_stride = a.out_slab_stride;
       if (nv_tail_supported(a.Cin, a.Cout)) HIP_TRY(launch_nv_tail(a, groups, s));     // st.we was packed in that kernel's K order
       else HIP_TRY(launch_nv_block(a, true, 2, n, groups, s));
-      if (h->nv_slabsum > 0 && groups >= h->nv_slabsum) { HIP_TRY(launch_nv_slab_sum(h->nv_feat_buf, groups, a.out_slab_stride, a.out_slab_stride, s)); h->nv_feat_slabs = 1; }
+      // no slab sum here: the VLAD stage reads every feature exactly once and adds the slabs, in slab order, while it stages them
       feat_done = true;
       continue;
     }
@@ -878,7 +885,7 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     // in a 1-image call, a 32-image batch and any pass of the frames-in-flight pipe.  A batch then runs with more groups than it needs to fill
     // the device (15 x 20 layers at 32 images: 7 slabs instead of 4) -- a few MB of partial-slab traffic
     nv_groups(tiles1, a.Chid / 16, next_fused ? pj.gmax : 1, &groups, &cpg, h->nv_blocks_target,
-              st.pblock ? nv_pblock_slots(a.Cin, a.Cout, h->ncu_dev, 1) * 85 / 100 : 0);
+              st.pblock ? nv_pblock_slots(a.Cin, a.Cout, h->ncu_dev, 1) * 85 / 100 : 0, next_single, h->nv_group_rule);
     a.cpg = cpg; a.out = pj.out; a.out_slab_stride = (long)n * a.Ho * a.Wo * a.Cout;
     pj.slabs = groups; pj.slab_stride = a.out_slab_stride;
     a.ncu = h->ncu; a.tpw = h->nv_front_tpw; a.nbuf = h->nv_nbuf;
@@ -973,6 +980,7 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
     { const int v = d2fe_dev_env("D2FE_NV_BLOCKS", 0); if (v > 0) h->nv_blocks_target = v; }
     { const int v = d2fe_dev_env("D2FE_NV_TAIL_BLOCKS", 0); if (v > 0) h->nv_tail_blocks = v; }
     h->nv_slabsum = d2fe_dev_env("D2FE_NV_SLABSUM", h->nv_slabsum);
+    h->nv_group_rule = d2fe_dev_env("D2FE_NV_GROUP_RULE", 1) != 0;
     h->nv_front_tpw = d2fe_dev_env("D2FE_NV_FRONT_TPW", 0); h->nv_nbuf = d2fe_dev_env("D2FE_NV_NBUF", 0);
     h->nv_stamp_step = d2fe_dev_env("D2FE_NV_STAMP_STEP", -1);
     if (h->nv_stamp_step >= 0 && !h->nv_stamps) HIP_TRY(hipMalloc(&h->nv_stamps, sizeof(unsigned long long) * 32 * 32768));
@@ -1223,7 +1231,7 @@ int clone_lane(d2fe_context* p, int max_batch, d2fe_context** out, hipStream_t s
     c->nv = p->nv;
     for (auto& l : c->nv) { l.out = nullptr; l.slabs = 1; l.slab_stride = 0; }
     c->nv_plan = p->nv_plan;
-    c->nv_feat_gmax = p->nv_feat_gmax; c->nv_blocks_target = p->nv_blocks_target; c->nv_tail_blocks = p->nv_tail_blocks; c->nv_slabsum = p->nv_slabsum;
+    c->nv_feat_gmax = p->nv_feat_gmax; c->nv_blocks_target = p->nv_blocks_target; c->nv_tail_blocks = p->nv_tail_blocks; c->nv_slabsum = p->nv_slabsum; c->nv_group_rule = p->nv_group_rule;
     c->nv_front_tpw = p->nv_front_tpw; c->nv_nbuf = p->nv_nbuf;
     c->nv_feat = p->nv_feat; c->nv_proj = p->nv_proj; c->nv_k = p->nv_k;
     c->nv_pre_w = p->nv_pre_w; c->nv_pre_b = p->nv_pre_b; c->nv_aw = p->nv_aw; c->nv_aw_pack = p->nv_aw_pack; c->nv_ab = p->nv_ab; c->nv_cen = p->nv_cen;

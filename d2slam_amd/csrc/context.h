@@ -111,12 +111,14 @@ struct d2fe_context {
   // and the number of partial slabs from which they are summed once instead of by every consumer (D2FE_NV_SLABSUM, 0 = never)
   int nv_front_tpw = 0, nv_nbuf = 0;       // D2FE_NV_FRONT_TPW, D2FE_NV_NBUF (0: the launchers decide)
   int nv_stamp_step = -1; unsigned long long* nv_stamps = nullptr; int nv_stamp_wgs = 0;     // D2FE_NV_STAMP_STEP (diagnostics)
-  int nv_blocks_target = 512, nv_tail_blocks = 768, nv_slabsum = 3;      // the pre-projected features (input of the VLAD stage), same slab scheme
+  int nv_blocks_target = 512, nv_tail_blocks = 30, nv_slabsum = 3;      // workgroups per IMAGE the hidden-channel split aims at (blocks; tail: 3 pixel tiles x 10 groups at 15 x 20)
+       // the pre-projected features (input of the VLAD stage), same slab scheme
   std::vector<NvStep> nv_plan;
   bool nv_loaded = false;
   int nv_feat = 0, nv_proj = 0, nv_k = 0;
   float *nv_pre_w = nullptr, *nv_pre_b = nullptr, *nv_aw = nullptr, *nv_aw_pack = nullptr, *nv_ab = nullptr, *nv_cen = nullptr;
   float *nv_feat_buf = nullptr, *nv_raw = nullptr, *nv_pca_out = nullptr, *nv_part = nullptr;
+  bool nv_group_rule = true;       // nv_groups(): no split past two groups when the slab-sum launch costs more than the chunks it saves (D2FE_NV_GROUP_RULE=0, development library: off)
   float *nv_pca_comp = nullptr, *nv_pca_mean = nullptr; int nv_pca_m = 0;
   uint8_t* nv_s_img = nullptr; float* nv_s_out = nullptr;
   bool fuse1a = true;      // conv1a fused into conv1b's staging (D2FE_FUSE1A=0 keeps the stand-alone conv1a kernel)

@@ -218,9 +218,12 @@ __global__ __launch_bounds__(256) void nv_vlad_partial_kernel(const float* __res
   }
 }
 
+// Every sum below has a fixed order (no float atomics): the descriptor is reproducible run to run for any K x D, as it is for the 32 x 128 head.
 __global__ __launch_bounds__(1024) void nv_vlad_final_kernel(const float* __restrict__ part, int nchunk, int D, int K,
                                                              float* __restrict__ out) {
-  __shared__ float red[130];
+  __shared__ float sq[8192];         // v^2 per element, then reused for nothing else (K * D <= 8192)
+  __shared__ float nk[64];           // squared norm per cluster
+  __shared__ float red2[16];
   const int img = blockIdx.x, tid = threadIdx.x;
   const int KD = K * D;
   float v[8];
@@ -228,16 +231,20 @@ __global__ __launch_bounds__(1024) void nv_vlad_final_kernel(const float* __rest
   for (int r = 0; r < 8; ++r) {
     const int e = tid + 1024 * r;
     float s = 0.f;
-    if (e < KD)
+    if (e < KD) {
       for (int c = 0; c < nchunk; ++c) s += part[((size_t)img * nchunk + c) * KD + e];
+      sq[e] = s * s;
+    }
     v[r] = s;
   }
-  for (int i = tid; i < 130; i += 1024) red[i] = 0.f;
   __syncthreads();
+  // one 16-lane group per cluster: lane j sums channels j, j + 16, .. in order, then a fixed butterfly over the 16 lanes
+  for (int k = tid >> 4; k < K; k += 64) {
+    float s = 0.f;
+    for (int j = tid & 15; j < D; j += 16) s += sq[k * D + j];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int e = tid + 1024 * r;
-    if (e < KD) atomicAdd(&red[e / D], v[r] * v[r]);
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+    if ((tid & 15) == 0) nk[k] = s;
   }
   __syncthreads();
   float tot = 0.f;
@@ -245,16 +252,19 @@ __global__ __launch_bounds__(1024) void nv_vlad_final_kernel(const float* __rest
   for (int r = 0; r < 8; ++r) {
     const int e = tid + 1024 * r;
     if (e < KD) {
-      const float n = __builtin_sqrtf(red[e / D]);
+      const float n = __builtin_sqrtf(nk[e / D]);
       v[r] = v[r] / (n > 1e-12f ? n : 1e-12f);
       tot += v[r] * v[r];
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-  if ((tid & 63) == 0) atomicAdd(&red[128], tot);
+  if ((tid & 63) == 0) red2[tid >> 6] = tot;
   __syncthreads();
-  const float nt = __builtin_sqrtf(red[128]);
+  float gsum = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) gsum += red2[w];
+  const float nt = __builtin_sqrtf(gsum);
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int e = tid + 1024 * r;
@@ -280,16 +290,45 @@ __global__ __launch_bounds__(256) void nv_vlad_mfma_kernel(const float* __restri
   const int p0 = chunk * 64;
   const int pn = (np - p0) < 64 ? (np - p0) : 64;
   const float* xi = x + ((size_t)img * np + p0) * 128;
-  for (int i = tid; i < 64 * 32; i += 256) {
-    const int p = i >> 5, j4 = i & 31;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (p < pn) {
-      const float* s0 = xi + (size_t)p * 128 + j4 * 4;
-      v = *reinterpret_cast<const f32x4*>(s0);
-      for (int sl = 1; sl < slabs; ++sl) v += *reinterpret_cast<const f32x4*>(s0 + (size_t)sl * slab_stride);
+  {
+    // x = the sum of the tail kernel's partial slabs, in slab order.  Thread (p8, j4) owns the float4 j4 of pixels p8, p8 + 8, ..: the eight loads of a slab
+    // (of two slabs) are issued as one batch -- a run-time loop over the slabs around EACH load would cost one memory round trip per slab and element
+    const int p8 = tid >> 5, j4 = tid & 31;
+    f32x4 v[8];
+    unsigned off[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int p = p8 + 8 * it;
+      off[it] = (unsigned)((p < pn ? p : 0) * 128 + j4 * 4);
+      v[it] = *reinterpret_cast<const f32x4*>(xi + off[it]);
     }
-    float* d = Xr + p * VM_DP + j4 * 4;
-    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    int sl = 1;
+    for (; sl + 1 < slabs; sl += 2) {
+      const float* xa = xi + (size_t)sl * slab_stride;
+      const float* xb = xa + slab_stride;
+      f32x4 a[8], b[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) a[it] = *reinterpret_cast<const f32x4*>(xa + off[it]);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) b[it] = *reinterpret_cast<const f32x4*>(xb + off[it]);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) { v[it] += a[it]; v[it] += b[it]; }
+    }
+    if (sl < slabs) {
+      const float* xa = xi + (size_t)sl * slab_stride;
+      f32x4 a[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) a[it] = *reinterpret_cast<const f32x4*>(xa + off[it]);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) v[it] += a[it];
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int p = p8 + 8 * it;
+      float* d = Xr + p * VM_DP + j4 * 4;
+      const bool ok = p < pn;
+      d[0] = ok ? v[it][0] : 0.f; d[1] = ok ? v[it][1] : 0.f; d[2] = ok ? v[it][2] : 0.f; d[3] = ok ? v[it][3] : 0.f;
+    }
   }
   for (int i = tid; i < 64 * 17; i += 256) { const int p = i / 17, c = i - p * 17; Xr[p * VM_DP + 128 + c] = (c == 0 && p < pn) ? 1.f : 0.f; }
   __syncthreads();
@@ -343,6 +382,7 @@ __global__ __launch_bounds__(1024) void nv_vlad_final_mfma_kernel(const float* _
   __shared__ float red[34];
   __shared__ float red2[16];
   __shared__ float S[32];
+  __shared__ float half[64];         // per 64 consecutive elements (one wave, half a cluster): sum of squares
   const int img = blockIdx.x, tid = threadIdx.x;
   const float* pp = part + (size_t)img * nchunk * 32 * VM_PP;
   if (tid < 32) {
@@ -350,7 +390,6 @@ __global__ __launch_bounds__(1024) void nv_vlad_final_mfma_kernel(const float* _
     for (int c = 0; c < nchunk; ++c) s += pp[((size_t)c * 32 + tid) * VM_PP + 128];
     S[tid] = s;
   }
-  for (int i = tid; i < 34; i += 1024) red[i] = 0.f;
   __syncthreads();
   float v[4];
 #pragma unroll
@@ -359,11 +398,13 @@ __global__ __launch_bounds__(1024) void nv_vlad_final_mfma_kernel(const float* _
     float s = 0.f;
     for (int c = 0; c < nchunk; ++c) s += pp[((size_t)c * 32 + k) * VM_PP + d];
     v[r] = cen[e] * S[k] - s;
-    float q = v[r] * v[r];           // the 128 channels of cluster k are 2 waves' worth of lanes: reduce per wave, then one atomic
+    float q = v[r] * v[r];           // the 128 channels of cluster k are 2 waves' worth of lanes: reduce per wave, the two halves added in wave order
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-    if ((tid & 63) == 0) atomicAdd(&red[k], q);
+    if ((tid & 63) == 0) half[e >> 6] = q;
   }
+  __syncthreads();
+  if (tid < 32) red[tid] = half[2 * tid] + half[2 * tid + 1];
   __syncthreads();
   float tot = 0.f;
 #pragma unroll

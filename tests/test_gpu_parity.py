@@ -500,6 +500,36 @@ def test_netvlad_vs_oracle(api, orc, H, W):
     fe.close()
 
 
+@pytest.mark.parametrize("K,D", [(16, 64), (24, 96), (64, 128)])
+def test_netvlad_general_head_is_reproducible(api, orc, K, D):
+    """Heads other than 32 x 128 take nv_vlad_partial_kernel / nv_vlad_final_kernel (netvlad.hip): against the oracle, and every sum in a fixed order --
+    the same bits run to run, alone and in a batch (the final kernel used to sum with multi-addend LDS float atomics)."""
+    from d2slam_amd import netvlad as nvm
+    H, W = 240, 320
+    nv = nvm.synthetic_netvlad_weights()
+    rng = np.random.RandomState(K * 1000 + D)
+    hd = dict(nv["head"])
+    feat = hd["pre_w"].shape[1]
+    bound = np.sqrt(3.0 / feat)
+    hd["pre_w"] = rng.uniform(-bound, bound, size=(D, feat)).astype(np.float32); hd["pre_b"] = rng.uniform(-0.05, 0.05, size=(D,)).astype(np.float32)
+    hd["assign_w"] = rng.normal(0, 1.0 / np.sqrt(D), size=(K, D)).astype(np.float32); hd["assign_b"] = rng.uniform(-0.1, 0.1, size=(K,)).astype(np.float32)
+    hd["centroids"] = rng.normal(0, 0.3, size=(K, D)).astype(np.float32)
+    nv = dict(nv); nv["head"] = hd
+    imgs = np.stack([synth_image(H, W, 11 + s) for s in range(3)])
+    fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=3))
+    fe.load_netvlad(nv)
+    assert fe.netvlad_dim == K * D
+    got = fe.netvlad(imgs)
+    for i in range(3):
+        ref = orc.netvlad_forward(imgs[i], nv)
+        assert np.abs(got[i] - ref).max() <= 1e-4, np.abs(got[i] - ref).max()
+    for _ in range(5):
+        np.testing.assert_array_equal(fe.netvlad(imgs), got)
+    for i in range(3):
+        np.testing.assert_array_equal(fe.netvlad(imgs[i:i + 1])[0], got[i])
+    fe.close()
+
+
 @pytest.mark.parametrize("H,W", [(96, 128), (120, 200), (480, 640)])
 def test_netvlad_fused_blocks_layerwise(api, orc, H, W):
     """Every tensor the fused MobileNetV2 block kernels (netvlad_fused.hip) write to HBM -- the last layer of each block -- against
