@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="submits in flight of the frames-in-flight pipe (0: LANES_FOR[frames])")
     ap.add_argument("--no-batch-curve", action="store_true", help="skip the batch curve (stereo fps at 1, 2, 4, 8, 16, 32 stereo frames per submit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic (HBM bytes per conv1b launch)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-netvlad", action="store_true", help="time BASELINE configs[1] (SuperPoint + match only) as `value`")
     ap.add_argument("--no-h2d", action="store_true", help="frames resident in HBM before the timed region (no copy stream)")
@@ -360,7 +361,7 @@ def main():
         if netvlad and nv_n:
             t = nv_ms / nv_n
             ach = NV_FLOP_PER_IMG * F / (t * 1e-3) / 1e12
-            roofline_nv = {"kernel": "NetVLAD sequence (27 launches: nv_fpair_kernel, nv_pblock_kernel x12 (stride 1), nv_xblock_kernel x4 (stride 2), nv_slab_sum_kernel x6, nv_tail_kernel, nv_vlad_* x2 + memset): MobileNetV2-0.35 trunk + NetVLAD head",
+            roofline_nv = {"kernel": "NetVLAD sequence (27 launches: nv_fpair_kernel, nv_pblock_kernel x12 (stride 1), nv_xblock_kernel x4 (stride 2), nv_slab_sum_kernel x7, nv_tail_kernel, nv_vlad_* x2): MobileNetV2-0.35 trunk + NetVLAD head",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
                            "ms_per_call": round(t, 4), "images_per_call": F, "algorithmic_flop_per_call": NV_FLOP_PER_IMG * F,
                            "note": "fp32 MFMA (v_mfma_f32_16x16x4_f32) + VALU depthwise; instruction/latency-bound small layers (DESIGN.md section 4); "
@@ -501,6 +502,10 @@ def main():
                                    "%d x 1, %.1f stereo fps): the launch has the device to itself" % (solo["steps"], solo["F"], solo["value"]),
                                    in_timed_region_of_value={"avg_launch_ms": shared["avg_launch_ms"], "launches": shared["launches"], "frac_executed": shared["frac_executed"],
                                                              "note": "with %d submits in flight the launch overlaps the other lanes' NetVLAD / post-processing / copy work" % primary["lanes"]})
+        if world == 1 and not args.single_mode and not args.no_live_traffic and args.precision == "wino" and args.frames == 32 and out["roofline"].get("kernel", "").startswith("conv_wino"):
+            live = live_traffic("conv_wino_kernel<64, true, true, 0, 1, true")
+            if live:
+                out["roofline"]["traffic"] = live["traffic"]; out["roofline"]["traffic_note"] = live["note"]; out["roofline"]["traffic_counters"] = live["counters"]
         if device_resident and device_resident.get("roofline_nv"):
             # NetVLAD by itself on the device (the device-API leg queues it in front of SuperPoint on one stream); in the pipe it runs on the lane's second
             # stream underneath SuperPoint's full-device launches, where its wall time is SuperPoint's
@@ -757,6 +762,45 @@ def profiled_traffic(kernel_tag):
     if fetch is None or write is None:
         return None, None
     return int((2.0 * fetch + write) * 1024), "profiles/r04_wino_rocprofv3_summary.txt: 2 x FETCH_SIZE %.4g KiB + WRITE_SIZE %.4g KiB per dispatch (rocprofv3 --pmc passes of `python bench.py`, same build; not collected inside this run)" % (fetch, write)
+
+
+def live_traffic(kernel_tag):
+    """roofline.traffic measured by THIS run: two child passes of this script under `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE, then WRITE_SIZE --
+    separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; KiB per dispatch; FETCH_SIZE doubled for gfx950's wide reads), the headline step with ONE
+    submit in flight and nothing else (--single-mode), averaged over the dispatches of the dominant kernel.  None when rocprofv3 is not there or a pass fails
+    (the committed profile is then quoted, see profiled_traffic)."""
+    import csv, glob, shutil, subprocess, tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp) or os.environ.get("D2FE_BENCH_CHILD"):
+        return None
+    vals, t0 = {}, time.time()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="d2fe_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, D2FE_BENCH_CHILD="1", TMPDIR="/tmp")
+            cmd = [rp, "--output-format", "csv", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--steps", "3", "--warmup", "1", "--precision", "wino", "--single-mode", "--no-cpu-baseline", "--lanes", "1"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not fs:
+                return None
+            acc = n = 0
+            for row in csv.DictReader(open(fs[0])):
+                if kernel_tag in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                    acc += float(row["Counter_Value"]); n += 1
+            if not n:
+                return None
+            vals[ctr] = (acc / n, n)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch, write = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+    return {"traffic": int((2.0 * fetch + write) * 1024),
+            "counters": {"FETCH_SIZE_KiB_per_dispatch": round(fetch, 1), "WRITE_SIZE_KiB_per_dispatch": round(write, 1), "dispatches_averaged": [vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]],
+                         "seconds": round(time.time() - t0, 1)},
+            "note": "measured by this run: two child passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --single-mode --lanes 1 --steps 3` (same build, same "
+                    "step, one submit in flight); traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB per dispatch of the dominant kernel (the doubling: gfx950's 128-byte reads, MI355X_MICROARCH.md)"}
 
 
 def conv1b_roofline(precision, avg_ms, launches, NI, fused):

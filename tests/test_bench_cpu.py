@@ -44,3 +44,33 @@ def test_roofline_arithmetic_and_profiled_traffic():
         assert 1.0 < r["traffic"] / r["compulsory_bytes_per_launch"] < 1.3 and "FETCH_SIZE" in r["traffic_note"]
     e = bench.conv1b_roofline("f32", 10.6, 20, 64, True)
     assert abs(e["frac"] - e["algorithmic_flop_per_launch"] / 10.6e-3 / 1e12 / 157.3) < 1e-3
+
+
+def test_live_traffic_parses_a_counter_pass_and_never_recurses(tmp_path, monkeypatch):
+    """bench.live_traffic(): the child passes never start passes of their own; a pass is averaged per dispatch of the named kernel and combined as
+    (2 x FETCH_SIZE + WRITE_SIZE) KiB; no rocprofv3 or a failed pass -> None (the committed profile is quoted instead)."""
+    import subprocess
+    monkeypatch.setenv("D2FE_BENCH_CHILD", "1")
+    assert bench.live_traffic("conv_wino_kernel") is None
+    monkeypatch.delenv("D2FE_BENCH_CHILD")
+    calls = []
+
+    def fake_run(cmd, cwd=None, env=None, capture_output=None, text=None, timeout=None):
+        ctr = cmd[cmd.index("--pmc") + 1]; d = cmd[cmd.index("-d") + 1]
+        assert env["D2FE_BENCH_CHILD"] == "1" and "--single-mode" in cmd and cmd[cmd.index("--lanes") + 1] == "1"
+        calls.append(ctr)
+        os.makedirs(os.path.join(d, "host", "1"), exist_ok=True)
+        with open(os.path.join(d, "host", "1", "p_counter_collection.csv"), "w") as f:
+            f.write("Kernel_Name,Counter_Name,Counter_Value\n")
+            for v in (100.0, 300.0):
+                f.write('"void d2fe::conv_wino_kernel<64, true, true, 0, 1, true, 2>(ConvArgs, int, int, int, int)",%s,%f\n' % (ctr, v if ctr == "FETCH_SIZE" else 10 * v))
+            f.write('"other_kernel",%s,5.0\n' % ctr)
+        return subprocess.CompletedProcess(cmd, 0, "", "")
+
+    monkeypatch.setattr(bench.shutil if hasattr(bench, "shutil") else __import__("shutil"), "which", lambda n: "/bin/true")
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    r = bench.live_traffic("conv_wino_kernel<64, true, true, 0, 1, true")
+    assert calls == ["FETCH_SIZE", "WRITE_SIZE"]
+    assert r["traffic"] == int((2 * 200.0 + 2000.0) * 1024) and r["counters"]["dispatches_averaged"] == [2, 2]
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: subprocess.CompletedProcess(a, 1, "", "boom"))
+    assert bench.live_traffic("conv_wino_kernel") is None
