@@ -413,6 +413,13 @@ def main():
                                             "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
                                             "note": "submit() stages the frame (its H2D starts at once); every %d-th submit launches ONE sequence over the staged frames, "
                                                     "4 such passes in flight; per-ticket results are bit-identical to the single calls (tests/test_pipe.py)" % cc})
+                    # dynamic batching (coalesce_depth = 2): a pass is launched as soon as fewer than two are in flight, so the SAME configuration serves a caller
+                    # that waits for every frame (1 in flight: launched at once) and one that keeps 16 in flight (passes grow to 4 frames)
+                    for infl in (1, 4, 16):
+                        r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, coalesce=4, depth=2, inflight=infl)
+                        batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": infl, "coalesce": 4, "coalesce_depth": 2, "stereo_fps": round(r["value"], 1),
+                                            "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
+                                            "note": "dynamic batching: up to 4 consecutive submits per pass, launched early whenever fewer than 2 passes are in flight"})
     else:
         primary = run_mode(args.precision, True, netvlad=use_nv)
         legs = {}
@@ -579,7 +586,7 @@ def pipe_frames(F, rank):
     return host
 
 
-def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup, local_rank, rank, netvlad=True, light=False, coalesce=1):
+def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup, local_rank, rank, netvlad=True, light=False, coalesce=1, depth=0, inflight=0):
     """`steps` submits of F stereo frames through the frames-in-flight pipe with `lanes` submits in flight: the timed region holds, per submit, the H2D of
     the 2F frames from pinned memory, SuperPoint on them, NetVLAD of the F left images, ONE matcher launch (L<->R, L<->previous L) and the D2H of every
     result into pinned memory.  Timing: barrier-free single process (N = 1), perf_counter around exactly `steps` submits + the waits for all of them."""
@@ -589,8 +596,8 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
     if netvlad:
         fe.load_netvlad(nv_weights)
     host = torch.from_numpy(pipe_frames(F, rank)).pin_memory()
-    pipe = api.StereoPipe(fe, lanes=lanes, frames=F, width=W, height=H, cap=CAP, netvlad=netvlad, ratio=0.8, pinned_input=True, coalesce=coalesce)
-    inflight = lanes * coalesce
+    pipe = api.StereoPipe(fe, lanes=lanes, frames=F, width=W, height=H, cap=CAP, netvlad=netvlad, ratio=0.8, pinned_input=True, coalesce=coalesce, coalesce_depth=depth)
+    inflight = inflight or lanes * coalesce
     base, per_set, per_side = host.data_ptr(), 2 * F * H * W, F * H * W
 
     def submit(i):

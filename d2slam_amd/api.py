@@ -77,7 +77,7 @@ class _MatchBatch(C.Structure):
 class _PipeConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("lanes", C.c_int32), ("frames", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
                 ("cap", C.c_int32), ("netvlad", C.c_int32), ("match_lr", C.c_int32), ("match_prev", C.c_int32), ("pinned_input", C.c_int32),
-                ("ratio", C.c_double), ("radius_lr", C.c_double), ("radius_prev", C.c_double), ("cu_partition", C.c_int32), ("netvlad_inline", C.c_int32), ("coalesce", C.c_int32), ("lane_cus", C.c_int32), ("netvlad_group", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("ratio", C.c_double), ("radius_lr", C.c_double), ("radius_prev", C.c_double), ("cu_partition", C.c_int32), ("netvlad_inline", C.c_int32), ("coalesce", C.c_int32), ("lane_cus", C.c_int32), ("netvlad_group", C.c_int32), ("coalesce_depth", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class _PipeResult(C.Structure):
@@ -693,7 +693,7 @@ class StereoPipe:
     submit() enqueues and returns a ticket; wait() returns views into the lane's pinned result block (copy what must outlive 2 * lanes submits)."""
 
     def __init__(self, fe: FrontEnd, lanes=4, frames=1, width=640, height=480, cap=None, netvlad=True, match_lr=True, match_prev=True,
-                 ratio=0.8, radius_lr=-1.0, radius_prev=-1.0, pinned_input=False, cu_partition=False, netvlad_inline=False, coalesce=1, lane_cus=0, netvlad_group=1):
+                 ratio=0.8, radius_lr=-1.0, radius_prev=-1.0, pinned_input=False, cu_partition=False, netvlad_inline=False, coalesce=1, lane_cus=0, netvlad_group=1, coalesce_depth=0):
         self._lib = fe._lib
         self._fe = fe           # the pipe borrows the handle's weights
         c = _PipeConfig()
@@ -702,7 +702,7 @@ class StereoPipe:
         c.cap = int(cap or fe.cfg.max_keypoints)
         c.netvlad, c.match_lr, c.match_prev, c.pinned_input = int(bool(netvlad)), int(bool(match_lr)), int(bool(match_prev)), int(bool(pinned_input))
         c.ratio, c.radius_lr, c.radius_prev = float(ratio), float(radius_lr), float(radius_prev)
-        c.cu_partition = int(bool(cu_partition)); c.netvlad_inline = int(bool(netvlad_inline)); c.coalesce = int(coalesce); c.lane_cus = int(lane_cus); c.netvlad_group = int(netvlad_group)
+        c.cu_partition = int(bool(cu_partition)); c.netvlad_inline = int(bool(netvlad_inline)); c.coalesce = int(coalesce); c.lane_cus = int(lane_cus); c.netvlad_group = int(netvlad_group); c.coalesce_depth = int(coalesce_depth)
         self._p = C.c_void_p()
         _check(self._lib.d2fe_pipe_create(fe.handle, C.byref(c), C.byref(self._p)))
         self.lanes, self.frames, self.width, self.height = int(lanes), int(frames), int(width), int(height)

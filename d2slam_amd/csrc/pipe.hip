@@ -61,7 +61,8 @@ struct d2fe_pipe_s {
   long long next_pass = 0;           // passes started so far
   int pend = 0;                      // submits of the newest pass that are staged but not launched yet (0: no pass open)
   int prev_g = 1;                    // submits of the last LAUNCHED pass
-  struct TInfo { long long pass = -1; int j = 0; };
+  struct TInfo { long long pass = -1; int j = 0; bool waited = true; };
+  long long oldest_unwaited = 0;     // every ticket below has been waited for (dynamic batching keeps the passes since then inside the result ring)
   std::vector<TInfo> tinfo;          // ring over tickets
   float* block(int lane, int set) const { return d_all + 64 + ((size_t)lane * 2 + set) * blk_words; }
   int left_row(int j, int f) const { return C > 1 ? 2 * j : f; }
@@ -179,6 +180,7 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
   if (cfg->lanes < 1 || cfg->lanes > 16 || cfg->frames < 1 || cfg->frames > 4096) return pipe_fail(D2FE_ERR_INVALID, "lanes must be 1..16, frames >= 1");
   const int C = cfg->coalesce > 0 ? cfg->coalesce : 1;
   if (C > 16 || (C > 1 && cfg->frames != 1)) return pipe_fail(D2FE_ERR_INVALID, "coalesce must be 1..16 and needs frames == 1");
+  if (cfg->coalesce_depth < 0 || cfg->coalesce_depth > cfg->lanes) return pipe_fail(D2FE_ERR_INVALID, "coalesce_depth must be 0..lanes");
   const int M = cfg->netvlad && cfg->netvlad_group > 1 ? cfg->netvlad_group : 1;
   if (M > 1 && (cfg->frames != 1 || C != 1 || cfg->lanes % M != 0)) return pipe_fail(D2FE_ERR_INVALID, "netvlad_group needs frames == 1, coalesce == 1 and lanes % netvlad_group == 0");
   if (cfg->cap < 1 || cfg->cap > 16384) return pipe_fail(D2FE_ERR_INVALID, "cap out of range");
@@ -378,11 +380,28 @@ int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int
     }
   }
   auto& ti = p->tinfo[(size_t)(t % (long long)p->tinfo.size())];
-  ti.pass = P; ti.j = j;
+  ti.pass = P; ti.j = j; ti.waited = false;
   ++p->pend;
   p->next_ticket = t + 1;
   *ticket = t;
-  if (p->pend == p->C) {
+  bool launch = p->pend == p->C;
+  if (!launch && p->cfg.coalesce_depth > 0) {
+    // dynamic batching: the device would run dry with fewer than `coalesce_depth` passes in flight -- launch what is staged; otherwise let the pass grow
+    int inflight = 0;
+    for (auto& Lq : p->lanes) {
+      if (Lq.done_synced) continue;
+      const hipError_t q = hipEventQuery(Lq.ev_done);
+      if (q == hipSuccess) Lq.done_synced = true;
+      else if (q == hipErrorNotReady) ++inflight;
+      else return ctx_fail(D2FE_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+    }
+    (void)hipGetLastError();        // hipErrorNotReady is sticky in hipGetLastError
+    // ... unless the tickets nobody has waited for yet already span `lanes` passes: small passes use up the ring of 2 * lanes result blocks as fast as
+    // full ones, so a caller with many frames outstanding gets full passes (which is what it wants anyway)
+    const long long p_old = p->tinfo[(size_t)(p->oldest_unwaited % (long long)p->tinfo.size())].pass;
+    launch = inflight < p->cfg.coalesce_depth && P - p_old < p->K;
+  }
+  if (launch) {
     rc = pipe_flush(p);
     if (rc) return rc;
     if (p->M > 1 && (t + 1) % p->M == 0) return pipe_flush_group(p, t + 1);      // the group is complete
@@ -407,6 +426,8 @@ int d2fe_pipe_wait(d2fe_pipe p, int64_t ticket, d2fe_pipe_result* out) {
   auto& L = p->lanes[k];
   int rc = lane_sync(L);
   if (rc) return rc;
+  p->tinfo[(size_t)(ticket % (long long)p->tinfo.size())].waited = true;
+  while (p->oldest_unwaited < p->next_ticket && p->tinfo[(size_t)(p->oldest_unwaited % (long long)p->tinfo.size())].waited) ++p->oldest_unwaited;
   const float* gdesc = nullptr;
   if (p->M > 1) {
     if (p->g_first <= ticket) { rc = pipe_flush_group(p, std::min<long long>((ticket / p->M + 1) * p->M, p->next_ticket)); if (rc) return rc; }

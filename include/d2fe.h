@@ -268,7 +268,12 @@ typedef struct {
                                d2fe_pipe_wait asks for one of them), while SuperPoint and the matches of every submit start at once.  NetVLAD of a
                                single image is ~20 launches of a few workgroups each (0.25 ms for one image, 0.28 ms for four); the descriptor feeds
                                loop detection, not the tracker, so it can trail the keypoints.  Bit-identical results */
-  int32_t reserved[3];
+  int32_t coalesce_depth;   /* with coalesce > 1.  0: a pass is launched when it is full (or when d2fe_pipe_wait asks).  N > 0: ALSO as soon as fewer than N
+                               passes are in flight on the device -- dynamic batching: a caller that waits for every frame before it submits the next
+                               gets every frame launched at once (the latency of coalesce = 1), a caller that keeps many frames in flight gets passes
+                               that grow up to `coalesce` frames while the device is busy with N others (the throughput of large passes).  2 is the
+                               measured choice: one pass running, one queued behind it */
+  int32_t reserved[2];
 } d2fe_pipe_config;
 typedef struct {            /* HOST pointers into the lane's pinned block; valid until 2 * lanes further submits */
   int32_t frames, cap, desc_dim, netvlad_dim;

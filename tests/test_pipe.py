@@ -57,10 +57,12 @@ def test_pipe_netvlad_group_equals_single_calls(lanes, group):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lanes,frames,netvlad,part,coal", [(1, 1, True, False, 1), (3, 1, True, False, 1), (2, 2, True, False, 1), (4, 1, False, False, 1),
-                                                           (2, 3, True, False, 1), (4, 1, True, True, 1), (3, 2, True, True, 1), (8, 1, True, True, 1),
-                                                           (2, 1, True, False, 2), (3, 1, True, False, 3), (1, 1, False, False, 4), (2, 1, True, True, 2)])
-def test_pipe_equals_single_calls(lanes, frames, netvlad, part, coal):
+@pytest.mark.parametrize("lanes,frames,netvlad,part,coal,depth", [(1, 1, True, False, 1, 0), (3, 1, True, False, 1, 0), (2, 2, True, False, 1, 0), (4, 1, False, False, 1, 0),
+                                                                 (2, 3, True, False, 1, 0), (4, 1, True, True, 1, 0), (3, 2, True, True, 1, 0), (8, 1, True, True, 1, 0),
+                                                                 (2, 1, True, False, 2, 0), (3, 1, True, False, 3, 0), (1, 1, False, False, 4, 0), (2, 1, True, True, 2, 0),
+                                                                 (4, 1, True, False, 4, 2), (2, 1, True, False, 3, 1), (3, 1, False, False, 4, 3), (4, 1, True, False, 8, 1)])
+def test_pipe_equals_single_calls(lanes, frames, netvlad, part, coal, depth):
+    """depth > 0: dynamic batching (d2fe_pipe_config.coalesce_depth) -- how many submits share a pass then depends on the device's progress; the results do not"""
     from d2slam_amd import api, netvlad as nvm
     from d2slam_amd.weights import synthetic_superpoint_weights
     fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2 * frames, precision=api.PREC_F32_WINO,
@@ -72,7 +74,7 @@ def test_pipe_equals_single_calls(lanes, frames, netvlad, part, coal):
     inflight = lanes * coal
     fr = _frames(nsub * frames)
     radius_lr, radius_prev = 0.2 * W, 0.05 * W
-    pipe = api.StereoPipe(fe, lanes=lanes, frames=frames, width=W, height=H, cap=CAP, netvlad=netvlad, ratio=0.8, radius_lr=radius_lr, radius_prev=radius_prev, cu_partition=part, coalesce=coal)
+    pipe = api.StereoPipe(fe, lanes=lanes, frames=frames, width=W, height=H, cap=CAP, netvlad=netvlad, ratio=0.8, radius_lr=radius_lr, radius_prev=radius_prev, cu_partition=part, coalesce=coal, coalesce_depth=depth)
     got = []
     tickets = []
     for sidx in range(nsub):

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--dev", action="store_true", help="the development library (honours the D2FE_* schedule switches)")
     ap.add_argument("--lane-cus", type=int, default=0, help="d2fe_pipe_config.lane_cus")
     ap.add_argument("--coalesce", type=int, default=1, help="d2fe_pipe_config.coalesce (frames per submit must be 1)")
+    ap.add_argument("--coalesce-depth", type=int, default=0, help="d2fe_pipe_config.coalesce_depth (dynamic batching)")
+    ap.add_argument("--inflight", type=int, default=0, help="submits the caller keeps in flight (default: lanes x coalesce)")
     ap.add_argument("--nv-inline", action="store_true", help="d2fe_pipe_config.netvlad_inline")
     ap.add_argument("--partition", action="store_true", help="d2fe_pipe_config.cu_partition: disjoint compute units per lane")
     args = ap.parse_args()
@@ -43,12 +45,12 @@ def main():
                 l, r = scenes[(s * F + f) % len(scenes)]
                 sh = (s % 3, (2 * s) % 5)
                 hn[s, 0, f] = np.roll(l, sh, (0, 1)); hn[s, 1, f] = np.roll(r, sh, (0, 1))
-        pipe = api.StereoPipe(fe, lanes=K, frames=F, width=W, height=H, cap=CAP, netvlad=not args.no_netvlad, match_lr=not args.no_match, match_prev=not args.no_match, pinned_input=True, cu_partition=args.partition, netvlad_inline=args.nv_inline, coalesce=args.coalesce, lane_cus=args.lane_cus, netvlad_group=args.nv_group)
+        pipe = api.StereoPipe(fe, lanes=K, frames=F, width=W, height=H, cap=CAP, netvlad=not args.no_netvlad, match_lr=not args.no_match, match_prev=not args.no_match, pinned_input=True, cu_partition=args.partition, netvlad_inline=args.nv_inline, coalesce=args.coalesce, lane_cus=args.lane_cus, netvlad_group=args.nv_group, coalesce_depth=args.coalesce_depth)
         base = host.data_ptr(); per = 2 * F * H * W
         def submit(i):
             s = i % NS
             return pipe.submit_ptr(base + s * per, base + s * per + F * H * W)
-        KC = K * args.coalesce          # submits in flight = lanes x submits per pass
+        KC = args.inflight or K * args.coalesce          # submits in flight = lanes x submits per pass
         tickets = [submit(i) for i in range(KC)]
         for i in range(KC, 3 * KC + 2):
             pipe.wait_raw(tickets[i - KC]); tickets.append(submit(i))
@@ -66,7 +68,7 @@ def main():
             r = pipe.wait_raw(t)
         dt = time.perf_counter() - t0
         o = pipe.wait(tickets[-1])
-        rec = {"nv_group": args.nv_group, "lane_cus": args.lane_cus, "coalesce": args.coalesce, "cu_partition": bool(args.partition), "nv_inline": bool(args.nv_inline), "hwq": os.environ.get("GPU_MAX_HW_QUEUES"), "lanes": K, "frames_per_submit": F, "stereo_fps": round(steps * F / dt, 1), "ms_per_submit": round(dt / steps * 1e3, 4),
+        rec = {"coalesce_depth": args.coalesce_depth, "inflight": KC, "nv_group": args.nv_group, "lane_cus": args.lane_cus, "coalesce": args.coalesce, "cu_partition": bool(args.partition), "nv_inline": bool(args.nv_inline), "hwq": os.environ.get("GPU_MAX_HW_QUEUES"), "lanes": K, "frames_per_submit": F, "stereo_fps": round(steps * F / dt, 1), "ms_per_submit": round(dt / steps * 1e3, 4),
                "host_submit_ms": round(th / steps * 1e3, 4), "avg_kp": float(o["n_kp"].mean()), "avg_lr": float(o["lr_n"].mean()) if o["lr_n"] is not None else None}
         print(json.dumps(rec), flush=True)
         res.append(rec)
