@@ -561,7 +561,9 @@ def main():
                 return {"ms_per_launch": ms, "algorithmic_bytes": int(nbytes), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
                         "frac_of_hbm_8000GBps": round(nbytes / (ms * 1e-3) / 8.0e12, 4)} if ms else None
             out["hbm_kernels"] = {
-                "softmax_cand_kernel": _gbps(65 * (H // 8) * (W // 8) * 4 * NI, b.get("softmax_cand")),
+                "softmax_cand_kernel": dict(_gbps(65 * (H // 8) * (W // 8) * 4 * NI, b.get("softmax_cand")) or {},
+                                            note="bound by VALU issue, not HBM: 65 correctly rounded exponentials + divisions per cell (bitwise scores) are ~1030 VALU instructions per "
+                                                 "wave, 2.0e7 per 64 images (SQ_INSTS_VALU, profiles/r04_wino_rocprofv3_summary.txt) = 32 us at the chip's full issue rate"),
                 "sample_b_kernel": _gbps(n_kp * NI * (4 * 1024 + 1024), b.get("sample")),
                 "match_kernel": dict(_gbps(2 * CAP * 256 * 4 * NP, b.get("match")) or {}, pairs_per_launch=NP,
                                      mfma_tflops=round(2 * 2.0 * CAP * CAP * 256 * NP / (b.get("match") * 1e-3) / 1e12, 2) if b.get("match") else None,

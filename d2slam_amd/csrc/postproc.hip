@@ -44,6 +44,9 @@ __device__ __forceinline__ float d2fe_expf(float x) {
 // keys (score_bits << 32) | (0xFFFFFFFF - raster_idx): descending key order == descending score, ties by ascending
 // raster index (the oracle's tie-break).  The list order is irrelevant (keys are unique, select_b sorts).
 // -----------------------------------------------------------------------------------------------------
+// Bound by VALU issue, not by HBM (rocprofv3, 64 images: 2.0e7 wave-level VALU instructions -- 65 correctly rounded exponentials and divisions per cell, ~1030
+// per wave -- are 32 us of the launch's 54 at the chip's full issue rate; the 80 MB of logits would take 13 us at 6 TB/s).  The exponential and the division are
+// the oracle's (bitwise scores), so the instruction count is the arithmetic's.
 __global__ __launch_bounds__(256) void softmax_cand_kernel(const float* __restrict__ logits, int lstride, int Hc, int Wc,
                                                            float thr, int border, float* __restrict__ semi,
                                                            unsigned long long* __restrict__ cand,
@@ -491,110 +494,117 @@ struct SparseHeadArgs {
   float* out;                                            // [img][max_slots][256]
 };
 
+// MT: 32-cell row tiles per workgroup.  Every workgroup streams ALL of convDa's and convDb's weights (1.44 MB) from L2 once, whatever its number of cells:
+// at a batch the launch is L2-bandwidth-bound on them (64 images x 25 workgroups x 1.44 MB = 2.3 GB per step at MT = 1), so a batch runs 64 cells per
+// workgroup -- each weight fragment feeds two MFMAs.  A stereo pair (a few dozen workgroups on 256 CUs) is latency-bound instead and keeps MT = 1: half the
+// MFMAs per wave.  The fmaf chain of an output does not depend on MT: bit-identical either way.
+template <int MT>
 __global__ __launch_bounds__(512) void desc_head_sparse_kernel(SparseHeadArgs a) {
-  constexpr int CIN = 128, CPA = CIN + 1, CMID = 256, CPD = CMID + 1, G = 4;
-  __shared__ float A[32 * CPA];      // one tap of the 32 cells' inputs
-  __shared__ float D[32 * CPD];      // ReLU(convDa) of the 32 cells = convDb's input
-  __shared__ int s_cell[32];
+  constexpr int CIN = 128, CPA = CIN + 1, CMID = 256, CPD = CMID + 1, G = 4, M = 32 * MT;
+  // A: one tap of the M cells' inputs [M][CPA]; D: ReLU(convDa) of the M cells = convDb's input [M][CPD] -- D overlays A (A is dead once the last tap is through)
+  extern __shared__ __attribute__((aligned(16))) float sparse_lds[];       // [M * CPD] floats + [M] cell indices (MT = 2: 66 KB, dynamic)
+  float* A = sparse_lds;
+  float* D = sparse_lds;
+  int* s_cell = reinterpret_cast<int*>(sparse_lds + M * CPD);
   const int img = blockIdx.y, mt = blockIdx.x;
   const int n = a.count[img];
-  if (mt * 32 >= n) return;
+  if (mt * M >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < 32) s_cell[tid] = mt * 32 + tid < n ? a.cells[(size_t)img * a.max_slots + mt * 32 + tid] : -1;
+  if (tid < M) s_cell[tid] = mt * M + tid < n ? a.cells[(size_t)img * a.max_slots + mt * M + tid] : -1;
   __syncthreads();
   const float* x = a.x + (size_t)img * a.x_img_stride;
   const f32x4* wda = reinterpret_cast<const f32x4*>(a.w_da);
   const f32x4* wdb = reinterpret_cast<const f32x4*>(a.w_db);
-  constexpr int NTW = 1;                                  // n-tiles per wave: 8 waves x 32 channels (short per-wave chains: the
-                                                          // kernel is latency-bound when only a stereo pair is in flight)
-  const int nt0 = wave * NTW;
+  const int nt0 = wave;                                   // 8 waves x 32 channels
 
   // ---- convDa: acc = bias; for tap (ky,kx): for ci ascending: fmaf -- the dense kernels' chain
-  f32x16 acc[NTW];
+  f32x16 acc[MT];
+  {
+    const float b = a.b_da[nt0 * 32 + (lane & 31)];
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    const float b = a.b_da[(nt0 + t) * 32 + (lane & 31)];
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = b;
+      for (int r = 0; r < 16; ++r) acc[m][r] = b;
   }
   const int arow = (lane & 31) * CPA + (lane >> 5);
   for (int tap = 0; tap < 9; ++tap) {
     __syncthreads();                                      // previous tap's A tile fully consumed
-    for (int i = tid; i < 32 * (CIN / 4); i += 512) {
+    // gather: M cells x 32 float4, MT * 2 per thread, all loads issued before the first LDS store
+    f32x4 gv[2 * MT];
+#pragma unroll
+    for (int j = 0; j < 2 * MT; ++j) {
+      const int i = tid + 512 * j;
       const int row = i / (CIN / 4), c4 = i % (CIN / 4);
       const int cell = s_cell[row];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (cell >= 0) {
-        const int cy = cell / a.Wc + tap / 3 - 1, cx = cell % a.Wc + tap % 3 - 1;
-        if (cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc)
-          v = *reinterpret_cast<const f32x4*>(x + ((size_t)cy * a.Wc + cx) * a.x_cstride + c4 * 4);
-      }
+      const int cy = cell / a.Wc + tap / 3 - 1, cx = cell % a.Wc + tap % 3 - 1;
+      const bool ok = cell >= 0 && cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (ok ? ((size_t)cy * a.Wc + cx) * a.x_cstride + c4 * 4 : 0));
+      gv[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * MT; ++j) {
+      const int i = tid + 512 * j;
+      const int row = i / (CIN / 4), c4 = i % (CIN / 4);
       float* d = A + row * CPA + c4 * 4;
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+      d[0] = gv[j][0]; d[1] = gv[j][1]; d[2] = gv[j][2]; d[3] = gv[j][3];
     }
     __syncthreads();
 #pragma unroll 1
     for (int g = 0; g < (CIN / 8) / G; ++g) {
-      f32x4 bq[G][NTW];
+      f32x4 bq[G];
 #pragma unroll
-      for (int j = 0; j < G; ++j)
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) bq[j][t] = wda[((size_t)((nt0 + t) * 9 + tap) * (CIN / 8) + g * G + j) * 64 + lane];
+      for (int j = 0; j < G; ++j) bq[j] = wda[((size_t)(nt0 * 9 + tap) * (CIN / 8) + g * G + j) * 64 + lane];
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const float* ap = A + arow + (g * G + j) * 8;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float av = ap[2 * q];
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[j][t][q], acc[t], 0, 0, 0);
-        }
+          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[m * 32 * CPA + 2 * q], bq[j][q], acc[m], 0, 0, 0);
       }
     }
   }
+  __syncthreads();                                        // everybody is through with A: D overlays it
   // ReLU -> D tile.  C layout: col = lane & 31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (cell)
 #pragma unroll
-  for (int t = 0; t < NTW; ++t)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const float v = acc[t][r];
-      D[row * CPD + (nt0 + t) * 32 + (lane & 31)] = v > 0.f ? v : 0.f;
+      const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const float v = acc[m][r];
+      D[row * CPD + nt0 * 32 + (lane & 31)] = v > 0.f ? v : 0.f;
     }
   __syncthreads();
   // ---- convDb (1x1): acc = bias; ci ascending
+  {
+    const float b = a.b_db[nt0 * 32 + (lane & 31)];
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    const float b = a.b_db[(nt0 + t) * 32 + (lane & 31)];
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = b;
+      for (int r = 0; r < 16; ++r) acc[m][r] = b;
   }
   const int drow = (lane & 31) * CPD + (lane >> 5);
 #pragma unroll 1
   for (int g = 0; g < (CMID / 8) / G; ++g) {
-    f32x4 bq[G][NTW];
+    f32x4 bq[G];
 #pragma unroll
-    for (int j = 0; j < G; ++j)
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) bq[j][t] = wdb[((size_t)(nt0 + t) * (CMID / 8) + g * G + j) * 64 + lane];
+    for (int j = 0; j < G; ++j) bq[j] = wdb[((size_t)nt0 * (CMID / 8) + g * G + j) * 64 + lane];
 #pragma unroll
     for (int j = 0; j < G; ++j) {
       const float* ap = D + drow + (g * G + j) * 8;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float av = ap[2 * q];
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[j][t][q], acc[t], 0, 0, 0);
-      }
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[m * 32 * CPD + 2 * q], bq[j][q], acc[m], 0, 0, 0);
     }
   }
-  float* out = a.out + ((size_t)img * a.max_slots + mt * 32) * 256;
+  float* out = a.out + ((size_t)img * a.max_slots + mt * M) * 256;
 #pragma unroll
-  for (int t = 0; t < NTW; ++t)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (mt * 32 + row < n) out[(size_t)row * 256 + (nt0 + t) * 32 + (lane & 31)] = acc[t][r];
+      const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (mt * M + row < n) out[(size_t)row * 256 + nt0 * 32 + (lane & 31)] = acc[m][r];
     }
 }
 
@@ -610,8 +620,15 @@ hipError_t launch_desc_head_sparse(const float* kps_xy, const int32_t* n_kp, int
   SparseHeadArgs a;
   a.x = x; a.x_cstride = x_cstride; a.x_img_stride = x_img_stride; a.w_da = w_da; a.b_da = b_da; a.w_db = w_db; a.b_db = b_db;
   a.cells = cells; a.count = count; a.max_slots = max_slots; a.Hc = Hc; a.Wc = Wc; a.out = out;
-  const int mtiles = (std::min(max_slots, 4 * cap) + 31) / 32;
-  hipLaunchKernelGGL(desc_head_sparse_kernel, dim3(mtiles, n_img), dim3(512), 0, s, a);
+  const int slots = std::min(max_slots, 4 * cap);
+  if (n_img >= 8) {
+    constexpr size_t lds = sizeof(float) * (64 * 257 + 64);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(desc_head_sparse_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(desc_head_sparse_kernel<2>, dim3((slots + 63) / 64, n_img), dim3(512), lds, s, a);
+  } else {
+    hipLaunchKernelGGL(desc_head_sparse_kernel<1>, dim3((slots + 31) / 32, n_img), dim3(512), sizeof(float) * (32 * 257 + 32), s, a);
+  }
   return hipGetLastError();
 }
 
