@@ -140,3 +140,34 @@ def test_pipe_argument_errors():
     with pytest.raises(api.D2FEError):
         p.wait(0)                                                               # nothing submitted
     p.close(); fe.close()
+
+
+@pytest.mark.gpu
+def test_pipe_waits_in_any_order_twice_and_close_with_passes_in_flight():
+    """Tickets may be waited for in any order and more than once (the result block stays valid for 2 * lanes passes); a pipe may be closed while passes are in
+    flight; a ticket whose block has been reused is refused, not served stale."""
+    from d2slam_amd import api
+    from d2slam_amd.weights import synthetic_superpoint_weights
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2, precision=api.PREC_F32_WINO, keypoint_threshold=0.005))
+    fe.load_superpoint(synthetic_superpoint_weights(dustbin_bias=7.5))
+    fr = _frames(12)
+    ref = [fe.extract_batch(np.stack(f), cap=CAP) for f in fr]
+    pipe = api.StereoPipe(fe, lanes=3, frames=1, width=W, height=H, cap=CAP, netvlad=False)
+    t = [pipe.submit(fr[i][0][None], fr[i][1][None]) for i in range(3)]
+    for i in (2, 0, 1, 0, 2):                                   # out of order, repeated
+        o = pipe.wait(t[i])
+        for im in range(2):
+            n = int(o["n_kp"][im]); assert n == len(ref[i][im][0])
+            np.testing.assert_array_equal(o["desc"][im, :n], ref[i][im][2])
+    for i in range(3, 10):
+        t.append(pipe.submit(fr[i][0][None], fr[i][1][None]))  # blocks only on the lane's own previous pass
+    with pytest.raises(api.D2FEError):
+        pipe.wait(t[0])                                         # 9 passes later: its block has been written twice since
+    o = pipe.wait(t[9])
+    n = int(o["n_kp"][0]); np.testing.assert_array_equal(o["kps_xy"][0, :n], ref[9][0][0])
+    t.append(pipe.submit(fr[10][0][None], fr[10][1][None])); t.append(pipe.submit(fr[11][0][None], fr[11][1][None]))
+    pipe.close()                                                # two passes still in flight
+    # the handle is still usable afterwards
+    again = fe.extract_batch(np.stack(fr[0]), cap=CAP)
+    np.testing.assert_array_equal(again[0][2], ref[0][0][2])
+    fe.close()
