@@ -141,7 +141,7 @@ def main():
     from d2slam_amd import netvlad as nvm
     nv_weights = nvm.synthetic_netvlad_weights()
 
-    def run_mode(precision, want_breakdown, netvlad=True, steps=None):
+    def run_mode(precision, want_breakdown, netvlad=True, steps=None, d2h=False):
         steps = steps or args.steps
         F = args.frames
         NI = 2 * F
@@ -217,6 +217,20 @@ def main():
         # N > 1: HIP events around the exchange on the stream it runs on -- pack, ONE all-gather, (int8: decode), count fix-up, gate -- one set per step
         xev = []
 
+        # d2h (N > 1): every result of the step -- local keypoints / scores / descriptors / counts / NetVLAD and ALL match lists, cross-agent ones included --
+        # lands in pinned host memory inside the timed region: a device-side staging copy behind the matcher, then the D2H on a stream of its own
+        # while the next step computes (the staging block is rewritten only after the previous step's D2H has read it)
+        d2h_pairs, d2h_bytes = [], 0
+        if d2h:
+            d2h_s = torch.cuda.Stream(device=dev)
+            ev_stage, ev_d2h = torch.cuda.Event(), torch.cuda.Event()
+            srcs = [kps[:NI], scores, desc[:NI], cnt[:NI], mq, mt, md, mn] + ([gdesc] if netvlad else [])
+            for t in srcs:
+                st = torch.empty_like(t)
+                d2h_pairs.append((t, st, torch.empty(t.shape, dtype=t.dtype).pin_memory()))
+                d2h_bytes += t.numel() * t.element_size()
+            ev_d2h.record(main)
+
         def upload(b):
             """frames of the next step: pinned host -> HBM on the copy stream (19.7 MB per 32 stereo frames)"""
             with torch.cuda.stream(copy_s):
@@ -275,6 +289,16 @@ def main():
                 fe.match_batch_device(pool.data_ptr(), pool.data_ptr(), a_off.data_ptr(), b_off.data_ptr(), a_cnt.data_ptr(),
                                       b_cnt.data_ptr(), NP, 256, CAP, mq.data_ptr(), mt.data_ptr(), md.data_ptr(), mn.data_ptr(),
                                       mode=0, ratio=0.8, radius=-1.0, stream=tstream)
+                if d2h:
+                    tail.wait_event(ev_d2h)
+                    for src, st, _ in d2h_pairs:
+                        st.copy_(src)
+                    ev_stage.record(tail)
+                    with torch.cuda.stream(d2h_s):
+                        d2h_s.wait_event(ev_stage)
+                        for _, st, hp in d2h_pairs:
+                            hp.copy_(st, non_blocking=True)
+                        ev_d2h.record(d2h_s)
                 # this step's left descriptors become the "previous keyframe" of the next step
                 desc[NI:NI + F].copy_(desc[:F])
                 cnt[NI:NI + F].copy_(cnt[:F])
@@ -368,7 +392,7 @@ def main():
                                    "HIP events around the whole sequence on the launch stream"}
 
         fe.close()
-        return dict(sel=sel, first=first, gfirst=gfirst, value=value, ms_per_step=ms_per_step, roofline=roofline, roofline_nv=roofline_nv, n_kp=n_kp,
+        return dict(sel=sel, first=first, gfirst=gfirst, value=value, ms_per_step=ms_per_step, roofline=roofline, roofline_nv=roofline_nv, n_kp=n_kp, d2h_bytes=d2h_bytes,
                     n_match=n_match, breakdown=breakdown, NI=NI, NP=NP, F=F, gated=gated, exch=exch, fallback_rows=fallback_rows)
 
     use_nv = not args.no_netvlad
@@ -421,7 +445,7 @@ def main():
                                             "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
                                             "note": "dynamic batching: up to 4 consecutive submits per pass, launched early whenever fewer than 2 passes are in flight"})
     else:
-        primary = run_mode(args.precision, True, netvlad=use_nv)
+        primary = run_mode(args.precision, True, netvlad=use_nv, d2h=True)
         legs = {}
         if not args.single_mode:
             legs["configs1"] = run_mode(args.precision, False, netvlad=False, steps=max(5, args.steps // 2))
@@ -482,11 +506,11 @@ def main():
                        "api": ("d2fe_pipe_submit / d2fe_pipe_wait (include/d2fe.h): host frames in (pinned), host results out (pinned), %d submits in flight"
                                % primary["lanes"]) if world == 1 else "device API on one handle per rank (d2fe_*_device) + torch.distributed collectives",
                        "h2d_in_timed_region": True if world == 1 else not args.no_h2d,
-                       "d2h_in_timed_region": world == 1,
-                       "d2h_bytes_per_step": primary.get("d2h_bytes") if world == 1 else 0,
+                       "d2h_in_timed_region": True,
+                       "d2h_bytes_per_step": primary.get("d2h_bytes"),
                        "delivered": "keypoints, scores, descriptors, counts, NetVLAD descriptors and both match lists of every frame land in host memory inside the timed "
-                                    "region (the reference's contract ends in host std::vectors, superpoint_tensorrt.cpp:172-180, loop_cam.cpp:619-645)" if world == 1 else
-                                    "results stay in HBM for the cross-agent step (the N = 1 line times the host-delivered form)",
+                                    "region (the reference's contract ends in host std::vectors, superpoint_tensorrt.cpp:172-180, loop_cam.cpp:619-645)" + ("" if world == 1 else
+                                    "; N > 1: cross-agent match lists included, through a device-side staging copy behind the matcher and a D2H stream of its own"),
                        "submits_in_flight": primary.get("lanes"), "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "async_tail": bool(args.async_tail or (use_nv and args.overlap)) if world > 1 else False,
                        "netvlad_overlaps_superpoint_tail": bool(use_nv and args.overlap) if world > 1 else "NetVLAD runs on the lane's second stream beside SuperPoint",
