@@ -171,3 +171,51 @@ def test_pipe_waits_in_any_order_twice_and_close_with_passes_in_flight():
     again = fe.extract_batch(np.stack(fr[0]), cap=CAP)
     np.testing.assert_array_equal(again[0][2], ref[0][0][2])
     fe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes,frames,coal,depth", [(2, 4, 1, 0), (4, 1, 4, 2)])
+def test_pipe_at_the_baseline_geometry(lanes, frames, coal, depth):
+    """BASELINE configs[1] / the metric configuration: 640 x 480 stereo, 200 keypoints, NetVLAD on the left image, L<->R and L<->previous-L matches -- the
+    pipe (what bench.py times) against the single-call entry points, bit for bit."""
+    from d2slam_amd import api, netvlad as nvm
+    from d2slam_amd.weights import synthetic_superpoint_weights
+    Hb, Wb, capb = 480, 640, 200
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=capb, input_width=Wb, input_height=Hb, max_batch=2 * frames, precision=api.PREC_F32_WINO))
+    fe.load_superpoint(synthetic_superpoint_weights(dustbin_bias=7.5)); fe.load_netvlad(nvm.synthetic_netvlad_weights())
+    nsub = 2 * lanes * coal + 1
+    scenes = [synth_stereo(Hb, Wb, seed=300 + s) for s in range(4)]
+    fr = []
+    for i in range(nsub * frames):
+        l, r = scenes[i % 4]; sh = ((i // 4) % 3, (2 * (i // 4)) % 5)
+        fr.append((np.roll(l, sh, (0, 1)), np.roll(r, sh, (0, 1))))
+    pipe = api.StereoPipe(fe, lanes=lanes, frames=frames, width=Wb, height=Hb, cap=capb, netvlad=True, ratio=0.8, coalesce=coal, coalesce_depth=depth)
+    tickets = [pipe.submit(np.stack([fr[s * frames + f][0] for f in range(frames)]), np.stack([fr[s * frames + f][1] for f in range(frames)])) for s in range(min(nsub, lanes * coal))]
+    got = []
+    for s in range(nsub):
+        got.append({k: (None if v is None else v.copy()) for k, v in pipe.wait(tickets[s]).items()})
+        nxt = len(tickets)
+        if nxt < nsub:
+            tickets.append(pipe.submit(np.stack([fr[nxt * frames + f][0] for f in range(frames)]), np.stack([fr[nxt * frames + f][1] for f in range(frames)])))
+    prev, nprev = None, 0
+    for s in range(nsub):
+        imgs = np.stack([fr[s * frames + f][0] for f in range(frames)] + [fr[s * frames + f][1] for f in range(frames)])
+        ext, g = fe.extract_all_batch(imgs, frames, cap=capb)
+        o = got[s]
+        np.testing.assert_array_equal(o["netvlad"], g)
+        for i, (kps, sc, desc) in enumerate(ext):
+            n = int(o["n_kp"][i]); assert n == len(kps) == capb
+            np.testing.assert_array_equal(o["kps_xy"][i, :n], kps); np.testing.assert_array_equal(o["scores"][i, :n], sc); np.testing.assert_array_equal(o["desc"][i, :n], desc)
+        for f in range(frames):
+            q, t, d = fe.match_knn(ext[f][2], ext[frames + f][2], 0.8)
+            n = int(o["lr_n"][f]); assert n == len(q) and n > 10
+            np.testing.assert_array_equal(o["lr_q"][f, :n], q); np.testing.assert_array_equal(o["lr_t"][f, :n], t); np.testing.assert_array_equal(o["lr_dist"][f, :n], d)
+            pv = ext[f - 1] if f > 0 else prev
+            if pv is not None:
+                q, t, d = fe.match_knn(ext[f][2], pv[2], 0.8)
+                n = int(o["prev_n"][f]); assert n == len(q)
+                np.testing.assert_array_equal(o["prev_q"][f, :n], q); np.testing.assert_array_equal(o["prev_t"][f, :n], t); np.testing.assert_array_equal(o["prev_dist"][f, :n], d)
+                nprev += n
+        prev = ext[frames - 1]
+    assert nprev > 0
+    pipe.close(); fe.close()
