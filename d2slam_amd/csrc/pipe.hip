@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -44,7 +45,7 @@ struct d2fe_pipe_s {
     uint8_t* d_img = nullptr;
     uint8_t* pin_in = nullptr;
     float* pin_out[2] = {nullptr, nullptr};
-    bool done_synced = true;
+    long long rec = -1, synced = -1;   // the pass whose completion ev_done last recorded / the newest pass known to be complete (idle: synced >= rec)
   };
   std::vector<Lane> lanes;
   uint8_t* d_img_all = nullptr;      // the lanes' input buffers, one allocation: lane k at k * NI images (netvlad_group reads several lanes' left images with one stride)
@@ -57,6 +58,7 @@ struct d2fe_pipe_s {
   std::vector<hipEvent_t> ev_g;                          // [2 sets][K / M]: the group's descriptors are in pinned memory
   std::vector<char> g_synced;
   long long g_first = 0;                                 // first ticket whose NetVLAD has not been launched
+  std::mutex mu;                     // submit() and wait() may come from different threads (image callback / tracker); wait() drops it while it blocks
   long long next_ticket = 0;
   long long next_pass = 0;           // passes started so far
   int pend = 0;                      // submits of the newest pass that are staged but not launched yet (0: no pass open)
@@ -75,10 +77,10 @@ size_t up64(size_t w) { return (w + 63) / 64 * 64; }
 
 int pipe_fail(int code, const std::string& msg) { return ctx_fail(code, msg); }
 
-int lane_sync(d2fe_pipe_s::Lane& L) {
-  if (!L.done_synced) {
+int lane_sync(d2fe_pipe_s::Lane& L) {       // called with the pipe's mutex held for the whole wait
+  if (L.synced < L.rec) {
     HIP_TRY(hipEventSynchronize(L.ev_done));
-    L.done_synced = true;
+    L.synced = L.rec;
   }
   return D2FE_OK;
 }
@@ -133,7 +135,7 @@ int pipe_flush(d2fe_pipe_s* p) {
   if (nv_side) HIP_TRY(hipStreamWaitEvent(s, L.ev_nv, 0));
   HIP_TRY(hipMemcpyAsync(L.pin_out[set], B, sizeof(float) * p->d2h_words, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipEventRecord(L.ev_done, s));
-  L.done_synced = false;
+  L.rec = P;
   p->prev_g = g;
   p->pend = 0;
   return D2FE_OK;
@@ -337,6 +339,7 @@ int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int
   if (!p || !left || !right || !ticket) return pipe_fail(D2FE_ERR_INVALID, "null argument");
   if (stride < p->W) return pipe_fail(D2FE_ERR_INVALID, "stride < width");
   HIP_TRY(hipSetDevice(p->parent->cfg.device_id));
+  std::lock_guard<std::mutex> lk(p->mu);
   const long long t = p->next_ticket;
   int rc;
   if (p->pend == 0) {
@@ -389,9 +392,9 @@ int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int
     // dynamic batching: the device would run dry with fewer than `coalesce_depth` passes in flight -- launch what is staged; otherwise let the pass grow
     int inflight = 0;
     for (auto& Lq : p->lanes) {
-      if (Lq.done_synced) continue;
+      if (Lq.synced >= Lq.rec) continue;
       const hipError_t q = hipEventQuery(Lq.ev_done);
-      if (q == hipSuccess) Lq.done_synced = true;
+      if (q == hipSuccess) Lq.synced = Lq.rec;
       else if (q == hipErrorNotReady) ++inflight;
       else return ctx_fail(D2FE_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
     }
@@ -412,8 +415,9 @@ int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int
 int d2fe_pipe_wait(d2fe_pipe p, int64_t ticket, d2fe_pipe_result* out) {
   if (!p || !out) return pipe_fail(D2FE_ERR_INVALID, "null argument");
   memset(out, 0, sizeof(*out));
+  std::unique_lock<std::mutex> lk(p->mu);
   if (ticket < 0 || ticket >= p->next_ticket) return pipe_fail(D2FE_ERR_INVALID, "unknown ticket");
-  const auto& ti = p->tinfo[(size_t)(ticket % (long long)p->tinfo.size())];
+  const auto ti = p->tinfo[(size_t)(ticket % (long long)p->tinfo.size())];      // a copy: the ring entry may be rewritten while this call blocks without the mutex
   // the ticket's result block is written again by the pass 2 K passes later
   if (ticket + (long long)p->tinfo.size() <= p->next_ticket || ti.pass < 0 || ti.pass + 2 * p->K < p->next_pass)
     return pipe_fail(D2FE_ERR_INVALID, "the ticket's result block has been reused: wait for a frame within 2 * lanes passes");
@@ -424,8 +428,20 @@ int d2fe_pipe_wait(d2fe_pipe p, int64_t ticket, d2fe_pipe_result* out) {
   }
   const int k = (int)(ti.pass % p->K), set = (int)((ti.pass / p->K) & 1), j = ti.j;
   auto& L = p->lanes[k];
-  int rc = lane_sync(L);
-  if (rc) return rc;
+  int rc = D2FE_OK;
+  if (L.synced < ti.pass) {
+    // block WITHOUT the mutex, so that the other thread can go on submitting.  The event may be recorded again meanwhile (a later pass of this lane):
+    // the wait then covers that record too, and everything the lane recorded up to `rec` is complete either way (one stream, in order)
+    const long long rec = L.rec;
+    hipEvent_t ev = L.ev_done;
+    lk.unlock();
+    const hipError_t e = hipEventSynchronize(ev);
+    lk.lock();
+    if (e != hipSuccess) return pipe_fail(D2FE_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+    if (L.synced < rec) L.synced = rec;
+    if (ticket + (long long)p->tinfo.size() <= p->next_ticket || ti.pass + 2 * p->K < p->next_pass)
+      return pipe_fail(D2FE_ERR_INVALID, "the ticket's result block was reused while this call waited for it");
+  }
   p->tinfo[(size_t)(ticket % (long long)p->tinfo.size())].waited = true;
   while (p->oldest_unwaited < p->next_ticket && p->tinfo[(size_t)(p->oldest_unwaited % (long long)p->tinfo.size())].waited) ++p->oldest_unwaited;
   const float* gdesc = nullptr;

@@ -235,7 +235,9 @@ D2FE_API int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, 
  * frames per submit with up to `lanes` submits in flight: d2fe_pipe_submit only enqueues (H2D, both networks, ONE matcher launch,
  * ONE D2H, on the lane's own streams), d2fe_pipe_wait returns pointers into the lane's pinned result block.  Results are bit-identical
  * to d2fe_extract_all_batch + d2fe_match_knn on the same frames.  A pipe borrows the handle's packed weights: keep the handle alive
- * and do not reload weights while a pipe exists.  One submitting thread per pipe. */
+ * and do not reload weights while a pipe exists.  One submitting thread per pipe; d2fe_pipe_wait may be called from a second thread (the reference's image
+ * callback and its tracker are two threads): the pipe serialises its own bookkeeping and does not hold the lock while a wait blocks.  The caller bounds the
+ * frames between its two threads (a queue of at most lanes * coalesce tickets is always safe), as the result blocks are a ring of 2 * lanes passes. */
 typedef struct d2fe_pipe_s* d2fe_pipe;
 typedef struct {
   int32_t struct_size;      /* sizeof(d2fe_pipe_config) */

@@ -219,3 +219,57 @@ def test_pipe_at_the_baseline_geometry(lanes, frames, coal, depth):
         prev = ext[frames - 1]
     assert nprev > 0
     pipe.close(); fe.close()
+
+
+@pytest.mark.gpu
+def test_pipe_submit_and_wait_from_two_threads():
+    """The reference's image callback and its tracker are two threads: one submits, the other waits (a bounded queue of tickets between them).  Results equal
+    the single calls whatever the interleaving."""
+    import queue
+    import threading
+    from d2slam_amd import api, netvlad as nvm
+    from d2slam_amd.weights import synthetic_superpoint_weights
+    lanes, nsub = 3, 40
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2, precision=api.PREC_F32_WINO, keypoint_threshold=0.005))
+    fe.load_superpoint(synthetic_superpoint_weights(dustbin_bias=7.5)); fe.load_netvlad(nvm.synthetic_netvlad_weights())
+    fr = _frames(nsub)
+    ref = [fe.extract_all_batch(np.stack(f), 1, cap=CAP) for f in fr]
+    pipe = api.StereoPipe(fe, lanes=lanes, frames=1, width=W, height=H, cap=CAP, netvlad=True, coalesce=2, coalesce_depth=1)
+    q = queue.Queue(maxsize=lanes * 2)                    # lanes x coalesce tickets between the two threads: always inside the ring of 2 x lanes result passes
+    got, errors = {}, []
+
+    def producer():
+        try:
+            for i in range(nsub):
+                q.put((i, pipe.submit(fr[i][0][None], fr[i][1][None])))
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+        q.put(None)
+
+    def consumer():
+        try:
+            while True:
+                it = q.get()
+                if it is None:
+                    return
+                i, t = it
+                got[i] = {k: (None if v is None else v.copy()) for k, v in pipe.wait(t).items()}
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=producer), threading.Thread(target=consumer)]
+    for t in th: t.start()
+    for t in th: t.join(120)
+    assert not errors, errors
+    assert len(got) == nsub
+    for i in range(nsub):
+        ext, g = ref[i]
+        np.testing.assert_array_equal(got[i]["netvlad"], g)
+        for im in range(2):
+            n = int(got[i]["n_kp"][im]); assert n == len(ext[im][0])
+            np.testing.assert_array_equal(got[i]["kps_xy"][im, :n], ext[im][0]); np.testing.assert_array_equal(got[i]["desc"][im, :n], ext[im][2])
+        kl, _, dl = ext[0]; kr, _, dr = ext[1]
+        mq, mt, md = fe.match_knn(dl, dr, 0.8)
+        n = int(got[i]["lr_n"][0]); assert n == len(mq)
+        np.testing.assert_array_equal(got[i]["lr_q"][0, :n], mq); np.testing.assert_array_equal(got[i]["lr_t"][0, :n], mt)
+    pipe.close(); fe.close()
