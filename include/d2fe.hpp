@@ -159,6 +159,62 @@ class MobileNetVLAD {
   std::vector<uint8_t> tmp_;
 };
 
+// The per-frame work of D2Frontend::processStereoframe (d2frontend.cpp:155-169: LoopCam::generateStereoImageDescriptor, loop_cam.cpp:440-470, then
+// D2FeatureTracker::trackLocalFrames, d2featuretracker.cpp:403-456,658-695) with several frames in flight: d2fe_pipe_* of include/d2fe.h behind the
+// containers the reference's call sites use.  submit() from the image callback, wait() from the tracker thread; results bit-identical to
+// SuperPoint::infer + MobileNetVLAD::inference + matchKNN on the same frames.
+struct StereoFrameResult {
+  std::vector<Point2f> kps_left, kps_right;
+  std::vector<float> scores_left, scores_right;
+  std::vector<float> desc_left, desc_right;          // [n][256]
+  std::vector<float> netvlad;                        // empty when the pipe runs without NetVLAD
+  std::vector<DMatch> left_right;                    // queryIdx: left keypoint, trainIdx: right keypoint
+  std::vector<DMatch> left_prev;                     // queryIdx: left keypoint, trainIdx: keypoint of the PREVIOUS left frame
+};
+class StereoPipe {
+ public:
+  // cfg: d2fe_pipe_default_config() + the fields the caller sets (lanes, width, height, cap, netvlad, coalesce, coalesce_depth, ...); frames is forced to 1
+  StereoPipe(d2fe_handle h, d2fe_pipe_config cfg) {
+    cfg.frames = 1;
+    if (d2fe_pipe_create(h, &cfg, &p_) != D2FE_OK) { std::fprintf(stderr, "[d2fe] d2fe_pipe_create: %s\n", d2fe_last_error()); p_ = nullptr; }
+  }
+  ~StereoPipe() { if (p_) d2fe_pipe_destroy(p_); }
+  StereoPipe(const StereoPipe&) = delete;
+  StereoPipe& operator=(const StereoPipe&) = delete;
+  bool ok() const { return p_ != nullptr; }
+  // returns the ticket (>= 0) or -1
+  int64_t submit(const ImageView& left, const ImageView& right) {
+    int64_t t = -1;
+    if (!p_ || left.channels != 1 || right.channels != 1 || left.step != right.step) return -1;
+    if (d2fe_pipe_submit(p_, left.data, right.data, (int)left.step, 0, &t) != D2FE_OK) { std::fprintf(stderr, "[d2fe] d2fe_pipe_submit: %s\n", d2fe_last_error()); return -1; }
+    return t;
+  }
+  bool wait(int64_t ticket, StereoFrameResult& out) {
+    d2fe_pipe_result r;
+    if (!p_ || d2fe_pipe_wait(p_, ticket, &r) != D2FE_OK) { std::fprintf(stderr, "[d2fe] d2fe_pipe_wait: %s\n", d2fe_last_error()); return false; }
+    auto side = [&](int i, std::vector<Point2f>& k, std::vector<float>& s, std::vector<float>& d) {
+      const int n = r.n_kp[i];
+      k.clear(); for (int j = 0; j < n; ++j) k.emplace_back(r.kps_xy[((size_t)i * r.cap + j) * 2], r.kps_xy[((size_t)i * r.cap + j) * 2 + 1]);
+      s.assign(r.scores + (size_t)i * r.cap, r.scores + (size_t)i * r.cap + n);
+      d.assign(r.desc + (size_t)i * r.cap * r.desc_dim, r.desc + ((size_t)i * r.cap + n) * r.desc_dim);
+    };
+    side(0, out.kps_left, out.scores_left, out.desc_left);
+    side(1, out.kps_right, out.scores_right, out.desc_right);
+    out.netvlad.clear();
+    if (r.netvlad) out.netvlad.assign(r.netvlad, r.netvlad + r.netvlad_dim);
+    auto matches = [&](const int32_t* q, const int32_t* t, const float* d, const int32_t* n, std::vector<DMatch>& m) {
+      m.clear();
+      if (q) for (int j = 0; j < n[0]; ++j) m.emplace_back(q[j], t[j], d[j]);
+    };
+    matches(r.lr_q, r.lr_t, r.lr_dist, r.lr_n, out.left_right);
+    matches(r.prev_q, r.prev_t, r.prev_dist, r.prev_n, out.left_prev);
+    return true;
+  }
+
+ private:
+  d2fe_pipe p_ = nullptr;
+};
+
 // feature_matcher.h:6-11.  `h` replaces the implicit global state of cv::BFMatcher; everything else as in the reference.
 inline std::vector<DMatch> matchKNN(d2fe_handle h, const DescView& desc_a, const DescView& desc_b, double knn_match_ratio = 0.8,
                                     const std::vector<Point2f>& pts_a = std::vector<Point2f>(),

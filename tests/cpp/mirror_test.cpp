@@ -79,6 +79,41 @@ int main(int argc, char** argv) {
   push(fillLandmarks(k0, [&](const Point2f& p) { return liftProjectiveMEI(mei, p); }));
   push(fillLandmarks(k0, [&](const Point2f& p) { return liftProjectiveCylindrical(W / 3.4906585039886591, W / 3.4906585039886591, W / 2, H / 2, p); }));
 
+  // the frames-in-flight pipe behind the reference's containers (StereoPipe): three frames in flight over the two images and their mirror order, two threads'
+  // worth of calls made from one; every result must equal infer() + matchKNN() on the same frames, bit for bit (the same kernels)
+  {
+    d2fe_pipe_config pc;
+    d2fe_pipe_default_config(&pc);
+    pc.lanes = 3; pc.width = W; pc.height = H; pc.cap = maxkp; pc.netvlad = 0; pc.match_lr = 1; pc.match_prev = 1; pc.ratio = 0.8; pc.coalesce = 2; pc.coalesce_depth = 1;
+    StereoPipe pipe(sp.handle(), pc);
+    if (!pipe.ok()) return 6;
+    const uint8_t* L[4] = {img0.data(), img1.data(), img0.data(), img1.data()};
+    const uint8_t* R[4] = {img1.data(), img0.data(), img1.data(), img0.data()};
+    int64_t t[4];
+    for (int i = 0; i < 4; ++i) { t[i] = pipe.submit(ImageView(L[i], H, W), ImageView(R[i], H, W)); if (t[i] < 0) return 6; }
+    const std::vector<Point2f>* K[2] = {&k0, &k1};
+    const std::vector<float>* D[2] = {&d0, &d1};
+    for (int i = 0; i < 4; ++i) {
+      StereoFrameResult fr;
+      if (!pipe.wait(t[i], fr)) return 6;
+      const int li = i & 1, ri = li ^ 1;
+      if (fr.kps_left.size() != K[li]->size() || fr.kps_right.size() != K[ri]->size()) return 7;
+      if (std::memcmp(fr.kps_left.data(), K[li]->data(), K[li]->size() * sizeof(Point2f)) || std::memcmp(fr.desc_left.data(), D[li]->data(), D[li]->size() * 4)) return 7;
+      if (std::memcmp(fr.desc_right.data(), D[ri]->data(), D[ri]->size() * 4)) return 7;
+      const DescView dl(D[li]->data(), (int)K[li]->size(), 256), dr(D[ri]->data(), (int)K[ri]->size(), 256);
+      const std::vector<DMatch> mlr = matchKNN(sp.handle(), dl, dr, 0.8);
+      if (mlr.size() != fr.left_right.size()) return 8;
+      for (size_t j = 0; j < mlr.size(); ++j)
+        if (mlr[j].queryIdx != fr.left_right[j].queryIdx || mlr[j].trainIdx != fr.left_right[j].trainIdx || mlr[j].distance != fr.left_right[j].distance) return 8;
+      if (i == 0) { if (!fr.left_prev.empty()) return 9; }
+      else {
+        // the previous left frame is the other image, i.e. this frame's right image: same match list
+        if (fr.left_prev.size() != mlr.size()) return 9;
+        for (size_t j = 0; j < mlr.size(); ++j) if (mlr[j].trainIdx != fr.left_prev[j].trainIdx || mlr[j].distance != fr.left_prev[j].distance) return 9;
+      }
+    }
+  }
+
   FILE* fo = fopen(argv[2], "wb");
   if (!fo) return 2;
   auto flat = [](const std::vector<Point2f>& p) { std::vector<float> o; for (auto& q : p) { o.push_back(q.x); o.push_back(q.y); } return o; };
