@@ -500,6 +500,30 @@ def test_netvlad_vs_oracle(api, orc, H, W):
     fe.close()
 
 
+@pytest.mark.parametrize("mult,H,W", [(0.5, 128, 160), (0.75, 96, 128), (1.0, 96, 128)])
+def test_netvlad_other_trunk_widths(api, orc, mult, H, W):
+    """The real mobilenetvlad_dyn_size.onnx is not in the reference tree, so its width is not known: the loader takes ANY MobileNetV2-style layer list
+    (d2fe_load_netvlad).  Depth multipliers other than the stand-in's 0.35 have channel counts the specialised block kernels do not cover (Cin 64, 96, 160 ...):
+    the plan then falls back to the generic fused block / per-layer kernels.  Against the oracle <= 1e-4, and the same bits alone and in a batch."""
+    from d2slam_amd import netvlad as nvm
+    nv = nvm.synthetic_netvlad_weights(seed=77, depth_multiplier=mult)
+    imgs = np.stack([synth_image(H, W, 21 + s) for s in range(3)])
+    fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=3))
+    fe.load_netvlad(nv)
+    got = fe.netvlad(imgs)
+    for i in range(3):
+        ref = orc.netvlad_forward(imgs[i], nv)
+        assert abs(np.linalg.norm(got[i]) - 1.0) < 1e-5
+        assert np.abs(got[i] - ref).max() <= 1e-4, (mult, np.abs(got[i] - ref).max())
+        np.testing.assert_array_equal(fe.netvlad(imgs[i:i + 1])[0], got[i])
+    # a shape outside the documented limits (first convolution wider than 32 channels: MobileNetV2-1.4) is refused with a message, and the handle stays usable
+    with pytest.raises(api.D2FEError, match="conv layer must be first"):
+        fe.load_netvlad(nvm.synthetic_netvlad_weights(seed=78, depth_multiplier=1.4))
+    fe.load_netvlad(nv)
+    np.testing.assert_array_equal(fe.netvlad(imgs), got)
+    fe.close()
+
+
 @pytest.mark.parametrize("K,D", [(16, 64), (24, 96), (64, 128)])
 def test_netvlad_general_head_is_reproducible(api, orc, K, D):
     """Heads other than 32 x 128 take nv_vlad_partial_kernel / nv_vlad_final_kernel (netvlad.hip): against the oracle, and every sum in a fixed order --
