@@ -1027,6 +1027,15 @@ def run_latency(api, weights, nv_weights, device_id, precision, calls):
         def stereo_all():
             all2(); mk(); mk()
         out["stereo_frame_with_netvlad_fused_host_to_host"] = stats(stereo_all)
+        # the same frame through the pipe with ONE frame in flight (submit + wait): one upload, both networks, ONE matcher launch over both pairs with the
+        # previous left frame's descriptors still on the device, ONE download -- the whole per-frame work of processStereoframe as a single round trip
+        pipe = api.StereoPipe(fe, lanes=1, frames=1, width=W, height=H, cap=CAP, netvlad=True, ratio=0.8)
+        l1, r1 = np.ascontiguousarray(l[None]), np.ascontiguousarray(r[None])
+        def through_pipe():
+            pipe.wait_raw(pipe.submit_ptr(l1.ctypes.data, r1.ctypes.data))
+        through_pipe()
+        out["stereo_frame_with_netvlad_through_the_pipe_one_in_flight"] = stats(through_pipe)
+        pipe.close()
     fe.close()
     # one quadcam frame (configs[2] geometry): 4 undistorted 800x400 views through extract_batch + netvlad_batch
     UH, UW, CAPQ = 400, 800, 100
