@@ -813,7 +813,7 @@ def live_traffic(kernel_tag):
             env = dict(os.environ, D2FE_BENCH_CHILD="1", TMPDIR="/tmp")
             cmd = [rp, "--output-format", "csv", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
                    "--steps", "3", "--warmup", "1", "--precision", "wino", "--single-mode", "--no-cpu-baseline", "--lanes", "1"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
             fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not fs:
                 return None
