@@ -806,6 +806,8 @@ def live_traffic(kernel_tag):
     rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rp) or os.environ.get("D2FE_BENCH_CHILD"):
         return None
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None              # this run is itself being profiled: no nested profiler
     vals, t0 = {}, time.time()
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="d2fe_pmc_", dir="/tmp")
