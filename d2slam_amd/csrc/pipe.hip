@@ -245,7 +245,10 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
           std::vector<uint32_t> mask((h->ncu + 31) / 32, 0u);
           for (int b = 8 * r0; b < 8 * r1; ++b) mask[b / 32] |= 1u << (b % 32);
           HIP_TRY(hipExtStreamCreateWithCUMask(&ms, (uint32_t)mask.size(), mask.data()));
-          HIP_TRY(hipExtStreamCreateWithCUMask(&L.nv, (uint32_t)mask.size(), mask.data()));
+          if (hipExtStreamCreateWithCUMask(&L.nv, (uint32_t)mask.size(), mask.data()) != hipSuccess) {      // `ms` has no owner yet
+            (void)hipStreamDestroy(ms);
+            return pipe_fail(D2FE_ERR_HIP, "hipExtStreamCreateWithCUMask");
+          }
           lane_cus = 8 * (r1 - r0);
         }
       }
