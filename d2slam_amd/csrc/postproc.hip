@@ -485,6 +485,57 @@ __global__ __launch_bounds__(1024) void desc_compact_kernel(const uint8_t* __res
   if (tid == 0) count[img] = s_base < max_slots ? s_base : max_slots;
 }
 
+// desc_mark_kernel + desc_compact_kernel in ONE launch per image batch (one workgroup per image, the cell flags in LDS): the form every map of up to
+// 64 Ki cells takes -- two launches and a memset less in front of the sparse head, which is what a one- or two-image call notices
+__global__ __launch_bounds__(1024) void desc_mark_compact_kernel(const float* __restrict__ kps_xy, const int32_t* __restrict__ n_kp, int cap, int Hc, int Wc,
+                                                                 int img_w, int img_h, int max_slots, int32_t* __restrict__ slotmap,
+                                                                 int32_t* __restrict__ cells, int32_t* __restrict__ count) {
+  extern __shared__ uint8_t mc_flags[];      // [ncell rounded up to 4]
+  __shared__ int wsum[16];
+  __shared__ int s_base;
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ncell = Hc * Wc;
+  for (int i = tid; i < (ncell + 3) / 4; i += 1024) reinterpret_cast<uint32_t*>(mc_flags)[i] = 0u;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  const int nk = min(n_kp[img], cap);
+  for (int k = tid; k < nk; k += 1024) {
+    const size_t o = (size_t)img * cap + k;
+    if (img_w > 0) {
+      float ix, iy;
+      sample_a_origin(kps_xy[2 * o], kps_xy[2 * o + 1], Hc, Wc, img_w, img_h, ix, iy);
+      const int x0 = (int)__builtin_floorf(ix), y0 = (int)__builtin_floorf(iy);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int xx = x0 + (q & 1), yy = y0 + (q >> 1);
+        if (yy >= 0 && yy < Hc && xx >= 0 && xx < Wc) mc_flags[yy * Wc + xx] = 1;
+      }
+    } else {
+      const SampleBCorners c = sample_b_corners(kps_xy[2 * o], kps_xy[2 * o + 1], Hc, Wc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mc_flags[c.iy[q] * Wc + c.ix[q]] = 1;
+    }
+  }
+  __syncthreads();
+  for (int c0 = 0; c0 < ncell; c0 += 1024) {
+    const int cell = c0 + tid;
+    const bool f = cell < ncell && mc_flags[cell];
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) wsum[wv] = __popcll(bal);
+    __syncthreads();
+    int pre = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int c = wsum[k]; pre += k < wv ? c : 0; tot += c; }
+    const int slot = s_base + pre + __popcll(bal & ((1ull << lane) - 1ull));
+    if (cell < ncell) slotmap[(size_t)img * ncell + cell] = (f && slot < max_slots) ? slot : -1;
+    if (f && slot < max_slots) cells[(size_t)img * max_slots + slot] = cell;
+    __syncthreads();
+    if (tid == 0) s_base += tot;
+    __syncthreads();
+  }
+  if (tid == 0) count[img] = s_base < max_slots ? s_base : max_slots;
+}
+
 struct SparseHeadArgs {
   const float* x; int x_cstride; long x_img_stride;      // conv4b output, NHWC [img][cell][128]
   const void* w_da; const float* b_da;                   // convDa packed fp32 fragments (8 n-tiles x 9 taps x 16 k-octets), bias[256]
@@ -613,10 +664,15 @@ hipError_t launch_desc_head_sparse(const float* kps_xy, const int32_t* n_kp, int
                                    const float* b_db, uint8_t* flags, int32_t* slotmap, int32_t* cells, int32_t* count,
                                    int max_slots, float* out, int img_w, int img_h, hipStream_t s) {
   const int ncell = Hc * Wc;
-  hipError_t e = hipMemsetAsync(flags, 0, (size_t)n_img * ncell, s);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(desc_mark_kernel, dim3((cap + 255) / 256, n_img), dim3(256), 0, s, kps_xy, n_kp, cap, Hc, Wc, img_w, img_h, flags);
-  hipLaunchKernelGGL(desc_compact_kernel, dim3(n_img), dim3(1024), 0, s, flags, ncell, max_slots, slotmap, cells, count);
+  hipError_t e = hipSuccess;
+  if (ncell <= 60 * 1024) {
+    hipLaunchKernelGGL(desc_mark_compact_kernel, dim3(n_img), dim3(1024), (size_t)(ncell + 3) / 4 * 4, s, kps_xy, n_kp, cap, Hc, Wc, img_w, img_h, max_slots, slotmap, cells, count);
+  } else {
+    e = hipMemsetAsync(flags, 0, (size_t)n_img * ncell, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(desc_mark_kernel, dim3((cap + 255) / 256, n_img), dim3(256), 0, s, kps_xy, n_kp, cap, Hc, Wc, img_w, img_h, flags);
+    hipLaunchKernelGGL(desc_compact_kernel, dim3(n_img), dim3(1024), 0, s, flags, ncell, max_slots, slotmap, cells, count);
+  }
   SparseHeadArgs a;
   a.x = x; a.x_cstride = x_cstride; a.x_img_stride = x_img_stride; a.w_da = w_da; a.b_da = b_da; a.w_db = w_db; a.b_db = b_db;
   a.cells = cells; a.count = count; a.max_slots = max_slots; a.Hc = Hc; a.Wc = Wc; a.out = out;
