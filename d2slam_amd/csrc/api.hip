@@ -1878,9 +1878,11 @@ int d2fe_debug_conv3x3_wino(d2fe_handle h, const float* in, int n, int H, int W,
   const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
   const size_t in_fl = (size_t)n * H * W * cin, out_fl = (size_t)n * Ho * Wo * cout;
   if ((size_t)H * W * cin * 4 >= (1ull << 31)) return fail(D2FE_ERR_INVALID, "image too large");
-  std::vector<float> pk(packed_weight_floats_wino(cout_pad, cin)), bp(cout_pad, 0.f);
-  pack_weights_wino(weight, cout, cin, cout_pad, pk.data());
+  const bool w43 = d2fe_dev_env("D2FE_WINO43", 0) != 0;      // the experimental F(4,3) x F(2,3) kernel (conv_wino43.hip) instead of F(2x2,3x3)
+  std::vector<float> pk(w43 ? packed_weight_floats_wino43(cout_pad, cin) : packed_weight_floats_wino(cout_pad, cin)), bp(cout_pad, 0.f);
+  if (w43) pack_weights_wino43(weight, cout, cin, cout_pad, pk.data()); else pack_weights_wino(weight, cout, cin, cout_pad, pk.data());
   memcpy(bp.data(), bias, sizeof(float) * cout);
+  auto launch = [&](const ConvArgs& ca) { return w43 ? launch_conv_wino43(cin, pool != 0, relu != 0, cout_pad, ca, h->stream) : launch_conv_wino(cin, pool != 0, relu != 0, cout_pad, ca, h->stream); };
   float *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = [&]() -> int {
@@ -1898,14 +1900,14 @@ int d2fe_debug_conv3x3_wino(d2fe_handle h, const float* in, int n, int H, int W,
     a.cout_real = cout; a.wpack = d_w; a.bias = d_b; a.H = H; a.W = W; a.n_img = n;
     a.in_img_stride = (long)H * W * cin; a.out_img_stride = (long)Ho * Wo * cout; a.zeros = h->zeros; a.ncu = h->ncu;
     a.ablate = d2fe_dev_env("D2FE_ABLATE", 0);
-    HIP_TRY(launch_conv_wino(cin, pool != 0, relu != 0, cout_pad, a, h->stream));
+    HIP_TRY(launch(a));
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(out, d_out, out_fl * 4, hipMemcpyDeviceToHost));
     if (iters > 0 && ms_per_launch) {
       HIP_TRY(hipEventCreate(&e0));
       HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, h->stream));
-      for (int i = 0; i < iters; ++i) HIP_TRY(launch_conv_wino(cin, pool != 0, relu != 0, cout_pad, a, h->stream));
+      for (int i = 0; i < iters; ++i) HIP_TRY(launch(a));
       HIP_TRY(hipEventRecord(e1, h->stream));
       HIP_TRY(hipEventSynchronize(e1));
       float ms = 0.f;
