@@ -6,11 +6,10 @@
 // Same replacement as conv_wino.hip (the TensorRT engine execution at d2frontend/src/CNN/superpoint_tensorrt.cpp:150 for the 3x3 layers with Cin >= 64);
 // the evaluation order is fixed here and restated by orc_conv3x3_wino43 (oracle/d2fe_oracle.c): outputs are bit-identical to that restatement.
 //
-// STATUS (round 4): bit-identical to the restatement for every layer shape of the network (tests/test_wino43.py); per-layer time equal to conv_wino.hip with a
-// static split of the work items and 25-30 % behind the tuned production path (dynamic claiming, two phase-shifted workgroups per CU): conv2a at 64 images
-// 1.77 ms against 1.36-1.43, 0.43 of the matrix pipe.  Measured with D2FE_ABLATE (tools/gpu_w43.sh): K loop without copies / window reads / epilogue 1.09-1.20 ms
-// (0.65-0.70), the epilogue 0.25 ms -- all twelve waves of a CU reach it together, so the matrix pipe idles through it -- the patch copies 0.27 ms.  What it needs
-// is in DESIGN.md section 7.6.
+// STATUS (round 4): bit-identical to the restatement for every layer shape of the network (tests/test_wino43.py).  Per layer at 64 images (conv2a / conv3b / conv4a):
+// 1.66 / 1.51 / 0.40 ms -- 3-9 % faster than conv_wino.hip with a static split of the work items, 7-18 % behind its tuned production path (dynamic claiming, two
+// phase-shifted workgroups per CU: 1.36-1.43 / 1.36-1.39 / 0.37-0.38).  D2FE_ABLATE (tools/gpu_w43.sh): without the epilogue 1.40 / 1.42 / 0.36 ms -- all twelve
+// waves of a CU reach the epilogue together, so the matrix pipe idles through it; K loop alone 1.06 ms.  What it needs is in DESIGN.md section 7.6.
 //
 // Work split (what changes against conv_wino.hip, whose row transform, accumulator layout, LDS slot pattern and U stream are kept):
 //   * a wave owns ONE ROW i of the 6 x 4 transform domain: the 4 positions (i, 0..3) x 32 tiles x 32 output channels = 64 accumulators; a workgroup is
@@ -109,28 +108,31 @@ __device__ __forceinline__ void w43_body(const ConvArgs& a, int nbx, int nby, in
   f32x16 acc[4];
   f32x4 t[4];              // t[dx]: row I of B4^T d for window column dx, the quad's 4 channels
   f32x4 ub[4];             // U fragments of k-step (slot): one float per position (I, 0..3)
+  f32x2 vp[4];             // the four positions' A operands for a pair of k-steps
 
   auto win = [&](const float* p, int dy, int dx) {
     return *reinterpret_cast<const f32x4*>(p + ((dy & 3) * 2 + (dx & 1)) * 256 + ((dy >> 2) * QROW + (dx >> 1)) * 4);
   };
-  auto fma4 = [](float c, f32x4 x, f32x4 y) {
-    f32x4 r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(c, x[e], y[e]);
-    return r;
-  };
+  // packed fp32 arithmetic by name (the compiler scalarises <2 x float> additions): the column transform is the wave's largest block of vector work
+  auto padd = [](f32x2 x, f32x2 y) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
+  auto psub = [](f32x2 x, f32x2 y) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y)); return d; };
+  auto pfma = [](float c, f32x2 x, f32x2 y) { return __builtin_elementwise_fma(f32x2{c, c}, x, y); };
+  auto lo2 = [](f32x4 v) { return f32x2{v[0], v[1]}; };
+  auto hi2 = [](f32x4 v) { return f32x2{v[2], v[3]}; };
+  auto cat = [](f32x2 a, f32x2 b) { return f32x4{a[0], a[1], b[0], b[1]}; };
   auto read_t = [&](int buf) {
     const float* p = lds + buf * QCHUNK + rd_off;
 #pragma unroll
     for (int dx = 0; dx < 4; ++dx) {
-      if constexpr (I == 0) { const f32x4 d0 = win(p, 0, dx), d2 = win(p, 2, dx), d4 = win(p, 4, dx); t[dx] = fma4(4.f, d0, fma4(-5.f, d2, d4)); }
-      else if constexpr (I == 5) { const f32x4 d1 = win(p, 1, dx), d3 = win(p, 3, dx), d5 = win(p, 5, dx); t[dx] = fma4(4.f, d1, fma4(-5.f, d3, d5)); }
-      else {
+      if constexpr (I == 0 || I == 5) {
+        const f32x4 da = win(p, I == 0 ? 0 : 1, dx), db = win(p, I == 0 ? 2 : 3, dx), dc = win(p, I == 0 ? 4 : 5, dx);      // t = 4 da - 5 db + dc
+        t[dx] = cat(pfma(4.f, lo2(da), pfma(-5.f, lo2(db), lo2(dc))), pfma(4.f, hi2(da), pfma(-5.f, hi2(db), hi2(dc))));
+      } else {
         const f32x4 d1 = win(p, 1, dx), d2 = win(p, 2, dx), d3 = win(p, 3, dx), d4 = win(p, 4, dx);
-        if constexpr (I == 1) t[dx] = fma4(-4.f, d1 + d2, d3 + d4);
-        else if constexpr (I == 2) t[dx] = fma4(4.f, d1 - d2, d4 - d3);
-        else if constexpr (I == 3) t[dx] = fma4(2.f, d3 - d1, d4 - d2);
-        else t[dx] = fma4(2.f, d1 - d3, d4 - d2);
+        if constexpr (I == 1) t[dx] = cat(pfma(-4.f, padd(lo2(d1), lo2(d2)), padd(lo2(d3), lo2(d4))), pfma(-4.f, padd(hi2(d1), hi2(d2)), padd(hi2(d3), hi2(d4))));
+        else if constexpr (I == 2) t[dx] = cat(pfma(4.f, psub(lo2(d1), lo2(d2)), psub(lo2(d4), lo2(d3))), pfma(4.f, psub(hi2(d1), hi2(d2)), psub(hi2(d4), hi2(d3))));
+        else if constexpr (I == 3) t[dx] = cat(pfma(2.f, psub(lo2(d3), lo2(d1)), psub(lo2(d4), lo2(d2))), pfma(2.f, psub(hi2(d3), hi2(d1)), psub(hi2(d4), hi2(d2))));
+        else t[dx] = cat(pfma(2.f, psub(lo2(d1), lo2(d3)), psub(lo2(d4), lo2(d2))), pfma(2.f, psub(hi2(d1), hi2(d3)), psub(hi2(d4), hi2(d2))));
       }
     }
   };
@@ -170,7 +172,12 @@ __device__ __forceinline__ void w43_body(const ConvArgs& a, int nbx, int nby, in
       for (int j = 0; j < 4; ++j) {
         const int kt = ch * 4 + j + 3;                          // U runs three k-steps ahead, across the item boundary
         if (kt < KSTEPS) load_u((j + 3) & 3, ucur, kt); else load_u((j + 3) & 3, unxt, kt - KSTEPS);
-        const float v0 = t[0][j] - t[2][j], v1 = t[1][j] + t[2][j], v2 = t[2][j] - t[1][j], v3 = t[1][j] - t[3][j];
+        // row transform (F(2,3)) for the k-step pair (j, j + 1) at the even one: four packed instructions instead of eight
+        if ((j & 1) == 0) {
+          const f32x2 t0 = j ? hi2(t[0]) : lo2(t[0]), t1 = j ? hi2(t[1]) : lo2(t[1]), t2 = j ? hi2(t[2]) : lo2(t[2]), t3 = j ? hi2(t[3]) : lo2(t[3]);
+          vp[0] = psub(t0, t2); vp[1] = padd(t1, t2); vp[2] = psub(t2, t1); vp[3] = psub(t1, t3);
+        }
+        const float v0 = vp[0][j & 1], v1 = vp[1][j & 1], v2 = vp[2][j & 1], v3 = vp[3][j & 1];
         __builtin_amdgcn_sched_barrier(0);
         if (j == 3) {
           // the last k-step's operands are in registers: t is free.  Chunk g + 1 (copied two iterations ago) must have landed: younger than its copies are the
