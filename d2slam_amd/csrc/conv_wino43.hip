@@ -244,14 +244,14 @@ __device__ __forceinline__ void w43_body(const ConvArgs& a, int nbx, int nby, in
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
               const float v = fmaxf(fmaxf(y[2 * pp][0], y[2 * pp][1]), fmaxf(y[2 * pp + 1][0], y[2 * pp + 1][1]));
-              if (cok && oy + 2 * pp + 1 < aH && ox + 1 < aW) out[((size_t)((oy >> 1) + pp) * (aW >> 1) + (ox >> 1)) * cs + co] = v;
+              if (cok && !D2FE_ABL(a, 8) && oy + 2 * pp + 1 < aH && ox + 1 < aW) out[((size_t)((oy >> 1) + pp) * (aW >> 1) + (ox >> 1)) * cs + co] = v;
             }
           } else {
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
               for (int b = 0; b < 2; ++b)
-                if (cok && oy + p < aH && ox + b < aW) out[((size_t)(oy + p) * aW + ox + b) * cs + co] = y[p][b];
+                if (cok && !D2FE_ABL(a, 8) && oy + p < aH && ox + b < aW) out[((size_t)(oy + p) * aW + ox + b) * cs + co] = y[p][b];
           }
         }
       }

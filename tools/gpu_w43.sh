@@ -1,6 +1,6 @@
 #!/bin/bash
 # experimental F(4,3) x F(2,3) kernel: layer tests, then per-layer timing against F(2x2,3x3) and with parts of the kernel switched off (D2FE_ABLATE: 1 no
-# epilogue, 2 no window reads / column transform, 4 no patch copies; results are wrong with a bit set)
+# epilogue, 2 no window reads / column transform, 4 no patch copies, 8 no output stores; results are wrong with a bit set)
 cd $GRAFT_REPO_ROOT
 timeout 300 python -m pytest tests/test_wino43.py -q -m gpu 2>&1 | tail -2
 L=${W43_LAYERS:-conv2a,conv3b,conv4a}
