@@ -178,6 +178,8 @@ __device__ __forceinline__ void w43_body(const ConvArgs& a, int nbx, int nby, in
           vp[0] = psub(t0, t2); vp[1] = padd(t1, t2); vp[2] = psub(t2, t1); vp[3] = psub(t1, t3);
         }
         const float v0 = vp[0][j & 1], v1 = vp[1][j & 1], v2 = vp[2][j & 1], v3 = vp[3][j & 1];
+        // the scheduling fences of this loop are load-bearing: the compiler does not see the LDS-DMA copies as writes to LDS, and without the fences it moved the
+        // window reads of the next chunk (results wrong on every layer; measured no faster either)
         __builtin_amdgcn_sched_barrier(0);
         if (j == 3) {
           // the last k-step's operands are in registers: t is free.  Chunk g + 1 (copied two iterations ago) must have landed: younger than its copies are the
