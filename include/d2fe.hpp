@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
@@ -73,7 +74,9 @@ struct DescView {                     // borrowed view of a continuous CV_32F cv
 
 // superpoint_tensorrt.h:17-33 (the fields the path uses) plus what the TensorRT engine carried implicitly
 struct SuperPointConfig {
-  int32_t max_keypoints = 100;
+  int32_t max_keypoints = 100;           // -1: keep every keypoint above the threshold, raster order (topKeypoints with k == -1, superpoint_tensorrt.cpp:241-253)
+  int32_t keep_all_capacity = 4096;      // max_keypoints == -1 only: the buffers infer() starts with; an image with more keypoints is re-run with 4x the
+                                         // capacity (up to width * height) until everything fits, so the result is the reference's, whatever the count
   int32_t remove_borders = 1;
   float keypoint_threshold = 0.015f;
   int32_t input_width = 640, input_height = 480;
@@ -110,11 +113,20 @@ class SuperPoint {
   // superpoint_tensorrt.cpp:161-183: keypoints are APPENDED (not cleared) on success, all three outputs cleared on failure
   bool infer(const ImageView& input, std::vector<Point2f>& keypoints, std::vector<float>& local_descriptors,
              std::vector<float>& scores) {
-    const int cap = cfg_.max_keypoints;
-    kp_.resize(2 * (size_t)cap); sc_.resize(cap); de_.resize((size_t)cap * 256);
-    int n = 0;
-    if (!h_ || input.channels != 1 ||
-        d2fe_superpoint_extract(h_, input.data, input.cols, input.rows, (int)input.step, kp_.data(), sc_.data(), de_.data(), cap, &n) != D2FE_OK) {
+    // never throws (the reference's contract is "return false", :164-170): sizes come from the configuration, not from max_keypoints == -1
+    const long most = input.empty() ? 1 : (long)input.rows * input.cols;
+    long cap = cfg_.max_keypoints > 0 ? cfg_.max_keypoints : (cfg_.keep_all_capacity > 0 ? cfg_.keep_all_capacity : 4096);
+    if (cap > most) cap = most;
+    int n = 0, rc = D2FE_ERR_INVALID;
+    for (;;) {
+      if (!reserve(cap)) break;
+      rc = (!h_ || input.channels != 1) ? (int)D2FE_ERR_INVALID
+                                        : d2fe_superpoint_extract(h_, input.data, input.cols, input.rows, (int)input.step, kp_.data(), sc_.data(), de_.data(), (int)cap, &n);
+      // keep-all with more keypoints than the buffers hold: the library has written the strongest `cap`; the reference returns ALL of them, so run again with room
+      if (rc != D2FE_ERR_TRUNCATED || cfg_.max_keypoints > 0 || cap >= most) break;
+      cap = cap * 4 < most ? cap * 4 : most;
+    }
+    if (rc != D2FE_OK) {
       keypoints.clear(); local_descriptors.clear(); scores.clear();
       report("superpoint infer failed");
       return false;
@@ -129,6 +141,14 @@ class SuperPoint {
 
  private:
   static void report(const char* what) { std::fprintf(stderr, "[d2fe] %s: %s\n", what, d2fe_last_error()); }
+  bool reserve(long cap) {               // grow-only staging for `cap` keypoints; false instead of an exception when memory is short
+    try {
+      if (kp_.size() < 2 * (size_t)cap) kp_.resize(2 * (size_t)cap);
+      if (sc_.size() < (size_t)cap) sc_.resize((size_t)cap);
+      if (de_.size() < (size_t)cap * 256) de_.resize((size_t)cap * 256);
+    } catch (...) { return false; }
+    return true;
+  }
   SuperPointConfig cfg_;
   d2fe_handle h_ = nullptr;
   std::vector<float> kp_, sc_, de_;

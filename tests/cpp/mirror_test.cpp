@@ -36,6 +36,29 @@ int main(int argc, char** argv) {
   }
   std::vector<uint8_t> img0((size_t)H * W), img1((size_t)H * W);
   if (!rd(fi, img0.data(), img0.size()) || !rd(fi, img1.data(), img1.size())) return 2;
+  if (maxkp == -1) {
+    // keep-all (SuperPointConfig::max_keypoints = -1, superpoint_tensorrt.cpp:241-253): infer() must neither throw nor truncate.  The file carries the
+    // threshold and a deliberately small starting capacity, so that the grow-and-run-again path of the mirror is what delivers the result
+    float thr; int32_t cap0;
+    if (!rd(fi, &thr, 1) || !rd(fi, &cap0, 1)) return 2;
+    fclose(fi);
+    SuperPointConfig kc;
+    kc.max_keypoints = -1; kc.keep_all_capacity = cap0; kc.keypoint_threshold = thr; kc.input_width = W; kc.input_height = H; kc.max_batch = 1;
+    SuperPoint ks(kc);
+    if (!ks.build(w)) return 3;
+    std::vector<Point2f> k(1, Point2f(-7.f, -7.f));        // infer() APPENDS keypoints (:172-174)
+    std::vector<float> d, sc;
+    bool ok = false;
+    try { ok = ks.infer(ImageView(img0.data(), H, W), k, d, sc); } catch (...) { return 10; }
+    if (!ok || k.empty() || k[0].x != -7.f) return 4;
+    k.erase(k.begin());
+    FILE* fo = fopen(argv[2], "wb");
+    if (!fo) return 2;
+    std::vector<float> kf; for (auto& q : k) { kf.push_back(q.x); kf.push_back(q.y); }
+    wr(fo, kf); wr(fo, sc); wr(fo, d);
+    fclose(fo);
+    return 0;
+  }
   fclose(fi);
 
   SuperPointConfig cfg;
