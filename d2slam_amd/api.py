@@ -21,7 +21,7 @@ from .weights import SP_LAYERS
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libd2fe_hip.so")
 DEV_LIB_PATH = os.path.join(_HERE, "lib", "libd2fe_hip_dev.so")      # -DD2FE_DEVTOOLS: d2fe_debug_* test hooks, phase stamps, D2FE_* schedule switches
-if os.environ.get("D2FE_LIB"):      # developer knob: same-box A/B of two builds of the library (tools/gpu_ab_lib.sh)
+if os.environ.get("D2FE_LIB"):      # developer knob: same-box A/B of two builds of the library (tools/gpu_run.sh ab)
     LIB_PATH = os.path.abspath(os.environ["D2FE_LIB"])
 
 POSTPROC_B, POSTPROC_A = 0, 1
@@ -321,6 +321,9 @@ class FrontEnd:
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
+            # pipes run on this handle's packed weights; the library refuses to destroy a handle that still has live pipes (d2fe_destroy), so they go first
+            for p in list(getattr(self, "_pipes", ())):
+                p.close()
             self._lib.d2fe_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -705,7 +708,12 @@ class StereoPipe:
         c.cu_partition = int(bool(cu_partition)); c.netvlad_inline = int(bool(netvlad_inline)); c.coalesce = int(coalesce); c.lane_cus = int(lane_cus); c.netvlad_group = int(netvlad_group); c.coalesce_depth = int(coalesce_depth)
         self._p = C.c_void_p()
         _check(self._lib.d2fe_pipe_create(fe.handle, C.byref(c), C.byref(self._p)))
+        if not hasattr(fe, "_pipes"):
+            import weakref
+            fe._pipes = weakref.WeakSet()
+        fe._pipes.add(self)
         self.lanes, self.frames, self.width, self.height = int(lanes), int(frames), int(width), int(height)
+        self._pinned_input = bool(pinned_input)
         self._res = _PipeResult()
 
     def close(self):
@@ -735,9 +743,14 @@ class StereoPipe:
         return int(t.value)
 
     def submit(self, left, right):
-        """left, right: u8 [frames, H, W] (or [H, W] when frames == 1)"""
+        """left, right: u8 [frames, H, W] (or [H, W] when frames == 1).  The library copies the frames into its own pinned staging before this returns
+        (pinned_input = 0), so the arrays -- and any contiguous temporaries made here -- are not referenced afterwards.  A pipe created with
+        pinned_input=True DMAs straight from the caller's memory until the ticket has been waited for: that contract (page-locked memory that
+        stays alive and unchanged) cannot be kept for numpy arrays, so it is refused here -- use submit_ptr with memory you own."""
+        if self._pinned_input:
+            raise ValueError("StereoPipe(pinned_input=True): submit() takes numpy arrays, which are neither page-locked nor kept alive until wait(); "
+                             "use submit_ptr() with page-locked memory that outlives the ticket")
         left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
-        self._keep = (left, right)
         return self.submit_ptr(left.ctypes.data, right.ctypes.data)
 
     def wait_raw(self, ticket):

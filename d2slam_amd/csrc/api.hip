@@ -349,7 +349,11 @@ void d2fe_default_config(d2fe_config* c) {
   c->async_tail = 0;
 }
 
-int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
+}  // extern "C"
+namespace d2fe {
+// lane = a context cloned for a pipe (clone_lane): no host-pointer staging (frame upload buffer, output block, pinned mirrors) -- a lane is only ever
+// driven through run_superpoint / run_netvlad on device buffers of the pipe
+static int create_context(const d2fe_config* cfg, d2fe_handle* out, bool lane) {
   if (!cfg || !out) return fail(D2FE_ERR_INVALID, "null argument");
   *out = nullptr;
   if (cfg->struct_size != (int32_t)sizeof(d2fe_config)) return fail(D2FE_ERR_INVALID, "d2fe_config size mismatch");
@@ -434,11 +438,12 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
       HIP_TRY(hipMalloc(&h->a_samp, sizeof(float) * 256 * (size_t)h->a_scap * B));
       HIP_TRY(hipMalloc(&h->a_cn, sizeof(float) * 256 * B));
     }
+    h->use_graphs = d2fe_dev_env("D2FE_GRAPH", 1) != 0;
+    if (lane) { h->use_pinned = false; return D2FE_OK; }
     h->s_cap = h->cfg.max_keypoints > 1024 ? h->cfg.max_keypoints : 1024;      // initial staging capacity per image; grows with the calls (ensure_staging)
     HIP_TRY(hipMalloc(&h->s_img, H * W * B));
     h->s_out_bytes = (sizeof(float) * (size_t)h->s_cap * 260 + sizeof(int32_t)) * B;
     HIP_TRY(hipMalloc(&h->s_out, h->s_out_bytes));
-    h->use_graphs = d2fe_dev_env("D2FE_GRAPH", 1) != 0;
     h->use_pinned = d2fe_dev_env("D2FE_PINNED", 1) != 0;
     if (h->use_pinned) {
       h->pin_in_bytes = (size_t)H * W * B;
@@ -459,6 +464,9 @@ int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) {
   *out = h;
   return D2FE_OK;
 }
+}  // namespace d2fe
+extern "C" {
+int d2fe_create(const d2fe_config* cfg, d2fe_handle* out) { return d2fe::create_context(cfg, out, false); }
 
 }  // extern "C"
 namespace { void nv_free(d2fe_context* h); }
@@ -466,6 +474,9 @@ extern "C" {
 
 void d2fe_destroy(d2fe_handle h) {
   if (!h) return;
+  // pipes created from this handle run on ITS packed weights: destroying it under them would leave every lane with dangling pointers.  Refuse
+  // (the handle stays valid; d2fe_last_error says why) -- destroy the pipes first
+  if (h->live_pipes.load() > 0) { fail(D2FE_ERR_INVALID, "d2fe_destroy: the handle still has live pipes (d2fe_pipe_destroy them first); nothing was released"); return; }
   hipSetDevice(h->cfg.device_id);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->tail_stream) { hipStreamSynchronize(h->tail_stream); (void)hipStreamDestroy(h->tail_stream); }
@@ -495,6 +506,7 @@ void d2fe_destroy(d2fe_handle h) {
 }
 
 int d2fe_load_superpoint(d2fe_handle h, const d2fe_superpoint_weights* w) {
+  if (h && h->live_pipes.load() > 0) return fail(D2FE_ERR_INVALID, "the handle has live pipes whose lanes read its packed weights: destroy them before loading weights or PCA matrices");
   if (h) graphs_clear(h);
   if (!h || !w) return fail(D2FE_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(h->cfg.device_id));
@@ -542,6 +554,7 @@ int d2fe_load_superpoint(d2fe_handle h, const d2fe_superpoint_weights* w) {
 }
 
 int d2fe_set_superpoint_pca(d2fe_handle h, const float* comp, const float* mean, int pca_dims) {
+  if (h && h->live_pipes.load() > 0) return fail(D2FE_ERR_INVALID, "the handle has live pipes whose lanes read its packed weights: destroy them before loading weights or PCA matrices");
   if (h) graphs_clear(h);
   if (!h) return fail(D2FE_ERR_INVALID, "null handle");
   if (pca_dims < 0 || pca_dims > 256 || (pca_dims > 0 && (!comp || !mean))) return fail(D2FE_ERR_INVALID, "bad PCA arguments");
@@ -917,6 +930,7 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
 extern "C" {
 
 int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
+  if (h && h->live_pipes.load() > 0) return fail(D2FE_ERR_INVALID, "the handle has live pipes whose lanes read its packed weights: destroy them before loading weights or PCA matrices");
   if (h) graphs_clear(h);
   if (!h || !w || !w->layers || w->n_layers < 1) return fail(D2FE_ERR_INVALID, "null argument");
   if (!w->pre_w || !w->pre_b || !w->assign_w || !w->assign_b || !w->centroids) return fail(D2FE_ERR_INVALID, "null head weights");
@@ -1133,6 +1147,7 @@ long d2fe_debug_netvlad_layer(d2fe_handle h, int layer, int n_images, void* dst,
 #endif  // D2FE_DEVTOOLS
 
 int d2fe_set_netvlad_pca(d2fe_handle h, const float* comp, const float* mean, int m) {
+  if (h && h->live_pipes.load() > 0) return fail(D2FE_ERR_INVALID, "the handle has live pipes whose lanes read its packed weights: destroy them before loading weights or PCA matrices");
   if (h) graphs_clear(h);
   if (!h) return fail(D2FE_ERR_INVALID, "null handle");
   if (!h->nv_loaded) return fail(D2FE_ERR_NOT_READY, "netvlad weights not loaded");
@@ -1210,13 +1225,13 @@ int d2fe_netvlad(d2fe_handle h, const uint8_t* gray, int width, int height, int 
 
 }  // extern "C"
 namespace d2fe {
-int clone_lane(d2fe_context* p, int max_batch, d2fe_context** out, hipStream_t stream, int ncu) {
+int clone_lane(d2fe_context* p, int max_batch, d2fe_context** out, hipStream_t stream, int ncu, bool with_netvlad) {
   *out = nullptr;
   d2fe_config cfg = p->cfg;
   cfg.max_batch = max_batch;
   cfg.async_tail = 0;
   d2fe_handle c = nullptr;
-  int rc = d2fe_create(&cfg, &c);
+  int rc = create_context(&cfg, &c, true);
   if (rc) return rc;
   c->borrowed = true;
   if (stream) { (void)hipStreamDestroy(c->stream); c->stream = stream; }
@@ -1226,7 +1241,7 @@ int clone_lane(d2fe_context* p, int max_batch, d2fe_context** out, hipStream_t s
   c->sp_loaded = p->sp_loaded;
   c->pca_comp_t = p->pca_comp_t; c->pca_mean = p->pca_mean; c->pca_dims = p->pca_dims;
   c->fuse1a = p->fuse1a; c->wino_dynamic = p->wino_dynamic; c->sp_min_batch = p->sp_min_batch;
-  if (p->nv_loaded) {
+  if (p->nv_loaded && with_netvlad) {
     const int B = max_batch;
     c->nv = p->nv;
     for (auto& l : c->nv) { l.out = nullptr; l.slabs = 1; l.slab_stride = 0; }
@@ -1243,9 +1258,7 @@ int clone_lane(d2fe_context* p, int max_batch, d2fe_context** out, hipStream_t s
       HIP_TRY(hipMalloc(&c->nv_feat_buf, sizeof(float) * (size_t)c->nv_feat_gmax * B * ch * cw * c->nv_proj));
       HIP_TRY(hipMalloc(&c->nv_raw, sizeof(float) * (size_t)B * c->nv_k * c->nv_proj));
       HIP_TRY(hipMalloc(&c->nv_part, sizeof(float) * (size_t)B * nv_vlad_part_floats(ch * cw, c->nv_proj, c->nv_k)));
-      HIP_TRY(hipMalloc(&c->nv_s_img, (size_t)cfg.max_width * cfg.max_height * B));
-      HIP_TRY(hipMalloc(&c->nv_s_out, sizeof(float) * 8192 * B));
-      return D2FE_OK;
+      return D2FE_OK;       // no nv_s_img / nv_s_out: the host-pointer NetVLAD calls never run on a lane
     };
     rc = alloc();
     if (rc) { d2fe_destroy(c); return rc; }
@@ -1878,11 +1891,10 @@ int d2fe_debug_conv3x3_wino(d2fe_handle h, const float* in, int n, int H, int W,
   const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
   const size_t in_fl = (size_t)n * H * W * cin, out_fl = (size_t)n * Ho * Wo * cout;
   if ((size_t)H * W * cin * 4 >= (1ull << 31)) return fail(D2FE_ERR_INVALID, "image too large");
-  const bool w43 = d2fe_dev_env("D2FE_WINO43", 0) != 0;      // the experimental F(4,3) x F(2,3) kernel (conv_wino43.hip) instead of F(2x2,3x3)
-  std::vector<float> pk(w43 ? packed_weight_floats_wino43(cout_pad, cin) : packed_weight_floats_wino(cout_pad, cin)), bp(cout_pad, 0.f);
-  if (w43) pack_weights_wino43(weight, cout, cin, cout_pad, pk.data()); else pack_weights_wino(weight, cout, cin, cout_pad, pk.data());
+  std::vector<float> pk(packed_weight_floats_wino(cout_pad, cin)), bp(cout_pad, 0.f);
+  pack_weights_wino(weight, cout, cin, cout_pad, pk.data());
   memcpy(bp.data(), bias, sizeof(float) * cout);
-  auto launch = [&](const ConvArgs& ca) { return w43 ? launch_conv_wino43(cin, pool != 0, relu != 0, cout_pad, ca, h->stream) : launch_conv_wino(cin, pool != 0, relu != 0, cout_pad, ca, h->stream); };
+  auto launch = [&](const ConvArgs& ca) { return launch_conv_wino(cin, pool != 0, relu != 0, cout_pad, ca, h->stream); };
   float *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = [&]() -> int {

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <array>
 #include <deque>
 #include <map>
@@ -47,6 +49,8 @@ struct d2fe_context {
   hipStream_t stream = nullptr;
   bool sp_loaded = false;
   bool borrowed = false;       // a pipeline lane (clone_lane): the packed weights belong to the parent context
+  std::atomic<int> live_pipes{0};   // pipes created from this handle and not destroyed yet: their lanes read THIS handle's packed weights, so d2fe_destroy,
+                               // d2fe_load_* and d2fe_set_*_pca refuse (D2FE_ERR_INVALID) while it is non-zero
   float* w1a = nullptr;  // [9][64]
   float* b1a = nullptr;
   d2fe::Layer L[d2fe::L_COUNT];
@@ -152,5 +156,6 @@ int nv_check(d2fe_context* h, int n, int W, int H, int stride);
 // the parent must outlive its lanes and must not reload weights while they exist
 // `stream` (optional): the lane's launch stream, e.g. one created with a CU mask (the lane then owns it); `ncu` (optional): the compute units that
 // stream may use -- the persistent kernels size their grids on it
-int clone_lane(d2fe_context* parent, int max_batch, d2fe_context** out, hipStream_t stream = nullptr, int ncu = 0);
+// with_netvlad: the lane will run NetVLAD itself (its own activation buffers); a lane never gets the host-pointer staging of d2fe_create
+int clone_lane(d2fe_context* parent, int max_batch, d2fe_context** out, hipStream_t stream = nullptr, int ncu = 0, bool with_netvlad = true);
 }  // namespace d2fe

@@ -64,10 +64,6 @@ hipError_t launch_conv_wino(int cin, bool pool, bool relu, int cout_pad, const C
 hipError_t launch_conv_wino_fused1b(int cout_pad, const ConvArgs& a, hipStream_t s);   // conv1a (u8 frame) + conv1b, ReLU, 2x2 pool
 size_t packed_weight_floats_wino(int cout_pad, int cin);
 void pack_weights_wino(const float* w /*[cout][cin][3][3]*/, int cout, int cin, int cout_pad, float* dst);
-// experimental F(4,3) x F(2,3) form (conv_wino43.hip; development library): 4 x 2 output tiles, 3 multiplies per output
-hipError_t launch_conv_wino43(int cin, bool pool, bool relu, int cout_pad, const ConvArgs& a, hipStream_t s);
-size_t packed_weight_floats_wino43(int cout_pad, int cin);
-void pack_weights_wino43(const float* w /*[cout][cin][3][3]*/, int cout, int cin, int cout_pad, float* dst);
 
 // conv1a: u8 gray [n][H][stride] -> NHWC fp32 [n][H][W][64], fused (float)u8 * (1/255), bias, ReLU.
 hipError_t launch_conv1a(const uint8_t* img, int stride, long img_stride_bytes, int H, int W, int n,

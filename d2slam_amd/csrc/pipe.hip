@@ -63,6 +63,9 @@ struct d2fe_pipe_s {
   long long next_pass = 0;           // passes started so far
   int pend = 0;                      // submits of the newest pass that are staged but not launched yet (0: no pass open)
   int prev_g = 1;                    // submits of the last LAUNCHED pass
+  int failed = D2FE_OK;              // sticky: the first error of an enqueue leaves a pass half-queued (frames copied or not, events recorded or not); the ring
+                                     // bookkeeping of every later pass would build on it, so every later submit / wait returns this code instead
+  std::string failed_msg;
   struct TInfo { long long pass = -1; int j = 0; bool waited = true; };
   long long oldest_unwaited = 0;     // every ticket below has been waited for (dynamic batching keeps the passes since then inside the result ring)
   std::vector<TInfo> tinfo;          // ring over tickets
@@ -191,6 +194,7 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
   HIP_TRY(hipSetDevice(h->cfg.device_id));
   d2fe_pipe_s* p = new d2fe_pipe_s();
   p->parent = h; p->cfg = *cfg;
+  h->live_pipes.fetch_add(1);        // from here on d2fe_pipe_destroy (every failure path below goes through it or through `delete p` + the decrement) gives it back
   p->M = M;
   p->K = cfg->lanes; p->F = cfg->frames; p->C = C; p->NI = 2 * cfg->frames * C; p->W = cfg->width; p->H = cfg->height;
   p->cap = cfg->cap < h->cfg.max_keypoints ? cfg->cap : h->cfg.max_keypoints;
@@ -200,8 +204,8 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
   p->tinfo.resize((size_t)2 * p->K * C + C);
   {
     int rc = check_geometry(h, 1, p->W, p->H, p->W, p->cap);
-    if (rc) { delete p; return rc; }
-    if (cfg->netvlad) { rc = nv_check(h, 1, p->W, p->H, p->W); if (rc) { delete p; return rc; } }
+    if (rc) { h->live_pipes.fetch_sub(1); delete p; return rc; }
+    if (cfg->netvlad) { rc = nv_check(h, 1, p->W, p->H, p->W); if (rc) { h->live_pipes.fetch_sub(1); delete p; return rc; } }
   }
   const size_t NI = p->NI, cap = p->cap, F = p->F, NL = (size_t)F * C, MP = (size_t)p->npp * C;
   size_t o = 0;
@@ -223,7 +227,7 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
     HIP_TRY(hipMemset(p->d_all, 0, sizeof(float) * all_words));
     HIP_TRY(hipMalloc(&p->d_img_all, (size_t)p->W * p->H * p->NI * p->K));
     if (p->M > 1) {
-      const int rcg = clone_lane(h, p->M, &p->gctx);
+      const int rcg = clone_lane(h, p->M, &p->gctx, nullptr, 0, true);
       if (rcg) return rcg;
       p->gnv = p->gctx->stream;
       HIP_TRY(hipMalloc(&p->d_gnv, sizeof(float) * 2 * p->K * p->G));
@@ -256,7 +260,7 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
       // full-device persistent launch holds every CU's LDS until it ends, so another lane's small launches cannot start beside it; grids sized
       // for a share of the device leave workgroup slots on every CU to the other lanes
       if (!lane_cus && cfg->lane_cus > 0 && cfg->lane_cus < h->ncu) lane_cus = cfg->lane_cus;
-      int rc2 = clone_lane(h, p->NI, &L.ctx, ms, lane_cus);
+      int rc2 = clone_lane(h, p->NI, &L.ctx, ms, lane_cus, cfg->netvlad && p->M == 1);
       if (rc2) { if (ms) (void)hipStreamDestroy(ms); return rc2; }
       L.s = L.ctx->stream;
       if (!L.nv) HIP_TRY(hipStreamCreateWithFlags(&L.nv, hipStreamNonBlocking));
@@ -335,6 +339,7 @@ void d2fe_pipe_destroy(d2fe_pipe p) {
   if (p->d_pairs) (void)hipFree(p->d_pairs);
   if (p->d_match_scratch) (void)hipFree(p->d_match_scratch);
   if (p->d_all) (void)hipFree(p->d_all);
+  p->parent->live_pipes.fetch_sub(1);
   delete p;
 }
 
@@ -343,6 +348,10 @@ int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int
   if (stride < p->W) return pipe_fail(D2FE_ERR_INVALID, "stride < width");
   HIP_TRY(hipSetDevice(p->parent->cfg.device_id));
   std::lock_guard<std::mutex> lk(p->mu);
+  if (p->failed) return pipe_fail(p->failed, "the pipe failed in an earlier call and accepts no more work (destroy it): " + p->failed_msg);
+  // an error anywhere below leaves the open pass half-enqueued while next_pass / pend / the ticket ring may or may not have advanced: no later pass can
+  // build on that (it would wait on a stale extraction event and index its pair table with a stale prev_g), so the first error is final for the pipe
+  const int rc_all = [&]() -> int {
   const long long t = p->next_ticket;
   int rc;
   if (p->pend == 0) {
@@ -413,12 +422,16 @@ int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int
     if (p->M > 1 && (t + 1) % p->M == 0) return pipe_flush_group(p, t + 1);      // the group is complete
   }
   return D2FE_OK;
+  }();
+  if (rc_all != D2FE_OK) { p->failed = rc_all; p->failed_msg = d2fe_last_error(); }
+  return rc_all;
 }
 
 int d2fe_pipe_wait(d2fe_pipe p, int64_t ticket, d2fe_pipe_result* out) {
   if (!p || !out) return pipe_fail(D2FE_ERR_INVALID, "null argument");
   memset(out, 0, sizeof(*out));
   std::unique_lock<std::mutex> lk(p->mu);
+  if (p->failed) return pipe_fail(p->failed, "the pipe failed in an earlier call (destroy it): " + p->failed_msg);
   if (ticket < 0 || ticket >= p->next_ticket) return pipe_fail(D2FE_ERR_INVALID, "unknown ticket");
   const auto ti = p->tinfo[(size_t)(ticket % (long long)p->tinfo.size())];      // a copy: the ring entry may be rewritten while this call blocks without the mutex
   // the ticket's result block is written again by the pass 2 K passes later
@@ -427,7 +440,7 @@ int d2fe_pipe_wait(d2fe_pipe p, int64_t ticket, d2fe_pipe_result* out) {
   HIP_TRY(hipSetDevice(p->parent->cfg.device_id));
   if (p->pend > 0 && ti.pass == p->next_pass - 1) {       // the ticket's pass is still filling: launch it with what it has
     const int rc = pipe_flush(p);
-    if (rc) return rc;
+    if (rc) { p->failed = rc; p->failed_msg = d2fe_last_error(); return rc; }
   }
   const int k = (int)(ti.pass % p->K), set = (int)((ti.pass / p->K) & 1), j = ti.j;
   auto& L = p->lanes[k];

@@ -192,98 +192,6 @@ ORC_API void orc_conv3x3_wino(const float* in, int h, int w, int cin, const floa
   free(U);
 }
 
-/* 3x3 / stride 1 / pad 1 convolution as Winograd F(4,3) down the columns x F(2,3) along the rows (output tiles of 4 x 2 pixels, 6 x 4 transform positions:
- * 3 multiplies per output where F(2x2,3x3) has 4), in the evaluation order of the HIP library's experimental kernel conv_wino43.hip (development library).
- * Like orc_conv3x3_wino this restates the KERNEL's order, not a reference file: the reference's TensorRT engine fixes no accumulation order
- * (superpoint_tensorrt.cpp:150); the value is held to the direct-convolution chain to ~1e-6 by tests/test_wino43.py.
- *   U = (float)(G4 g G2^T) in double;   column transform (rows r of the 6 x 4 window, per column):
- *     t0 = fma(4, d0, fma(-5, d2, d4))      t1 = fma(-4, d1 + d2, d3 + d4)      t2 = fma(4, d1 - d2, d4 - d3)
- *     t3 = fma(2, d3 - d1, d4 - d2)         t4 = fma(2, d1 - d3, d4 - d2)       t5 = fma(4, d1, fma(-5, d3, d5))
- *   row transform as F(2,3): v0 = t0 - t2, v1 = t1 + t2, v2 = t2 - t1, v3 = t1 - t3;   M: one fmaf chain from +0, channels 0,4,1,5,2,6,3,7 of every 8;
- *   A: along the row  s_b0 = (m0 + m1) + m2, s_b1 = (m1 - m2) - m3;  down the column (s_i = row i):
- *     y0 = ((s0 + s1) + s2) + (s3 + s4)     y1 = fma(2, s3 - s4, s1 - s2)       y2 = fma(4, s3 + s4, s1 + s2)       y3 = fma(8, s3 - s4, s1 - s2) + s5 */
-ORC_API void orc_conv3x3_wino43(const float* in, int h, int w, int cin, const float* wgt, const float* bias, int cout, int relu, float* out) {
-  static const double G4[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                  {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
-  static const double G2[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
-  float* U = (float*)malloc(sizeof(float) * 24 * (size_t)cin * cout);   /* [xi = 4 i + j][ci][co] */
-  for (int xi = 0; xi < 24; ++xi)
-    for (int ci = 0; ci < cin; ++ci)
-      for (int co = 0; co < cout; ++co) {
-        const float* g = wgt + ((size_t)co * cin + ci) * 9;
-        double s = 0.0;
-        for (int a = 0; a < 3; ++a)
-          for (int b = 0; b < 3; ++b) s += G4[xi >> 2][a] * G2[xi & 3][b] * (double)g[a * 3 + b];
-        U[((size_t)xi * cin + ci) * cout + co] = (float)s;
-      }
-  const int th = (h + 3) / 4, tw = (w + 1) / 2;
-#pragma omp parallel for schedule(static)
-  for (int ty = 0; ty < th; ++ty) {
-    float* V = (float*)malloc(sizeof(float) * 24 * cin);
-    float* M = (float*)malloc(sizeof(float) * 24 * cout);
-    for (int tx = 0; tx < tw; ++tx) {
-      for (int ci = 0; ci < cin; ++ci) {
-        float d[6][4], t[6][4];
-        for (int r = 0; r < 6; ++r)
-          for (int c = 0; c < 4; ++c) {
-            const int yy = 4 * ty - 1 + r, xx = 2 * tx - 1 + c;
-            d[r][c] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? in[((size_t)yy * w + xx) * cin + ci] : 0.f;
-          }
-        for (int c = 0; c < 4; ++c) {
-          t[0][c] = fmaf(4.f, d[0][c], fmaf(-5.f, d[2][c], d[4][c]));
-          t[1][c] = fmaf(-4.f, d[1][c] + d[2][c], d[3][c] + d[4][c]);
-          t[2][c] = fmaf(4.f, d[1][c] - d[2][c], d[4][c] - d[3][c]);
-          t[3][c] = fmaf(2.f, d[3][c] - d[1][c], d[4][c] - d[2][c]);
-          t[4][c] = fmaf(2.f, d[1][c] - d[3][c], d[4][c] - d[2][c]);
-          t[5][c] = fmaf(4.f, d[1][c], fmaf(-5.f, d[3][c], d[5][c]));
-        }
-        for (int i = 0; i < 6; ++i) {
-          V[(i * 4 + 0) * cin + ci] = t[i][0] - t[i][2]; V[(i * 4 + 1) * cin + ci] = t[i][1] + t[i][2];
-          V[(i * 4 + 2) * cin + ci] = t[i][2] - t[i][1]; V[(i * 4 + 3) * cin + ci] = t[i][1] - t[i][3];
-        }
-      }
-      for (int xi = 0; xi < 24; ++xi) {
-        float* m = M + (size_t)xi * cout;
-        for (int co = 0; co < cout; ++co) m[co] = 0.f;
-        for (int c8 = 0; c8 < cin; c8 += 8)
-          for (int j = 0; j < 4; ++j)
-            for (int hh = 0; hh < 2; ++hh) {
-              const int ci = c8 + 4 * hh + j;
-              const float v = V[xi * cin + ci];
-              const float* u = U + ((size_t)xi * cin + ci) * cout;
-              for (int co = 0; co < cout; ++co) m[co] = fmaf(v, u[co], m[co]);
-            }
-      }
-      for (int co = 0; co < cout; ++co) {
-        float s[6][2], y[4][2];
-        for (int i = 0; i < 6; ++i) {
-          const float m0 = M[(i * 4 + 0) * cout + co], m1 = M[(i * 4 + 1) * cout + co], m2 = M[(i * 4 + 2) * cout + co],
-                      m3 = M[(i * 4 + 3) * cout + co];
-          s[i][0] = (m0 + m1) + m2;
-          s[i][1] = (m1 - m2) - m3;
-        }
-        for (int b = 0; b < 2; ++b) {
-          y[0][b] = ((s[0][b] + s[1][b]) + s[2][b]) + (s[3][b] + s[4][b]);
-          y[1][b] = fmaf(2.f, s[3][b] - s[4][b], s[1][b] - s[2][b]);
-          y[2][b] = fmaf(4.f, s[3][b] + s[4][b], s[1][b] + s[2][b]);
-          y[3][b] = fmaf(8.f, s[3][b] - s[4][b], s[1][b] - s[2][b]) + s[5][b];
-        }
-        for (int p = 0; p < 4; ++p)
-          for (int b = 0; b < 2; ++b) {
-            const int oy = 4 * ty + p, ox = 2 * tx + b;
-            if (oy >= h || ox >= w) continue;
-            float v = y[p][b] + bias[co];
-            if (relu) v = v > 0.f ? v : 0.f;
-            out[((size_t)oy * w + ox) * cout + co] = v;
-          }
-      }
-    }
-    free(V);
-    free(M);
-  }
-  free(U);
-}
-
 /* MaxPool2d(kernel 2, stride 2), NHWC.  superpoint.ipynb:304,336,339,342 */
 ORC_API void orc_maxpool2(const float* in, int h, int w, int c, float* out) {
   const int ho = h / 2, wo = w / 2;

@@ -76,18 +76,6 @@ def conv_wino(x, wgt, bias, relu):
     return out
 
 
-def conv_wino43(x, wgt, bias, relu):
-    """3x3 conv as Winograd F(4,3) x F(2,3) (4 x 2 output tiles, 3 multiplies per output) in the evaluation order of the experimental kernel
-    conv_wino43.hip (orc_conv3x3_wino43)."""
-    x = _f(x); wgt = _f(wgt); bias = _f(bias)
-    h, w, cin = x.shape
-    cout, cin2, k, _ = wgt.shape
-    assert cin == cin2 and k == 3 and cin % 8 == 0
-    out = np.empty((h, w, cout), np.float32)
-    lib().orc_conv3x3_wino43(_p(x), h, w, cin, _p(wgt), _p(bias), cout, int(relu), _p(out))
-    return out
-
-
 def maxpool2(x):
     x = _f(x)
     h, w, c = x.shape

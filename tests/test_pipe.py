@@ -143,6 +143,36 @@ def test_pipe_argument_errors():
 
 
 @pytest.mark.gpu
+def test_handle_with_live_pipes_refuses_destroy_and_reload():
+    """A pipe's lanes read the parent handle's packed weights: while a pipe exists d2fe_destroy releases nothing and d2fe_load_* /
+    d2fe_set_*_pca return D2FE_ERR_INVALID instead of leaving the lanes with dangling pointers; numpy frames through a pinned_input pipe are refused
+    (the DMA would read memory nobody keeps alive); after the pipe is gone everything works again."""
+    import ctypes as C
+    from d2slam_amd import api
+    from d2slam_amd.weights import synthetic_superpoint_weights
+    w = synthetic_superpoint_weights(dustbin_bias=7.5)
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2, keypoint_threshold=0.005))
+    fe.load_superpoint(w)
+    fr = _frames(2)
+    ref = fe.extract_batch(np.stack(fr[0]), cap=CAP)
+    pipe = api.StereoPipe(fe, lanes=2, frames=1, width=W, height=H, cap=CAP, netvlad=False)
+    with pytest.raises(api.D2FEError):
+        fe.load_superpoint(w)
+    fe._lib.d2fe_destroy(fe.handle)                              # refused: the handle stays valid and the pipe keeps working
+    assert b"live pipes" in fe._lib.d2fe_last_error()
+    o = pipe.wait(pipe.submit(fr[0][0][None], fr[0][1][None]))
+    n = int(o["n_kp"][0]); np.testing.assert_array_equal(o["desc"][0, :n], ref[0][2])
+    pipe.close()
+    fe.load_superpoint(w)                                        # allowed again
+    np.testing.assert_array_equal(fe.extract_batch(np.stack(fr[0]), cap=CAP)[0][2], ref[0][2])
+    pin = api.StereoPipe(fe, lanes=2, frames=1, width=W, height=H, cap=CAP, netvlad=False, pinned_input=True)
+    with pytest.raises(ValueError):
+        pin.submit(fr[0][0][None], fr[0][1][None])
+    fe.close()                                                   # closes `pin` first (FrontEnd.close), then the handle
+    assert not pin._p.value
+
+
+@pytest.mark.gpu
 def test_pipe_waits_in_any_order_twice_and_close_with_passes_in_flight():
     """Tickets may be waited for in any order and more than once (the result block stays valid for 2 * lanes passes); a pipe may be closed while passes are in
     flight; a ticket whose block has been reused is refused, not served stale."""
