@@ -87,6 +87,11 @@ class _PipeResult(C.Structure):
                 ("prev_q", C.c_void_p), ("prev_t", C.c_void_p), ("prev_dist", C.c_void_p), ("prev_n", C.c_void_p)]
 
 
+class _PipeDeviceResult(C.Structure):
+    _fields_ = [("frames", C.c_int32), ("cap", C.c_int32), ("desc_dim", C.c_int32), ("netvlad_dim", C.c_int32),
+                ("d_kps_xy", C.c_void_p), ("d_scores", C.c_void_p), ("d_desc", C.c_void_p), ("d_n_kp", C.c_void_p), ("d_netvlad", C.c_void_p)]
+
+
 _lib = None
 _dev_lib = None
 
@@ -103,7 +108,8 @@ EXPORTS = [
     "d2fe_gen_cylinder_map", "d2fe_gen_cylinder_map_device", "d2fe_gen_pinhole_map", "d2fe_gen_pinhole_map_device", "d2fe_lk_frame_create",
     "d2fe_lk_frame_create_device", "d2fe_lk_frame_destroy", "d2fe_lk_frame_read_level", "d2fe_lk_track", "d2fe_lk_track_batch",
     "d2fe_detect_fast_by_region", "d2fe_good_features_to_track", "d2fe_pipe_default_config", "d2fe_pipe_create", "d2fe_pipe_destroy",
-    "d2fe_pipe_lanes", "d2fe_pipe_submit", "d2fe_pipe_wait", "d2fe_pipe_profile_enable", "d2fe_pipe_profile_read"]
+    "d2fe_pipe_lanes", "d2fe_pipe_submit", "d2fe_pipe_wait", "d2fe_pipe_profile_enable", "d2fe_pipe_profile_read",
+    "d2fe_pipe_device_view", "d2fe_pipe_device_release"]
 # the development library (lib/libd2fe_hip_dev.so, include/d2fe_debug.h) exports these on top: test hooks and kernel diagnostics
 DEBUG_EXPORTS = [
     "d2fe_debug_graph_count", "d2fe_debug_read", "d2fe_debug_netvlad_layer", "d2fe_debug_netvlad_stamps", "d2fe_debug_pack_wino",
@@ -242,6 +248,8 @@ def _open_library(path, dev):
         lib.d2fe_pipe_lanes.argtypes = [C.c_void_p]
         lib.d2fe_pipe_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
         lib.d2fe_pipe_wait.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        lib.d2fe_pipe_device_view.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        lib.d2fe_pipe_device_release.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         lib.d2fe_pipe_profile_enable.argtypes = [C.c_void_p, C.c_int]
         lib.d2fe_pipe_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
@@ -752,6 +760,16 @@ class StereoPipe:
                              "use submit_ptr() with page-locked memory that outlives the ticket")
         left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
         return self.submit_ptr(left.ctypes.data, right.ctypes.data)
+
+    def device_view(self, ticket, stream):
+        """DEVICE pointers into the ticket's result block for a consumer on `stream` (a raw hipStream_t, not 0): the stream is made to wait for the ticket's SuperPoint
+        and NetVLAD results; release with device_release(ticket, stream) once the consumer's work is queued (include/d2fe.h, d2fe_pipe_device_view)."""
+        r = _PipeDeviceResult()
+        _check(self._lib.d2fe_pipe_device_view(self._p, C.c_int64(ticket), C.c_void_p(stream), C.byref(r)))
+        return r
+
+    def device_release(self, ticket, stream):
+        _check(self._lib.d2fe_pipe_device_release(self._p, C.c_int64(ticket), C.c_void_p(stream)))
 
     def wait_raw(self, ticket):
         _check(self._lib.d2fe_pipe_wait(self._p, C.c_int64(ticket), C.byref(self._res)))

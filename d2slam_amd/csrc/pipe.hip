@@ -42,6 +42,10 @@ struct d2fe_pipe_s {
     d2fe_context* ctx = nullptr;
     hipStream_t s = nullptr, nv = nullptr;
     hipEvent_t ev_up = nullptr, ev_nv = nullptr, ev_ext[2] = {nullptr, nullptr}, ev_done = nullptr;
+    // device views of the two result blocks (d2fe_pipe_device_view / _release): views handed out and not released yet; ev_rel = the consumers' last release
+    hipEvent_t ev_rel[2] = {nullptr, nullptr};
+    int views[2] = {0, 0};
+    bool rel_pending[2] = {false, false};
     uint8_t* d_img = nullptr;
     uint8_t* pin_in = nullptr;
     float* pin_out[2] = {nullptr, nullptr};
@@ -102,6 +106,10 @@ int pipe_flush(d2fe_pipe_s* p) {
   const size_t left_stride = p->C > 1 ? 2 * img : img;
   int rc;
   const bool nv_side = p->cfg.netvlad && !p->cfg.netvlad_inline && p->M == 1;
+  // device views of this block (handed out 2 K passes ago): the consumers' stream must be through with it before this pass writes it.  The NetVLAD
+  // stream is ordered behind this wait through ev_up
+  if (L.views[set] > 0) return pipe_fail(D2FE_ERR_INVALID, "a device view of this lane's result block was not released (d2fe_pipe_device_release) within 2 * lanes passes");
+  if (L.rel_pending[set]) { HIP_TRY(hipStreamWaitEvent(s, L.ev_rel[set], 0)); L.rel_pending[set] = false; }
   if (p->cfg.netvlad && p->M > 1) HIP_TRY(hipEventRecord(L.ev_up, s));       // netvlad_group: the pipe's NetVLAD stream waits for this lane's frames
   // NetVLAD of the pass's left images in ONE call (its arithmetic order does not depend on the batch: run_netvlad decides the hidden-channel
   // split per image), C > 1: the left images are every second image of the lane's input buffer
@@ -269,6 +277,8 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
       HIP_TRY(hipEventCreateWithFlags(&L.ev_ext[0], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&L.ev_ext[1], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&L.ev_rel[0], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&L.ev_rel[1], hipEventDisableTiming));
       L.d_img = p->d_img_all + (size_t)k * p->NI * p->W * p->H;
       if (!cfg->pinned_input) HIP_TRY(hipHostMalloc(&L.pin_in, (size_t)p->W * p->H * p->NI, hipHostMallocDefault));
       for (int set = 0; set < 2; ++set) HIP_TRY(hipHostMalloc(&L.pin_out[set], sizeof(float) * p->d2h_words, hipHostMallocDefault));
@@ -325,7 +335,7 @@ void d2fe_pipe_destroy(d2fe_pipe p) {
   for (auto& L : p->lanes) {
     if (L.s) (void)hipStreamSynchronize(L.s);
     if (L.nv) { (void)hipStreamSynchronize(L.nv); (void)hipStreamDestroy(L.nv); }
-    for (hipEvent_t e : {L.ev_up, L.ev_nv, L.ev_ext[0], L.ev_ext[1], L.ev_done}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {L.ev_up, L.ev_nv, L.ev_ext[0], L.ev_ext[1], L.ev_done, L.ev_rel[0], L.ev_rel[1]}) if (e) (void)hipEventDestroy(e);
     if (L.pin_in) (void)hipHostFree(L.pin_in);
     for (float* q : L.pin_out) if (q) (void)hipHostFree(q);
     if (L.ctx) d2fe_destroy(L.ctx);
@@ -484,6 +494,67 @@ int d2fe_pipe_wait(d2fe_pipe p, int64_t ticket, d2fe_pipe_result* out) {
     out->prev_q = reinterpret_cast<const int32_t*>(B + p->o_mq) + pi * cap; out->prev_t = reinterpret_cast<const int32_t*>(B + p->o_mt) + pi * cap;
     out->prev_dist = B + p->o_md + pi * cap; out->prev_n = reinterpret_cast<const int32_t*>(B + p->o_mn) + pi;
   }
+  return D2FE_OK;
+}
+
+// ---- device-side consumers of a ticket (the cross-agent exchange on a stream of its own) ----------------------------------------------------------------
+namespace {
+// the ticket's (lane, set, submit index) while its result block is still the one the ticket wrote; launches its pass if it is still staged
+int view_locate(d2fe_pipe_s* p, int64_t ticket, bool may_flush, int* k, int* set, int* j) {
+  if (p->failed) return pipe_fail(p->failed, "the pipe failed in an earlier call (destroy it): " + p->failed_msg);
+  if (ticket < 0 || ticket >= p->next_ticket) return pipe_fail(D2FE_ERR_INVALID, "unknown ticket");
+  const auto ti = p->tinfo[(size_t)(ticket % (long long)p->tinfo.size())];
+  if (ticket + (long long)p->tinfo.size() <= p->next_ticket || ti.pass < 0 || ti.pass + 2 * p->K < p->next_pass)
+    return pipe_fail(D2FE_ERR_INVALID, "the ticket's result block has been reused: take the view within 2 * lanes passes");
+  if (p->pend > 0 && ti.pass == p->next_pass - 1) {
+    if (!may_flush) return pipe_fail(D2FE_ERR_INVALID, "the ticket's pass has not been launched");
+    const int rc = pipe_flush(p);
+    if (rc) { p->failed = rc; p->failed_msg = d2fe_last_error(); return rc; }
+  }
+  *k = (int)(ti.pass % p->K); *set = (int)((ti.pass / p->K) & 1); *j = ti.j;
+  return D2FE_OK;
+}
+}  // namespace
+
+int d2fe_pipe_device_view(d2fe_pipe p, int64_t ticket, void* stream, d2fe_pipe_device_result* out) {
+  if (!p || !out || !stream) return pipe_fail(D2FE_ERR_INVALID, "null argument (the consumer's stream must be a real hipStream_t)");
+  memset(out, 0, sizeof(*out));
+  if (p->M > 1) return pipe_fail(D2FE_ERR_UNSUPPORTED, "device views are not available with netvlad_group > 1 (the descriptors of a group live outside the result blocks)");
+  std::lock_guard<std::mutex> lk(p->mu);
+  HIP_TRY(hipSetDevice(p->parent->cfg.device_id));
+  int k, set, j;
+  const int rc = view_locate(p, ticket, true, &k, &set, &j);
+  if (rc) return rc;
+  auto& L = p->lanes[k];
+  hipStream_t cs = static_cast<hipStream_t>(stream);
+  // SuperPoint of the pass: ev_ext[set] (re-recorded only by the pass that rewrites this block, which view_locate has excluded).  NetVLAD on the lane's second
+  // stream: ev_nv -- a later pass of the lane may have re-recorded it; waiting for that later record is merely later, never earlier
+  HIP_TRY(hipStreamWaitEvent(cs, L.ev_ext[set], 0));
+  if (p->cfg.netvlad && !p->cfg.netvlad_inline) HIP_TRY(hipStreamWaitEvent(cs, L.ev_nv, 0));
+  const float* B = p->block(k, set);
+  const size_t cap = p->cap, r0 = p->left_row(j, 0);
+  out->frames = p->F; out->cap = p->cap; out->desc_dim = p->D; out->netvlad_dim = p->G;
+  out->d_kps_xy = B + p->o_kps + r0 * cap * 2; out->d_scores = B + p->o_scores + r0 * cap; out->d_desc = B + p->o_desc + r0 * cap * p->D;
+  out->d_n_kp = reinterpret_cast<const int32_t*>(B + p->o_cnt) + r0;
+  out->d_netvlad = p->G ? B + p->o_nv + (p->C > 1 ? (size_t)j : 0) * p->G : nullptr;
+  ++L.views[set];
+  return D2FE_OK;
+}
+
+int d2fe_pipe_device_release(d2fe_pipe p, int64_t ticket, void* stream) {
+  if (!p || !stream) return pipe_fail(D2FE_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(p->mu);
+  HIP_TRY(hipSetDevice(p->parent->cfg.device_id));
+  int k, set, j;
+  const int rc = view_locate(p, ticket, false, &k, &set, &j);
+  if (rc) return rc;
+  auto& L = p->lanes[k];
+  if (L.views[set] <= 0) return pipe_fail(D2FE_ERR_INVALID, "no device view of this ticket's block is outstanding");
+  // several consumers may share a block (coalesced submits): the event is re-recorded by each release; the lane waits for the last record, and consumers that
+  // release on DIFFERENT streams must order those streams themselves (documented: one consumer stream per pipe)
+  HIP_TRY(hipEventRecord(L.ev_rel[set], static_cast<hipStream_t>(stream)));
+  L.rel_pending[set] = true;
+  --L.views[set];
   return D2FE_OK;
 }
 

@@ -83,3 +83,23 @@ def synthetic_netvlad_pca(out_dims=1024, seed=99):
     comp = rng.normal(0, 1.0 / np.sqrt(NETVLAD_DIM), size=(out_dims, NETVLAD_DIM)).astype(np.float32)
     mean = rng.normal(0, 0.002, size=(NETVLAD_DIM,)).astype(np.float32)
     return comp, mean
+
+
+def arch_flops(depth_multiplier=0.35, H=480, W=640, head=False):
+    """Algorithmic FLOPs (2 x MACs) of one image through the stand-in's TRUNK at this width (TF "SAME" strided layers: ceil division): 0.666 GFLOP at 0.35 and
+    640 x 480 (bench.py's NetVLAD roofline objects use 0.6626, the figure of rounds 2-4); head=True adds the NetVLAD head's pre-projection, soft-assignment and
+    residual aggregation (0.103 GFLOP)."""
+    h, w = H, W
+    macs = 0
+    for l in mobilenetvlad_arch(depth_multiplier):
+        if l["stride"] == 2:
+            h, w = (h + 1) // 2, (w + 1) // 2
+        if l["kind"] == "conv":
+            macs += h * w * l["cout"] * 9 * l["cin"]
+        elif l["kind"] == "dw":
+            macs += h * w * l["cin"] * 9
+        else:
+            macs += h * w * l["cin"] * l["cout"]
+    if head:
+        macs += h * w * (1280 * NETVLAD_D + 2 * NETVLAD_K * NETVLAD_D)      # pre-projection, soft-assignment logits, residual aggregation
+    return 2.0 * macs

@@ -165,3 +165,135 @@ class QuadSwarm:
         fe.match_batch_device(c.desc.data_ptr(), self.gath.data_ptr(), self.a_off.data_ptr(), self.b_off.data_ptr(), self.a_cnt.data_ptr(),
                               self.b_cnt.data_ptr(), self.NP, 256, cap, self.mq.data_ptr(), self.mt.data_ptr(), self.md.data_ptr(), self.mn.data_ptr(),
                               mode=0, ratio=self.ratio, radius=-1.0, stream=st)
+
+
+class PipeExchange:
+    """The cross-agent exchange of one rank BEHIND a frames-in-flight pipe (d2slam_amd.api.StereoPipe, include/d2fe.h d2fe_pipe_*): the stand-in for the reference's
+    broadcast of the frame it has just extracted (loop_net.cpp:24-87) and trackRemoteFrames on the receivers (d2featuretracker.cpp:237-310), as ONE sequence per
+    submit on a stream of its own --
+
+        d2fe_pipe_device_view(ticket)         this stream waits for the ticket's SuperPoint + NetVLAD; device pointers into the lane's result block
+        pack_blocks(_int8)                    one fixed-capacity block per left frame
+        ONE all-gather                        RCCL over xGMI (backend "nccl"); gloo in the tests
+        [int8: decode]  counts  NetVLAD gate  getMatchedPrevKeyframe's threshold on the device (d2featuretracker.cpp:185-203)
+        ONE matcher launch                    L_f of this rank against the frame with the same time index of every other rank; the a side is read in place in the
+                                              lane's block, the b side in place in the gathered blocks (row-block decomposition, no second exchange)
+        d2fe_pipe_device_release(ticket)      the lane may write that block again once this stream got here
+        D2H of the cross-agent match lists    into a ring of pinned slots; an event per slot
+
+    -- so the N > 1 step IS the N = 1 step (the pipe: host frames in, host results out, `lanes` submits in flight) plus this sequence beside it; the lanes'
+    convolutions never wait for the collective.  enqueue() is called one submit BEHIND the pipe (after submit(i): enqueue(ticket i-1)), which keeps a host-blocking
+    collective (gloo) from starving the device."""
+
+    def __init__(self, torch, fe, pipe, dev, world, rank, F, cap, netvlad_dim, exchange="fp32", gate_thres=0.8, ratio=0.8, slots=4, group=None):
+        assert exchange in ("fp32", "int8", "int8-renorm256") and world > 1
+        self.torch, self.fe, self.pipe, self.world, self.rank, self.F, self.cap, self.G = torch, fe, pipe, world, rank, F, cap, netvlad_dim
+        self.exchange, self.group, self.thres, self.ratio = exchange, group, gate_thres, ratio
+        self.int8 = exchange.startswith("int8")
+        self.renorm = 1 if exchange == "int8-renorm256" else 0
+        self.BLK = block_words(cap, netvlad_dim)
+        self.BLKB = block_bytes_int8(cap, netvlad_dim)
+        self.block_bytes = self.BLKB if self.int8 else 4 * self.BLK
+        rows_per_block = self.BLK // 256
+        f32, i32, i64 = torch.float32, torch.int32, torch.int64
+        self.stream = torch.cuda.Stream(device=dev)
+        self.blocks = torch.zeros((F, self.BLK), dtype=f32, device=dev)
+        self.gath = torch.zeros((world, F, self.BLK), dtype=f32, device=dev)
+        self.gath_i32 = self.gath.view(i32).view(world * F, self.BLK)
+        if self.int8:
+            assert (cap * 256 + netvlad_dim + cap * 8) % 4 == 0
+            self.blocks_q = torch.zeros((F, self.BLKB), dtype=torch.int8, device=dev)
+            self.gath_q = torch.zeros((world, F, self.BLKB), dtype=torch.int8, device=dev)
+            self.own_n = self.blocks_q.view(i32).view(F, self.BLKB // 4)[:, (cap * 256 + netvlad_dim + cap * 8) // 4]
+        else:
+            self.own_n = self.blocks.view(i32).view(F, self.BLK)[:, block_field_offset(cap, netvlad_dim, "n")]
+        self.n_off = block_field_offset(cap, netvlad_dim, "n"); self.g_off = block_field_offset(cap, netvlad_dim, "netvlad")
+        a_off, b_off, qf, rb = [], [], [], []
+        for r in range(world):
+            if r == rank:
+                continue
+            for f in range(F):
+                a_off.append(f * cap); b_off.append((r * F + f) * rows_per_block); qf.append(f); rb.append(r * F + f)
+        self.NR = len(a_off)
+        t = lambda x, dt: torch.tensor(x, dtype=dt, device=dev)
+        self.a_off, self.b_off = t(a_off, i32), t(b_off, i32)
+        self.q_frame64, self.rem_blk64 = t(qf, i64), t(rb, i64)
+        self.gate_q, self.gate_db = t(qf, i32), t(rb, i32)
+        NR = self.NR
+        self.a_cnt = torch.zeros(NR, dtype=i32, device=dev); self.b_cnt = torch.zeros(NR, dtype=i32, device=dev)
+        self.mq = torch.zeros((NR, cap), dtype=i32, device=dev); self.mt = torch.zeros((NR, cap), dtype=i32, device=dev)
+        self.md = torch.zeros((NR, cap), dtype=f32, device=dev); self.mn = torch.zeros(NR, dtype=i32, device=dev)
+        self.gate_pass = torch.zeros(NR, dtype=i32, device=dev); self.gate_n = torch.zeros(1, dtype=i32, device=dev)
+        self.sims = torch.zeros(NR, dtype=f32, device=dev)
+        # ring of pinned result slots: cross-agent match lists, counts, gate decisions
+        self.slots = []
+        for _ in range(slots):
+            self.slots.append({"mq": torch.empty((NR, cap), dtype=i32).pin_memory(), "mt": torch.empty((NR, cap), dtype=i32).pin_memory(),
+                               "md": torch.empty((NR, cap), dtype=f32).pin_memory(), "mn": torch.empty(NR, dtype=i32).pin_memory(),
+                               "gate_pass": torch.empty(NR, dtype=i32).pin_memory(), "gate_n": torch.empty(1, dtype=i32).pin_memory(),
+                               "done": torch.cuda.Event(), "ev": None})
+        self.d2h_bytes = 4 * (3 * NR * cap + 2 * NR + 1)
+        self.timing = True
+        self.timeline = []          # per enqueue: 6 timing events on the exchange stream
+
+    def enqueue(self, ticket, slot):
+        """the whole sequence for one submitted ticket, asynchronous on the exchange stream (a host-blocking backend blocks in the all-gather only)"""
+        torch, fe, F, cap, G, X = self.torch, self.fe, self.F, self.cap, self.G, self.stream
+        st = X.cuda_stream
+        S = self.slots[slot]
+        with torch.cuda.stream(X):
+            v = self.pipe.device_view(ticket, st)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if self.timing else None
+            mark = (lambda i: ev[i].record(X)) if ev else (lambda i: None)
+            mark(0)
+            if self.int8:
+                fe.pack_blocks_int8_device(v.d_desc, v.d_kps_xy, v.d_n_kp, v.d_netvlad, 0, 1, F, cap, G, self.blocks_q.data_ptr(), stream=st)
+                mark(1)
+                all_gather_blocks(self.gath_q, self.blocks_q, self.group)
+                mark(2)
+                fe.unpack_blocks_int8_device(self.gath_q.data_ptr(), self.world * F, cap, G, self.gath.data_ptr(), renorm=self.renorm, stream=st)
+            else:
+                fe.pack_blocks_device(v.d_desc, v.d_kps_xy, v.d_scores, v.d_n_kp, v.d_netvlad, 0, 1, F, cap, G, self.blocks.data_ptr(), stream=st)
+                mark(1)
+                all_gather_blocks(self.gath, self.blocks, self.group)
+                mark(2)
+            torch.index_select(self.own_n, 0, self.q_frame64, out=self.a_cnt)
+            self.b_cnt.copy_(self.gath_i32[self.rem_blk64, self.n_off])
+            if G:
+                self.gate_n.zero_()
+                # all-to-all mode (BASELINE configs[3]/[4]): every pair is matched; the reference's gate is evaluated and counted
+                fe.gate_pairs_device(v.d_netvlad, G, self.gath.data_ptr() + 4 * self.g_off, self.BLK, G, self.gate_q.data_ptr(), self.gate_db.data_ptr(),
+                                     self.NR, self.thres, d_pass=self.gate_pass.data_ptr(), d_sims=self.sims.data_ptr(), d_n_pass=self.gate_n.data_ptr(), stream=st)
+            mark(3)
+            fe.match_batch_device(v.d_desc, self.gath.data_ptr(), self.a_off.data_ptr(), self.b_off.data_ptr(), self.a_cnt.data_ptr(), self.b_cnt.data_ptr(),
+                                  self.NR, 256, cap, self.mq.data_ptr(), self.mt.data_ptr(), self.md.data_ptr(), self.mn.data_ptr(),
+                                  mode=0, ratio=self.ratio, radius=-1.0, stream=st)
+            mark(4)
+            self.pipe.device_release(ticket, st)
+            for k in ("mq", "mt", "md", "mn", "gate_pass", "gate_n"):
+                S[k].copy_(getattr(self, k), non_blocking=True)
+            mark(5)
+            S["done"].record(X)
+        S["ev"] = ev
+        S["ticket"] = ticket
+
+    def collect(self, slot):
+        """blocks until the slot's results are in host memory; returns the slot (pinned tensors) and appends its timeline"""
+        S = self.slots[slot]
+        S["done"].synchronize()
+        if S["ev"]:
+            e = S["ev"]
+            self.timeline.append([e[i].elapsed_time(e[i + 1]) for i in range(5)])
+            S["ev"] = None
+        return S
+
+    def timeline_ms(self):
+        import numpy as np
+        if not self.timeline:
+            return None
+        t = np.array(self.timeline)
+        names = ("pack_blocks", "all_gather", "decode_counts_gate", "match_remote", "release_and_d2h")
+        out = {n: round(float(np.median(t[:, i])), 4) for i, n in enumerate(names)}
+        out["all_gather_max"] = round(float(t[:, 1].max()), 4)
+        out["exchange_stream_busy_ms_per_submit"] = round(float(np.median(t.sum(1))), 4)
+        return out

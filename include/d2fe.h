@@ -234,8 +234,9 @@ D2FE_API int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, 
  * (D2FeatureTracker::trackLocalFrames, d2featuretracker.cpp:403-456,658-695).  A pipe runs exactly that work for `frames` stereo
  * frames per submit with up to `lanes` submits in flight: d2fe_pipe_submit only enqueues (H2D, both networks, ONE matcher launch,
  * ONE D2H, on the lane's own streams), d2fe_pipe_wait returns pointers into the lane's pinned result block.  Results are bit-identical
- * to d2fe_extract_all_batch + d2fe_match_knn on the same frames.  A pipe borrows the handle's packed weights: keep the handle alive
- * and do not reload weights while a pipe exists.  One submitting thread per pipe; d2fe_pipe_wait may be called from a second thread (the reference's image
+ * to d2fe_extract_all_batch + d2fe_match_knn on the same frames.  A pipe borrows the handle's packed weights: while a pipe exists d2fe_destroy
+ * of its handle releases nothing (d2fe_last_error says why) and d2fe_load_* / d2fe_set_*_pca return D2FE_ERR_INVALID -- destroy the pipes first.  The first error of a
+ * submit or wait is final for the pipe: every later call returns it (a half-enqueued pass cannot be built on); destroy the pipe and create a new one.  One submitting thread per pipe; d2fe_pipe_wait may be called from a second thread (the reference's image
  * callback and its tracker are two threads): the pipe serialises its own bookkeeping and does not hold the lock while a wait blocks.  The caller bounds the
  * frames between its two threads (a queue of at most lanes * coalesce tickets is always safe), as the result blocks are a ring of 2 * lanes passes. */
 typedef struct d2fe_pipe_s* d2fe_pipe;
@@ -300,6 +301,25 @@ D2FE_API int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* r
 /* Blocks until the ticket's frame is complete on the host (launching its pass first if coalescing still holds it back).  Tickets may be waited
  * for in any order, each within 2 * lanes passes (a pass = `coalesce` submits). */
 D2FE_API int d2fe_pipe_wait(d2fe_pipe p, int64_t ticket, d2fe_pipe_result* out);
+
+/* Device-side consumers of a ticket's results: the cross-agent exchange (pack -> all-gather -> gate -> remote matching; the reference broadcasts
+ * the frame it has just extracted, loop_net.cpp:24-87, d2featuretracker.cpp:237-310) runs on a stream of its OWN, behind the extraction of the ticket and beside the
+ * pipe's later passes -- the lanes' convolutions never wait for a collective.
+ *   d2fe_pipe_device_view     launches the ticket's pass if coalescing still holds it back, makes `stream` (a hipStream_t, not NULL) wait for the ticket's SuperPoint and
+ *                             NetVLAD results (not for its matcher or its D2H) and returns DEVICE pointers into the lane's result block: the same arrays, in the same
+ *                             row order, as d2fe_pipe_result.  Read-only.  Valid until the matching release, at most 2 * lanes passes.
+ *   d2fe_pipe_device_release  everything queued on `stream` so far is what read the view: the lane's next write of that block waits for it (an event, no host wait).
+ * A block whose view has not been released when its lane comes round again (2 * lanes passes later) fails that submit with D2FE_ERR_INVALID.  Not available with netvlad_group > 1. */
+typedef struct {
+  int32_t frames, cap, desc_dim, netvlad_dim;
+  const float* d_kps_xy;    /* [2 frames][cap][2] */
+  const float* d_scores;    /* [2 frames][cap] */
+  const float* d_desc;      /* [2 frames][cap][desc_dim] */
+  const int32_t* d_n_kp;    /* [2 frames] */
+  const float* d_netvlad;   /* [frames][netvlad_dim] or NULL */
+} d2fe_pipe_device_result;
+D2FE_API int d2fe_pipe_device_view(d2fe_pipe p, int64_t ticket, void* stream, d2fe_pipe_device_result* out);
+D2FE_API int d2fe_pipe_device_release(d2fe_pipe p, int64_t ticket, void* stream);
 
 /* Half-image filter for quadcam neighbour matching.  Replaces getFeatureHalfImg
  * (d2featuretracker.cpp:1051-1075): map[c] = source index of the c-th kept keypoint; returns count in *n_out. */

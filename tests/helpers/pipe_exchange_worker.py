@@ -1,0 +1,122 @@
+"""One rank of the world-2 test of the exchange BEHIND the pipe (tests/test_swarm_gpu.py launches two of these on ONE GPU with the gloo backend): the path
+`bench.py --gpus N` times.  Every rank drives a frames-in-flight pipe (d2fe_pipe_*) over its own frames and, one submit behind it, swarm.PipeExchange on a stream
+of its own (d2fe_pipe_device_view -> pack -> all-gather -> gate -> remote matchKNN -> d2fe_pipe_device_release -> D2H).  Checked per submit: the cross-agent match
+lists and the gate decisions against the CPU oracle on the descriptors both ranks delivered (the local ones from d2fe_pipe_wait, the remote ones gathered over the
+host), and that the pipe's own results are untouched by the exchange running beside it.  PIPE_XCHG_MODE = fp32 | int8 | int8-renorm256.  Exit code 0 = all held."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from d2slam_amd import api, netvlad as nvm, swarm
+    from d2slam_amd.synth import synth_stereo
+    from d2slam_amd.weights import synthetic_superpoint_weights
+    from oracle import oracle as orc
+
+    mode = os.environ.get("PIPE_XCHG_MODE", "fp32")
+    rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    H, W, CAP, F, STEPS, LANES = 120, 160, 60, 2, 5, 2
+    w = synthetic_superpoint_weights(dustbin_bias=7.5)
+    nv = nvm.synthetic_netvlad_weights()
+
+    def frames(r, step):
+        # both ranks look at the same scenes (seed from step and f) with rank-specific noise, so that cross-agent matches exist
+        L, R = [], []
+        for f in range(F):
+            l, rr = synth_stereo(H, W, seed=300 + 7 * step + f)
+            rng = np.random.RandomState(1000 * r + 31 * step + f)
+            L.append(np.clip(l.astype(np.int32) + rng.randint(-2, 3, l.shape), 0, 255).astype(np.uint8)); R.append(rr)
+        return np.stack(L), np.stack(R)
+
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2 * F, precision=api.PREC_F32_WINO))
+    fe.load_superpoint(w); fe.load_netvlad(nv)
+    G = fe.netvlad_dim
+    pipe = api.StereoPipe(fe, lanes=LANES, frames=F, width=W, height=H, cap=CAP, netvlad=True)
+    NS = LANES + 2
+    x = swarm.PipeExchange(torch, fe, pipe, dev, world, rank, F, CAP, G, exchange=mode, gate_thres=0.8, ratio=0.8, slots=NS)
+    assert x.NR == (world - 1) * F
+
+    tk, outs = [], []
+    enq = 0
+    for i in range(STEPS):
+        l, r = frames(rank, i)
+        tk.append(pipe.submit(l, r))
+        while enq <= i - 1:                       # one submit behind the pipe
+            x.enqueue(tk[enq], enq % NS); enq += 1
+        if i >= LANES:
+            j = i - LANES
+            o = pipe.wait(tk[j]); S = x.collect(j % NS)
+            outs.append((j, {k: (v.copy() if v is not None else None) for k, v in o.items()}, {k: S[k].numpy().copy() for k in ("mq", "mt", "md", "mn", "gate_pass", "gate_n")}))
+    while enq < STEPS:
+        x.enqueue(tk[enq], enq % NS); enq += 1
+    for j in range(max(0, STEPS - LANES), STEPS):
+        o = pipe.wait(tk[j]); S = x.collect(j % NS)
+        outs.append((j, {k: (v.copy() if v is not None else None) for k, v in o.items()}, {k: S[k].numpy().copy() for k in ("mq", "mt", "md", "mn", "gate_pass", "gate_n")}))
+    assert len(outs) == STEPS and x.timeline_ms()["pack_blocks"] > 0
+
+    # a reference run WITHOUT the exchange: the pipe's own results must be the same bits
+    pipe2 = api.StereoPipe(fe, lanes=LANES, frames=F, width=W, height=H, cap=CAP, netvlad=True)
+    for i in range(STEPS):
+        l, r = frames(rank, i)
+        o2 = pipe2.wait(pipe2.submit(l, r))
+        o = [q for q in outs if q[0] == i][0][1]
+        for k in ("kps_xy", "desc", "n_kp", "netvlad", "lr_q", "lr_t", "lr_n"):
+            assert np.array_equal(o[k], o2[k]), (i, k)
+    pipe2.close()
+
+    n_cross = 0
+    for j, o, S in outs:
+        # what every rank delivered for this step (left frames only), gathered over the host
+        mine = {"n": o["n_kp"][:F].copy(), "desc": o["desc"][:F].copy(), "nv": o["netvlad"].copy()}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        p = 0
+        for r in range(world):
+            if r == rank:
+                continue
+            for f in range(F):
+                na, nb = int(mine["n"][f]), int(allr[r]["n"][f])
+                da, db = mine["desc"][f, :na], allr[r]["desc"][f, :nb]
+                ga, gb = mine["nv"][f], allr[r]["nv"][f]
+                if mode != "fp32":
+                    # the remote side went over the wire as int8 and was decoded as the reference's LCM constructor does (renorm 0) or per 256 floats (renorm 1)
+                    qb = orc.quant_int8(db.reshape(-1)) if nb else np.zeros(0, np.int8)
+                    if mode == "int8":
+                        db = orc.dequant_int8(qb, nb).reshape(nb, 256) if nb else db
+                    else:
+                        xq = (qb.astype(np.float64) / 127.0).astype(np.float32).reshape(nb, 256)
+                        db = (xq / np.linalg.norm(xq, axis=1, keepdims=True)).astype(np.float32)
+                    gb = orc.dequant_int8(orc.quant_int8(gb, double_max=True), -1)
+                rq, rt, rd = orc.match_knn(da, db, 0.8)
+                n = int(S["mn"][p])
+                if mode == "int8-renorm256":      # the renormalisation divides in float on the device: distances to ~1e-7, indices exact
+                    assert n == len(rq) and np.array_equal(S["mq"][p, :n], rq) and np.array_equal(S["mt"][p, :n], rt) and np.abs(S["md"][p, :n] - rd).max(initial=0) <= 1e-6, (j, r, f)
+                else:
+                    assert n == len(rq), (j, r, f, n, len(rq))
+                    assert np.array_equal(S["mq"][p, :n], rq) and np.array_equal(S["mt"][p, :n], rt) and np.array_equal(S["md"][p, :n], rd), (j, r, f)
+                sim = float(np.dot(ga.astype(np.float32), gb.astype(np.float32)))
+                if abs(sim - 0.8) > 1e-3:
+                    assert bool(S["gate_pass"][p]) == (sim >= 0.8), (j, r, f, sim)
+                n_cross += n
+                p += 1
+        assert p == x.NR
+    if mode != "int8":        # the reference's own int8 decode leaves most rows un-normalised: no matches survive
+        assert n_cross > 0, "the two ranks look at the same scenes: cross-agent matches must exist"
+    pipe.close(); fe.close()
+    dist.barrier()
+    print("rank %d OK: %d submits, %d cross-agent matches, exchange %s" % (rank, STEPS, n_cross, mode), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

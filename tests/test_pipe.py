@@ -173,6 +173,57 @@ def test_handle_with_live_pipes_refuses_destroy_and_reload():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("coal", [1, 2])
+def test_pipe_device_view_feeds_a_consumer_stream(coal):
+    """d2fe_pipe_device_view / _release (the hook the cross-agent exchange hangs on): a consumer on its OWN stream packs exchange blocks straight out of the lane's
+    result block -- no host trip, no wait on the host -- and what it packed equals the ticket's host results bit for bit; the lane's next write of that block waits
+    for the release; a view that is never released fails the submit that would overwrite it (and that failure is final for the pipe)."""
+    import torch
+    from d2slam_amd import api, netvlad as nvm
+    from d2slam_amd.weights import synthetic_superpoint_weights
+    dev = torch.device("cuda", 0)
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2, precision=api.PREC_F32_WINO, keypoint_threshold=0.005))
+    fe.load_superpoint(synthetic_superpoint_weights(dustbin_bias=7.5)); fe.load_netvlad(nvm.synthetic_netvlad_weights())
+    G = fe.netvlad_dim
+    BLK = api.block_words(CAP, G)
+    off = {f: api.block_field_offset(CAP, G, f) for f in ("desc", "kps", "scores", "netvlad", "n")}
+    fr = _frames(8)
+    pipe = api.StereoPipe(fe, lanes=2, frames=1, width=W, height=H, cap=CAP, netvlad=True, coalesce=coal)
+    X = torch.cuda.Stream(device=dev)
+    blocks = [torch.zeros((1, BLK), dtype=torch.float32, device=dev) for _ in fr]
+    tk = []
+    for i, (l, r) in enumerate(fr):
+        tk.append(pipe.submit(l[None], r[None]))
+        if i >= 1:        # one submit behind, as the exchange does it; nothing here waits on the host
+            j = i - 1
+            v = pipe.device_view(tk[j], X.cuda_stream)
+            assert v.frames == 1 and v.cap == CAP and v.netvlad_dim == G
+            fe.pack_blocks_device(v.d_desc, v.d_kps_xy, v.d_scores, v.d_n_kp, v.d_netvlad, 0, 1, 1, CAP, G, blocks[j].data_ptr(), stream=X.cuda_stream)
+            pipe.device_release(tk[j], X.cuda_stream)
+        if i >= 3:
+            o = pipe.wait(tk[i - 3])
+            X.synchronize()
+            b = blocks[i - 3].cpu().numpy()[0]
+            n = int(o["n_kp"][0])
+            assert int(b.view(np.int32)[off["n"]]) == n and n > 10
+            np.testing.assert_array_equal(b[off["desc"]:off["desc"] + n * 256].reshape(n, 256), o["desc"][0, :n])
+            np.testing.assert_array_equal(b[off["kps"]:off["kps"] + 2 * n].reshape(n, 2), o["kps_xy"][0, :n])
+            np.testing.assert_array_equal(b[off["netvlad"]:off["netvlad"] + G], o["netvlad"][0])
+    with pytest.raises(api.D2FEError):
+        pipe.device_release(tk[-1], X.cuda_stream)               # no view outstanding
+    with pytest.raises(api.D2FEError):
+        pipe.device_view(tk[0], X.cuda_stream)                   # its block has been rewritten since
+    # a view that is never released: the pass that comes round to its block (2 * lanes passes later) is refused, and the pipe stays failed
+    pipe.device_view(tk[-1], X.cuda_stream)
+    with pytest.raises(api.D2FEError):
+        for l, r in fr + fr:
+            pipe.submit(l[None], r[None])
+    with pytest.raises(api.D2FEError):
+        pipe.submit(fr[0][0][None], fr[0][1][None])
+    pipe.close(); fe.close()
+
+
+@pytest.mark.gpu
 def test_pipe_waits_in_any_order_twice_and_close_with_passes_in_flight():
     """Tickets may be waited for in any order and more than once (the result block stays valid for 2 * lanes passes); a pipe may be closed while passes are in
     flight; a ticket whose block has been reused is refused, not served stale."""

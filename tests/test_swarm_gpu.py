@@ -37,6 +37,16 @@ def test_world2_cross_agent_matches_equal_oracle():
     assert r.stdout.count(" OK: ") == 2, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("mode", ["fp32", "int8", "int8-renorm256"])
+def test_world2_exchange_behind_the_pipe_equals_oracle(mode):
+    """The path `bench.py --gpus N` times (round 5): every rank's frames-in-flight pipe with swarm.PipeExchange on a stream of its own one submit behind it
+    (d2fe_pipe_device_view -> pack -> all-gather -> gate -> remote matchKNN -> d2fe_pipe_device_release -> D2H): cross-agent match lists and gate decisions against
+    the oracle per submit, the pipe's own results bit-identical with and without the exchange beside it."""
+    r = _torchrun([os.path.join(ROOT, "tests", "helpers", "pipe_exchange_worker.py")], {"PIPE_XCHG_MODE": mode})
+    assert r.returncode == 0, _rank_errors(r)
+    assert r.stdout.count(" OK: ") == 2, r.stdout[-2000:]
+
+
 @pytest.mark.parametrize("mode", ["gated", "all2all"])
 def test_world2_quadcam_swarm_equals_oracle(mode):
     """BASELINE configs[4] on one GPU: two quadcam agents, one block per view, the FOURCORNER_FISHEYE gate, view x view matching."""
@@ -189,9 +199,14 @@ def test_bench_gpus2_one_frame_per_step_timeline():
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["config"]["frames_per_step_per_gpu"] == 1 and j["config"]["match_pairs_per_step_per_gpu"] == 3
     tl = j["exchange"]["step_timeline_ms"]
-    assert 0 < tl["pack_blocks"] <= 0.10 and 0 < tl["decode_counts_gate"] <= 0.25, tl           # budget: 0.35 ms of a ~1 ms step, without the collective
-    assert tl["all_gather"] > 0
+    # budget: 0.35 ms of a ~1 ms step, without the collective (round 5: the exchange stream runs BESIDE the lanes' launches of the next submit and beside
+    # the other rank's work on the same GPU, so an entry is a wall time on a shared device: twice the solo budget)
+    assert 0 < tl["pack_blocks"] <= 0.20 and 0 < tl["decode_counts_gate"] <= 0.50, tl
+    assert tl["all_gather"] > 0 and tl["match_remote"] > 0
     assert j["netvlad_gate"]["pairs"] == 1
+    # the N > 1 step is the N = 1 step (the pipe) plus the exchange stream: same API string, and the cost of the exchange is reported against the same ranks without it
+    assert j["config"]["same_path_for_every_n_gpus"] is True and "d2fe_pipe_submit" in j["config"]["api"]
+    assert j["exchange"]["ms_per_step_without_exchange"] > 0 and "overlapped" in j["exchange"]
 
 
 def test_bench_int8_exchange_runs_under_gloo():
