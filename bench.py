@@ -733,6 +733,8 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
         if netvlad and nv_n:
             res["roofline_nv"] = netvlad_roofline(nv_ms / nv_n, F, "HIP events around the whole sequence on the lane's NetVLAD stream, which runs BESIDE that lane's SuperPoint launches "
                                                   "(the figure includes what the two sequences cost each other)", nv_flop_per_img)
+    if xch:
+        xch.close()
     pipe.close(); fe.close()
     return res
 
@@ -954,10 +956,14 @@ def run_quadcam(args, torch, api, weights, dev, local_rank, world, rank=0):
     qs = swarm.QuadSwarm(chain, torch, dev, world, rank, fe.netvlad_dim, NETVLAD_GATE, mode=os.environ.get("D2FE_QUAD_SWARM_MODE", "all2all"),
                          exchange=args.exchange) if world > 1 else None
 
+    side = torch.cuda.Stream(device=dev) if world > 1 else None
+
     def step():
         chain.step(raw, RH, RW, maps, st)
         if qs:
-            qs.step(st)        # configs[4]: one block per view, ONE all-gather, the quadcam NetVLAD gate, view x view cross-agent matchKNN
+            # configs[4]: one block per view, ONE all-gather, the quadcam NetVLAD gate, view x view cross-agent matchKNN -- on a stream of its own behind a
+            # snapshot of the step's outputs, beside the next step's convolutions (the main stream waits for the 1.7 MB snapshot, never for the collective)
+            qs.step_overlapped(main, side)
 
     def barrier():
         if world > 1:
@@ -1006,7 +1012,8 @@ def run_quadcam(args, torch, api, weights, dev, local_rank, world, rank=0):
         dp = qs.dir_prev.cpu().numpy()
         out["cross_agent"] = {"jobs_per_step_per_gpu": qs.njobs, "view_pairs_per_step_per_gpu": qs.NP, "mode": qs.mode,
                               "avg_matches_per_view_pair": round(qs.mn.float().mean().item(), 2),
-                              "wire_precision": qs.exchange, "block_bytes": qs.block_bytes, "all_gather_bytes_received_per_step": qs.block_bytes * NI * (world - 1)}
+                              "wire_precision": qs.exchange, "block_bytes": qs.block_bytes, "all_gather_bytes_received_per_step": qs.block_bytes * NI * (world - 1),
+                              "stream": "its own, behind a snapshot of the step's outputs (QuadSwarm.step_overlapped): the main stream never waits for the collective"}
         out["netvlad_gate"] = {"jobs": qs.njobs, "passing_netvlad_gate": int(qs.n_pass.item()), "threshold": NETVLAD_GATE,
                                "rotation_histogram_dir_prev": {str(k): int((dp == k).sum()) for k in (-1, 0, 1, 2, 3)},
                                "rule": "remote view 2 vs local views 2,3,0,1 in order, first similarity >= threshold (d2featuretracker.cpp:212-233)"}

@@ -141,30 +141,49 @@ class QuadSwarm:
         self.n_pass = torch.zeros(1, dtype=i32, device=dev)
         self.n_off = block_field_offset(cap, netvlad_dim, "n"); self.g_off = block_field_offset(cap, netvlad_dim, "netvlad")
 
-    def step(self, st, group=None):
-        """pack -> ONE all-gather -> gate -> cross-agent matching, all ordered on the current torch stream (raw handle `st`)."""
+    def step(self, st, group=None, src=None):
+        """pack -> ONE all-gather -> gate -> cross-agent matching, all ordered on the current torch stream (raw handle `st`).  src: the (desc, pts, scores, cnt,
+        gdesc) tensors the exchange reads -- the chain's own (default) or a snapshot of them (step_overlapped)."""
         c, fe, torch = self.chain, self.chain.fe, self.torch
         Q, NI, cap, G = c.Q, c.NI, c.cap, self.G
+        desc, pts, scores, cnt, gdesc = src or (c.desc, c.pts, c.scores, c.cnt, c.gdesc)
         if self.exchange.startswith("int8"):
-            fe.pack_blocks_int8_device(c.desc.data_ptr(), c.pts.data_ptr(), c.cnt.data_ptr(), c.gdesc.data_ptr(), 0, 1, NI, cap, G,
+            fe.pack_blocks_int8_device(desc.data_ptr(), pts.data_ptr(), cnt.data_ptr(), gdesc.data_ptr(), 0, 1, NI, cap, G,
                                        self.blocks_q.data_ptr(), stream=st)
             all_gather_blocks(self.gath_q, self.blocks_q, group)
             fe.unpack_blocks_int8_device(self.gath_q.data_ptr(), self.world * NI, cap, G, self.gath.data_ptr(), renorm=self.renorm, stream=st)
         else:
-            fe.pack_blocks_device(c.desc.data_ptr(), c.pts.data_ptr(), c.scores.data_ptr(), c.cnt.data_ptr(), c.gdesc.data_ptr(), 0, 1, NI, cap, G,
+            fe.pack_blocks_device(desc.data_ptr(), pts.data_ptr(), scores.data_ptr(), cnt.data_ptr(), gdesc.data_ptr(), 0, 1, NI, cap, G,
                                   self.blocks.data_ptr(), stream=st)
             all_gather_blocks(self.gath, self.blocks, group)
         if self.NP == 0:
             return
-        torch.index_select(c.cnt, 0, self.a_row, out=self.a_cnt)
+        torch.index_select(cnt, 0, self.a_row, out=self.a_cnt)
         self.b_cnt.copy_(self.gath_i32[self.rem_blk, self.n_off])
         self.n_pass.zero_()
-        fe.quad_gate_device(c.gdesc.data_ptr(), G, self.gath.data_ptr() + 4 * self.g_off, self.BLK, G, self.job_loc.data_ptr(),
+        fe.quad_gate_device(gdesc.data_ptr(), G, self.gath.data_ptr() + 4 * self.g_off, self.BLK, G, self.job_loc.data_ptr(),
                             self.job_rem.data_ptr(), Q, Q, self.njobs, self.thres, d_dir_prev=self.dir_prev.data_ptr(), d_sims=self.sims.data_ptr(),
                             d_cnt_inout=self.a_cnt.data_ptr() if self.mode == "gated" else None, d_n_pass=self.n_pass.data_ptr(), stream=st)
-        fe.match_batch_device(c.desc.data_ptr(), self.gath.data_ptr(), self.a_off.data_ptr(), self.b_off.data_ptr(), self.a_cnt.data_ptr(),
+        fe.match_batch_device(desc.data_ptr(), self.gath.data_ptr(), self.a_off.data_ptr(), self.b_off.data_ptr(), self.a_cnt.data_ptr(),
                               self.b_cnt.data_ptr(), self.NP, 256, cap, self.mq.data_ptr(), self.mt.data_ptr(), self.md.data_ptr(), self.mn.data_ptr(),
                               mode=0, ratio=self.ratio, radius=-1.0, stream=st)
+
+    def step_overlapped(self, main, side, group=None):
+        """The exchange of the chain step just queued on `main`, on the stream `side`: a snapshot of what the exchange reads (current views' descriptors, points,
+        scores, counts, NetVLAD descriptors: 1.7 MB at 4 x 4 views) is taken on `side` as soon as the chain step is through, `main` waits for THAT only, and pack ->
+        all-gather -> gate -> view x view matchKNN run on `side` beside the next chain step's convolutions (with RCCL; a host-blocking backend serialises)."""
+        c, torch, NI = self.chain, self.torch, self.chain.NI
+        if not hasattr(self, "snap"):
+            self.snap = (torch.empty_like(c.desc[:NI]), torch.empty_like(c.pts[:NI]), torch.empty_like(c.scores), torch.empty_like(c.cnt[:NI]), torch.empty_like(c.gdesc))
+            self.ev_chain, self.ev_snap = torch.cuda.Event(), torch.cuda.Event()
+        self.ev_chain.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(self.ev_chain)
+            for dst, srct in zip(self.snap, (c.desc[:NI], c.pts[:NI], c.scores, c.cnt[:NI], c.gdesc)):
+                dst.copy_(srct, non_blocking=True)
+            self.ev_snap.record(side)
+            main.wait_event(self.ev_snap)          # the next chain step overwrites the chain's buffers: it may start once the snapshot exists
+            self.step(side.cuda_stream, group, src=self.snap)
 
 
 class PipeExchange:
@@ -235,9 +254,45 @@ class PipeExchange:
         self.d2h_bytes = 4 * (3 * NR * cap + 2 * NR + 1)
         self.timing = True
         self.timeline = []          # per enqueue: 6 timing events on the exchange stream
+        # A host-blocking backend (gloo: the all-gather is staged through the host and returns when it is complete) would hold the SUBMITTING thread for a full
+        # extraction + host round trip per submit and starve the pipe.  The sequence then runs on a worker thread of its own -- as the reference's LCM handler does
+        # (loop_net.cpp runs beside the front-end thread) -- and enqueue() only posts the ticket.  RCCL collectives are asynchronous: no thread, enqueue() queues
+        # the work directly.  Collectives of the caller's thread (barriers) must not interleave with posted tickets: collect() every slot first (bench.py does)
+        self.dev = dev
+        self.worker = None
+        self.err = None
+        if dist.get_backend(group) != "nccl":
+            import queue, threading
+            self.q = queue.Queue()
+            self.posted = [threading.Event() for _ in range(slots)]
+            self.worker = threading.Thread(target=self._work, daemon=True)
+            self.worker.start()
+
+    def _work(self):
+        self.torch.cuda.set_device(self.dev)
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            try:
+                self._enqueue(*item)
+            except Exception as e:      # noqa: BLE001 -- surfaced by collect()
+                self.err = e
+            self.posted[item[1]].set()
+
+    def close(self):
+        if self.worker:
+            self.q.put(None); self.worker.join(timeout=30); self.worker = None
 
     def enqueue(self, ticket, slot):
-        """the whole sequence for one submitted ticket, asynchronous on the exchange stream (a host-blocking backend blocks in the all-gather only)"""
+        """the whole sequence for one submitted ticket, asynchronous on the exchange stream (host-blocking backend: posted to the worker thread)"""
+        if self.worker:
+            self.posted[slot].clear()
+            self.q.put((ticket, slot))
+        else:
+            self._enqueue(ticket, slot)
+
+    def _enqueue(self, ticket, slot):
         torch, fe, F, cap, G, X = self.torch, self.fe, self.F, self.cap, self.G, self.stream
         st = X.cuda_stream
         S = self.slots[slot]
@@ -280,6 +335,10 @@ class PipeExchange:
     def collect(self, slot):
         """blocks until the slot's results are in host memory; returns the slot (pinned tensors) and appends its timeline"""
         S = self.slots[slot]
+        if self.worker:
+            self.posted[slot].wait()
+        if self.err:
+            raise self.err
         S["done"].synchronize()
         if S["ev"]:
             e = S["ev"]

@@ -112,7 +112,7 @@ def main():
         assert p == x.NR
     if mode != "int8":        # the reference's own int8 decode leaves most rows un-normalised: no matches survive
         assert n_cross > 0, "the two ranks look at the same scenes: cross-agent matches must exist"
-    pipe.close(); fe.close()
+    x.close(); pipe.close(); fe.close()
     dist.barrier()
     print("rank %d OK: %d submits, %d cross-agent matches, exchange %s" % (rank, STEPS, n_cross, mode), flush=True)
     dist.destroy_process_group()

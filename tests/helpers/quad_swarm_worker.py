@@ -66,7 +66,15 @@ def main():
     qs = swarm.QuadSwarm(chain, torch, dev, world, rank, G, thres, mode=mode)
 
     chain.step(raw, RH, RW, maps, s)
-    qs.step(s)
+    if os.environ.get("QUAD_SWARM_OVERLAP") == "1":
+        # the form bench.py times: the exchange on a stream of its own behind a snapshot of the step's outputs, and the NEXT chain step queued right behind it on
+        # the main stream (it overwrites the chain's buffers while the exchange is still reading the snapshot) -- the results checked below are step 1's
+        side = torch.cuda.Stream(device=dev)
+        qs.step_overlapped(torch.cuda.current_stream(dev), side)
+        raw2 = torch.roll(raw, shifts=(5, 9), dims=(1, 2))
+        chain.step(raw2, RH, RW, maps, s)
+    else:
+        qs.step(s)
     torch.cuda.synchronize()
 
     # ---- blocks ------------------------------------------------------------------------------------------------------------------------
@@ -107,7 +115,8 @@ def main():
             rq, rt, rdist = orc.match_knn(ref[(rank, lv)][2], ref[(other, rv)][2], 0.8)
             n = int(mn[p])
             # GPU descriptors differ from the oracle's by <= 1e-6: the match LISTS are compared through the GPU's own descriptors
-            da = chain.desc[lv * Q, :int(chain.cnt[lv * Q].item())].cpu().numpy()
+            sdesc, scnt = (qs.snap[0], qs.snap[3]) if os.environ.get("QUAD_SWARM_OVERLAP") == "1" else (chain.desc, chain.cnt)      # step 1's outputs
+            da = sdesc[lv * Q, :int(scnt[lv * Q].item())].cpu().numpy()
             nb = int(gh[other, rv * Q].view(np.int32)[off["n"]])
             db = gh[other, rv * Q][off["desc"]:off["desc"] + 256 * nb].reshape(nb, 256)
             gq, gt, gd = orc.match_knn(da, db, 0.8)

@@ -45,6 +45,20 @@ def _read_vecs(path, dtypes):
 
 
 @pytest.mark.gpu
+def test_cpp_swarm_two_devices_or_clean_skip(tmp_path):
+    """`swarm_test --two-devices`: the exchange as TWO ranks of one process on devices 0 and 1 (ncclCommInitAll, grouped ncclAllGather) -- a real N > 1 RCCL
+    collective between pack and gate, self-checked (gathered buffers identical on both devices and equal to both agents' packed blocks, symmetric gate
+    similarities and match counts).  On a 1-GPU box the program reports that and exits 77: a skip, not a failure."""
+    exe = _build(tmp_path)
+    res = subprocess.run([exe, "--two-devices"], capture_output=True, text=True, timeout=300)
+    if res.returncode == 77:
+        assert "SKIP" in res.stdout
+        pytest.skip(res.stdout.strip())
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "two devices" in res.stdout
+
+
+@pytest.mark.gpu
 def test_cpp_swarm_sequence_equals_python_path_and_oracle(tmp_path, orc):
     import torch
     from d2slam_amd import api

@@ -211,8 +211,9 @@ def test_pipe_device_view_feeds_a_consumer_stream(coal):
             np.testing.assert_array_equal(b[off["netvlad"]:off["netvlad"] + G], o["netvlad"][0])
     with pytest.raises(api.D2FEError):
         pipe.device_release(tk[-1], X.cuda_stream)               # no view outstanding
-    with pytest.raises(api.D2FEError):
-        pipe.device_view(tk[0], X.cuda_stream)                   # its block has been rewritten since
+    if coal == 1:
+        with pytest.raises(api.D2FEError):
+            pipe.device_view(tk[0], X.cuda_stream)               # 8 passes on a ring of 2 * lanes = 4: its block has been rewritten since
     # a view that is never released: the pass that comes round to its block (2 * lanes passes later) is refused, and the pipe stays failed
     pipe.device_view(tk[-1], X.cuda_stream)
     with pytest.raises(api.D2FEError):

@@ -47,10 +47,11 @@ def test_world2_exchange_behind_the_pipe_equals_oracle(mode):
     assert r.stdout.count(" OK: ") == 2, r.stdout[-2000:]
 
 
-@pytest.mark.parametrize("mode", ["gated", "all2all"])
-def test_world2_quadcam_swarm_equals_oracle(mode):
-    """BASELINE configs[4] on one GPU: two quadcam agents, one block per view, the FOURCORNER_FISHEYE gate, view x view matching."""
-    r = _torchrun([os.path.join(ROOT, "tests", "helpers", "quad_swarm_worker.py")], {"QUAD_SWARM_MODE": mode})
+@pytest.mark.parametrize("mode,overlap", [("gated", "0"), ("all2all", "0"), ("all2all", "1")])
+def test_world2_quadcam_swarm_equals_oracle(mode, overlap):
+    """BASELINE configs[4] on one GPU: two quadcam agents, one block per view, the FOURCORNER_FISHEYE gate, view x view matching; overlap = 1: the exchange on
+    a stream of its own behind a snapshot, with the next chain step overwriting the chain's buffers beside it (QuadSwarm.step_overlapped, what bench.py times)."""
+    r = _torchrun([os.path.join(ROOT, "tests", "helpers", "quad_swarm_worker.py")], {"QUAD_SWARM_MODE": mode, "QUAD_SWARM_OVERLAP": overlap})
     assert r.returncode == 0, _rank_errors(r)
     assert r.stdout.count(" OK: ") == 2, r.stdout[-2000:]
 
