@@ -200,7 +200,9 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
   const bool tail_elsewhere = s_tail && s_tail != s;
   const bool wctr = prec == D2FE_PREC_F32_WINO && h->wino_dynamic;
   if (wctr || !tail_elsewhere)
-    HIP_TRY(hipMemsetAsync(wctr ? h->work_ctrs : h->cand_count, 0, ((wctr ? 64 : 0) + (tail_elsewhere ? 0 : n)) * sizeof(int), s));
+    // the cleared range is padded to a multiple of 64 ints (256 B; the allocation is): the runtime splits a memset whose size is not a multiple of its fill width
+    // into an aligned fill and a tail fill -- two ~5 us kernels in front of every pass instead of one (kernel trace of a one-frame pass, round 5)
+    HIP_TRY(hipMemsetAsync(wctr ? h->work_ctrs : h->cand_count, 0, ((wctr ? 64 : 0) + (tail_elsewhere ? 0 : (n + 63) / 64 * 64)) * sizeof(int), s));
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, Hc = H / 8, Wc = W / 8;
   auto conv = [&](ConvShape shape, const Layer& L, const float* in, int ics, int ico, long iis, float* out, int ocs,
                   long ois, int hh, int ww, bool pool, bool relu, int oco = 0, bool direct = false) -> hipError_t {
@@ -295,7 +297,7 @@ int run_superpoint(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, 
     { ProfScope ps(h, D2FE_PROF_CONVDB, s);
       HIP_TRY(launch_desc_head_sparse(d_kps, d_n, cap, Hc, Wc, n, a4b.p, 128, (long)Hc * Wc * 128, h->L[L_DA32].wpack, h->L[L_DA32].bias,
                                       h->L[L_DB32].wpack, h->L[L_DB32].bias, h->sp_flags, h->sp_slotmap, h->sp_cells, h->sp_count,
-                                      h->sp_slots, h->sp_desc, varA ? W : 0, varA ? H : 0, s)); }
+                                      h->sp_slots, h->sp_desc, h->sp_mid, h->sp_mid_imgs, varA ? W : 0, varA ? H : 0, s)); }
     ProfScope ps(h, D2FE_PROF_SAMPLE, s);
     if (varA)
       HIP_TRY(launch_sample_a(h->sp_desc, 256, 0, Hc, Wc, W, H, n, d_kps, d_n, cap, h->pca_dims ? h->pca_comp_t : nullptr,
@@ -399,8 +401,8 @@ static int create_context(const d2fe_config* cfg, d2fe_handle* out, bool lane) {
     h->cand_cap = (long)(H * W);
     HIP_TRY(hipMalloc(&h->cand, sizeof(unsigned long long) * h->cand_cap * B));
     // the per-image candidate counters sit directly behind the 64 Winograd work counters: ONE memset clears both at the start of a pass
-    HIP_TRY(hipMalloc(&h->work_ctrs, (64 + (size_t)B) * sizeof(int)));
-    HIP_TRY(hipMemset(h->work_ctrs, 0, (64 + (size_t)B) * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->work_ctrs, (64 + ((size_t)B + 63) / 64 * 64) * sizeof(int)));      // counts padded to 64 ints: see the memset of a pass (run_superpoint)
+    HIP_TRY(hipMemset(h->work_ctrs, 0, (64 + ((size_t)B + 63) / 64 * 64) * sizeof(int)));
     h->cand_count = h->work_ctrs + 64;
     if (cfg->async_tail) {
       HIP_TRY(hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
@@ -423,6 +425,8 @@ static int create_context(const d2fe_config* cfg, d2fe_handle* out, bool lane) {
       HIP_TRY(hipMalloc(&h->sp_cells, sizeof(int32_t) * (size_t)h->sp_slots * B));
       HIP_TRY(hipMalloc(&h->sp_count, sizeof(int32_t) * B));
       HIP_TRY(hipMalloc(&h->sp_desc, sizeof(float) * 256 * (size_t)h->sp_slots * B));
+      h->sp_mid_imgs = B < 4 ? B : 4;
+      HIP_TRY(hipMalloc(&h->sp_mid, sizeof(float) * 256 * (size_t)h->sp_slots * h->sp_mid_imgs));
     }
     HIP_TRY(hipMalloc(&h->zeros, 1024));
     HIP_TRY(hipMemset(h->zeros, 0, 1024));
@@ -487,7 +491,7 @@ void d2fe_destroy(d2fe_handle h) {
     for (auto& L : h->L) { if (L.wpack) hipFree(L.wpack); if (L.bias) hipFree(L.bias); }
     for (void* p : {(void*)h->w1a, (void*)h->b1a, (void*)h->pca_comp_t, (void*)h->pca_mean, (void*)h->nv_pca_comp, (void*)h->nv_pca_mean}) if (p) hipFree(p);
   }
-  for (void* p : {(void*)h->cand, (void*)h->s_img, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->work_ctrs, (void*)h->match_stats, (void*)h->match_stamps, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc})
+  for (void* p : {(void*)h->cand, (void*)h->s_img, (void*)h->aconf, (void*)h->clist, (void*)h->a_ncand, (void*)h->a_samp, (void*)h->a_cn, h->lk_scratch, (void*)h->zeros, (void*)h->work_ctrs, (void*)h->match_stats, (void*)h->match_stamps, (void*)h->sp_flags, (void*)h->sp_slotmap, (void*)h->sp_cells, (void*)h->sp_count, (void*)h->sp_desc, (void*)h->sp_mid})
     if (p) hipFree(p);
   nv_free(h);
   for (void* p : {(void*)h->nv_s_img, (void*)h->nv_s_out}) if (p) hipFree(p);

@@ -98,6 +98,7 @@ struct d2fe_context {
   // sparse descriptor head (variant B unless cfg.dense_descriptors): cell flags, cell -> slot map, slot -> cell list, counts, descriptors
   bool sparse_desc = false; int sp_slots = 0; int sp_min_batch = 4;
   uint8_t* sp_flags = nullptr; int32_t* sp_slotmap = nullptr; int32_t* sp_cells = nullptr; int32_t* sp_count = nullptr; float* sp_desc = nullptr;
+  float* sp_mid = nullptr; int sp_mid_imgs = 0;      // ReLU(convDa) at the selected cells between the two stages of the split sparse head (passes of <= 4 images)
   void* lk_scratch = nullptr; size_t lk_scratch_bytes = 0;   // grow-only scratch of the LK / detector entry points (lk.hip)
   float* a_samp = nullptr; float* a_cn = nullptr; int a_scap = 0;   // variant A sampling: [batch][a_scap][256] samples, [batch][256] channel norms
   float* pca_comp_t = nullptr; float* pca_mean = nullptr; int pca_dims = 0;

@@ -91,7 +91,7 @@ hipError_t launch_sample_b(const float* desc_raw, int dstride, int dcoff, int Hc
 hipError_t launch_desc_head_sparse(const float* kps_xy, const int32_t* n_kp, int cap, int Hc, int Wc, int n_img, const float* x,
                                    int x_cstride, long x_img_stride, const void* w_da, const float* b_da, const void* w_db,
                                    const float* b_db, uint8_t* flags, int32_t* slotmap, int32_t* cells, int32_t* count,
-                                   int max_slots, float* out, int img_w, int img_h, hipStream_t s);
+                                   int max_slots, float* out, float* mid, int mid_imgs, int img_w, int img_h, hipStream_t s);
 
 // variant A (SuperPointONNX path): NMS2-exact and grid_sampler(align_corners=false) sampling with optional PCA
 hipError_t launch_nms2_a(const float* semi, int H, int W, int n_img, float thr, int dist, float* aconf, int* clist,

@@ -114,13 +114,11 @@ int pipe_flush(d2fe_pipe_s* p) {
   // NetVLAD of the pass's left images in ONE call (its arithmetic order does not depend on the batch: run_netvlad decides the hidden-channel
   // split per image), C > 1: the left images are every second image of the lane's input buffer
   auto netvlad = [&](hipStream_t st) -> int { return run_netvlad(L.ctx, L.d_img, n_left, W, H, W, left_stride, B + p->o_nv, st); };
-  if (nv_side) {
-    HIP_TRY(hipEventRecord(L.ev_up, s));
-    HIP_TRY(hipStreamWaitEvent(L.nv, L.ev_up, 0));
-    rc = netvlad(L.nv);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(L.ev_nv, L.nv));
-  } else if (p->cfg.netvlad && p->M == 1) {
+  // Launch order on the host: SuperPoint FIRST.  Its 13 dependent launches are the long pole of a pass (0.58 ms of kernels for one stereo pair against NetVLAD's
+  // 0.25-0.3 ms beside it), and enqueuing NetVLAD's 27 launches costs ~0.12 ms of host time: issued first (rounds 3-4) they held conv1b back by that much in a
+  // pass of one frame.  NetVLAD on the lane's second stream still only waits for the frames (ev_up)
+  if (nv_side) HIP_TRY(hipEventRecord(L.ev_up, s));
+  else if (p->cfg.netvlad && p->M == 1) {        // netvlad_inline: one stream, NetVLAD in front (half as many streams; order is the stream's)
     rc = netvlad(s);
     if (rc) return rc;
   }
@@ -128,6 +126,12 @@ int pipe_flush(d2fe_pipe_s* p) {
                       reinterpret_cast<int32_t*>(B + p->o_cnt), s);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(L.ev_ext[set], s));
+  if (nv_side) {
+    HIP_TRY(hipStreamWaitEvent(L.nv, L.ev_up, 0));
+    rc = netvlad(L.nv);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(L.ev_nv, L.nv));
+  }
   if (p->npp > 0) {
     if (p->cfg.match_prev && P > 0 && p->K > 1) {      // the first temporal pair reads the previous pass's block: wait for ITS extraction only
       const int pk = k > 0 ? k - 1 : p->K - 1, pset = k > 0 ? set : set ^ 1;
@@ -271,7 +275,7 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
       int rc2 = clone_lane(h, p->NI, &L.ctx, ms, lane_cus, cfg->netvlad && p->M == 1);
       if (rc2) { if (ms) (void)hipStreamDestroy(ms); return rc2; }
       L.s = L.ctx->stream;
-      if (!L.nv) HIP_TRY(hipStreamCreateWithFlags(&L.nv, hipStreamNonBlocking));
+      if (!L.nv) HIP_TRY(hipStreamCreateWithFlags(&L.nv, hipStreamNonBlocking));      // (a lowest-priority NetVLAD stream measured no different: 1345 vs 1351 fps at one frame per pass)
       HIP_TRY(hipEventCreateWithFlags(&L.ev_up, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&L.ev_nv, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&L.ev_ext[0], hipEventDisableTiming));
@@ -385,8 +389,13 @@ int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int
   const size_t img = (size_t)p->W * p->H;
   const int F = p->F, W = p->W, H = p->H;
   hipStream_t s = L.s;
-  // frames of this submit -> the lane's input buffer at the rows of submit j (H2D is issued at once: it travels while the pass fills)
-  for (int side = 0; side < 2; ++side) {
+  // frames of this submit -> the lane's input buffer at the rows of submit j (H2D is issued at once: it travels while the pass fills).  Left and right frames that are
+  // one contiguous run on the host AND in the lane's buffer (C == 1: rows [0, F) | [F, 2F); C > 1: rows 2j, 2j + 1) travel as ONE copy: a DMA costs ~10 us of
+  // set-up whatever its size, and a one-frame pass waits for it
+  const bool one_run = p->cfg.pinned_input && stride == W && image_stride == img && right == left + img * F &&
+                       p->right_row(j, 0) == p->left_row(j, 0) + (size_t)F;
+  if (one_run) HIP_TRY(hipMemcpyAsync(L.d_img + (size_t)p->left_row(j, 0) * img, left, 2 * img * F, hipMemcpyHostToDevice, s));
+  for (int side = 0; side < 2 && !one_run; ++side) {
     const uint8_t* src = side ? right : left;
     const size_t row0 = side ? p->right_row(j, 0) : p->left_row(j, 0);       // the F images of a side are consecutive rows (C > 1: F = 1)
     uint8_t* dst = L.d_img + row0 * img;
@@ -401,7 +410,11 @@ int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int
         if (stride == W) memcpy(stage + f * img, sf, img);
         else for (int y = 0; y < H; ++y) memcpy(stage + f * img + (size_t)y * W, sf + (size_t)y * stride, W);
       }
-      HIP_TRY(hipMemcpyAsync(dst, stage, img * F, hipMemcpyHostToDevice, s));
+      // the staging buffer has the lane buffer's row order: after the right side was staged, both sides of a submit are one run
+      if (side == 0 && p->right_row(j, 0) == p->left_row(j, 0) + (size_t)F) continue;
+      if (side == 1 && p->right_row(j, 0) == p->left_row(j, 0) + (size_t)F)
+        HIP_TRY(hipMemcpyAsync(L.d_img + (size_t)p->left_row(j, 0) * img, L.pin_in + (size_t)p->left_row(j, 0) * img, 2 * img * F, hipMemcpyHostToDevice, s));
+      else HIP_TRY(hipMemcpyAsync(dst, stage, img * F, hipMemcpyHostToDevice, s));
     }
   }
   auto& ti = p->tinfo[(size_t)(t % (long long)p->tinfo.size())];

@@ -543,15 +543,21 @@ struct SparseHeadArgs {
   const int32_t* cells; const int32_t* count; int max_slots;
   int Hc, Wc;
   float* out;                                            // [img][max_slots][256]
+  float* mid;                                            // [img][max_slots][256]: ReLU(convDa) between the two stages of the split form (may be null: whole-head launches)
 };
 
 // MT: 32-cell row tiles per workgroup.  Every workgroup streams ALL of convDa's and convDb's weights (1.44 MB) from L2 once, whatever its number of cells:
 // at a batch the launch is L2-bandwidth-bound on them (64 images x 25 workgroups x 1.44 MB = 2.3 GB per step at MT = 1), so a batch runs 64 cells per
 // workgroup -- each weight fragment feeds two MFMAs.  A stereo pair (a few dozen workgroups on 256 CUs) is latency-bound instead and keeps MT = 1: half the
 // MFMAs per wave.  The fmaf chain of an output does not depend on MT: bit-identical either way.
-template <int MT>
-__global__ __launch_bounds__(512) void desc_head_sparse_kernel(SparseHeadArgs a) {
-  constexpr int CIN = 128, CPA = CIN + 1, CMID = 256, CPD = CMID + 1, G = 4, M = 32 * MT;
+// NW / STAGE (round 5): a one- or two-image pass has ~20 tiles per image -- 42 workgroups of 8 waves, each CU-bound on 32 cells x (9 x 128 x 256 + 256 x 256)
+// MACs = 38 us of matrix-pipe time with two waves per SIMD, 68 us measured, on a sixth of the chip.  STAGE 1 / 2 split the launch in two over TWICE the
+// workgroups of FOUR waves (one per SIMD): blockIdx.z picks 128 of the 256 output channels; STAGE 1 = convDa + ReLU into `mid` [img][slot][256] (global, L2-resident),
+// STAGE 2 = convDb from `mid`.  Every output keeps its chain (bias, taps, ci ascending): bit-identical to STAGE 0.
+template <int MT, int NW, int STAGE>
+__global__ __launch_bounds__(64 * NW) void desc_head_sparse_kernel(SparseHeadArgs a) {
+  constexpr int CIN = 128, CPA = CIN + 1, CMID = 256, CPD = CMID + 1, G = 4, M = 32 * MT, NT = 64 * NW;
+  static_assert((NW == 8 && STAGE == 0) || (NW == 4 && STAGE != 0 && MT == 1), "whole head: 8 waves x 32 channels; split stages: 4 waves per channel half");
   // A: one tap of the M cells' inputs [M][CPA]; D: ReLU(convDa) of the M cells = convDb's input [M][CPD] -- D overlays A (A is dead once the last tap is through)
   extern __shared__ __attribute__((aligned(16))) float sparse_lds[];       // [M * CPD] floats + [M] cell indices (MT = 2: 66 KB, dynamic)
   float* A = sparse_lds;
@@ -566,66 +572,98 @@ __global__ __launch_bounds__(512) void desc_head_sparse_kernel(SparseHeadArgs a)
   const float* x = a.x + (size_t)img * a.x_img_stride;
   const f32x4* wda = reinterpret_cast<const f32x4*>(a.w_da);
   const f32x4* wdb = reinterpret_cast<const f32x4*>(a.w_db);
-  const int nt0 = wave;                                   // 8 waves x 32 channels
+  const int nt0 = (STAGE == 0 ? 0 : (int)blockIdx.z * NW) + wave;      // this wave's 32 output channels
+  float* mid = a.mid + ((size_t)img * a.max_slots + mt * M) * 256;     // STAGE 1 writes, STAGE 2 reads
 
-  // ---- convDa: acc = bias; for tap (ky,kx): for ci ascending: fmaf -- the dense kernels' chain
   f32x16 acc[MT];
-  {
-    const float b = a.b_da[nt0 * 32 + (lane & 31)];
+  if constexpr (STAGE != 2) {
+    // ---- convDa: acc = bias; for tap (ky,kx): for ci ascending: fmaf -- the dense kernels' chain
+    {
+      const float b = a.b_da[nt0 * 32 + (lane & 31)];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = b;
+    }
+    const int arow = (lane & 31) * CPA + (lane >> 5);
+    constexpr int NG = M * (CIN / 4) / NT;                  // float4 gathers per thread and tap
+    for (int tap = 0; tap < 9; ++tap) {
+      __syncthreads();                                      // previous tap's A tile fully consumed
+      // gather: M cells x 32 float4, all loads issued before the first LDS store
+      f32x4 gv[NG];
+#pragma unroll
+      for (int j = 0; j < NG; ++j) {
+        const int i = tid + NT * j;
+        const int row = i / (CIN / 4), c4 = i % (CIN / 4);
+        const int cell = s_cell[row];
+        const int cy = cell / a.Wc + tap / 3 - 1, cx = cell % a.Wc + tap % 3 - 1;
+        const bool ok = cell >= 0 && cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (ok ? ((size_t)cy * a.Wc + cx) * a.x_cstride + c4 * 4 : 0));
+        gv[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < NG; ++j) {
+        const int i = tid + NT * j;
+        const int row = i / (CIN / 4), c4 = i % (CIN / 4);
+        float* d = A + row * CPA + c4 * 4;
+        d[0] = gv[j][0]; d[1] = gv[j][1]; d[2] = gv[j][2]; d[3] = gv[j][3];
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int g = 0; g < (CIN / 8) / G; ++g) {
+        f32x4 bq[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) bq[j] = wda[((size_t)(nt0 * 9 + tap) * (CIN / 8) + g * G + j) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          const float* ap = A + arow + (g * G + j) * 8;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[m * 32 * CPA + 2 * q], bq[j][q], acc[m], 0, 0, 0);
+        }
+      }
+    }
+    if constexpr (STAGE == 1) {
+      // ReLU -> mid (rows beyond the image's cell count are never read).  C layout: col = lane & 31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (cell)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float v = acc[0][r];
+        if (mt * M + row < n) mid[(size_t)row * 256 + nt0 * 32 + (lane & 31)] = v > 0.f ? v : 0.f;
+      }
+      return;
+    }
+    __syncthreads();                                        // everybody is through with A: D overlays it
+    // ReLU -> D tile
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][r] = b;
-  }
-  const int arow = (lane & 31) * CPA + (lane >> 5);
-  for (int tap = 0; tap < 9; ++tap) {
-    __syncthreads();                                      // previous tap's A tile fully consumed
-    // gather: M cells x 32 float4, MT * 2 per thread, all loads issued before the first LDS store
-    f32x4 gv[2 * MT];
+      for (int r = 0; r < 16; ++r) {
+        const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float v = acc[m][r];
+        D[row * CPD + nt0 * 32 + (lane & 31)] = v > 0.f ? v : 0.f;
+      }
+    __syncthreads();
+  } else {
+    // STAGE 2: the D tile from `mid` (rows beyond the count: zeros; their outputs are not stored)
+    constexpr int ND = M * (CMID / 4) / NT;
+    f32x4 dv[ND];
 #pragma unroll
-    for (int j = 0; j < 2 * MT; ++j) {
-      const int i = tid + 512 * j;
-      const int row = i / (CIN / 4), c4 = i % (CIN / 4);
-      const int cell = s_cell[row];
-      const int cy = cell / a.Wc + tap / 3 - 1, cx = cell % a.Wc + tap % 3 - 1;
-      const bool ok = cell >= 0 && cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (ok ? ((size_t)cy * a.Wc + cx) * a.x_cstride + c4 * 4 : 0));
-      gv[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < ND; ++j) {
+      const int i = tid + NT * j;
+      const int row = i / (CMID / 4), c4 = i % (CMID / 4);
+      dv[j] = mt * M + row < n ? *reinterpret_cast<const f32x4*>(mid + (size_t)row * 256 + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int j = 0; j < 2 * MT; ++j) {
-      const int i = tid + 512 * j;
-      const int row = i / (CIN / 4), c4 = i % (CIN / 4);
-      float* d = A + row * CPA + c4 * 4;
-      d[0] = gv[j][0]; d[1] = gv[j][1]; d[2] = gv[j][2]; d[3] = gv[j][3];
+    for (int j = 0; j < ND; ++j) {
+      const int i = tid + NT * j;
+      const int row = i / (CMID / 4), c4 = i % (CMID / 4);
+      float* d = D + row * CPD + c4 * 4;
+      d[0] = dv[j][0]; d[1] = dv[j][1]; d[2] = dv[j][2]; d[3] = dv[j][3];
     }
     __syncthreads();
-#pragma unroll 1
-    for (int g = 0; g < (CIN / 8) / G; ++g) {
-      f32x4 bq[G];
-#pragma unroll
-      for (int j = 0; j < G; ++j) bq[j] = wda[((size_t)(nt0 * 9 + tap) * (CIN / 8) + g * G + j) * 64 + lane];
-#pragma unroll
-      for (int j = 0; j < G; ++j) {
-        const float* ap = A + arow + (g * G + j) * 8;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[m * 32 * CPA + 2 * q], bq[j][q], acc[m], 0, 0, 0);
-      }
-    }
   }
-  __syncthreads();                                        // everybody is through with A: D overlays it
-  // ReLU -> D tile.  C layout: col = lane & 31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (cell)
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const float v = acc[m][r];
-      D[row * CPD + nt0 * 32 + (lane & 31)] = v > 0.f ? v : 0.f;
-    }
-  __syncthreads();
   // ---- convDb (1x1): acc = bias; ci ascending
   {
     const float b = a.b_db[nt0 * 32 + (lane & 31)];
@@ -662,7 +700,7 @@ __global__ __launch_bounds__(512) void desc_head_sparse_kernel(SparseHeadArgs a)
 hipError_t launch_desc_head_sparse(const float* kps_xy, const int32_t* n_kp, int cap, int Hc, int Wc, int n_img, const float* x,
                                    int x_cstride, long x_img_stride, const void* w_da, const float* b_da, const void* w_db,
                                    const float* b_db, uint8_t* flags, int32_t* slotmap, int32_t* cells, int32_t* count,
-                                   int max_slots, float* out, int img_w, int img_h, hipStream_t s) {
+                                   int max_slots, float* out, float* mid, int mid_imgs, int img_w, int img_h, hipStream_t s) {
   const int ncell = Hc * Wc;
   hipError_t e = hipSuccess;
   if (ncell <= 60 * 1024) {
@@ -675,15 +713,20 @@ hipError_t launch_desc_head_sparse(const float* kps_xy, const int32_t* n_kp, int
   }
   SparseHeadArgs a;
   a.x = x; a.x_cstride = x_cstride; a.x_img_stride = x_img_stride; a.w_da = w_da; a.b_da = b_da; a.w_db = w_db; a.b_db = b_db;
-  a.cells = cells; a.count = count; a.max_slots = max_slots; a.Hc = Hc; a.Wc = Wc; a.out = out;
+  a.cells = cells; a.count = count; a.max_slots = max_slots; a.Hc = Hc; a.Wc = Wc; a.out = out; a.mid = mid;
   const int slots = std::min(max_slots, 4 * cap);
   if (n_img >= 8) {
     constexpr size_t lds = sizeof(float) * (64 * 257 + 64);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(desc_head_sparse_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(desc_head_sparse_kernel<2, 8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(desc_head_sparse_kernel<2>, dim3((slots + 63) / 64, n_img), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((desc_head_sparse_kernel<2, 8, 0>), dim3((slots + 63) / 64, n_img), dim3(512), lds, s, a);
+  } else if (mid && n_img <= mid_imgs && n_img <= 4) {
+    // a one- to four-image pass: the split form, twice the workgroups with one wave per SIMD (see the kernel)
+    const dim3 grid((slots + 31) / 32, n_img, 2);
+    hipLaunchKernelGGL((desc_head_sparse_kernel<1, 4, 1>), grid, dim3(256), sizeof(float) * (32 * 257 + 32), s, a);
+    hipLaunchKernelGGL((desc_head_sparse_kernel<1, 4, 2>), grid, dim3(256), sizeof(float) * (32 * 257 + 32), s, a);
   } else {
-    hipLaunchKernelGGL(desc_head_sparse_kernel<1>, dim3((slots + 31) / 32, n_img), dim3(512), sizeof(float) * (32 * 257 + 32), s, a);
+    hipLaunchKernelGGL((desc_head_sparse_kernel<1, 8, 0>), dim3((slots + 31) / 32, n_img), dim3(512), sizeof(float) * (32 * 257 + 32), s, a);
   }
   return hipGetLastError();
 }

@@ -910,6 +910,32 @@ def test_sparse_descriptor_head_equals_dense(api, orc, sp_weights, prec):
     assert len(outs[0][0][0]) == 300
 
 
+@pytest.mark.parametrize("prec,n", [("f32", 4), ("wino", 2), ("wino", 3)])
+def test_split_sparse_head_of_small_passes_is_bit_identical(api, sp_weights, prec, n):
+    """Round 5: passes of <= 4 images run the sparse descriptor head as two launches over twice the workgroups (desc_head_sparse_kernel<1, 4, 1 / 2>: convDa + ReLU
+    into a scratch, convDb from it, 128 output channels per workgroup).  Same fmaf chain per output: the descriptors of a frame are the same BITS as in a 9-image
+    call, which runs the whole-head kernel with 64 cells per workgroup (and, exact mode, as the dense map's) -- incl. an image without keypoints."""
+    H, W = 240, 320
+    p = api.PREC_F32 if prec == "f32" else api.PREC_F32_WINO
+    imgs = np.stack([synth_image(H, W, 71), np.full((H, W), 90, np.uint8), synth_image(H, W, 72), synth_image(H, W, 73)] + [synth_image(H, W, 80 + i) for i in range(5)])
+    fe = _fe_dev(api, H, W, 9, p, max_kp=300, dense=False)
+    fe.load_superpoint(sp_weights)
+    big = fe.extract_batch(imgs, cap=300)                     # 9 images: desc_head_sparse_kernel<2, 8, 0>
+    small = fe.extract_batch(imgs[:n], cap=300)               # n <= 4: the split form
+    fe.close()
+    for i in range(n):
+        assert np.array_equal(small[i][0], big[i][0]) and np.array_equal(small[i][1], big[i][1])
+        assert np.array_equal(small[i][2].view(np.uint32), big[i][2].view(np.uint32)), i
+    assert len(small[0][0]) == 300 and len(small[1][0]) == 0
+    if prec == "f32":
+        fd = _fe_dev(api, H, W, 9, p, max_kp=300, dense=True)
+        fd.load_superpoint(sp_weights)
+        dense = fd.extract_batch(imgs[:n], cap=300)
+        fd.close()
+        for i in range(n):
+            assert np.array_equal(small[i][2].view(np.uint32), dense[i][2].view(np.uint32)), i
+
+
 @pytest.mark.parametrize("n,wino", [(2, False), (6, False), (6, True)])
 def test_async_tail_equals_synchronous(api, sp_weights, n, wino):
     """async_tail: convolutions on the caller's stream, post-processing on the handle's tail stream with double-buffered inputs.

@@ -16,6 +16,7 @@
 #   layers [args...]             tools/bench_wino.py (per-layer timing of the Winograd kernels, development library)
 #   match                        tools/bench_match.py (matchKNN launch time for 1..64 pairs)
 #   netvlad [n...]               tools/bench_netvlad.py n... --fused-only + the per-dispatch timeline (tools/nv_timeline.sh)
+#   timeline [pipe_probe args]   rocprofv3 kernel trace of the running pipe, per-dispatch timeline of one pass (tools/pipe_timeline.py)
 #   py <script> [args...]        any tools/*.py
 cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
@@ -69,7 +70,7 @@ run_task() {
              done; done
              for v in "$a" "$b"; do grep "per-stage" $d/err_$v.txt | tail -1 >> $d/ab.txt; done; cat $d/ab.txt ;;
     latency) timeout 300 python bench.py --latency-only "$@" 2>/dev/null | python -c 'import sys,json; j=json.loads([l for l in sys.stdin if l.startswith("{")][-1])["latency"]; print({k:v["p50_ms"] for k,v in j.items() if isinstance(v,dict)})' ;;
-    pipe)    local sw=$1; shift; timeout 300 python tools/pipe_probe.py --sweep $sw "$@" 2>/dev/null | grep '^{' | python -c '
+    pipe)    local sw=$1; shift; timeout 300 python tools/pipe_probe.py --sweep $sw "$@" 2>/dev/null | grep '^{"coalesce_depth' | python -c '
 import sys, json
 for l in sys.stdin:
     j = json.loads(l); print("   lanes %d x %d frames (coalesce %s depth %s): %7.1f stereo fps" % (j["lanes"], j["frames_per_submit"], j.get("coalesce"), j.get("coalesce_depth"), j["stereo_fps"]))' ;;
@@ -77,6 +78,9 @@ for l in sys.stdin:
     match)   timeout 300 python tools/bench_match.py "$@" 2>&1 | grep -v amdgpu ;;
     netvlad) bash tools/nv_timeline.sh gpurun_out/run/nv ${@:-1 32} ;;
     py)      local s=$1; shift; timeout 900 python tools/$s "$@" 2>&1 | grep -v amdgpu.ids | tail -60 ;;
+    timeline) # kernel-trace timeline of ONE pass of the pipe: timeline [pipe_probe args, default --sweep 1x1]
+             local d=$PWD/gpurun_out/run/ptl; rm -rf $d; ( export TMPDIR=/tmp; cd /tmp; rocprofv3 --output-format csv --kernel-trace -d $d -o t -- python $OLDPWD/tools/pipe_probe.py --seconds 0.05 ${@:---sweep 1x1} > /dev/null 2>&1 )
+             python tools/pipe_timeline.py $d; rm -rf $d ;;
     *)       echo "unknown task $t"; return 2 ;;
   esac
 }
