@@ -204,8 +204,10 @@ class PipeExchange:
     convolutions never wait for the collective.  enqueue() is called one submit BEHIND the pipe (after submit(i): enqueue(ticket i-1)), which keeps a host-blocking
     collective (gloo) from starving the device."""
 
-    def __init__(self, torch, fe, pipe, dev, world, rank, F, cap, netvlad_dim, exchange="fp32", gate_thres=0.8, ratio=0.8, slots=4, group=None):
-        assert exchange in ("fp32", "int8", "int8-renorm256") and world > 1
+    def __init__(self, torch, fe, pipe, dev, world, rank, F, cap, netvlad_dim, exchange="fp32", gate_thres=0.8, ratio=0.8, slots=4, group=None, loopback=False):
+        # loopback: the rank's OWN gathered blocks count as a remote agent too (a one-rank communicator then exercises the whole sequence: how the RCCL path is
+        # checked on a 1-GPU box, tools/check_rccl_1rank.py)
+        assert exchange in ("fp32", "int8", "int8-renorm256") and (world > 1 or loopback)
         self.torch, self.fe, self.pipe, self.world, self.rank, self.F, self.cap, self.G = torch, fe, pipe, world, rank, F, cap, netvlad_dim
         self.exchange, self.group, self.thres, self.ratio = exchange, group, gate_thres, ratio
         self.int8 = exchange.startswith("int8")
@@ -229,7 +231,7 @@ class PipeExchange:
         self.n_off = block_field_offset(cap, netvlad_dim, "n"); self.g_off = block_field_offset(cap, netvlad_dim, "netvlad")
         a_off, b_off, qf, rb = [], [], [], []
         for r in range(world):
-            if r == rank:
+            if r == rank and not loopback:
                 continue
             for f in range(F):
                 a_off.append(f * cap); b_off.append((r * F + f) * rows_per_block); qf.append(f); rb.append(r * F + f)

@@ -1,0 +1,14 @@
+#!/bin/bash
+# the N > 1 path on ONE GPU: two ranks share GPU 0 over gloo (RCCL does not put two ranks on one device).  usage: tools/gloo2.sh <tag> [bench args...]
+cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
+TAG=$1; shift
+O=gpurun_out/run; mkdir -p $O
+D2FE_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --single-mode --no-cpu-baseline "$@" > $O/bench_gpus2_$TAG.json 2> $O/bench_gpus2_$TAG.err
+grep -v "amdgpu\|socket" $O/bench_gpus2_$TAG.err | tail -3
+python - $O/bench_gpus2_$TAG.json <<'PY'
+import json, sys
+j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+print("gpus 2 (gloo, one GPU): value", j["value"], "ms/step", j["ms_per_step"])
+for k in ("exchange", "cross_agent", "netvlad_gate"):
+    if j.get(k): print(" ", k, json.dumps(j[k])[:1200])
+PY
