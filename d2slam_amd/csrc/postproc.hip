@@ -6,7 +6,6 @@
 // (softmax / dustbin drop / 8x8 depth-to-space, d2frontend/superpoint.ipynb:355-364).
 // All kernels here are HBM/latency bound integer+fp32 work; the arithmetic follows the oracle
 // (oracle/d2fe_oracle.c) operation by operation so that scores and indices compare exactly.
-#include <cmath>
 #include <algorithm>
 
 #include "kernels.h"
@@ -48,18 +47,11 @@ __device__ __forceinline__ float d2fe_expf(float x) {
 // Bound by VALU issue, not by HBM (rocprofv3, 64 images: 2.0e7 wave-level VALU instructions -- 65 correctly rounded exponentials and divisions per cell, ~1030
 // per wave -- are 32 us of the launch's 54 at the chip's full issue rate; the 80 MB of logits would take 13 us at 6 TB/s).  The exponential and the division are
 // the oracle's (bitwise scores), so the instruction count is the arithmetic's.
-// Cell skip (round 5).  Without a dense score map (variant B, bounded top-K: the candidates are all that is kept) a cell whose dustbin logit exceeds every one of
-// its 64 position logits by skip_gap = ln(1 / thr) + 0.01 cannot hold a candidate: the oracle's maximum is then the dustbin, its exponential is exactly 1
-// (d2fe_expf(0) = 1), the sequential sum is >= 1 (adding non-negative terms never rounds below a term), so every score is <= expf(l_c - l_dust) <= e^-skip_gap (1 + 2e-7)
-// < thr.  Such cells (most of an image: keypoints are sparse) need no exponential at all.  The cells that remain are compacted to the front of the workgroup and
-// processed by the SAME four-lanes-per-cell code, so their scores are the same bits; only the order of the candidate list changes, which nobody reads (unique keys).
 __global__ __launch_bounds__(256) void softmax_cand_kernel(const float* __restrict__ logits, int lstride, int Hc, int Wc,
-                                                           float thr, float skip_gap, int border, float* __restrict__ semi,
+                                                           float thr, int border, float* __restrict__ semi,
                                                            unsigned long long* __restrict__ cand,
                                                            int* __restrict__ cand_count, long cand_cap) {
   __shared__ float sl[64 * 65];
-  __shared__ int s_list[64];       // the cells of this block that may hold a candidate (all of them when a dense map is written)
-  __shared__ int s_nlist;
   const int img = blockIdx.y;
   const int ncell = Hc * Wc;
   const int cell0 = blockIdx.x * 64;
@@ -75,70 +67,49 @@ __global__ __launch_bounds__(256) void softmax_cand_kernel(const float* __restri
     }
   }
   __syncthreads();
-  {
-    // wave 0: lane = cell.  keep = the cell needs its softmax; compacted in cell order
-    if (tid < 64) {
-      bool keep = tid < nvalid;
-      if (keep && !semi) {
-        const float* lc = sl + tid * 65;
-        float mc = lc[0];
-#pragma unroll 8
-        for (int k = 1; k < 64; ++k) mc = lc[k] > mc ? lc[k] : mc;
-        keep = !(lc[64] - mc >= skip_gap);          // NaNs compare false: kept
-      }
-      const unsigned long long bal = __ballot(keep);
-      if (keep) s_list[__popcll(bal & ((1ull << tid) - 1ull))] = tid;
-      if (tid == 0) s_nlist = __popcll(bal);
-    }
-  }
-  __syncthreads();
-  const int nlist = s_nlist;
-  const int q = tid & 3;
-  const bool live = (tid >> 2) < nlist;
-  const int cl = live ? s_list[tid >> 2] : 0;
+  const int cl = tid >> 2, q = tid & 3;
+  const bool live = cl < nvalid;
   const int c0 = q == 0 ? 0 : 1 + 16 * q;          // 0, 17, 33, 49
   const int nc = q == 0 ? 17 : 16;
-  int mine = 0;
-  unsigned pass_mask = 0;
+  const float* l = sl + (live ? cl : 0) * 65 + c0;
   float v[17];
+  float m = l[0];
+#pragma unroll
+  for (int i = 0; i < 17; ++i) {
+    v[i] = i < nc ? l[i] : l[0];
+    m = v[i] > m ? v[i] : m;
+  }
+  m = fmaxf(m, __shfl_xor(m, 1, 64));
+  m = fmaxf(m, __shfl_xor(m, 2, 64));
+#pragma unroll
+  for (int i = 0; i < 17; ++i) v[i] = d2fe_expf(v[i] - m);
+  float s = 0.f;
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    if (q == qq) {
+#pragma unroll
+      for (int i = 0; i < 17; ++i)
+        if (i < nc) s += v[i];
+    }
+    s = __shfl(s, (lane & ~3) | qq, 64);
+  }
   const int cell = cell0 + cl;
   const int cy = cell / Wc, cx = cell % Wc;
   const int W = Wc * 8, H = Hc * 8;
-  if (tid < 4 * nlist + 63 - ((4 * nlist + 63) & 63) + 0 || (tid >> 6) * 64 < 4 * nlist) {      // whole waves without a live cell skip the arithmetic (wave-uniform)
-    const float* l = sl + cl * 65 + c0;
-    float m = l[0];
+  unsigned long long* cd = cand + (size_t)img * cand_cap;
+  int mine = 0;
+  unsigned pass_mask = 0;
 #pragma unroll
-    for (int i = 0; i < 17; ++i) {
-      v[i] = i < nc ? l[i] : l[0];
-      m = v[i] > m ? v[i] : m;
-    }
-    m = fmaxf(m, __shfl_xor(m, 1, 64));
-    m = fmaxf(m, __shfl_xor(m, 2, 64));
-#pragma unroll
-    for (int i = 0; i < 17; ++i) v[i] = d2fe_expf(v[i] - m);
-    float s = 0.f;
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-      if (q == qq) {
-#pragma unroll
-        for (int i = 0; i < 17; ++i)
-          if (i < nc) s += v[i];
-      }
-      s = __shfl(s, (lane & ~3) | qq, 64);
-    }
-#pragma unroll
-    for (int i = 0; i < 17; ++i) {
-      const int c = c0 + i;
-      if (i < nc && c < 64) {
-        const float p = v[i] / s;
-        v[i] = p;
-        const int y = cy * 8 + (c >> 3), x = cx * 8 + (c & 7);
-        if (semi && live) semi[(size_t)img * H * W + y * W + x] = p;
-        if (live && p > thr && y >= border && y < H - border && x >= border && x < W - border) { ++mine; pass_mask |= 1u << i; }
-      }
+  for (int i = 0; i < 17; ++i) {
+    const int c = c0 + i;
+    if (i < nc && c < 64) {
+      const float p = v[i] / s;
+      v[i] = p;
+      const int y = cy * 8 + (c >> 3), x = cx * 8 + (c & 7);
+      if (semi && live) semi[(size_t)img * H * W + y * W + x] = p;
+      if (live && p > thr && y >= border && y < H - border && x >= border && x < W - border) { ++mine; pass_mask |= 1u << i; }
     }
   }
-  unsigned long long* cd = cand + (size_t)img * cand_cap;
   // one reservation per BLOCK (same-address atomics serialise in L2 at ~5 ns each; measured): exclusive prefix of the
   // per-lane counts inside the wave, wave totals through LDS, a single atomic for the block's total
   __shared__ int wtot[4];
@@ -181,9 +152,7 @@ hipError_t launch_softmax_cand(const float* logits, int lstride, int Hc, int Wc,
     if (e != hipSuccess) return e;
   }
   dim3 grid((Hc * Wc + 63) / 64, n_img), block(256);
-  // cell skip (see the kernel): only meaningful for a threshold in (0, 1); thr <= 0 keeps every cell (log(1 / 0) = +inf)
-  const float skip_gap = thr > 0.f && thr < 1.f ? (float)(std::log(1.0 / (double)thr) + 0.01) : __builtin_inff();
-  hipLaunchKernelGGL(softmax_cand_kernel, grid, block, 0, s, logits, lstride, Hc, Wc, thr, skip_gap, border, semi, cand,
+  hipLaunchKernelGGL(softmax_cand_kernel, grid, block, 0, s, logits, lstride, Hc, Wc, thr, border, semi, cand,
                      cand_count, cand_cap);
   return hipGetLastError();
 }
