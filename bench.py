@@ -636,7 +636,7 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
     inflight = inflight or lanes * coalesce
     base, per_set, per_side = host.data_ptr(), 2 * F * H * W, F * H * W
     dev = torch.device("cuda", local_rank)
-    NS = inflight + 2
+    NS = inflight + 3
     xch = None
     if world > 1 and exchange:
         xch = swarm.PipeExchange(torch, fe, pipe, dev, world, rank, F, CAP, fe.netvlad_dim if netvlad else 0, exchange=exchange, gate_thres=NETVLAD_GATE, ratio=0.8, slots=NS)
@@ -661,11 +661,16 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
             while xch and enq[0] <= j:
                 xch.enqueue(tk[enq[0]], enq[0] % NS); enq[0] += 1
 
-        def finish(j):            # host results of ticket j: the pipe's block and (N > 1) its cross-agent match lists
+        def finish(j):            # host results of ticket j: the pipe's block now, the cross-agent lists of ticket j - 1 (N > 1)
             pipe.wait_raw(tk[j])
             if xch:
+                # one submit of slack between a frame's own results and its cross-agent results: the all-gather of step j completes when the SLOWEST rank has
+                # extracted step j, and the ranks are not in lock step (on one GPU under gloo they even alternate)
                 enq_upto(j)
-                last["x"] = xch.collect(j % NS)
+                if j >= 1:
+                    last["x"] = xch.collect((j - 1) % NS)
+                if j == n - 1:
+                    last["x"] = xch.collect(j % NS)
         for i in range(n):
             if i >= inflight:
                 finish(i - inflight)
@@ -828,12 +833,13 @@ def index_parity_evidence():
 
 
 def profiled_traffic(kernel_tag):
-    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes of this command (profiles/r04_wino_rocprofv3_summary.txt:
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes of this command (profiles/r05_wino_rocprofv3_summary.txt, else round 4's:
     separate --pmc FETCH_SIZE and WRITE_SIZE passes, tools/profile.sh; KiB per dispatch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
     gfx950's wide reads).  bench.py itself does not collect counters: null when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r04_wino_rocprofv3_summary.txt")
-    if not os.path.exists(path):
+    name = next((n for n in ("r05_wino_rocprofv3_summary.txt", "r04_wino_rocprofv3_summary.txt") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+    if name is None:
         return None, None
+    path = os.path.join(ROOT, "profiles", name)
     fetch = write = None
     lines = open(path).read().split("\n")
     sect = ""
@@ -848,7 +854,7 @@ def profiled_traffic(kernel_tag):
                 write = float(nxt.split("WRITE_SIZE=")[1].split()[0])
     if fetch is None or write is None:
         return None, None
-    return int((2.0 * fetch + write) * 1024), "profiles/r04_wino_rocprofv3_summary.txt: 2 x FETCH_SIZE %.4g KiB + WRITE_SIZE %.4g KiB per dispatch (rocprofv3 --pmc passes of `python bench.py`, same build; not collected inside this run)" % (fetch, write)
+    return int((2.0 * fetch + write) * 1024), "profiles/" + name + ": 2 x FETCH_SIZE %.4g KiB + WRITE_SIZE %.4g KiB per dispatch (rocprofv3 --pmc passes of `python bench.py`, same build; not collected inside this run)" % (fetch, write)
 
 
 def live_traffic(kernel_tag):

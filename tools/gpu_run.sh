@@ -80,7 +80,7 @@ for l in sys.stdin:
     py)      local s=$1; shift; timeout 900 python tools/$s "$@" 2>&1 | grep -v amdgpu.ids | tail -60 ;;
     timeline) # kernel-trace timeline of ONE pass of the pipe: timeline [pipe_probe args, default --sweep 1x1]
              local d=$PWD/gpurun_out/run/ptl; rm -rf $d; ( export TMPDIR=/tmp; cd /tmp; rocprofv3 --output-format csv --kernel-trace -d $d -o t -- python $OLDPWD/tools/pipe_probe.py --seconds 0.05 ${@:---sweep 1x1} > /dev/null 2>&1 )
-             python tools/pipe_timeline.py $d; rm -rf $d ;;
+             python tools/pipe_timeline.py $d | tee $O/pipe_timeline.txt; rm -rf $d ;;
     *)       echo "unknown task $t"; return 2 ;;
   esac
 }
