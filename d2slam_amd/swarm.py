@@ -186,6 +186,22 @@ class QuadSwarm:
             self.step(side.cuda_stream, group, src=self.snap)
 
 
+def remote_pair_layout(world: int, rank: int, F: int, cap: int, blk_words: int, loopback: bool = False):
+    """The cross-agent matchKNN problems of one submit on one rank (pure host logic; PipeExchange and its CPU test share it): local left frame f against the frame
+    with the same time index of every OTHER rank (trackRemoteFrames, d2featuretracker.cpp:237-310), rank-major.  Returns (a_off, b_off, q_frame, remote_block):
+    a_off = row of the local frame's descriptors in the lane's result block (rows of 256 floats, left frames first), b_off = row of the remote block's descriptors in
+    the gathered buffer [world][F][blk_words] (blocks are multiples of 256 words and start with their descriptors), q_frame = f, remote_block = r * F + f."""
+    assert blk_words % 256 == 0
+    rows = blk_words // 256
+    a_off, b_off, qf, rb = [], [], [], []
+    for r in range(world):
+        if r == rank and not loopback:
+            continue
+        for f in range(F):
+            a_off.append(f * cap); b_off.append((r * F + f) * rows); qf.append(f); rb.append(r * F + f)
+    return a_off, b_off, qf, rb
+
+
 class PipeExchange:
     """The cross-agent exchange of one rank BEHIND a frames-in-flight pipe (d2slam_amd.api.StereoPipe, include/d2fe.h d2fe_pipe_*): the stand-in for the reference's
     broadcast of the frame it has just extracted (loop_net.cpp:24-87) and trackRemoteFrames on the receivers (d2featuretracker.cpp:237-310), as ONE sequence per
@@ -215,7 +231,6 @@ class PipeExchange:
         self.BLK = block_words(cap, netvlad_dim)
         self.BLKB = block_bytes_int8(cap, netvlad_dim)
         self.block_bytes = self.BLKB if self.int8 else 4 * self.BLK
-        rows_per_block = self.BLK // 256
         f32, i32, i64 = torch.float32, torch.int32, torch.int64
         self.stream = torch.cuda.Stream(device=dev)
         self.blocks = torch.zeros((F, self.BLK), dtype=f32, device=dev)
@@ -229,12 +244,7 @@ class PipeExchange:
         else:
             self.own_n = self.blocks.view(i32).view(F, self.BLK)[:, block_field_offset(cap, netvlad_dim, "n")]
         self.n_off = block_field_offset(cap, netvlad_dim, "n"); self.g_off = block_field_offset(cap, netvlad_dim, "netvlad")
-        a_off, b_off, qf, rb = [], [], [], []
-        for r in range(world):
-            if r == rank and not loopback:
-                continue
-            for f in range(F):
-                a_off.append(f * cap); b_off.append((r * F + f) * rows_per_block); qf.append(f); rb.append(r * F + f)
+        a_off, b_off, qf, rb = remote_pair_layout(world, rank, F, cap, self.BLK, loopback)
         self.NR = len(a_off)
         t = lambda x, dt: torch.tensor(x, dtype=dt, device=dev)
         self.a_off, self.b_off = t(a_off, i32), t(b_off, i32)

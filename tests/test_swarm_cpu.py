@@ -91,6 +91,24 @@ def test_pair_list_layout():
     assert pl.b_off[4:] == [60 + b * (BLK // 256) for b in (0, 1, 4, 5)]
 
 
+def test_remote_pair_layout_of_the_exchange_behind_the_pipe():
+    """swarm.remote_pair_layout (what PipeExchange matches per submit): the same problems, in the same order, as PairList's remote part -- local left frame f against
+    frame f of every other rank, rank-major -- with b-side rows relative to the gathered buffer instead of the device-API pool; loopback adds the rank's own blocks."""
+    from d2slam_amd import swarm
+    F, cap, G = 3, 50, 512
+    BLK = swarm.block_words(cap, G)
+    for world, rank in ((2, 0), (2, 1), (4, 2), (8, 7)):
+        a, b, qf, rb = swarm.remote_pair_layout(world, rank, F, cap, BLK)
+        pl = swarm.PairList(F, cap, world, rank, BLK)
+        assert len(a) == pl.n_remote == (world - 1) * F
+        assert a == pl.a_off[pl.n_local:] and qf == pl.remote_q_frame and rb == pl.remote_block
+        assert [x + 3 * F * cap for x in b] == pl.b_off[pl.n_local:]
+        assert all(r // F != rank for r in rb) and all(0 <= x < world * F * (BLK // 256) for x in b)
+    a, b, qf, rb = swarm.remote_pair_layout(1, 0, F, cap, BLK, loopback=True)
+    assert qf == [0, 1, 2] and rb == [0, 1, 2] and b == [f * (BLK // 256) for f in range(F)]
+    assert swarm.remote_pair_layout(1, 0, F, cap, BLK) == ([], [], [], [])
+
+
 def test_block_layout_matches_the_abi():
     """swarm.block_words / block_field_offset (pure Python, used by the CPU tests) == the C ABI's (d2fe_block_words / _field_offset)."""
     from d2slam_amd import api, swarm
