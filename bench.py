@@ -817,11 +817,12 @@ def index_parity_evidence():
     fp16 hi/lo modes against the exact fp32 mode over 1056 images (992 synthetic + 64 derived from the real crops of the reference's sample image) at
     N = 100 / 150 / 200 and thresholds 0.015 / 0.15.  Summarised here as the worst rate over the six configurations; the bench frames of THIS run are
     compared live in `wino_vs_exact_on_bench_frames` / `f16x2_vs_exact_on_bench_frames`."""
-    path = os.path.join(ROOT, "profiles", "r04_mode_disagreement.json")
-    if not os.path.exists(path):
+    name = next((n for n in ("r05_mode_disagreement.json", "r04_mode_disagreement.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+    if name is None:
         return None
-    j = json.load(open(path))
-    out = {"source": "profiles/r04_mode_disagreement.json (python tools/mode_disagreement.py on MI355X, same kernels; not collected inside this run)",
+    j = json.load(open(os.path.join(ROOT, "profiles", name)))
+    out = {"source": "profiles/" + name + " (python tools/mode_disagreement.py on MI355X, same kernels; the FULL study is not collected inside this run -- its 128-image subset is: "
+                     "`index_parity_in_run`)",
            "images": j["images"], "real_derived_images": j["real_derived_images"], "pairs": j["pairs"], "configs": "N in {100, 150, 200} x threshold in {0.015, 0.15}"}
     for m in ("wino", "f16x2"):
         rows = [c["%s_vs_f32_all" % m] for c in j["configs"]]
