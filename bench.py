@@ -360,6 +360,14 @@ def main():
                                         "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
                                         "note": "submit() stages the frame (its H2D starts at once); every %d-th submit launches ONE sequence over the staged frames, "
                                                 "4 such passes in flight; per-ticket results are bit-identical to the single calls (tests/test_pipe.py)" % cc})
+                if use_nv:
+                    # four single-frame passes in flight, the NetVLAD descriptors of four consecutive submits from ONE call (d2fe_pipe_config.netvlad_group: the
+                    # global descriptor feeds loop detection, not the tracker, so it may trail the keypoints by up to three submits); SuperPoint and the matches of
+                    # every submit still start at once
+                    r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=True, light=True, nv_group=4)
+                    batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": 4, "coalesce": 1, "netvlad_group": 4, "stereo_fps": round(r["value"], 1),
+                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
+                                        "note": "netvlad_group = 4: one NetVLAD call per four consecutive single-frame submits; bit-identical results"})
                 # dynamic batching (coalesce_depth = 2): a pass is launched as soon as fewer than two are in flight, so the SAME configuration serves a caller
                 # that waits for every frame (1 in flight: launched at once) and one that keeps 16 in flight (passes grow to 4 frames)
                 for infl in (1, 4, 16):
@@ -618,7 +626,7 @@ def netvlad_roofline(t_ms, F, how, flop_per_img=NV_FLOP_PER_IMG):
 
 
 def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup, local_rank, rank, netvlad=True, light=False, coalesce=1, depth=0, inflight=0,
-             world=1, dist=None, exchange=None, nv_flop_per_img=NV_FLOP_PER_IMG):
+             world=1, dist=None, exchange=None, nv_flop_per_img=NV_FLOP_PER_IMG, nv_group=1):
     """`steps` submits of F stereo frames through the frames-in-flight pipe with `lanes` submits in flight: the timed region holds, per submit, the H2D of
     the 2F frames from pinned memory, SuperPoint on them, NetVLAD of the F left images, ONE matcher launch (L<->R, L<->previous L) and the D2H of every
     result into pinned memory.  EVERY --gpus N runs this function (N = 1: no process group, no barrier).  N > 1 with `exchange`: one cross-agent exchange
@@ -632,7 +640,7 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
     if netvlad:
         fe.load_netvlad(nv_weights)
     host = torch.from_numpy(pipe_frames(F, rank)).pin_memory()
-    pipe = api.StereoPipe(fe, lanes=lanes, frames=F, width=W, height=H, cap=CAP, netvlad=netvlad, ratio=0.8, pinned_input=True, coalesce=coalesce, coalesce_depth=depth)
+    pipe = api.StereoPipe(fe, lanes=lanes, frames=F, width=W, height=H, cap=CAP, netvlad=netvlad, ratio=0.8, pinned_input=True, coalesce=coalesce, coalesce_depth=depth, netvlad_group=nv_group)
     inflight = inflight or lanes * coalesce
     base, per_set, per_side = host.data_ptr(), 2 * F * H * W, F * H * W
     dev = torch.device("cuda", local_rank)
