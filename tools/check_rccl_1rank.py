@@ -38,7 +38,8 @@ import numpy as np  # noqa: E402
 from d2slam_amd import api, netvlad as nvm  # noqa: E402
 from d2slam_amd.synth import synth_stereo  # noqa: E402
 from d2slam_amd.weights import synthetic_superpoint_weights  # noqa: E402
-H, W, CAP, FR, LANES, STEPS = 120, 160, 60, 2, 2, 5
+H, W, CAP, FR, LANES = 120, 160, 60, 2, 2
+STEPS = int(os.environ.get("D2FE_RCCL_CHECK_STEPS", "5"))      # e.g. 4000: a soak of the view / release hand-over between the lanes and the exchange stream
 fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2 * FR, precision=api.PREC_F32_WINO))
 fe.load_superpoint(synthetic_superpoint_weights(dustbin_bias=7.5)); fe.load_netvlad(nvm.synthetic_netvlad_weights())
 pipe = api.StereoPipe(fe, lanes=LANES, frames=FR, width=W, height=H, cap=CAP, netvlad=True)
@@ -46,9 +47,12 @@ NS = LANES + 2
 x = swarm.PipeExchange(torch, fe, pipe, dev, 1, 0, FR, CAP, fe.netvlad_dim, exchange="fp32", slots=NS, loopback=True)
 assert x.worker is None and x.NR == FR
 tk, enq, checked = [], 0, 0
-for i in range(STEPS):
+sets = []
+for i in range(6):      # a ring of frame sets (the soak cycles over them: every result block of the pipe is rewritten hundreds of times)
     fr = [synth_stereo(H, W, seed=900 + 3 * i + f) for f in range(FR)]
-    tk.append(pipe.submit(np.stack([p[0] for p in fr]), np.stack([p[1] for p in fr])))
+    sets.append((np.stack([p[0] for p in fr]), np.stack([p[1] for p in fr])))
+for i in range(STEPS):
+    tk.append(pipe.submit(*sets[i % len(sets)]))
     while enq <= i - 1:
         x.enqueue(tk[enq], enq % NS); enq += 1
     if i >= LANES:
