@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency leg (host-pointer C ABI, one frame per call)")
     ap.add_argument("--latency-calls", type=int, default=300)
     ap.add_argument("--no-width-sensitivity", action="store_true", help="skip the NetVLAD trunk-width legs (`netvlad_width_sensitivity`)")
+    ap.add_argument("--no-exchange-loopback", action="store_true", help="skip the one-GPU RCCL leg of the cross-agent exchange (`exchange_on_one_gpu_rccl`)")
     ap.add_argument("--no-parity-study", action="store_true", help="skip the in-run 128-image index-parity study (`index_parity_in_run`)")
     ap.add_argument("--no-solo", action="store_true", help="with --single-mode: skip the extra leg with ONE submit in flight that measures the dominant kernel alone")
     ap.add_argument("--latency-only", action="store_true", help="print only the single-call latency leg, in a process that does nothing but call the C ABI")
@@ -287,6 +288,7 @@ def main():
     noexch = None
     width_sens = None
     parity_in_run = None
+    exch_1gpu = None
     # EVERY --gpus N times the frames-in-flight pipe (include/d2fe.h, d2fe_pipe_*): host frames in, host results out, `lanes` submits in flight.  N > 1 adds the
     # cross-agent exchange on a stream of its own beside it (run_pipe / swarm.PipeExchange); nothing else differs between `--gpus 1` and `--gpus 8`
     lanes = args.lanes or LANES_FOR.get(args.frames, 2)
@@ -326,6 +328,8 @@ def main():
                                  netvlad=True, nv_flop_per_img=nvm2.arch_flops(mult, H, W))
                 width_sens["points"].append({"depth_multiplier": mult, "trunk_gflop_per_image": round(nvm2.arch_flops(mult, H, W) / 1e9, 3), "value": round(r["value"], 1),
                                              "ms_per_step": round(r["ms_per_step"], 3), "netvlad_ms_per_call_beside_superpoint": (r.get("roofline_nv") or {}).get("ms_per_call")})
+        if not args.no_exchange_loopback:
+            exch_1gpu = exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, lanes, short, local_rank, rank, use_nv, dev)
         if not args.no_parity_study:
             # index parity of the TIMED build, collected in this run: a 128-image subset of tools/mode_disagreement.py's study
             from d2slam_amd import parity_study as ps
@@ -515,6 +519,8 @@ def main():
             out["index_parity_evidence"] = ev
         if width_sens:
             out["netvlad_width_sensitivity"] = width_sens
+        if exch_1gpu:
+            out["exchange_on_one_gpu_rccl"] = exch_1gpu
         if batch_curve:
             out["batch_curve"] = {"what": "stereo fps of the same step (H2D, SuperPoint L+R, NetVLAD L, matchKNN L<->R and L<->previous L, D2H of everything) against the stereo frames "
                                           "per submit, through d2fe_pipe_*; submits_in_flight = 1 is the synchronous single-call form (the way the reference calls the path, "
@@ -616,6 +622,41 @@ def pipe_frames(F, rank):
     return host
 
 
+def exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, lanes, steps, local_rank, rank, use_nv, dev):
+    """What the N > 1 exchange costs the step on the REAL backend, as far as one GPU can show it ("--gpus 1 through that path equals BENCH value within 1 %"):
+    a one-rank RCCL communicator, the rank's own blocks as the remote agent (PipeExchange loopback: F cross-agent pairs per submit, every keypoint matches itself), the same
+    pipe configuration as `value`, alternating with the same step without the exchange.  Any failure (no RCCL, rendezvous) is reported, never fatal."""
+    created = False
+    try:
+        if not dist.is_initialized():
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(port)
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            created = True
+        runs = []
+        for _ in range(2):
+            w = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, steps, 2, local_rank, rank, netvlad=use_nv, light=True, world=1, dist=dist,
+                         exchange=args.exchange, loopback=True)
+            wo = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, steps, 2, local_rank, rank, netvlad=use_nv, light=True)
+            runs.append((w, wo))
+        w = min((r[0] for r in runs), key=lambda r: r["ms_per_step"]); wo = min((r[1] for r in runs), key=lambda r: r["ms_per_step"])
+        return {"backend": dist.get_backend(), "what": "the value step (%d stereo frames per submit, %d submits in flight) with the cross-agent exchange of `--gpus N` on its own stream over a ONE-rank "
+                           "RCCL communicator (loopback: the rank's own blocks as the remote agent, %d cross-agent pairs per submit), against the same step without it; best of two "
+                           "alternating runs each" % (args.frames, lanes, w["exch"]["cross_agent_pairs_per_step_per_gpu"]),
+                "value_with_exchange": round(w["value"], 2), "value_without_exchange": round(wo["value"], 2), "ms_per_step_with_exchange": round(w["ms_per_step"], 3),
+                "ms_per_step_without_exchange": round(wo["ms_per_step"], 3), "exchange_cost_frac_of_step": round(w["ms_per_step"] / wo["ms_per_step"] - 1.0, 4),
+                "step_timeline_ms": w["exch"]["step_timeline_ms"], "wire_precision": args.exchange}
+    except Exception as e:      # noqa: BLE001
+        return {"error": str(e)[:300]}
+    finally:
+        if created:
+            try:
+                dist.destroy_process_group()
+            except Exception:      # noqa: BLE001
+                pass
+
+
 def netvlad_roofline(t_ms, F, how, flop_per_img=NV_FLOP_PER_IMG):
     ach = flop_per_img * F / (t_ms * 1e-3) / 1e12
     return {"kernel": "NetVLAD launch sequence (27 launches: nv_fpair_kernel, nv_pblock_kernel x12 (stride 1), nv_xblock_kernel x4 (stride 2), nv_slab_sum_kernel x7, nv_tail_kernel, "
@@ -626,7 +667,7 @@ def netvlad_roofline(t_ms, F, how, flop_per_img=NV_FLOP_PER_IMG):
 
 
 def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup, local_rank, rank, netvlad=True, light=False, coalesce=1, depth=0, inflight=0,
-             world=1, dist=None, exchange=None, nv_flop_per_img=NV_FLOP_PER_IMG, nv_group=1):
+             world=1, dist=None, exchange=None, nv_flop_per_img=NV_FLOP_PER_IMG, nv_group=1, loopback=False):
     """`steps` submits of F stereo frames through the frames-in-flight pipe with `lanes` submits in flight: the timed region holds, per submit, the H2D of
     the 2F frames from pinned memory, SuperPoint on them, NetVLAD of the F left images, ONE matcher launch (L<->R, L<->previous L) and the D2H of every
     result into pinned memory.  EVERY --gpus N runs this function (N = 1: no process group, no barrier).  N > 1 with `exchange`: one cross-agent exchange
@@ -646,8 +687,9 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
     dev = torch.device("cuda", local_rank)
     NS = inflight + 3
     xch = None
-    if world > 1 and exchange:
-        xch = swarm.PipeExchange(torch, fe, pipe, dev, world, rank, F, CAP, fe.netvlad_dim if netvlad else 0, exchange=exchange, gate_thres=NETVLAD_GATE, ratio=0.8, slots=NS)
+    if (world > 1 or loopback) and exchange:
+        xch = swarm.PipeExchange(torch, fe, pipe, dev, world, rank, F, CAP, fe.netvlad_dim if netvlad else 0, exchange=exchange, gate_thres=NETVLAD_GATE, ratio=0.8, slots=NS,
+                                 loopback=loopback)
 
     def submit(i):
         o = base + (i & 1) * per_set
@@ -713,7 +755,7 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
                breakdown=None, fallback_rows=(fb[0] / float(steps + warmup), fb[1] / float(steps + warmup)), roofline=None, roofline_nv=None)
     if xch:
         S = last["x"]
-        res["exch"] = {"wire_precision": exchange, "block_bytes": xch.block_bytes, "all_gather_bytes_received_per_step_per_gpu": xch.block_bytes * F * (world - 1),
+        res["exch"] = {"wire_precision": exchange, "block_bytes": xch.block_bytes, "all_gather_bytes_received_per_step_per_gpu": xch.block_bytes * F * (world - 1 + (1 if loopback else 0)),
                        "cross_agent_pairs_per_step_per_gpu": xch.NR, "avg_cross_agent_matches_per_pair": round(float(S["mn"].float().mean()), 2),
                        "d2h_bytes_per_step": xch.d2h_bytes, "enqueued": "one submit behind the pipe, on a stream of its own; collected with the ticket",
                        "step_timeline_ms": dict(xch.timeline_ms() or {}, note="rank 0, medians over the timed submits, HIP events on the exchange stream (which shares the device "
