@@ -137,6 +137,20 @@ def test_rccl_single_rank_collectives():
     assert r.returncode == 0 and "RCCL 1-rank OK" in r.stdout, (r.stdout + r.stderr)[-2000:]
 
 
+def test_bench_one_gpu_rccl_loopback_leg():
+    """bench.py's `exchange_on_one_gpu_rccl`: the N > 1 exchange sequence behind the value step over a ONE-rank RCCL communicator (loopback), with vs without -- the
+    real backend's asynchronous all-gather on the exchange stream, as far as a 1-GPU box can show it.  The leg must run (no "error") and cost a few per cent at most."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--frames", "8", "--no-cpu-baseline", "--no-latency", "--no-batch-curve",
+                        "--no-live-traffic", "--no-width-sensitivity", "--no-parity-study"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    e = j["exchange_on_one_gpu_rccl"]
+    assert "error" not in e, e
+    assert e["backend"] == "nccl" and e["value_with_exchange"] > 0 and e["step_timeline_ms"]["all_gather"] > 0
+    assert e["exchange_cost_frac_of_step"] < 0.25, e      # ~2 % at 32 frames per submit; small steps on a shared box are noisier
+
+
 def test_int8_exchange_blocks_vs_reference_codec():
     """The int8 wire format of the exchange block: bytes equal the reference's own toLCM quantisation (oracle/_ref, compiled in place) on the
     frame's n x 256 descriptor vector and on the NetVLAD vector; the decoded fp32 block equals the reference's LCM-constructor decode
