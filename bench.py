@@ -328,8 +328,6 @@ def main():
                                  netvlad=True, nv_flop_per_img=nvm2.arch_flops(mult, H, W))
                 width_sens["points"].append({"depth_multiplier": mult, "trunk_gflop_per_image": round(nvm2.arch_flops(mult, H, W) / 1e9, 3), "value": round(r["value"], 1),
                                              "ms_per_step": round(r["ms_per_step"], 3), "netvlad_ms_per_call_beside_superpoint": (r.get("roofline_nv") or {}).get("ms_per_call")})
-        if not args.no_exchange_loopback:
-            exch_1gpu = exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, lanes, short, local_rank, rank, use_nv, dev)
         if not args.no_parity_study:
             # index parity of the TIMED build, collected in this run: a 128-image subset of tools/mode_disagreement.py's study
             from d2slam_amd import parity_study as ps
@@ -413,6 +411,10 @@ def main():
     if rank == 0 and world == 1 and not args.single_mode:
         qa = argparse.Namespace(**vars(args)); qa.steps = 8; qa.warmup = 2
         quad = run_quadcam(qa, torch, api, weights, dev, local_rank, world)
+
+    if rank == 0 and world == 1 and not args.single_mode and not args.no_exchange_loopback:
+        # LAST leg of the run: it creates (and destroys) a one-rank RCCL communicator, whose proxy threads and streams must not sit beside any other measurement
+        exch_1gpu = exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, lanes, short, local_rank, rank, use_nv, dev)
 
     if rank == 0:
         value, ms_per_step = primary["value"], primary["ms_per_step"]
