@@ -1065,7 +1065,9 @@ def run_quadcam(args, torch, api, weights, dev, local_rank, world, rank=0):
            "avg_matches_per_pair": round(chain.mn.float().mean().item(), 1),
            "roofline": {"kernel": "conv1b (executed MFMA FLOPs)", "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "frac_executed": round(ach / peak, 4), "frac_algorithmic": round(flop / (avg_ms * 1e-3) / 1e12 / peak, 4) if avg_ms else 0,
-                        "traffic": None},
+                        "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": c1b_n,
+                        "measured": "HIP events on the one stream the quadcam chain runs on (undistort, NetVLAD, SuperPoint, matching in stream order): the launch has the device to itself",
+                        "traffic_note": "not collected for this leg (the d435 headline's conv1b launch is the same kernel: `roofline.traffic`)"},
            "cpu_baseline": None}
     if qs:
         dp = qs.dir_prev.cpu().numpy()
