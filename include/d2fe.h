@@ -309,7 +309,9 @@ D2FE_API int d2fe_pipe_wait(d2fe_pipe p, int64_t ticket, d2fe_pipe_result* out);
  *                             NetVLAD results (not for its matcher or its D2H) and returns DEVICE pointers into the lane's result block: the same arrays, in the same
  *                             row order, as d2fe_pipe_result.  Read-only.  Valid until the matching release, at most 2 * lanes passes.
  *   d2fe_pipe_device_release  everything queued on `stream` so far is what read the view: the lane's next write of that block waits for it (an event, no host wait).
- * A block whose view has not been released when its lane comes round again (2 * lanes passes later) fails that submit with D2FE_ERR_INVALID.  Not available with netvlad_group > 1. */
+ * A block whose view has not been released when its lane comes round again (2 * lanes passes later) fails that submit with D2FE_ERR_INVALID (and, like every failed
+ * submit, ends the pipe).  Use ONE consumer stream per pipe (the lane waits for the LAST release recorded for a block: consumers on several streams would have to order
+ * those streams among themselves).  Both calls may come from a thread other than the submitting one.  Not available with netvlad_group > 1. */
 typedef struct {
   int32_t frames, cap, desc_dim, netvlad_dim;
   const float* d_kps_xy;    /* [2 frames][cap][2] */
