@@ -80,7 +80,6 @@ def main():
     ap.add_argument("--no-exchange-loopback", action="store_true", help="skip the one-GPU RCCL leg of the cross-agent exchange (`exchange_on_one_gpu_rccl`)")
     ap.add_argument("--no-parity-study", action="store_true", help="skip the in-run 128-image index-parity study (`index_parity_in_run`)")
     ap.add_argument("--no-solo", action="store_true", help="with --single-mode: skip the extra leg with ONE submit in flight that measures the dominant kernel alone")
-    ap.add_argument("--batch-curve-child", action="store_true", help="print only the batch-curve points (what the default run spawns: a process that only drives the pipe)")
     ap.add_argument("--latency-only", action="store_true", help="print only the single-call latency leg, in a process that does nothing but call the C ABI")
     args = ap.parse_args()
     for k in REFUSED_ENV:
@@ -101,17 +100,6 @@ def main():
         print(json.dumps({"latency": run_latency(api, synthetic_superpoint_weights(dustbin_bias=7.5), nvm.synthetic_netvlad_weights(),
                                                  int(os.environ.get("LOCAL_RANK", "0")), args.precision, args.latency_calls),
                           }), flush=True)
-        return
-
-    if args.batch_curve_child:
-        # the batch curve in a process of its own (see the parent's comment): torch only for pinned memory and synchronisation
-        import torch
-        from d2slam_amd import api, netvlad as nvm
-        from d2slam_amd.weights import synthetic_superpoint_weights
-        lr = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(lr)
-        print(json.dumps({"batch_curve_points": batch_curve_points(torch, api, synthetic_superpoint_weights(dustbin_bias=7.5), nvm.synthetic_netvlad_weights(), args.precision,
-                                                                   args.frames, args.lanes or LANES_FOR.get(args.frames, 2), lr, 0, not args.no_netvlad)}), flush=True)
         return
 
     import torch
@@ -301,7 +289,6 @@ def main():
     width_sens = None
     parity_in_run = None
     exch_1gpu = None
-    batch_curve_where = None
     # EVERY --gpus N times the frames-in-flight pipe (include/d2fe.h, d2fe_pipe_*): host frames in, host results out, `lanes` submits in flight.  N > 1 adds the
     # cross-agent exchange on a stream of its own beside it (run_pipe / swarm.PipeExchange); nothing else differs between `--gpus 1` and `--gpus 8`
     lanes = args.lanes or LANES_FOR.get(args.frames, 2)
@@ -353,29 +340,43 @@ def main():
                              "wino_vs_f32": rec["wino_vs_f32_all"], "f16x2_vs_f32": rec["f16x2_vs_f32_all"], "wino_vs_f32_real_derived": rec["wino_vs_f32_real_derived"],
                              "seconds": round(time.time() - t_ps, 1)}
     if world == 1 and not args.no_batch_curve and not args.single_mode:
-        # the two points of the headline's own frame count are this process's measurements (`primary`, and the same step with ONE submit in flight: every
-        # kernel has the device to itself -- the `roofline` object); every other point comes from a child process that does nothing but drive the pipe
-        # (--batch-curve-child): in THIS process the dozens of streams of the other legs share the runtime's hardware queues with the lanes' streams, which costs
-        # the many-small-launches points up to 10 % (the latency leg is run in a child for the same reason)
-        solo = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, 1, max(12, min(400, int(700 / args.frames))), 4, local_rank, rank, netvlad=use_nv)
-        pts, where = None, "a process of its own that only drives the pipe (python bench.py --batch-curve-child)"
-        try:
-            import subprocess
-            cmd = [sys.executable, os.path.abspath(__file__), "--batch-curve-child", "--precision", args.precision, "--frames", str(args.frames), "--lanes", str(lanes)]
-            r = subprocess.run(cmd + (["--no-netvlad"] if not use_nv else []), capture_output=True, text=True, timeout=600, env=dict(os.environ, LOCAL_RANK=str(local_rank)))
-            pts = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["batch_curve_points"]
-        except Exception as e:      # noqa: BLE001
-            where = "the benchmark process (the child process failed: %s)" % str(e)[:100]
-        if pts is None:
-            pts = batch_curve_points(torch, api, weights, nv_weights, args.precision, args.frames, lanes, local_rank, rank, use_nv)
         batch_curve = []
-        for pt in pts:
-            if pt.get("placeholder"):
-                r = primary if pt["submits_in_flight"] == lanes else solo
-                pt = {"stereo_frames_per_submit": pt["stereo_frames_per_submit"], "submits_in_flight": pt["submits_in_flight"], "coalesce": 1, "stereo_fps": round(r["value"], 1),
-                      "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "measured_in": "the benchmark process"}
-            batch_curve.append(pt)
-        batch_curve_where = where
+        for Fc in (1, 2, 4, 8, 16, 32):
+            for Kc in sorted({1, LANES_FOR[Fc]}):
+                if Fc == args.frames and Kc == lanes:
+                    r = primary
+                else:
+                    alone = Fc == args.frames and Kc == 1      # the step with ONE submit in flight: every kernel has the device to itself
+                    r = run_pipe(torch, api, weights, nv_weights, args.precision, Fc, Kc, max(12, min(400, int(700 / Fc))), max(2 * Kc, 4), local_rank, rank, netvlad=use_nv,
+                                 light=not alone)
+                    if alone:
+                        solo = r
+                batch_curve.append({"stereo_frames_per_submit": Fc, "submits_in_flight": Kc, "coalesce": 1, "stereo_fps": round(r["value"], 1), "ms_per_submit": round(r["ms_per_step"], 4),
+                                    "host_ms_per_submit_call": round(r["host_submit_ms"], 4)})
+            if Fc == 1:
+                # one stereo frame per submit, consecutive submits coalesced into one launch sequence when they arrive before anybody waits
+                # (d2fe_pipe_config.coalesce): what a caller that receives single frames gets without batching by hand
+                for cc in (2, 4):
+                    r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, coalesce=cc)
+                    batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": 4 * cc, "coalesce": cc, "stereo_fps": round(r["value"], 1),
+                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
+                                        "note": "submit() stages the frame (its H2D starts at once); every %d-th submit launches ONE sequence over the staged frames, "
+                                                "4 such passes in flight; per-ticket results are bit-identical to the single calls (tests/test_pipe.py)" % cc})
+                if use_nv:
+                    # four single-frame passes in flight, the NetVLAD descriptors of four consecutive submits from ONE call (d2fe_pipe_config.netvlad_group: the
+                    # global descriptor feeds loop detection, not the tracker, so it may trail the keypoints by up to three submits); SuperPoint and the matches of
+                    # every submit still start at once
+                    r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=True, light=True, nv_group=4)
+                    batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": 4, "coalesce": 1, "netvlad_group": 4, "stereo_fps": round(r["value"], 1),
+                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
+                                        "note": "netvlad_group = 4: one NetVLAD call per four consecutive single-frame submits; bit-identical results"})
+                # dynamic batching (coalesce_depth = 2): a pass is launched as soon as fewer than two are in flight, so the SAME configuration serves a caller
+                # that waits for every frame (1 in flight: launched at once) and one that keeps 16 in flight (passes grow to 4 frames)
+                for infl in (1, 4, 16):
+                    r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, coalesce=4, depth=2, inflight=infl)
+                    batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": infl, "coalesce": 4, "coalesce_depth": 2, "stereo_fps": round(r["value"], 1),
+                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
+                                        "note": "dynamic batching: up to 4 consecutive submits per pass, launched early whenever fewer than 2 passes are in flight"})
     if world == 1 and solo is None and lanes > 1 and not args.no_solo:
         # --single-mode / --no-batch-curve: the headline kernel's solo measurement still belongs to the line
         solo = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, 1, short, 2, local_rank, rank, netvlad=use_nv)
@@ -525,7 +526,7 @@ def main():
         if batch_curve:
             out["batch_curve"] = {"what": "stereo fps of the same step (H2D, SuperPoint L+R, NetVLAD L, matchKNN L<->R and L<->previous L, D2H of everything) against the stereo frames "
                                           "per submit, through d2fe_pipe_*; submits_in_flight = 1 is the synchronous single-call form (the way the reference calls the path, "
-                                          "loop_cam.cpp:609-616), the other line keeps that many submits in flight on separate streams", "measured_in": batch_curve_where, "points": batch_curve}
+                                          "loop_cam.cpp:609-616), the other line keeps that many submits in flight on separate streams", "points": batch_curve}
         if device_resident:
             out["device_resident"] = {k: device_resident[k] for k in ("value", "unit", "ms_per_step", "workload")}
         if latency:
@@ -621,42 +622,6 @@ def pipe_frames(F, rank):
         host[0, 0, f], host[0, 1, f] = l, r
         host[1, 0, f], host[1, 1, f] = np.roll(l, (2, 3), (0, 1)), np.roll(r, (2, 3), (0, 1))
     return host
-
-
-def batch_curve_points(torch, api, weights, nv_weights, precision, frames, lanes, local_rank, rank, use_nv):
-    """The points of `batch_curve` (stereo fps of the same step against the stereo frames per submit and the submits in flight), except the two at the headline's own
-    frame count, which the caller measures itself (placeholders here).  Run in a process of its own by the default bench (--batch-curve-child)."""
-    pts = []
-
-    def rec(r, F, K, coalesce=1, **extra):
-        return dict({"stereo_frames_per_submit": F, "submits_in_flight": K, "coalesce": coalesce, "stereo_fps": round(r["value"], 1), "ms_per_submit": round(r["ms_per_step"], 4),
-                     "host_ms_per_submit_call": round(r["host_submit_ms"], 4)}, **extra)
-    for Fc in (1, 2, 4, 8, 16, 32):
-        for Kc in sorted({1, LANES_FOR[Fc]} | ({lanes} if Fc == frames else set())):
-            if Fc == frames and Kc in (1, lanes):
-                pts.append({"placeholder": True, "stereo_frames_per_submit": Fc, "submits_in_flight": Kc})
-                continue
-            r = run_pipe(torch, api, weights, nv_weights, precision, Fc, Kc, max(12, min(400, int(700 / Fc))), max(2 * Kc, 4), local_rank, rank, netvlad=use_nv, light=True)
-            pts.append(rec(r, Fc, Kc))
-        if Fc == 1:
-            # one stereo frame per submit, consecutive submits coalesced into one launch sequence when they arrive before anybody waits
-            # (d2fe_pipe_config.coalesce): what a caller that receives single frames gets without batching by hand
-            for cc in (2, 4):
-                r = run_pipe(torch, api, weights, nv_weights, precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, coalesce=cc)
-                pts.append(rec(r, 1, 4 * cc, cc, note="submit() stages the frame (its H2D starts at once); every %d-th submit launches ONE sequence over the staged frames, "
-                                                      "4 such passes in flight; per-ticket results are bit-identical to the single calls (tests/test_pipe.py)" % cc))
-            if use_nv:
-                # four single-frame passes in flight, the NetVLAD descriptors of four consecutive submits from ONE call (d2fe_pipe_config.netvlad_group: the
-                # global descriptor feeds loop detection, not the tracker, so it may trail the keypoints by up to three submits); SuperPoint and the matches of
-                # every submit still start at once
-                r = run_pipe(torch, api, weights, nv_weights, precision, 1, 4, 600, 16, local_rank, rank, netvlad=True, light=True, nv_group=4)
-                pts.append(rec(r, 1, 4, 1, netvlad_group=4, note="netvlad_group = 4: one NetVLAD call per four consecutive single-frame submits; bit-identical results"))
-            # dynamic batching (coalesce_depth = 2): a pass is launched as soon as fewer than two are in flight, so the SAME configuration serves a caller
-            # that waits for every frame (1 in flight: launched at once) and one that keeps 16 in flight (passes grow to 4 frames)
-            for infl in (1, 4, 16):
-                r = run_pipe(torch, api, weights, nv_weights, precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, coalesce=4, depth=2, inflight=infl)
-                pts.append(rec(r, 1, infl, 4, coalesce_depth=2, note="dynamic batching: up to 4 consecutive submits per pass, launched early whenever fewer than 2 passes are in flight"))
-    return pts
 
 
 def exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, lanes, steps, local_rank, rank, use_nv, dev):
