@@ -342,7 +342,7 @@ def main():
     if world == 1 and not args.no_batch_curve and not args.single_mode:
         batch_curve = []
         for Fc in (1, 2, 4, 8, 16, 32):
-            for Kc in sorted({1, LANES_FOR[Fc]}):
+            for Kc in sorted({1, LANES_FOR[Fc]} | ({2} if Fc <= 2 else set())):      # one or two frames per submit: also TWO in flight (the best plain configuration at F = 1)
                 if Fc == args.frames and Kc == lanes:
                     r = primary
                 else:
