@@ -704,7 +704,7 @@ class StereoPipe:
     submit() enqueues and returns a ticket; wait() returns views into the lane's pinned result block (copy what must outlive 2 * lanes submits)."""
 
     def __init__(self, fe: FrontEnd, lanes=4, frames=1, width=640, height=480, cap=None, netvlad=True, match_lr=True, match_prev=True,
-                 ratio=0.8, radius_lr=-1.0, radius_prev=-1.0, pinned_input=False, cu_partition=False, netvlad_inline=False, coalesce=1, lane_cus=0, netvlad_group=1, coalesce_depth=0):
+                 ratio=0.8, radius_lr=-1.0, radius_prev=-1.0, pinned_input=False, cu_partition=False, netvlad_inline=None, coalesce=1, lane_cus=0, netvlad_group=1, coalesce_depth=0):
         self._lib = fe._lib
         self._fe = fe           # the pipe borrows the handle's weights
         c = _PipeConfig()
@@ -713,7 +713,7 @@ class StereoPipe:
         c.cap = int(cap or fe.cfg.max_keypoints)
         c.netvlad, c.match_lr, c.match_prev, c.pinned_input = int(bool(netvlad)), int(bool(match_lr)), int(bool(match_prev)), int(bool(pinned_input))
         c.ratio, c.radius_lr, c.radius_prev = float(ratio), float(radius_lr), float(radius_prev)
-        c.cu_partition = int(bool(cu_partition)); c.netvlad_inline = int(bool(netvlad_inline)); c.coalesce = int(coalesce); c.lane_cus = int(lane_cus); c.netvlad_group = int(netvlad_group); c.coalesce_depth = int(coalesce_depth)
+        c.cu_partition = int(bool(cu_partition)); c.netvlad_inline = 2 if netvlad_inline is None else int(bool(netvlad_inline));      # None: auto (inline when lanes > 2) c.coalesce = int(coalesce); c.lane_cus = int(lane_cus); c.netvlad_group = int(netvlad_group); c.coalesce_depth = int(coalesce_depth)
         self._p = C.c_void_p()
         _check(self._lib.d2fe_pipe_create(fe.handle, C.byref(c), C.byref(self._p)))
         if not hasattr(fe, "_pipes"):

@@ -67,6 +67,7 @@ struct d2fe_pipe_s {
   long long next_pass = 0;           // passes started so far
   int pend = 0;                      // submits of the newest pass that are staged but not launched yet (0: no pass open)
   int prev_g = 1;                    // submits of the last LAUNCHED pass
+  bool nv_inline = false;            // cfg.netvlad_inline resolved (2 = auto: inline when lanes > 2)
   int failed = D2FE_OK;              // sticky: the first error of an enqueue leaves a pass half-queued (frames copied or not, events recorded or not); the ring
                                      // bookkeeping of every later pass would build on it, so every later submit / wait returns this code instead
   std::string failed_msg;
@@ -105,7 +106,7 @@ int pipe_flush(d2fe_pipe_s* p) {
   const int n_left = p->C > 1 ? g : F, n_img = p->C > 1 ? 2 * g : 2 * F;
   const size_t left_stride = p->C > 1 ? 2 * img : img;
   int rc;
-  const bool nv_side = p->cfg.netvlad && !p->cfg.netvlad_inline && p->M == 1;
+  const bool nv_side = p->cfg.netvlad && !p->nv_inline && p->M == 1;
   // device views of this block (handed out 2 K passes ago): the consumers' stream must be through with it before this pass writes it.  The NetVLAD
   // stream is ordered behind this wait through ev_up
   if (L.views[set] > 0) return pipe_fail(D2FE_ERR_INVALID, "a device view of this lane's result block was not released (d2fe_pipe_device_release) within 2 * lanes passes");
@@ -118,7 +119,7 @@ int pipe_flush(d2fe_pipe_s* p) {
   // 0.25-0.3 ms beside it), and enqueuing NetVLAD's 27 launches costs ~0.12 ms of host time: issued first (rounds 3-4) they held conv1b back by that much in a
   // pass of one frame.  NetVLAD on the lane's second stream still only waits for the frames (ev_up)
   if (nv_side) HIP_TRY(hipEventRecord(L.ev_up, s));
-  else if (p->cfg.netvlad && p->M == 1) {        // netvlad_inline: one stream, NetVLAD in front (half as many streams; order is the stream's)
+  else if (p->cfg.netvlad && p->M == 1) {        // inline: ONE stream per lane, NetVLAD in front of SuperPoint (behind it measured 8 % slower at four lanes: 1869 vs 2039)
     rc = netvlad(s);
     if (rc) return rc;
   }
@@ -186,6 +187,7 @@ void d2fe_pipe_default_config(d2fe_pipe_config* c) {
   c->netvlad = 1; c->match_lr = 1; c->match_prev = 1; c->pinned_input = 0;
   c->ratio = 0.8; c->radius_lr = -1.0; c->radius_prev = -1.0;
   c->coalesce = 1;
+  c->netvlad_inline = 2;      // auto
 }
 
 int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out) {
@@ -198,6 +200,7 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
   const int C = cfg->coalesce > 0 ? cfg->coalesce : 1;
   if (C > 16 || (C > 1 && cfg->frames != 1)) return pipe_fail(D2FE_ERR_INVALID, "coalesce must be 1..16 and needs frames == 1");
   if (cfg->coalesce_depth < 0 || cfg->coalesce_depth > cfg->lanes) return pipe_fail(D2FE_ERR_INVALID, "coalesce_depth must be 0..lanes");
+  if (cfg->netvlad_inline < 0 || cfg->netvlad_inline > 2) return pipe_fail(D2FE_ERR_INVALID, "netvlad_inline must be 0 (side stream), 1 (inline) or 2 (auto)");
   const int M = cfg->netvlad && cfg->netvlad_group > 1 ? cfg->netvlad_group : 1;
   if (M > 1 && (cfg->frames != 1 || C != 1 || cfg->lanes % M != 0)) return pipe_fail(D2FE_ERR_INVALID, "netvlad_group needs frames == 1, coalesce == 1 and lanes % netvlad_group == 0");
   if (cfg->cap < 1 || cfg->cap > 16384) return pipe_fail(D2FE_ERR_INVALID, "cap out of range");
@@ -208,6 +211,7 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
   p->parent = h; p->cfg = *cfg;
   h->live_pipes.fetch_add(1);        // from here on d2fe_pipe_destroy (every failure path below goes through it or through `delete p` + the decrement) gives it back
   p->M = M;
+  p->nv_inline = cfg->netvlad_inline == 1 || (cfg->netvlad_inline == 2 && cfg->lanes > 2);
   p->K = cfg->lanes; p->F = cfg->frames; p->C = C; p->NI = 2 * cfg->frames * C; p->W = cfg->width; p->H = cfg->height;
   p->cap = cfg->cap < h->cfg.max_keypoints ? cfg->cap : h->cfg.max_keypoints;
   p->D = d2fe_desc_dim(h);
@@ -248,6 +252,11 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
       for (auto& e : p->ev_g) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     p->lanes.resize(p->K);
+    // Streams (round 5).  The device services FOUR busy compute streams of a process side by side; a fifth takes turns with one of them (lanes x 1 frame, NetVLAD on a
+    // second stream per lane: 2 lanes 1830-1855 stereo fps, 3 lanes 1470-1515, 4 lanes 1640-1780; NetVLAD inline, one stream per lane: 3 lanes 1779, FOUR lanes 2039, 5 lanes 1544;
+    // profiles/r05_pipe_one_frame.txt).  So: a stream that would never be used (inline mode, netvlad_group, no NetVLAD) is not created at all -- even idle it shifts the others'
+    // hardware queues (4 inline lanes with four unused NetVLAD streams beside them: 1184-1290) -- and netvlad_inline = auto keeps the busy streams at four or fewer when it can
+    const bool nv_streams = cfg->netvlad && !p->nv_inline && p->M == 1;
     for (int k = 0; k < p->K; ++k) {
       auto& L = p->lanes[k];
       hipStream_t ms = nullptr;
@@ -261,7 +270,7 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
           std::vector<uint32_t> mask((h->ncu + 31) / 32, 0u);
           for (int b = 8 * r0; b < 8 * r1; ++b) mask[b / 32] |= 1u << (b % 32);
           HIP_TRY(hipExtStreamCreateWithCUMask(&ms, (uint32_t)mask.size(), mask.data()));
-          if (hipExtStreamCreateWithCUMask(&L.nv, (uint32_t)mask.size(), mask.data()) != hipSuccess) {      // `ms` has no owner yet
+          if (nv_streams && hipExtStreamCreateWithCUMask(&L.nv, (uint32_t)mask.size(), mask.data()) != hipSuccess) {      // `ms` has no owner yet
             (void)hipStreamDestroy(ms);
             return pipe_fail(D2FE_ERR_HIP, "hipExtStreamCreateWithCUMask");
           }
@@ -275,7 +284,7 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
       int rc2 = clone_lane(h, p->NI, &L.ctx, ms, lane_cus, cfg->netvlad && p->M == 1);
       if (rc2) { if (ms) (void)hipStreamDestroy(ms); return rc2; }
       L.s = L.ctx->stream;
-      if (!L.nv) HIP_TRY(hipStreamCreateWithFlags(&L.nv, hipStreamNonBlocking));      // (a lowest-priority NetVLAD stream measured no different: 1345 vs 1351 fps at one frame per pass)
+      if (!L.nv && nv_streams) HIP_TRY(hipStreamCreateWithFlags(&L.nv, hipStreamNonBlocking));      // (a lowest-priority NetVLAD stream measured no different: 1345 vs 1351 at one lane)
       HIP_TRY(hipEventCreateWithFlags(&L.ev_up, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&L.ev_nv, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&L.ev_ext[0], hipEventDisableTiming));
@@ -543,7 +552,7 @@ int d2fe_pipe_device_view(d2fe_pipe p, int64_t ticket, void* stream, d2fe_pipe_d
   // SuperPoint of the pass: ev_ext[set] (re-recorded only by the pass that rewrites this block, which view_locate has excluded).  NetVLAD on the lane's second
   // stream: ev_nv -- a later pass of the lane may have re-recorded it; waiting for that later record is merely later, never earlier
   HIP_TRY(hipStreamWaitEvent(cs, L.ev_ext[set], 0));
-  if (p->cfg.netvlad && !p->cfg.netvlad_inline) HIP_TRY(hipStreamWaitEvent(cs, L.ev_nv, 0));
+  if (p->cfg.netvlad && !p->nv_inline) HIP_TRY(hipStreamWaitEvent(cs, L.ev_nv, 0));
   const float* B = p->block(k, set);
   const size_t cap = p->cap, r0 = p->left_row(j, 0);
   out->frames = p->F; out->cap = p->cap; out->desc_dim = p->D; out->netvlad_dim = p->G;

@@ -143,6 +143,47 @@ def test_pipe_argument_errors():
 
 
 @pytest.mark.gpu
+def test_pipe_netvlad_stream_modes_give_the_same_bits():
+    """d2fe_pipe_config.netvlad_inline: 0 = NetVLAD on a second stream per lane, 1 = on the lane's one stream in front of SuperPoint, 2 (default) = auto (inline above two
+    lanes: the device runs four busy streams side by side).  Where a kernel is queued does not change what it computes: every mode returns the same bits, and a bad value is refused."""
+    from d2slam_amd import api, netvlad as nvm
+    from d2slam_amd.weights import synthetic_superpoint_weights
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2, precision=api.PREC_F32_WINO, keypoint_threshold=0.005))
+    fe.load_superpoint(synthetic_superpoint_weights(dustbin_bias=7.5)); fe.load_netvlad(nvm.synthetic_netvlad_weights())
+    fr = _frames(9)
+    outs = {}
+    for lanes, mode in ((2, False), (2, True), (2, None), (4, False), (4, True), (4, None)):
+        pipe = api.StereoPipe(fe, lanes=lanes, frames=1, width=W, height=H, cap=CAP, netvlad=True, netvlad_inline=mode)
+        tk = [pipe.submit(l[None], r[None]) for l, r in fr[:lanes]]
+        res = []
+        for i, (l, r) in enumerate(fr):
+            if i >= lanes:
+                tk.append(pipe.submit(l[None], r[None]))
+            o = pipe.wait(tk[i])
+            res.append({k: (None if v is None else v.copy()) for k, v in o.items()})
+        outs[(lanes, mode)] = res
+        pipe.close()
+    ref = outs[(2, False)]
+    for key, res in outs.items():
+        for a, b in zip(ref, res):
+            for k in ("kps_xy", "scores", "desc", "n_kp", "netvlad", "lr_q", "lr_t", "lr_dist", "lr_n", "prev_q", "prev_t", "prev_dist", "prev_n"):
+                np.testing.assert_array_equal(a[k], b[k], err_msg="%s %s" % (key, k))
+    c = api._PipeConfig()
+    fe._lib.d2fe_pipe_default_config(ctypes_byref(c))
+    assert c.netvlad_inline == 2
+    c.lanes, c.frames, c.width, c.height, c.cap, c.netvlad_inline = 2, 1, W, H, CAP, 3
+    import ctypes as C
+    p = C.c_void_p()
+    assert fe._lib.d2fe_pipe_create(fe.handle, C.byref(c), C.byref(p)) == -1 and b"netvlad_inline" in fe._lib.d2fe_last_error()
+    fe.close()
+
+
+def ctypes_byref(x):
+    import ctypes as C
+    return C.byref(x)
+
+
+@pytest.mark.gpu
 def test_handle_with_live_pipes_refuses_destroy_and_reload():
     """A pipe's lanes read the parent handle's packed weights: while a pipe exists d2fe_destroy releases nothing and d2fe_load_* /
     d2fe_set_*_pca return D2FE_ERR_INVALID instead of leaving the lanes with dangling pointers; numpy frames through a pinned_input pipe are refused

@@ -20,7 +20,8 @@ def main():
     ap.add_argument("--coalesce", type=int, default=1, help="d2fe_pipe_config.coalesce (frames per submit must be 1)")
     ap.add_argument("--coalesce-depth", type=int, default=0, help="d2fe_pipe_config.coalesce_depth (dynamic batching)")
     ap.add_argument("--inflight", type=int, default=0, help="submits the caller keeps in flight (default: lanes x coalesce)")
-    ap.add_argument("--nv-inline", action="store_true", help="d2fe_pipe_config.netvlad_inline")
+    ap.add_argument("--nv-inline", action="store_true", help="d2fe_pipe_config.netvlad_inline = 1 (default: auto = inline when lanes > 2)")
+    ap.add_argument("--nv-side", action="store_true", help="d2fe_pipe_config.netvlad_inline = 0: NetVLAD on a second stream per lane whatever the lane count")
     ap.add_argument("--partition", action="store_true", help="d2fe_pipe_config.cu_partition: disjoint compute units per lane")
     args = ap.parse_args()
     import torch
@@ -45,7 +46,7 @@ def main():
                 l, r = scenes[(s * F + f) % len(scenes)]
                 sh = (s % 3, (2 * s) % 5)
                 hn[s, 0, f] = np.roll(l, sh, (0, 1)); hn[s, 1, f] = np.roll(r, sh, (0, 1))
-        pipe = api.StereoPipe(fe, lanes=K, frames=F, width=W, height=H, cap=CAP, netvlad=not args.no_netvlad, match_lr=not args.no_match, match_prev=not args.no_match, pinned_input=True, cu_partition=args.partition, netvlad_inline=args.nv_inline, coalesce=args.coalesce, lane_cus=args.lane_cus, netvlad_group=args.nv_group, coalesce_depth=args.coalesce_depth)
+        pipe = api.StereoPipe(fe, lanes=K, frames=F, width=W, height=H, cap=CAP, netvlad=not args.no_netvlad, match_lr=not args.no_match, match_prev=not args.no_match, pinned_input=True, cu_partition=args.partition, netvlad_inline=(True if args.nv_inline else False if args.nv_side else None), coalesce=args.coalesce, lane_cus=args.lane_cus, netvlad_group=args.nv_group, coalesce_depth=args.coalesce_depth)
         base = host.data_ptr(); per = 2 * F * H * W
         def submit(i):
             s = i % NS
