@@ -713,7 +713,8 @@ class StereoPipe:
         c.cap = int(cap or fe.cfg.max_keypoints)
         c.netvlad, c.match_lr, c.match_prev, c.pinned_input = int(bool(netvlad)), int(bool(match_lr)), int(bool(match_prev)), int(bool(pinned_input))
         c.ratio, c.radius_lr, c.radius_prev = float(ratio), float(radius_lr), float(radius_prev)
-        c.cu_partition = int(bool(cu_partition)); c.netvlad_inline = 2 if netvlad_inline is None else int(bool(netvlad_inline));      # None: auto (inline when lanes > 2) c.coalesce = int(coalesce); c.lane_cus = int(lane_cus); c.netvlad_group = int(netvlad_group); c.coalesce_depth = int(coalesce_depth)
+        c.cu_partition = int(bool(cu_partition)); c.coalesce = int(coalesce); c.lane_cus = int(lane_cus); c.netvlad_group = int(netvlad_group); c.coalesce_depth = int(coalesce_depth)
+        c.netvlad_inline = 2 if netvlad_inline is None else int(bool(netvlad_inline))      # None: auto (inline when lanes > 2)
         self._p = C.c_void_p()
         _check(self._lib.d2fe_pipe_create(fe.handle, C.byref(c), C.byref(self._p)))
         if not hasattr(fe, "_pipes"):
