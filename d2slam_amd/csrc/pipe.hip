@@ -46,6 +46,7 @@ struct d2fe_pipe_s {
     hipEvent_t ev_rel[2] = {nullptr, nullptr};
     int views[2] = {0, 0};
     bool rel_pending[2] = {false, false};
+    bool nv_on_side[2] = {false, false};      // the pass that wrote this block ran NetVLAD on the lane's second stream (auto mode decides per pass)
     uint8_t* d_img = nullptr;
     uint8_t* pin_in = nullptr;
     float* pin_out[2] = {nullptr, nullptr};
@@ -67,7 +68,8 @@ struct d2fe_pipe_s {
   long long next_pass = 0;           // passes started so far
   int pend = 0;                      // submits of the newest pass that are staged but not launched yet (0: no pass open)
   int prev_g = 1;                    // submits of the last LAUNCHED pass
-  bool nv_inline = false;            // cfg.netvlad_inline resolved (2 = auto: inline when lanes > 2)
+  bool nv_inline = false;            // cfg.netvlad_inline == 1: NetVLAD always on the lane's one stream (no second stream exists)
+  bool nv_auto = false;              // cfg.netvlad_inline == 2: per pass (pipe_flush): the second stream while at most two passes are in flight, inline beyond
   int failed = D2FE_OK;              // sticky: the first error of an enqueue leaves a pass half-queued (frames copied or not, events recorded or not); the ring
                                      // bookkeeping of every later pass would build on it, so every later submit / wait returns this code instead
   std::string failed_msg;
@@ -93,6 +95,20 @@ int lane_sync(d2fe_pipe_s::Lane& L) {       // called with the pipe's mutex held
   return D2FE_OK;
 }
 
+// passes launched and not known to be complete (one hipEventQuery per busy lane); < 0: a HIP error (d2fe_last_error is set)
+int passes_in_flight(d2fe_pipe_s* p) {
+  int inflight = 0;
+  for (auto& Lq : p->lanes) {
+    if (Lq.synced >= Lq.rec) continue;
+    const hipError_t q = hipEventQuery(Lq.ev_done);
+    if (q == hipSuccess) Lq.synced = Lq.rec;
+    else if (q == hipErrorNotReady) ++inflight;
+    else { (void)ctx_fail(D2FE_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q)); return -1; }
+  }
+  (void)hipGetLastError();        // hipErrorNotReady is sticky in hipGetLastError
+  return inflight;
+}
+
 // launches the open pass (its `pend` submits are staged in the lane's device input buffer): NetVLAD, SuperPoint, ONE matcher launch, ONE D2H
 int pipe_flush(d2fe_pipe_s* p) {
   if (p->pend == 0) return D2FE_OK;
@@ -106,7 +122,16 @@ int pipe_flush(d2fe_pipe_s* p) {
   const int n_left = p->C > 1 ? g : F, n_img = p->C > 1 ? 2 * g : 2 * F;
   const size_t left_stride = p->C > 1 ? 2 * img : img;
   int rc;
-  const bool nv_side = p->cfg.netvlad && !p->nv_inline && p->M == 1;
+  // Where this pass's NetVLAD runs.  The device runs FOUR busy streams of a process side by side and makes a fifth take turns (d2fe_pipe_create), so in auto mode a pass
+  // takes the lane's second stream (SuperPoint and NetVLAD beside each other: the shortest latency of one frame) only while that keeps the busy streams at four or fewer,
+  // i.e. with at most one other pass in flight; beyond, NetVLAD goes in front of SuperPoint on the lane's one stream
+  bool nv_side = p->cfg.netvlad && !p->nv_inline && p->M == 1;
+  if (nv_side && p->nv_auto) {
+    const int infl = passes_in_flight(p);
+    if (infl < 0) return D2FE_ERR_HIP;
+    nv_side = infl <= 1;
+  }
+  L.nv_on_side[set] = nv_side;
   // device views of this block (handed out 2 K passes ago): the consumers' stream must be through with it before this pass writes it.  The NetVLAD
   // stream is ordered behind this wait through ev_up
   if (L.views[set] > 0) return pipe_fail(D2FE_ERR_INVALID, "a device view of this lane's result block was not released (d2fe_pipe_device_release) within 2 * lanes passes");
@@ -211,7 +236,8 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
   p->parent = h; p->cfg = *cfg;
   h->live_pipes.fetch_add(1);        // from here on d2fe_pipe_destroy (every failure path below goes through it or through `delete p` + the decrement) gives it back
   p->M = M;
-  p->nv_inline = cfg->netvlad_inline == 1 || (cfg->netvlad_inline == 2 && cfg->lanes > 2);
+  p->nv_inline = cfg->netvlad_inline == 1;
+  p->nv_auto = cfg->netvlad_inline == 2 && cfg->lanes > 2;      // one or two lanes: never more than four busy streams, the second stream always
   p->K = cfg->lanes; p->F = cfg->frames; p->C = C; p->NI = 2 * cfg->frames * C; p->W = cfg->width; p->H = cfg->height;
   p->cap = cfg->cap < h->cfg.max_keypoints ? cfg->cap : h->cfg.max_keypoints;
   p->D = d2fe_desc_dim(h);
@@ -284,7 +310,6 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
       int rc2 = clone_lane(h, p->NI, &L.ctx, ms, lane_cus, cfg->netvlad && p->M == 1);
       if (rc2) { if (ms) (void)hipStreamDestroy(ms); return rc2; }
       L.s = L.ctx->stream;
-      if (!L.nv && nv_streams) HIP_TRY(hipStreamCreateWithFlags(&L.nv, hipStreamNonBlocking));      // (a lowest-priority NetVLAD stream measured no different: 1345 vs 1351 at one lane)
       HIP_TRY(hipEventCreateWithFlags(&L.ev_up, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&L.ev_nv, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&L.ev_ext[0], hipEventDisableTiming));
@@ -296,6 +321,10 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
       if (!cfg->pinned_input) HIP_TRY(hipHostMalloc(&L.pin_in, (size_t)p->W * p->H * p->NI, hipHostMallocDefault));
       for (int set = 0; set < 2; ++set) HIP_TRY(hipHostMalloc(&L.pin_out[set], sizeof(float) * p->d2h_words, hipHostMallocDefault));
     }
+    // the second streams AFTER every lane's own stream: the lanes' SuperPoint streams then hold consecutive hardware queues whether or not the second streams are ever
+    // used (auto mode with many passes in flight uses none of them).  (A lowest-priority NetVLAD stream measured no different: 1345 vs 1351 at one lane.)
+    if (nv_streams)
+      for (auto& L : p->lanes) if (!L.nv) HIP_TRY(hipStreamCreateWithFlags(&L.nv, hipStreamNonBlocking));
     if (p->npp > 0) {
       // pair tables [lane][set][variant v = submits of the previous pass - 1][C * npp].  Submit j of a pass contributes npp consecutive pairs:
       // L_f <-> R_f for its F frames (when match_lr), then L_f <-> L_(f-1); the first left frame of a pass pairs with the LAST left frame
@@ -434,15 +463,8 @@ int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int
   bool launch = p->pend == p->C;
   if (!launch && p->cfg.coalesce_depth > 0) {
     // dynamic batching: the device would run dry with fewer than `coalesce_depth` passes in flight -- launch what is staged; otherwise let the pass grow
-    int inflight = 0;
-    for (auto& Lq : p->lanes) {
-      if (Lq.synced >= Lq.rec) continue;
-      const hipError_t q = hipEventQuery(Lq.ev_done);
-      if (q == hipSuccess) Lq.synced = Lq.rec;
-      else if (q == hipErrorNotReady) ++inflight;
-      else return ctx_fail(D2FE_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
-    }
-    (void)hipGetLastError();        // hipErrorNotReady is sticky in hipGetLastError
+    const int inflight = passes_in_flight(p);
+    if (inflight < 0) return D2FE_ERR_HIP;
     // ... unless the tickets nobody has waited for yet already span `lanes` passes: small passes use up the ring of 2 * lanes result blocks as fast as
     // full ones, so a caller with many frames outstanding gets full passes (which is what it wants anyway)
     const long long p_old = p->tinfo[(size_t)(p->oldest_unwaited % (long long)p->tinfo.size())].pass;
@@ -552,7 +574,7 @@ int d2fe_pipe_device_view(d2fe_pipe p, int64_t ticket, void* stream, d2fe_pipe_d
   // SuperPoint of the pass: ev_ext[set] (re-recorded only by the pass that rewrites this block, which view_locate has excluded).  NetVLAD on the lane's second
   // stream: ev_nv -- a later pass of the lane may have re-recorded it; waiting for that later record is merely later, never earlier
   HIP_TRY(hipStreamWaitEvent(cs, L.ev_ext[set], 0));
-  if (p->cfg.netvlad && !p->nv_inline) HIP_TRY(hipStreamWaitEvent(cs, L.ev_nv, 0));
+  if (L.nv_on_side[set]) HIP_TRY(hipStreamWaitEvent(cs, L.ev_nv, 0));
   const float* B = p->block(k, set);
   const size_t cap = p->cap, r0 = p->left_row(j, 0);
   out->frames = p->F; out->cap = p->cap; out->desc_dim = p->D; out->netvlad_dim = p->G;

@@ -259,9 +259,10 @@ typedef struct {
                                behaves like a (256 / lanes)-CU device working on its own frame */
   int32_t netvlad_inline;   /* 0: NetVLAD on a second stream per lane, beside SuperPoint (shortest latency of one frame: 0.72 ms);
                                1: on the lane's one stream, in front of SuperPoint (half as many streams);
-                               2 (d2fe_pipe_default_config): auto = 0 for lanes <= 2, 1 above.  The device runs FOUR busy streams of a process side by side and makes
-                               a fifth take turns: with single-frame passes, 2 lanes x 2 streams reach 1830-1855 stereo frames/s and 4 lanes x 1 stream 2040, where
-                               3 lanes x 2 streams fall to 1500 and 4 x 2 to 1640-1780 (profiles/r05_pipe_one_frame.txt).  Results are the same bits in every mode */
+                               2 (d2fe_pipe_default_config): auto -- decided per pass: the second stream while at most one OTHER pass is in flight, inline beyond
+                               (one or two lanes: always the second stream).  The device runs FOUR busy streams of a process side by side and makes a fifth take
+                               turns: with single-frame passes, 2 lanes x 2 streams reach 1830-1855 stereo frames/s and 4 lanes x 1 stream 2040, where 3 lanes x 2
+                               streams fall to 1500 and 4 x 2 to 1640-1780 (profiles/r05_pipe_one_frame.txt).  Results are the same bits in every mode */
   int32_t coalesce;         /* > 1 (needs frames == 1): up to this many consecutive submits run as ONE launch sequence when they are submitted before
                                anybody waits for them -- submit() stages the frame (its H2D starts at once) and the pass is launched when it is full
                                or when d2fe_pipe_wait asks for one of its tickets; results per ticket are unchanged (bit-identical).  What a
