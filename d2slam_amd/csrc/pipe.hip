@@ -323,8 +323,13 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
     }
     // the second streams AFTER every lane's own stream: the lanes' SuperPoint streams then hold consecutive hardware queues whether or not the second streams are ever
     // used (auto mode with many passes in flight uses none of them).  (A lowest-priority NetVLAD stream measured no different: 1345 vs 1351 at one lane.)
+    // ... and rotated by one lane when the lane count is a multiple of four: hardware queue i is served by hardware pipe i mod 4, and a lane's two streams must not
+    // share a pipe (4 lanes, second streams created in lane order: a pass alone on the device ran at 873 stereo fps -- its SuperPoint and NetVLAD took turns -- instead of 1400)
     if (nv_streams)
-      for (auto& L : p->lanes) if (!L.nv) HIP_TRY(hipStreamCreateWithFlags(&L.nv, hipStreamNonBlocking));
+      for (int i = 0; i < p->K; ++i) {
+        auto& L = p->lanes[(size_t)((i + (p->K % 4 == 0 ? 1 : 0)) % p->K)];
+        if (!L.nv) HIP_TRY(hipStreamCreateWithFlags(&L.nv, hipStreamNonBlocking));
+      }
     if (p->npp > 0) {
       // pair tables [lane][set][variant v = submits of the previous pass - 1][C * npp].  Submit j of a pass contributes npp consecutive pairs:
       // L_f <-> R_f for its F frames (when match_lr), then L_f <-> L_(f-1); the first left frame of a pass pairs with the LAST left frame

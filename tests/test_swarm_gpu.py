@@ -171,9 +171,11 @@ def test_int8_exchange_blocks_vs_reference_codec():
     t = lambda a: torch.from_numpy(a).to(dev)
     d_desc, d_kps, d_n, d_g = t(desc), t(kps), t(n), t(g)
     bq = torch.full((rows, BB), 7, dtype=torch.int8, device=dev)
+    torch.cuda.synchronize()      # the library launches on the handle's own non-blocking stream, which does not wait for torch's fills on the default stream
     fe.pack_blocks_int8_device(d_desc.data_ptr(), d_kps.data_ptr(), d_n.data_ptr(), d_g.data_ptr(), 0, 1, rows, cap, G, bq.data_ptr())
     for renorm in (0, 1):
         out = torch.full((rows, BLK), 7.0, device=dev)
+        torch.cuda.synchronize()
         fe.unpack_blocks_int8_device(bq.data_ptr(), rows, cap, G, out.data_ptr(), renorm=renorm)
         fe.sync(); torch.cuda.synchronize()
         q = bq.cpu().numpy(); o = out.cpu().numpy()
