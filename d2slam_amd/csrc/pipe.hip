@@ -53,6 +53,7 @@ struct d2fe_pipe_s {
     long long rec = -1, synced = -1;   // the pass whose completion ev_done last recorded / the newest pass known to be complete (idle: synced >= rec)
   };
   std::vector<Lane> lanes;
+  std::vector<hipStream_t> spacers;  // idle streams that only position the lanes' second streams on the hardware pipes (d2fe_pipe_create)
   uint8_t* d_img_all = nullptr;      // the lanes' input buffers, one allocation: lane k at k * NI images (netvlad_group reads several lanes' left images with one stride)
   // netvlad_group = M > 1 (frames == 1, coalesce == 1, lanes % M == 0): the NetVLAD descriptors of M consecutive submits come from ONE call on the pipe's own
   // context and stream (NetVLAD at one image is ~20 launches of a few workgroups each: 0.25 ms for one image, 0.28 ms for four), while SuperPoint and the
@@ -323,13 +324,15 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
     }
     // the second streams AFTER every lane's own stream: the lanes' SuperPoint streams then hold consecutive hardware queues whether or not the second streams are ever
     // used (auto mode with many passes in flight uses none of them).  (A lowest-priority NetVLAD stream measured no different: 1345 vs 1351 at one lane.)
-    // ... and rotated by one lane when the lane count is a multiple of four: hardware queue i is served by hardware pipe i mod 4, and a lane's two streams must not
-    // share a pipe (4 lanes, second streams created in lane order: a pass alone on the device ran at 873 stereo fps -- its SuperPoint and NetVLAD took turns -- instead of 1400)
-    if (nv_streams)
-      for (int i = 0; i < p->K; ++i) {
-        auto& L = p->lanes[(size_t)((i + (p->K % 4 == 0 ? 1 : 0)) % p->K)];
-        if (!L.nv) HIP_TRY(hipStreamCreateWithFlags(&L.nv, hipStreamNonBlocking));
-      }
+    // ... and placed TWO hardware pipes away from their lane's own stream: hardware queue i is served by hardware pipe i mod 4 and streams get queues in creation order,
+    // so the K lane streams are followed by (2 - K) mod 4 idle spacer streams and then the K second streams in lane order.  A lane's two streams then never share a pipe, and
+    // neither do the four streams of two consecutive lanes (4 lanes, second streams right behind the lane streams: a pass alone on the device ran at 873 stereo frames/s -- its
+    // SuperPoint and NetVLAD took turns on one pipe -- instead of 1400; rotated by one lane: 1389 alone but 1549 with two passes in flight, where two lanes reach 1840)
+    if (nv_streams) {
+      p->spacers.resize((size_t)(((2 - p->K) % 4 + 4) % 4), nullptr);
+      for (auto& sp : p->spacers) HIP_TRY(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
+      for (auto& L : p->lanes) if (!L.nv) HIP_TRY(hipStreamCreateWithFlags(&L.nv, hipStreamNonBlocking));
+    }
     if (p->npp > 0) {
       // pair tables [lane][set][variant v = submits of the previous pass - 1][C * npp].  Submit j of a pass contributes npp consecutive pairs:
       // L_f <-> R_f for its F frames (when match_lr), then L_f <-> L_(f-1); the first left frame of a pass pairs with the LAST left frame
@@ -387,6 +390,7 @@ void d2fe_pipe_destroy(d2fe_pipe p) {
     for (float* q : L.pin_out) if (q) (void)hipHostFree(q);
     if (L.ctx) d2fe_destroy(L.ctx);
   }
+  for (hipStream_t sp : p->spacers) if (sp) (void)hipStreamDestroy(sp);
   if (p->gnv) (void)hipStreamSynchronize(p->gnv);
   for (auto e : p->ev_g) if (e) (void)hipEventDestroy(e);
   if (p->gctx) d2fe_destroy(p->gctx);
