@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 # streams that share a queue serialise.  Must be set before the HIP runtime initialises; recorded in the JSON line (`env_overrides`).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 # lanes in flight per frames-per-submit for the batch curve (measured: tools/pipe_probe.py; more lanes than this do not pay)
-LANES_FOR = {1: 4, 2: 4, 4: 4, 8: 3, 16: 2, 32: 2}
+LANES_FOR = {1: 4, 2: 4, 4: 4, 8: 4, 16: 2, 32: 2}
 REFUSED_ENV = ("D2FE_ABLATE", "D2FE_MATCH_NOFALLBACK")     # switches that make results wrong or parity unproven: never inside a benchmark
 
 H, W, CAP = 480, 640, 200
@@ -370,6 +370,13 @@ def main():
                     batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": 4, "coalesce": 1, "netvlad_group": 4, "stereo_fps": round(r["value"], 1),
                                         "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
                                         "note": "netvlad_group = 4: one NetVLAD call per four consecutive single-frame submits; bit-identical results"})
+                # ONE 4-lane pipe of plain single-frame passes (coalesce = 1) under callers that keep 1 / 2 / 3 submits outstanding (4: the K = 4 point above): the
+                # pipe decides per pass which stream NetVLAD goes to (d2fe_pipe_config.netvlad_inline = auto), so the lone pass keeps the single-lane latency
+                for infl in (1, 2, 3):
+                    r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, inflight=infl)
+                    batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": infl, "lanes": 4, "coalesce": 1, "stereo_fps": round(r["value"], 1),
+                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
+                                        "note": "the 4-lane pipe of the K = 4 point with fewer submits outstanding"})
                 # dynamic batching (coalesce_depth = 2): a pass is launched as soon as fewer than two are in flight, so the SAME configuration serves a caller
                 # that waits for every frame (1 in flight: launched at once) and one that keeps 16 in flight (passes grow to 4 frames)
                 for infl in (1, 4, 16):

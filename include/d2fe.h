@@ -257,12 +257,15 @@ typedef struct {
   int32_t cu_partition;     /* 1: every lane launches on its own disjoint 1/lanes of the compute units (CU-masked streams): the lanes' kernels run
                                side by side instead of queueing behind each other's full-device launches.  For small `frames`: a lane then
                                behaves like a (256 / lanes)-CU device working on its own frame */
-  int32_t netvlad_inline;   /* 0: NetVLAD on a second stream per lane, beside SuperPoint (shortest latency of one frame: 0.72 ms);
-                               1: on the lane's one stream, in front of SuperPoint (half as many streams);
-                               2 (d2fe_pipe_default_config): auto -- decided per pass: the second stream while at most one OTHER pass is in flight, inline beyond
-                               (one or two lanes: always the second stream).  The device runs FOUR busy streams of a process side by side and makes a fifth take
-                               turns: with single-frame passes, 2 lanes x 2 streams reach 1830-1855 stereo frames/s and 4 lanes x 1 stream 2040, where 3 lanes x 2
-                               streams fall to 1500 and 4 x 2 to 1640-1780 (profiles/r05_pipe_one_frame.txt).  Results are the same bits in every mode */
+  int32_t netvlad_inline;   /* which stream a pass's NetVLAD call is launched on.  0: the lane's second stream, beside SuperPoint (shortest single pass: 0.72 ms);
+                               1: the lane's one stream, in front of SuperPoint (no second streams are created);
+                               2 (d2fe_pipe_default_config): auto -- decided per pass: the second stream while at most one OTHER pass is in flight, the lane's own
+                               stream beyond that (one or two lanes: always the second stream).  Why: the device runs FOUR busy streams of a process side by side
+                               (hardware queue i is served by hardware pipe i mod 4) and makes a fifth take turns.  Single-frame passes on a 4-lane pipe, auto:
+                               1390 / 1838 / 1789 / 2044 stereo frames/s with 1 / 2 / 3 / 4 passes in flight; forced second streams: 1627 with 4
+                               (profiles/r05_pipe_one_frame.txt (8)).  The pipe creates its streams so that a lane's two streams sit two hardware pipes apart; this
+                               needs GPU_MAX_HW_QUEUES >= 8 in the process environment (16 recommended; the runtime's default of 4 makes streams share queues).
+                               Results are the same bits in every mode */
   int32_t coalesce;         /* > 1 (needs frames == 1): up to this many consecutive submits run as ONE launch sequence when they are submitted before
                                anybody waits for them -- submit() stages the frame (its H2D starts at once) and the pass is launched when it is full
                                or when d2fe_pipe_wait asks for one of its tickets; results per ticket are unchanged (bit-identical).  What a

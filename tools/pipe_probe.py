@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--coalesce", type=int, default=1, help="d2fe_pipe_config.coalesce (frames per submit must be 1)")
     ap.add_argument("--coalesce-depth", type=int, default=0, help="d2fe_pipe_config.coalesce_depth (dynamic batching)")
     ap.add_argument("--inflight", type=int, default=0, help="submits the caller keeps in flight (default: lanes x coalesce)")
-    ap.add_argument("--nv-inline", action="store_true", help="d2fe_pipe_config.netvlad_inline = 1 (default: auto = inline when lanes > 2)")
+    ap.add_argument("--nv-inline", action="store_true", help="d2fe_pipe_config.netvlad_inline = 1: NetVLAD on the lane stream, in front of SuperPoint (default: auto, decided per pass)")
     ap.add_argument("--nv-side", action="store_true", help="d2fe_pipe_config.netvlad_inline = 0: NetVLAD on a second stream per lane whatever the lane count")
     ap.add_argument("--partition", action="store_true", help="d2fe_pipe_config.cu_partition: disjoint compute units per lane")
     args = ap.parse_args()
