@@ -108,7 +108,7 @@ EXPORTS = [
     "d2fe_gen_cylinder_map", "d2fe_gen_cylinder_map_device", "d2fe_gen_pinhole_map", "d2fe_gen_pinhole_map_device", "d2fe_lk_frame_create",
     "d2fe_lk_frame_create_device", "d2fe_lk_frame_destroy", "d2fe_lk_frame_read_level", "d2fe_lk_track", "d2fe_lk_track_batch",
     "d2fe_detect_fast_by_region", "d2fe_good_features_to_track", "d2fe_pipe_default_config", "d2fe_pipe_create", "d2fe_pipe_destroy",
-    "d2fe_pipe_lanes", "d2fe_pipe_submit", "d2fe_pipe_wait", "d2fe_pipe_profile_enable", "d2fe_pipe_profile_read",
+    "d2fe_pipe_lanes", "d2fe_pipe_stream_placement", "d2fe_pipe_submit", "d2fe_pipe_wait", "d2fe_pipe_profile_enable", "d2fe_pipe_profile_read",
     "d2fe_pipe_device_view", "d2fe_pipe_device_release"]
 # the development library (lib/libd2fe_hip_dev.so, include/d2fe_debug.h) exports these on top: test hooks and kernel diagnostics
 DEBUG_EXPORTS = [
@@ -246,6 +246,7 @@ def _open_library(path, dev):
         lib.d2fe_pipe_destroy.argtypes = [C.c_void_p]
         lib.d2fe_pipe_destroy.restype = None
         lib.d2fe_pipe_lanes.argtypes = [C.c_void_p]
+        lib.d2fe_pipe_stream_placement.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         lib.d2fe_pipe_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
         lib.d2fe_pipe_wait.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         lib.d2fe_pipe_device_view.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
@@ -761,6 +762,13 @@ class StereoPipe:
                              "use submit_ptr() with page-locked memory that outlives the ticket")
         left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
         return self.submit_ptr(left.ctypes.data, right.ctypes.data)
+
+    def stream_placement(self):
+        """(classes, n_classes) of d2fe_pipe_stream_placement: classes[k] = (hardware-pipe class of lane k's own stream, of its second stream)."""
+        K = self.lanes
+        arr = (C.c_int32 * (2 * K))(); n = C.c_int32(0)
+        _check(self._lib.d2fe_pipe_stream_placement(self._p, arr, C.byref(n)))
+        return [(arr[2 * k], arr[2 * k + 1]) for k in range(K)], n.value
 
     def device_view(self, ticket, stream):
         """DEVICE pointers into the ticket's result block for a consumer on `stream` (a raw hipStream_t, not 0): the stream is made to wait for the ticket's SuperPoint

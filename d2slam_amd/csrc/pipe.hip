@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -53,7 +54,8 @@ struct d2fe_pipe_s {
     long long rec = -1, synced = -1;   // the pass whose completion ev_done last recorded / the newest pass known to be complete (idle: synced >= rec)
   };
   std::vector<Lane> lanes;
-  std::vector<hipStream_t> spacers;  // idle streams that only position the lanes' second streams on the hardware pipes (d2fe_pipe_create)
+  std::vector<int> first_class, second_class;   // the hardware-pipe class place_streams() measured for each lane's two streams (-1: not measured / no such stream)
+  int n_classes = 0;
   uint8_t* d_img_all = nullptr;      // the lanes' input buffers, one allocation: lane k at k * NI images (netvlad_group reads several lanes' left images with one stride)
   // netvlad_group = M > 1 (frames == 1, coalesce == 1, lanes % M == 0): the NetVLAD descriptors of M consecutive submits come from ONE call on the pipe's own
   // context and stream (NetVLAD at one image is ~20 launches of a few workgroups each: 0.25 ms for one image, 0.28 ms for four), while SuperPoint and the
@@ -87,6 +89,90 @@ namespace {
 size_t up64(size_t w) { return (w + 63) / 64 * 64; }
 
 int pipe_fail(int code, const std::string& msg) { return ctx_fail(code, msg); }
+
+// ---- stream placement by measurement ---------------------------------------------------------------------------------------------------------
+// The device runs the busy streams of a process side by side only when they sit on different hardware pipes (four of them); two busy streams on one pipe take turns
+// (profiles/r05_pipe_one_frame.txt (8): a lone single-frame pass whose SuperPoint and NetVLAD streams shared a pipe ran at 873 stereo frames/s instead of 1400).  Which pipe a
+// stream gets is the runtime's business (hardware queues are handed out from a pool that earlier streams of the process have used and returned), so it is MEASURED: a few
+// more candidate streams than needed are created, chains of short dependent spin launches are timed on pairs of them, candidates whose chains take turns are one class,
+// and the lanes then take their streams from the classes so that a lane's two streams -- and the streams of consecutive lanes -- are in different ones.
+__global__ void pipe_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
+}
+
+constexpr int PROBE_CHAIN = 6;         // dependent launches per stream and probe
+constexpr double PROBE_SPIN_US = 20.0;
+
+double probe_pair_us(hipStream_t a, hipStream_t b, long long ticks) {       // < 0: HIP error
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < PROBE_CHAIN; ++i) {
+    hipLaunchKernelGGL(pipe_spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+    if (b) hipLaunchKernelGGL(pipe_spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+  }
+  if (hipStreamSynchronize(a) != hipSuccess || (b && hipStreamSynchronize(b) != hipSuccess) || hipGetLastError() != hipSuccess) return -1.0;
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// n_first + n_second streams out of measured classes; on any doubt (HIP error, no two classes told apart) the candidates are handed out in creation order
+int place_streams(int device_id, int n_first, int n_second, std::vector<hipStream_t>& first, std::vector<hipStream_t>& second, std::vector<int>& first_class,
+                  std::vector<int>& second_class, int* n_classes) {
+  const int need = n_first + n_second;
+  first.assign((size_t)n_first, nullptr); second.assign((size_t)n_second, nullptr);
+  first_class.assign((size_t)n_first, -1); second_class.assign((size_t)n_second, -1);
+  *n_classes = 0;
+  const int NC = need + (need > 1 ? 4 : 0);
+  std::vector<hipStream_t> cand((size_t)NC, nullptr);
+  auto drop = [&](int rc) { for (auto c : cand) if (c) (void)hipStreamDestroy(c); first.assign(first.size(), nullptr); second.assign(second.size(), nullptr); return rc; };
+  for (auto& c : cand) if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return drop(pipe_fail(D2FE_ERR_HIP, "hipStreamCreateWithFlags"));
+  std::vector<int> cls((size_t)NC, -1);
+  int ncls = 0;
+  if (need > 1) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_id) != hipSuccess || khz <= 0) khz = 100000;
+    const long long ticks = (long long)(PROBE_SPIN_US * 1e-3 * khz);
+    bool ok = hipDeviceSynchronize() == hipSuccess;
+    // the chain alone (second sample: the first pays for loading the kernel)
+    double solo = -1.0;
+    for (int i = 0; ok && i < 3; ++i) { const double t = probe_pair_us(cand[0], nullptr, ticks); if (t < 0) ok = false; else if (i > 0) solo = solo < 0 ? t : std::min(solo, t); }
+    const double turns = 1.6 * std::max(solo, PROBE_CHAIN * PROBE_SPIN_US);
+    std::vector<int> rep;        // one candidate per class
+    for (int c = 0; ok && c < NC; ++c) {
+      for (size_t r = 0; ok && r < rep.size() && cls[c] < 0; ++r) {
+        double t = probe_pair_us(cand[c], cand[rep[r]], ticks);
+        if (t >= turns) t = std::min(t, probe_pair_us(cand[c], cand[rep[r]], ticks));       // a slow sample is confirmed once (a busy host looks the same)
+        if (t < 0) ok = false;
+        else if (t >= turns) cls[c] = (int)r;
+      }
+      if (ok && cls[c] < 0) { if (rep.size() < 8) { cls[c] = (int)rep.size(); rep.push_back(c); } else cls[c] = c % 8; }
+    }
+    (void)hipGetLastError();
+    ncls = ok ? (int)rep.size() : 0;
+    if (ncls < 2) { ncls = 0; std::fill(cls.begin(), cls.end(), -1); }       // nothing told apart: creation order below
+  }
+  std::vector<char> used((size_t)NC, 0);
+  auto take = [&](int want) -> int {      // first unused candidate of class `want`; else of the class with the most unused candidates; else any
+    int best = -1;
+    if (ncls > 0) {
+      for (int c = 0; c < NC && best < 0; ++c) if (!used[c] && cls[c] == want) best = c;
+      if (best < 0) {
+        std::vector<int> left((size_t)ncls, 0);
+        for (int c = 0; c < NC; ++c) if (!used[c] && cls[c] >= 0 && cls[c] < ncls) ++left[cls[c]];
+        const int big = (int)(std::max_element(left.begin(), left.end()) - left.begin());
+        for (int c = 0; c < NC && best < 0; ++c) if (!used[c] && cls[c] == big) best = c;
+      }
+    }
+    for (int c = 0; c < NC && best < 0; ++c) if (!used[c]) best = c;
+    used[best] = 1;
+    return best;
+  };
+  // lane k: its own stream from class k mod n, its second stream half the classes further on (two of four): consecutive lanes' four streams in four classes
+  for (int k = 0; k < n_first; ++k) { const int c = take(ncls ? k % ncls : -1); first[k] = cand[c]; first_class[k] = cls[c]; }
+  for (int k = 0; k < n_second; ++k) { const int c = take(ncls ? (k + (ncls + 1) / 2) % ncls : -1); second[k] = cand[c]; second_class[k] = cls[c]; }
+  for (int c = 0; c < NC; ++c) if (!used[c]) { (void)hipStreamDestroy(cand[c]); }
+  *n_classes = ncls;
+  return D2FE_OK;
+}
 
 int lane_sync(d2fe_pipe_s::Lane& L) {       // called with the pipe's mutex held for the whole wait
   if (L.synced < L.rec) {
@@ -279,11 +365,21 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
       for (auto& e : p->ev_g) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     p->lanes.resize(p->K);
-    // Streams (round 5).  The device services FOUR busy compute streams of a process side by side; a fifth takes turns with one of them (lanes x 1 frame, NetVLAD on a
-    // second stream per lane: 2 lanes 1830-1855 stereo fps, 3 lanes 1470-1515, 4 lanes 1640-1780; NetVLAD inline, one stream per lane: 3 lanes 1779, FOUR lanes 2039, 5 lanes 1544;
-    // profiles/r05_pipe_one_frame.txt).  So: a stream that would never be used (inline mode, netvlad_group, no NetVLAD) is not created at all -- even idle it shifts the others'
-    // hardware queues (4 inline lanes with four unused NetVLAD streams beside them: 1184-1290) -- and netvlad_inline = auto keeps the busy streams at four or fewer when it can
+    // Streams (round 5).  The device services FOUR busy compute streams of a process side by side -- one per hardware pipe -- and a fifth takes turns with one of them
+    // (lanes x 1 frame, NetVLAD on a second stream per lane: 2 lanes 1830-1855 stereo fps, 3 lanes 1470-1515, 4 lanes 1640-1780; NetVLAD inline, one stream per lane: 3 lanes
+    // 1779, FOUR lanes 2039, 5 lanes 1544; profiles/r05_pipe_one_frame.txt).  So: (1) a stream that would never be used (inline mode, netvlad_group, no NetVLAD) is not created
+    // at all; (2) netvlad_inline = auto keeps the busy streams at four or fewer when it can (pipe_flush); (3) place_streams() MEASURES which candidate streams take turns and
+    // hands every lane two streams of different hardware pipes, consecutive lanes' streams on different ones too.  (In a fresh process streams get hardware queues in creation
+    // order and queue i sits on pipe i mod 4, and an arrangement by creation order measured 1390 / 1838 / 1789 / 2044 stereo frames/s for 1 / 2 / 3 / 4 single-frame passes in flight
+    // on a 4-lane pipe -- but in a process that had created and destroyed other streams before, bench.py after its other legs, the same arrangement put the two streams of a
+    // 1-lane pipe on ONE pipe: 878 instead of 1400.)
     const bool nv_streams = cfg->netvlad && !p->nv_inline && p->M == 1;
+    const bool masked = cfg->cu_partition && p->K > 1;           // CU-masked streams are created per lane below
+    struct Spare { std::vector<hipStream_t> first, second; ~Spare() { for (auto& v : {&first, &second}) for (hipStream_t q : *v) if (q) (void)hipStreamDestroy(q); } } spare;
+    if (!masked) {
+      const int rcs = place_streams(h->cfg.device_id, p->K, nv_streams ? p->K : 0, spare.first, spare.second, p->first_class, p->second_class, &p->n_classes);
+      if (rcs) return rcs;
+    }
     for (int k = 0; k < p->K; ++k) {
       auto& L = p->lanes[k];
       hipStream_t ms = nullptr;
@@ -308,6 +404,7 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
       // full-device persistent launch holds every CU's LDS until it ends, so another lane's small launches cannot start beside it; grids sized
       // for a share of the device leave workgroup slots on every CU to the other lanes
       if (!lane_cus && cfg->lane_cus > 0 && cfg->lane_cus < h->ncu) lane_cus = cfg->lane_cus;
+      if (!masked) { ms = spare.first[k]; spare.first[k] = nullptr; if (nv_streams) { L.nv = spare.second[k]; spare.second[k] = nullptr; } }
       int rc2 = clone_lane(h, p->NI, &L.ctx, ms, lane_cus, cfg->netvlad && p->M == 1);
       if (rc2) { if (ms) (void)hipStreamDestroy(ms); return rc2; }
       L.s = L.ctx->stream;
@@ -322,17 +419,8 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
       if (!cfg->pinned_input) HIP_TRY(hipHostMalloc(&L.pin_in, (size_t)p->W * p->H * p->NI, hipHostMallocDefault));
       for (int set = 0; set < 2; ++set) HIP_TRY(hipHostMalloc(&L.pin_out[set], sizeof(float) * p->d2h_words, hipHostMallocDefault));
     }
-    // the second streams AFTER every lane's own stream: the lanes' SuperPoint streams then hold consecutive hardware queues whether or not the second streams are ever
-    // used (auto mode with many passes in flight uses none of them).  (A lowest-priority NetVLAD stream measured no different: 1345 vs 1351 at one lane.)
-    // ... and placed TWO hardware pipes away from their lane's own stream: hardware queue i is served by hardware pipe i mod 4 and streams get queues in creation order,
-    // so the K lane streams are followed by (2 - K) mod 4 idle spacer streams and then the K second streams in lane order.  A lane's two streams then never share a pipe, and
-    // neither do the four streams of two consecutive lanes (4 lanes, second streams right behind the lane streams: a pass alone on the device ran at 873 stereo frames/s -- its
-    // SuperPoint and NetVLAD took turns on one pipe -- instead of 1400; rotated by one lane: 1389 alone but 1549 with two passes in flight, where two lanes reach 1840)
-    if (nv_streams) {
-      p->spacers.resize((size_t)(((2 - p->K) % 4 + 4) % 4), nullptr);
-      for (auto& sp : p->spacers) HIP_TRY(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
+    if (nv_streams)      // CU-masked lanes whose second stream could not be created with the mask above
       for (auto& L : p->lanes) if (!L.nv) HIP_TRY(hipStreamCreateWithFlags(&L.nv, hipStreamNonBlocking));
-    }
     if (p->npp > 0) {
       // pair tables [lane][set][variant v = submits of the previous pass - 1][C * npp].  Submit j of a pass contributes npp consecutive pairs:
       // L_f <-> R_f for its F frames (when match_lr), then L_f <-> L_(f-1); the first left frame of a pass pairs with the LAST left frame
@@ -381,7 +469,7 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
 
 void d2fe_pipe_destroy(d2fe_pipe p) {
   if (!p) return;
-  hipSetDevice(p->parent->cfg.device_id);
+  (void)hipSetDevice(p->parent->cfg.device_id);
   for (auto& L : p->lanes) {
     if (L.s) (void)hipStreamSynchronize(L.s);
     if (L.nv) { (void)hipStreamSynchronize(L.nv); (void)hipStreamDestroy(L.nv); }
@@ -390,7 +478,6 @@ void d2fe_pipe_destroy(d2fe_pipe p) {
     for (float* q : L.pin_out) if (q) (void)hipHostFree(q);
     if (L.ctx) d2fe_destroy(L.ctx);
   }
-  for (hipStream_t sp : p->spacers) if (sp) (void)hipStreamDestroy(sp);
   if (p->gnv) (void)hipStreamSynchronize(p->gnv);
   for (auto e : p->ev_g) if (e) (void)hipEventDestroy(e);
   if (p->gctx) d2fe_destroy(p->gctx);
@@ -630,5 +717,15 @@ int d2fe_pipe_profile_read(d2fe_pipe p, float* ms, int32_t* launches) {
 }
 
 int d2fe_pipe_lanes(d2fe_pipe p) { return p ? p->K : pipe_fail(D2FE_ERR_INVALID, "null pipe"); }
+
+int d2fe_pipe_stream_placement(d2fe_pipe p, int32_t* classes, int32_t* n_classes) {
+  if (!p || !classes || !n_classes) return pipe_fail(D2FE_ERR_INVALID, "null argument");
+  for (int k = 0; k < p->K; ++k) {
+    classes[2 * k] = k < (int)p->first_class.size() ? p->first_class[k] : -1;
+    classes[2 * k + 1] = k < (int)p->second_class.size() ? p->second_class[k] : -1;
+  }
+  *n_classes = p->n_classes;
+  return D2FE_OK;
+}
 
 }  // extern "C"

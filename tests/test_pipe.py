@@ -143,6 +143,39 @@ def test_pipe_argument_errors():
 
 
 @pytest.mark.gpu
+def test_pipe_stream_placement_is_measured_and_separates_a_lanes_streams():
+    """d2fe_pipe_create measures which candidate streams take turns on the device (one hardware pipe) and hands every lane two streams of different classes, whatever the
+    process has done to the runtime's queue pool before (here: streams created and destroyed in an irregular pattern first).  d2fe_pipe_stream_placement reports it."""
+    import torch
+    from d2slam_amd import api, netvlad as nvm
+    from d2slam_amd.weights import synthetic_superpoint_weights
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2, precision=api.PREC_F32_WINO, keypoint_threshold=0.005))
+    fe.load_superpoint(synthetic_superpoint_weights(dustbin_bias=7.5)); fe.load_netvlad(nvm.synthetic_netvlad_weights())
+    keep = []
+    for i in range(7):                 # holes in the pool: seven streams, every other one given back
+        keep.append(torch.cuda.Stream())
+    del keep[::2]
+    for lanes, inline in ((1, None), (2, None), (4, None), (4, True)):
+        pipe = api.StereoPipe(fe, lanes=lanes, frames=1, width=W, height=H, cap=CAP, netvlad=True, netvlad_inline=inline)
+        cls, n = pipe.stream_placement()
+        assert len(cls) == lanes and (n == 0 or 2 <= n <= 8)
+        for k, (a, b) in enumerate(cls):
+            if inline:
+                assert b == -1                                      # no second streams exist
+            elif n >= 2:
+                assert 0 <= a < n and 0 <= b < n and a != b, (lanes, cls)
+        if n >= 4 and lanes <= 4:
+            assert len({a for a, _ in cls}) == lanes, cls           # the lanes' own streams: all different
+        if n >= 4 and lanes == 2 and not inline:
+            assert len({c for ab in cls for c in ab}) == 4, cls    # two lanes: four streams in four classes
+        l, r = _frames(1)[0]
+        o = pipe.wait(pipe.submit(l[None], r[None]))                # the pipe works on the streams it chose
+        assert int(o["n_kp"][0]) > 0
+        pipe.close()
+    fe.close()
+
+
+@pytest.mark.gpu
 def test_pipe_netvlad_stream_modes_give_the_same_bits():
     """d2fe_pipe_config.netvlad_inline: 0 = NetVLAD on a second stream per lane, 1 = on the lane's one stream in front of SuperPoint, 2 (default) = auto (inline above two
     lanes: the device runs four busy streams side by side).  Where a kernel is queued does not change what it computes: every mode returns the same bits, and a bad value is refused."""

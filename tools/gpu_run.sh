@@ -73,7 +73,7 @@ run_task() {
     pipe)    local sw=$1; shift; timeout 300 python tools/pipe_probe.py --sweep $sw "$@" 2>/dev/null | grep '^{"coalesce_depth' | python -c '
 import sys, json
 for l in sys.stdin:
-    j = json.loads(l); print("   lanes %d x %d frames (coalesce %s depth %s): %7.1f stereo fps" % (j["lanes"], j["frames_per_submit"], j.get("coalesce"), j.get("coalesce_depth"), j["stereo_fps"]))' ;;
+    j = json.loads(l); print("   lanes %d x %d frames (coalesce %s depth %s): %7.1f stereo fps   streams %s" % (j["lanes"], j["frames_per_submit"], j.get("coalesce"), j.get("coalesce_depth"), j["stereo_fps"], json.dumps(j.get("stream_classes"))))' ;;
     layers)  timeout 600 python tools/bench_wino.py "$@" 2>&1 | grep -v amdgpu ;;
     match)   timeout 300 python tools/bench_match.py "$@" 2>&1 | grep -v amdgpu ;;
     netvlad) bash tools/nv_timeline.sh gpurun_out/run/nv ${@:-1 32} ;;

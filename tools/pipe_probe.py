@@ -71,6 +71,8 @@ def main():
         o = pipe.wait(tickets[-1])
         rec = {"coalesce_depth": args.coalesce_depth, "inflight": KC, "nv_group": args.nv_group, "lane_cus": args.lane_cus, "coalesce": args.coalesce, "cu_partition": bool(args.partition), "nv_inline": bool(args.nv_inline), "hwq": os.environ.get("GPU_MAX_HW_QUEUES"), "lanes": K, "frames_per_submit": F, "stereo_fps": round(steps * F / dt, 1), "ms_per_submit": round(dt / steps * 1e3, 4),
                "host_submit_ms": round(th / steps * 1e3, 4), "avg_kp": float(o["n_kp"].mean()), "avg_lr": float(o["lr_n"].mean()) if o["lr_n"] is not None else None}
+        pl, ncl = pipe.stream_placement()
+        rec["stream_classes"] = {"n": ncl, "lanes": pl}
         print(json.dumps(rec), flush=True)
         res.append(rec)
         pipe.close()
