@@ -332,6 +332,9 @@ typedef struct {
   const int32_t* d_n_kp;    /* [2 frames] */
   const float* d_netvlad;   /* [frames][netvlad_dim] or NULL */
 } d2fe_pipe_device_result;
+/* A stream (hipStream_t) of the pipe's own for such consumers, placed -- by the measurement of d2fe_pipe_stream_placement -- where it takes turns with a lane's NetVLAD
+ * stream at worst, not with a lane's SuperPoint.  Owned by the pipe (destroyed with it); any other stream of the caller's works too. */
+D2FE_API int d2fe_pipe_exchange_stream(d2fe_pipe p, void** stream);
 D2FE_API int d2fe_pipe_device_view(d2fe_pipe p, int64_t ticket, void* stream, d2fe_pipe_device_result* out);
 D2FE_API int d2fe_pipe_device_release(d2fe_pipe p, int64_t ticket, void* stream);
 

@@ -271,7 +271,9 @@ def test_pipe_device_view_feeds_a_consumer_stream(coal):
     off = {f: api.block_field_offset(CAP, G, f) for f in ("desc", "kps", "scores", "netvlad", "n")}
     fr = _frames(8)
     pipe = api.StereoPipe(fe, lanes=2, frames=1, width=W, height=H, cap=CAP, netvlad=True, coalesce=coal)
-    X = torch.cuda.Stream(device=dev)
+    # coal == 2: the consumer runs on the pipe's own consumer stream (d2fe_pipe_exchange_stream), coal == 1 on a stream of the caller's
+    X = torch.cuda.ExternalStream(pipe.exchange_stream(), device=dev) if coal == 2 else torch.cuda.Stream(device=dev)
+    assert pipe.exchange_stream() != 0
     blocks = [torch.zeros((1, BLK), dtype=torch.float32, device=dev) for _ in fr]
     tk = []
     for i, (l, r) in enumerate(fr):
