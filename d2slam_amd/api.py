@@ -108,7 +108,7 @@ EXPORTS = [
     "d2fe_gen_cylinder_map", "d2fe_gen_cylinder_map_device", "d2fe_gen_pinhole_map", "d2fe_gen_pinhole_map_device", "d2fe_lk_frame_create",
     "d2fe_lk_frame_create_device", "d2fe_lk_frame_destroy", "d2fe_lk_frame_read_level", "d2fe_lk_track", "d2fe_lk_track_batch",
     "d2fe_detect_fast_by_region", "d2fe_good_features_to_track", "d2fe_pipe_default_config", "d2fe_pipe_create", "d2fe_pipe_destroy",
-    "d2fe_pipe_lanes", "d2fe_pipe_stream_placement", "d2fe_pipe_exchange_stream", "d2fe_pipe_submit", "d2fe_pipe_wait", "d2fe_pipe_profile_enable", "d2fe_pipe_profile_read",
+    "d2fe_pipe_lanes", "d2fe_pipe_stream_placement", "d2fe_pipe_classify_stream", "d2fe_pipe_submit", "d2fe_pipe_wait", "d2fe_pipe_profile_enable", "d2fe_pipe_profile_read",
     "d2fe_pipe_device_view", "d2fe_pipe_device_release"]
 # the development library (lib/libd2fe_hip_dev.so, include/d2fe_debug.h) exports these on top: test hooks and kernel diagnostics
 DEBUG_EXPORTS = [
@@ -247,7 +247,7 @@ def _open_library(path, dev):
         lib.d2fe_pipe_destroy.restype = None
         lib.d2fe_pipe_lanes.argtypes = [C.c_void_p]
         lib.d2fe_pipe_stream_placement.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-        lib.d2fe_pipe_exchange_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        lib.d2fe_pipe_classify_stream.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
         lib.d2fe_pipe_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
         lib.d2fe_pipe_wait.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         lib.d2fe_pipe_device_view.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
@@ -771,11 +771,24 @@ class StereoPipe:
         _check(self._lib.d2fe_pipe_stream_placement(self._p, arr, C.byref(n)))
         return [(arr[2 * k], arr[2 * k + 1]) for k in range(K)], n.value
 
-    def exchange_stream(self):
-        """hipStream_t (an int) of d2fe_pipe_exchange_stream: the pipe's own stream for device-side consumers of its results."""
-        st = C.c_void_p()
-        _check(self._lib.d2fe_pipe_exchange_stream(self._p, C.byref(st)))
-        return int(st.value or 0)
+    def classify_stream(self, stream):
+        """d2fe_pipe_classify_stream: the class of the pipe's streams `stream` (a hipStream_t as int) takes turns with on the device, -1: none.  Idle pipe only."""
+        c = C.c_int32(-1)
+        _check(self._lib.d2fe_pipe_classify_stream(self._p, C.c_void_p(int(stream)), C.byref(c)))
+        return int(c.value)
+
+    def pick_consumer_stream(self, streams):
+        """Of the caller's candidate streams (hipStream_t ints) the one that disturbs the lanes least: a class no lane uses, else one only second (NetVLAD) streams
+        use, else the first.  Returns its index."""
+        placement, n = self.stream_placement()
+        if n < 2:
+            return 0
+        own = {a for a, _ in placement}
+        rank = []
+        for i, st in enumerate(streams):
+            c = self.classify_stream(st)
+            rank.append((0 if c < 0 else 1 if c not in own else 2, i))
+        return min(rank)[1]
 
     def device_view(self, ticket, stream):
         """DEVICE pointers into the ticket's result block for a consumer on `stream` (a raw hipStream_t, not 0): the stream is made to wait for the ticket's SuperPoint

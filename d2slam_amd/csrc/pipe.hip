@@ -55,8 +55,8 @@ struct d2fe_pipe_s {
   };
   std::vector<Lane> lanes;
   std::vector<int> first_class, second_class;   // the hardware-pipe class place_streams() measured for each lane's two streams (-1: not measured / no such stream)
-  int n_classes = 0, aux_class = -1;
-  hipStream_t aux = nullptr;         // d2fe_pipe_exchange_stream
+  int n_classes = 0;
+  long long probe_ticks = 0; double probe_turns_us = 0.0;      // the spin length and the 'takes turns' threshold of that measurement (d2fe_pipe_classify_stream)
   uint8_t* d_img_all = nullptr;      // the lanes' input buffers, one allocation: lane k at k * NI images (netvlad_group reads several lanes' left images with one stride)
   // netvlad_group = M > 1 (frames == 1, coalesce == 1, lanes % M == 0): the NetVLAD descriptors of M consecutive submits come from ONE call on the pipe's own
   // context and stream (NetVLAD at one image is ~20 launches of a few workgroups each: 0.25 ms for one image, 0.28 ms for four), while SuperPoint and the
@@ -116,16 +116,16 @@ double probe_pair_us(hipStream_t a, hipStream_t b, long long ticks) {       // <
 }
 
 // n_first + n_second streams out of measured classes; on any doubt (HIP error, no two classes told apart) the candidates are handed out in creation order
-int place_streams(int device_id, int n_first, int n_second, std::vector<hipStream_t>& first, std::vector<hipStream_t>& second, hipStream_t* aux, std::vector<int>& first_class,
-                  std::vector<int>& second_class, int* aux_class, int* n_classes) {
-  const int need = n_first + n_second + 1;
-  *aux = nullptr; *aux_class = -1;
+int place_streams(int device_id, int n_first, int n_second, std::vector<hipStream_t>& first, std::vector<hipStream_t>& second, std::vector<int>& first_class,
+                  std::vector<int>& second_class, int* n_classes, long long* probe_ticks, double* probe_turns_us) {
+  const int need = n_first + n_second;
+  *probe_ticks = 0; *probe_turns_us = 0.0;
   first.assign((size_t)n_first, nullptr); second.assign((size_t)n_second, nullptr);
   first_class.assign((size_t)n_first, -1); second_class.assign((size_t)n_second, -1);
   *n_classes = 0;
   const int NC = need + 4;
   std::vector<hipStream_t> cand((size_t)NC, nullptr);
-  auto drop = [&](int rc) { for (auto c : cand) if (c) (void)hipStreamDestroy(c); first.assign(first.size(), nullptr); second.assign(second.size(), nullptr); *aux = nullptr; return rc; };
+  auto drop = [&](int rc) { for (auto c : cand) if (c) (void)hipStreamDestroy(c); first.assign(first.size(), nullptr); second.assign(second.size(), nullptr); return rc; };
   for (auto& c : cand) if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return drop(pipe_fail(D2FE_ERR_HIP, "hipStreamCreateWithFlags"));
   std::vector<int> cls((size_t)NC, -1);
   int ncls = 0;
@@ -150,6 +150,7 @@ int place_streams(int device_id, int n_first, int n_second, std::vector<hipStrea
     }
     (void)hipGetLastError();
     ncls = ok ? (int)rep.size() : 0;
+    if (ok) { *probe_ticks = ticks; *probe_turns_us = turns; }
     if (ncls < 2) { ncls = 0; std::fill(cls.begin(), cls.end(), -1); }       // nothing told apart: creation order below
   }
   std::vector<char> used((size_t)NC, 0);
@@ -171,8 +172,6 @@ int place_streams(int device_id, int n_first, int n_second, std::vector<hipStrea
   // lane k: its own stream from class k mod n, its second stream half the classes further on (two of four): consecutive lanes' four streams in four classes
   for (int k = 0; k < n_first; ++k) { const int c = take(ncls ? k % ncls : -1); first[k] = cand[c]; first_class[k] = cls[c]; }
   for (int k = 0; k < n_second; ++k) { const int c = take(ncls ? (k + (ncls + 1) / 2) % ncls : -1); second[k] = cand[c]; second_class[k] = cls[c]; }
-  // the stream offered to device-side consumers (d2fe_pipe_exchange_stream): beside a second stream (NetVLAD: a twentieth of a lane's time) rather than beside a lane's own
-  { const int c = take(ncls ? (n_second > 0 ? second_class[0] : n_first % ncls) : -1); *aux = cand[c]; *aux_class = cls[c]; }
   for (int c = 0; c < NC; ++c) if (!used[c]) { (void)hipStreamDestroy(cand[c]); }
   *n_classes = ncls;
   return D2FE_OK;
@@ -381,7 +380,7 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
     const bool masked = cfg->cu_partition && p->K > 1;           // CU-masked streams are created per lane below
     struct Spare { std::vector<hipStream_t> first, second; ~Spare() { for (auto& v : {&first, &second}) for (hipStream_t q : *v) if (q) (void)hipStreamDestroy(q); } } spare;
     if (!masked) {
-      const int rcs = place_streams(h->cfg.device_id, p->K, nv_streams ? p->K : 0, spare.first, spare.second, &p->aux, p->first_class, p->second_class, &p->aux_class, &p->n_classes);
+      const int rcs = place_streams(h->cfg.device_id, p->K, nv_streams ? p->K : 0, spare.first, spare.second, p->first_class, p->second_class, &p->n_classes, &p->probe_ticks, &p->probe_turns_us);
       if (rcs) return rcs;
     }
     for (int k = 0; k < p->K; ++k) {
@@ -423,7 +422,6 @@ int d2fe_pipe_create(d2fe_handle h, const d2fe_pipe_config* cfg, d2fe_pipe* out)
       if (!cfg->pinned_input) HIP_TRY(hipHostMalloc(&L.pin_in, (size_t)p->W * p->H * p->NI, hipHostMallocDefault));
       for (int set = 0; set < 2; ++set) HIP_TRY(hipHostMalloc(&L.pin_out[set], sizeof(float) * p->d2h_words, hipHostMallocDefault));
     }
-    if (!p->aux) HIP_TRY(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));       // CU-masked lanes: no measured placement
     if (nv_streams)      // CU-masked lanes whose second stream could not be created with the mask above
       for (auto& L : p->lanes) if (!L.nv) HIP_TRY(hipStreamCreateWithFlags(&L.nv, hipStreamNonBlocking));
     if (p->npp > 0) {
@@ -483,7 +481,6 @@ void d2fe_pipe_destroy(d2fe_pipe p) {
     for (float* q : L.pin_out) if (q) (void)hipHostFree(q);
     if (L.ctx) d2fe_destroy(L.ctx);
   }
-  if (p->aux) { (void)hipStreamSynchronize(p->aux); (void)hipStreamDestroy(p->aux); }
   if (p->gnv) (void)hipStreamSynchronize(p->gnv);
   for (auto e : p->ev_g) if (e) (void)hipEventDestroy(e);
   if (p->gctx) d2fe_destroy(p->gctx);
@@ -724,9 +721,27 @@ int d2fe_pipe_profile_read(d2fe_pipe p, float* ms, int32_t* launches) {
 
 int d2fe_pipe_lanes(d2fe_pipe p) { return p ? p->K : pipe_fail(D2FE_ERR_INVALID, "null pipe"); }
 
-int d2fe_pipe_exchange_stream(d2fe_pipe p, void** stream) {
-  if (!p || !stream) return pipe_fail(D2FE_ERR_INVALID, "null argument");
-  *stream = p->aux;
+int d2fe_pipe_classify_stream(d2fe_pipe p, void* stream, int32_t* cls) {
+  if (!p || !stream || !cls) return pipe_fail(D2FE_ERR_INVALID, "null argument");
+  *cls = -1;
+  if (p->n_classes < 2 || p->probe_ticks <= 0) return D2FE_OK;            // nothing was told apart at creation
+  std::lock_guard<std::mutex> lk(p->mu);
+  HIP_TRY(hipSetDevice(p->parent->cfg.device_id));
+  if (passes_in_flight(p) != 0) return pipe_fail(D2FE_ERR_INVALID, "d2fe_pipe_classify_stream measures on an idle pipe: wait for every ticket first");
+  const hipStream_t x = (hipStream_t)stream;
+  HIP_TRY(hipStreamSynchronize(x));
+  std::vector<char> seen((size_t)p->n_classes, 0);
+  for (int k = 0; k < p->K && *cls < 0; ++k)
+    for (int w = 0; w < 2 && *cls < 0; ++w) {
+      const int c = w == 0 ? (k < (int)p->first_class.size() ? p->first_class[k] : -1) : (k < (int)p->second_class.size() ? p->second_class[k] : -1);
+      const hipStream_t r = w == 0 ? p->lanes[k].s : p->lanes[k].nv;
+      if (c < 0 || c >= p->n_classes || !r || seen[c]) continue;
+      seen[c] = 1;
+      double t = probe_pair_us(x, r, p->probe_ticks);
+      if (t >= p->probe_turns_us) t = std::min(t, probe_pair_us(x, r, p->probe_ticks));
+      if (t < 0) return pipe_fail(D2FE_ERR_HIP, "stream probe");
+      if (t >= p->probe_turns_us) *cls = c;
+    }
   return D2FE_OK;
 }
 

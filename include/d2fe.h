@@ -332,9 +332,10 @@ typedef struct {
   const int32_t* d_n_kp;    /* [2 frames] */
   const float* d_netvlad;   /* [frames][netvlad_dim] or NULL */
 } d2fe_pipe_device_result;
-/* A stream (hipStream_t) of the pipe's own for such consumers, placed -- by the measurement of d2fe_pipe_stream_placement -- where it takes turns with a lane's NetVLAD
- * stream at worst, not with a lane's SuperPoint.  Owned by the pipe (destroyed with it); any other stream of the caller's works too. */
-D2FE_API int d2fe_pipe_exchange_stream(d2fe_pipe p, void** stream);
+/* Where a stream of the CALLER's sits relative to the pipe's streams (same measurement as d2fe_pipe_stream_placement, against one lane stream per class; the pipe must be
+ * idle; ~1 ms): *cls = the class it takes turns with, or -1 = none of the classes the lanes use.  A consumer that may choose among several streams (torch.cuda.Stream()
+ * hands out pool streams) takes one of class -1, else one that only meets second (NetVLAD) streams. */
+D2FE_API int d2fe_pipe_classify_stream(d2fe_pipe p, void* stream, int32_t* cls);
 D2FE_API int d2fe_pipe_device_view(d2fe_pipe p, int64_t ticket, void* stream, d2fe_pipe_device_result* out);
 D2FE_API int d2fe_pipe_device_release(d2fe_pipe p, int64_t ticket, void* stream);
 
