@@ -687,7 +687,8 @@ static int extract_host(d2fe_handle h, const uint8_t* gray, int n, int width, in
     // NetVLAD reads the frames SuperPoint reads (one upload), on its own stream: at one or two images per call both launch sequences are
     // latency-bound and leave most of the chip idle, so they overlap almost completely (the reference calls infer and then inference
     // for the same image, loop_cam.cpp:609-616)
-    if (!h->nv_stream) { HIP_TRY(hipStreamCreateWithFlags(&h->nv_stream, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming)); }
+    // (a stream on another hardware pipe than the handle's own: two busy streams on one pipe take turns, pipe.hip)
+    if (!h->nv_stream) { HIP_TRY(create_stream_beside(h->cfg.device_id, h->stream, &h->nv_stream)); HIP_TRY(hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming)); }
     const int G = d2fe_netvlad_dim(h);
     nv_bytes = sizeof(float) * (size_t)G * n_netvlad;
     if (h->use_pinned && nv_bytes > h->pin_nv_bytes) {

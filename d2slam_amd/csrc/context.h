@@ -159,4 +159,7 @@ int nv_check(d2fe_context* h, int n, int W, int H, int stride);
 // stream may use -- the persistent kernels size their grids on it
 // with_netvlad: the lane will run NetVLAD itself (its own activation buffers); a lane never gets the host-pointer staging of d2fe_create
 int clone_lane(d2fe_context* parent, int max_batch, d2fe_context** out, hipStream_t stream = nullptr, int ncu = 0, bool with_netvlad = true);
+// a new non-blocking stream that does NOT take turns with `beside` on the device (pipe.hip: the same measurement as d2fe_pipe_create's stream placement, on up to four
+// candidates; the first candidate if none can be told apart).  hipSuccess or the failing call's error
+hipError_t create_stream_beside(int device_id, hipStream_t beside, hipStream_t* out);
 }  // namespace d2fe

@@ -291,6 +291,34 @@ int pipe_flush_group(d2fe_pipe_s* p, long long upto) {
 
 }  // namespace
 
+namespace d2fe {
+hipError_t create_stream_beside(int device_id, hipStream_t beside, hipStream_t* out) {
+  *out = nullptr;
+  hipStream_t cand[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  for (auto& c : cand) if ((e = hipStreamCreateWithFlags(&c, hipStreamNonBlocking)) != hipSuccess) break;
+  int pick = 0;
+  if (e == hipSuccess && beside) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_id) != hipSuccess || khz <= 0) khz = 100000;
+    const long long ticks = (long long)(PROBE_SPIN_US * 1e-3 * khz);
+    double solo = -1.0;
+    for (int i = 0; i < 3; ++i) { const double t = probe_pair_us(cand[0], nullptr, ticks); if (i > 0 && t >= 0) solo = solo < 0 ? t : std::min(solo, t); }
+    const double turns = 1.6 * std::max(solo, PROBE_CHAIN * PROBE_SPIN_US);
+    bool found = false;
+    for (int c = 0; solo >= 0 && c < 4 && !found; ++c) {
+      double t = probe_pair_us(cand[c], beside, ticks);
+      if (t >= turns) t = std::min(t, probe_pair_us(cand[c], beside, ticks));
+      if (t >= 0 && t < turns) { pick = c; found = true; }
+    }
+    (void)hipGetLastError();
+  }
+  for (int c = 0; c < 4; ++c) if (cand[c] && (e != hipSuccess || c != pick)) (void)hipStreamDestroy(cand[c]);
+  if (e == hipSuccess) *out = cand[pick];
+  return e;
+}
+}  // namespace d2fe
+
 extern "C" {
 
 void d2fe_pipe_destroy(d2fe_pipe p);
