@@ -352,14 +352,14 @@ def main():
                     if alone:
                         solo = r
                 batch_curve.append({"stereo_frames_per_submit": Fc, "submits_in_flight": Kc, "coalesce": 1, "stereo_fps": round(r["value"], 1), "ms_per_submit": round(r["ms_per_step"], 4),
-                                    "host_ms_per_submit_call": round(r["host_submit_ms"], 4)})
+                                    "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r)})
             if Fc == 1:
                 # one stereo frame per submit, consecutive submits coalesced into one launch sequence when they arrive before anybody waits
                 # (d2fe_pipe_config.coalesce): what a caller that receives single frames gets without batching by hand
                 for cc in (2, 4):
                     r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, coalesce=cc)
                     batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": 4 * cc, "coalesce": cc, "stereo_fps": round(r["value"], 1),
-                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
+                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r),
                                         "note": "submit() stages the frame (its H2D starts at once); every %d-th submit launches ONE sequence over the staged frames, "
                                                 "4 such passes in flight; per-ticket results are bit-identical to the single calls (tests/test_pipe.py)" % cc})
                 if use_nv:
@@ -368,21 +368,21 @@ def main():
                     # every submit still start at once
                     r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=True, light=True, nv_group=4)
                     batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": 4, "coalesce": 1, "netvlad_group": 4, "stereo_fps": round(r["value"], 1),
-                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
+                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r),
                                         "note": "netvlad_group = 4: one NetVLAD call per four consecutive single-frame submits; bit-identical results"})
                 # ONE 4-lane pipe of plain single-frame passes (coalesce = 1) under callers that keep 1 / 2 / 3 submits outstanding (4: the K = 4 point above): the
                 # pipe decides per pass which stream NetVLAD goes to (d2fe_pipe_config.netvlad_inline = auto), so the lone pass keeps the single-lane latency
                 for infl in (1, 2, 3):
                     r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, inflight=infl)
                     batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": infl, "lanes": 4, "coalesce": 1, "stereo_fps": round(r["value"], 1),
-                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
+                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r),
                                         "note": "the 4-lane pipe of the K = 4 point with fewer submits outstanding"})
                 # dynamic batching (coalesce_depth = 2): a pass is launched as soon as fewer than two are in flight, so the SAME configuration serves a caller
                 # that waits for every frame (1 in flight: launched at once) and one that keeps 16 in flight (passes grow to 4 frames)
                 for infl in (1, 4, 16):
                     r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, coalesce=4, depth=2, inflight=infl)
                     batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": infl, "coalesce": 4, "coalesce_depth": 2, "stereo_fps": round(r["value"], 1),
-                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4),
+                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r),
                                         "note": "dynamic batching: up to 4 consecutive submits per pass, launched early whenever fewer than 2 passes are in flight"})
     if world == 1 and solo is None and lanes > 1 and not args.no_solo:
         # --single-mode / --no-batch-curve: the headline kernel's solo measurement still belongs to the line
@@ -453,6 +453,9 @@ def main():
                                     "region (the reference's contract ends in host std::vectors, superpoint_tensorrt.cpp:172-180, loop_cam.cpp:619-645)" + ("" if world == 1 else
                                     "; N > 1: the cross-agent match lists and gate decisions too (a ring of pinned slots, one D2H per submit on the exchange stream)"),
                        "submits_in_flight": primary.get("lanes"), "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "stream_placement": dict(primary.get("stream_placement") or {}, what="d2fe_pipe_stream_placement of the timed pipe: the hardware-pipe class d2fe_pipe_create MEASURED "
+                                                "for each lane's (own, second) stream; streams of one class take turns on the device; classes_told_apart 0 = the device was not quiet "
+                                                "when the pipe was created (e.g. two ranks sharing one GPU) and creation order was used"),
                        "netvlad_overlaps_superpoint": "NetVLAD runs on the lane's second stream beside SuperPoint",
                        "max_keypoints": CAP, "postproc": "B",
                        "precision": args.precision, "netvlad": use_nv,
@@ -675,6 +678,12 @@ def netvlad_roofline(t_ms, F, how, flop_per_img=NV_FLOP_PER_IMG):
             "note": "fp32 MFMA (v_mfma_f32_16x16x4_f32) + VALU depthwise; instruction/latency-bound small layers (DESIGN.md section 4); " + how}
 
 
+def stream_classes(r):
+    """compact form of a run's d2fe_pipe_stream_placement for the batch curve: 'n: own/second own/second ...' (n = classes told apart, 0 = not measured)"""
+    p = r.get("stream_placement") or {}
+    return "%s: %s" % (p.get("classes_told_apart"), " ".join("%d/%d" % (a, b) for a, b in p.get("lanes") or []))
+
+
 def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup, local_rank, rank, netvlad=True, light=False, coalesce=1, depth=0, inflight=0,
              world=1, dist=None, exchange=None, nv_flop_per_img=NV_FLOP_PER_IMG, nv_group=1, loopback=False):
     """`steps` submits of F stereo frames through the frames-in-flight pipe with `lanes` submits in flight: the timed region holds, per submit, the H2D of
@@ -797,7 +806,13 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
         if netvlad and nv_n:
             res["roofline_nv"] = netvlad_roofline(nv_ms / nv_n, F, "HIP events around the whole sequence on the lane's NetVLAD stream, which runs BESIDE that lane's SuperPoint launches "
                                                   "(the figure includes what the two sequences cost each other)", nv_flop_per_img)
+    pl, ncl = pipe.stream_placement()
+    res["stream_placement"] = {"classes_told_apart": ncl, "lanes": pl, "exchange_stream_class": None}
     if xch:
+        try:
+            res["stream_placement"]["exchange_stream_class"] = pipe.classify_stream(xch.stream.cuda_stream)
+        except Exception as e:      # not idle (should not happen here: every ticket has been waited for)
+            res["stream_placement"]["exchange_stream_class"] = str(e)[:80]
         xch.close()
     pipe.close(); fe.close()
     return res

@@ -777,18 +777,24 @@ class StereoPipe:
         _check(self._lib.d2fe_pipe_classify_stream(self._p, C.c_void_p(int(stream)), C.byref(c)))
         return int(c.value)
 
-    def pick_consumer_stream(self, streams):
-        """Of the caller's candidate streams (hipStream_t ints) the one that disturbs the lanes least: a class no lane uses, else one only second (NetVLAD) streams
-        use, else the first.  Returns its index."""
+    def pick_consumer_stream(self, make, handle=lambda s: s, tries=4):
+        """A stream for a device-side consumer of this pipe's results that disturbs the lanes least: `make()` creates candidate streams one at a time (`handle(stream)` = its
+        hipStream_t as int) until one takes turns with none of the lanes' streams, or only with second (NetVLAD) streams; after `tries` candidates the best seen.  One at a
+        time because every stream a process creates costs it a hardware queue for good."""
         placement, n = self.stream_placement()
-        if n < 2:
-            return 0
         own = {a for a, _ in placement}
-        rank = []
-        for i, st in enumerate(streams):
-            c = self.classify_stream(st)
-            rank.append((0 if c < 0 else 1 if c not in own else 2, i))
-        return min(rank)[1]
+        best = None
+        for _ in range(tries if n >= 2 else 1):
+            st = make()
+            if n < 2:
+                return st
+            c = self.classify_stream(handle(st))
+            rank = 0 if c < 0 else 1 if c not in own else 2
+            if best is None or rank < best[0]:
+                best = (rank, st)
+            if rank < 2:
+                break
+        return best[1]
 
     def device_view(self, ticket, stream):
         """DEVICE pointers into the ticket's result block for a consumer on `stream` (a raw hipStream_t, not 0): the stream is made to wait for the ticket's SuperPoint

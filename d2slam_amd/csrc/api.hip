@@ -355,7 +355,7 @@ void d2fe_default_config(d2fe_config* c) {
 namespace d2fe {
 // lane = a context cloned for a pipe (clone_lane): no host-pointer staging (frame upload buffer, output block, pinned mirrors) -- a lane is only ever
 // driven through run_superpoint / run_netvlad on device buffers of the pipe
-static int create_context(const d2fe_config* cfg, d2fe_handle* out, bool lane) {
+static int create_context(const d2fe_config* cfg, d2fe_handle* out, bool lane, hipStream_t adopt = nullptr) {
   if (!cfg || !out) return fail(D2FE_ERR_INVALID, "null argument");
   *out = nullptr;
   if (cfg->struct_size != (int32_t)sizeof(d2fe_config)) return fail(D2FE_ERR_INVALID, "d2fe_config size mismatch");
@@ -381,7 +381,9 @@ static int create_context(const d2fe_config* cfg, d2fe_handle* out, bool lane) {
   // conv1a is evaluated inside conv1b's staging in every mode (the Winograd kernel runs it on the matrix pipe): the 78.6 MB/image
   // activation never exists.  D2FE_FUSE1A=0 falls back to a stand-alone conv1a kernel (bit-identical; kept for A/B measurements).
   h->fuse1a = d2fe_dev_env("D2FE_FUSE1A", 1) != 0;
-    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    // (a lane that is handed its stream does not create one first: every stream ever created costs the process a hardware queue, and two processes of one GPU that
+    // hold more queues than the device has slots are time-sliced against each other)
+    if (adopt) h->stream = adopt; else HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     const size_t H = cfg->max_height, W = cfg->max_width;
     const int B = cfg->max_batch;
     int rc = 0;
@@ -462,9 +464,10 @@ static int create_context(const d2fe_config* cfg, d2fe_handle* out, bool lane) {
     }
     return D2FE_OK;
   }();
-  if (rc_alloc != D2FE_OK) { d2fe_destroy(h); return rc_alloc; }   // everything allocated so far is released
+  // (an adopted stream stays the caller's on failure)
+  if (rc_alloc != D2FE_OK) { if (adopt) h->stream = nullptr; d2fe_destroy(h); return rc_alloc; }   // everything allocated so far is released
   // the hipMemsets above ran on the null stream; the handle's work runs on non-blocking streams that do not wait for it
-  if (hipDeviceSynchronize() != hipSuccess) { d2fe_destroy(h); return fail(D2FE_ERR_HIP, "hipDeviceSynchronize"); }
+  if (hipDeviceSynchronize() != hipSuccess) { if (adopt) h->stream = nullptr; d2fe_destroy(h); return fail(D2FE_ERR_HIP, "hipDeviceSynchronize"); }
   *out = h;
   return D2FE_OK;
 }
@@ -1236,10 +1239,9 @@ int clone_lane(d2fe_context* p, int max_batch, d2fe_context** out, hipStream_t s
   cfg.max_batch = max_batch;
   cfg.async_tail = 0;
   d2fe_handle c = nullptr;
-  int rc = create_context(&cfg, &c, true);
+  int rc = create_context(&cfg, &c, true, stream);       // on failure the stream stays the caller's (create_context un-adopts it below)
   if (rc) return rc;
   c->borrowed = true;
-  if (stream) { (void)hipStreamDestroy(c->stream); c->stream = stream; }
   if (ncu > 0) c->ncu = ncu;
   c->w1a = p->w1a; c->b1a = p->b1a;
   for (int i = 0; i < L_COUNT; ++i) c->L[i] = p->L[i];
@@ -1266,7 +1268,7 @@ int clone_lane(d2fe_context* p, int max_batch, d2fe_context** out, hipStream_t s
       return D2FE_OK;       // no nv_s_img / nv_s_out: the host-pointer NetVLAD calls never run on a lane
     };
     rc = alloc();
-    if (rc) { d2fe_destroy(c); return rc; }
+    if (rc) { if (stream) c->stream = nullptr; d2fe_destroy(c); return rc; }       // the stream stays the caller's
     c->nv_loaded = true;
   }
   *out = c;

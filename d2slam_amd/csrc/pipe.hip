@@ -115,7 +115,8 @@ double probe_pair_us(hipStream_t a, hipStream_t b, long long ticks) {       // <
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
 }
 
-// n_first + n_second streams out of measured classes; on any doubt (HIP error, no two classes told apart) the candidates are handed out in creation order
+// n_first + n_second streams out of measured classes; on any doubt (HIP error, a device that is not quiet, nothing told apart) the classes a fresh process would have
+// (hardware queues in creation order, queue i on hardware pipe i mod 4) are assumed instead and *n_classes = 0 says so
 int place_streams(int device_id, int n_first, int n_second, std::vector<hipStream_t>& first, std::vector<hipStream_t>& second, std::vector<int>& first_class,
                   std::vector<int>& second_class, int* n_classes, long long* probe_ticks, double* probe_turns_us) {
   const int need = n_first + n_second;
@@ -123,57 +124,128 @@ int place_streams(int device_id, int n_first, int n_second, std::vector<hipStrea
   first.assign((size_t)n_first, nullptr); second.assign((size_t)n_second, nullptr);
   first_class.assign((size_t)n_first, -1); second_class.assign((size_t)n_second, -1);
   *n_classes = 0;
-  const int NC = need + 4;
-  std::vector<hipStream_t> cand((size_t)NC, nullptr);
+  // Exactly the streams the pipe needs to begin with: every stream ever created costs the process a hardware queue (the runtime keeps it when the stream is destroyed), and
+  // two processes of one GPU that together hold more queues than the device has slots are time-sliced against each other (two ranks on one GPU, each pipe with four spare
+  // candidates: 36-71 instead of 26 ms per step).  A spare is only created while the streams at hand cannot be dealt out as wanted (never in a fresh process).
+  std::vector<hipStream_t> cand;
   auto drop = [&](int rc) { for (auto c : cand) if (c) (void)hipStreamDestroy(c); first.assign(first.size(), nullptr); second.assign(second.size(), nullptr); return rc; };
-  for (auto& c : cand) if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return drop(pipe_fail(D2FE_ERR_HIP, "hipStreamCreateWithFlags"));
-  std::vector<int> cls((size_t)NC, -1);
-  int ncls = 0;
-  {
+  auto add_candidate = [&]() { hipStream_t q = nullptr; if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) return false; cand.push_back(q); return true; };
+  for (int c = 0; c < need; ++c) if (!add_candidate()) return drop(pipe_fail(D2FE_ERR_HIP, "hipStreamCreateWithFlags"));
+  std::vector<int> cls, rep;        // class of every candidate; one candidate per class
+  long long ticks = 0;
+  double turns = 0.0;
+  bool ok = true, quiet = false;
+  auto takes_turns = [&](hipStream_t a, hipStream_t b) {       // a slow sample is confirmed once (a busy host or device looks the same)
+    double t = probe_pair_us(a, b, ticks);
+    if (t >= turns) t = std::min(t, probe_pair_us(a, b, ticks));
+    if (t < 0) ok = false;
+    return t >= turns;
+  };
+  auto classify = [&](int c) {       // appends cls[c]
+    int k = -1;
+    for (size_t r = 0; ok && r < rep.size() && k < 0; ++r) if (takes_turns(cand[c], cand[rep[r]])) k = (int)r;
+    if (ok && k < 0) { if (rep.size() < 8) { k = (int)rep.size(); rep.push_back(c); } else { quiet = false; k = 0; } }     // more than eight classes: noise, not hardware
+    cls.push_back(k);
+  };
+  if (need > 1 && d2fe_dev_env("D2FE_PIPE_PLACEMENT", 1) != 0) {
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_id) != hipSuccess || khz <= 0) khz = 100000;
-    const long long ticks = (long long)(PROBE_SPIN_US * 1e-3 * khz);
-    bool ok = hipDeviceSynchronize() == hipSuccess;
-    // the chain alone (second sample: the first pays for loading the kernel)
-    double solo = -1.0;
-    for (int i = 0; ok && i < 3; ++i) { const double t = probe_pair_us(cand[0], nullptr, ticks); if (t < 0) ok = false; else if (i > 0) solo = solo < 0 ? t : std::min(solo, t); }
-    const double turns = 1.6 * std::max(solo, PROBE_CHAIN * PROBE_SPIN_US);
-    std::vector<int> rep;        // one candidate per class
-    for (int c = 0; ok && c < NC; ++c) {
-      for (size_t r = 0; ok && r < rep.size() && cls[c] < 0; ++r) {
-        double t = probe_pair_us(cand[c], cand[rep[r]], ticks);
-        if (t >= turns) t = std::min(t, probe_pair_us(cand[c], cand[rep[r]], ticks));       // a slow sample is confirmed once (a busy host looks the same)
-        if (t < 0) ok = false;
-        else if (t >= turns) cls[c] = (int)r;
-      }
-      if (ok && cls[c] < 0) { if (rep.size() < 8) { cls[c] = (int)rep.size(); rep.push_back(c); } else cls[c] = c % 8; }
+    ticks = (long long)(PROBE_SPIN_US * 1e-3 * khz);
+    ok = hipDeviceSynchronize() == hipSuccess;
+    // the chain alone (the first sample pays for loading the kernel).  The measurement needs a quiet device: when the solo samples disagree by more than a third, somebody
+    // else is using it (another process of a shared GPU, another handle of this process at work) and nothing below would mean anything
+    double solo = -1.0, solo_max = 0.0;
+    for (int i = 0; ok && i < 5; ++i) {
+      const double t = probe_pair_us(cand[(size_t)i % cand.size()], nullptr, ticks);
+      if (t < 0) ok = false; else if (i > 0) { solo = solo < 0 ? t : std::min(solo, t); solo_max = std::max(solo_max, t); }
     }
-    (void)hipGetLastError();
-    ncls = ok ? (int)rep.size() : 0;
-    if (ok) { *probe_ticks = ticks; *probe_turns_us = turns; }
-    if (ncls < 2) { ncls = 0; std::fill(cls.begin(), cls.end(), -1); }       // nothing told apart: creation order below
+    quiet = ok && solo_max <= 1.35 * solo;
+    turns = 1.6 * std::max(solo, PROBE_CHAIN * PROBE_SPIN_US);
+    for (int c = 0; ok && quiet && c < need; ++c) classify(c);
+    // cross-check: two members of one class (neither its representative) take turns with each other too
+    for (int c = 0; ok && quiet && c < (int)cls.size(); ++c)
+      for (int d = c + 1; ok && quiet && d < (int)cls.size(); ++d)
+        if (cls[c] == cls[d] && c != rep[cls[c]] && d != rep[cls[d]]) { if (!takes_turns(cand[c], cand[d])) quiet = false; break; }
   }
-  std::vector<char> used((size_t)NC, 0);
-  auto take = [&](int want) -> int {      // first unused candidate of class `want`; else of the class with the most unused candidates; else any
-    int best = -1;
-    if (ncls > 0) {
-      for (int c = 0; c < NC && best < 0; ++c) if (!used[c] && cls[c] == want) best = c;
-      if (best < 0) {
-        std::vector<int> left((size_t)ncls, 0);
-        for (int c = 0; c < NC; ++c) if (!used[c] && cls[c] >= 0 && cls[c] < ncls) ++left[cls[c]];
-        const int big = (int)(std::max_element(left.begin(), left.end()) - left.begin());
-        for (int c = 0; c < NC && best < 0; ++c) if (!used[c] && cls[c] == big) best = c;
+  bool measured = ok && quiet && rep.size() >= 2 && (int)cls.size() == need;
+  std::vector<int> pick_first, pick_second;
+  // lane k: its own stream from class k mod n, its second stream half the classes further on (two of four), so that the four streams of two consecutive lanes sit in four
+  // classes -- as far as the streams at hand allow: a class that has run out is replaced by the one that meets the fewest of the neighbouring lanes' streams.  Returns how
+  // far the deal is from that: streams of one class within a lane's pair, or within two consecutive lanes' streams (beyond what n < 4 classes force)
+  auto deal = [&](const std::vector<int>& cl, int ncls) {
+    const int NC = (int)cand.size();
+    std::vector<char> used((size_t)NC, 0);
+    auto take = [&](int want, const std::vector<int>& avoid) -> int {
+      std::vector<int> left((size_t)ncls, 0);
+      for (int c = 0; c < NC; ++c) if (!used[c]) ++left[cl[c]];
+      int cls_pick = -1;
+      if (left[want] > 0) cls_pick = want;
+      else {
+        long best_score = -1;
+        for (int k = 0; k < ncls; ++k) {
+          if (!left[k]) continue;
+          int meets = 0;
+          for (int a : avoid) meets += a == k;
+          const long score = (long)(16 - meets) * 1024 + left[k];        // fewest neighbours first, then the class with the most streams left
+          if (score > best_score) { best_score = score; cls_pick = k; }
+        }
       }
+      for (int c = 0; c < NC; ++c) if (!used[c] && cl[c] == cls_pick) { used[c] = 1; return c; }
+      return -1;      // not reached: the pipe never asks for more streams than there are candidates
+    };
+    pick_first.clear(); pick_second.clear();
+    std::vector<int> fc, sc;
+    for (int k = 0; k < n_first; ++k) {
+      std::vector<int> avoid;
+      if (k > 0) avoid.push_back(fc[k - 1]);
+      if (k + 1 == n_first && n_first > 2) avoid.push_back(fc[0]);
+      pick_first.push_back(take(k % ncls, avoid)); fc.push_back(cl[pick_first.back()]);
     }
-    for (int c = 0; c < NC && best < 0; ++c) if (!used[c]) best = c;
-    used[best] = 1;
-    return best;
+    for (int k = 0; k < n_second; ++k) {
+      std::vector<int> avoid = {fc[k], fc[(k + 1) % n_first], fc[(k + n_first - 1) % n_first]};
+      if (k > 0) avoid.push_back(sc[k - 1]);
+      if (k + 1 == n_second && n_second > 2) avoid.push_back(sc[0]);
+      pick_second.push_back(take((k + (ncls + 1) / 2) % ncls, avoid)); sc.push_back(cl[pick_second.back()]);
+    }
+    auto clashes = [&](std::vector<int> v) {       // streams beyond the first of every class, less what fewer classes than streams force
+      const int n = (int)v.size();
+      std::sort(v.begin(), v.end());
+      const int distinct = (int)(std::unique(v.begin(), v.end()) - v.begin());
+      return std::max(0, std::min(n, ncls) - distinct);
+    };
+    int bad = 0;
+    if (n_second) {
+      if (n_first == 1) bad += clashes({fc[0], sc[0]});
+      // pairs of consecutive lanes; the pair (last, first) only where the pattern closes (a multiple of four lanes)
+      for (int k = 0; k + 1 < n_first || (k + 1 == n_first && n_first > 2 && n_first % 4 == 0); ++k) { const int m = (k + 1) % n_first; bad += clashes({fc[k], sc[k], fc[m], sc[m]}); }
+    } else {
+      for (int k = 0; k < n_first; k += 4) bad += clashes(std::vector<int>(fc.begin() + k, fc.begin() + std::min(k + 4, n_first)));      // blocks of four lanes
+    }
+    return bad;
   };
-  // lane k: its own stream from class k mod n, its second stream half the classes further on (two of four): consecutive lanes' four streams in four classes
-  for (int k = 0; k < n_first; ++k) { const int c = take(ncls ? k % ncls : -1); first[k] = cand[c]; first_class[k] = cls[c]; }
-  for (int k = 0; k < n_second; ++k) { const int c = take(ncls ? (k + (ncls + 1) / 2) % ncls : -1); second[k] = cand[c]; second_class[k] = cls[c]; }
-  for (int c = 0; c < NC; ++c) if (!used[c]) { (void)hipStreamDestroy(cand[c]); }
-  *n_classes = ncls;
+  if (measured) {
+    int bad = deal(cls, (int)rep.size());
+    // (up to sixteen: a process that already holds every hardware queue of its pool gets new streams on the least-shared queues first, and those may all sit on three of
+    // the four pipes -- measured in bench.py after its other legs: twelve candidates, three classes; creating them costs such a process no further queue)
+    for (int extra = 0; bad > 0 && extra < 16 && ok && quiet; ++extra) {
+      if (!add_candidate()) break;
+      classify((int)cand.size() - 1);
+      if (ok && quiet) bad = deal(cls, (int)rep.size());
+    }
+    measured = ok && quiet;
+    (void)hipGetLastError();
+  }
+  if (!measured) {      // creation order of the first `need` candidates
+    cls.assign(cand.size(), 0);
+    for (size_t c = 0; c < cand.size(); ++c) cls[c] = (int)(c % 4);
+    (void)deal(cls, 4);
+  } else {
+    *probe_ticks = ticks; *probe_turns_us = turns; *n_classes = (int)rep.size();
+  }
+  std::vector<char> keep(cand.size(), 0);
+  for (int k = 0; k < n_first; ++k) { first[k] = cand[pick_first[k]]; keep[pick_first[k]] = 1; if (measured) first_class[k] = cls[pick_first[k]]; }
+  for (int k = 0; k < n_second; ++k) { second[k] = cand[pick_second[k]]; keep[pick_second[k]] = 1; if (measured) second_class[k] = cls[pick_second[k]]; }
+  for (size_t c = 0; c < cand.size(); ++c) if (!keep[c]) (void)hipStreamDestroy(cand[c]);
   return D2FE_OK;
 }
 
@@ -294,26 +366,33 @@ int pipe_flush_group(d2fe_pipe_s* p, long long upto) {
 namespace d2fe {
 hipError_t create_stream_beside(int device_id, hipStream_t beside, hipStream_t* out) {
   *out = nullptr;
+  // candidates one at a time (the first is almost always the one: a stream created right after `beside` sits on the next hardware pipe); the ones that took turns are
+  // given back at the end, not before -- the runtime would hand the same queue out again
   hipStream_t cand[4] = {nullptr, nullptr, nullptr, nullptr};
+  int n = 0, pick = -1;
+  long long ticks = 0;
+  double turns = 0.0;
   hipError_t e = hipSuccess;
-  for (auto& c : cand) if ((e = hipStreamCreateWithFlags(&c, hipStreamNonBlocking)) != hipSuccess) break;
-  int pick = 0;
-  if (e == hipSuccess && beside) {
-    int khz = 0;
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_id) != hipSuccess || khz <= 0) khz = 100000;
-    const long long ticks = (long long)(PROBE_SPIN_US * 1e-3 * khz);
-    double solo = -1.0;
-    for (int i = 0; i < 3; ++i) { const double t = probe_pair_us(cand[0], nullptr, ticks); if (i > 0 && t >= 0) solo = solo < 0 ? t : std::min(solo, t); }
-    const double turns = 1.6 * std::max(solo, PROBE_CHAIN * PROBE_SPIN_US);
-    bool found = false;
-    for (int c = 0; solo >= 0 && c < 4 && !found; ++c) {
-      double t = probe_pair_us(cand[c], beside, ticks);
-      if (t >= turns) t = std::min(t, probe_pair_us(cand[c], beside, ticks));
-      if (t >= 0 && t < turns) { pick = c; found = true; }
+  while (pick < 0 && n < 4) {
+    if ((e = hipStreamCreateWithFlags(&cand[n], hipStreamNonBlocking)) != hipSuccess) break;
+    ++n;
+    if (!beside || d2fe_dev_env("D2FE_PIPE_PLACEMENT", 1) == 0) { pick = 0; break; }
+    if (n == 1) {
+      int khz = 0;
+      if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_id) != hipSuccess || khz <= 0) khz = 100000;
+      ticks = (long long)(PROBE_SPIN_US * 1e-3 * khz);
+      double solo = -1.0, solo_max = 0.0;
+      for (int i = 0; i < 4; ++i) { const double t = probe_pair_us(cand[0], nullptr, ticks); if (i > 0 && t >= 0) { solo = solo < 0 ? t : std::min(solo, t); solo_max = std::max(solo_max, t); } }
+      if (solo < 0 || solo_max > 1.35 * solo) { pick = 0; break; }      // not a quiet device: nothing to measure
+      turns = 1.6 * std::max(solo, PROBE_CHAIN * PROBE_SPIN_US);
     }
-    (void)hipGetLastError();
+    double t = probe_pair_us(cand[n - 1], beside, ticks);
+    if (t >= turns) t = std::min(t, probe_pair_us(cand[n - 1], beside, ticks));
+    if (t >= 0 && t < turns) pick = n - 1;
   }
-  for (int c = 0; c < 4; ++c) if (cand[c] && (e != hipSuccess || c != pick)) (void)hipStreamDestroy(cand[c]);
+  (void)hipGetLastError();
+  if (e == hipSuccess && pick < 0) pick = 0;
+  for (int c = 0; c < n; ++c) if (e != hipSuccess || c != pick) (void)hipStreamDestroy(cand[c]);
   if (e == hipSuccess) *out = cand[pick];
   return e;
 }

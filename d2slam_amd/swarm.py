@@ -232,10 +232,10 @@ class PipeExchange:
         self.BLKB = block_bytes_int8(cap, netvlad_dim)
         self.block_bytes = self.BLKB if self.int8 else 4 * self.BLK
         f32, i32, i64 = torch.float32, torch.int32, torch.int64
-        # of a few pool streams the one that takes turns with none of the lanes' streams on the device (d2fe_pipe_classify_stream), else one that only meets a NetVLAD
-        # stream: a stream picked blindly shares a hardware pipe with some lane's SuperPoint stream every other time
-        cands = [torch.cuda.Stream(device=dev) for _ in range(6)]
-        self.stream = cands[pipe.pick_consumer_stream([c.cuda_stream for c in cands])] if hasattr(pipe, "pick_consumer_stream") else cands[0]
+        # a pool stream that takes turns with none of the lanes' SuperPoint streams on the device (d2fe_pipe_classify_stream; candidates one at a time): a stream picked
+        # blindly shares a hardware pipe with some lane's SuperPoint stream every other time
+        mk = lambda: torch.cuda.Stream(device=dev)
+        self.stream = pipe.pick_consumer_stream(mk, handle=lambda s: s.cuda_stream) if hasattr(pipe, "pick_consumer_stream") else mk()
         self.blocks = torch.zeros((F, self.BLK), dtype=f32, device=dev)
         self.gath = torch.zeros((world, F, self.BLK), dtype=f32, device=dev)
         self.gath_i32 = self.gath.view(i32).view(world * F, self.BLK)

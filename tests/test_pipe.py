@@ -271,9 +271,9 @@ def test_pipe_device_view_feeds_a_consumer_stream(coal):
     off = {f: api.block_field_offset(CAP, G, f) for f in ("desc", "kps", "scores", "netvlad", "n")}
     fr = _frames(8)
     pipe = api.StereoPipe(fe, lanes=2, frames=1, width=W, height=H, cap=CAP, netvlad=True, coalesce=coal)
-    # coal == 2: the consumer's stream is the one of six pool streams the pipe ranks best (d2fe_pipe_classify_stream), coal == 1 the first that comes
-    cands = [torch.cuda.Stream(device=dev) for _ in range(6)]
-    X = cands[pipe.pick_consumer_stream([c.cuda_stream for c in cands])] if coal == 2 else cands[0]
+    # coal == 2: the consumer's stream is a pool stream the pipe ranks harmless (d2fe_pipe_classify_stream), coal == 1 the first that comes
+    mk = lambda: torch.cuda.Stream(device=dev)
+    X = pipe.pick_consumer_stream(mk, handle=lambda s: s.cuda_stream) if coal == 2 else mk()
     if coal == 2 and pipe.stream_placement()[1] >= 4:
         assert pipe.classify_stream(X.cuda_stream) not in {a for a, _ in pipe.stream_placement()[0]}       # never beside a lane's SuperPoint stream (2 lanes: two classes are free of those)
     blocks = [torch.zeros((1, BLK), dtype=torch.float32, device=dev) for _ in fr]

@@ -33,7 +33,7 @@ for k in ("configs1", "exact_mode", "fast_mode", "device_resident", "quadcam"):
     if j.get(k): print(" ", k, j[k].get("value"), (j[k].get("roofline") or {}).get("frac"))
 for k in ("step_roofline", "netvlad_width_sensitivity", "exchange", "index_parity_in_run"):
     if j.get(k): print(" ", k, json.dumps(j[k])[:600])
-for p in (j.get("batch_curve") or {}).get("points", []): print("  curve", {k: v for k, v in p.items() if k != "note"})
+for p in (j.get("batch_curve") or {}).get("points", []): print("  curve", {k: v for k, v in p.items() if k not in ("note", "host_ms_per_submit_call", "ms_per_submit")})
 if j.get("stage_ms"): print("  stage_ms", j["stage_ms"])
 if j.get("hbm_kernels"): print("  hbm", json.dumps({k: (v or {}).get("ms_per_launch") for k, v in j["hbm_kernels"].items()}))
 if j.get("parity"): print("  parity", {k: v for k, v in j["parity"].items() if k != "note"})
