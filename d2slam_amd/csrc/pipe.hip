@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -211,7 +212,7 @@ int place_streams(int device_id, int n_first, int n_second, std::vector<hipStrea
       const int n = (int)v.size();
       std::sort(v.begin(), v.end());
       const int distinct = (int)(std::unique(v.begin(), v.end()) - v.begin());
-      return std::max(0, std::min(n, ncls) - distinct);
+      return std::max(0, std::min(n, std::max(ncls, 4)) - distinct);      // (four hardware pipes are there even when fewer classes have shown up so far)
     };
     int bad = 0;
     if (n_second) {
@@ -227,13 +228,20 @@ int place_streams(int device_id, int n_first, int n_second, std::vector<hipStrea
     int bad = deal(cls, (int)rep.size());
     // (up to sixteen: a process that already holds every hardware queue of its pool gets new streams on the least-shared queues first, and those may all sit on three of
     // the four pipes -- measured in bench.py after its other legs: twelve candidates, three classes; creating them costs such a process no further queue)
-    for (int extra = 0; bad > 0 && extra < 16 && ok && quiet; ++extra) {
+    for (int extra = 0, stale = 0; bad > 0 && extra < 16 && stale < 6 && ok && quiet; ++extra) {      // (six spares in a row that change nothing: that is all there is)
       if (!add_candidate()) break;
       classify((int)cand.size() - 1);
+      const int was = bad;
       if (ok && quiet) bad = deal(cls, (int)rep.size());
+      stale = bad < was ? 0 : stale + 1;
     }
     measured = ok && quiet;
     (void)hipGetLastError();
+  }
+  if (d2fe_dev_env("D2FE_PIPE_PLACEMENT", 1) == 2) {      // development library: the classes in creation order
+    fprintf(stderr, "[d2fe] place_streams need %d candidates %zu classes %zu measured %d:", need, cand.size(), rep.size(), (int)measured);
+    for (int c : cls) fprintf(stderr, " %d", c);
+    fprintf(stderr, "\n");
   }
   if (!measured) {      // creation order of the first `need` candidates
     cls.assign(cand.size(), 0);

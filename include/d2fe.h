@@ -264,8 +264,7 @@ typedef struct {
                                (hardware queue i is served by hardware pipe i mod 4) and makes a fifth take turns.  Single-frame passes on a 4-lane pipe, auto:
                                1390 / 1838 / 1789 / 2044 stereo frames/s with 1 / 2 / 3 / 4 passes in flight; forced second streams: 1627 with 4
                                (profiles/r05_pipe_one_frame.txt (8)).  d2fe_pipe_create measures which streams share a hardware pipe and gives a lane two streams of
-                               different pipes (d2fe_pipe_stream_placement); this needs GPU_MAX_HW_QUEUES >= 8 in the process environment (16 recommended; the
-                               runtime's default of 4 makes streams share queues).
+                               different pipes (d2fe_pipe_stream_placement); create the pipe on a quiet device.
                                Results are the same bits in every mode */
   int32_t coalesce;         /* > 1 (needs frames == 1): up to this many consecutive submits run as ONE launch sequence when they are submitted before
                                anybody waits for them -- submit() stages the frame (its H2D starts at once) and the pass is launched when it is full
@@ -302,7 +301,7 @@ D2FE_API void d2fe_pipe_destroy(d2fe_pipe p);
 D2FE_API int d2fe_pipe_lanes(d2fe_pipe p);
 /* How d2fe_pipe_create placed the lanes' streams: it measures which of its candidate streams take turns on the device (streams of one hardware pipe) and gives every
  * lane two streams of different pipes.  classes[2 k] / classes[2 k + 1] = the class of lane k's own / second stream (-1: no such stream, or CU-masked lanes),
- * *n_classes = the classes told apart (4 on an idle MI355X with GPU_MAX_HW_QUEUES >= 8; 0: the measurement was inconclusive and creation order was used) */
+ * *n_classes = the classes told apart (4 on an idle MI355X; 0: the device was not quiet or nothing could be told apart -- the arrangement of a fresh process was used) */
 D2FE_API int d2fe_pipe_stream_placement(d2fe_pipe p, int32_t* classes /*[2 * lanes]*/, int32_t* n_classes);
 /* d2fe_profile_enable / d2fe_profile_read over all lanes (sums) */
 D2FE_API int d2fe_pipe_profile_enable(d2fe_pipe p, int mode);
