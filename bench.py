@@ -2,7 +2,7 @@
 """bench.py -- BASELINE.json's metric on MI355X: stereo frames/s for SuperPoint + NetVLAD + match at 640x480.
 
 Workload of `value` (the metric's configuration), EVERY --gpus N: one step = F stereo frames (u8, 640x480) through the frames-in-flight pipe of the C ABI
-(include/d2fe.h, d2fe_pipe_submit / d2fe_pipe_wait) with 2 submits in flight -- pinned HOST frames in, HOST results out, inside the timed region:
+(include/d2fe.h, d2fe_pipe_submit / d2fe_pipe_wait) with 4 submits in flight -- pinned HOST frames in, HOST results out, inside the timed region:
   H2D of the 2F frames,
   SuperPoint on the 2F images (200 keypoints, variant-B post-processing: the live TensorRT path of the reference),
   NetVLAD global descriptor of the F left images (loop_cam.cpp:446-451: left image SP+NetVLAD, right image SP only),
@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 # streams that share a queue serialise.  Must be set before the HIP runtime initialises; recorded in the JSON line (`env_overrides`).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 # lanes in flight per frames-per-submit for the batch curve (measured: tools/pipe_probe.py; more lanes than this do not pay)
-LANES_FOR = {1: 4, 2: 4, 4: 4, 8: 4, 16: 2, 32: 2}
+LANES_FOR = {1: 4, 2: 4, 4: 4, 8: 4, 16: 4, 32: 4}
 REFUSED_ENV = ("D2FE_ABLATE", "D2FE_MATCH_NOFALLBACK")     # switches that make results wrong or parity unproven: never inside a benchmark
 
 H, W, CAP = 480, 640, 200

@@ -25,7 +25,8 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    H, W, CAP, F, STEPS, LANES = 120, 160, 60, 2, 5, 2
+    LANES = int(os.environ.get("PIPE_XCHG_LANES", "2"))          # 4: what bench.py --gpus N runs (netvlad_inline = auto then chooses NetVLAD's stream per pass)
+    H, W, CAP, F, STEPS = 120, 160, 60, 2, 5 if LANES <= 2 else 11
     w = synthetic_superpoint_weights(dustbin_bias=7.5)
     nv = nvm.synthetic_netvlad_weights()
 

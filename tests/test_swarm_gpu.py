@@ -37,12 +37,13 @@ def test_world2_cross_agent_matches_equal_oracle():
     assert r.stdout.count(" OK: ") == 2, r.stdout[-2000:]
 
 
-@pytest.mark.parametrize("mode", ["fp32", "int8", "int8-renorm256"])
+@pytest.mark.parametrize("mode", ["fp32", "int8", "int8-renorm256", "fp32-4lanes"])
 def test_world2_exchange_behind_the_pipe_equals_oracle(mode):
     """The path `bench.py --gpus N` times (round 5): every rank's frames-in-flight pipe with swarm.PipeExchange on a stream of its own one submit behind it
     (d2fe_pipe_device_view -> pack -> all-gather -> gate -> remote matchKNN -> d2fe_pipe_device_release -> D2H): cross-agent match lists and gate decisions against
     the oracle per submit, the pipe's own results bit-identical with and without the exchange beside it."""
-    r = _torchrun([os.path.join(ROOT, "tests", "helpers", "pipe_exchange_worker.py")], {"PIPE_XCHG_MODE": mode})
+    lanes = "4" if mode.endswith("-4lanes") else "2"
+    r = _torchrun([os.path.join(ROOT, "tests", "helpers", "pipe_exchange_worker.py")], {"PIPE_XCHG_MODE": mode.replace("-4lanes", ""), "PIPE_XCHG_LANES": lanes})
     assert r.returncode == 0, _rank_errors(r)
     assert r.stdout.count(" OK: ") == 2, r.stdout[-2000:]
 
