@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "context.h"
+#include "stream_deal.h"
 
 using namespace d2fe;
 
@@ -170,60 +171,8 @@ int place_streams(int device_id, int n_first, int n_second, std::vector<hipStrea
   }
   bool measured = ok && quiet && rep.size() >= 2 && (int)cls.size() == need;
   std::vector<int> pick_first, pick_second;
-  // lane k: its own stream from class k mod n, its second stream half the classes further on (two of four), so that the four streams of two consecutive lanes sit in four
-  // classes -- as far as the streams at hand allow: a class that has run out is replaced by the one that meets the fewest of the neighbouring lanes' streams.  Returns how
-  // far the deal is from that: streams of one class within a lane's pair, or within two consecutive lanes' streams (beyond what n < 4 classes force)
-  auto deal = [&](const std::vector<int>& cl, int ncls) {
-    const int NC = (int)cand.size();
-    std::vector<char> used((size_t)NC, 0);
-    auto take = [&](int want, const std::vector<int>& avoid) -> int {
-      std::vector<int> left((size_t)ncls, 0);
-      for (int c = 0; c < NC; ++c) if (!used[c]) ++left[cl[c]];
-      int cls_pick = -1;
-      if (left[want] > 0) cls_pick = want;
-      else {
-        long best_score = -1;
-        for (int k = 0; k < ncls; ++k) {
-          if (!left[k]) continue;
-          int meets = 0;
-          for (int a : avoid) meets += a == k;
-          const long score = (long)(16 - meets) * 1024 + left[k];        // fewest neighbours first, then the class with the most streams left
-          if (score > best_score) { best_score = score; cls_pick = k; }
-        }
-      }
-      for (int c = 0; c < NC; ++c) if (!used[c] && cl[c] == cls_pick) { used[c] = 1; return c; }
-      return -1;      // not reached: the pipe never asks for more streams than there are candidates
-    };
-    pick_first.clear(); pick_second.clear();
-    std::vector<int> fc, sc;
-    for (int k = 0; k < n_first; ++k) {
-      std::vector<int> avoid;
-      if (k > 0) avoid.push_back(fc[k - 1]);
-      if (k + 1 == n_first && n_first > 2) avoid.push_back(fc[0]);
-      pick_first.push_back(take(k % ncls, avoid)); fc.push_back(cl[pick_first.back()]);
-    }
-    for (int k = 0; k < n_second; ++k) {
-      std::vector<int> avoid = {fc[k], fc[(k + 1) % n_first], fc[(k + n_first - 1) % n_first]};
-      if (k > 0) avoid.push_back(sc[k - 1]);
-      if (k + 1 == n_second && n_second > 2) avoid.push_back(sc[0]);
-      pick_second.push_back(take((k + (ncls + 1) / 2) % ncls, avoid)); sc.push_back(cl[pick_second.back()]);
-    }
-    auto clashes = [&](std::vector<int> v) {       // streams beyond the first of every class, less what fewer classes than streams force
-      const int n = (int)v.size();
-      std::sort(v.begin(), v.end());
-      const int distinct = (int)(std::unique(v.begin(), v.end()) - v.begin());
-      return std::max(0, std::min(n, std::max(ncls, 4)) - distinct);      // (four hardware pipes are there even when fewer classes have shown up so far)
-    };
-    int bad = 0;
-    if (n_second) {
-      if (n_first == 1) bad += clashes({fc[0], sc[0]});
-      // pairs of consecutive lanes; the pair (last, first) only where the pattern closes (a multiple of four lanes)
-      for (int k = 0; k + 1 < n_first || (k + 1 == n_first && n_first > 2 && n_first % 4 == 0); ++k) { const int m = (k + 1) % n_first; bad += clashes({fc[k], sc[k], fc[m], sc[m]}); }
-    } else {
-      for (int k = 0; k < n_first; k += 4) bad += clashes(std::vector<int>(fc.begin() + k, fc.begin() + std::min(k + 4, n_first)));      // blocks of four lanes
-    }
-    return bad;
-  };
+  // (stream_deal.h: lane k's own stream from class k mod n, its second stream two classes further on, as far as the streams at hand allow; returns how far from that)
+  auto deal = [&](const std::vector<int>& cl, int ncls) { return deal_streams(cl, ncls, n_first, n_second, pick_first, pick_second); };
   if (measured) {
     int bad = deal(cls, (int)rep.size());
     // (up to sixteen: a process that already holds every hardware queue of its pool gets new streams on the least-shared queues first, and those may all sit on three of
