@@ -381,8 +381,7 @@ static int create_context(const d2fe_config* cfg, d2fe_handle* out, bool lane, h
   // conv1a is evaluated inside conv1b's staging in every mode (the Winograd kernel runs it on the matrix pipe): the 78.6 MB/image
   // activation never exists.  D2FE_FUSE1A=0 falls back to a stand-alone conv1a kernel (bit-identical; kept for A/B measurements).
   h->fuse1a = d2fe_dev_env("D2FE_FUSE1A", 1) != 0;
-    // (a lane that is handed its stream does not create one first: every stream ever created costs the process a hardware queue, and two processes of one GPU that
-    // hold more queues than the device has slots are time-sliced against each other)
+    // (a lane that is handed its stream does not create one first: no stream is created that is not needed, see place_streams in pipe.hip)
     if (adopt) h->stream = adopt; else HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     const size_t H = cfg->max_height, W = cfg->max_width;
     const int B = cfg->max_batch;

@@ -96,9 +96,9 @@ int pipe_fail(int code, const std::string& msg) { return ctx_fail(code, msg); }
 // ---- stream placement by measurement ---------------------------------------------------------------------------------------------------------
 // The device runs the busy streams of a process side by side only when they sit on different hardware pipes (four of them); two busy streams on one pipe take turns
 // (profiles/r05_pipe_one_frame.txt (8): a lone single-frame pass whose SuperPoint and NetVLAD streams shared a pipe ran at 873 stereo frames/s instead of 1400).  Which pipe a
-// stream gets is the runtime's business (hardware queues are handed out from a pool that earlier streams of the process have used and returned), so it is MEASURED: a few
-// more candidate streams than needed are created, chains of short dependent spin launches are timed on pairs of them, candidates whose chains take turns are one class,
-// and the lanes then take their streams from the classes so that a lane's two streams -- and the streams of consecutive lanes -- are in different ones.
+// stream gets is the runtime's business (hardware queues are handed out from a pool that earlier streams of the process have used and returned), so it is MEASURED: chains
+// of short dependent spin launches are timed on pairs of the candidate streams, candidates whose chains take turns are one class, and the lanes then take their streams
+// from the classes so that a lane's two streams -- and the streams of consecutive lanes -- are in different ones (stream_deal.h).
 __global__ void pipe_spin_kernel(long long ticks) {
   const long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
@@ -126,9 +126,10 @@ int place_streams(int device_id, int n_first, int n_second, std::vector<hipStrea
   first.assign((size_t)n_first, nullptr); second.assign((size_t)n_second, nullptr);
   first_class.assign((size_t)n_first, -1); second_class.assign((size_t)n_second, -1);
   *n_classes = 0;
-  // Exactly the streams the pipe needs to begin with: every stream ever created costs the process a hardware queue (the runtime keeps it when the stream is destroyed), and
-  // two processes of one GPU that together hold more queues than the device has slots are time-sliced against each other (two ranks on one GPU, each pipe with four spare
-  // candidates: 36-71 instead of 26 ms per step).  A spare is only created while the streams at hand cannot be dealt out as wanted (never in a fresh process).
+  // Exactly the streams the pipe needs to begin with.  A version with four spare candidates per pipe (and lanes that created and destroyed a stream of their own before
+  // adopting one) measured the same in one process, but two ranks sharing ONE GPU went from 26 to 36-71 ms per step (bisected, profiles/r05_pipe_one_frame.txt (8g)) --
+  // consistent with the two processes' hardware queues no longer fitting the device's queue slots.  So a spare is only created while the streams at hand cannot be dealt
+  // out as wanted (never in a fresh process).
   std::vector<hipStream_t> cand;
   auto drop = [&](int rc) { for (auto c : cand) if (c) (void)hipStreamDestroy(c); first.assign(first.size(), nullptr); second.assign(second.size(), nullptr); return rc; };
   auto add_candidate = [&]() { hipStream_t q = nullptr; if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) return false; cand.push_back(q); return true; };
