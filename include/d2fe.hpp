@@ -230,6 +230,17 @@ class StereoPipe {
     matches(r.prev_q, r.prev_t, r.prev_dist, r.prev_n, out.left_prev);
     return true;
   }
+  // d2fe_pipe_stream_placement: the hardware-pipe class measured for every lane's (own, second) stream; the return value = classes told apart (0: not measured)
+  int streamPlacement(std::vector<std::pair<int, int>>& lanes) const {
+    lanes.clear();
+    if (!p_) return 0;
+    const int K = d2fe_pipe_lanes(p_);
+    std::vector<int32_t> c((size_t)2 * (K > 0 ? K : 0));
+    int32_t n = 0;
+    if (K <= 0 || d2fe_pipe_stream_placement(p_, c.data(), &n) != D2FE_OK) return 0;
+    for (int k = 0; k < K; ++k) lanes.emplace_back(c[2 * k], c[2 * k + 1]);
+    return n;
+  }
 
  private:
   d2fe_pipe p_ = nullptr;

@@ -110,6 +110,12 @@ int main(int argc, char** argv) {
     pc.lanes = 3; pc.width = W; pc.height = H; pc.cap = maxkp; pc.netvlad = 0; pc.match_lr = 1; pc.match_prev = 1; pc.ratio = 0.8; pc.coalesce = 2; pc.coalesce_depth = 1;
     StereoPipe pipe(sp.handle(), pc);
     if (!pipe.ok()) return 6;
+    {       // every lane's two streams sit in different hardware-pipe classes when the placement could be measured (pc.netvlad = 0 here: no second streams, class -1)
+      std::vector<std::pair<int, int>> pl;
+      const int ncl = pipe.streamPlacement(pl);
+      if ((int)pl.size() != pc.lanes || ncl < 0 || ncl > 8) return 6;
+      for (auto& q : pl) if (q.second != -1 || (ncl >= 2 && (q.first < 0 || q.first >= ncl))) return 6;
+    }
     const uint8_t* L[4] = {img0.data(), img1.data(), img0.data(), img1.data()};
     const uint8_t* R[4] = {img1.data(), img0.data(), img1.data(), img0.data()};
     int64_t t[4];
