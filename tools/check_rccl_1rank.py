@@ -38,7 +38,7 @@ import numpy as np  # noqa: E402
 from d2slam_amd import api, netvlad as nvm  # noqa: E402
 from d2slam_amd.synth import synth_stereo  # noqa: E402
 from d2slam_amd.weights import synthetic_superpoint_weights  # noqa: E402
-H, W, CAP, FR, LANES = 120, 160, 60, 2, 2
+H, W, CAP, FR, LANES = 120, 160, 60, 2, int(os.environ.get("D2FE_RCCL_CHECK_LANES", "2"))
 STEPS = int(os.environ.get("D2FE_RCCL_CHECK_STEPS", "5"))      # e.g. 4000: a soak of the view / release hand-over between the lanes and the exchange stream
 fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2 * FR, precision=api.PREC_F32_WINO))
 fe.load_superpoint(synthetic_superpoint_weights(dustbin_bias=7.5)); fe.load_netvlad(nvm.synthetic_netvlad_weights())
