@@ -168,3 +168,41 @@ def test_quad_swarm_pairs_world2():
                     assert ncnt[i] == 1 + (rv * Q + qq) % cap
                     i += 1
         assert i == 32
+
+
+def test_pick_consumer_stream_ranks_candidates_without_a_gpu():
+    """StereoPipe.pick_consumer_stream (the exchange's choice of ITS stream, d2slam_amd/swarm.py: PipeExchange): candidates are created one at a time and the first
+    that takes turns with none of the lanes' streams -- or only with second (NetVLAD) streams -- is taken; after `tries` candidates the best seen; with no measured
+    placement the first.  The pipe's two C calls are replaced by a table here (the measurement itself: tests/test_pipe.py on the GPU)."""
+    from d2slam_amd import api
+
+    class Fake(api.StereoPipe):
+        def __init__(self, placement, n, classes):
+            self._placement, self._n, self._classes, self.made, self.asked = placement, n, classes, 0, []
+
+        def stream_placement(self):
+            return self._placement, self._n
+
+        def classify_stream(self, st):
+            self.asked.append(st)
+            return self._classes[st]
+
+        def __del__(self):
+            pass
+
+    def run(placement, n, classes, tries=4):
+        p = Fake(placement, n, classes)
+
+        def make():
+            p.made += 1
+            return p.made - 1
+        return p.pick_consumer_stream(make, tries=tries), p.made
+
+    two = [(0, 2), (1, 3)]                                   # two lanes: classes 0 / 1 carry SuperPoint streams, 2 / 3 only NetVLAD streams
+    assert run(two, 4, {0: 2}) == (0, 1)                     # first candidate beside a NetVLAD stream: taken at once
+    assert run(two, 4, {0: 0, 1: 1, 2: 3}) == (2, 3)         # two candidates beside SuperPoint streams are passed over
+    assert run(two, 4, {0: 0, 1: -1}) == (1, 2)              # a class no lane uses beats everything
+    assert run(two, 4, {0: 1, 1: 0, 2: 1, 3: 0}) == (0, 4)   # nothing better within four tries: the first of the best rank
+    four = [(0, 2), (1, 3), (2, 0), (3, 1)]                  # four lanes: every class carries a SuperPoint stream
+    assert run(four, 4, {0: 2, 1: 3, 2: 0, 3: 1}) == (0, 4)
+    assert run(two, 0, {}) == (0, 1)                         # no measured placement: the first candidate, nothing asked
