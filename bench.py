@@ -33,6 +33,10 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 # lanes in flight per frames-per-submit for the batch curve (measured: tools/pipe_probe.py; more lanes than this do not pay)
 LANES_FOR = {1: 4, 2: 4, 4: 4, 8: 4, 16: 4, 32: 4}
+# ... and with the cross-agent exchange beside the lanes (--gpus N > 1, and the one-GPU RCCL leg): the device runs four busy streams side by side, so two lanes (SuperPoint
+# and NetVLAD stream each) leave the exchange stream a hardware pipe it shares with a NetVLAD stream only: 2445-2453 stereo frames/s per rank with the exchange against
+# 2416-2425 with three or four lanes, where it takes turns with a lane's SuperPoint stream (measured over one-rank RCCL)
+LANES_WITH_EXCHANGE = {16: 2, 32: 2}
 REFUSED_ENV = ("D2FE_ABLATE", "D2FE_MATCH_NOFALLBACK")     # switches that make results wrong or parity unproven: never inside a benchmark
 
 H, W, CAP = 480, 640, 200
@@ -290,8 +294,9 @@ def main():
     parity_in_run = None
     exch_1gpu = None
     # EVERY --gpus N times the frames-in-flight pipe (include/d2fe.h, d2fe_pipe_*): host frames in, host results out, `lanes` submits in flight.  N > 1 adds the
-    # cross-agent exchange on a stream of its own beside it (run_pipe / swarm.PipeExchange); nothing else differs between `--gpus 1` and `--gpus 8`
-    lanes = args.lanes or LANES_FOR.get(args.frames, 2)
+    # cross-agent exchange on a stream of its own beside it (run_pipe / swarm.PipeExchange) and keeps two submits in flight instead of four (LANES_WITH_EXCHANGE: the
+    # exchange stream then has a hardware pipe it shares with a NetVLAD stream only); nothing else differs between `--gpus 1` and `--gpus 8`
+    lanes = args.lanes or (LANES_FOR.get(args.frames, 2) if world == 1 else LANES_WITH_EXCHANGE.get(args.frames, LANES_FOR.get(args.frames, 2)))
     xmode = args.exchange if world > 1 else None
     pk = dict(world=world, dist=dist, exchange=xmode)
     primary = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, args.steps, args.warmup, local_rank, rank, netvlad=use_nv, **pk)
@@ -421,7 +426,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.single_mode and not args.no_exchange_loopback:
         # LAST leg of the run: it creates (and destroys) a one-rank RCCL communicator, whose proxy threads and streams must not sit beside any other measurement
-        exch_1gpu = exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, lanes, short, local_rank, rank, use_nv, dev)
+        exch_1gpu = exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, args.lanes or LANES_WITH_EXCHANGE.get(args.frames, lanes), short, local_rank, rank, use_nv, dev)
 
     if rank == 0:
         value, ms_per_step = primary["value"], primary["ms_per_step"]
@@ -653,7 +658,7 @@ def exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, lanes, step
             wo = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, steps, 2, local_rank, rank, netvlad=use_nv, light=True)
             runs.append((w, wo))
         w = min((r[0] for r in runs), key=lambda r: r["ms_per_step"]); wo = min((r[1] for r in runs), key=lambda r: r["ms_per_step"])
-        return {"backend": dist.get_backend(), "what": "the value step (%d stereo frames per submit, %d submits in flight) with the cross-agent exchange of `--gpus N` on its own stream over a ONE-rank "
+        return {"backend": dist.get_backend(), "what": "the step `--gpus N` runs on every rank (%d stereo frames per submit, %d submits in flight: LANES_WITH_EXCHANGE) with the cross-agent exchange on its own stream over a ONE-rank "
                            "RCCL communicator (loopback: the rank's own blocks as the remote agent, %d cross-agent pairs per submit), against the same step without it; best of two "
                            "alternating runs each" % (args.frames, lanes, w["exch"]["cross_agent_pairs_per_step_per_gpu"]),
                 "value_with_exchange": round(w["value"], 2), "value_without_exchange": round(wo["value"], 2), "ms_per_step_with_exchange": round(w["ms_per_step"], 3),
