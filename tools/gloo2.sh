@@ -3,8 +3,8 @@
 cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 TAG=$1; shift
 O=gpurun_out/run; mkdir -p $O
-# --lanes 2: the two ranks SHARE the device here, so each keeps two submits in flight (four on the device, as one rank alone would); with bench.py's default of four per rank the
-# two processes hold more hardware queues than the device has slots and are time-sliced against each other (44 instead of 26 ms per step, with or without the exchange)
+# --lanes 2 (also bench.py's own choice for --gpus N > 1, LANES_WITH_EXCHANGE; stated because it matters twice here): the two ranks SHARE the device, so each keeps two submits
+# in flight (four on the device, as one rank alone would); with four per rank the two processes measured 44 instead of 26 ms per step, with or without the exchange
 D2FE_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --lanes 2 --single-mode --no-cpu-baseline "$@" > $O/bench_gpus2_$TAG.json 2> $O/bench_gpus2_$TAG.err
 grep -v "amdgpu\|socket" $O/bench_gpus2_$TAG.err | tail -3
 python - $O/bench_gpus2_$TAG.json <<'PY'
