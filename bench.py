@@ -461,7 +461,8 @@ def main():
                        "stream_placement": dict(primary.get("stream_placement") or {}, what="d2fe_pipe_stream_placement of the timed pipe: the hardware-pipe class d2fe_pipe_create MEASURED "
                                                 "for each lane's (own, second) stream; streams of one class take turns on the device; classes_told_apart 0 = the device was not quiet "
                                                 "when the pipe was created (e.g. two ranks sharing one GPU) and creation order was used"),
-                       "netvlad_overlaps_superpoint": "NetVLAD runs on the lane's second stream beside SuperPoint",
+                       "netvlad_overlaps_superpoint": "d2fe_pipe_config.netvlad_inline = auto: a pass's NetVLAD call runs on the lane's second stream beside its SuperPoint while at most one other pass is in "
+                                                      "flight (always with one or two lanes), in front of its SuperPoint on the lane's own stream beyond that -- beside the OTHER lanes' work",
                        "max_keypoints": CAP, "postproc": "B",
                        "precision": args.precision, "netvlad": use_nv,
                        "weights": "seeded random-init SuperPoint / MobileNetVLAD stand-in (no checkpoints in the reference tree)"},
