@@ -489,11 +489,12 @@ def main():
             if live:
                 out["roofline"]["traffic"] = live["traffic"]; out["roofline"]["traffic_note"] = live["note"]; out["roofline"]["traffic_counters"] = live["counters"]
         if device_resident and device_resident.get("roofline_nv"):
-            # NetVLAD by itself on the device (the device-API leg queues it in front of SuperPoint on one stream); in the pipe it runs on the lane's second
-            # stream underneath SuperPoint's full-device launches, where its wall time is SuperPoint's
+            # NetVLAD by itself on the device (the device-API leg queues it in front of SuperPoint on one stream); in the pipe it runs beside the lanes'
+            # full-device launches, where its wall time is mostly waiting for compute units
             out["roofline_netvlad"] = dict(device_resident["roofline_nv"], measured="the device-API leg of this run (`device_resident`): the sequence alone on its stream",
                                            in_timed_region_of_value={"ms_per_call": (primary.get("roofline_nv") or {}).get("ms_per_call"),
-                                                                     "note": "beside SuperPoint on the lane's second stream: hidden under it"})
+                                                                     "note": "wall time of the sequence inside the running pipe (beside or in front of its lane's SuperPoint, the other lanes' "
+                                                                             "full-device launches on the chip): waits for compute units included"})
         flag_above_peak(out["roofline"])
         if world == 1 and SP_FLOP_PER_IMG * 2 * value / 1e12 > PEAK_TFLOPS[args.precision] and args.precision == "wino":
             out["sp_tflops_algorithmic_note"] = ("algorithmic (direct-convolution) FLOPs of SURVEY.md section 8(a) per second: above the %.1f TF fp32-MFMA peak because the "
@@ -810,8 +811,9 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
         res["roofline"] = conv1b_roofline(precision, c1b_ms / max(c1b_n, 1), c1b_n, NI, True)
         nv_ms, nv_n = prof["netvlad"]
         if netvlad and nv_n:
-            res["roofline_nv"] = netvlad_roofline(nv_ms / nv_n, F, "HIP events around the whole sequence on the lane's NetVLAD stream, which runs BESIDE that lane's SuperPoint launches "
-                                                  "(the figure includes what the two sequences cost each other)", nv_flop_per_img)
+            res["roofline_nv"] = netvlad_roofline(nv_ms / nv_n, F, "HIP events around the whole sequence where the pipe queued it (netvlad_inline = auto: the lane's second stream beside that lane's SuperPoint, or the "
+                                                  "lane's own stream in front of it), with the other lanes' full-device launches on the chip: the figure is the sequence's WALL time in the "
+                                                  "running pipe (waits for compute units included), not its cost -- that is `roofline_netvlad` of the full line (the sequence alone)", nv_flop_per_img)
     pl, ncl = pipe.stream_placement()
     res["stream_placement"] = {"classes_told_apart": ncl, "lanes": pl, "exchange_stream_class": None}
     if xch:
