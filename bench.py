@@ -46,8 +46,121 @@ NV_FLOP_PER_IMG = 0.6626e9                                # the stand-in MobileN
 PEAK_TFLOPS = {"f32": 157.3, "f16x2": 2500.0, "wino": 157.3}             # MI355X_MICROARCH.md: fp32 MFMA / dense f16 MFMA
 NETVLAD_GATE = 0.8                                        # track_remote_netvlad_thres stand-in (the YAMLs carry 0.5..0.8)
 
+# ---- the stdout contract: ONE JSON line, the LAST thing on stdout, on every rank, small enough to survive a tail ------------------------------------------------------
+# RCCL prints its version banner through C stdio, which on a pipe or file is flushed at process exit -- behind anything Python printed (round 5's line was lost to that).
+# So (i) fd 1 is pointed at stderr for the whole run (the banner, torch, rocprofv3 children, stray prints land there), the JSON line goes to the saved descriptor;
+# (ii) before the line is written every C stream is flushed (a driver that merges stderr into stdout still sees the banner BEFORE the line); (iii) after the line fds 1 and 2
+# of this process go to /dev/null: nothing can follow it.  Ranks other than 0 never own stdout at all.
+_REAL_STDOUT = None
+LINE_BUDGET = 6000                  # bytes; the driver keeps an 8 KB tail
+HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                 "roofline", "cpu_baseline", "step_roofline", "parity", "roofline_netvlad", "rccl", "exchange", "netvlad_gate", "cross_agent", "extras")
+# dropped from the line (kept in the extras file) in this order while the line is above LINE_BUDGET
+SHED_ORDER = ("cross_agent", "netvlad_gate", "exchange", "roofline_netvlad", "rccl")
+
+
+def claim_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def silence_this_process():
+    """fds 1 and 2 -> /dev/null (after flushing every C and Python stream): whatever this process still prints (exit-time banners, teardown warnings) goes nowhere"""
+    import ctypes
+    try:
+        sys.stdout.flush(); sys.stderr.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:      # noqa: BLE001
+        pass
+    nul = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(nul, 1); os.dup2(nul, 2)
+
+
+def emit_line(obj):
+    """the JSON line: everything buffered so far is flushed first, the line is written to the process's ORIGINAL stdout in one piece, then the process goes silent"""
+    global _REAL_STDOUT
+    import ctypes
+    data = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush(); sys.stderr.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:      # noqa: BLE001
+        pass
+    fd = _REAL_STDOUT if _REAL_STDOUT is not None else 1
+    while data:
+        n = os.write(fd, data)
+        data = data[n:]
+    silence_this_process()
+    if _REAL_STDOUT is not None:
+        os.close(_REAL_STDOUT)
+        _REAL_STDOUT = None
+
+
+def slim(o, maxlen=150, keep=("workload", "sample", "kernel", "api")):
+    """the headline form of a (nested) record: prose longer than `maxlen` characters lives in the extras file; the strings a reader needs to identify the
+    workload stay, cut to 320 characters"""
+    if isinstance(o, dict):
+        out = {}
+        for k, v in o.items():
+            if isinstance(v, str) and len(v) > maxlen:
+                if k in keep:
+                    out[k] = v if len(v) <= 320 else v[:317] + "..."
+                continue
+            out[k] = slim(v, maxlen, keep)
+        return out
+    if isinstance(o, list):
+        return [slim(v, maxlen, keep) for v in o]
+    return o
+
+
+def extras_path():
+    p = os.environ.get("D2FE_BENCH_EXTRAS")
+    if p:
+        return p
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        return os.path.join(d, "bench_extras.json")
+    except OSError:
+        import tempfile
+        return os.path.join(tempfile.gettempdir(), "d2fe_bench_extras.json")
+
+
+def headline(full):
+    """(line, path): the full record goes to the extras file (named in the line), the line keeps HEADLINE_KEYS in slim form and fits LINE_BUDGET"""
+    path = extras_path()
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        rel = os.path.relpath(path, ROOT)
+        named = rel if not rel.startswith("..") else path
+    except OSError as e:
+        named = "not written: %s" % str(e)[:80]
+    always = ("vs_baseline", "cpu_baseline", "roofline")          # present (null when this run has none) in every line
+    line = {k: slim(full.get(k)) for k in HEADLINE_KEYS if k in always or full.get(k) is not None}
+    cb = line.get("cpu_baseline")
+    if isinstance(cb, dict):          # the per-stage tables and the fmaf-chain extra stay in the file
+        cb = {k: ({a: b for a, b in v.items() if a != "ms_per_stereo_frame"} if isinstance(v, dict) else v) for k, v in cb.items() if k != "fmaf_oracle"}
+        line["cpu_baseline"] = dict(cb, per_stage="extras file: cpu_baseline.{all_cores,single_thread}.ms_per_stereo_frame")
+    line["extras"] = {"file": named, "keys": sorted(k for k in full if k not in line)}
+    if isinstance(line.get("rccl"), dict) and len(line["rccl"].get("ranks") or []) > 2:
+        line["rccl"] = dict(line["rccl"], ranks="%d entries in the extras file" % len(line["rccl"]["ranks"]))
+    for k in SHED_ORDER:
+        if len(json.dumps(line)) <= LINE_BUDGET:
+            break
+        if k in line:
+            del line[k]
+            line["extras"]["keys"] = sorted(line["extras"]["keys"] + [k])
+    if len(json.dumps(line)) > LINE_BUDGET:
+        line["extras"]["keys"] = "see the file"
+    return line, path
+
 
 def main():
+    claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -60,7 +173,6 @@ def main():
     ap.add_argument("--no-batch-curve", action="store_true", help="skip the batch curve (stereo fps at 1, 2, 4, 8, 16, 32 stereo frames per submit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic (HBM bytes per conv1b launch)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-netvlad", action="store_true", help="time BASELINE configs[1] (SuperPoint + match only) as `value`")
     ap.add_argument("--no-h2d", action="store_true", help="frames resident in HBM before the timed region (no copy stream)")
     ap.add_argument("--workload", choices=["d435", "quadcam"], default="d435",
@@ -85,15 +197,33 @@ def main():
     ap.add_argument("--no-parity-study", action="store_true", help="skip the in-run 128-image index-parity study (`index_parity_in_run`)")
     ap.add_argument("--no-solo", action="store_true", help="with --single-mode: skip the extra leg with ONE submit in flight that measures the dominant kernel alone")
     ap.add_argument("--latency-only", action="store_true", help="print only the single-call latency leg, in a process that does nothing but call the C ABI")
+    ap.add_argument("--cpu-baseline-only", choices=["all_cores", "single_thread"], default=None,
+                    help="print only that half of `cpu_baseline` (SURVEY.md section 8d protocol: warm-up 5, >= 50 timed iterations, median + p95); the default run starts both as "
+                         "child processes beside its secondary GPU legs")
+    ap.add_argument("--cpu-iterations", type=int, default=50, help="timed iterations of each cpu_baseline half (SURVEY.md section 8d: >= 50)")
+    ap.add_argument("--force-dist", action="store_true", default=bool(int(os.environ.get("D2FE_BENCH_FORCE_DIST", "0") or 0)),
+                    help="send --gpus 1 through the path --gpus 8 takes: self-launch under torch.distributed.run, init_process_group('nccl', device_id=...), the "
+                         "collective evidence, the cross-agent exchange behind the pipe over the one-rank communicator (loopback: the rank's own blocks as the remote "
+                         "agent), the N > 1 lane count, destroy_process_group")
     args = ap.parse_args()
     for k in REFUSED_ENV:
         if os.environ.get(k):
             raise SystemExit("%s is set: that switch changes what the kernels compute; bench.py refuses to time it" % k)
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         # a bare `python bench.py --gpus N`: re-launch this command line as N ranks (one process per GPU) under torch.distributed.run;
-        # rank 0's JSON line passes through on stdout and the exit code is the launcher's
-        raise SystemExit(self_launch(args.gpus))
+        # rank 0's JSON line passes through on (the original) stdout and the exit code is the launcher's
+        rc = self_launch(args.gpus)
+        silence_this_process()
+        raise SystemExit(rc)
+
+    if args.cpu_baseline_only:
+        from d2slam_amd import netvlad as nvm
+        from d2slam_amd.weights import synthetic_superpoint_weights
+        emit_line({"cpu_baseline_half": args.cpu_baseline_only,
+                   "result": run_cpu_baseline_half(args.cpu_baseline_only, synthetic_superpoint_weights(dustbin_bias=7.5), None if args.no_netvlad else nvm.synthetic_netvlad_weights(),
+                                                   args.cpu_iterations)})
+        return
 
     if args.latency_only:
         # the single-call latency leg in a process of its own that does nothing but call the C ABI (no torch, no other streams): how a D2SLAM
@@ -101,9 +231,8 @@ def main():
         # share the runtime's few hardware queues, the two-stream entry points measure up to 70 % slower
         from d2slam_amd import api, netvlad as nvm
         from d2slam_amd.weights import synthetic_superpoint_weights
-        print(json.dumps({"latency": run_latency(api, synthetic_superpoint_weights(dustbin_bias=7.5), nvm.synthetic_netvlad_weights(),
-                                                 int(os.environ.get("LOCAL_RANK", "0")), args.precision, args.latency_calls),
-                          }), flush=True)
+        emit_line({"latency": run_latency(api, synthetic_superpoint_weights(dustbin_bias=7.5), nvm.synthetic_netvlad_weights(),
+                                          int(os.environ.get("LOCAL_RANK", "0")), args.precision, args.latency_calls)})
         return
 
     import torch
@@ -129,24 +258,35 @@ def main():
         local_rank = local_rank % ndev      # debug only: several ranks share one GPU under gloo
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # `dist_path`: the N > 1 path -- process group, collective evidence, the exchange behind the pipe, the N > 1 lane count.  --force-dist takes it with ONE rank
+    # (the exchange then loops the rank's own blocks back as the remote agent), so that the first 8-GPU run can only fail for reasons that need 8 GPUs
+    dist_path = world > 1 or args.force_dist
+    loopback = dist_path and world == 1
+    if dist_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    rccl = collective_evidence(torch, dist, dev, backend, rank, world) if world > 1 else None
+    def finish(full):
+        """every rank: leave the process group; rank 0 alone owns stdout and writes the line LAST"""
+        if rank != 0:
+            silence_this_process()
+        if dist_path:
+            dist.destroy_process_group()
+        if rank == 0:
+            line, _ = headline(full)
+            emit_line(line)
+
+    rccl = collective_evidence(torch, dist, dev, backend, rank, world) if dist_path else None
 
     weights = synthetic_superpoint_weights(dustbin_bias=7.5)
     if args.workload == "quadcam":
         out = run_quadcam(args, torch, api, weights, dev, local_rank, world, rank)
-        if rank == 0:
-            if rccl:
-                out["rccl"] = rccl
-            print(json.dumps(out), flush=True)
-        if world > 1:
-            dist.destroy_process_group()
+        if rccl:
+            out["rccl"] = rccl
+        finish(out)
         return
 
     from d2slam_amd import netvlad as nvm
@@ -296,13 +436,33 @@ def main():
     # EVERY --gpus N times the frames-in-flight pipe (include/d2fe.h, d2fe_pipe_*): host frames in, host results out, `lanes` submits in flight.  N > 1 adds the
     # cross-agent exchange on a stream of its own beside it (run_pipe / swarm.PipeExchange) and keeps two submits in flight instead of four (LANES_WITH_EXCHANGE: the
     # exchange stream then has a hardware pipe it shares with a NetVLAD stream only); nothing else differs between `--gpus 1` and `--gpus 8`
-    lanes = args.lanes or (LANES_FOR.get(args.frames, 2) if world == 1 else LANES_WITH_EXCHANGE.get(args.frames, LANES_FOR.get(args.frames, 2)))
-    xmode = args.exchange if world > 1 else None
-    pk = dict(world=world, dist=dist, exchange=xmode)
+    lanes = args.lanes or (LANES_FOR.get(args.frames, 2) if not dist_path else LANES_WITH_EXCHANGE.get(args.frames, LANES_FOR.get(args.frames, 2)))
+    xmode = args.exchange if dist_path else None
+    pk = dict(world=world, dist=dist, exchange=xmode, loopback=loopback)
+    full_run = world == 1 and not dist_path and not args.single_mode          # the default `python bench.py`: every secondary leg
     primary = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, args.steps, args.warmup, local_rank, rank, netvlad=use_nv, **pk)
+    if world == 1 and not dist_path and lanes > 1 and not args.no_solo:
+        # the step with ONE submit in flight: every kernel has the device to itself -- the dominant kernel's own roofline measurement (also the batch curve's F x 1 point)
+        solo = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, 1, max(5, args.steps // 2) if args.single_mode else max(12, min(400, int(700 / args.frames))), 4,
+                        local_rank, rank, netvlad=use_nv)
+    latency = None
+    if rank == 0 and full_run and not args.no_latency:
+        # in a fresh process (see --latency-only); falls back to this process if the child fails.  Before the CPU children start: single calls are host-latency bound
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--latency-only", "--precision", args.precision, "--latency-calls",
+                                str(args.latency_calls)], capture_output=True, text=True, timeout=600, env=dict(os.environ, LOCAL_RANK=str(local_rank)))
+            latency = json.loads(r.stdout.strip().splitlines()[-1])["latency"]
+            latency["process"] = "a process of its own that only calls the C ABI (python bench.py --latency-only)"
+        except Exception as e:      # noqa: BLE001
+            latency = run_latency(api, weights, nv_weights, local_rank, args.precision, args.latency_calls)
+            latency["process"] = "the benchmark process (the child process failed: %s)" % str(e)[:100]
+    # cpu_baseline (SURVEY.md section 8d protocol: warm-up 5, >= 50 timed iterations, median + p95; one thread and all cores): two child processes started HERE, after the
+    # headline, solo and latency legs, so that their 1-2 minutes pass beside the secondary GPU legs below (a few host threads on a 256-core box) instead of adding to the run
+    cpu_children = start_cpu_baseline(args, use_nv) if (rank == 0 and world == 1 and not dist_path and not args.no_cpu_baseline) else None
     legs, legs_solo = {}, {}
     short = max(5, args.steps // 2)
-    if world > 1:
+    if dist_path:
         # the same ranks, the same step, WITHOUT the exchange: what the exchange costs the step (its kernels share the device with the lanes' launches)
         noexch = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, short, 2, local_rank, rank, netvlad=use_nv, light=True, world=world, dist=dist)
     if not args.single_mode:
@@ -310,11 +470,11 @@ def main():
         for om in ("f32", "f16x2", "wino"):
             if om != args.precision:
                 legs[om] = run_pipe(torch, api, weights, nv_weights, om, args.frames, lanes, short, 2, local_rank, rank, netvlad=use_nv, **pk)
-                if world == 1:
+                if not dist_path:
                     # the mode's OWN roofline object: the same step with ONE submit in flight (with several, the HIP-event duration of a launch includes the
                     # other lane's launches it shares the device with -- VERDICT r04 weak #5)
                     legs_solo[om] = run_pipe(torch, api, weights, nv_weights, om, args.frames, 1, short, 2, local_rank, rank, netvlad=use_nv)
-    if world == 1 and not args.single_mode:
+    if full_run:
         dr = run_mode(args.precision, True, netvlad=use_nv, steps=short)
         device_resident = {"value": round(dr["value"], 2), "unit": "stereo_frames/s", "ms_per_step": round(dr["ms_per_step"], 3),
                            "workload": "the same step through the device API on one handle: frames uploaded on a copy stream inside the timed region, keypoints / "
@@ -344,18 +504,17 @@ def main():
                                      % (len(imgs_ps), n_syn // 2, (len(imgs_ps) - n_syn) // 2, CAP),
                              "wino_vs_f32": rec["wino_vs_f32_all"], "f16x2_vs_f32": rec["f16x2_vs_f32_all"], "wino_vs_f32_real_derived": rec["wino_vs_f32_real_derived"],
                              "seconds": round(time.time() - t_ps, 1)}
-    if world == 1 and not args.no_batch_curve and not args.single_mode:
+    if full_run and not args.no_batch_curve:
         batch_curve = []
         for Fc in (1, 2, 4, 8, 16, 32):
             for Kc in sorted({1, LANES_FOR[Fc]} | ({2} if Fc <= 2 else set())):      # one or two frames per submit: also TWO in flight (the best plain configuration at F = 1)
                 if Fc == args.frames and Kc == lanes:
                     r = primary
+                elif Fc == args.frames and Kc == 1 and solo is not None:
+                    r = solo
                 else:
-                    alone = Fc == args.frames and Kc == 1      # the step with ONE submit in flight: every kernel has the device to itself
                     r = run_pipe(torch, api, weights, nv_weights, args.precision, Fc, Kc, max(12, min(400, int(700 / Fc))), max(2 * Kc, 4), local_rank, rank, netvlad=use_nv,
-                                 light=not alone)
-                    if alone:
-                        solo = r
+                                 light=True)
                 batch_curve.append({"stereo_frames_per_submit": Fc, "submits_in_flight": Kc, "coalesce": 1, "stereo_fps": round(r["value"], 1), "ms_per_submit": round(r["ms_per_step"], 4),
                                     "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r)})
             if Fc == 1:
@@ -389,16 +548,6 @@ def main():
                     batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": infl, "coalesce": 4, "coalesce_depth": 2, "stereo_fps": round(r["value"], 1),
                                         "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r),
                                         "note": "dynamic batching: up to 4 consecutive submits per pass, launched early whenever fewer than 2 passes are in flight"})
-    if world == 1 and solo is None and lanes > 1 and not args.no_solo:
-        # --single-mode / --no-batch-curve: the headline kernel's solo measurement still belongs to the line
-        solo = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, 1, short, 2, local_rank, rank, netvlad=use_nv)
-
-    cpu_baseline = None
-    parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(weights, nv_weights if use_nv else None, args.cpu_seconds)
-        parity = run_parity_check(primary, weights, nv_weights if use_nv else None, args.precision)
-
     disagreement = None
     disagreement_fast = None
     if rank == 0 and world == 1 and "f32" in legs and args.precision == "wino":
@@ -406,28 +555,22 @@ def main():
         if "f16x2" in legs:
             disagreement_fast = mode_disagreement(legs["f16x2"]["sel"], legs["f32"]["sel"], primary["F"])
 
-    latency = None
-    if rank == 0 and world == 1 and not args.single_mode and not args.no_latency:
-        # in a fresh process (see --latency-only); falls back to this process if the child fails
-        import subprocess
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--latency-only", "--precision", args.precision, "--latency-calls",
-                                str(args.latency_calls)], capture_output=True, text=True, timeout=600, env=dict(os.environ, LOCAL_RANK=str(local_rank)))
-            latency = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["latency"]
-            latency["process"] = "a process of its own that only calls the C ABI (python bench.py --latency-only)"
-        except Exception as e:      # noqa: BLE001
-            latency = run_latency(api, weights, nv_weights, local_rank, args.precision, args.latency_calls)
-            latency["process"] = "the benchmark process (the child process failed: %s)" % str(e)[:100]
-
     quad = None
-    if rank == 0 and world == 1 and not args.single_mode:
+    if rank == 0 and full_run:
         qa = argparse.Namespace(**vars(args)); qa.steps = 8; qa.warmup = 2
         quad = run_quadcam(qa, torch, api, weights, dev, local_rank, world)
 
-    if rank == 0 and world == 1 and not args.single_mode and not args.no_exchange_loopback:
+    if rank == 0 and full_run and not args.no_exchange_loopback:
         # LAST leg of the run: it creates (and destroys) a one-rank RCCL communicator, whose proxy threads and streams must not sit beside any other measurement
         exch_1gpu = exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, args.lanes or LANES_WITH_EXCHANGE.get(args.frames, lanes), short, local_rank, rank, use_nv, dev)
 
+    cpu_baseline = None
+    parity = None
+    if rank == 0 and world == 1 and not dist_path and not args.no_cpu_baseline:
+        cpu_baseline = join_cpu_baseline(cpu_children, weights)
+        parity = run_parity_check(primary, weights, nv_weights if use_nv else None, args.precision)
+
+    out = None
     if rank == 0:
         value, ms_per_step = primary["value"], primary["ms_per_step"]
         NI, NP, F = primary["NI"], primary["NP"], primary["F"]
@@ -445,17 +588,18 @@ def main():
             "config": {"workload": "BASELINE metric configuration: realsense_d435 stereo 640x480, 200 keypoints/frame: SuperPoint (both images) + "
                                    + ("NetVLAD (left image; stand-in MobileNetVLAD graph, the reference's ONNX is not in its tree) + " if use_nv else "")
                                    + "matchKNN L<->R and L<->prevL"
-                                   + ("; + one RCCL all-gather of exchange blocks, device NetVLAD gate, cross-agent matchKNN vs every remote frame" if world > 1 else ""),
+                                   + ("; + one RCCL all-gather of exchange blocks, device NetVLAD gate, cross-agent matchKNN vs every remote frame" if dist_path else "")
+                                   + ("; ONE rank through the N > 1 path (--force-dist): the rank's own blocks come back as the remote agent" if loopback else ""),
                        "frames_per_step_per_gpu": F, "images_per_step_per_gpu": NI, "match_pairs_per_step_per_gpu": NP,
                        "api": ("d2fe_pipe_submit / d2fe_pipe_wait (include/d2fe.h): host frames in (pinned), host results out (pinned), %d submits in flight" % primary["lanes"])
-                              + ("" if world == 1 else "; cross-agent exchange per submit on a stream of its own behind d2fe_pipe_device_view / _release (pack -> ONE all-gather -> gate -> "
+                              + ("" if not dist_path else "; cross-agent exchange per submit on a stream of its own behind d2fe_pipe_device_view / _release (pack -> ONE all-gather -> gate -> "
                                                        "remote matchKNN -> D2H), enqueued one submit behind the pipe -- the SAME path as --gpus 1 plus that stream"),
                        "same_path_for_every_n_gpus": True,
                        "h2d_in_timed_region": True,
                        "d2h_in_timed_region": True,
                        "d2h_bytes_per_step": primary.get("d2h_bytes"),
                        "delivered": "keypoints, scores, descriptors, counts, NetVLAD descriptors and both match lists of every frame land in host memory inside the timed "
-                                    "region (the reference's contract ends in host std::vectors, superpoint_tensorrt.cpp:172-180, loop_cam.cpp:619-645)" + ("" if world == 1 else
+                                    "region (the reference's contract ends in host std::vectors, superpoint_tensorrt.cpp:172-180, loop_cam.cpp:619-645)" + ("" if not dist_path else
                                     "; N > 1: the cross-agent match lists and gate decisions too (a ring of pinned slots, one D2H per submit on the exchange stream)"),
                        "submits_in_flight": primary.get("lanes"), "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "stream_placement": dict(primary.get("stream_placement") or {}, what="d2fe_pipe_stream_placement of the timed pipe: the hardware-pipe class d2fe_pipe_create MEASURED "
@@ -484,7 +628,7 @@ def main():
                                    "%d x 1, %.1f stereo fps): the launch has the device to itself" % (solo["steps"], solo["F"], solo["value"]),
                                    in_timed_region_of_value={"avg_launch_ms": shared["avg_launch_ms"], "launches": shared["launches"], "frac_executed": shared["frac_executed"],
                                                              "note": "with %d submits in flight the launch overlaps the other lanes' NetVLAD / post-processing / copy work" % primary["lanes"]})
-        if world == 1 and not args.single_mode and not args.no_live_traffic and args.precision == "wino" and args.frames == 32 and out["roofline"].get("kernel", "").startswith("conv_wino"):
+        if full_run and not args.no_live_traffic and args.precision == "wino" and args.frames == 32 and out["roofline"].get("kernel", "").startswith("conv_wino"):
             live = live_traffic("conv_wino_kernel<64, true, true, 0, 1, true")
             if live:
                 out["roofline"]["traffic"] = live["traffic"]; out["roofline"]["traffic_note"] = live["note"]; out["roofline"]["traffic_counters"] = live["counters"]
@@ -569,9 +713,7 @@ def main():
                                      mfma_tflops=round(2 * 2.0 * CAP * CAP * 256 * NP / (b.get("match") * 1e-3) / 1e12, 2) if b.get("match") else None,
                                      note="two distance strips per pair (one per direction): 2 x 2 x na x nb x 256 FLOP on v_mfma_f32_16x16x4_f32"),
             }
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    finish(out)
 
 
 # executed matrix-pipe FLOPs of ONE 640x480 image through SuperPoint (sparse descriptor head at <= 4 corner cells per keypoint, 200 keypoints): the layer table of
@@ -720,8 +862,10 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
         o = base + (i & 1) * per_set
         return pipe.submit_ptr(o, o + per_side)
 
+    use_dist = dist is not None and dist.is_initialized()      # N > 1, or one rank sent through the N > 1 path (--force-dist)
+
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -770,7 +914,7 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
     prof = pipe.profile_read() if not light else None
     if not light:
         pipe.profile_enable(0)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -869,7 +1013,8 @@ def self_launch(n):
     env.setdefault("OMP_NUM_THREADS", "8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    # the ranks inherit this process's ORIGINAL stdout as their fd 1 (this process's own fd 1 already points at stderr, see claim_stdout)
+    return subprocess.call(cmd, env=env, stdout=_REAL_STDOUT if _REAL_STDOUT is not None else None)
 
 
 def collective_evidence(torch, dist, dev, backend, rank, world):
@@ -1240,14 +1385,17 @@ def _torch_superpoint(torch, F, x, w):
     return sm, desc
 
 
-def run_cpu_baseline(weights, nv_weights, budget_s):
-    """The same step on the host cores, BASELINE.md section 3 / SURVEY.md section 8d.  The reference has no runnable CPU extractor,
-    so this is kind "port": the network in PyTorch (oneDNN convolutions) + the C oracle's variant-B post-processing, NetVLAD and matchKNN.
-    Inputs are generated BEFORE timing; every iteration is timed per stage (prep u8 -> f32/255, conv stack, post-processing, NetVLAD,
-    matching: L<->R and L<->previous L); median and p95 per stage and end to end.  (i) ONE thread -- what the reference pins every host
-    library to (d2frontend.cpp:303, onnx_generic.h:32, superpoint_onnx.cpp:26); (ii) the best of several thread counts, with the C stages
-    threaded over frames (ctypes releases the GIL) and OpenMP inside the NetVLAD convolutions.  The protocol's 5 + >= 50 iterations do not fit
-    bench.py's bounded CPU sample at ~1 s per single-thread frame: iterations are time-bounded and the counts are stated."""
+CPU_WARMUP = 5          # warm-up 5, >= 50 timed iterations, median + p95
+
+
+def run_cpu_baseline_half(which, weights, nv_weights, iterations):
+    """One half of `cpu_baseline`: the same step on the host cores, BASELINE.md section 3 / SURVEY.md section 8(d).  The reference has no runnable CPU extractor
+    (SURVEY F2), so this is kind "port": the network in PyTorch (oneDNN convolutions) + the C oracle's variant-B post-processing, NetVLAD and matchKNN.
+    Inputs are generated BEFORE timing; 5 warm-up iterations, then `iterations` (>= 50 by default) timed ones of ONE stereo frame each (all_cores: TWO, so that the
+    batch dimension feeds the threads), every iteration timed per stage (prep u8 -> f32/255, conv stack, post-processing, NetVLAD, matching: L<->R and
+    L<->previous L); median and p95 per stage and end to end.  `single_thread`: ONE thread -- what the reference pins every host library to (d2frontend.cpp:303,
+    onnx_generic.h:32, superpoint_onnx.cpp:26).  `all_cores`: the best of 16 / 32 / 64 threads (3-iteration probes; more intra-op threads collapse oneDNN's
+    convolutions), the C stages threaded over frames (ctypes releases the GIL) and OpenMP inside the NetVLAD convolutions."""
     import ctypes
     import torch
     import torch.nn.functional as F
@@ -1294,7 +1442,7 @@ def run_cpu_baseline(weights, nv_weights, budget_s):
         t["match"] = time.perf_counter() - t0
         return t
 
-    def measure(nthreads, B, warm, min_iters, max_iters, seconds):
+    def measure(nthreads, B, warm, iters):
         torch.set_num_threads(nthreads)
         if gomp is not None:
             gomp.omp_set_num_threads(int(nthreads))
@@ -1302,10 +1450,7 @@ def run_cpu_baseline(weights, nv_weights, budget_s):
         state = {}
         for w_ in range(warm):
             iteration(B, w_ * B, pool, state)
-        rows = []
-        t_start = time.perf_counter()
-        while len(rows) < max_iters and (len(rows) < min_iters or time.perf_counter() - t_start < seconds):
-            rows.append(iteration(B, len(rows) * B, pool, state))
+        rows = [iteration(B, i * B, pool, state) for i in range(iters)]
         if pool:
             pool.shutdown()
         per = {k: np.array([r[k] for r in rows]) / B * 1e3 for k in STAGES}          # ms per stereo frame
@@ -1314,32 +1459,60 @@ def run_cpu_baseline(weights, nv_weights, budget_s):
                 "stereo_frames_per_s_median": round(1e3 / float(np.median(tot)), 4), "stereo_frames_per_s_p95_slowest": round(1e3 / float(np.percentile(tot, 95)), 4),
                 "ms_per_stereo_frame": {k: {"median": round(float(np.median(v)), 3), "p95": round(float(np.percentile(v, 95)), 3)} for k, v in per.items()}}
 
-    t_all0 = time.perf_counter()
-    one = measure(1, 1, 1, 3, 50, 0.35 * budget_s)
-    best = None
-    cands = sorted({min(ncores, c) for c in (16, 32, 64)})
-    for nthr in cands:
-        r = measure(nthr, 4, 2, 5, 50, 0.3 * budget_s / len(cands))
-        if best is None or r["stereo_frames_per_s_median"] > best["stereo_frames_per_s_median"]:
-            best = r
-    torch.set_num_threads(min(ncores, 32))
-    if gomp is not None:
-        gomp.omp_set_num_threads(int(ncores))
-    # the scalar fmaf-chain oracle the parity tests use (OpenMP over all cores): a labelled extra, not a tuned CPU path
     t0 = time.perf_counter()
-    l, r = frames[0]
+    if which == "single_thread":
+        r = measure(1, 1, CPU_WARMUP, iterations)
+        r["note"] = "the reference pins its host libraries to one thread (d2frontend.cpp:303)"
+    else:
+        cands = sorted({min(ncores, c) for c in (16, 32, 64)})
+        probe = {c: measure(c, 2, 1, 3)["stereo_frames_per_s_median"] for c in cands}
+        r = measure(max(probe, key=probe.get), 2, CPU_WARMUP, iterations)
+        r["thread_count_probe"] = {str(k): v for k, v in probe.items()}
+    r["host_cores"] = ncores
+    r["seconds"] = round(time.perf_counter() - t0, 1)
+    return r
+
+
+def start_cpu_baseline(args, use_nv):
+    """both halves of `cpu_baseline` as child processes of their own (python bench.py --cpu-baseline-only ...): no GPU, no torch.cuda in them"""
+    import subprocess
+    kids = {}
+    for which in ("all_cores", "single_thread"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", which, "--cpu-iterations", str(args.cpu_iterations)] + ([] if use_nv else ["--no-netvlad"])
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", D2FE_BENCH_CHILD="1")
+        kids[which] = (subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env), time.time())
+    return kids
+
+
+def join_cpu_baseline(kids, weights):
+    from oracle import oracle as orc
+    from d2slam_amd.synth import synth_stereo
+    halves = {}
+    waited = time.time()
+    for which, (p, t_start) in (kids or {}).items():
+        try:
+            so, se = p.communicate(timeout=900)
+            halves[which] = json.loads(so.strip().splitlines()[-1])["result"]
+        except Exception as e:      # noqa: BLE001
+            p.kill()
+            halves[which] = {"error": str(e)[:200]}
+    waited = time.time() - waited
+    best, one = halves.get("all_cores") or {}, halves.get("single_thread") or {}
+    ncores = os.cpu_count() or 1
+    # the scalar fmaf-chain oracle the parity tests use (OpenMP over all cores): a labelled extra, not a tuned CPU path.  After the children: it takes every core
+    orc.build()
+    t0 = time.perf_counter()
+    l, r = synth_stereo(H, W, seed=0)
     kl, sl, dl, _, _ = orc.extract_b(l, weights, 0.015, 1, CAP)
     kr, sr, dr, _, _ = orc.extract_b(r, weights, 0.015, 1, CAP)
     orc.match_knn(dl, dr, 0.8); orc.match_knn(dl, dl, 0.8)
     fps_orc = 1.0 / (time.perf_counter() - t0)
-    el = time.perf_counter() - t_all0
-    what = "SuperPoint (L+R) + " + ("NetVLAD (L) + " if nv_weights is not None else "") + "2 matchKNN per stereo frame, 640x480"
-    return {"value": best["stereo_frames_per_s_median"], "unit": "stereo_frames/s", "cores": best["threads"], "kind": "port", "host_cores": ncores,
-            "sample": "%s; %d pre-generated stereo frames cycled; network in PyTorch-CPU (oneDNN), post-processing / NetVLAD / matching in the C oracle (threaded over "
-                      "frames); best of %s threads on this %d-core host (more intra-op threads than ~64 collapse oneDNN's convolutions); protocol of BASELINE.md section 3 with "
-                      "time-bounded iteration counts (stated per line); %.1f s for everything" % (what, NF, cands, ncores, el),
-            "protocol": "inputs generated before timing; per-stage wall time per iteration; median / p95 over the timed iterations",
-            "all_cores": best, "single_thread": dict(one, note="the reference pins its host libraries to one thread (d2frontend.cpp:303)"),
+    return {"value": best.get("stereo_frames_per_s_median"), "unit": "stereo_frames/s", "cores": best.get("threads"), "kind": "port", "host_cores": ncores,
+            "sample": "%d + %d iterations of 2 stereo frames (all cores) / 1 stereo frame (one thread), 640x480, SuperPoint (L+R) + NetVLAD (L) + 2 matchKNN per frame; 8 pre-generated "
+                      "stereo frames cycled; network in PyTorch-CPU (oneDNN), post-processing / NetVLAD / matching in the C oracle" % (CPU_WARMUP, best.get("timed_iterations") or 0),
+            "protocol": "SURVEY.md section 8(d): inputs generated before timing; warm-up %d; >= 50 timed iterations; per-stage wall time per iteration; median / p95.  Both halves ran as child "
+                        "processes beside this run's secondary GPU legs (a few host threads); the run waited %.1f s for them at the end" % (CPU_WARMUP, waited),
+            "all_cores": best, "single_thread": one,
             "fmaf_oracle": {"value": round(fps_orc, 4), "unit": "stereo_frames/s", "cores": ncores,
                             "sample": "1 stereo frame through oracle/d2fe_oracle.c (one fp32 fmaf chain per output, OpenMP): the parity checker, not a tuned CPU path"}}
 

@@ -103,3 +103,62 @@ def test_netvlad_flop_table():
     assert abs(nvm.arch_flops(0.35) / 1e9 - 0.666) < 0.005 and abs(nvm.arch_flops(0.35, head=True) / 1e9 - 0.769) < 0.005
     assert nvm.arch_flops(0.5) < nvm.arch_flops(0.75) < nvm.arch_flops(1.0)
     assert abs(bench.NV_FLOP_PER_IMG / nvm.arch_flops(0.35) - 1.0) < 0.01
+
+
+def test_json_line_is_the_last_thing_on_stdout_even_with_buffered_c_stdio_and_merged_stderr(tmp_path):
+    """The driver's contract: a library that prints through C stdio (RCCL's version banner: buffered on a pipe, flushed at process exit) must not land
+    behind the JSON line -- neither on stdout alone nor when the caller merges stderr into stdout -- and nothing printed after the line may reach either stream."""
+    import json
+    import subprocess
+    import sys
+    prog = ("import ctypes, sys, os\n"
+            "sys.path.insert(0, %r)\n"
+            "import bench\n"
+            "libc = ctypes.CDLL(None)\n"
+            "bench.claim_stdout()\n"
+            "libc.printf(b'RCCL version : banner through C stdio\\n')\n"      # stays in libc's buffer until somebody flushes it
+            "print('python print before the line')\n"
+            "bench.emit_line({'metric': 'm', 'value': 1.5, 'roofline': {'frac': 0.5}, 'cpu_baseline': None})\n"
+            "libc.printf(b'Librccl path : printed at teardown\\n')\n"
+            "print('python print after the line'); sys.stderr.write('stderr after the line\\n')\n" % bench.ROOT)
+    for merged in (False, True):
+        r = subprocess.run([sys.executable, "-c", prog], stdout=subprocess.PIPE, stderr=subprocess.STDOUT if merged else subprocess.PIPE, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + (r.stderr or "")
+        lines = r.stdout.strip().splitlines()
+        j = json.loads(lines[-1])
+        assert j["value"] == 1.5 and j["roofline"]["frac"] == 0.5
+        assert "after the line" not in r.stdout and "teardown" not in r.stdout
+        if merged:
+            assert any("banner through C stdio" in l for l in lines[:-1]) and any("before the line" in l for l in lines[:-1])
+        else:
+            assert lines == [lines[-1]] and "banner through C stdio" in r.stderr
+
+
+def test_headline_fits_the_tail_and_names_the_extras_file(tmp_path, monkeypatch):
+    """the line keeps the contract's keys + roofline + cpu_baseline in < 6 KB whatever the full record holds; everything else is in the file the line names"""
+    import json
+    monkeypatch.setenv("D2FE_BENCH_EXTRAS", str(tmp_path / "extras.json"))
+    prose = "x" * 900
+    full = {"metric": "m", "value": 2.0, "unit": "u", "n_gpus": 8, "steps": 3, "warmup": 1, "ms_per_step": 1.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "config": {"workload": "w" * 500, "note": prose, "lanes": 4},
+            "roofline": {"bound": "mfma", "achieved": 1.0, "peak": 2.0, "unit": "TFLOP/s", "frac": 0.5, "traffic": 7, "note": prose, "kernel": "k"},
+            "cpu_baseline": {"value": 3.0, "unit": "u", "cores": 32, "kind": "port", "sample": "s" * 400,
+                             "all_cores": {"threads": 32, "timed_iterations": 50, "ms_per_stereo_frame": {"conv": {"median": 1.0, "p95": 2.0}}},
+                             "single_thread": {"threads": 1, "timed_iterations": 50, "ms_per_stereo_frame": {"conv": {"median": 1.0, "p95": 2.0}}}, "fmaf_oracle": {"value": 1}},
+            "step_roofline": {"frac": 0.7}, "parity": {"keypoints_equal": True},
+            "rccl": {"backend": "nccl", "is_rccl": True, "world_size": 8, "ranks": [{"rank": i, "uuid": "u" * 40, "name": "AMD Instinct MI355X"} for i in range(8)]},
+            "exchange": {"step_timeline_ms": {k: 0.1 for k in "abcdefgh"}, "note": prose}, "batch_curve": {"points": [{"note": prose}] * 30}, "latency": {"a": prose}}
+    line, path = bench.headline(full)
+    assert path == str(tmp_path / "extras.json") and json.load(open(path))["batch_curve"]["points"][0]["note"] == prose
+    txt = json.dumps(line)
+    assert len(txt) < bench.LINE_BUDGET
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["roofline"]["frac"] == 0.5 and line["roofline"]["traffic"] == 7 and "note" not in line["roofline"]
+    assert line["cpu_baseline"]["all_cores"]["timed_iterations"] == 50 and "ms_per_stereo_frame" not in line["cpu_baseline"]["all_cores"]
+    assert line["config"]["workload"].startswith("www") and len(line["config"]["workload"]) <= 320
+    assert "batch_curve" not in line and "batch_curve" in line["extras"]["keys"] and line["extras"]["file"].endswith("extras.json")
+    assert line["rccl"]["world_size"] == 8 and isinstance(line["rccl"]["ranks"], str)
+    # a run without a CPU baseline / roofline still carries the keys (null)
+    line2, _ = bench.headline({"metric": "m", "value": 1.0})
+    assert line2["cpu_baseline"] is None and line2["roofline"] is None and line2["vs_baseline"] is None

@@ -18,11 +18,27 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _torchrun(script_args, env_extra, timeout=900):
+def _torchrun(script_args, env_extra, timeout=900, merged=False):
     env = dict(os.environ); env.update(env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + script_args
+    if merged:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+        r.stderr = ""
+        return r
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _last_line(r):
+    """the bench contract: the JSON line is the LAST line of stdout -- callers below run bench.py with stderr merged into stdout (the worst case: RCCL's exit-time banner
+    and every warning share the stream with the line), so a line that is not last fails json.loads here"""
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def _full(j):
+    """the full record of a run: the extras file its line names (legs, timelines, per-stage tables, prose)"""
+    f = j["extras"]["file"]
+    return json.load(open(f if os.path.isabs(f) else os.path.join(ROOT, f)))
 
 
 def _rank_errors(r):
@@ -64,9 +80,11 @@ def test_bench_self_launches_n_ranks_from_a_bare_shell():
     env["D2FE_BENCH_BACKEND"] = "gloo"
     for extra, key in ((["--frames", "2"], "netvlad_gate"), (["--workload", "quadcam", "--frames", "4"], "cross_agent")):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--single-mode",
-                            "--no-cpu-baseline"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, _rank_errors(r)
-        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                            "--no-cpu-baseline"] + extra, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+        j = _last_line(r)
+        assert "roofline" in j and "cpu_baseline" in j and len(r.stdout.strip().splitlines()[-1]) < 6000
+        j = _full(j)
         assert j["n_gpus"] == 2 and j["value"] > 0 and key in j
         e = j["rccl"]
         assert e["backend"] == "gloo" and e["world_size"] == 2 and e["allreduce_sum_of_ranks"] == 1.0 and len(e["ranks"]) == 2
@@ -76,10 +94,9 @@ def test_bench_self_launches_n_ranks_from_a_bare_shell():
 
 def test_bench_gpus2_path_runs_under_gloo():
     r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "2", "--single-mode", "--no-cpu-baseline"],
-                  {"D2FE_BENCH_BACKEND": "gloo"})
-    assert r.returncode == 0, _rank_errors(r)
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    j = json.loads(line)
+                  {"D2FE_BENCH_BACKEND": "gloo"}, merged=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    j = _full(_last_line(r))
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["match_pairs_per_step_per_gpu"] == 2 * 2 + 2
     assert j["netvlad_gate"]["pairs"] == 2 and 0 <= j["netvlad_gate"]["passing_netvlad_gate"] <= 2
     assert j["avg_matches_per_pair"] > 1
@@ -138,18 +155,54 @@ def test_rccl_single_rank_collectives():
     assert r.returncode == 0 and "RCCL 1-rank OK" in r.stdout, (r.stdout + r.stderr)[-2000:]
 
 
-def test_bench_one_gpu_rccl_loopback_leg():
-    """bench.py's `exchange_on_one_gpu_rccl`: the N > 1 exchange sequence behind the value step over a ONE-rank RCCL communicator (loopback), with vs without -- the
-    real backend's asynchronous all-gather on the exchange stream, as far as a 1-GPU box can show it.  The leg must run (no "error") and cost a few per cent at most."""
+def _bare_env(**extra):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--frames", "8", "--no-cpu-baseline", "--no-latency", "--no-batch-curve",
-                        "--no-live-traffic", "--no-width-sensitivity", "--no-parity-study"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
-    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    e = j["exchange_on_one_gpu_rccl"]
+    env.update(extra)
+    return env
+
+
+def test_bench_default_line_contract_and_one_gpu_rccl_loopback_leg(tmp_path):
+    """`python bench.py` as the driver runs it (fewer steps / CPU iterations, the long legs off), stderr MERGED into stdout: the JSON line is the last line although the run
+    creates and destroys a one-rank RCCL communicator (whose banner C stdio flushes at exit -- round 5's line was lost to it), it is < 6 KB and carries `roofline` and
+    `cpu_baseline` by the SURVEY 8(d) protocol; the other legs are in the extras file it names.  `exchange_on_one_gpu_rccl` there: the N > 1 exchange sequence behind the
+    value step over the one-rank communicator (loopback), with vs without; it must run (no "error") and cost a few per cent at most."""
+    ex = str(tmp_path / "extras.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--frames", "8", "--cpu-iterations", "3", "--no-latency", "--no-batch-curve",
+                        "--no-live-traffic", "--no-width-sensitivity", "--no-parity-study"], cwd=ROOT, env=_bare_env(D2FE_BENCH_EXTRAS=ex),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    j = json.loads(last)
+    assert len(last) < 6000 and j["n_gpus"] == 1 and j["value"] > 0
+    assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1 and j["roofline"]["avg_launch_ms"] > 0
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["all_cores"]["timed_iterations"] == 3 and cb["all_cores"]["warmup_iterations"] == 5 and cb["single_thread"]["threads"] == 1
+    assert j["parity"]["keypoints_equal"] and j["parity"]["scores_equal"]
+    assert j["extras"]["file"] == ex and "exchange_on_one_gpu_rccl" in j["extras"]["keys"]
+    full = json.load(open(ex))
+    assert full["value"] == j["value"] and "ms_per_stereo_frame" in full["cpu_baseline"]["all_cores"]
+    e = full["exchange_on_one_gpu_rccl"]
     assert "error" not in e, e
     assert e["backend"] == "nccl" and e["value_with_exchange"] > 0 and e["step_timeline_ms"]["all_gather"] > 0
     assert e["exchange_cost_frac_of_step"] < 0.25, e      # ~2 % at 32 frames per submit; small steps on a shared box are noisier
+
+
+def test_bench_force_dist_sends_one_rank_through_the_n_gpu_path(tmp_path):
+    """--force-dist: --gpus 1 through self_launch -> torch.distributed.run -> init_process_group("nccl", device_id) -> collective_evidence -> PipeExchange
+    (loopback) -> destroy_process_group with the N > 1 lane count; the line is still the last line of the merged stream and says what it ran."""
+    ex = str(tmp_path / "extras.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "6", "--warmup", "2", "--frames", "8", "--single-mode"], cwd=ROOT,
+                       env=_bare_env(D2FE_BENCH_EXTRAS=ex), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    j = _last_line(r)
+    assert j["n_gpus"] == 1 and j["value"] > 0 and "roofline" in j and "cpu_baseline" in j
+    e = j["rccl"]
+    assert e["is_rccl"] and e["backend"] == "nccl" and e["world_size"] == 1 and e["allreduce_sum_of_ranks"] == 0.0
+    full = json.load(open(ex))
+    x = full["exchange"]
+    assert x["cross_agent_pairs_per_step_per_gpu"] == 8 and x["step_timeline_ms"]["all_gather"] > 0 and x["value_without_exchange"] > 0
+    assert full["netvlad_gate"]["pairs"] == 8 and full["netvlad_gate"]["passing_netvlad_gate"] == 8      # every frame against itself
+    assert "--force-dist" in full["config"]["workload"]
 
 
 def test_int8_exchange_blocks_vs_reference_codec():
@@ -212,9 +265,9 @@ def test_bench_gpus2_one_frame_per_step_timeline():
     through the host there, so ITS time says nothing about xGMI); what is held to a budget is everything this library adds on the device beside
     it: packing the blocks and decode / count fix-up / NetVLAD gate, from HIP events on the exchange's stream."""
     r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--frames", "1", "--single-mode", "--no-cpu-baseline"],
-                  {"D2FE_BENCH_BACKEND": "gloo"})
-    assert r.returncode == 0, _rank_errors(r)
-    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                  {"D2FE_BENCH_BACKEND": "gloo"}, merged=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    j = _full(_last_line(r))
     assert j["n_gpus"] == 2 and j["config"]["frames_per_step_per_gpu"] == 1 and j["config"]["match_pairs_per_step_per_gpu"] == 3
     tl = j["exchange"]["step_timeline_ms"]
     # budget: 0.35 ms of a ~1 ms step, without the collective (round 5: the exchange stream runs BESIDE the lanes' launches of the next submit and beside
@@ -229,14 +282,14 @@ def test_bench_gpus2_one_frame_per_step_timeline():
 
 def test_bench_int8_exchange_runs_under_gloo():
     r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "2", "--single-mode", "--no-cpu-baseline",
-                   "--exchange", "int8"], {"D2FE_BENCH_BACKEND": "gloo"})
-    assert r.returncode == 0, _rank_errors(r)
-    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                   "--exchange", "int8"], {"D2FE_BENCH_BACKEND": "gloo"}, merged=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    j = _full(_last_line(r))
     assert j["exchange"]["wire_precision"] == "int8" and j["exchange"]["block_bytes"] * 3.5 < 4 * 56064
     assert j["exchange"]["avg_cross_agent_matches_per_pair"] >= 0
     # the quadcam swarm over int8 blocks (one per view)
     r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "4", "--workload", "quadcam",
-                   "--exchange", "int8"], {"D2FE_BENCH_BACKEND": "gloo"})
-    assert r.returncode == 0, _rank_errors(r)
-    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                   "--exchange", "int8"], {"D2FE_BENCH_BACKEND": "gloo"}, merged=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    j = _full(_last_line(r))
     assert j["cross_agent"]["wire_precision"] == "int8" and j["cross_agent"]["view_pairs_per_step_per_gpu"] == 16 and j["n_gpus"] == 2

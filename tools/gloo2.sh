@@ -9,7 +9,10 @@ D2FE_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --lanes 2 --single-
 grep -v "amdgpu\|socket" $O/bench_gpus2_$TAG.err | tail -3
 python - $O/bench_gpus2_$TAG.json <<'PY'
 import json, sys
-j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+import os
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])          # the line is the LAST line of stdout (bench.py's contract)
+f = (j.get("extras") or {}).get("file")
+if f and os.path.exists(f): j = json.load(open(f))                           # the full record
 print("gpus 2 (gloo, one GPU): value", j["value"], "ms/step", j["ms_per_step"])
 for k in ("exchange", "cross_agent", "netvlad_gate"):
     if j.get(k): print(" ", k, json.dumps(j[k])[:1200])

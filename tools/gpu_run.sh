@@ -25,8 +25,13 @@ BENCH_N=0
 
 bench_summary() {      # the key numbers of a bench JSON line
 python - "$1" <<'PY'
-import json, sys
-j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+import json, os, sys
+txt = open(sys.argv[1]).read().strip().splitlines()
+j = json.loads(txt[-1])                                   # bench.py's contract: the JSON line is the LAST line of stdout
+print("line bytes", len(txt[-1]), "| stdout lines", len(txt))
+f = (j.get("extras") or {}).get("file")
+if f and os.path.exists(f):
+    full = json.load(open(f)); os.replace(f, sys.argv[1].replace(".json", "_extras.json")); j = full      # the full record, kept beside the line
 r = j.get("roofline") or {}
 print("value", j.get("value"), "ms/step", j.get("ms_per_step"), "| conv1b ms", r.get("avg_launch_ms"), "frac", r.get("frac"), "| nv ms", (j.get("roofline_netvlad") or {}).get("ms_per_call"))
 for k in ("configs1", "exact_mode", "fast_mode", "device_resident", "quadcam"):
@@ -44,7 +49,7 @@ if j.get("cpu_baseline"): print("  cpu", j["cpu_baseline"].get("value"), j["cpu_
 PY
 }
 
-ab_line='import sys,json; j=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); print(j["value"], j["ms_per_step"], j["roofline"]["avg_launch_ms"], (j.get("roofline_netvlad") or {}).get("ms_per_call"))'
+ab_line='import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j["value"], j["ms_per_step"], j["roofline"]["avg_launch_ms"], (j.get("roofline_netvlad") or {}).get("ms_per_call"))'
 
 run_task() {
   local t=$1; shift
@@ -69,7 +74,7 @@ run_task() {
                env $var=$v timeout 300 python bench.py --single-mode --no-cpu-baseline --no-latency --breakdown "$@" 2>$d/err_$v.txt | python -c "$ab_line" >> $d/ab.txt 2>&1
              done; done
              for v in "$a" "$b"; do grep "per-stage" $d/err_$v.txt | tail -1 >> $d/ab.txt; done; cat $d/ab.txt ;;
-    latency) timeout 300 python bench.py --latency-only "$@" 2>/dev/null | python -c 'import sys,json; j=json.loads([l for l in sys.stdin if l.startswith("{")][-1])["latency"]; print({k:v["p50_ms"] for k,v in j.items() if isinstance(v,dict)})' ;;
+    latency) timeout 300 python bench.py --latency-only "$@" 2>/dev/null | python -c 'import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1])["latency"]; print({k:v["p50_ms"] for k,v in j.items() if isinstance(v,dict)})' ;;
     pipe)    local sw=$1; shift; timeout 300 python tools/pipe_probe.py --sweep $sw "$@" 2>/dev/null | grep '^{"coalesce_depth' | python -c '
 import sys, json
 for l in sys.stdin:
