@@ -12,14 +12,15 @@ O, n = sys.argv[1], sys.argv[2]
 rows = list(csv.DictReader(open(glob.glob(O + "/**/t_kernel_trace.csv", recursive=True)[0])))
 rows = [r for r in rows if 'nv_' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'nv_fpair_kernel' in r['Kernel_Name']]
+first = rows[0]['Kernel_Name']          # a call starts with the first block's kernel (nv_fpair_kernel, or the generic front kernels at other widths)
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'] == first and (i == 0 or rows[i - 1]['Kernel_Name'] != first)]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]['Start_Timestamp'])
 tot = 0
 print("one NetVLAD call of %s image(s): %d launches" % (n, b - a))
 for r in rows[a:b]:
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3; tot += d
-    print(r['Kernel_Name'][:58].ljust(58), 'grid', r['Grid_Size_X'].rjust(7), r['Grid_Size_Y'].rjust(3), r['Grid_Size_Z'].rjust(3), 'lds', r['LDS_Block_Size'].rjust(6),
+    print(r['Kernel_Name'].replace('void d2fe::', '')[:64].ljust(64), 'grid', r['Grid_Size_X'].rjust(7), r['Grid_Size_Y'].rjust(3), r['Grid_Size_Z'].rjust(3), 'lds', r['LDS_Block_Size'].rjust(6),
           'vgpr', r['VGPR_Count'], r['Accum_VGPR_Count'], 'start %8.1f' % ((int(r['Start_Timestamp']) - t0) / 1e3), 'dur %7.1f us' % d)
 print('sum of kernel durations: %.1f us; span to the next call %.1f us' % (tot, (int(rows[b]['Start_Timestamp']) - t0) / 1e3))
 PY
