@@ -42,7 +42,8 @@ REFUSED_ENV = ("D2FE_ABLATE", "D2FE_MATCH_NOFALLBACK")     # switches that make 
 H, W, CAP = 480, 640, 200
 CONV1B_FLOP_PER_IMG = 2.0 * H * W * 64 * 64 * 9          # 22.65 GFLOP (SURVEY.md section 8a layer table)
 SP_FLOP_PER_IMG = 52.1e9
-NV_FLOP_PER_IMG = 0.6626e9                                # the stand-in MobileNetVLAD at 640x480: 0.3313 GMAC (d2slam_amd/netvlad.py)
+NV_MULT = 0.75                                            # MobileNetV2 alpha = 0.75 trunk (HF-Net's width) -> NetVLAD K = 32 -> 4096
+NV_FLOP_PER_IMG = 2.4780096e9                             # the stand-in MobileNetVLAD trunk at that width, 640x480: 1.239 GMAC (d2slam_amd.netvlad.arch_flops(0.75))
 PEAK_TFLOPS = {"f32": 157.3, "f16x2": 2500.0, "wino": 157.3}             # MI355X_MICROARCH.md: fp32 MFMA / dense f16 MFMA
 NETVLAD_GATE = 0.8                                        # track_remote_netvlad_thres stand-in (the YAMLs carry 0.5..0.8)
 
@@ -480,13 +481,13 @@ def main():
                            "workload": "the same step through the device API on one handle: frames uploaded on a copy stream inside the timed region, keypoints / "
                                        "descriptors / matches left in HBM (round 3's headline configuration; no D2H)", "breakdown": dr["breakdown"], "n_kp": dr["n_kp"], "NI": dr["NI"], "NP": dr["NP"], "roofline_nv": dr["roofline_nv"]}
         if use_nv and not args.no_width_sensitivity:
-            # A9's architecture is an assumption (the reference's ONNX graph is not in its tree): what `value` becomes if the trunk is wider than the stand-in's 0.35
+            # A9's architecture is an assumption (the reference's ONNX graph is not in its tree): what `value` becomes at other trunk widths
             from d2slam_amd import netvlad as nvm2
-            width_sens = {"what": "`value` (same step, same pipe configuration) with the MobileNetVLAD stand-in at other MobileNetV2 depth multipliers; 0.35 is the headline's. "
-                                  "Widths other than 0.35 have channel counts the specialised block kernels do not cover and run the generic fused-block / per-layer "
-                                  "kernels (tests/test_gpu_parity.py::test_netvlad_other_trunk_widths holds them to the oracle)", "points": []}
+            width_sens = {"what": "`value` (same step, same pipe configuration) with the MobileNetVLAD stand-in at other MobileNetV2 depth multipliers; 0.75 (SURVEY A9's, HF-Net's) is "
+                                  "the headline's, 0.35 was the width of rounds 2-5.  Both have specialised block kernels; 0.5 and 1.0 have channel counts those do not cover and run "
+                                  "the generic fused-block / per-layer kernels (tests/test_gpu_parity.py::test_netvlad_other_trunk_widths holds every width to the oracle)", "points": []}
             for mult in (0.35, 0.5, 0.75, 1.0):
-                if mult == 0.35:
+                if mult == NV_MULT:
                     r = primary
                 else:
                     r = run_pipe(torch, api, weights, nvm2.synthetic_netvlad_weights(depth_multiplier=mult), args.precision, args.frames, lanes, short, 2, local_rank, rank,
@@ -586,7 +587,7 @@ def main():
             "vs_baseline": None, "dtype": {"f32": "f32", "f16x2": "f16x2(hi+lo split)/f32-acc", "wino": "f32"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "BASELINE metric configuration: realsense_d435 stereo 640x480, 200 keypoints/frame: SuperPoint (both images) + "
-                                   + ("NetVLAD (left image; stand-in MobileNetVLAD graph, the reference's ONNX is not in its tree) + " if use_nv else "")
+                                   + ("NetVLAD (left image; stand-in MobileNetVLAD graph: MobileNetV2 alpha = 0.75 trunk, K = 32 -> 4096 (SURVEY A9); the reference's ONNX is not in its tree) + " if use_nv else "")
                                    + "matchKNN L<->R and L<->prevL"
                                    + ("; + one RCCL all-gather of exchange blocks, device NetVLAD gate, cross-agent matchKNN vs every remote frame" if dist_path else "")
                                    + ("; ONE rank through the N > 1 path (--force-dist): the rank's own blocks come back as the remote agent" if loopback else ""),
@@ -733,7 +734,7 @@ def sp_executed_gflop_per_image(precision):
 
 def step_roofline(precision, F, ms_per_step, netvlad, npairs):
     """The WHOLE step against the matrix pipe: executed MFMA FLOPs of everything a step launches / ms_per_step / peak.  Analytic counts (the layer
-    table above; NetVLAD 0.6626 GFLOP per left image on the fp32 pipe; matchKNN 2 strips x 2 na nb 256 per pair); the per-kernel SQ_INSTS_MFMA sums of the committed
+    table above; NetVLAD 2.478 GFLOP per left image (MobileNetV2-0.75 trunk) on the fp32 pipe; matchKNN 2 strips x 2 na nb 256 per pair); the per-kernel SQ_INSTS_MFMA sums of the committed
     profile of the same command agree (profiles/: 3.46e8 x 4096 = 1.42 TFLOP per 64-image step in Winograd mode)."""
     peak = PEAK_TFLOPS[precision]
     sp = sp_executed_gflop_per_image(precision) * 1e9 * 2 * F
@@ -820,8 +821,8 @@ def exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, lanes, step
 
 def netvlad_roofline(t_ms, F, how, flop_per_img=NV_FLOP_PER_IMG):
     ach = flop_per_img * F / (t_ms * 1e-3) / 1e12
-    return {"kernel": "NetVLAD launch sequence (27 launches: nv_fpair_kernel, nv_pblock_kernel x12 (stride 1), nv_xblock_kernel x4 (stride 2), nv_slab_sum_kernel x7, nv_tail_kernel, "
-                      "nv_vlad_* x2; d2slam_amd/csrc/netvlad*.hip): MobileNetV2-0.35 trunk + NetVLAD head",
+    return {"kernel": "NetVLAD launch sequence (one launch per MobileNetV2 block: nv_fpair_kernel, nv_pblock_kernel (stride 1), nv_xblock_kernel (stride 2), nv_slab_sum_kernel, nv_tail_kernel, "
+                      "nv_vlad_* x2; d2slam_amd/csrc/netvlad*.hip): MobileNetV2-%.2f trunk + NetVLAD head" % (NV_MULT if abs(flop_per_img - NV_FLOP_PER_IMG) < 1 else -1),
             "bound": "mfma", "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
             "ms_per_call": round(t_ms, 4), "images_per_call": F, "algorithmic_flop_per_call": flop_per_img * F,
             "note": "fp32 MFMA (v_mfma_f32_16x16x4_f32) + VALU depthwise; instruction/latency-bound small layers (DESIGN.md section 4); " + how}

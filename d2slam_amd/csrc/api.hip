@@ -793,7 +793,7 @@ void nv_free(d2fe_context* h) {
   const bool own = !h->borrowed;      // a pipeline lane owns its activations only
   for (auto& l : h->nv) { if (own && l.w) hipFree(l.w); if (own && l.b) hipFree(l.b); if (l.out) hipFree(l.out); }
   h->nv.clear();
-  if (own) for (auto& st : h->nv_plan) { if (st.we) hipFree(st.we); if (st.wp) hipFree(st.wp); if (st.bp) hipFree(st.bp); if (st.w0) hipFree(st.w0); }
+  if (own) for (auto& st : h->nv_plan) { if (st.we) hipFree(st.we); if (st.wp) hipFree(st.wp); if (st.bp) hipFree(st.bp); if (st.w0) hipFree(st.w0); if (st.wp2) hipFree(st.wp2); if (st.bp2) hipFree(st.bp2); }
   h->nv_plan.clear();
   for (float** p : {&h->nv_pre_w, &h->nv_pre_b, &h->nv_aw, &h->nv_aw_pack, &h->nv_ab, &h->nv_cen})
     if (*p) { if (own) hipFree(*p); *p = nullptr; }
@@ -835,7 +835,8 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     const auto& st = h->nv_plan[si];
     const bool next_fused = si + 1 < h->nv_plan.size() && h->nv_plan[si + 1].fused;
     // nv_xblock_kernel (stride-2 blocks) and nv_tail_kernel read ONE input slab: their producer's partial slabs are summed first
-    const bool next_single = next_fused && ((h->nv_plan[si + 1].xblock && !h->nv_plan[si + 1].pblock) || h->nv_plan[si + 1].tail);
+    const bool next_single = next_fused && ((h->nv_plan[si + 1].xblock && !h->nv_plan[si + 1].pblock) || h->nv_plan[si + 1].tail ||
+                                            (h->nv_plan[si + 1].pblock && !h->nv_plan[si + 1].front && nv_pblock_single_input(h->nv[h->nv_plan[si + 1].l0].cin)));
     if (!st.fused) {
       auto& l = h->nv[st.l0];
       const float* in = st.l0 ? h->nv[st.l0 - 1].out : nullptr;
@@ -914,6 +915,14 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
       a.stamps = h->nv_stamps; h->nv_stamp_wgs = (int)(tiles * groups);
     }
     if (st.pblock && st.front) HIP_TRY(launch_nv_fpair(a, n, s));
+    else if (st.pblock && st.wp2) {
+      // more than 128 output channels: two launches over channel halves, each with its own project record (the expand + depthwise stages run in both)
+      NvBlockArgs h0 = a, h1 = a;
+      h0.co0 = 0; h0.Cv = nv_pblock_half_cout(a.Cout, 0);
+      h1.co0 = h0.Cv; h1.Cv = a.Cout - h0.Cv; h1.wp = st.wp2; h1.bp = st.bp2; h1.stamps = nullptr;
+      HIP_TRY(launch_nv_pblock(h0, n, groups, s));
+      HIP_TRY(launch_nv_pblock(h1, n, groups, s));
+    }
     else if (st.pblock) HIP_TRY(launch_nv_pblock(a, n, groups, s));
     else if (st.xblock) HIP_TRY(launch_nv_xblock(a, n, groups, s));
     else HIP_TRY(launch_nv_block(a, st.expand, st.front ? 1 : 0, n, groups, s));
@@ -1013,23 +1022,28 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
       d2fe_context::NvStep st;
       st.l0 = st.l1 = i;
       if (!legacy) {
+        const bool pair_on = d2fe_dev_env("D2FE_NV_PAIR", 1) != 0;
+        // pixel-pair forms (netvlad_pair.hip): the first block with a first conv of 16 / 24 / 32 channels, stride-1 expand blocks of the widths in NVP_SHAPES
+        const bool fp_ok = pair_on && K(i) == D2FE_NV_CONV && K(i + 1) == D2FE_NV_DW && K(i + 2) == D2FE_NV_PW &&
+                           nv_fpair_supported(h->nv[i].cout, h->nv[i].stride, h->nv[i + 1].stride, h->nv[i + 2].cout);
+        const bool pb_ok = pair_on && i > 0 && K(i) == D2FE_NV_PW && K(i + 1) == D2FE_NV_DW && K(i + 2) == D2FE_NV_PW &&
+                           nv_pblock_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride);
         if (K(i) == D2FE_NV_CONV && K(i + 1) == D2FE_NV_DW && K(i + 2) == D2FE_NV_PW && h->nv[i + 1].res < 0 && h->nv[i + 2].res < 0 &&
-            nv_block_supported(h->nv[i + 1].cin, h->nv[i + 1].cin, h->nv[i + 2].cout, h->nv[i + 1].stride, false, 1)) {
+            (fp_ok || nv_block_supported(h->nv[i + 1].cin, h->nv[i + 1].cin, h->nv[i + 2].cout, h->nv[i + 1].stride, false, 1))) {
           st.fused = true; st.front = true; st.l1 = i + 2;
-          {       // pixel-pair form of the first block too (netvlad_pair.hip)
-            st.pblock = d2fe_dev_env("D2FE_NV_PAIR", 1) != 0 && nv_fpair_supported(h->nv[i].cout, h->nv[i].stride, h->nv[i + 1].stride, h->nv[i + 2].cout); }
+          st.pblock = fp_ok;
         } else if (i > 0 && K(i) == D2FE_NV_PW && K(i + 1) == D2FE_NV_DW && K(i + 2) == D2FE_NV_PW && h->nv[i].res < 0 &&
-                   nv_block_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride, true, 0)) {
+                   (pb_ok || nv_block_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride, true, 0))) {
           st.fused = true; st.expand = true; st.l1 = i + 2;
           {       // input-in-registers form of the block where the shape allows it (otherwise the LDS-resident form)
             st.xblock = d2fe_dev_env("D2FE_NV_XBLOCK", 1) != 0 && nv_xblock_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride);
-            // stride 1: the pixel-pair form of the same block (netvlad_pair.hip; D2FE_NV_PAIR=0: nv_xblock_kernel)
-            st.pblock = st.xblock && d2fe_dev_env("D2FE_NV_PAIR", 1) != 0 && nv_pblock_supported(h->nv[i].cin, h->nv[i].cout, h->nv[i + 2].cout, h->nv[i + 1].stride); }
+            // stride 1: the pixel-pair form of the same block (netvlad_pair.hip; D2FE_NV_PAIR=0: nv_xblock_kernel / nv_block_kernel)
+            st.pblock = pb_ok; }
         } else if (i > 0 && K(i) == D2FE_NV_DW && K(i + 1) == D2FE_NV_PW &&
                    nv_block_supported(h->nv[i].cin, h->nv[i].cin, h->nv[i + 1].cout, h->nv[i].stride, false, 0)) {
           st.fused = true; st.l1 = i + 1;
         } else if (i > 0 && i == nl - 1 && K(i) == D2FE_NV_PW && h->nv[i].res < 0 &&
-                   nv_block_supported(h->nv[i].cin, h->nv[i].cout, w->proj_dim, 1, true, 2)) {
+                   (nv_tail_supported(h->nv[i].cin, w->proj_dim) || nv_block_supported(h->nv[i].cin, h->nv[i].cout, w->proj_dim, 1, true, 2))) {
           st.fused = true; st.tail = true; st.expand = true;        // last 1x1 of the trunk + the NetVLAD pre-projection in one launch
         }
         // a residual must read a tensor that exists in HBM: the output of an earlier step
@@ -1059,18 +1073,29 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
         const float* pwt = st.tail ? w->pre_w : w->layers[li + 1].weight;
         const float* pbs = st.tail ? w->pre_b : w->layers[li + 1].bias;
         const int pco = st.tail ? w->proj_dim : w->layers[li + 1].cout, pci = st.tail ? w->feat_dim : w->layers[li + 1].cin;
-        const int nt = nv_block_ntiles(pco);
+        // pixel-pair kernels: any n-tile count up to 8 per launch, wider outputs as two channel halves (each with its own project record and bias)
+        const int halves = st.pblock ? nv_pblock_halves(pco) : 1, pco0 = st.pblock ? nv_pblock_half_cout(pco, 0) : pco;
+        const int nt = st.pblock ? nv_pblock_ntiles(pco0) : nv_block_ntiles(pco);
         std::vector<float> pk(st.pblock ? pack_nv_dwproj_pair_floats(pci, nt) : pack_nv_dwproj_floats(pci, nt)), pb(nt * 16, 0.f);
-        if (st.pblock) pack_nv_dwproj_pair(w->layers[li].weight, w->layers[li].bias, pwt, pco, pci, nt, pk.data());
+        if (st.pblock) pack_nv_dwproj_pair(w->layers[li].weight, w->layers[li].bias, pwt, pco0, pci, nt, pk.data(), 0);
         else if (st.tail && nv_tail_supported(w->layers[st.l0].cin, w->proj_dim)) pack_nv_proj_t(pwt, pco, pci, nt, pk.data());
         else if (st.xblock && !st.tail) pack_nv_dwproj_x(w->layers[li].weight, w->layers[li].bias, pwt, pco, pci, nt, pk.data());
         else pack_nv_dwproj(st.tail ? nullptr : w->layers[li].weight, st.tail ? nullptr : w->layers[li].bias, pwt, pco, pci, nt, pk.data());
-        for (int co = 0; co < pco; ++co) pb[co] = pbs[co];
+        for (int co = 0; co < pco0; ++co) pb[co] = pbs[co];
         h->nv_plan.push_back(st);
         auto& ds = h->nv_plan.back();
         int rc = upload(pk.data(), pk.size() * sizeof(float), reinterpret_cast<void**>(&ds.wp));
         rc = rc ? rc : upload(pb.data(), pb.size() * sizeof(float), reinterpret_cast<void**>(&ds.bp));
         if (rc) return rc;
+        if (halves == 2) {
+          const int pco1 = pco - pco0, nt1 = nv_pblock_ntiles(pco1);
+          std::vector<float> pk1(pack_nv_dwproj_pair_floats(pci, nt1)), pb1(nt1 * 16, 0.f);
+          pack_nv_dwproj_pair(w->layers[li].weight, w->layers[li].bias, pwt, pco1, pci, nt1, pk1.data(), pco0);
+          for (int co = 0; co < pco1; ++co) pb1[co] = pbs[pco0 + co];
+          rc = upload(pk1.data(), pk1.size() * sizeof(float), reinterpret_cast<void**>(&ds.wp2));
+          rc = rc ? rc : upload(pb1.data(), pb1.size() * sizeof(float), reinterpret_cast<void**>(&ds.bp2));
+          if (rc) return rc;
+        }
         if (st.tail) {
           h->nv_feat_gmax = std::max(1, std::min(16, w->feat_dim / 32));
         } else if (h->nv[st.l1].act == 0) {
@@ -1861,7 +1886,7 @@ int d2fe_debug_netvlad_tile(int kind, int Ho, int Wo, int stride, int* th, int* 
 long d2fe_debug_pack_netvlad(int kind, const float* we, const float* be, const float* wd, const float* bd, const float* wp, int cin, int chid,
                              int cout, float* out, long max_floats) {
   if (!out || cin < 8 || (cin & 7) || chid < 16 || (chid & 15) || cout < 1) return fail(D2FE_ERR_INVALID, "bad argument");
-  const int nt = nv_block_ntiles(cout);
+  const int nt = kind <= 1 ? nv_pblock_ntiles(cout) : nv_block_ntiles(cout);
   if (nt < 0) return fail(D2FE_ERR_UNSUPPORTED, "cout");
   size_t n = 0;
   switch (kind) {

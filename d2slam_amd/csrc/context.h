@@ -109,7 +109,8 @@ struct d2fe_context {
   std::vector<NvLayer> nv;
   // execution plan over the flat layer list: fused MobileNetV2 blocks (netvlad_fused.hip) where the pattern matches, single layers otherwise;
   // only the LAST layer of a step is materialised in HBM (NvLayer::out), everything inside a fused block lives in LDS
-  struct NvStep { int l0 = 0, l1 = 0; bool fused = false, expand = false, front = false, tail = false, xblock = false, pblock = false; float* we = nullptr; float* wp = nullptr; float* bp = nullptr; float* w0 = nullptr; };
+  struct NvStep { int l0 = 0, l1 = 0; bool fused = false, expand = false, front = false, tail = false, xblock = false, pblock = false; float* we = nullptr; float* wp = nullptr; float* bp = nullptr; float* w0 = nullptr;
+                  float* wp2 = nullptr; float* bp2 = nullptr; };      // pblock with more than 128 output channels: the second channel half's project record / bias (netvlad_pair.hip)
   int nv_feat_gmax = 1, nv_feat_slabs = 1; long nv_feat_slab_stride = 0;
   // scheduling knobs of the fused plan, read from the environment by d2fe_load_netvlad (A/B measurements; defaults measured best):
   // workgroups per launch the hidden-channel split aims at (D2FE_NV_BLOCKS), the same for the tail kernel (D2FE_NV_TAIL_BLOCKS),

@@ -126,6 +126,7 @@ struct NvBlockArgs {
   float* out; long out_slab_stride;      // NHWC [n][Ho][Wo][Cout]; hidden-channel group g writes slab g
   const float* res; int res_slabs; long res_slab_stride;   // residual: same shape as out (sum of res_slabs slabs) or null
   int H, W, Cin, Chid, Cout, stride, Ho, Wo, pt, pl;
+  int co0, Cv;                     // nv_pblock_kernel: this launch computes output channels co0 .. co0 + Cv - 1 of the Cout (Cv = 0: all of them)
   long P;                          // mode 2: number of pixels in the flat list
   int th, tw;                      // nv_xblock_kernel: output tile (th x tw <= 128 pixels)
   unsigned inv_iw, inv_tw;         // ceil(2^20 / d) for d = patch width, tile width: n / d = (n * inv) >> 20 for n < 1024 (filled in by the launcher)
@@ -163,7 +164,11 @@ void nv_pblock_tile(int Ho, int Wo, int* th, int* tw, int c0_stride = 0);
 size_t pack_nv_expand_pair_floats(int chid, int cin);
 void pack_nv_expand_pair(const float* w, const float* b, int chid, int cin, float* dst);
 size_t pack_nv_dwproj_pair_floats(int chid, int nt);
-void pack_nv_dwproj_pair(const float* wd, const float* bd, const float* wp, int cout, int chid, int nt, float* dst);
+void pack_nv_dwproj_pair(const float* wd, const float* bd, const float* wp, int cout, int chid, int nt, float* dst, int co0 = 0);     // `cout` output channels from row co0 of wp
+int nv_pblock_ntiles(int cout);           // n-tiles of one launch (1..8), -1 beyond 128 channels
+int nv_pblock_halves(int cout);           // launches a block of `cout` output channels takes (1, or 2 beyond 128), -1 beyond 256
+int nv_pblock_half_cout(int cout, int half);
+bool nv_pblock_single_input(int cin);     // the kernel of this input width reads ONE input slab (its producer's partial slabs are summed first)
 hipError_t launch_nv_pblock(const NvBlockArgs& a, int n, int groups, hipStream_t s);
 bool nv_fpair_supported(int c0_cout, int c0_stride, int dw_stride, int cout);      // the first block (conv from u8 -> dw -> pw) in the same form
 hipError_t launch_nv_fpair(const NvBlockArgs& a, int n, hipStream_t s);

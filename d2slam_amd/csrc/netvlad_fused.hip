@@ -717,8 +717,9 @@ hipError_t launch_nv_xblock(const NvBlockArgs& a_in, int n, int groups, hipStrea
 // just the two weight double buffers (35 KB: four workgroups per CU instead of one).  A float4 load hands a lane 4 CONSECUTIVE input
 // channels of its pixel, so the K dimension is walked in the permuted order k = (lq + 4 j) * 4 + e (j = load, e = element); the host
 // packs the expand fragments in the same order (pack_nv_expand_tail).
+// NJ = Cin / 16: 7 / 8 (MobileNetV2 x 0.35 / 0.4: three workgroups per CU) and 15 (x 0.75, Cin = 240: 120 input registers per lane, two per CU).
 template <int NJ, int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void nv_tail_kernel(NvBlockArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJ > 8 ? 2 : 3, NJ > 8 ? 2 : 3))) void nv_tail_kernel(NvBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CIN = NJ * 16, KSE1 = CIN / 4 + 1, WE_N = nvb_we_rec(CIN), WD_N = nvb_wd_rec(NT);
   constexpr int WER = WE_N / 256, WDR = WD_N / 256;
@@ -839,11 +840,11 @@ void pack_nv_expand_tail(const float* w /*[chid][cin]*/, const float* b, int chi
     for (int c = 0; c < 16; ++c) d[(cin / 4) * 64 + c] = b[ch * 16 + c];
   }
 }
-bool nv_tail_supported(int cin, int cout) { return (cin == 112 || cin == 128) && nv_block_ntiles(cout) == 8; }
+bool nv_tail_supported(int cin, int cout) { return (cin == 112 || cin == 128 || cin == 240) && nv_block_ntiles(cout) == 8; }
 hipError_t launch_nv_tail(const NvBlockArgs& a, int groups, hipStream_t s) {
   if (a.P * (long)std::max(a.Cin, a.Cout) >= (1l << 31) || a.in_slabs > 1) return hipErrorInvalidValue;
   const size_t lds = sizeof(float) * (2 * (size_t)nvb_we_rec(a.Cin) + 2 * (size_t)nvb_wd_rec(8));
-  auto k = a.Cin == 112 ? nv_tail_kernel<7, 8> : nv_tail_kernel<8, 8>;
+  auto k = a.Cin == 112 ? nv_tail_kernel<7, 8> : a.Cin == 128 ? nv_tail_kernel<8, 8> : nv_tail_kernel<15, 8>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((unsigned)((a.P + 127) / 128), 1, groups), dim3(256), lds, s, a);

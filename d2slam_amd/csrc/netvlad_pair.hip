@@ -35,25 +35,57 @@ __device__ __forceinline__ float nvp_clamp(float v, float lo, float hi) { return
 constexpr int NVP_EROW = 256, NVP_EBUF = 16 * NVP_EROW, NVP_PATCH = 192;      // patch pixels = 12 m-tiles, 3 per wave
 constexpr int NVP_U8_PITCH = 40, NVP_U8_ROWS = 24, NVP_U8_DUMMY = 2 * NVP_U8_PITCH + 8;      // first block: u8 copy of the patch's receptive field, (10 - 1) * 2 + 3 = 21 rows x 37 bytes at stride 2
 __host__ __device__ constexpr int nvp_we_rec(int nk) { return (nk * 64 + 16 + 255) / 256 * 256; }      // [nk/4][lane][4] (+ [lane][2]) + bias[16]
-__host__ __device__ constexpr int nvp_wd_rec(int nt) { return 256 + nt * 256; }                         // [lq][ks][12] + pad, [ks][nt/ntv][lane][ntv]
+// project B fragments of one k-step: the n-tiles in groups that ONE LDS read fetches per lane -- nt / 4 groups of four ([lane][4], ds_read_b128), then the remaining
+// 1 / 2 / 3 n-tiles as [lane][1] (b32), [lane][2] (b64) or [lane][4] with the last float unused (b128).  nt = 1, 2, 4, 8 are the layouts of rounds 3-5
+__host__ __device__ constexpr int nvp_rem_width(int nt) { return nt % 4 == 3 ? 4 : nt % 4; }
+__host__ __device__ constexpr int nvp_ks_floats(int nt) { return 64 * (4 * (nt / 4) + nvp_rem_width(nt)); }
+__host__ __device__ constexpr int nvp_wd_rec(int nt) { return (256 + 4 * nvp_ks_floats(nt) + 255) / 256 * 256; }      // [lq][ks][12] + pad, [ks][groups as above]
 __host__ __device__ constexpr int nvp_row(int c) { return c * NVP_EROW + 4 * (c & 7) + 32 * (c >> 3); }
 
 // waves per SIMD the register allocation must leave room for (unified VGPR + AGPR file, 512 per lane): what the launches of this network need to be
 // resident in ONE round -- 640 workgroups of <2, 8> on 256 CUs need 3 per CU, 1280 of <1, 4> need 5; left alone the compiler settles for 2 and 4
-__host__ __device__ constexpr int nvp_min_waves(int nt, int nk) { return nt == 1 ? 5 : nt == 2 ? 3 : 2; }
+__host__ __device__ constexpr int nvp_min_waves(int nt, int nk) { return nt == 1 ? (nk <= 4 ? 5 : nk <= 8 ? 4 : 3) : nt == 2 ? (nk <= 8 ? 3 : 2) : 2; }
+// Cin >= 120 (30 k-steps: 90 input registers per lane): no second register set for a producer's partial slabs -- the input must be ONE slab (run_netvlad sums first)
+__host__ __device__ constexpr bool nvp_multi_in(int nk) { return nk < 30; }
+// project stage of one k-step: the pair's two depthwise outputs (even pixel -> m-tile 0, odd pixel -> m-tile 1) against the NT n-tiles of B fragments at `wks`
+template <int NT>
+__device__ __forceinline__ void nvp_project(const float* wks, int lane, float d0, float d1, f32x4 (&acc)[2][NT]) {
+  constexpr int NG4 = NT / 4, REM = NT % 4;
+#pragma unroll
+  for (int hf = 0; hf < NG4; ++hf) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(wks + (hf * 64 + lane) * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[0][hf * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d0, v[e], acc[0][hf * 4 + e], 0, 0, 0);
+      acc[1][hf * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1, v[e], acc[1][hf * 4 + e], 0, 0, 0);
+    }
+  }
+  if constexpr (REM != 0) {
+    float wv[REM];
+    const float* wr = wks + NG4 * 256;
+    if constexpr (REM == 3) { const f32x4 v = *reinterpret_cast<const f32x4*>(wr + lane * 4); wv[0] = v[0]; wv[1] = v[1]; wv[2] = v[2]; }
+    else if constexpr (REM == 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(wr + lane * 2); wv[0] = v[0]; wv[1] = v[1]; }
+    else wv[0] = wr[lane];
+#pragma unroll
+    for (int e = 0; e < REM; ++e) {
+      acc[0][NG4 * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d0, wv[e], acc[0][NG4 * 4 + e], 0, 0, 0);
+      acc[1][NG4 * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1, wv[e], acc[1][NG4 * 4 + e], 0, 0, 0);
+    }
+  }
+}
+
 template <int NT, int NK, int NBUF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_waves(NT, NK)))) void nv_pblock_kernel(NvBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WE_N = nvp_we_rec(NK), WD_N = nvp_wd_rec(NT), WER = WE_N / 256, WDR = WD_N / 256;
-  constexpr int NK4 = NK / 4, NK2 = (NK % 4) / 2;
-  constexpr int NTV = NT < 4 ? NT : 4, NTH = NT / NTV;
+  constexpr int NK4 = NK / 4, NK2 = (NK % 4) / 2, KSF = nvp_ks_floats(NT);
   static_assert(NK % 2 == 0, "Cin must be a multiple of 8");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane >> 4, lp = lane & 15;
   float* E = lds;                         // [NBUF][16 rows, NVP_EROW pitch, swizzled starts]
   float* WE = E + NBUF * NVP_EBUF;        // [2][WE_N]
   float* WD = WE + 2 * WE_N;              // [2][WD_N]
-  const int Cin = a.Cin, Cout = a.Cout, th = a.th, tw = a.tw, pw = tw >> 1;
+  const int Cin = a.Cin, Cout = a.Cout, Cv = a.Cv, th = a.th, tw = a.tw, pw = tw >> 1;        // this launch computes output channels co0 .. co0 + Cv - 1 of the Cout
   const int iw = tw + 2, npx = (th + 2) * iw;
   const int tiles_x = (a.Wo + tw - 1) / tw;
   const int n = blockIdx.y;
@@ -80,7 +112,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
     const int oy = (int)(((unsigned)P * a.inv_tw) >> 20), px = P - oy * pw;
     const int gy = oy0 + oy, gx = ox0 + 2 * px;
     const bool okp = P < th * pw && gy < a.Ho && gx < a.Wo;
-    obase[r] = okp ? (gy * a.Wo + gx) * Cout + lp : -1;
+    obase[r] = okp ? (gy * a.Wo + gx) * Cout + a.co0 + lp : -1;
     ok2[r] = okp && gx + 1 < a.Wo;
   }
   // every global load of the prologue is issued before anything waits on one: batches per slab, no load inside a run-time loop (a loop over the
@@ -96,7 +128,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int t = 0; t < (RES_EARLY ? NT : 1); ++t) {
-          const bool okr = obase[r] >= 0 && (m2 == 0 || ok2[r]) && t * 16 + lp < Cout;
+          const bool okr = obase[r] >= 0 && (m2 == 0 || ok2[r]) && t * 16 + lp < Cv;
           resv[m2][r][t] = rp[okr ? (unsigned)(obase[r] + m2 * Cout + t * 16) : 0u];
         }
     if (a.res_slabs > 1) {
@@ -107,7 +139,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int t = 0; t < (RES_EARLY ? NT : 1); ++t) {
-            const bool okr = obase[r] >= 0 && (m2 == 0 || ok2[r]) && t * 16 + lp < Cout;
+            const bool okr = obase[r] >= 0 && (m2 == 0 || ok2[r]) && t * 16 + lp < Cv;
             r1[m2][r][t] = rp1[okr ? (unsigned)(obase[r] + m2 * Cout + t * 16) : 0u];
           }
       for (int sl = 2; sl < a.res_slabs; ++sl)
@@ -117,7 +149,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int t = 0; t < (RES_EARLY ? NT : 1); ++t) {
-              const bool okr = obase[r] >= 0 && (m2 == 0 || ok2[r]) && t * 16 + lp < Cout;
+              const bool okr = obase[r] >= 0 && (m2 == 0 || ok2[r]) && t * 16 + lp < Cv;
               r1[m2][r][t] += (rp + (size_t)sl * a.res_slab_stride)[okr ? (unsigned)(obase[r] + m2 * Cout + t * 16) : 0u];
             }
     }
@@ -157,7 +189,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
   };
   bool okm[3]; unsigned offm[3];
   const float* ip = a.in + (size_t)n * a.H * a.W * Cin;
-  float x1[3][NK];
+  constexpr bool MULTI_IN = nvp_multi_in(NK);
+  float x1[3][MULTI_IN ? NK : 1];
   {
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
@@ -176,7 +209,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
         maskc[m][r] = (pc < npx && hy >= 0 && hy < a.H && hx >= 0 && hx < a.W) ? 1.f : 0.f;
       }
     }
-    if (a.in_slabs > 1) {
+    if constexpr (MULTI_IN) if (a.in_slabs > 1) {
 #pragma unroll
       for (int m = 0; m < 3; ++m)
 #pragma unroll
@@ -213,7 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
 #pragma unroll
         for (int t = 0; t < (RES_EARLY ? NT : 1); ++t) resv[m2][r][t] += r1[m2][r][t];
   }
-  if (a.in_slabs > 1) {
+  if constexpr (MULTI_IN) if (a.in_slabs > 1) {
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
@@ -291,19 +324,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
         d = __builtin_elementwise_fma(B, f32x2{tap[ky * 3 + 2], tap[ky * 3 + 2]}, d);
       }
       d[0] = nvp_clamp(d[0], lo_d, hi_d); d[1] = nvp_clamp(d[1], lo_d, hi_d);
-      const float* wpl = wd + 256 + (ks * NTH * 64 + lane) * NTV;
-#pragma unroll
-      for (int hf = 0; hf < NTH; ++hf) {
-        float wv[NTV];
-        if constexpr (NTV == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(wpl + hf * 256); wv[0] = v[0]; wv[1] = v[1]; wv[2] = v[2]; wv[3] = v[3]; }
-        else if constexpr (NTV == 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(wpl); wv[0] = v[0]; wv[1] = v[1]; }
-        else wv[0] = wpl[0];
-#pragma unroll
-        for (int e = 0; e < NTV; ++e) {
-          acc[0][hf * NTV + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[0], wv[e], acc[0][hf * NTV + e], 0, 0, 0);
-          acc[1][hf * NTV + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[1], wv[e], acc[1][hf * NTV + e], 0, 0, 0);
-        }
-      }
+      nvp_project<NT>(wd + 256 + ks * KSF, lane, d[0], d[1], acc);
     }
     STAMP();
     if (ch + 1 < ch1) store_wd(wb_i ^ 1);              // everybody passed this chunk's barrier, so chunk ch - 1 is done with WD[wb_i ^ 1]
@@ -316,7 +337,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
   const float lo_p = nvp_lo(a.act_p), hi_p = nvp_hi(a.act_p);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    if (t * 16 + lp >= Cout) continue;
+    if (t * 16 + lp >= Cv) continue;
     const float bv = lead ? bvv[t] : 0.f;
 #pragma unroll
     for (int m2 = 0; m2 < 2; ++m2)
@@ -339,17 +360,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
 // walked the u8 patch in a run-time loop: four memory round trips per workgroup, and was bound by the LDS reads of its per-pixel depthwise stage).
 //   conv: M = patch pixels (12 m-tiles), K = 9 taps + 1 bias row (+ 2 zero rows), N = 16; A = (u8 - 128) / 128 read from the u8 copy in LDS; a pixel
 //   outside the conv's output map zeroes its whole A row, bias included, so the depthwise stage sees its zero padding.
-template <int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 7 : NT == 2 ? 5 : NT == 4 ? 4 : 2))) void nv_fpair_kernel(NvBlockArgs a) {
+// NCH = chunks of 16 hidden channels: 1 for a first conv of <= 16 output channels (MobileNetV2 x 0.35 / 0.5), 2 for <= 32 (x 0.75: 24, x 1.0: 32; the
+// second chunk's missing channels are zero weights, whose ReLU6(0) contributes exact zeros).  With two chunks the conv stage runs once per chunk over the
+// same u8 copy, into the same E rows, and the project accumulators run over both.
+template <int NT, int NCH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? (NCH == 1 ? 7 : 5) : NT == 2 ? (NCH == 1 ? 5 : 4) : NT <= 4 ? 4 : 2))) void nv_fpair_kernel(NvBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int WD_N = nvp_wd_rec(NT), WDR = WD_N / 256;
-  constexpr int NTV = NT < 4 ? NT : 4, NTH = NT / NTV;
+  constexpr int WD_N = nvp_wd_rec(NT), WDR = NCH * WD_N / 256, KSF = nvp_ks_floats(NT);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane >> 4, lp = lane & 15;
   float* E = lds;                                   // [16 rows], as nv_pblock_kernel
-  float* WD = E + NVP_EBUF;                         // [WD_N]
-  float* W0 = WD + WD_N;                            // [3][64] B fragments of the conv (n-tile 0 of pack_nv_conv0's [3][2][64])
-  uint8_t* U8 = reinterpret_cast<uint8_t*>(W0 + 192);      // [NVP_U8_ROWS][NVP_U8_PITCH]
+  float* WD = E + NVP_EBUF;                         // [NCH][WD_N]
+  float* W0 = WD + NCH * WD_N;                      // [NCH][3][64] B fragments of the conv (n-tile chunk of pack_nv_conv0's [3][2][64])
+  uint8_t* U8 = reinterpret_cast<uint8_t*>(W0 + NCH * 192);      // [NVP_U8_ROWS][NVP_U8_PITCH]
   const int Cout = a.Cout, th = a.th, tw = a.tw, pw = tw >> 1;
   const int iw = tw + 2, npx = (th + 2) * iw;
   const int tiles_x = (a.Wo + tw - 1) / tw, ntiles = tiles_x * ((a.Ho + th - 1) / th);
@@ -417,14 +440,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 7
   };
   // ---- one batch of loads: first u8 patch, conv fragments, depthwise + project record, project bias ---------------------------------------------
   if (t_begin < t_end) load_u8(t_begin);
-  const float w0v = tid < 192 ? a.w0[(tid >> 6) * 128 + (tid & 63)] : 0.f;
+  float w0v[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) w0v[c] = tid < 192 ? a.w0[(tid >> 6) * 128 + c * 64 + (tid & 63)] : 0.f;
   float wds[WDR];
 #pragma unroll
   for (int i = 0; i < WDR; ++i) wds[i] = a.wp[i * 256 + tid];
   float bvv[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) bvv[t] = a.bp[t * 16 + lp];
-  if (tid < 192) W0[tid] = (tid >> 6) * 4 + ((tid & 63) >> 4) < 9 ? w0v * 0.0078125f : w0v;       // tap rows carry the 1 / 128
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    if (tid < 192) W0[c * 192 + tid] = (tid >> 6) * 4 + ((tid & 63) >> 4) < 9 ? w0v[c] * 0.0078125f : w0v[c];       // tap rows carry the 1 / 128
   if (tid < NVP_U8_DUMMY) U8[NVP_U8_ROWS * NVP_U8_PITCH + tid] = 128;                               // the all-128 window of pixels outside the map
 #pragma unroll
   for (int i = 0; i < WDR; ++i) WD[i * 256 + tid] = wds[i];
@@ -450,75 +477,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 7
     STAMP();
     if (t + 1 < t_end) load_u8(t + 1);
 
-    // ---- first conv on the matrix pipe -> E rows (channel lp, pixels 4 lq .. + 3 of m-tile mt) ------------------------------------------------
-    // A = u8 - 128 (the 1/128 of the normalisation sits in the tap rows of B: a power of two, so every product and the result are bit-identical to
-    // ((u8 - 128) / 128) * w); a pixel outside the conv's output reads the all-128 dummy window, i.e. zeros, and gets no bias
-    {
-      float wf[3];
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks) wf[ks] = W0[ks * 64 + lane];
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        const int cy = c_yx[m] >> 8, cx = c_yx[m] & 255;
-        const int gy = iy0 + cy, gx = ix0 + cx;
-        const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const uint8_t* up = U8 + (ok ? (cy * cs) * NVP_U8_PITCH + cx * cs : NVP_U8_ROWS * NVP_U8_PITCH);
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-          float av = (float)up[toff[ks]] - 128.0f;           // k = 4 ks + lq: a tap for k < 9 (toff), the bias row for k == 9, nothing beyond
-          if (ks == 2) av = lq == 0 ? av : (lq == 1 && ok ? 1.f : 0.f);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wf[ks], c, 0, 0, 0);
-        }
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = nvp_clamp(c[r], lo0, hi0);
-        *reinterpret_cast<f32x4*>(E + wr0 + (wave + 4 * m) * 16) = o;
-      }
-    }
-    STAMP();
-    __syncthreads();
-    STAMP();
-
-    // ---- depthwise (pixel pairs) + project, as one chunk of nv_pblock_kernel ---------------------------------------------------------------------
     f32x4 acc[2][NT];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) acc[m][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
-      const float* r0 = E + rd0;
-      const float* r1 = r0 + iw;
-      const float* r2 = r1 + iw;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const f32x4 wa = *reinterpret_cast<const f32x4*>(WD + (lq * 4 + ks) * 12);
-        const f32x4 wb = *reinterpret_cast<const f32x4*>(WD + (lq * 4 + ks) * 12 + 4);
-        const f32x4 wc = *reinterpret_cast<const f32x4*>(WD + (lq * 4 + ks) * 12 + 8);
-        const float tap[9] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3], wc[0]};
-        f32x2 d = {wc[1], wc[1]};
-        const float* rr[3] = {r0, r1, r2};
+    for (int chn = 0; chn < NCH; ++chn) {
+      if (chn > 0) __syncthreads();          // everybody is done reading the previous chunk's E rows
+      // ---- first conv on the matrix pipe -> E rows (channel lp of this chunk, pixels 4 lq .. + 3 of m-tile mt) ---------------------------------
+      // A = u8 - 128 (the 1/128 of the normalisation sits in the tap rows of B: a power of two, so every product and the result are bit-identical to
+      // ((u8 - 128) / 128) * w); a pixel outside the conv's output reads the all-128 dummy window, i.e. zeros, and gets no bias
+      {
+        float wf[3];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const f32x2 A = *reinterpret_cast<const f32x2*>(rr[ky] + ks * 260);
-          const f32x2 B = *reinterpret_cast<const f32x2*>(rr[ky] + ks * 260 + 2);
-          d = __builtin_elementwise_fma(A, f32x2{tap[ky * 3], tap[ky * 3]}, d);
-          d = __builtin_elementwise_fma(f32x2{A[1], B[0]}, f32x2{tap[ky * 3 + 1], tap[ky * 3 + 1]}, d);
-          d = __builtin_elementwise_fma(B, f32x2{tap[ky * 3 + 2], tap[ky * 3 + 2]}, d);
-        }
-        d[0] = nvp_clamp(d[0], lo_d, hi_d); d[1] = nvp_clamp(d[1], lo_d, hi_d);
-        const float* wpl = WD + 256 + (ks * NTH * 64 + lane) * NTV;
+        for (int ks = 0; ks < 3; ++ks) wf[ks] = W0[chn * 192 + ks * 64 + lane];
 #pragma unroll
-        for (int hf = 0; hf < NTH; ++hf) {
-          float wv[NTV];
-          if constexpr (NTV == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(wpl + hf * 256); wv[0] = v[0]; wv[1] = v[1]; wv[2] = v[2]; wv[3] = v[3]; }
-          else if constexpr (NTV == 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(wpl); wv[0] = v[0]; wv[1] = v[1]; }
-          else wv[0] = wpl[0];
+        for (int m = 0; m < 3; ++m) {
+          const int cy = c_yx[m] >> 8, cx = c_yx[m] & 255;
+          const int gy = iy0 + cy, gx = ix0 + cx;
+          const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+          const uint8_t* up = U8 + (ok ? (cy * cs) * NVP_U8_PITCH + cx * cs : NVP_U8_ROWS * NVP_U8_PITCH);
+          f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int e = 0; e < NTV; ++e) {
-            acc[0][hf * NTV + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[0], wv[e], acc[0][hf * NTV + e], 0, 0, 0);
-            acc[1][hf * NTV + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[1], wv[e], acc[1][hf * NTV + e], 0, 0, 0);
+          for (int ks = 0; ks < 3; ++ks) {
+            float av = (float)up[toff[ks]] - 128.0f;           // k = 4 ks + lq: a tap for k < 9 (toff), the bias row for k == 9, nothing beyond
+            if (ks == 2) av = lq == 0 ? av : (lq == 1 && ok ? 1.f : 0.f);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wf[ks], c, 0, 0, 0);
           }
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = nvp_clamp(c[r], lo0, hi0);
+          *reinterpret_cast<f32x4*>(E + wr0 + (wave + 4 * m) * 16) = o;
+        }
+      }
+      STAMP();
+      __syncthreads();
+      STAMP();
+
+      // ---- depthwise (pixel pairs) + project, as one chunk of nv_pblock_kernel -------------------------------------------------------------------
+      {
+        const float* wdc = WD + chn * WD_N;
+        const float* r0 = E + rd0;
+        const float* r1 = r0 + iw;
+        const float* r2 = r1 + iw;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(wdc + (lq * 4 + ks) * 12);
+          const f32x4 wb = *reinterpret_cast<const f32x4*>(wdc + (lq * 4 + ks) * 12 + 4);
+          const f32x4 wc = *reinterpret_cast<const f32x4*>(wdc + (lq * 4 + ks) * 12 + 8);
+          const float tap[9] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3], wc[0]};
+          f32x2 d = {wc[1], wc[1]};
+          const float* rr[3] = {r0, r1, r2};
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const f32x2 A = *reinterpret_cast<const f32x2*>(rr[ky] + ks * 260);
+            const f32x2 B = *reinterpret_cast<const f32x2*>(rr[ky] + ks * 260 + 2);
+            d = __builtin_elementwise_fma(A, f32x2{tap[ky * 3], tap[ky * 3]}, d);
+            d = __builtin_elementwise_fma(f32x2{A[1], B[0]}, f32x2{tap[ky * 3 + 1], tap[ky * 3 + 1]}, d);
+            d = __builtin_elementwise_fma(B, f32x2{tap[ky * 3 + 2], tap[ky * 3 + 2]}, d);
+          }
+          d[0] = nvp_clamp(d[0], lo_d, hi_d); d[1] = nvp_clamp(d[1], lo_d, hi_d);
+          nvp_project<NT>(wdc + 256 + ks * KSF, lane, d[0], d[1], acc);
         }
       }
     }
@@ -545,9 +565,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 7
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------------------
+// n-tiles of 16 output channels one launch of the pixel-pair kernels computes: any count up to 8 (128 channels); wider outputs are computed in two
+// launches over channel halves (NvBlockArgs::co0 / Cv), each of which repeats the expand + depthwise stages
+int nv_pblock_ntiles(int cout) { const int nt = (cout + 15) / 16; return nt >= 1 && nt <= 8 ? nt : -1; }
+int nv_pblock_halves(int cout) { return cout <= 128 ? 1 : cout <= 256 ? 2 : -1; }
+int nv_pblock_half_cout(int cout, int half) { if (cout <= 128) return cout; const int c0 = (cout / 2 + 15) / 16 * 16; return half == 0 ? c0 : cout - c0; }
+static bool nvp_shape_exists(int nk, int nt);
+bool nv_pblock_single_input(int cin) { return !nvp_multi_in(cin / 4); }
 bool nv_pblock_supported(int cin, int chid, int cout, int stride) {
-  const int nk = cin / 4;
-  return stride == 1 && !(cin & 7) && !(chid & 15) && (nk == 2 || nk == 4 || nk == 6 || nk == 8 || nk == 14) && nv_block_ntiles(cout) > 0;
+  if (stride != 1 || (cin & 7) || (chid & 15) || nv_pblock_halves(cout) < 0) return false;
+  for (int hf = 0; hf < nv_pblock_halves(cout); ++hf)
+    if (!nvp_shape_exists(cin / 4, nv_pblock_ntiles(nv_pblock_half_cout(cout, hf)))) return false;
+  return true;
 }
 // tile: th x tw output pixels, tw even, th * tw / 2 <= 64 pairs, (th + 2)(tw + 2) <= 192 patch pixels; maximise the useful fraction of the MFMA rows
 // (c0_stride > 0: the first block -- the u8 receptive field of the patch must fit its LDS copy)
@@ -580,27 +609,31 @@ void pack_nv_expand_pair(const float* w /*[chid][cin]*/, const float* b, int chi
     for (int c = 0; c < 16; ++c) d[nk * 64 + c] = b[ch * 16 + c];
   }
 }
-size_t pack_nv_dwproj_pair_floats(int chid, int nt) { return (size_t)(chid / 16) * nvp_wd_rec(nt); }
-// depthwise + project record: [lq][ks][12] = 9 taps, bias, 0, 0 of hidden channel c(ks, lq) = ks + 4 (lq >> 1) + 8 (lq & 1); then at 256:
-// [ks][nt / ntv][lane][ntv] = Wp[t*16 + (lane & 15)][chunk*16 + c(ks, lane >> 4)]
-void pack_nv_dwproj_pair(const float* wd /*[chid][9]*/, const float* bd, const float* wp /*[cout][chid]*/, int cout, int chid, int nt, float* dst) {
-  const int rec = nvp_wd_rec(nt), ntv = nt < 4 ? nt : 4, nth = nt / ntv;
-  for (int ch = 0; ch < chid / 16; ++ch) {
+size_t pack_nv_dwproj_pair_floats(int chid, int nt) { return (size_t)((chid + 15) / 16) * nvp_wd_rec(nt); }
+// depthwise + project record: [lq][ks][12] = 9 taps, bias, 0, 0 of hidden channel c(ks, lq) = ks + 4 (lq >> 1) + 8 (lq & 1); then at 256 per k-step ks
+// (nvp_ks_floats(nt) floats each) the groups of n-tiles nvp_project reads: Wp[co0 + t*16 + (lane & 15)][chunk*16 + c(ks, lane >> 4)].  `cout` output channels
+// starting at row `co0` of wp; hidden channels beyond chid (a last chunk of fewer than 16: the first block's 24) are zero weights
+void pack_nv_dwproj_pair(const float* wd /*[chid][9]*/, const float* bd, const float* wp /*[..][chid]*/, int cout, int chid, int nt, float* dst, int co0) {
+  const int rec = nvp_wd_rec(nt), ksf = nvp_ks_floats(nt), ng4 = nt / 4, rem = nt % 4, remw = nvp_rem_width(nt);
+  for (int ch = 0; ch < (chid + 15) / 16; ++ch) {
     float* d = dst + (size_t)ch * rec;
     for (int i = 0; i < rec; ++i) d[i] = 0.f;
     for (int lq = 0; lq < 4; ++lq)
       for (int ks = 0; ks < 4; ++ks) {
         const int c = ch * 16 + ks + 4 * (lq >> 1) + 8 * (lq & 1);
+        if (c >= chid) continue;
         for (int t = 0; t < 9; ++t) d[(lq * 4 + ks) * 12 + t] = wd[(size_t)c * 9 + t];
         d[(lq * 4 + ks) * 12 + 9] = bd[c];
       }
     for (int ks = 0; ks < 4; ++ks)
-      for (int hf = 0; hf < nth; ++hf)
-        for (int l = 0; l < 64; ++l)
-          for (int e = 0; e < ntv; ++e) {
-            const int co = (hf * ntv + e) * 16 + (l & 15), lq = l >> 4, k = ch * 16 + ks + 4 * (lq >> 1) + 8 * (lq & 1);
-            d[256 + ((ks * nth + hf) * 64 + l) * ntv + e] = co < cout ? wp[(size_t)co * chid + k] : 0.f;
-          }
+      for (int l = 0; l < 64; ++l) {
+        const int lq = l >> 4, k = ch * 16 + ks + 4 * (lq >> 1) + 8 * (lq & 1);
+        auto W = [&](int t) { const int co = t * 16 + (l & 15); return (co < cout && k < chid) ? wp[(size_t)(co0 + co) * chid + k] : 0.f; };
+        float* dk = d + 256 + ks * ksf;
+        for (int hf = 0; hf < ng4; ++hf)
+          for (int e = 0; e < 4; ++e) dk[(hf * 64 + l) * 4 + e] = W(hf * 4 + e);
+        for (int e = 0; e < rem; ++e) dk[ng4 * 256 + l * remw + e] = W(ng4 * 4 + e);
+      }
   }
 }
 
@@ -617,7 +650,7 @@ static hipError_t launch_pblock_b(const NvBlockArgs& a, int n, int groups, hipSt
 static size_t nvp_lds_bytes(int nt, int nk, int nbuf) { return sizeof(float) * ((size_t)nbuf * NVP_EBUF + 2 * nvp_we_rec(nk) + 2 * nvp_wd_rec(nt)); }
 // workgroups of this block shape that can be resident at once (registers: nvp_min_waves; LDS with `nbuf` E buffers)
 long nv_pblock_slots(int cin, int cout, int ncu, int nbuf) {
-  const int nt = nv_block_ntiles(cout), nk = cin / 4;
+  const int nt = nv_pblock_ntiles(nv_pblock_half_cout(cout, 0)), nk = cin / 4;
   const long per_cu = std::min<long>(nvp_min_waves(nt, nk), (long)((160 * 1024) / nvp_lds_bytes(nt, nk, nbuf)));
   return (long)(ncu > 0 ? ncu : 256) * per_cu;
 }
@@ -631,23 +664,25 @@ static hipError_t launch_pblock_t(const NvBlockArgs& a, int n, int groups, hipSt
   const bool one = force ? force == 1 : wgs * 100 > nv_pblock_slots(a.Cin, a.Cout, a.ncu, 2) * 85;
   return one ? launch_pblock_b<NT, NK, 1>(a, n, groups, s) : launch_pblock_b<NT, NK, 2>(a, n, groups, s);
 }
-template <int NK>
-static hipError_t launch_pblock_nt(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
-  switch (nv_block_ntiles(a.Cout)) {
-    case 1: return launch_pblock_t<1, NK>(a, n, groups, s);
-    case 2: return launch_pblock_t<2, NK>(a, n, groups, s);
-    case 4: return launch_pblock_t<4, NK>(a, n, groups, s);
-    case 8: return launch_pblock_t<8, NK>(a, n, groups, s);
-  }
-  return hipErrorInvalidValue;
+// the (k-steps of the expand GEMM = Cin / 4, n-tiles of the project GEMM) pairs that exist as kernels: MobileNetV2 x 0.35 (rounds 3-5) and x 0.75 (round 6:
+// Cin 48 -> 48 / 72, 72 -> 72, 120 -> 120 and the two halves 128 + 112 of 120 -> 240) with their neighbours
+#define NVP_SHAPES(X) \
+  X(2, 1) X(2, 2) X(2, 4) X(2, 8) X(4, 1) X(4, 2) X(4, 4) X(4, 8) X(6, 1) X(6, 2) X(6, 3) X(6, 4) X(6, 8) X(8, 1) X(8, 2) X(8, 4) X(8, 8) \
+  X(12, 3) X(12, 4) X(12, 5) X(14, 1) X(14, 2) X(14, 4) X(14, 7) X(14, 8) X(18, 5) X(18, 8) X(30, 7) X(30, 8)
+static bool nvp_shape_exists(int nk, int nt) {
+#define X(K, T) if (nk == K && nt == T) return true;
+  NVP_SHAPES(X)
+#undef X
+  return false;
 }
 bool nv_fpair_supported(int c0_cout, int c0_stride, int dw_stride, int cout) {
-  return c0_cout == 16 && (c0_stride == 1 || c0_stride == 2) && dw_stride == 1 && nv_block_ntiles(cout) > 0;
+  const int nt = nv_pblock_ntiles(cout);
+  return (c0_cout == 16 || c0_cout == 24 || c0_cout == 32) && (c0_stride == 1 || c0_stride == 2) && dw_stride == 1 && (nt == 1 || nt == 2 || nt == 4 || nt == 8);
 }
-template <int NT>
+template <int NT, int NCH>
 static hipError_t launch_fpair_t(const NvBlockArgs& a, int n, hipStream_t s) {
-  const size_t lds = sizeof(float) * ((size_t)NVP_EBUF + nvp_wd_rec(NT) + 192) + NVP_U8_ROWS * NVP_U8_PITCH + NVP_U8_DUMMY;
-  auto k = nv_fpair_kernel<NT>;
+  const size_t lds = sizeof(float) * ((size_t)NVP_EBUF + NCH * (nvp_wd_rec(NT) + 192)) + NVP_U8_ROWS * NVP_U8_PITCH + NVP_U8_DUMMY;
+  auto k = nv_fpair_kernel<NT, NCH>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const long tiles = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th);
@@ -670,11 +705,12 @@ hipError_t launch_nv_fpair(const NvBlockArgs& a_in, int n, hipStream_t s) {
   const int iw = a.tw + 2, pw = a.tw / 2;
   a.inv_iw = ((1u << 20) + iw - 1) / iw; a.inv_tw = ((1u << 20) + pw - 1) / pw;
   if ((long)a.H0 * a.img_stride >= (1l << 31) || (long)a.Ho * a.Wo * a.Cout >= (1l << 31)) return hipErrorInvalidValue;
-  switch (nv_block_ntiles(a.Cout)) {
-    case 1: return launch_fpair_t<1>(a, n, s);
-    case 2: return launch_fpair_t<2>(a, n, s);
-    case 4: return launch_fpair_t<4>(a, n, s);
-    case 8: return launch_fpair_t<8>(a, n, s);
+  const bool two = a.Chid > 16;        // hidden channels = the first conv's outputs: one or two chunks of 16
+  switch (nv_pblock_ntiles(a.Cout)) {
+    case 1: return two ? launch_fpair_t<1, 2>(a, n, s) : launch_fpair_t<1, 1>(a, n, s);
+    case 2: return two ? launch_fpair_t<2, 2>(a, n, s) : launch_fpair_t<2, 1>(a, n, s);
+    case 4: return two ? launch_fpair_t<4, 2>(a, n, s) : launch_fpair_t<4, 1>(a, n, s);
+    case 8: return two ? launch_fpair_t<8, 2>(a, n, s) : launch_fpair_t<8, 1>(a, n, s);
   }
   return hipErrorInvalidValue;
 }
@@ -684,13 +720,13 @@ hipError_t launch_nv_pblock(const NvBlockArgs& a_in, int n, int groups, hipStrea
   const int iw = a.tw + 2, pw = a.tw / 2;
   a.inv_iw = ((1u << 20) + iw - 1) / iw; a.inv_tw = ((1u << 20) + pw - 1) / pw;       // exact for n < 2^20 / d: n < 256 here
   if ((long)a.H * a.W * a.Cin >= (1l << 31) || (long)a.Ho * a.Wo * a.Cout >= (1l << 31)) return hipErrorInvalidValue;
-  switch (a.Cin / 4) {
-    case 2: return launch_pblock_nt<2>(a, n, groups, s);
-    case 4: return launch_pblock_nt<4>(a, n, groups, s);
-    case 6: return launch_pblock_nt<6>(a, n, groups, s);
-    case 8: return launch_pblock_nt<8>(a, n, groups, s);
-    case 14: return launch_pblock_nt<14>(a, n, groups, s);
-  }
+  if (a.Cv <= 0) { a.Cv = a.Cout; a.co0 = 0; }           // one launch computes every output channel
+  if (a.co0 < 0 || a.co0 + a.Cv > a.Cout || a.Cv > 128) return hipErrorInvalidValue;
+  const int nk = a.Cin / 4, nt = nv_pblock_ntiles(a.Cv);
+  if (a.in_slabs > 1 && !nvp_multi_in(nk)) return hipErrorInvalidValue;
+#define X(K, T) if (nk == K && nt == T) return launch_pblock_t<T, K>(a, n, groups, s);
+  NVP_SHAPES(X)
+#undef X
   return hipErrorInvalidValue;
 }
 

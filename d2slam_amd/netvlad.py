@@ -4,7 +4,7 @@ The reference runs `mobilenetvlad_dyn_size.onnx` through ONNX Runtime (mobilenet
 `image:0` -> `descriptor:0`, 4096-D, input gray float NOT scaled); that file is not in the tree and nothing in the tree
 pins its graph.  The stand-in follows the HF-Net MobileNetVLAD lineage the tensor names point to:
 
-  gray u8 -> (x-128)/128 -> MobileNetV2 (depth multiplier 0.35, channels rounded to multiples of 8, TF "SAME" padding,
+  gray u8 -> (x-128)/128 -> MobileNetV2 (depth multiplier 0.75 -- HF-Net's width; rounds 2-5 used 0.35 -- channels rounded to multiples of 8, TF "SAME" padding,
   BatchNorm folded, ReLU6) up to the 1280-channel 1x1 conv ("layer_18", stride 32) -> 1x1 pre-projection to 128
   -> NetVLAD (K = 32 clusters, soft-assignment conv, residuals c_k - x, intra-normalisation, flatten, L2) -> 4096-D.
 
@@ -14,6 +14,7 @@ Weights layouts (PyTorch-like): conv [cout][1][3][3], dw [c][3][3], pw [cout][ci
 """
 import numpy as np
 
+DEPTH_MULTIPLIER = 0.75        # "MobileNetV2 (alpha = 0.75) trunk -> NetVLAD layer (K = 32 clusters) -> 4096" (HF-Net's MobileNetVLAD)
 NETVLAD_K = 32
 NETVLAD_D = 128
 NETVLAD_DIM = NETVLAD_K * NETVLAD_D   # 4096, NETVLAD_DESC_RAW_SIZE (mobilenetvlad_onnx.h:5)
@@ -27,7 +28,7 @@ def _div8(v, divisor=8, min_value=8):
     return nv
 
 
-def mobilenetvlad_arch(depth_multiplier=0.35):
+def mobilenetvlad_arch(depth_multiplier=DEPTH_MULTIPLIER):
     """Flat layer list of the trunk (MobileNetV2 table: t, c, n, s)."""
     L = []
     c_in = _div8(32 * depth_multiplier)
@@ -49,7 +50,7 @@ def mobilenetvlad_arch(depth_multiplier=0.35):
     return L
 
 
-def synthetic_netvlad_weights(seed=4321, depth_multiplier=0.35):
+def synthetic_netvlad_weights(seed=4321, depth_multiplier=DEPTH_MULTIPLIER):
     """Seeded random-init weights of the stand-in (He-uniform, small biases standing in for folded BatchNorm)."""
     rng = np.random.RandomState(seed)
     arch = mobilenetvlad_arch(depth_multiplier)
@@ -85,9 +86,9 @@ def synthetic_netvlad_pca(out_dims=1024, seed=99):
     return comp, mean
 
 
-def arch_flops(depth_multiplier=0.35, H=480, W=640, head=False):
-    """Algorithmic FLOPs (2 x MACs) of one image through the stand-in's TRUNK at this width (TF "SAME" strided layers: ceil division): 0.666 GFLOP at 0.35 and
-    640 x 480 (bench.py's NetVLAD roofline objects use 0.6626, the figure of rounds 2-4); head=True adds the NetVLAD head's pre-projection, soft-assignment and
+def arch_flops(depth_multiplier=DEPTH_MULTIPLIER, H=480, W=640, head=False):
+    """Algorithmic FLOPs (2 x MACs) of one image through the stand-in's TRUNK at this width (TF "SAME" strided layers: ceil division): 2.478 GFLOP at 0.75 (0.666 at 0.35, the
+    width of rounds 2-5) and 640 x 480; head=True adds the NetVLAD head's pre-projection, soft-assignment and
     residual aggregation (0.103 GFLOP)."""
     h, w = H, W
     macs = 0

@@ -500,11 +500,12 @@ def test_netvlad_vs_oracle(api, orc, H, W):
     fe.close()
 
 
-@pytest.mark.parametrize("mult,H,W", [(0.5, 128, 160), (0.75, 96, 128), (1.0, 96, 128)])
+@pytest.mark.parametrize("mult,H,W", [(0.35, 96, 128), (0.35, 480, 640), (0.5, 128, 160), (0.75, 128, 160), (1.0, 96, 128)])
 def test_netvlad_other_trunk_widths(api, orc, mult, H, W):
     """The real mobilenetvlad_dyn_size.onnx is not in the reference tree, so its width is not known: the loader takes ANY MobileNetV2-style layer list
-    (d2fe_load_netvlad).  Depth multipliers other than the stand-in's 0.35 have channel counts the specialised block kernels do not cover (Cin 64, 96, 160 ...):
-    the plan then falls back to the generic fused block / per-layer kernels.  Against the oracle <= 1e-4, and the same bits alone and in a batch."""
+    (d2fe_load_netvlad).  The specialised block kernels cover the channel counts of depth multipliers 0.75 (SURVEY A9's, the default: test_netvlad_vs_oracle) and
+    0.35 (rounds 2-5); other widths (Cin 64, 96, 160 ...) fall back to the generic fused block / per-layer kernels where no specialised shape exists.
+    Against the oracle <= 1e-4, and the same bits alone and in a batch."""
     from d2slam_amd import netvlad as nvm
     nv = nvm.synthetic_netvlad_weights(seed=77, depth_multiplier=mult)
     imgs = np.stack([synth_image(H, W, 21 + s) for s in range(3)])

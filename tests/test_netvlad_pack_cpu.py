@@ -46,16 +46,20 @@ LANES = np.arange(64)
 N, LQ = LANES & 15, LANES >> 4
 
 
-@pytest.mark.parametrize("cin,chid,cout", [(8, 48, 8), (16, 96, 16), (24, 144, 32), (32, 192, 32), (56, 336, 56), (56, 336, 112)])
+@pytest.mark.parametrize("cin,chid,cout", [(8, 48, 8), (16, 96, 16), (24, 144, 32), (32, 192, 32), (56, 336, 56), (56, 336, 112),
+                                           (24, 144, 24), (48, 288, 48), (48, 288, 72), (72, 432, 72), (120, 720, 120), (120, 720, 96)])
 def test_pixel_pair_kernel_records(lib, cin, chid, cout):
     """nv_pblock_kernel: lane group lq owns input channels lq*nk .. (k-step s -> channel lq*nk + s); hidden channel of depthwise / project k-step ks for
-    lane group lq: ks + 4 (lq >> 1) + 8 (lq & 1)."""
+    lane group lq: ks + 4 (lq >> 1) + 8 (lq & 1).  Project fragments of a k-step (nvp_project): nt // 4 groups of four n-tiles as [lane][4], then the remaining
+    1 / 2 / 3 n-tiles as [lane][1], [lane][2] or [lane][4] with the last float unused -- the MobileNetV2-0.75 widths (48, 72, 120) have 3 / 5 / 8 n-tiles."""
     we, be, wd, bd, wp = _weights(cin, chid, cout, 1)
-    nk, nt = cin // 4, _ntiles(cout)
-    ntv, nth = min(nt, 4), nt // min(nt, 4)
+    nk, nt = cin // 4, (cout + 15) // 16
+    ng4, rem = nt // 4, nt % 4
+    remw = {0: 0, 1: 1, 2: 2, 3: 4}[rem]
+    ksf = 64 * (4 * ng4 + remw)
     rec_e = (nk * 64 + 16 + 255) // 256 * 256
     pe = _pack(lib, 0, cin, chid, cout, we=we, be=be).reshape(chid // 16, rec_e)
-    rec_d = 256 + nt * 256
+    rec_d = (256 + 4 * ksf + 255) // 256 * 256
     pd = _pack(lib, 1, cin, chid, cout, wd=wd, bd=bd, wp=wp).reshape(chid // 16, rec_d)
     x = np.random.default_rng(2).standard_normal(cin).astype(np.float64)
     d = np.random.default_rng(3).standard_normal(chid).astype(np.float64)
@@ -79,20 +83,22 @@ def test_pixel_pair_kernel_records(lib, cin, chid, cout):
                 blk = pd[ch, (lq * 4 + ks) * 12:(lq * 4 + ks) * 12 + 12]
                 assert np.array_equal(blk[:9], wd[c]) and blk[9] == bd[c] and not blk[10:].any()
         assert not pd[ch, 192:256].any()
-        # project fragments [ks][nt / ntv][lane][ntv]; every hidden channel of the chunk is used exactly once
+        # project fragments as nvp_project reads them; every hidden channel of the chunk is used exactly once
         proj = np.zeros(nt * 16)
         seen = set()
         for ks in range(4):
             cmap = ch * 16 + ks + 4 * (LQ >> 1) + 8 * (LQ & 1)
             seen.update(cmap.tolist())
-            for hf in range(nth):
-                for e in range(ntv):
-                    t = hf * ntv + e
-                    frag_p = pd[ch, 256 + ((ks * nth + hf) * 64 + LANES) * ntv + e]
-                    co = t * 16 + N
-                    ref = np.where(co < cout, wp[np.minimum(co, cout - 1), cmap], 0.0)
-                    assert np.array_equal(frag_p, ref.astype(np.float32))
-                    np.add.at(proj, co, frag_p.astype(np.float64) * d[cmap])
+            base = 256 + ks * ksf
+            for t in range(nt):
+                hf, e = t // 4, t % 4
+                frag_p = pd[ch, base + (hf * 64 + LANES) * 4 + e] if hf < ng4 else pd[ch, base + ng4 * 256 + LANES * remw + e]
+                co = t * 16 + N
+                ref = np.where(co < cout, wp[np.minimum(co, cout - 1), cmap], 0.0)
+                assert np.array_equal(frag_p, ref.astype(np.float32))
+                np.add.at(proj, co, frag_p.astype(np.float64) * d[cmap])
+            if rem == 3:
+                assert not pd[ch, base + ng4 * 256 + LANES * 4 + 3].any()
         assert seen == set(range(ch * 16, ch * 16 + 16))
         assert np.allclose(proj[:cout], wp[:, ch * 16:ch * 16 + 16].astype(np.float64) @ d[ch * 16:ch * 16 + 16], rtol=1e-12, atol=1e-12)
         assert not proj[cout:].any()
