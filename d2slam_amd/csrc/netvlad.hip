@@ -481,9 +481,13 @@ hipError_t launch_nv_pw(const float* in, long P, int Cin, int Cout, int CoutPad,
   const int ntiles = CoutPad / 32;
   const f32x4* wp = reinterpret_cast<const f32x4*>(w);
   const unsigned gx = (unsigned)((P + 127) / 128);
-  if (ntiles % 4 == 0) hipLaunchKernelGGL(nv_pw_mfma_kernel<4>, dim3(gx, ntiles / 4), dim3(256), 0, s, in, P, Cin, Cout, act, wp, b, res, out);
-  else if (ntiles == 3) hipLaunchKernelGGL(nv_pw_mfma_kernel<3>, dim3(gx, 1), dim3(256), 0, s, in, P, Cin, Cout, act, wp, b, res, out);
-  else if (ntiles % 2 == 0) hipLaunchKernelGGL(nv_pw_mfma_kernel<2>, dim3(gx, ntiles / 2), dim3(256), 0, s, in, P, Cin, Cout, act, wp, b, res, out);
+  // channel tiles per workgroup: as many as divide the layer (each staged input chunk feeds more MFMAs) -- but a launch of fewer than one workgroup per CU
+  // (15 x 20 layers: 75 pixel spans per 32 images) trades that for more workgroups.  An output's sum runs over Cin in the same order either way: same bits
+  int nt = ntiles % 4 == 0 ? 4 : ntiles == 3 ? 3 : ntiles % 2 == 0 ? 2 : 1;
+  while (nt > 1 && nt != 3 && (long)gx * (ntiles / nt) < 256) nt /= 2;
+  if (nt == 4) hipLaunchKernelGGL(nv_pw_mfma_kernel<4>, dim3(gx, ntiles / 4), dim3(256), 0, s, in, P, Cin, Cout, act, wp, b, res, out);
+  else if (nt == 3) hipLaunchKernelGGL(nv_pw_mfma_kernel<3>, dim3(gx, 1), dim3(256), 0, s, in, P, Cin, Cout, act, wp, b, res, out);
+  else if (nt == 2) hipLaunchKernelGGL(nv_pw_mfma_kernel<2>, dim3(gx, ntiles / 2), dim3(256), 0, s, in, P, Cin, Cout, act, wp, b, res, out);
   else hipLaunchKernelGGL(nv_pw_mfma_kernel<1>, dim3(gx, ntiles), dim3(256), 0, s, in, P, Cin, Cout, act, wp, b, res, out);
   return hipGetLastError();
 }

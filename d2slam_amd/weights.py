@@ -134,3 +134,39 @@ def load_superpoint_onnx(path):
         if tuple(w[n][0].shape) != (SP_SHAPES[n][0], SP_SHAPES[n][1], SP_SHAPES[n][2], SP_SHAPES[n][2]):
             raise ValueError("unexpected shape for %s: %s" % (n, w[n][0].shape))
     return w
+
+
+# ---- "D2FW" weight container: what the C++ adapter (include/d2fe_adapter.cpp) reads in SuperPoint::build / MobileNetVLADONNX's constructor ---------
+# D2SLAM's configuration names model FILES (superpoint_model / netvlad_model, d2frontend_params.cpp:86-106); the C ABI takes plain arrays.  The container
+# is the smallest thing in between: b"D2FW" | u32 version = 1 | u32 n | n x { u32 name_len | name | u32 ndim | ndim x i64 dims | f32 data, C order }
+# (little endian).  include/d2fe_weights_file.hpp is the reader.
+def save_d2fw(path, tensors):
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"D2FW" + struct.pack("<II", 1, len(tensors)))
+        for name, a in tensors.items():
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            nb = name.encode()
+            f.write(struct.pack("<I", len(nb)) + nb + struct.pack("<I", a.ndim) + struct.pack("<%dq" % a.ndim, *a.shape))
+            f.write(a.tobytes())
+
+
+def save_superpoint_d2fw(path, w):
+    """the 12 conv layers under their state_dict names (conv1a.weight ... convDb.bias)"""
+    t = {}
+    for n in SP_LAYERS:
+        t[n + ".weight"], t[n + ".bias"] = w[n]
+    save_d2fw(path, t)
+
+
+def save_netvlad_d2fw(path, nv):
+    """the flat layer list of d2slam_amd.netvlad (or onnx_graph.load_mobilenetvlad_onnx): `arch` [n_layers][6] = kind (C ABI: 0 conv, 1 pw, 2 dw), cin, cout, stride,
+    act, res as floats; layer.<i>.weight / .bias; the head's five arrays"""
+    kinds = {"conv": 0, "pw": 1, "dw": 2}
+    L = nv["layers"]
+    t = {"arch": np.array([[kinds[l["kind"]], l["cin"], l["cout"], l["stride"], l["act"], l["res"]] for l in L], np.float32)}
+    for i, l in enumerate(L):
+        t["layer.%d.weight" % i], t["layer.%d.bias" % i] = l["weight"], l["bias"]
+    for k in ("pre_w", "pre_b", "assign_w", "assign_b", "centroids"):
+        t["head." + k] = nv["head"][k]
+    save_d2fw(path, t)

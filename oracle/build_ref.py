@@ -55,6 +55,74 @@ RANGES = {
 }
 
 
+# round 6 (ref_shim/spref_loopcam.cpp): the reference's own CALLER of the extractor, LoopCam::extractorImgDescDeepnet, with the structs it fills -- compiled
+# twice: over include/d2fe_adapter.cpp + libd2fe_hip.so, and over the reference's own SuperPoint::infer post-processing (ranges above)
+LOOPCAM_RANGES = {
+    "SPREF_GEN_LOOPCAM_EXTRACT": ("d2frontend/src/loop_cam.cpp", 589, 648, "VisualImageDesc LoopCam::extractorImgDescDeepnet(ros::Time stamp, cv::Mat img,", "}"),
+    "SPREF_GEN_VISUAL_IMAGE_DESC": ("d2common/include/d2common/d2frontend_types.h", 85, 110, "struct VisualImageDesc {", "double cur_td = 0;"),
+    "SPREF_GEN_LANDMARK_PER_FRAME": ("d2common/include/d2common/d2landmarks.h", 28, 70, "struct LandmarkPerFrame {", "{}"),
+    "SPREF_GEN_BASETYPES_IDS": ("d2common/include/d2common/d2basetypes.h", 18, 20, "typedef int64_t FrameIdType;", "typedef int32_t CamIdType;"),
+    "SPREF_GEN_BASETYPES_CAMCFG": ("d2common/include/d2common/d2basetypes.h", 40, 46, "enum CameraConfig{", "};"),
+    "SPREF_GEN_EXTRACT_COLOR": ("d2frontend/src/loop_utils.cpp", 54, 63, "cv::Vec3b extractColor(const cv::Mat &img, cv::Point2f p) {", "}"),
+}
+LOOPCAM_SHARED = ("SPREF_GEN_TENSORRT_INFER", "SPREF_GEN_TENSORRT_POST", "SPREF_GEN_CATA_INVK", "SPREF_GEN_CATA_LIFT", "SPREF_GEN_CATA_DIST")
+LOOPCAM_LIBS = {"hip": os.path.join(OUT_DIR, "libspref_loopcam_hip.so"), "ref": os.path.join(OUT_DIR, "libspref_loopcam_ref.so")}
+PRODUCT_LIBDIR = os.path.join(os.path.dirname(HERE), "d2slam_amd", "lib")
+
+
+def _write_ranges(tmp, ranges):
+    defs = []
+    for macro, (rel, a, b, anchor_a, anchor_b) in ranges.items():
+        path = os.path.join(REF, rel)
+        with open(path, encoding="utf-8") as f:
+            lines = f.read().split("\n")
+        first, last = lines[a - 1], lines[b - 1]
+        if anchor_a not in first or anchor_b not in last:
+            raise RuntimeError("%s:%d-%d does not look like the surveyed reference (anchors %r / %r not found in %r / %r)" % (rel, a, b, anchor_a, anchor_b, first, last))
+        inc = os.path.join(tmp, macro.lower() + ".inc")
+        with open(inc, "w", encoding="utf-8") as f:
+            f.write('#line %d "%s"\n' % (a, path))
+            f.write("\n".join(lines[a - 1:b]) + "\n")
+        defs.append('-D%s="%s"' % (macro, inc))
+    return defs
+
+
+def build_loopcam(force=False, verbose=False):
+    """oracle/_ref/libspref_loopcam_{hip,ref}.so: LoopCam::extractorImgDescDeepnet (loop_cam.cpp:589-648) over include/d2fe_adapter.cpp + libd2fe_hip.so and over the
+    reference's own SuperPoint::infer.  Returns {side: path}; sides that cannot be built here (no reference tree and no prebuilt library; the HIP side also
+    needs d2slam_amd/lib/libd2fe_hip.so to link against) are absent."""
+    out = {}
+    if not available():
+        return {k: v for k, v in LOOPCAM_LIBS.items() if os.path.exists(v)}
+    src = os.path.join(SHIM, "spref_loopcam.cpp")
+    adapter = [os.path.join(os.path.dirname(HERE), "include", f) for f in ("d2fe_adapter.cpp", "d2fe_weights_file.hpp", "d2fe.h")]
+    ranges = dict(LOOPCAM_RANGES, **{k: RANGES[k] for k in LOOPCAM_SHARED})
+    deps = [src, os.path.abspath(__file__)] + adapter + [os.path.join(REF, r[0]) for r in ranges.values()]
+    for root, _, files in os.walk(SHIM):
+        deps += [os.path.join(root, f) for f in files if f.endswith((".h", ".hpp"))]
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with tempfile.TemporaryDirectory(prefix="spref_lc_") as tmp:
+        defs = None
+        for side, lib in LOOPCAM_LIBS.items():
+            if side == "hip" and not os.path.exists(os.path.join(PRODUCT_LIBDIR, "libd2fe_hip.so")):
+                continue
+            if not force and os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps if os.path.exists(d)):
+                out[side] = lib
+                continue
+            defs = defs or _write_ranges(tmp, ranges)
+            cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-w", "-DLOOPCAM_SIDE_%s" % side.upper(),
+                   "-I" + SHIM, "-I" + os.path.join(REF, "d2frontend", "include")] + defs + [src, "-o", lib]
+            if side == "hip":
+                cmd += ["-L" + PRODUCT_LIBDIR, "-ld2fe_hip", "-Wl,-rpath,$ORIGIN/../../d2slam_amd/lib"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("building %s failed:\n%s" % (lib, (r.stdout + r.stderr)[-6000:]))
+            out[side] = lib
+    return out
+
+
 TORCH_LIB = os.path.join(OUT_DIR, "libspref_torch.so")
 TORCH_RANGE = ("SPREF_GEN_COMPUTE_DESC", "d2frontend/src/CNN/superpoint_common.cpp", 42, 99, "void computeDescriptors(const torch::Tensor& mProb, const torch::Tensor& mDesc,", "}")
 
@@ -149,3 +217,5 @@ if __name__ == "__main__":
     print(build(force="-f" in sys.argv, verbose=True))
     if "--torch" in sys.argv:
         print(build_torch(force="-f" in sys.argv, verbose=True))
+    if "--loopcam" in sys.argv:
+        print(build_loopcam(force="-f" in sys.argv, verbose=True))

@@ -242,3 +242,55 @@ def compute_descriptors(desc_hwc, kps, img_w, img_h, pca_comp=None, pca_mean=Non
                                         _p(mean) if mean is not None else None, pd, _p(out))
     assert m == n * (pd or dim), (m, n)
     return out[:n].copy()
+
+
+# ---- round 6: LoopCam::extractorImgDescDeepnet (loop_cam.cpp:589-648) compiled in place over the adapter / over the reference's own SuperPoint::infer ---------
+class LoopCam:
+    """One side of oracle/_ref/libspref_loopcam_{hip,ref}.so (oracle/ref_shim/spref_loopcam.cpp).  side "hip": superpoint_ptr / netvlad_onnx are
+    include/d2fe_adapter.cpp over libd2fe_hip.so (needs a GPU; sp_path / nv_path = D2FW weight containers).  side "ref": the reference's own
+    SuperPoint::infer + processOutput on network outputs handed in with set_network_outputs()."""
+
+    def __init__(self, side, width, height, max_keypoints, threshold=0.015, remove_borders=1, self_id=0, camera_configuration=0, cams=((0, (400.0, 400.0, 320.0, 240.0)),),
+                 sp_path=None, nv_path=None, precision=0):
+        from oracle import build_ref
+        libs = build_ref.build_loopcam()
+        if side not in libs:
+            raise RuntimeError("libspref_loopcam_%s.so is not available (no reference tree and no prebuilt library)" % side)
+        self.lib = C.CDLL(libs[side])
+        self.lib.spref_loopcam_create.restype = C.c_void_p
+        self.side, self.W, self.H = side, width, height
+        kinds = (C.c_int * len(cams))(*[k for k, _ in cams])
+        prm = np.zeros((len(cams), 9), np.float64)
+        for i, (_, p) in enumerate(cams):
+            prm[i, :len(p)] = p
+        self.h = self.lib.spref_loopcam_create(width, height, int(max_keypoints), C.c_float(threshold), int(remove_borders), int(self_id), int(camera_configuration),
+                                               len(cams), kinds, _p(prm), (sp_path or "").encode(), (nv_path or "").encode(), int(precision))
+        if not self.h:
+            raise RuntimeError("spref_loopcam_create failed (side %s)" % side)
+        self._keep = None
+
+    def set_network_outputs(self, semi, desc_hwc, netvlad=None):
+        semi = _f(semi); chw = _f(np.transpose(desc_hwc, (2, 0, 1)))
+        g = _f(netvlad) if netvlad is not None else None
+        self._keep = (semi, chw, g)
+        self.lib.spref_loopcam_set_network_outputs(C.c_void_p(self.h), _p(semi), _p(chw), _p(g), 0 if g is None else int(g.size))
+
+    def extract(self, img, stamp=12.5, camera_index=0, camera_id=7, superpoint_mode=False, cap_lm=20000, gdim=8192):
+        """-> dict of every field the function sets; `img` (u8 [H][W]) is modified in place where the reference does (STEREO_FISHEYE mask)"""
+        assert img.dtype == np.uint8 and img.flags.c_contiguous and img.shape == (self.H, self.W)
+        head = np.zeros(8, np.float64); pt2d = np.zeros((cap_lm, 2), np.float32); pt3d = np.zeros((cap_lm, 3), np.float64)
+        meta = np.zeros((cap_lm, 4), np.float64); color = np.zeros((cap_lm, 3), np.uint8)
+        desc = np.zeros(cap_lm * 256, np.float32); sc = np.zeros(cap_lm, np.float32); g = np.zeros(gdim, np.float32)
+        nan_w = C.c_int(0)
+        n = self.lib.spref_loopcam_extract(C.c_void_p(self.h), C.c_double(stamp), _p(img), self.W, self.H, self.W, int(camera_index), int(camera_id), int(bool(superpoint_mode)),
+                                           _p(head), _p(pt2d), _p(pt3d), _p(meta), _p(color), cap_lm, _p(desc), C.c_long(desc.size), _p(sc), C.c_long(sc.size), _p(g),
+                                           C.c_long(g.size), C.byref(nan_w))
+        assert n >= 0, n
+        return dict(stamp=head[0], camera_index=int(head[1]), camera_id=int(head[2]), drone_id=int(head[3]), n_landmarks=int(head[4]),
+                    pt2d=pt2d[:n].copy(), pt3d_norm=pt3d[:n].copy(), lm_camera_index=meta[:n, 0].copy(), lm_camera_id=meta[:n, 1].copy(), lm_stamp=meta[:n, 2].copy(),
+                    lm_stamp_discover=meta[:n, 3].copy(), color=color[:n].copy(), landmark_descriptor=desc[:int(head[5])].copy(), landmark_scores=sc[:int(head[6])].copy(),
+                    image_desc=g[:int(head[7])].copy(), nan_warnings=int(nan_w.value))
+
+    def close(self):
+        if self.h:
+            self.lib.spref_loopcam_destroy(C.c_void_p(self.h)); self.h = None

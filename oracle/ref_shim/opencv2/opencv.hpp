@@ -11,6 +11,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -27,12 +28,20 @@ template <class T> struct Point_ {
   Point_() : x(0), y(0) {}
   Point_(T x_, T y_) : x(x_), y(y_) {}
   Point_ operator-(const Point_& o) const { return Point_((T)(x - o.x), (T)(y - o.y)); }
+  // core/types.hpp: template<typename _Tp2> operator Point_<_Tp2>() const = Point_<_Tp2>(saturate_cast<_Tp2>(x), saturate_cast<_Tp2>(y)); float -> int
+  // is cvRound (round half to even, lrintf) -- what img.at<uchar>(cv::Point2f) does with a keypoint (loop_utils.cpp:54-63, round 6)
+  template <class T2> operator Point_<T2>() const { return Point_<T2>(shim_sat<T2>(x), shim_sat<T2>(y)); }
+  template <class T2, class S> static T2 shim_sat(S v) { if (std::is_integral<T2>::value && std::is_floating_point<S>::value) return (T2)std::lrint(v); return (T2)v; }
 };
 typedef Point_<int> Point;
 typedef Point_<float> Point2f;
 // cv::norm(Point_<T>) = std::sqrt((double)pt.x*pt.x + (double)pt.y*pt.y)   (core/types.hpp)
 template <class T> inline double norm(const Point_<T>& p) { return std::sqrt((double)p.x * p.x + (double)p.y * p.y); }
 struct Size { int width, height; Size(int w, int h) : width(w), height(h) {} };
+// round 6 (spref_loopcam.cpp: LoopCam::extractorImgDescDeepnet, loop_cam.cpp:589-648, and extractColor, loop_utils.cpp:54-63)
+struct Rect { int x, y, width, height; Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {} };
+struct Scalar { double v[4]; Scalar(double a = 0, double b = 0, double c = 0, double d = 0) : v{a, b, c, d} {} };
+struct Vec3b { unsigned char v[3]; Vec3b() : v{0, 0, 0} {} Vec3b(unsigned char a, unsigned char b, unsigned char c) : v{a, b, c} {} unsigned char operator[](int i) const { return v[i]; } };
 
 class Mat {
  public:
@@ -55,6 +64,12 @@ class Mat {
   template <class T> const T* ptr(int r) const { return reinterpret_cast<const T*>(data + (size_t)r * step); }
   void setTo(int v) { if (data) std::memset(data, v, (size_t)rows * step); }   // only ever called with 0
   Size size() const { return Size(cols, rows); }
+  // round 6: single-channel images only (the stand-in has no channel count: CV_8UC1 frames are what the path extracts from)
+  int channels() const { return 1; }
+  bool empty() const { return !data || rows <= 0 || cols <= 0; }
+  Mat operator()(const Rect& r) const { Mat m; m.rows = r.height; m.cols = r.width; m.type_ = type_; m.step = step; m.own = own; m.data = data + (size_t)r.y * step + (size_t)r.x * esz(type_); return m; }   // a view, as in OpenCV
+  void setTo(const Scalar& s) { for (int y = 0; data && y < rows; ++y) std::memset(data + (size_t)y * step, (int)s.v[0], (size_t)cols * esz(type_)); }      // CV_8U views (the STEREO_FISHEYE mask, loop_cam.cpp:601-604)
+  template <class T> const T& at(Point_<int> p) const { return *reinterpret_cast<const T*>(data + (size_t)p.y * step + (size_t)p.x * sizeof(T)); }
 };
 // (prob > threshold): CV_8U mask, 255 where true (cv::compare CMP_GT with a scalar, single precision)
 inline Mat operator>(const Mat& m, float thr) {
