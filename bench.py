@@ -36,7 +36,7 @@ LANES_FOR = {1: 4, 2: 4, 4: 4, 8: 4, 16: 4, 32: 4}
 # ... and with the cross-agent exchange beside the lanes (--gpus N > 1, and the one-GPU RCCL leg): the device runs four busy streams side by side, so two lanes (SuperPoint
 # and NetVLAD stream each) leave the exchange stream a hardware pipe it shares with a NetVLAD stream only: 2445-2453 stereo frames/s per rank with the exchange against
 # 2416-2425 with three or four lanes, where it takes turns with a lane's SuperPoint stream (measured over one-rank RCCL)
-LANES_WITH_EXCHANGE = {16: 2, 32: 2}
+LANES_WITH_EXCHANGE = {16: 2, 32: 2}          # --exchange-impl torch only (round 5's placement: a stream of the exchange's own)
 REFUSED_ENV = ("D2FE_ABLATE", "D2FE_MATCH_NOFALLBACK")     # switches that make results wrong or parity unproven: never inside a benchmark
 
 H, W, CAP = 480, 640, 200
@@ -191,6 +191,10 @@ def main():
                          "decoded exactly as its LCM constructor does: q/127 and the hard-coded 32-float renormalisation of the first n segments, which with "
                          "256-D descriptors leaves most rows un-normalised -- the reference's own cross-agent numerics); int8-renorm256 = the same bytes, every "
                          "descriptor re-normalised over its 256 floats on decode.  Either way 3.9x fewer all-gather bytes")
+    ap.add_argument("--exchange-impl", choices=["capi", "torch"], default=os.environ.get("D2FE_BENCH_EXCHANGE_IMPL", "capi"),
+                    help="N>1: capi = d2fe_exchange_* of the C ABI (csrc/exchange.hip): the sequence queued by the library on the stream of the lane that produced the ticket, "
+                         "ncclAllGather on an RCCL communicator of the library's own (dlopen), all four lanes kept; torch = round 5's form (Python-driven, torch.distributed "
+                         "collective, one stream of its own, two lanes).  capi falls back to torch when the C exchange cannot be created (recorded in `exchange.impl`)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency leg (host-pointer C ABI, one frame per call)")
     ap.add_argument("--latency-calls", type=int, default=300)
     ap.add_argument("--no-width-sensitivity", action="store_true", help="skip the NetVLAD trunk-width legs (`netvlad_width_sensitivity`)")
@@ -437,9 +441,9 @@ def main():
     # EVERY --gpus N times the frames-in-flight pipe (include/d2fe.h, d2fe_pipe_*): host frames in, host results out, `lanes` submits in flight.  N > 1 adds the
     # cross-agent exchange on a stream of its own beside it (run_pipe / swarm.PipeExchange) and keeps two submits in flight instead of four (LANES_WITH_EXCHANGE: the
     # exchange stream then has a hardware pipe it shares with a NetVLAD stream only); nothing else differs between `--gpus 1` and `--gpus 8`
-    lanes = args.lanes or (LANES_FOR.get(args.frames, 2) if not dist_path else LANES_WITH_EXCHANGE.get(args.frames, LANES_FOR.get(args.frames, 2)))
+    lanes = args.lanes or (LANES_FOR.get(args.frames, 2) if (not dist_path or args.exchange_impl == "capi") else LANES_WITH_EXCHANGE.get(args.frames, LANES_FOR.get(args.frames, 2)))
     xmode = args.exchange if dist_path else None
-    pk = dict(world=world, dist=dist, exchange=xmode, loopback=loopback)
+    pk = dict(world=world, dist=dist, exchange=xmode, loopback=loopback, exchange_impl=args.exchange_impl)
     full_run = world == 1 and not dist_path and not args.single_mode          # the default `python bench.py`: every secondary leg
     primary = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, args.steps, args.warmup, local_rank, rank, netvlad=use_nv, **pk)
     if world == 1 and not dist_path and lanes > 1 and not args.no_solo:
@@ -563,7 +567,7 @@ def main():
 
     if rank == 0 and full_run and not args.no_exchange_loopback:
         # LAST leg of the run: it creates (and destroys) a one-rank RCCL communicator, whose proxy threads and streams must not sit beside any other measurement
-        exch_1gpu = exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, args.lanes or LANES_WITH_EXCHANGE.get(args.frames, lanes), short, local_rank, rank, use_nv, dev)
+        exch_1gpu = exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, args.lanes or (lanes if args.exchange_impl == "capi" else LANES_WITH_EXCHANGE.get(args.frames, lanes)), short, local_rank, rank, use_nv, dev)
 
     cpu_baseline = None
     parity = None
@@ -593,7 +597,7 @@ def main():
                                    + ("; ONE rank through the N > 1 path (--force-dist): the rank's own blocks come back as the remote agent" if loopback else ""),
                        "frames_per_step_per_gpu": F, "images_per_step_per_gpu": NI, "match_pairs_per_step_per_gpu": NP,
                        "api": ("d2fe_pipe_submit / d2fe_pipe_wait (include/d2fe.h): host frames in (pinned), host results out (pinned), %d submits in flight" % primary["lanes"])
-                              + ("" if not dist_path else "; cross-agent exchange per submit on a stream of its own behind d2fe_pipe_device_view / _release (pack -> ONE all-gather -> gate -> "
+                              + ("" if not dist_path else "; cross-agent exchange per submit (d2fe_exchange_*: on the producing lane's stream) behind d2fe_pipe_device_view / _release (pack -> ONE all-gather -> gate -> "
                                                        "remote matchKNN -> D2H), enqueued one submit behind the pipe -- the SAME path as --gpus 1 plus that stream"),
                        "same_path_for_every_n_gpus": True,
                        "h2d_in_timed_region": True,
@@ -799,11 +803,11 @@ def exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, lanes, step
         runs = []
         for _ in range(2):
             w = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, steps, 2, local_rank, rank, netvlad=use_nv, light=True, world=1, dist=dist,
-                         exchange=args.exchange, loopback=True)
+                         exchange=args.exchange, loopback=True, exchange_impl=args.exchange_impl)
             wo = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, steps, 2, local_rank, rank, netvlad=use_nv, light=True)
             runs.append((w, wo))
         w = min((r[0] for r in runs), key=lambda r: r["ms_per_step"]); wo = min((r[1] for r in runs), key=lambda r: r["ms_per_step"])
-        return {"backend": dist.get_backend(), "what": "the step `--gpus N` runs on every rank (%d stereo frames per submit, %d submits in flight: LANES_WITH_EXCHANGE) with the cross-agent exchange on its own stream over a ONE-rank "
+        return {"backend": dist.get_backend(), "impl": w["exch"].get("impl"), "what": "the step `--gpus N` runs on every rank (%d stereo frames per submit, %d submits in flight) with the cross-agent exchange over a ONE-rank "
                            "RCCL communicator (loopback: the rank's own blocks as the remote agent, %d cross-agent pairs per submit), against the same step without it; best of two "
                            "alternating runs each" % (args.frames, lanes, w["exch"]["cross_agent_pairs_per_step_per_gpu"]),
                 "value_with_exchange": round(w["value"], 2), "value_without_exchange": round(wo["value"], 2), "ms_per_step_with_exchange": round(w["ms_per_step"], 3),
@@ -835,7 +839,7 @@ def stream_classes(r):
 
 
 def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup, local_rank, rank, netvlad=True, light=False, coalesce=1, depth=0, inflight=0,
-             world=1, dist=None, exchange=None, nv_flop_per_img=NV_FLOP_PER_IMG, nv_group=1, loopback=False):
+             world=1, dist=None, exchange=None, nv_flop_per_img=NV_FLOP_PER_IMG, nv_group=1, loopback=False, exchange_impl="capi"):
     """`steps` submits of F stereo frames through the frames-in-flight pipe with `lanes` submits in flight: the timed region holds, per submit, the H2D of
     the 2F frames from pinned memory, SuperPoint on them, NetVLAD of the F left images, ONE matcher launch (L<->R, L<->previous L) and the D2H of every
     result into pinned memory.  EVERY --gpus N runs this function (N = 1: no process group, no barrier).  N > 1 with `exchange`: one cross-agent exchange
@@ -855,9 +859,19 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
     dev = torch.device("cuda", local_rank)
     NS = inflight + 3
     xch = None
+    ximpl = None
     if (world > 1 or loopback) and exchange:
-        xch = swarm.PipeExchange(torch, fe, pipe, dev, world, rank, F, CAP, fe.netvlad_dim if netvlad else 0, exchange=exchange, gate_thres=NETVLAD_GATE, ratio=0.8, slots=NS,
-                                 loopback=loopback)
+        G = fe.netvlad_dim if netvlad else 0
+        if exchange_impl == "capi":
+            try:
+                xch = swarm.PipeExchange(torch, fe, pipe, dev, world, rank, F, CAP, G, exchange=exchange, gate_thres=NETVLAD_GATE, ratio=0.8, slots=NS, loopback=loopback)
+                ximpl = "capi: d2fe_exchange_* (csrc/exchange.hip), queued on the producing lane's stream; collective = %s" % (
+                    "ncclAllGather on the library's own RCCL communicator (%s)" % api.load_library().d2fe_rccl_path().decode() if xch.backend == "nccl" else "host-staged callback (%s)" % xch.backend)
+            except Exception as e:      # noqa: BLE001 -- e.g. no loadable librccl: the torch.distributed form still runs (every rank decides alike: same library, same box)
+                ximpl = "torch (the C exchange could not be created: %s)" % str(e)[:160]
+        if xch is None:
+            xch = swarm.TorchPipeExchange(torch, fe, pipe, dev, world, rank, F, CAP, G, exchange=exchange, gate_thres=NETVLAD_GATE, ratio=0.8, slots=NS, loopback=loopback)
+            ximpl = ximpl or "torch: Python-driven sequence on a stream of its own, torch.distributed collective"
 
     def submit(i):
         o = base + (i & 1) * per_set
@@ -925,9 +939,9 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
                breakdown=None, fallback_rows=(fb[0] / float(steps + warmup), fb[1] / float(steps + warmup)), roofline=None, roofline_nv=None)
     if xch:
         S = last["x"]
-        res["exch"] = {"wire_precision": exchange, "block_bytes": xch.block_bytes, "all_gather_bytes_received_per_step_per_gpu": xch.block_bytes * F * (world - 1 + (1 if loopback else 0)),
+        res["exch"] = {"impl": ximpl, "wire_precision": exchange, "block_bytes": xch.block_bytes, "all_gather_bytes_received_per_step_per_gpu": xch.block_bytes * F * (world - 1 + (1 if loopback else 0)),
                        "cross_agent_pairs_per_step_per_gpu": xch.NR, "avg_cross_agent_matches_per_pair": round(float(S["mn"].float().mean()), 2),
-                       "d2h_bytes_per_step": xch.d2h_bytes, "enqueued": "one submit behind the pipe, on a stream of its own; collected with the ticket",
+                       "d2h_bytes_per_step": xch.d2h_bytes, "enqueued": "one submit behind the pipe; collected with the ticket",
                        "step_timeline_ms": dict(xch.timeline_ms() or {}, note="rank 0, medians over the timed submits, HIP events on the exchange stream (which shares the device "
                                                 "with the lanes' launches: an entry is the wall time of that phase beside them); backend %s" % dist.get_backend())}
         if netvlad:
@@ -962,10 +976,13 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
     pl, ncl = pipe.stream_placement()
     res["stream_placement"] = {"classes_told_apart": ncl, "lanes": pl, "exchange_stream_class": None}
     if xch:
-        try:
-            res["stream_placement"]["exchange_stream_class"] = pipe.classify_stream(xch.stream.cuda_stream)
-        except Exception as e:      # not idle (should not happen here: every ticket has been waited for)
-            res["stream_placement"]["exchange_stream_class"] = str(e)[:80]
+        if getattr(xch, "stream", None) is not None:
+            try:
+                res["stream_placement"]["exchange_stream_class"] = pipe.classify_stream(xch.stream.cuda_stream)
+            except Exception as e:      # not idle (should not happen here: every ticket has been waited for)
+                res["stream_placement"]["exchange_stream_class"] = str(e)[:80]
+        else:
+            res["stream_placement"]["exchange_stream_class"] = "none: the exchange runs on the lanes' own streams"
         xch.close()
     pipe.close(); fe.close()
     return res

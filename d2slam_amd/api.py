@@ -74,6 +74,20 @@ class _MatchBatch(C.Structure):
                 ("d_q_idx", C.c_void_p), ("d_t_idx", C.c_void_p), ("d_dist", C.c_void_p), ("d_n_out", C.c_void_p)]
 
 
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)      # d2fe_all_gather_fn
+
+
+class _ExchangeConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("world", C.c_int32), ("rank", C.c_int32), ("wire", C.c_int32), ("loopback", C.c_int32), ("slots", C.c_int32),
+                ("own_stream", C.c_int32), ("timing", C.c_int32), ("gate_thres", C.c_double), ("ratio", C.c_double), ("all_gather", ALL_GATHER_FN),
+                ("all_gather_user", C.c_void_p), ("reserved", C.c_int32 * 6)]
+
+
+class _ExchangeResult(C.Structure):
+    _fields_ = [("ticket", C.c_int64), ("npairs", C.c_int32), ("cap", C.c_int32), ("q_idx", C.c_void_p), ("t_idx", C.c_void_p), ("dist", C.c_void_p),
+                ("n_match", C.c_void_p), ("gate_pass", C.c_void_p), ("gate_sims", C.c_void_p), ("gate_n", C.c_int32), ("phase_ms", C.c_float * 5)]
+
+
 class _PipeConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("lanes", C.c_int32), ("frames", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
                 ("cap", C.c_int32), ("netvlad", C.c_int32), ("match_lr", C.c_int32), ("match_prev", C.c_int32), ("pinned_input", C.c_int32),
@@ -109,7 +123,9 @@ EXPORTS = [
     "d2fe_lk_frame_create_device", "d2fe_lk_frame_destroy", "d2fe_lk_frame_read_level", "d2fe_lk_track", "d2fe_lk_track_batch",
     "d2fe_detect_fast_by_region", "d2fe_good_features_to_track", "d2fe_pipe_default_config", "d2fe_pipe_create", "d2fe_pipe_destroy",
     "d2fe_pipe_lanes", "d2fe_pipe_stream_placement", "d2fe_pipe_classify_stream", "d2fe_pipe_submit", "d2fe_pipe_wait", "d2fe_pipe_profile_enable", "d2fe_pipe_profile_read",
-    "d2fe_pipe_device_view", "d2fe_pipe_device_release"]
+    "d2fe_pipe_device_view", "d2fe_pipe_device_release", "d2fe_pipe_lane_stream", "d2fe_pipe_geometry", "d2fe_pipe_handle",
+    "d2fe_exchange_default_config", "d2fe_exchange_create", "d2fe_exchange_destroy", "d2fe_exchange_enqueue", "d2fe_exchange_collect", "d2fe_exchange_pairs",
+    "d2fe_exchange_block_bytes", "d2fe_exchange_stream", "d2fe_rccl_load", "d2fe_rccl_path", "d2fe_rccl_unique_id", "d2fe_rccl_comm_init_rank", "d2fe_rccl_comm_destroy"]
 # the development library (lib/libd2fe_hip_dev.so, include/d2fe_debug.h) exports these on top: test hooks and kernel diagnostics
 DEBUG_EXPORTS = [
     "d2fe_debug_graph_count", "d2fe_debug_read", "d2fe_debug_netvlad_layer", "d2fe_debug_netvlad_stamps", "d2fe_debug_pack_wino",
@@ -254,6 +270,22 @@ def _open_library(path, dev):
         lib.d2fe_pipe_device_release.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         lib.d2fe_pipe_profile_enable.argtypes = [C.c_void_p, C.c_int]
         lib.d2fe_pipe_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.d2fe_pipe_lane_stream.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        lib.d2fe_pipe_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.d2fe_pipe_handle.argtypes = [C.c_void_p]; lib.d2fe_pipe_handle.restype = C.c_void_p
+        lib.d2fe_exchange_default_config.argtypes = [C.c_void_p]; lib.d2fe_exchange_default_config.restype = None
+        lib.d2fe_exchange_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.d2fe_exchange_destroy.argtypes = [C.c_void_p]; lib.d2fe_exchange_destroy.restype = None
+        lib.d2fe_exchange_enqueue.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+        lib.d2fe_exchange_collect.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.d2fe_exchange_pairs.argtypes = [C.c_void_p]
+        lib.d2fe_exchange_block_bytes.argtypes = [C.c_void_p]
+        lib.d2fe_exchange_stream.argtypes = [C.c_void_p]; lib.d2fe_exchange_stream.restype = C.c_void_p
+        lib.d2fe_rccl_load.argtypes = [C.c_char_p]
+        lib.d2fe_rccl_path.restype = C.c_char_p
+        lib.d2fe_rccl_unique_id.argtypes = [C.c_void_p]
+        lib.d2fe_rccl_comm_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.d2fe_rccl_comm_destroy.argtypes = [C.c_void_p]
     return lib
 
 
@@ -1116,3 +1148,84 @@ def get_feature_half_img(pts, desc, require_left, width_undistort, undistort_fov
     idx = m[:cnt.value].copy()
     desc = np.asarray(desc, np.float32).reshape(-1, dims)
     return desc[idx].copy(), pts[idx].copy(), idx
+
+
+# ---- cross-agent exchange behind a pipe (include/d2fe.h, d2fe_exchange_* / d2fe_rccl_*; csrc/exchange.hip) ---------------------------------------------
+WIRE = {"fp32": 0, "int8": 1, "int8-renorm256": 2}
+EXCHANGE_PHASES = ("pack_blocks", "all_gather", "decode_counts_gate", "match_remote", "release_and_d2h")
+
+
+def rccl_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 makes it; every rank needs the same bytes)"""
+    buf = (C.c_char * 128)()
+    _check(load_library().d2fe_rccl_unique_id(buf))
+    return bytes(buf.raw)
+
+
+def rccl_comm_init_rank(uid, world, rank, device=0):
+    """ncclCommInitRank through the library's own dlopen of librccl -> an opaque ncclComm_t (int address)"""
+    assert len(uid) == 128
+    comm = C.c_void_p()
+    _check(load_library().d2fe_rccl_comm_init_rank(C.create_string_buffer(uid, 128), int(world), int(rank), int(device), C.byref(comm)))
+    return comm.value
+
+
+def rccl_comm_destroy(comm):
+    if comm:
+        _check(load_library().d2fe_rccl_comm_destroy(C.c_void_p(comm)))
+
+
+class Exchange:
+    """d2fe_exchange_*: pack -> ONE all-gather -> gate -> remote matchKNN -> D2H per ticket of a StereoPipe, queued on the stream of the lane that produced the
+    ticket (own_stream=False) or on one stream of its own.  comm: an ncclComm_t address (rccl_comm_init_rank, or D2SLAM's own) or None with `all_gather` =
+    a Python callable (user, d_send, d_recv, bytes_per_rank, stream) -> 0 (tests over gloo)."""
+
+    def __init__(self, pipe, comm=None, world=1, rank=0, wire="fp32", loopback=False, slots=4, own_stream=False, timing=False, gate_thres=0.8, ratio=0.8, all_gather=None):
+        self._lib = pipe._lib
+        self._pipe = pipe
+        c = _ExchangeConfig()
+        self._lib.d2fe_exchange_default_config(C.byref(c))
+        c.world, c.rank, c.wire, c.loopback, c.slots = int(world), int(rank), WIRE[wire], int(bool(loopback)), int(slots)
+        c.own_stream, c.timing, c.gate_thres, c.ratio = int(bool(own_stream)), int(bool(timing)), float(gate_thres), float(ratio)
+        self._cb = ALL_GATHER_FN(all_gather) if all_gather is not None else ALL_GATHER_FN()
+        c.all_gather = self._cb
+        self._x = C.c_void_p()
+        _check(self._lib.d2fe_exchange_create(pipe._p, C.c_void_p(comm) if comm else None, C.byref(c), C.byref(self._x)))
+        self.npairs = int(self._lib.d2fe_exchange_pairs(self._x))
+        self.block_bytes = int(self._lib.d2fe_exchange_block_bytes(self._x))
+        self.slots, self.timing = int(slots), bool(timing)
+        self._res = _ExchangeResult()
+
+    @property
+    def stream(self):
+        """own_stream=True: that hipStream_t (int), else None"""
+        return self._lib.d2fe_exchange_stream(self._x)
+
+    def enqueue(self, ticket, slot):
+        _check(self._lib.d2fe_exchange_enqueue(self._x, int(ticket), int(slot)))
+
+    def collect(self, slot):
+        """blocks until the slot's results are in host memory; numpy VIEWS into the pinned slot (valid until the slot is enqueued again)"""
+        r = self._res
+        _check(self._lib.d2fe_exchange_collect(self._x, int(slot), C.byref(r)))
+        n, cap = int(r.npairs), int(r.cap)
+
+        def view(addr, ct, shape):
+            if not addr:
+                return None
+            cnt = int(np.prod(shape)) if len(shape) else 1
+            return np.ctypeslib.as_array(C.cast(addr, C.POINTER(ct)), shape=(max(cnt, 1),))[:cnt].reshape(shape)
+        return {"ticket": int(r.ticket), "mq": view(r.q_idx, C.c_int32, (n, cap)), "mt": view(r.t_idx, C.c_int32, (n, cap)), "md": view(r.dist, C.c_float, (n, cap)),
+                "mn": view(r.n_match, C.c_int32, (n,)), "gate_pass": view(r.gate_pass, C.c_int32, (n,)), "sims": view(r.gate_sims, C.c_float, (n,)),
+                "gate_n": int(r.gate_n), "phase_ms": [float(v) for v in r.phase_ms] if self.timing else None}
+
+    def close(self):
+        if getattr(self, "_x", None) and self._x.value:
+            self._lib.d2fe_exchange_destroy(self._x)
+            self._x = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libd2fe_hip.so")
-SOURCES = ["api.hip", "conv.hip", "conv_f16.hip", "conv_pc.hip", "conv_wino.hip", "conv1x1.hip", "postproc.hip", "match.hip", "netvlad.hip", "netvlad_fused.hip", "netvlad_pair.hip", "next.hip", "swarm.hip", "lk.hip", "pipe.hip"]
+SOURCES = ["api.hip", "conv.hip", "conv_f16.hip", "conv_pc.hip", "conv_wino.hip", "conv1x1.hip", "postproc.hip", "match.hip", "netvlad.hip", "netvlad_fused.hip", "netvlad_pair.hip", "next.hip", "swarm.hip", "lk.hip", "pipe.hip", "exchange.hip"]
 HEADERS = ["kernels.h", "conv_common.h", "context.h", "stream_deal.h", os.path.join("..", "..", "include", "d2fe.h"), os.path.join("..", "..", "include", "d2fe_debug.h")]
 # -ffp-contract=off: the post-processing arithmetic must follow the oracle operation by operation
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",

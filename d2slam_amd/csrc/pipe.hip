@@ -749,6 +749,27 @@ int d2fe_pipe_device_view(d2fe_pipe p, int64_t ticket, void* stream, d2fe_pipe_d
   return D2FE_OK;
 }
 
+/* what a device-side consumer needs to size its buffers, and the stream it may queue behind (d2fe_exchange_*, csrc/exchange.hip) */
+int d2fe_pipe_geometry(d2fe_pipe p, int32_t* frames, int32_t* cap, int32_t* desc_dim, int32_t* netvlad_dim) {
+  if (!p) return pipe_fail(D2FE_ERR_INVALID, "null pipe");
+  if (frames) *frames = p->F;
+  if (cap) *cap = p->cap;
+  if (desc_dim) *desc_dim = p->D;
+  if (netvlad_dim) *netvlad_dim = p->G;
+  return D2FE_OK;
+}
+d2fe_handle d2fe_pipe_handle(d2fe_pipe p) { return p ? p->parent : nullptr; }
+int d2fe_pipe_lane_stream(d2fe_pipe p, int64_t ticket, void** stream) {
+  if (!p || !stream) return pipe_fail(D2FE_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(p->mu);
+  HIP_TRY(hipSetDevice(p->parent->cfg.device_id));
+  int k, set, j;
+  const int rc = view_locate(p, ticket, true, &k, &set, &j);      // launches the ticket's pass if coalescing still holds it back: the stream order below needs it queued
+  if (rc) return rc;
+  *stream = p->lanes[k].s;
+  return D2FE_OK;
+}
+
 int d2fe_pipe_device_release(d2fe_pipe p, int64_t ticket, void* stream) {
   if (!p || !stream) return pipe_fail(D2FE_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(p->mu);

@@ -203,7 +203,147 @@ def remote_pair_layout(world: int, rank: int, F: int, cap: int, blk_words: int, 
 
 
 class PipeExchange:
-    """The cross-agent exchange of one rank BEHIND a frames-in-flight pipe (d2slam_amd.api.StereoPipe, include/d2fe.h d2fe_pipe_*): the stand-in for the reference's
+    """The cross-agent exchange of one rank BEHIND a frames-in-flight pipe, as a thin caller of the C ABI (include/d2fe.h d2fe_exchange_*, csrc/exchange.hip; round 6):
+    the stand-in for the reference's broadcast of the frame it has just extracted (loop_net.cpp:24-87) and trackRemoteFrames on the receivers
+    (d2featuretracker.cpp:237-310).  Per ticket the LIBRARY queues, on the stream of the lane that produced the ticket (behind that lane's D2H; no stream of its own):
+
+        device view -> pack_blocks(_int8) -> ONE all-gather -> [int8: decode] -> counts -> NetVLAD gate -> ONE matcher launch -> release -> ONE D2H into a pinned slot
+
+    Backend "nccl": the collective is ncclAllGather on an RCCL communicator of the library's own (d2fe_rccl_*: librccl through dlopen; the 128-byte id travels over
+    the torch.distributed group once, at creation) -- neither torch's stream wrapper nor Python is in the per-ticket path.  Any other backend (gloo in the tests, two
+    ranks on one GPU): the library calls back into all_gather_host below, which stages the blocks through the host, from a worker thread (a host-blocking collective
+    on the submitting thread would starve the pipe; the reference's LCM handler runs beside the front-end thread too, loop_net.cpp).
+    enqueue() is called one submit BEHIND the pipe (after submit(i): enqueue(ticket i - 1)).  collect() returns torch views of the pinned slot."""
+
+    def __init__(self, torch, fe, pipe, dev, world, rank, F, cap, netvlad_dim, exchange="fp32", gate_thres=0.8, ratio=0.8, slots=4, group=None, loopback=False, own_stream=False,
+                 timing=True):
+        from . import api
+        assert exchange in ("fp32", "int8", "int8-renorm256") and (world > 1 or loopback)
+        self.torch, self.pipe, self.world, self.rank, self.F, self.cap, self.G, self.group, self.dev = torch, pipe, world, rank, F, cap, netvlad_dim, group, dev
+        self.exchange = exchange
+        self.comm = None
+        self.worker = None
+        self.err = None
+        self.timeline = []
+        self.backend = dist.get_backend(group)
+        cb = None
+        if self.backend == "nccl":
+            uid = [api.rccl_unique_id() if dist.get_rank(group) == 0 else None]
+            dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            self.comm = api.rccl_comm_init_rank(uid[0], world, rank, dev.index if dev.index is not None else 0)
+        else:
+            cb = self._all_gather_host
+        self.x = api.Exchange(pipe, comm=self.comm, world=world, rank=rank, wire=exchange, loopback=loopback, slots=slots, own_stream=own_stream, timing=timing,
+                              gate_thres=gate_thres, ratio=ratio, all_gather=cb)
+        self.NR = self.x.npairs
+        self.block_bytes = self.x.block_bytes
+        self.d2h_bytes = 4 * (3 * self.NR * cap + 2 * self.NR + 1)
+        self.stream = None          # the sequence runs on the lanes' own streams (own_stream: a hipStream_t address in self.x.stream)
+        if self.backend != "nccl":
+            import queue, threading
+            self.q = queue.Queue()
+            self.posted = [threading.Event() for _ in range(slots)]
+            self.worker = threading.Thread(target=self._work, daemon=True)
+            self.worker.start()
+
+    def _all_gather_host(self, user, d_send, d_recv, nbytes, stream):
+        """d2fe_all_gather_fn for backends without device collectives: stream -> host -> torch.distributed.all_gather -> device; complete on return"""
+        try:
+            import ctypes as C
+            torch, hip = self.torch, _hip_runtime()
+            if hip.hipStreamSynchronize(C.c_void_p(stream)):
+                return 1
+            send = torch.empty(nbytes, dtype=torch.uint8)
+            if hip.hipMemcpy(C.c_void_p(send.data_ptr()), C.c_void_p(d_send), C.c_size_t(nbytes), 2):      # hipMemcpyDeviceToHost
+                return 2
+            recv = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(recv, send, group=self.group)
+            allb = torch.cat(recv)
+            if hip.hipMemcpy(C.c_void_p(d_recv), C.c_void_p(allb.data_ptr()), C.c_size_t(nbytes * self.world), 1):      # hipMemcpyHostToDevice
+                return 3
+            return 0
+        except Exception as e:      # noqa: BLE001 -- never raise through the C frame
+            self.err = e
+            return 9
+
+    def _work(self):
+        self.torch.cuda.set_device(self.dev)
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            try:
+                if self.err is None:        # after a failure no later ticket is processed (collect() surfaces the error)
+                    self.x.enqueue(*item)
+            except Exception as e:      # noqa: BLE001
+                self.err = e
+            self.posted[item[1]].set()
+
+    def close(self):
+        if self.worker:
+            self.q.put(None); self.worker.join(timeout=30); self.worker = None
+        if getattr(self, "x", None):
+            self.x.close(); self.x = None
+        if self.comm:
+            from . import api
+            api.rccl_comm_destroy(self.comm); self.comm = None
+
+    def enqueue(self, ticket, slot):
+        if self.worker:
+            self.posted[slot].clear()
+            self.q.put((ticket, slot))
+        else:
+            self.x.enqueue(ticket, slot)
+
+    def collect(self, slot):
+        """blocks until the slot's results are in host memory; torch views of the pinned slot (valid until the slot is enqueued again)"""
+        if self.worker:
+            self.posted[slot].wait()
+        if self.err:
+            raise self.err
+        r = self.x.collect(slot)
+        if r["phase_ms"] is not None and len(self.timeline) < 4096:
+            self.timeline.append(r["phase_ms"])
+        t = self.torch
+        S = {k: t.from_numpy(r[k]) for k in ("mq", "mt", "md", "mn") if r[k] is not None}
+        S["gate_pass"] = t.from_numpy(r["gate_pass"]) if r["gate_pass"] is not None else t.zeros(self.NR, dtype=t.int32)
+        S["gate_n"] = t.tensor([r["gate_n"]], dtype=t.int32)
+        S["ticket"] = r["ticket"]
+        return S
+
+    def timeline_ms(self):
+        import numpy as np
+        from . import api
+        if not self.timeline:
+            return None
+        tl = np.array(self.timeline)
+        out = {n: round(float(np.median(tl[:, i])), 4) for i, n in enumerate(api.EXCHANGE_PHASES)}
+        out["all_gather_max"] = round(float(tl[:, 1].max()), 4)
+        out["exchange_stream_busy_ms_per_submit"] = round(float(np.median(tl.sum(1))), 4)
+        return out
+
+
+_HIP = None
+
+
+def _hip_runtime():
+    """the HIP runtime the process already holds (the library's and torch's), for the host-staged collective of the test backends"""
+    global _HIP
+    if _HIP is None:
+        import ctypes as C
+        path = "libamdhip64.so"
+        try:        # the very file that is mapped already (a second copy of the runtime would not see the first one's streams)
+            with open("/proc/self/maps") as f:
+                path = next((l.split()[-1] for l in f if "libamdhip64.so" in l), path)
+        except OSError:
+            pass
+        _HIP = C.CDLL(path)
+    return _HIP
+
+
+class TorchPipeExchange:
+    """Round 5's form of the same exchange (kept as the fallback `bench.py --exchange-impl torch`): the sequence driven from Python, torch.distributed for the
+    collective, ONE stream of its own.  The cross-agent exchange of one rank BEHIND a frames-in-flight pipe (d2slam_amd.api.StereoPipe, include/d2fe.h d2fe_pipe_*): the stand-in for the reference's
     broadcast of the frame it has just extracted (loop_net.cpp:24-87) and trackRemoteFrames on the receivers (d2featuretracker.cpp:237-310), as ONE sequence per
     submit on a stream of its own --
 

@@ -338,6 +338,69 @@ D2FE_API int d2fe_pipe_classify_stream(d2fe_pipe p, void* stream, int32_t* cls);
 D2FE_API int d2fe_pipe_device_view(d2fe_pipe p, int64_t ticket, void* stream, d2fe_pipe_device_result* out);
 D2FE_API int d2fe_pipe_device_release(d2fe_pipe p, int64_t ticket, void* stream);
 
+/* The stream of the lane that ran the ticket's pass (a hipStream_t): work queued on it now runs behind that pass's matcher and D2H and in front of the lane's next
+ * pass (lanes - 1 submits later) -- where the cross-agent exchange below goes by default.  d2fe_pipe_geometry / d2fe_pipe_handle: what such a consumer sizes its
+ * buffers from, and the handle whose kernels it launches. */
+D2FE_API int d2fe_pipe_lane_stream(d2fe_pipe p, int64_t ticket, void** stream);
+D2FE_API int d2fe_pipe_geometry(d2fe_pipe p, int32_t* frames, int32_t* cap, int32_t* desc_dim, int32_t* netvlad_dim);
+D2FE_API d2fe_handle d2fe_pipe_handle(d2fe_pipe p);
+
+/* ---- Cross-agent exchange behind a pipe -------------------------------------------------------------------------------------
+ * Replaces, per submitted stereo frame set: the LCM broadcast of the frame an agent has just extracted (LoopNet::broadcastVisualImageDescArray,
+ * d2frontend/src/loop_net.cpp:24-87; wire precision VisualImageDesc::toLCM, d2common/include/d2common/d2frontend_types.h:228-268) and, on every receiver,
+ * D2FeatureTracker::trackRemoteFrames (d2frontend/src/d2featuretracker.cpp:237-310: the NetVLAD gate of getMatchedPrevKeyframe :185-203, then matchKNN of the
+ * local frame against the remote one).  One sequence per ticket, asynchronous, on the stream of the lane that produced the ticket (own_stream = 0; the lane is idle
+ * there until its next turn, so the exchange takes no hardware pipe of its own) or on one stream of the exchange's own (own_stream = 1):
+ *   device view of the ticket -> pack one block per left frame (fp32, or the reference's int8 wire form) -> ONE all-gather over the communicator -> [int8: decode
+ *   as the receiving constructor does, :319-338] -> counts -> NetVLAD gate of every (local frame f, remote frame f of rank r) pair -> ONE matcher launch (local
+ *   descriptors read in place in the lane's result block, remote ones in place in the gathered blocks) -> release of the view -> ONE D2H into pinned slot `slot`.
+ * The communicator is an RCCL ncclComm_t made by the caller (ncclCommInitRank in D2SLAM's own start-up code, or d2fe_rccl_comm_init_rank below: librccl is loaded
+ * with dlopen, only when these entry points are used); every rank must enqueue its tickets in the same order.  A caller without RCCL (tests over gloo on one GPU)
+ * passes comm = NULL and an all_gather callback.  Pair p = (rank-major over the OTHER ranks r, then frame f): local left frame f against frame f of rank r. */
+typedef enum { D2FE_WIRE_FP32 = 0, D2FE_WIRE_INT8 = 1, D2FE_WIRE_INT8_RENORM256 = 2 } d2fe_wire;
+typedef int (*d2fe_all_gather_fn)(void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* stream);   /* 0 = ok; must be complete or stream-ordered on return */
+typedef struct {
+  int32_t struct_size;
+  int32_t world, rank;          /* of the communicator */
+  int32_t wire;                 /* d2fe_wire: fp32 blocks, the reference's int8 LCM precision (hard-coded 32-float renormalisation), or int8 + 256-float renormalisation */
+  int32_t loopback;             /* the rank's OWN gathered blocks count as a remote agent too (how a one-rank communicator exercises the whole sequence) */
+  int32_t slots;                /* ring of pinned result slots (>= the exchanges the caller keeps in flight) */
+  int32_t own_stream;           /* 0: each ticket's sequence on its lane's stream (default); 1: one stream of the exchange's own */
+  int32_t timing;               /* 1: HIP events around the five phases (d2fe_exchange_result.phase_ms) */
+  double gate_thres;            /* track_remote_netvlad_thres (d2featuretracker.cpp:199) */
+  double ratio;                 /* knn_match_ratio */
+  d2fe_all_gather_fn all_gather; void* all_gather_user;      /* used when the communicator is NULL */
+  int32_t reserved[6];
+} d2fe_exchange_config;
+typedef struct {
+  int64_t ticket;
+  int32_t npairs, cap;
+  const int32_t* q_idx;         /* [npairs][cap] local keypoint index   } host pointers into the pinned slot, valid until the slot is enqueued again */
+  const int32_t* t_idx;         /* [npairs][cap] remote keypoint index  } */
+  const float* dist;            /* [npairs][cap] */
+  const int32_t* n_match;       /* [npairs] */
+  const int32_t* gate_pass;     /* [npairs] 1 = the reference would have tracked this pair (NULL without NetVLAD) */
+  const float* gate_sims;       /* [npairs] */
+  int32_t gate_n;               /* pairs passing the gate */
+  float phase_ms[5];            /* timing = 1: pack, all-gather, decode + counts + gate, remote matchKNN, release + D2H */
+} d2fe_exchange_result;
+typedef struct d2fe_exchange_s* d2fe_exchange;
+D2FE_API void d2fe_exchange_default_config(d2fe_exchange_config* c);
+D2FE_API int d2fe_exchange_create(d2fe_pipe p, void* nccl_comm, const d2fe_exchange_config* cfg, d2fe_exchange* out);
+D2FE_API void d2fe_exchange_destroy(d2fe_exchange x);      /* before the pipe */
+D2FE_API int d2fe_exchange_enqueue(d2fe_exchange x, int64_t ticket, int slot);       /* asynchronous; within 2 * lanes passes of the ticket's submit */
+D2FE_API int d2fe_exchange_collect(d2fe_exchange x, int slot, d2fe_exchange_result* out);      /* blocks until the slot's results are in host memory */
+D2FE_API int d2fe_exchange_pairs(d2fe_exchange x);
+D2FE_API int d2fe_exchange_block_bytes(d2fe_exchange x);   /* bytes one frame contributes to the all-gather */
+D2FE_API void* d2fe_exchange_stream(d2fe_exchange x);      /* own_stream = 1: that stream (hipStream_t), else NULL */
+/* RCCL without any other dependency: rank 0 makes a 128-byte id, every rank gets it by whatever channel D2SLAM has (its LCM bus, a file, MPI), then all ranks call
+ * comm_init_rank.  path: a librccl to load (NULL: one the process already holds, else librccl.so.1 / librccl.so on the loader path, else /opt/rocm/lib). */
+D2FE_API int d2fe_rccl_load(const char* path);
+D2FE_API const char* d2fe_rccl_path(void);
+D2FE_API int d2fe_rccl_unique_id(void* id128);
+D2FE_API int d2fe_rccl_comm_init_rank(const void* id128, int world, int rank, int device, void** comm_out);
+D2FE_API int d2fe_rccl_comm_destroy(void* comm);
+
 /* Half-image filter for quadcam neighbour matching.  Replaces getFeatureHalfImg
  * (d2featuretracker.cpp:1051-1075): map[c] = source index of the c-th kept keypoint; returns count in *n_out. */
 D2FE_API int d2fe_half_image_filter(const float* pts_xy, int n, int require_left, int width_undistort,

@@ -44,7 +44,8 @@ def main():
     G = fe.netvlad_dim
     pipe = api.StereoPipe(fe, lanes=LANES, frames=F, width=W, height=H, cap=CAP, netvlad=True)
     NS = LANES + 2
-    x = swarm.PipeExchange(torch, fe, pipe, dev, world, rank, F, CAP, G, exchange=mode, gate_thres=0.8, ratio=0.8, slots=NS)
+    Impl = swarm.TorchPipeExchange if os.environ.get("PIPE_XCHG_IMPL", "capi") == "torch" else swarm.PipeExchange
+    x = Impl(torch, fe, pipe, dev, world, rank, F, CAP, G, exchange=mode, gate_thres=0.8, ratio=0.8, slots=NS)
     assert x.NR == (world - 1) * F
 
     tk, outs = [], []

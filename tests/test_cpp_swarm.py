@@ -109,3 +109,82 @@ def test_cpp_swarm_sequence_equals_python_path_and_oracle(tmp_path, orc):
         nmatch += n
     assert nmatch > 50
     fe.close()
+
+
+def _build_exchange(tmp_path):
+    """exchange_test.cpp links ONLY libd2fe_hip.so: RCCL is loaded by the library (dlopen) when d2fe_rccl_* / d2fe_exchange_* are used"""
+    from d2slam_amd import build as hipbuild
+    lib = hipbuild.build()
+    exe = str(tmp_path / "exchange_test")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "exchange_test.cpp"),
+           "-L", os.path.dirname(lib), "-ld2fe_hip", "-Wl,-rpath," + os.path.dirname(lib), "-Wl,--allow-shlib-undefined", "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_cpp_exchange_compiles_against_the_c_abi_alone(tmp_path):
+    exe = _build_exchange(tmp_path)
+    assert subprocess.run([exe], capture_output=True).returncode == 2          # usage error path: runs without touching the GPU
+    ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libd2fe_hip" in ldd and "librccl" not in ldd and "torch" not in ldd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes,wire,own_stream", [(4, 0, 0), (2, 0, 1), (4, 1, 0), (3, 2, 0)])
+def test_cpp_exchange_entry_points_behind_the_pipe(tmp_path, orc, lanes, wire, own_stream):
+    """d2fe_exchange_* + d2fe_rccl_* driven from g++ (tests/cpp/exchange_test.cpp: no Python, no torch in the process): a ONE-rank RCCL communicator made by the
+    library itself, loopback, the sequence on the producing lane's stream (own_stream = 0) or on a stream of its own.  Per submit: the pipe's keypoint counts equal the
+    single calls', every left frame against ITSELF matches keypoint i with keypoint i at distance 0 (fp32 wire) or -- int8 wire, the reference's LCM precision --
+    equals the oracle's matchKNN of the frame's descriptors against their quantised-and-decoded copy; the gate passes (similarity 1)."""
+    from d2slam_amd import api, netvlad as nvm
+    from d2slam_amd.synth import synth_stereo
+    from d2slam_amd.weights import synthetic_superpoint_weights, save_superpoint_d2fw, save_netvlad_d2fw
+    exe = _build_exchange(tmp_path)
+    H, W, cap, F, steps = 120, 160, 60, 2, 9
+    w = synthetic_superpoint_weights(dustbin_bias=7.5); nv = nvm.synthetic_netvlad_weights()
+    sp, nvp, fin, fout = (str(tmp_path / n) for n in ("sp.d2fw", "nv.d2fw", "frames.bin", "out.bin"))
+    save_superpoint_d2fw(sp, w); save_netvlad_d2fw(nvp, nv)
+    frames = []
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<5i", steps, F, H, W, cap))
+        for i in range(steps):
+            fr = [synth_stereo(H, W, seed=500 + 5 * i + k) for k in range(F)]
+            l, r = np.stack([p[0] for p in fr]), np.stack([p[1] for p in fr])
+            frames.append((l, r)); f.write(l.tobytes()); f.write(r.tobytes())
+    res = subprocess.run([exe, sp, nvp, fin, fout, str(lanes), str(wire), str(own_stream)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "exchange_test OK" in res.stdout and "rccl" in res.stdout.lower()
+    data, pos = open(fout, "rb").read(), 0
+
+    def take(dt, n):
+        nonlocal pos
+        a = np.frombuffer(data, dt, n, pos).copy(); pos += n * np.dtype(dt).itemsize
+        return a
+    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=cap, input_width=W, input_height=H, max_batch=2 * F, precision=api.PREC_F32_WINO))
+    fe.load_superpoint(w)
+    total = 0
+    for i in range(steps):
+        nkp = take("<i4", 2 * F); npairs = int(take("<i4", 1)[0]); nm = take("<i4", npairs); gp = take("<i4", npairs)
+        q = take("<i4", npairs * cap).reshape(npairs, cap); t = take("<i4", npairs * cap).reshape(npairs, cap); d = take("<f4", npairs * cap).reshape(npairs, cap)
+        assert npairs == F and np.all(gp == 1)
+        ext = fe.extract_batch(np.concatenate(frames[i]), cap=cap)
+        for f in range(F):
+            n = int(nkp[f])
+            assert n == len(ext[f][0]) and n > 10
+            if wire == 0:
+                assert nm[f] == n and np.array_equal(q[f, :n], np.arange(n)) and np.array_equal(t[f, :n], np.arange(n)) and not d[f, :n].any()
+            else:
+                da = ext[f][2]
+                qb = orc.quant_int8(da.reshape(-1))
+                if wire == 1:
+                    db = orc.dequant_int8(qb, n).reshape(n, 256)
+                else:
+                    xq = (qb.astype(np.float64) / 127.0).astype(np.float32).reshape(n, 256)
+                    db = (xq / np.linalg.norm(xq, axis=1, keepdims=True)).astype(np.float32)
+                rq, rt, rd = orc.match_knn(da, db, 0.8)
+                k = int(nm[f])
+                assert k == len(rq) and np.array_equal(q[f, :k], rq) and np.array_equal(t[f, :k], rt)
+                assert np.abs(d[f, :k] - rd).max(initial=0) <= (0 if wire == 1 else 1e-6)
+            total += int(nm[f])
+    assert pos == len(data) and (total > 100 or wire == 1)
+    fe.close()

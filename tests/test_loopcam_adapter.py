@@ -28,7 +28,7 @@ PINHOLE = (0, (385.7, 386.1, 322.3, 238.9))                                   # 
 # MEI cameras (xi, k1, k2, p1, p2, gamma1, gamma2, u0, v0): a fisheye with distortion, and one whose xi > 1 and short focal length send the image corners
 # past the model's domain -- 1 + (1 - xi^2) rho^2 < 0 -> sqrt of a negative number -> NaN rays (CataCamera.cc:466-480)
 MEI = (1, (1.9, -0.25, 0.08, 0.0007, -0.0004, 780.0, 779.0, 321.0, 243.0))
-MEI_NAN = (1, (2.2, 0.0, 0.0, 0.0, 0.0, 330.0, 330.0, 320.0, 240.0))
+MEI_NAN = (1, (1.5, 0.0, 0.0, 0.0, 0.0, 330.0, 330.0, 320.0, 240.0))          # NaN beyond 295 px from the centre
 
 
 @pytest.fixture(scope="module")
@@ -82,7 +82,7 @@ def test_reference_caller_over_reference_infer_vs_numpy(orc, cam, cfg):
     masked = img.copy()
     if cfg == 1:
         masked[H * 3 // 4:] = 0
-    camv = cam if cam is not MEI_NAN else (1, (2.2, 0.0, 0.0, 0.0, 0.0, 66.0, 66.0, 64.0, 48.0))       # the small image's version of the NaN camera
+    camv = cam if cam is not MEI_NAN else (1, (1.8, 0.0, 0.0, 0.0, 0.0, 66.0, 66.0, 64.0, 48.0))       # the small image's version of the NaN camera
     f = orc.superpoint_forward(masked, w)
     g = np.linspace(-1, 1, 64).astype(np.float32)
     lc = ref.LoopCam("ref", W, H, N, self_id=3, camera_configuration=cfg, cams=(PINHOLE, camv))
@@ -94,7 +94,7 @@ def test_reference_caller_over_reference_infer_vs_numpy(orc, cam, cfg):
     exp = _expected_from_post(masked, rk, rs, rd, camv, 99.25, 1, 3001)
     assert out["stamp"] == 99.25 and out["camera_index"] == 1 and out["camera_id"] == 3001 and out["drone_id"] == 3
     assert out["n_landmarks"] == exp["n"] and out["nan_warnings"] == exp["nan"]
-    if camv[0] == 1 and camv[1][0] > 2:
+    if cam is MEI_NAN:
         assert 0 < exp["nan"] < len(rk), "the NaN camera must drop some keypoints and keep others (%d of %d)" % (exp["nan"], len(rk))
     assert np.array_equal(out["pt2d"], exp["pt2d"]) and np.array_equal(out["color"], exp["color"])
     assert np.array_equal(out["pt3d_norm"], exp["pt3d"])

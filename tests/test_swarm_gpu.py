@@ -53,13 +53,15 @@ def test_world2_cross_agent_matches_equal_oracle():
     assert r.stdout.count(" OK: ") == 2, r.stdout[-2000:]
 
 
-@pytest.mark.parametrize("mode", ["fp32", "int8", "int8-renorm256", "fp32-4lanes"])
+@pytest.mark.parametrize("mode", ["fp32", "int8", "int8-renorm256", "fp32-4lanes", "fp32-4lanes-torch"])
 def test_world2_exchange_behind_the_pipe_equals_oracle(mode):
     """The path `bench.py --gpus N` times (round 5): every rank's frames-in-flight pipe with swarm.PipeExchange on a stream of its own one submit behind it
     (d2fe_pipe_device_view -> pack -> all-gather -> gate -> remote matchKNN -> d2fe_pipe_device_release -> D2H): cross-agent match lists and gate decisions against
     the oracle per submit, the pipe's own results bit-identical with and without the exchange beside it."""
+    impl = "torch" if mode.endswith("-torch") else "capi"          # capi: d2fe_exchange_* on the lanes' streams (round 6); torch: round 5's Python-driven form, kept as the fallback
+    mode = mode.replace("-torch", "")
     lanes = "4" if mode.endswith("-4lanes") else "2"
-    r = _torchrun([os.path.join(ROOT, "tests", "helpers", "pipe_exchange_worker.py")], {"PIPE_XCHG_MODE": mode.replace("-4lanes", ""), "PIPE_XCHG_LANES": lanes})
+    r = _torchrun([os.path.join(ROOT, "tests", "helpers", "pipe_exchange_worker.py")], {"PIPE_XCHG_MODE": mode.replace("-4lanes", ""), "PIPE_XCHG_LANES": lanes, "PIPE_XCHG_IMPL": impl})
     assert r.returncode == 0, _rank_errors(r)
     assert r.stdout.count(" OK: ") == 2, r.stdout[-2000:]
 

@@ -55,7 +55,8 @@ run_task() {
   local t=$1; shift
   echo "=== $t $*"
   case $t in
-    suite)   ( time timeout 2400 python -m pytest tests -x -q -m gpu "$@" 2>&1 | tail -25 ) > $O/pytest_gpu.txt 2>&1; tail -8 $O/pytest_gpu.txt ;;
+    suite)   local where=tests; case "$1" in tests/*) where=; ;; esac      # `suite tests/test_x.py [args]` runs that file only
+             ( time timeout 2400 python -m pytest $where -x -q -m gpu "$@" 2>&1 | tail -25 ) > $O/pytest_gpu.txt 2>&1; tail -8 $O/pytest_gpu.txt ;;
     smoke)   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -3 $O/smoke.txt ;;
     bench)   BENCH_N=$((BENCH_N+1)); local f=$O/bench$BENCH_N
              ( time timeout 1200 python bench.py "$@" > $f.json 2> $f.err ) 2> $f.time; tail -3 $f.time | head -1; grep -v amdgpu.ids $f.err | tail -4; bench_summary $f.json ;;
