@@ -36,7 +36,8 @@ LANES_FOR = {1: 4, 2: 4, 4: 4, 8: 4, 16: 4, 32: 4}
 # ... and with the cross-agent exchange beside the lanes (--gpus N > 1, and the one-GPU RCCL leg): the device runs four busy streams side by side, so two lanes (SuperPoint
 # and NetVLAD stream each) leave the exchange stream a hardware pipe it shares with a NetVLAD stream only: 2445-2453 stereo frames/s per rank with the exchange against
 # 2416-2425 with three or four lanes, where it takes turns with a lane's SuperPoint stream (measured over one-rank RCCL)
-LANES_WITH_EXCHANGE = {16: 2, 32: 2}          # --exchange-impl torch only (round 5's placement: a stream of the exchange's own)
+LANES_WITH_EXCHANGE = {16: 2, 32: 2}          # round 6 A/B over RCCL loopback (profiles/r06_exchange_placement_ab.txt): d2fe_exchange_* on ONE stream of its own beside TWO lanes
+                                              # 2230-2235; beside four lanes 2200-2206; on the producing lanes' streams 2128-2151 (the lane's next pass waits for the sequence)
 REFUSED_ENV = ("D2FE_ABLATE", "D2FE_MATCH_NOFALLBACK")     # switches that make results wrong or parity unproven: never inside a benchmark
 
 H, W, CAP = 480, 640, 200
@@ -192,9 +193,11 @@ def main():
                          "256-D descriptors leaves most rows un-normalised -- the reference's own cross-agent numerics); int8-renorm256 = the same bytes, every "
                          "descriptor re-normalised over its 256 floats on decode.  Either way 3.9x fewer all-gather bytes")
     ap.add_argument("--exchange-impl", choices=["capi", "torch"], default=os.environ.get("D2FE_BENCH_EXCHANGE_IMPL", "capi"),
-                    help="N>1: capi = d2fe_exchange_* of the C ABI (csrc/exchange.hip): the sequence queued by the library on the stream of the lane that produced the ticket, "
-                         "ncclAllGather on an RCCL communicator of the library's own (dlopen), all four lanes kept; torch = round 5's form (Python-driven, torch.distributed "
-                         "collective, one stream of its own, two lanes).  capi falls back to torch when the C exchange cannot be created (recorded in `exchange.impl`)")
+                    help="N>1: capi = d2fe_exchange_* of the C ABI (csrc/exchange.hip): the sequence queued by the library on one stream of its own, "
+                         "ncclAllGather on an RCCL communicator of the library's own (dlopen); torch = round 5's form (Python-driven, torch.distributed "
+                         "collective, one stream of its own).  Two lanes either way.  capi falls back to torch when the C exchange cannot be created (recorded in `exchange.impl`)")
+    ap.add_argument("--exchange-lane-streams", action="store_true", help="capi: the exchange on the producing lanes' streams instead of ONE stream of its own (A/B: measured 5-7 %% slower, "
+                                                                         "profiles/r06_exchange_placement_ab.txt)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency leg (host-pointer C ABI, one frame per call)")
     ap.add_argument("--latency-calls", type=int, default=300)
     ap.add_argument("--no-width-sensitivity", action="store_true", help="skip the NetVLAD trunk-width legs (`netvlad_width_sensitivity`)")
@@ -441,9 +444,9 @@ def main():
     # EVERY --gpus N times the frames-in-flight pipe (include/d2fe.h, d2fe_pipe_*): host frames in, host results out, `lanes` submits in flight.  N > 1 adds the
     # cross-agent exchange on a stream of its own beside it (run_pipe / swarm.PipeExchange) and keeps two submits in flight instead of four (LANES_WITH_EXCHANGE: the
     # exchange stream then has a hardware pipe it shares with a NetVLAD stream only); nothing else differs between `--gpus 1` and `--gpus 8`
-    lanes = args.lanes or (LANES_FOR.get(args.frames, 2) if (not dist_path or args.exchange_impl == "capi") else LANES_WITH_EXCHANGE.get(args.frames, LANES_FOR.get(args.frames, 2)))
+    lanes = args.lanes or (LANES_FOR.get(args.frames, 2) if not dist_path else LANES_WITH_EXCHANGE.get(args.frames, LANES_FOR.get(args.frames, 2)))
     xmode = args.exchange if dist_path else None
-    pk = dict(world=world, dist=dist, exchange=xmode, loopback=loopback, exchange_impl=args.exchange_impl)
+    pk = dict(world=world, dist=dist, exchange=xmode, loopback=loopback, exchange_impl=args.exchange_impl, exchange_own_stream=not args.exchange_lane_streams)
     full_run = world == 1 and not dist_path and not args.single_mode          # the default `python bench.py`: every secondary leg
     primary = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, args.steps, args.warmup, local_rank, rank, netvlad=use_nv, **pk)
     if world == 1 and not dist_path and lanes > 1 and not args.no_solo:
@@ -567,7 +570,7 @@ def main():
 
     if rank == 0 and full_run and not args.no_exchange_loopback:
         # LAST leg of the run: it creates (and destroys) a one-rank RCCL communicator, whose proxy threads and streams must not sit beside any other measurement
-        exch_1gpu = exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, args.lanes or (lanes if args.exchange_impl == "capi" else LANES_WITH_EXCHANGE.get(args.frames, lanes)), short, local_rank, rank, use_nv, dev)
+        exch_1gpu = exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, args.lanes or LANES_WITH_EXCHANGE.get(args.frames, lanes), short, local_rank, rank, use_nv, dev)
 
     cpu_baseline = None
     parity = None
@@ -811,7 +814,7 @@ def exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, lanes, step
                            "RCCL communicator (loopback: the rank's own blocks as the remote agent, %d cross-agent pairs per submit), against the same step without it; best of two "
                            "alternating runs each" % (args.frames, lanes, w["exch"]["cross_agent_pairs_per_step_per_gpu"]),
                 "value_with_exchange": round(w["value"], 2), "value_without_exchange": round(wo["value"], 2), "ms_per_step_with_exchange": round(w["ms_per_step"], 3),
-                "ms_per_step_without_exchange": round(wo["ms_per_step"], 3), "exchange_cost_frac_of_step": round(w["ms_per_step"] / wo["ms_per_step"] - 1.0, 4),
+                "ms_per_step_without_exchange": round(wo["ms_per_step"], 3), "exchange_cost_frac_of_step": round(w["ms_per_step"] / wo["ms_per_step"] - 1.0, 4), "lanes": lanes,
                 "step_timeline_ms": w["exch"]["step_timeline_ms"], "wire_precision": args.exchange}
     except Exception as e:      # noqa: BLE001
         return {"error": str(e)[:300]}
@@ -839,7 +842,7 @@ def stream_classes(r):
 
 
 def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup, local_rank, rank, netvlad=True, light=False, coalesce=1, depth=0, inflight=0,
-             world=1, dist=None, exchange=None, nv_flop_per_img=NV_FLOP_PER_IMG, nv_group=1, loopback=False, exchange_impl="capi"):
+             world=1, dist=None, exchange=None, nv_flop_per_img=NV_FLOP_PER_IMG, nv_group=1, loopback=False, exchange_impl="capi", exchange_own_stream=True):
     """`steps` submits of F stereo frames through the frames-in-flight pipe with `lanes` submits in flight: the timed region holds, per submit, the H2D of
     the 2F frames from pinned memory, SuperPoint on them, NetVLAD of the F left images, ONE matcher launch (L<->R, L<->previous L) and the D2H of every
     result into pinned memory.  EVERY --gpus N runs this function (N = 1: no process group, no barrier).  N > 1 with `exchange`: one cross-agent exchange
@@ -864,8 +867,9 @@ def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup
         G = fe.netvlad_dim if netvlad else 0
         if exchange_impl == "capi":
             try:
-                xch = swarm.PipeExchange(torch, fe, pipe, dev, world, rank, F, CAP, G, exchange=exchange, gate_thres=NETVLAD_GATE, ratio=0.8, slots=NS, loopback=loopback)
-                ximpl = "capi: d2fe_exchange_* (csrc/exchange.hip), queued on the producing lane's stream; collective = %s" % (
+                xch = swarm.PipeExchange(torch, fe, pipe, dev, world, rank, F, CAP, G, exchange=exchange, gate_thres=NETVLAD_GATE, ratio=0.8, slots=NS, loopback=loopback,
+                                         own_stream=exchange_own_stream)
+                ximpl = "capi: d2fe_exchange_* (csrc/exchange.hip), queued on %s; collective = %s" % ("ONE stream of its own" if exchange_own_stream else "the producing lane's stream",
                     "ncclAllGather on the library's own RCCL communicator (%s)" % api.load_library().d2fe_rccl_path().decode() if xch.backend == "nccl" else "host-staged callback (%s)" % xch.backend)
             except Exception as e:      # noqa: BLE001 -- e.g. no loadable librccl: the torch.distributed form still runs (every rank decides alike: same library, same box)
                 ximpl = "torch (the C exchange could not be created: %s)" % str(e)[:160]

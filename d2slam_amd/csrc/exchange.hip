@@ -7,10 +7,11 @@
 //   -> ONE matcher launch (a side in place in the lane's result block, b side in place in the gathered blocks) -> d2fe_pipe_device_release -> ONE D2H into a pinned slot
 //
 // Rounds 3-5 had this sequence in Python (d2slam_amd/swarm.py PipeExchange, torch.distributed for the collective) and as a C++ test program (tests/cpp/swarm_test.cpp);
-// here it is behind the C ABI, so D2SLAM's C++ calls it and neither torch's stream wrapper nor Python is in the path.  Where it runs: by default on the stream of the
-// LANE that produced the ticket (d2fe_pipe_lane_stream), behind that lane's D2H -- the lane is idle there until its next turn (lanes - 1 submits later), so the
-// exchange takes no hardware pipe of its own and the pipe keeps all its lanes at N > 1 (round 5: a stream of its own took turns with a lane's SuperPoint stream,
-// +2.9 % per step, which is why --gpus N > 1 ran two lanes instead of four).  RCCL is loaded at run time (dlopen), only when a communicator is made or used.
+// here it is behind the C ABI, so D2SLAM's C++ calls it and neither torch's stream wrapper nor Python is in the path (measured over one-rank RCCL: 2230-2235 stereo
+// frames/s with the exchange against 2202-2211 for the Python-driven form).  Where it runs: ONE stream of the exchange's own (default) or the stream of the LANE
+// that produced the ticket (d2fe_pipe_lane_stream, behind that lane's D2H).  The second form needs no further hardware pipe, but the lane's NEXT pass -- which
+// a saturated pipe submits the moment the ticket has been waited for -- then queues behind 0.3 ms of latency-bound launches: measured 5-7 % per step against 1-3 %
+// (profiles/r06_exchange_placement_ab.txt), so it is an option, not the default.  RCCL is loaded at run time (dlopen), only when a communicator is made or used.
 #include <dlfcn.h>
 
 #include <cstring>
@@ -128,7 +129,7 @@ void d2fe_exchange_default_config(d2fe_exchange_config* c) {
   if (!c) return;
   memset(c, 0, sizeof(*c));
   c->struct_size = (int32_t)sizeof(*c);
-  c->world = 1; c->rank = 0; c->wire = D2FE_WIRE_FP32; c->loopback = 0; c->slots = 4; c->gate_thres = 0.8; c->ratio = 0.8; c->own_stream = 0; c->timing = 0;
+  c->world = 1; c->rank = 0; c->wire = D2FE_WIRE_FP32; c->loopback = 0; c->slots = 4; c->gate_thres = 0.8; c->ratio = 0.8; c->own_stream = 1; c->timing = 0;
 }
 
 void d2fe_exchange_destroy(d2fe_exchange x) {

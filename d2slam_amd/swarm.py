@@ -205,7 +205,8 @@ def remote_pair_layout(world: int, rank: int, F: int, cap: int, blk_words: int, 
 class PipeExchange:
     """The cross-agent exchange of one rank BEHIND a frames-in-flight pipe, as a thin caller of the C ABI (include/d2fe.h d2fe_exchange_*, csrc/exchange.hip; round 6):
     the stand-in for the reference's broadcast of the frame it has just extracted (loop_net.cpp:24-87) and trackRemoteFrames on the receivers
-    (d2featuretracker.cpp:237-310).  Per ticket the LIBRARY queues, on the stream of the lane that produced the ticket (behind that lane's D2H; no stream of its own):
+    (d2featuretracker.cpp:237-310).  Per ticket the LIBRARY queues, on ONE stream of the exchange's own (own_stream=True, the measured best: profiles/r06_exchange_placement_ab.txt)
+    or on the stream of the lane that produced the ticket (behind that lane's D2H; that lane's next pass then waits for the sequence):
 
         device view -> pack_blocks(_int8) -> ONE all-gather -> [int8: decode] -> counts -> NetVLAD gate -> ONE matcher launch -> release -> ONE D2H into a pinned slot
 
@@ -215,7 +216,7 @@ class PipeExchange:
     on the submitting thread would starve the pipe; the reference's LCM handler runs beside the front-end thread too, loop_net.cpp).
     enqueue() is called one submit BEHIND the pipe (after submit(i): enqueue(ticket i - 1)).  collect() returns torch views of the pinned slot."""
 
-    def __init__(self, torch, fe, pipe, dev, world, rank, F, cap, netvlad_dim, exchange="fp32", gate_thres=0.8, ratio=0.8, slots=4, group=None, loopback=False, own_stream=False,
+    def __init__(self, torch, fe, pipe, dev, world, rank, F, cap, netvlad_dim, exchange="fp32", gate_thres=0.8, ratio=0.8, slots=4, group=None, loopback=False, own_stream=True,
                  timing=True):
         from . import api
         assert exchange in ("fp32", "int8", "int8-renorm256") and (world > 1 or loopback)

@@ -349,8 +349,9 @@ D2FE_API d2fe_handle d2fe_pipe_handle(d2fe_pipe p);
  * Replaces, per submitted stereo frame set: the LCM broadcast of the frame an agent has just extracted (LoopNet::broadcastVisualImageDescArray,
  * d2frontend/src/loop_net.cpp:24-87; wire precision VisualImageDesc::toLCM, d2common/include/d2common/d2frontend_types.h:228-268) and, on every receiver,
  * D2FeatureTracker::trackRemoteFrames (d2frontend/src/d2featuretracker.cpp:237-310: the NetVLAD gate of getMatchedPrevKeyframe :185-203, then matchKNN of the
- * local frame against the remote one).  One sequence per ticket, asynchronous, on the stream of the lane that produced the ticket (own_stream = 0; the lane is idle
- * there until its next turn, so the exchange takes no hardware pipe of its own) or on one stream of the exchange's own (own_stream = 1):
+ * local frame against the remote one).  One sequence per ticket, asynchronous, on ONE stream of the exchange's own (own_stream = 1, the default and the measured best
+ * beside a two-lane pipe: profiles/r06_exchange_placement_ab.txt) or on the stream of the lane that produced the ticket (own_stream = 0: no further stream, but that
+ * lane's next pass waits for the sequence):
  *   device view of the ticket -> pack one block per left frame (fp32, or the reference's int8 wire form) -> ONE all-gather over the communicator -> [int8: decode
  *   as the receiving constructor does, :319-338] -> counts -> NetVLAD gate of every (local frame f, remote frame f of rank r) pair -> ONE matcher launch (local
  *   descriptors read in place in the lane's result block, remote ones in place in the gathered blocks) -> release of the view -> ONE D2H into pinned slot `slot`.
@@ -365,7 +366,7 @@ typedef struct {
   int32_t wire;                 /* d2fe_wire: fp32 blocks, the reference's int8 LCM precision (hard-coded 32-float renormalisation), or int8 + 256-float renormalisation */
   int32_t loopback;             /* the rank's OWN gathered blocks count as a remote agent too (how a one-rank communicator exercises the whole sequence) */
   int32_t slots;                /* ring of pinned result slots (>= the exchanges the caller keeps in flight) */
-  int32_t own_stream;           /* 0: each ticket's sequence on its lane's stream (default); 1: one stream of the exchange's own */
+  int32_t own_stream;           /* 1 (default): one stream of the exchange's own; 0: each ticket's sequence on its lane's stream */
   int32_t timing;               /* 1: HIP events around the five phases (d2fe_exchange_result.phase_ms) */
   double gate_thres;            /* track_remote_netvlad_thres (d2featuretracker.cpp:199) */
   double ratio;                 /* knn_match_ratio */

@@ -130,7 +130,7 @@ def test_cpp_exchange_compiles_against_the_c_abi_alone(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lanes,wire,own_stream", [(4, 0, 0), (2, 0, 1), (4, 1, 0), (3, 2, 0)])
+@pytest.mark.parametrize("lanes,wire,own_stream", [(4, 0, 0), (2, 0, 1), (4, 1, 1), (3, 2, 0)])
 def test_cpp_exchange_entry_points_behind_the_pipe(tmp_path, orc, lanes, wire, own_stream):
     """d2fe_exchange_* + d2fe_rccl_* driven from g++ (tests/cpp/exchange_test.cpp: no Python, no torch in the process): a ONE-rank RCCL communicator made by the
     library itself, loopback, the sequence on the producing lane's stream (own_stream = 0) or on a stream of its own.  Per submit: the pipe's keypoint counts equal the
