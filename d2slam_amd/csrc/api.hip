@@ -820,6 +820,10 @@ inline void nv_groups(long base_blocks, int nchunk, int gmax, int* groups, int* 
   const double chunk_us = 2.3, launch_us = 6.0;
   if (rule && g >= 3 && (per(2) - per(g)) * chunk_us < launch_us) g = 2;
   if (rule && g == 2 && sum_at_2 && (per(1) - per(2)) * chunk_us < launch_us) g = 1;
+  // round 6 (MobileNetV2-0.75: 9 chunks at 120 x 160 and 60 x 80): with 32 or more tiles per image a second group halves a workgroup's chunks (~10 us of ONE image's
+  // latency) but makes every batch stage each input patch twice, write and re-read a second slab and, where the consumer wants one slab, launch the slab sum:
+  // measured at 32 images 194 + 26 us with two groups against 160 us with one (profiles/r06_netvlad_timeline.txt).  The split stays per IMAGE (batch invariance)
+  if (rule && g == 2 && base_blocks >= 32 && nchunk <= 12) g = 1;
   *cpg = per(g);
   *groups = (nchunk + *cpg - 1) / *cpg;
 }
