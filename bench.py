@@ -1086,7 +1086,7 @@ def profiled_traffic(kernel_tag):
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes of this command (profiles/r05_wino_rocprofv3_summary.txt, else round 4's:
     separate --pmc FETCH_SIZE and WRITE_SIZE passes, tools/profile.sh; KiB per dispatch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
     gfx950's wide reads).  bench.py itself does not collect counters: null when the file is absent."""
-    name = next((n for n in ("r05_wino_rocprofv3_summary.txt", "r04_wino_rocprofv3_summary.txt") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+    name = next((n for n in ("r06_wino_rocprofv3_summary.txt", "r05_wino_rocprofv3_summary.txt", "r04_wino_rocprofv3_summary.txt") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
     if name is None:
         return None, None
     path = os.path.join(ROOT, "profiles", name)

@@ -480,9 +480,10 @@ extern "C" {
 
 void d2fe_destroy(d2fe_handle h) {
   if (!h) return;
-  // pipes created from this handle run on ITS packed weights: destroying it under them would leave every lane with dangling pointers.  Refuse
-  // (the handle stays valid; d2fe_last_error says why) -- destroy the pipes first
-  if (h->live_pipes.load() > 0) { fail(D2FE_ERR_INVALID, "d2fe_destroy: the handle still has live pipes (d2fe_pipe_destroy them first); nothing was released"); return; }
+  // pipes created from this handle run on ITS packed weights: destroying it under them would leave every lane with dangling pointers.  The destruction is
+  // DEFERRED: the handle is marked and the last d2fe_pipe_destroy releases it (a silent refusal leaked the handle when a wrapper destroyed in the
+  // wrong order).  Until then the handle must not be used for anything else; d2fe_last_error records what happened
+  if (h->live_pipes.load() > 0) { h->doomed.store(true); fail(D2FE_ERR_INVALID, "d2fe_destroy: the handle still has live pipes; it will be released when the last of them is destroyed"); return; }
   hipSetDevice(h->cfg.device_id);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->tail_stream) { hipStreamSynchronize(h->tail_stream); (void)hipStreamDestroy(h->tail_stream); }

@@ -49,6 +49,7 @@ struct d2fe_context {
   hipStream_t stream = nullptr;
   bool sp_loaded = false;
   bool borrowed = false;       // a pipeline lane (clone_lane): the packed weights belong to the parent context
+  std::atomic<bool> doomed{false};    // d2fe_destroy was called while pipes were alive: the last d2fe_pipe_destroy releases the handle
   std::atomic<int> live_pipes{0};   // pipes created from this handle and not destroyed yet: their lanes read THIS handle's packed weights, so d2fe_destroy,
                                // d2fe_load_* and d2fe_set_*_pca refuse (D2FE_ERR_INVALID) while it is non-zero
   float* w1a = nullptr;  // [9][64]

@@ -555,8 +555,10 @@ void d2fe_pipe_destroy(d2fe_pipe p) {
   if (p->d_pairs) (void)hipFree(p->d_pairs);
   if (p->d_match_scratch) (void)hipFree(p->d_match_scratch);
   if (p->d_all) (void)hipFree(p->d_all);
-  p->parent->live_pipes.fetch_sub(1);
+  d2fe_context* parent = p->parent;
   delete p;
+  // a handle destroyed while this pipe was alive was only MARKED (d2fe_destroy): the last pipe to go releases it
+  if (parent->live_pipes.fetch_sub(1) == 1 && parent->doomed.load()) d2fe_destroy(parent);
 }
 
 int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int stride, size_t image_stride, int64_t* ticket) {
@@ -565,6 +567,14 @@ int d2fe_pipe_submit(d2fe_pipe p, const uint8_t* left, const uint8_t* right, int
   HIP_TRY(hipSetDevice(p->parent->cfg.device_id));
   std::lock_guard<std::mutex> lk(p->mu);
   if (p->failed) return pipe_fail(p->failed, "the pipe failed in an earlier call and accepts no more work (destroy it): " + p->failed_msg);
+  // A device view of the block the NEXT pass will write that its consumer has not released is the CALLER's protocol error, found here before anything is staged or
+  // advanced: the submit is refused (D2FE_ERR_NOT_READY, not sticky -- release the view and submit again); finished tickets stay collectable
+  if (p->pend == 0) {
+    const long long Pn = p->next_pass;
+    const auto& Ln = p->lanes[(size_t)(Pn % p->K)];
+    if (Ln.views[(int)((Pn / p->K) & 1)] > 0)
+      return pipe_fail(D2FE_ERR_NOT_READY, "a device view of the result block this submit's pass would write has not been released (d2fe_pipe_device_release): nothing was queued");
+  }
   // an error anywhere below leaves the open pass half-enqueued while next_pass / pend / the ticket ring may or may not have advanced: no later pass can
   // build on that (it would wait on a stale extraction event and index its pair table with a stale prev_g), so the first error is final for the pipe
   const int rc_all = [&]() -> int {

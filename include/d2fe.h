@@ -235,7 +235,9 @@ D2FE_API int d2fe_match_batch_device(d2fe_handle h, const d2fe_match_batch* mb, 
  * frames per submit with up to `lanes` submits in flight: d2fe_pipe_submit only enqueues (H2D, both networks, ONE matcher launch,
  * ONE D2H, on the lane's own streams), d2fe_pipe_wait returns pointers into the lane's pinned result block.  Results are bit-identical
  * to d2fe_extract_all_batch + d2fe_match_knn on the same frames.  A pipe borrows the handle's packed weights: while a pipe exists d2fe_destroy
- * of its handle releases nothing (d2fe_last_error says why) and d2fe_load_* / d2fe_set_*_pca return D2FE_ERR_INVALID -- destroy the pipes first.  The first error of a
+ * of its handle is DEFERRED (the handle is released by the last d2fe_pipe_destroy; d2fe_last_error says so) and d2fe_load_* / d2fe_set_*_pca return
+ * D2FE_ERR_INVALID -- destroy the pipes first.  A submit whose pass would overwrite a result block with an unreleased device view returns D2FE_ERR_NOT_READY
+ * and queues nothing (release the view, submit again).  The first error of a
  * submit or wait is final for the pipe: every later call returns it (a half-enqueued pass cannot be built on); destroy the pipe and create a new one.  One submitting thread per pipe; d2fe_pipe_wait may be called from a second thread (the reference's image
  * callback and its tracker are two threads): the pipe serialises its own bookkeeping and does not hold the lock while a wait blocks.  The caller bounds the
  * frames between its two threads (a queue of at most lanes * coalesce tickets is always safe), as the result blocks are a ring of 2 * lanes passes. */

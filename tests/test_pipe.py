@@ -247,13 +247,23 @@ def test_handle_with_live_pipes_refuses_destroy_and_reload():
     pipe = api.StereoPipe(fe, lanes=2, frames=1, width=W, height=H, cap=CAP, netvlad=False)
     with pytest.raises(api.D2FEError):
         fe.load_superpoint(w)
-    fe._lib.d2fe_destroy(fe.handle)                              # refused: the handle stays valid and the pipe keeps working
-    assert b"live pipes" in fe._lib.d2fe_last_error()
     o = pipe.wait(pipe.submit(fr[0][0][None], fr[0][1][None]))
     n = int(o["n_kp"][0]); np.testing.assert_array_equal(o["desc"][0, :n], ref[0][2])
     pipe.close()
     fe.load_superpoint(w)                                        # allowed again
     np.testing.assert_array_equal(fe.extract_batch(np.stack(fr[0]), cap=CAP)[0][2], ref[0][2])
+    # d2fe_destroy under a live pipe is DEFERRED (round 6): the handle is marked, the pipe keeps working on its weights, and the last
+    # d2fe_pipe_destroy releases the handle (a wrapper that destroys in the wrong order no longer leaks it)
+    fe2 = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2, keypoint_threshold=0.005))
+    fe2.load_superpoint(w)
+    p2 = api.StereoPipe(fe2, lanes=2, frames=1, width=W, height=H, cap=CAP, netvlad=False)
+    fe2._lib.d2fe_destroy(fe2.handle)
+    assert b"live pipes" in fe2._lib.d2fe_last_error() and b"released when the last" in fe2._lib.d2fe_last_error()
+    o2 = p2.wait(p2.submit(fr[0][0][None], fr[0][1][None]))
+    n2 = int(o2["n_kp"][0]); np.testing.assert_array_equal(o2["desc"][0, :n2], ref[0][2])
+    p2.close()                                                   # releases the handle too
+    import ctypes as C2
+    fe2._h = C2.c_void_p()                                       # the wrapper must not destroy it a second time
     pin = api.StereoPipe(fe, lanes=2, frames=1, width=W, height=H, cap=CAP, netvlad=False, pinned_input=True)
     with pytest.raises(ValueError):
         pin.submit(fr[0][0][None], fr[0][1][None])
@@ -307,13 +317,22 @@ def test_pipe_device_view_feeds_a_consumer_stream(coal):
     if coal == 1:
         with pytest.raises(api.D2FEError):
             pipe.device_view(tk[0], X.cuda_stream)               # 8 passes on a ring of 2 * lanes = 4: its block has been rewritten since
-    # a view that is never released: the pass that comes round to its block (2 * lanes passes later) is refused, and the pipe stays failed
+    # a view that is never released: the submit whose pass would overwrite its block (2 * lanes passes later) is REFUSED before anything is queued
+    # (D2FE_ERR_NOT_READY, round 6: not sticky) -- the tickets in flight stay collectable, and after the release the pipe goes on, same bits as ever
     pipe.device_view(tk[-1], X.cuda_stream)
-    with pytest.raises(api.D2FEError):
+    more = []
+    with pytest.raises(api.D2FEError) as ei:
         for l, r in fr + fr:
-            pipe.submit(l[None], r[None])
+            more.append(pipe.submit(l[None], r[None]))
+    assert ei.value.code == -3 and len(more) >= 1, (ei.value.code, len(more))
     with pytest.raises(api.D2FEError):
-        pipe.submit(fr[0][0][None], fr[0][1][None])
+        pipe.submit(fr[0][0][None], fr[0][1][None])               # still refused: the view is still out
+    o_last = pipe.wait(more[-1])                                     # finished work is not thrown away
+    assert int(o_last["n_kp"][0]) > 10
+    pipe.device_release(tk[-1], X.cuda_stream)
+    o_next = pipe.wait(pipe.submit(fr[0][0][None], fr[0][1][None]))
+    ref0 = fe.extract_batch(np.stack(fr[0]), cap=CAP)
+    n0 = int(o_next["n_kp"][0]); np.testing.assert_array_equal(o_next["desc"][0, :n0], ref0[0][2])
     pipe.close(); fe.close()
 
 
