@@ -465,8 +465,53 @@ def main():
         except Exception as e:      # noqa: BLE001
             latency = run_latency(api, weights, nv_weights, local_rank, args.precision, args.latency_calls)
             latency["process"] = "the benchmark process (the child process failed: %s)" % str(e)[:100]
+    # the batch curve BEFORE the CPU children start: its one-frame points are host-latency-bound (measured: 1338 stereo fps at 1 x 4 beside the children, 1686-1691 without)
+    if full_run and not args.no_batch_curve:
+        batch_curve = []
+        for Fc in (1, 2, 4, 8, 16, 32):
+            for Kc in sorted({1, LANES_FOR[Fc]} | ({2} if Fc <= 2 else set())):      # one or two frames per submit: also TWO in flight (the best plain configuration at F = 1)
+                if Fc == args.frames and Kc == lanes:
+                    r = primary
+                elif Fc == args.frames and Kc == 1 and solo is not None:
+                    r = solo
+                else:
+                    r = run_pipe(torch, api, weights, nv_weights, args.precision, Fc, Kc, max(12, min(400, int(700 / Fc))), max(2 * Kc, 4), local_rank, rank, netvlad=use_nv,
+                                 light=True)
+                batch_curve.append({"stereo_frames_per_submit": Fc, "submits_in_flight": Kc, "coalesce": 1, "stereo_fps": round(r["value"], 1), "ms_per_submit": round(r["ms_per_step"], 4),
+                                    "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r)})
+            if Fc == 1:
+                # one stereo frame per submit, consecutive submits coalesced into one launch sequence when they arrive before anybody waits
+                # (d2fe_pipe_config.coalesce): what a caller that receives single frames gets without batching by hand
+                for cc in (2, 4):
+                    r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, coalesce=cc)
+                    batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": 4 * cc, "coalesce": cc, "stereo_fps": round(r["value"], 1),
+                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r),
+                                        "note": "submit() stages the frame (its H2D starts at once); every %d-th submit launches ONE sequence over the staged frames, "
+                                                "4 such passes in flight; per-ticket results are bit-identical to the single calls (tests/test_pipe.py)" % cc})
+                if use_nv:
+                    # four single-frame passes in flight, the NetVLAD descriptors of four consecutive submits from ONE call (d2fe_pipe_config.netvlad_group: the
+                    # global descriptor feeds loop detection, not the tracker, so it may trail the keypoints by up to three submits); SuperPoint and the matches of
+                    # every submit still start at once
+                    r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=True, light=True, nv_group=4)
+                    batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": 4, "coalesce": 1, "netvlad_group": 4, "stereo_fps": round(r["value"], 1),
+                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r),
+                                        "note": "netvlad_group = 4: one NetVLAD call per four consecutive single-frame submits; bit-identical results"})
+                # ONE 4-lane pipe of plain single-frame passes (coalesce = 1) under callers that keep 1 / 2 / 3 submits outstanding (4: the K = 4 point above): the
+                # pipe decides per pass which stream NetVLAD goes to (d2fe_pipe_config.netvlad_inline = auto), so the lone pass keeps the single-lane latency
+                for infl in (1, 2, 3):
+                    r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, inflight=infl)
+                    batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": infl, "lanes": 4, "coalesce": 1, "stereo_fps": round(r["value"], 1),
+                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r),
+                                        "note": "the 4-lane pipe of the K = 4 point with fewer submits outstanding"})
+                # dynamic batching (coalesce_depth = 2): a pass is launched as soon as fewer than two are in flight, so the SAME configuration serves a caller
+                # that waits for every frame (1 in flight: launched at once) and one that keeps 16 in flight (passes grow to 4 frames)
+                for infl in (1, 4, 16):
+                    r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, coalesce=4, depth=2, inflight=infl)
+                    batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": infl, "coalesce": 4, "coalesce_depth": 2, "stereo_fps": round(r["value"], 1),
+                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r),
+                                        "note": "dynamic batching: up to 4 consecutive submits per pass, launched early whenever fewer than 2 passes are in flight"})
     # cpu_baseline (SURVEY.md section 8d protocol: warm-up 5, >= 50 timed iterations, median + p95; one thread and all cores): two child processes started HERE, after the
-    # headline, solo and latency legs, so that their 1-2 minutes pass beside the secondary GPU legs below (a few host threads on a 256-core box) instead of adding to the run
+    # headline, solo, latency and batch-curve legs, so that their 1-2 minutes pass beside the secondary GPU legs below (a few host threads on a 256-core box) instead of adding to the run
     cpu_children = start_cpu_baseline(args, use_nv) if (rank == 0 and world == 1 and not dist_path and not args.no_cpu_baseline) else None
     legs, legs_solo = {}, {}
     short = max(5, args.steps // 2)
@@ -512,50 +557,6 @@ def main():
                                      % (len(imgs_ps), n_syn // 2, (len(imgs_ps) - n_syn) // 2, CAP),
                              "wino_vs_f32": rec["wino_vs_f32_all"], "f16x2_vs_f32": rec["f16x2_vs_f32_all"], "wino_vs_f32_real_derived": rec["wino_vs_f32_real_derived"],
                              "seconds": round(time.time() - t_ps, 1)}
-    if full_run and not args.no_batch_curve:
-        batch_curve = []
-        for Fc in (1, 2, 4, 8, 16, 32):
-            for Kc in sorted({1, LANES_FOR[Fc]} | ({2} if Fc <= 2 else set())):      # one or two frames per submit: also TWO in flight (the best plain configuration at F = 1)
-                if Fc == args.frames and Kc == lanes:
-                    r = primary
-                elif Fc == args.frames and Kc == 1 and solo is not None:
-                    r = solo
-                else:
-                    r = run_pipe(torch, api, weights, nv_weights, args.precision, Fc, Kc, max(12, min(400, int(700 / Fc))), max(2 * Kc, 4), local_rank, rank, netvlad=use_nv,
-                                 light=True)
-                batch_curve.append({"stereo_frames_per_submit": Fc, "submits_in_flight": Kc, "coalesce": 1, "stereo_fps": round(r["value"], 1), "ms_per_submit": round(r["ms_per_step"], 4),
-                                    "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r)})
-            if Fc == 1:
-                # one stereo frame per submit, consecutive submits coalesced into one launch sequence when they arrive before anybody waits
-                # (d2fe_pipe_config.coalesce): what a caller that receives single frames gets without batching by hand
-                for cc in (2, 4):
-                    r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, coalesce=cc)
-                    batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": 4 * cc, "coalesce": cc, "stereo_fps": round(r["value"], 1),
-                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r),
-                                        "note": "submit() stages the frame (its H2D starts at once); every %d-th submit launches ONE sequence over the staged frames, "
-                                                "4 such passes in flight; per-ticket results are bit-identical to the single calls (tests/test_pipe.py)" % cc})
-                if use_nv:
-                    # four single-frame passes in flight, the NetVLAD descriptors of four consecutive submits from ONE call (d2fe_pipe_config.netvlad_group: the
-                    # global descriptor feeds loop detection, not the tracker, so it may trail the keypoints by up to three submits); SuperPoint and the matches of
-                    # every submit still start at once
-                    r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=True, light=True, nv_group=4)
-                    batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": 4, "coalesce": 1, "netvlad_group": 4, "stereo_fps": round(r["value"], 1),
-                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r),
-                                        "note": "netvlad_group = 4: one NetVLAD call per four consecutive single-frame submits; bit-identical results"})
-                # ONE 4-lane pipe of plain single-frame passes (coalesce = 1) under callers that keep 1 / 2 / 3 submits outstanding (4: the K = 4 point above): the
-                # pipe decides per pass which stream NetVLAD goes to (d2fe_pipe_config.netvlad_inline = auto), so the lone pass keeps the single-lane latency
-                for infl in (1, 2, 3):
-                    r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, inflight=infl)
-                    batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": infl, "lanes": 4, "coalesce": 1, "stereo_fps": round(r["value"], 1),
-                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r),
-                                        "note": "the 4-lane pipe of the K = 4 point with fewer submits outstanding"})
-                # dynamic batching (coalesce_depth = 2): a pass is launched as soon as fewer than two are in flight, so the SAME configuration serves a caller
-                # that waits for every frame (1 in flight: launched at once) and one that keeps 16 in flight (passes grow to 4 frames)
-                for infl in (1, 4, 16):
-                    r = run_pipe(torch, api, weights, nv_weights, args.precision, 1, 4, 600, 16, local_rank, rank, netvlad=use_nv, light=True, coalesce=4, depth=2, inflight=infl)
-                    batch_curve.append({"stereo_frames_per_submit": 1, "submits_in_flight": infl, "coalesce": 4, "coalesce_depth": 2, "stereo_fps": round(r["value"], 1),
-                                        "ms_per_submit": round(r["ms_per_step"], 4), "host_ms_per_submit_call": round(r["host_submit_ms"], 4), "stream_classes": stream_classes(r),
-                                        "note": "dynamic batching: up to 4 consecutive submits per pass, launched early whenever fewer than 2 passes are in flight"})
     disagreement = None
     disagreement_fast = None
     if rank == 0 and world == 1 and "f32" in legs and args.precision == "wino":

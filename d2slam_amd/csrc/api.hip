@@ -910,8 +910,11 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     // image's tile count and the DEVICE's compute units (not the batch, not a pipeline lane's share): an image's descriptor is the same bits
     // in a 1-image call, a 32-image batch and any pass of the frames-in-flight pipe.  A batch then runs with more groups than it needs to fill
     // the device (15 x 20 layers at 32 images: 7 slabs instead of 4) -- a few MB of partial-slab traffic
-    nv_groups(tiles1, a.Chid / 16, next_fused ? pj.gmax : 1, &groups, &cpg, h->nv_blocks_target,
-              st.pblock ? nv_pblock_slots(a.Cin, a.Cout, h->ncu_dev, 1) * 85 / 100 : 0, next_single, h->nv_group_rule);
+    // a consumer that is NOT a fused step (a generic per-layer launch: the stride-2 block 72 -> 432 -> 120 of the 0.75-wide trunk) reads one plain tensor: the split is
+    // still worth it (27 chunks in ONE workgroup per tile ran 115 us at 32 images and 70 us for one image; nine groups + the slab sum: 55 + 17 us), the slabs are summed below
+    const bool sum_for_plain_consumer = !next_fused;
+    nv_groups(tiles1, a.Chid / 16, pj.gmax, &groups, &cpg, h->nv_blocks_target,
+              st.pblock ? nv_pblock_slots(a.Cin, a.Cout, h->ncu_dev, 1) * 85 / 100 : 0, next_single || sum_for_plain_consumer, h->nv_group_rule);
     a.cpg = cpg; a.out = pj.out; a.out_slab_stride = (long)n * a.Ho * a.Wo * a.Cout;
     pj.slabs = groups; pj.slab_stride = a.out_slab_stride;
     a.ncu = h->ncu; a.tpw = h->nv_front_tpw; a.nbuf = h->nv_nbuf;
@@ -932,7 +935,7 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     else if (st.xblock) HIP_TRY(launch_nv_xblock(a, n, groups, s));
     else HIP_TRY(launch_nv_block(a, st.expand, st.front ? 1 : 0, n, groups, s));
     // three or more partial slabs: sum them once instead of in every consumer workgroup (and in every residual read)
-    if ((h->nv_slabsum > 0 && groups >= h->nv_slabsum) || (next_single && groups > 1)) { HIP_TRY(launch_nv_slab_sum(pj.out, groups, pj.slab_stride, pj.slab_stride, s)); pj.slabs = 1; }
+    if ((h->nv_slabsum > 0 && groups >= h->nv_slabsum) || ((next_single || sum_for_plain_consumer) && groups > 1)) { HIP_TRY(launch_nv_slab_sum(pj.out, groups, pj.slab_stride, pj.slab_stride, s)); pj.slabs = 1; }
     ch = a.Ho; cw = a.Wo;
   }
   const int np = ch * cw;

@@ -44,9 +44,11 @@ __host__ __device__ constexpr int nvp_row(int c) { return c * NVP_EROW + 4 * (c 
 
 // waves per SIMD the register allocation must leave room for (unified VGPR + AGPR file, 512 per lane): what the launches of this network need to be
 // resident in ONE round -- 640 workgroups of <2, 8> on 256 CUs need 3 per CU, 1280 of <1, 4> need 5; left alone the compiler settles for 2 and 4
-__host__ __device__ constexpr int nvp_min_waves(int nt, int nk) { return nt == 1 ? (nk <= 4 ? 5 : nk <= 8 ? 4 : 3) : nt == 2 ? (nk <= 8 ? 3 : 2) : 2; }
-// Cin >= 120 (30 k-steps: 90 input registers per lane): no second register set for a producer's partial slabs -- the input must be ONE slab (run_netvlad sums first)
-__host__ __device__ constexpr bool nvp_multi_in(int nk) { return nk < 30; }
+__host__ __device__ constexpr int nvp_min_waves(int nt, int nk) { return nt == 1 ? (nk <= 4 ? 5 : nk <= 8 ? 4 : 3) : nt == 2 ? (nk <= 8 ? 3 : 2) : (nt <= 5 && nk <= 12) ? 3 : 2; }
+// Cin >= 72 (18 / 30 k-steps: 54 / 90 input registers per lane): no second register set for a producer's partial slabs -- the input must be ONE slab (run_netvlad sums
+// first; these layers' producers split into >= 3 groups and are summed anyway).  That, and the residual read in the epilogue from Cin 48 on, is what lets the 48-wide
+// blocks run three workgroups per CU instead of two (166 registers, no spills; the 72-wide ones spill at 168 and measured slower: two; tools/kernel_resources.py)
+__host__ __device__ constexpr bool nvp_multi_in(int nk) { return nk < 18; }
 // project stage of one k-step: the pair's two depthwise outputs (even pixel -> m-tile 0, odd pixel -> m-tile 1) against the NT n-tiles of B fragments at `wks`
 template <int NT>
 __device__ __forceinline__ void nvp_project(const float* wks, int lane, float d0, float d1, f32x4 (&acc)[2][NT]) {
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
 
   // ---- residual (hidden-channel group 0 only): C layout of the project accumulators, row = pair 16 wave + 4 lq + r, pixel 2 px + m2 ----------
   const float* rp = (a.res && lead) ? a.res + (size_t)n * a.Ho * a.Wo * Cout : nullptr;
-  constexpr bool RES_EARLY = NT <= 4;
+  constexpr bool RES_EARLY = NT <= 4 && NK < 12;
   float resv[2][4][RES_EARLY ? NT : 1];
   int obase[4];                 // element offset of (pixel of pair r, m2 = 0, channel lp), or -1
   bool ok2[4];                  // the pair's odd pixel is inside the output too
