@@ -542,10 +542,12 @@ def main():
                 if mult == NV_MULT:
                     r = primary
                 else:
-                    r = run_pipe(torch, api, weights, nvm2.synthetic_netvlad_weights(depth_multiplier=mult), args.precision, args.frames, lanes, short, 2, local_rank, rank,
-                                 netvlad=True, nv_flop_per_img=nvm2.arch_flops(mult, H, W))
+                    # best of two short runs: a leg of ten steps beside the CPU children's start-up has shown single outliers of 15 % (2039 / 2417 for the same build)
+                    wts = nvm2.synthetic_netvlad_weights(depth_multiplier=mult)
+                    r = min((run_pipe(torch, api, weights, wts, args.precision, args.frames, lanes, short, 4, local_rank, rank, netvlad=True, light=True,
+                                      nv_flop_per_img=nvm2.arch_flops(mult, H, W)) for _ in range(2)), key=lambda q: q["ms_per_step"])
                 width_sens["points"].append({"depth_multiplier": mult, "trunk_gflop_per_image": round(nvm2.arch_flops(mult, H, W) / 1e9, 3), "value": round(r["value"], 1),
-                                             "ms_per_step": round(r["ms_per_step"], 3), "netvlad_ms_per_call_beside_superpoint": (r.get("roofline_nv") or {}).get("ms_per_call")})
+                                             "ms_per_step": round(r["ms_per_step"], 3)})
         if not args.no_parity_study:
             # index parity of the TIMED build, collected in this run: a 128-image subset of tools/mode_disagreement.py's study
             from d2slam_amd import parity_study as ps
