@@ -31,134 +31,12 @@ sys.path.insert(0, ROOT)
 # The frames-in-flight pipe gives every lane two HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
 # streams that share a queue serialise.  Must be set before the HIP runtime initialises; recorded in the JSON line (`env_overrides`).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-# lanes in flight per frames-per-submit for the batch curve (measured: tools/pipe_probe.py; more lanes than this do not pay)
-LANES_FOR = {1: 4, 2: 4, 4: 4, 8: 4, 16: 4, 32: 4}
-# ... and with the cross-agent exchange beside the lanes (--gpus N > 1, and the one-GPU RCCL leg): the device runs four busy streams side by side, so two lanes (SuperPoint
-# and NetVLAD stream each) leave the exchange stream a hardware pipe it shares with a NetVLAD stream only: 2445-2453 stereo frames/s per rank with the exchange against
-# 2416-2425 with three or four lanes, where it takes turns with a lane's SuperPoint stream (measured over one-rank RCCL)
-LANES_WITH_EXCHANGE = {16: 2, 32: 2}          # round 6 A/B over RCCL loopback (profiles/r06_exchange_placement_ab.txt): d2fe_exchange_* on ONE stream of its own beside TWO lanes
-                                              # 2230-2235; beside four lanes 2200-2206; on the producing lanes' streams 2128-2151 (the lane's next pass waits for the sequence)
-REFUSED_ENV = ("D2FE_ABLATE", "D2FE_MATCH_NOFALLBACK")     # switches that make results wrong or parity unproven: never inside a benchmark
-
-H, W, CAP = 480, 640, 200
-CONV1B_FLOP_PER_IMG = 2.0 * H * W * 64 * 64 * 9          # 22.65 GFLOP (SURVEY.md section 8a layer table)
-SP_FLOP_PER_IMG = 52.1e9
-NV_MULT = 0.75                                            # MobileNetV2 alpha = 0.75 trunk (HF-Net's width) -> NetVLAD K = 32 -> 4096
-NV_FLOP_PER_IMG = 2.4780096e9                             # the stand-in MobileNetVLAD trunk at that width, 640x480: 1.239 GMAC (d2slam_amd.netvlad.arch_flops(0.75))
-PEAK_TFLOPS = {"f32": 157.3, "f16x2": 2500.0, "wino": 157.3}             # MI355X_MICROARCH.md: fp32 MFMA / dense f16 MFMA
-NETVLAD_GATE = 0.8                                        # track_remote_netvlad_thres stand-in (the YAMLs carry 0.5..0.8)
-
-# ---- the stdout contract: ONE JSON line, the LAST thing on stdout, on every rank, small enough to survive a tail ------------------------------------------------------
-# RCCL prints its version banner through C stdio, which on a pipe or file is flushed at process exit -- behind anything Python printed (round 5's line was lost to that).
-# So (i) fd 1 is pointed at stderr for the whole run (the banner, torch, rocprofv3 children, stray prints land there), the JSON line goes to the saved descriptor;
-# (ii) before the line is written every C stream is flushed (a driver that merges stderr into stdout still sees the banner BEFORE the line); (iii) after the line fds 1 and 2
-# of this process go to /dev/null: nothing can follow it.  Ranks other than 0 never own stdout at all.
-_REAL_STDOUT = None
-LINE_BUDGET = 6000                  # bytes; the driver keeps an 8 KB tail
-HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-                 "roofline", "cpu_baseline", "step_roofline", "parity", "roofline_netvlad", "rccl", "exchange", "netvlad_gate", "cross_agent", "extras")
-# dropped from the line (kept in the extras file) in this order while the line is above LINE_BUDGET
-SHED_ORDER = ("cross_agent", "netvlad_gate", "exchange", "roofline_netvlad", "rccl")
-
-
-def claim_stdout():
-    global _REAL_STDOUT
-    if _REAL_STDOUT is None:
-        sys.stdout.flush()
-        _REAL_STDOUT = os.dup(1)
-        os.dup2(2, 1)
-
-
-def silence_this_process():
-    """fds 1 and 2 -> /dev/null (after flushing every C and Python stream): whatever this process still prints (exit-time banners, teardown warnings) goes nowhere"""
-    import ctypes
-    try:
-        sys.stdout.flush(); sys.stderr.flush()
-        ctypes.CDLL(None).fflush(None)
-    except Exception:      # noqa: BLE001
-        pass
-    nul = os.open(os.devnull, os.O_WRONLY)
-    os.dup2(nul, 1); os.dup2(nul, 2)
-
-
-def emit_line(obj):
-    """the JSON line: everything buffered so far is flushed first, the line is written to the process's ORIGINAL stdout in one piece, then the process goes silent"""
-    global _REAL_STDOUT
-    import ctypes
-    data = (json.dumps(obj) + "\n").encode()
-    sys.stdout.flush(); sys.stderr.flush()
-    try:
-        ctypes.CDLL(None).fflush(None)
-    except Exception:      # noqa: BLE001
-        pass
-    fd = _REAL_STDOUT if _REAL_STDOUT is not None else 1
-    while data:
-        n = os.write(fd, data)
-        data = data[n:]
-    silence_this_process()
-    if _REAL_STDOUT is not None:
-        os.close(_REAL_STDOUT)
-        _REAL_STDOUT = None
-
-
-def slim(o, maxlen=150, keep=("workload", "sample", "kernel", "api")):
-    """the headline form of a (nested) record: prose longer than `maxlen` characters lives in the extras file; the strings a reader needs to identify the
-    workload stay, cut to 320 characters"""
-    if isinstance(o, dict):
-        out = {}
-        for k, v in o.items():
-            if isinstance(v, str) and len(v) > maxlen:
-                if k in keep:
-                    out[k] = v if len(v) <= 320 else v[:317] + "..."
-                continue
-            out[k] = slim(v, maxlen, keep)
-        return out
-    if isinstance(o, list):
-        return [slim(v, maxlen, keep) for v in o]
-    return o
-
-
-def extras_path():
-    p = os.environ.get("D2FE_BENCH_EXTRAS")
-    if p:
-        return p
-    d = os.path.join(ROOT, "gpurun_out")
-    try:
-        os.makedirs(d, exist_ok=True)
-        return os.path.join(d, "bench_extras.json")
-    except OSError:
-        import tempfile
-        return os.path.join(tempfile.gettempdir(), "d2fe_bench_extras.json")
-
-
-def headline(full):
-    """(line, path): the full record goes to the extras file (named in the line), the line keeps HEADLINE_KEYS in slim form and fits LINE_BUDGET"""
-    path = extras_path()
-    try:
-        with open(path, "w") as f:
-            json.dump(full, f, indent=1)
-        rel = os.path.relpath(path, ROOT)
-        named = rel if not rel.startswith("..") else path
-    except OSError as e:
-        named = "not written: %s" % str(e)[:80]
-    always = ("vs_baseline", "cpu_baseline", "roofline")          # present (null when this run has none) in every line
-    line = {k: slim(full.get(k)) for k in HEADLINE_KEYS if k in always or full.get(k) is not None}
-    cb = line.get("cpu_baseline")
-    if isinstance(cb, dict):          # the per-stage tables and the fmaf-chain extra stay in the file
-        cb = {k: ({a: b for a, b in v.items() if a != "ms_per_stereo_frame"} if isinstance(v, dict) else v) for k, v in cb.items() if k != "fmaf_oracle"}
-        line["cpu_baseline"] = dict(cb, per_stage="extras file: cpu_baseline.{all_cores,single_thread}.ms_per_stereo_frame")
-    line["extras"] = {"file": named, "keys": sorted(k for k in full if k not in line)}
-    if isinstance(line.get("rccl"), dict) and len(line["rccl"].get("ranks") or []) > 2:
-        line["rccl"] = dict(line["rccl"], ranks="%d entries in the extras file" % len(line["rccl"]["ranks"]))
-    for k in SHED_ORDER:
-        if len(json.dumps(line)) <= LINE_BUDGET:
-            break
-        if k in line:
-            del line[k]
-            line["extras"]["keys"] = sorted(line["extras"]["keys"] + [k])
-    if len(json.dumps(line)) > LINE_BUDGET:
-        line["extras"]["keys"] = "see the file"
-    return line, path
+from benchlib.common import *  # noqa: F401,F403,E402  (H, W, CAP, LANES_FOR, NV_FLOP_PER_IMG, PEAK_TFLOPS, ...)
+from benchlib.stdout_contract import LINE_BUDGET, HEADLINE_KEYS, claim_stdout, silence_this_process, emit_line, slim, extras_path, headline  # noqa: E402
+from benchlib.rooflines import (sp_executed_gflop_per_image, step_roofline, flag_above_peak, build_record, netvlad_roofline, index_parity_evidence,  # noqa: E402
+                                profiled_traffic, live_traffic, conv1b_roofline)
+from benchlib.pipe_legs import pipe_frames, exchange_on_one_gpu, stream_classes, run_pipe, mode_disagreement, self_launch, collective_evidence  # noqa: E402
+from benchlib.other_legs import run_quadcam, run_latency, synthetic_sp_for_threshold  # noqa: E402
 
 
 def main():
@@ -727,670 +605,8 @@ def main():
     finish(out)
 
 
-# executed matrix-pipe FLOPs of ONE 640x480 image through SuperPoint (sparse descriptor head at <= 4 corner cells per keypoint, 200 keypoints): the layer table of
-# SURVEY.md section 8(a) with the arithmetic each mode runs.  GFLOP: conv1a 0.354 (as staged inside conv1b's kernel: 60 MFMAs per 8x16 item = 0.590), conv1b 22.65,
-# conv2a 5.66, conv2b 5.66, conv3a 2.83, conv3b 5.66, conv4a 1.416, conv4b 1.416, convPa 2.831, convPb 0.160, descriptor head at the selected cells 0.28 (18 GFLOP per
-# 64 images, DESIGN.md section 4; the dense convDa + convDb would be 3.46)
-_SP_WINO_LAYERS_GF = 22.65 + 5.66 + 5.66 + 2.83 + 5.66 + 1.416 + 1.416 + 2.831       # the eight 3x3 layers the Winograd mode runs as F(2x2,3x3): 16/36 of these
-_SP_OTHER_GF = 0.160 + 0.28
-
-
-def sp_executed_gflop_per_image(precision):
-    if precision == "wino":
-        return 0.590 + _SP_WINO_LAYERS_GF * 16.0 / 36.0 + _SP_OTHER_GF
-    direct = 0.354 + _SP_WINO_LAYERS_GF + _SP_OTHER_GF
-    return direct * (3.0 if precision == "f16x2" else 1.0)
-
-
-def step_roofline(precision, F, ms_per_step, netvlad, npairs):
-    """The WHOLE step against the matrix pipe (VERDICT r04 #4): executed MFMA FLOPs of everything a step launches / ms_per_step / peak.  Analytic counts (the layer
-    table above; NetVLAD 2.478 GFLOP per left image (MobileNetV2-0.75 trunk) on the fp32 pipe; matchKNN 2 strips x 2 na nb 256 per pair); the per-kernel SQ_INSTS_MFMA sums of the committed
-    profile of the same command agree (profiles/: 3.46e8 x 4096 = 1.42 TFLOP per 64-image step in Winograd mode)."""
-    peak = PEAK_TFLOPS[precision]
-    sp = sp_executed_gflop_per_image(precision) * 1e9 * 2 * F
-    nv = NV_FLOP_PER_IMG * F if netvlad else 0.0
-    mt = 2 * 2.0 * CAP * CAP * 256 * npairs
-    # NetVLAD and the matcher run on the fp32 pipe in every mode; in f16x2 mode their FLOPs are priced at the fp32 peak separately
-    if precision == "f16x2":
-        frac = (sp / (peak * 1e12) + (nv + mt) / (PEAK_TFLOPS["f32"] * 1e12)) / (ms_per_step * 1e-3)
-    else:
-        frac = (sp + nv + mt) / (peak * 1e12) / (ms_per_step * 1e-3)
-    return {"bound": "mfma", "executed_mfma_tflop_per_step": round((sp + nv + mt) / 1e12, 4), "superpoint": round(sp / 1e12, 4), "netvlad": round(nv / 1e12, 4), "matcher": round(mt / 1e12, 4),
-            "ms_per_step": round(ms_per_step, 3), "achieved": round((sp + nv + mt) / (ms_per_step * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(frac, 4),
-            "algorithmic_tflop_per_step": round((SP_FLOP_PER_IMG * 2 * F + nv + mt / 2) / 1e12, 4),
-            "note": "executed matrix-pipe FLOPs of every launch of a step / wall time of the step (H2D, D2H, post-processing and launch gaps included) / peak"
-                    + ("; f16x2: SuperPoint's 3 MFMA FLOPs per algorithmic FLOP against the f16 peak, NetVLAD + matcher against the fp32 peak" if precision == "f16x2" else "")}
-
-
-def flag_above_peak(r):
-    """a roofline object whose ALGORITHMIC fraction exceeds 1 says why, next to the number (VERDICT r04 #4 / weak #6)"""
-    if r and (r.get("frac_algorithmic") or 0) > 1.0:
-        r["algorithmic_above_peak"] = "Winograd F(2x2,3x3): 16/36 of the direct convolution's multiplies are executed; `frac` (= frac_executed) is the matrix pipe's fraction"
-    return r
-
-
-def build_record():
-    """what d2slam_amd.build recorded for the library this run timed (ADVICE r04: a build that fell back to untuned flags must be visible in the line)"""
-    try:
-        from d2slam_amd import build as hb
-        bi = hb.build_info() or {}
-        return {"hipcc": bi.get("hipcc"), "tuned_flags": bi.get("tuned_flags"), "compiled_without_tuned_flags": bi.get("compiled_without_tuned_flags"),
-                "recorded": bool(bi)}
-    except Exception:      # noqa: BLE001
-        return {"recorded": False}
-
-
-def pipe_frames(F, rank):
-    """two alternating host frame sets for the pipe, [2 sets][L|R][F][H][W] u8: consecutive frames are pairs (scene, the scene after a small camera
-    motion), so L_f <-> L_(f-1) is a real temporal match for odd f; set 1 = set 0 after a further motion (F = 1: the temporal partner is the other set)"""
-    from d2slam_amd.synth import synth_stereo
-    host = np.empty((2, 2, F, H, W), np.uint8)
-    for f in range(F):
-        l, r = synth_stereo(H, W, seed=rank * 1000 + f // 2)
-        if f & 1:
-            l, r = np.roll(l, (1, 2), (0, 1)), np.roll(r, (1, 2), (0, 1))
-        host[0, 0, f], host[0, 1, f] = l, r
-        host[1, 0, f], host[1, 1, f] = np.roll(l, (2, 3), (0, 1)), np.roll(r, (2, 3), (0, 1))
-    return host
-
-
-def exchange_on_one_gpu(torch, dist, api, weights, nv_weights, args, lanes, steps, local_rank, rank, use_nv, dev):
-    """What the N > 1 exchange costs the step on the REAL backend, as far as one GPU can show it (VERDICT r04 #3: "--gpus 1 through that path equals BENCH value within 1 %"):
-    a one-rank RCCL communicator, the rank's own blocks as the remote agent (PipeExchange loopback: F cross-agent pairs per submit, every keypoint matches itself), the same
-    pipe configuration as `value`, alternating with the same step without the exchange.  Any failure (no RCCL, rendezvous) is reported, never fatal."""
-    created = False
-    try:
-        if not dist.is_initialized():
-            import socket
-            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(port)
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-            created = True
-        runs = []
-        for _ in range(2):
-            w = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, steps, 2, local_rank, rank, netvlad=use_nv, light=True, world=1, dist=dist,
-                         exchange=args.exchange, loopback=True, exchange_impl=args.exchange_impl)
-            wo = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, steps, 2, local_rank, rank, netvlad=use_nv, light=True)
-            runs.append((w, wo))
-        w = min((r[0] for r in runs), key=lambda r: r["ms_per_step"]); wo = min((r[1] for r in runs), key=lambda r: r["ms_per_step"])
-        return {"backend": dist.get_backend(), "impl": w["exch"].get("impl"), "what": "the step `--gpus N` runs on every rank (%d stereo frames per submit, %d submits in flight) with the cross-agent exchange over a ONE-rank "
-                           "RCCL communicator (loopback: the rank's own blocks as the remote agent, %d cross-agent pairs per submit), against the same step without it; best of two "
-                           "alternating runs each" % (args.frames, lanes, w["exch"]["cross_agent_pairs_per_step_per_gpu"]),
-                "value_with_exchange": round(w["value"], 2), "value_without_exchange": round(wo["value"], 2), "ms_per_step_with_exchange": round(w["ms_per_step"], 3),
-                "ms_per_step_without_exchange": round(wo["ms_per_step"], 3), "exchange_cost_frac_of_step": round(w["ms_per_step"] / wo["ms_per_step"] - 1.0, 4), "lanes": lanes,
-                "step_timeline_ms": w["exch"]["step_timeline_ms"], "wire_precision": args.exchange}
-    except Exception as e:      # noqa: BLE001
-        return {"error": str(e)[:300]}
-    finally:
-        if created:
-            try:
-                dist.destroy_process_group()
-            except Exception:      # noqa: BLE001
-                pass
-
-
-def netvlad_roofline(t_ms, F, how, flop_per_img=NV_FLOP_PER_IMG):
-    ach = flop_per_img * F / (t_ms * 1e-3) / 1e12
-    return {"kernel": "NetVLAD launch sequence (one launch per MobileNetV2 block: nv_fpair_kernel, nv_pblock_kernel (stride 1), nv_xblock_kernel (stride 2), nv_slab_sum_kernel, nv_tail_kernel, "
-                      "nv_vlad_* x2; d2slam_amd/csrc/netvlad*.hip): MobileNetV2-%.2f trunk + NetVLAD head" % (NV_MULT if abs(flop_per_img - NV_FLOP_PER_IMG) < 1 else -1),
-            "bound": "mfma", "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
-            "ms_per_call": round(t_ms, 4), "images_per_call": F, "algorithmic_flop_per_call": flop_per_img * F,
-            "note": "fp32 MFMA (v_mfma_f32_16x16x4_f32) + VALU depthwise; instruction/latency-bound small layers (DESIGN.md section 4); " + how}
-
-
-def stream_classes(r):
-    """compact form of a run's d2fe_pipe_stream_placement for the batch curve: 'n: own/second own/second ...' (n = classes told apart, 0 = not measured)"""
-    p = r.get("stream_placement") or {}
-    return "%s: %s" % (p.get("classes_told_apart"), " ".join("%d/%d" % (a, b) for a, b in p.get("lanes") or []))
-
-
-def run_pipe(torch, api, weights, nv_weights, precision, F, lanes, steps, warmup, local_rank, rank, netvlad=True, light=False, coalesce=1, depth=0, inflight=0,
-             world=1, dist=None, exchange=None, nv_flop_per_img=NV_FLOP_PER_IMG, nv_group=1, loopback=False, exchange_impl="capi", exchange_own_stream=True):
-    """`steps` submits of F stereo frames through the frames-in-flight pipe with `lanes` submits in flight: the timed region holds, per submit, the H2D of
-    the 2F frames from pinned memory, SuperPoint on them, NetVLAD of the F left images, ONE matcher launch (L<->R, L<->previous L) and the D2H of every
-    result into pinned memory.  EVERY --gpus N runs this function (N = 1: no process group, no barrier).  N > 1 with `exchange`: one cross-agent exchange
-    (d2slam_amd.swarm.PipeExchange: pack -> ONE all-gather -> gate -> remote matches -> D2H) per submit on a stream of its own, enqueued one submit behind the
-    pipe and collected with the ticket -- inside the timed region, beside the lanes' work.  Timing: barrier + device synchronisation on both sides (N > 1),
-    perf_counter around exactly `steps` submits + the waits for all of them; the caller takes the MAX over ranks."""
-    from d2slam_amd import swarm
-    prec = {"f32": api.PREC_F32, "f16x2": api.PREC_F16X2, "wino": api.PREC_F32_WINO}[precision]
-    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=1, precision=prec, device_id=local_rank))
-    fe.load_superpoint(weights)
-    if netvlad:
-        fe.load_netvlad(nv_weights)
-    host = torch.from_numpy(pipe_frames(F, rank)).pin_memory()
-    pipe = api.StereoPipe(fe, lanes=lanes, frames=F, width=W, height=H, cap=CAP, netvlad=netvlad, ratio=0.8, pinned_input=True, coalesce=coalesce, coalesce_depth=depth, netvlad_group=nv_group)
-    inflight = inflight or lanes * coalesce
-    base, per_set, per_side = host.data_ptr(), 2 * F * H * W, F * H * W
-    dev = torch.device("cuda", local_rank)
-    NS = inflight + 3
-    xch = None
-    ximpl = None
-    if (world > 1 or loopback) and exchange:
-        G = fe.netvlad_dim if netvlad else 0
-        if exchange_impl == "capi":
-            try:
-                xch = swarm.PipeExchange(torch, fe, pipe, dev, world, rank, F, CAP, G, exchange=exchange, gate_thres=NETVLAD_GATE, ratio=0.8, slots=NS, loopback=loopback,
-                                         own_stream=exchange_own_stream)
-                ximpl = "capi: d2fe_exchange_* (csrc/exchange.hip), queued on %s; collective = %s" % ("ONE stream of its own" if exchange_own_stream else "the producing lane's stream",
-                    "ncclAllGather on the library's own RCCL communicator (%s)" % api.load_library().d2fe_rccl_path().decode() if xch.backend == "nccl" else "host-staged callback (%s)" % xch.backend)
-            except Exception as e:      # noqa: BLE001 -- e.g. no loadable librccl: the torch.distributed form still runs (every rank decides alike: same library, same box)
-                ximpl = "torch (the C exchange could not be created: %s)" % str(e)[:160]
-        if xch is None:
-            xch = swarm.TorchPipeExchange(torch, fe, pipe, dev, world, rank, F, CAP, G, exchange=exchange, gate_thres=NETVLAD_GATE, ratio=0.8, slots=NS, loopback=loopback)
-            ximpl = ximpl or "torch: Python-driven sequence on a stream of its own, torch.distributed collective"
-
-    def submit(i):
-        o = base + (i & 1) * per_set
-        return pipe.submit_ptr(o, o + per_side)
-
-    use_dist = dist is not None and dist.is_initialized()      # N > 1, or one rank sent through the N > 1 path (--force-dist)
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    last = {}
-
-    def drive(n, start):
-        tk = []
-        th = 0.0
-        enq = [0]
-
-        def enq_upto(j):          # the exchange of tickets <= j is queued (one submit behind the pipe: see PipeExchange)
-            while xch and enq[0] <= j:
-                xch.enqueue(tk[enq[0]], enq[0] % NS); enq[0] += 1
-
-        def finish(j):            # host results of ticket j: the pipe's block now, the cross-agent lists of ticket j - 1 (N > 1)
-            pipe.wait_raw(tk[j])
-            if xch:
-                # one submit of slack between a frame's own results and its cross-agent results: the all-gather of step j completes when the SLOWEST rank has
-                # extracted step j, and the ranks are not in lock step (on one GPU under gloo they even alternate)
-                enq_upto(j)
-                if j >= 1:
-                    last["x"] = xch.collect((j - 1) % NS)
-                if j == n - 1:
-                    last["x"] = xch.collect(j % NS)
-        for i in range(n):
-            if i >= inflight:
-                finish(i - inflight)
-            ta = time.perf_counter(); tk.append(submit(start + i)); th += time.perf_counter() - ta
-            enq_upto(i - 1)
-        for j in range(max(0, n - inflight), n):
-            finish(j)
-        return tk, th
-    warmup = max(warmup, 2)
-    warmup += warmup & 1                       # an even number of submits: the timed region starts on frame set 0
-    drive(warmup, 0)
-    barrier()
-    if xch:
-        xch.timeline.clear()
-    if not light:
-        pipe.profile_enable(1)
-    barrier()
-    t0 = time.perf_counter()
-    tk, th = drive(steps, 0)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = pipe.profile_read() if not light else None
-    if not light:
-        pipe.profile_enable(0)
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    fb = fe.match_fallback_rows(reset=True, full=True)
-    NI, NP = 2 * F, 2 * F + (xch.NR if xch else 0)
-    res = dict(steps=steps, value=F * world * steps / elapsed, ms_per_step=elapsed / steps * 1e3, host_submit_ms=th / steps * 1e3, lanes=lanes, F=F, NI=NI, NP=NP, gated=None, exch=None,
-               breakdown=None, fallback_rows=(fb[0] / float(steps + warmup), fb[1] / float(steps + warmup)), roofline=None, roofline_nv=None)
-    if xch:
-        S = last["x"]
-        res["exch"] = {"impl": ximpl, "wire_precision": exchange, "block_bytes": xch.block_bytes, "all_gather_bytes_received_per_step_per_gpu": xch.block_bytes * F * (world - 1 + (1 if loopback else 0)),
-                       "cross_agent_pairs_per_step_per_gpu": xch.NR, "avg_cross_agent_matches_per_pair": round(float(S["mn"].float().mean()), 2),
-                       "d2h_bytes_per_step": xch.d2h_bytes, "enqueued": "one submit behind the pipe; collected with the ticket",
-                       "step_timeline_ms": dict(xch.timeline_ms() or {}, note="rank 0, medians over the timed submits, HIP events on the exchange stream (which shares the device "
-                                                "with the lanes' launches: an entry is the wall time of that phase beside them); backend %s" % dist.get_backend())}
-        if netvlad:
-            res["gated"] = {"pairs": xch.NR, "passing_netvlad_gate": int(S["gate_n"][0]), "threshold": NETVLAD_GATE}
-    if not light:
-        # one more submit of frame set 0 right behind one of set 1: what this mode selected and matched (parity / mode comparison)
-        tl = [submit(1), submit(0)]
-        if xch:
-            for j, t in enumerate(tl):
-                xch.enqueue(t, j)
-        pipe.wait_raw(tl[0])
-        o = pipe.wait(tl[1])
-        if xch:
-            xch.collect(0); xch.collect(1)
-        cnt = o["n_kp"].copy()
-        kidx = (o["kps_xy"][:, :, 1].astype(np.int64) * W + o["kps_xy"][:, :, 0].astype(np.int64)).astype(np.int32)
-        k0 = int(cnt[0])
-        res["first"] = (o["kps_xy"][0, :k0].copy(), o["scores"][0, :k0].copy(), o["desc"][0, :k0].copy())
-        res["gfirst"] = o["netvlad"][0].copy() if netvlad else None
-        res["sel"] = {"kidx": kidx, "cnt": cnt, "mq": np.concatenate([o["lr_q"], o["prev_q"]]).copy(), "mt": np.concatenate([o["lr_t"], o["prev_t"]]).copy(),
-                      "mn": np.concatenate([o["lr_n"], o["prev_n"]]).copy(), "a_row": list(range(F)) + list(range(F)),
-                      "b_row": [F + f for f in range(F)] + [None] + list(range(F - 1))}
-        res["n_kp"] = float(cnt.mean()); res["n_match"] = float(res["sel"]["mn"].mean())
-        res["d2h_bytes"] = int(4 * (NI * CAP * 259 + F * (fe.netvlad_dim if netvlad else 0) + NI + 2 * F + 3 * 2 * F * CAP)) + (xch.d2h_bytes if xch else 0)
-        c1b_ms, c1b_n = prof["conv1b"]
-        res["roofline"] = conv1b_roofline(precision, c1b_ms / max(c1b_n, 1), c1b_n, NI, True)
-        nv_ms, nv_n = prof["netvlad"]
-        if netvlad and nv_n:
-            res["roofline_nv"] = netvlad_roofline(nv_ms / nv_n, F, "HIP events around the whole sequence where the pipe queued it (netvlad_inline = auto: the lane's second stream beside that lane's SuperPoint, or the "
-                                                  "lane's own stream in front of it), with the other lanes' full-device launches on the chip: the figure is the sequence's WALL time in the "
-                                                  "running pipe (waits for compute units included), not its cost -- that is `roofline_netvlad` of the full line (the sequence alone)", nv_flop_per_img)
-    pl, ncl = pipe.stream_placement()
-    res["stream_placement"] = {"classes_told_apart": ncl, "lanes": pl, "exchange_stream_class": None}
-    if xch:
-        if getattr(xch, "stream", None) is not None:
-            try:
-                res["stream_placement"]["exchange_stream_class"] = pipe.classify_stream(xch.stream.cuda_stream)
-            except Exception as e:      # not idle (should not happen here: every ticket has been waited for)
-                res["stream_placement"]["exchange_stream_class"] = str(e)[:80]
-        else:
-            res["stream_placement"]["exchange_stream_class"] = "none: the exchange runs on the lanes' own streams"
-        xch.close()
-    pipe.close(); fe.close()
-    return res
-
-
-def mode_disagreement(a, b, F):
-    """MEASURED difference between the headline mode (Winograd fp32, `a`) and the bitwise-exact direct-convolution mode (`b`) on the very
-    frames the bench times: keypoints that one mode selects and the other does not (raster indices, per image), and matches
-    (as pairs of raster indices, so independent of the order inside a keypoint list) that one mode reports and the other does not.
-    Both modes are fp32 evaluations of the same network; they can only differ where two scores are closer than their ~1e-6 round-off."""
-    NI = 2 * F
-    kp_tot = kp_diff = img_diff = 0
-    for i in range(NI):
-        sa = set(a["kidx"][i, :a["cnt"][i]].tolist()); sb = set(b["kidx"][i, :b["cnt"][i]].tolist())
-        d = len(sa ^ sb)
-        kp_tot += len(sb); kp_diff += d; img_diff += d > 0
-    m_tot = m_diff = lr_tot = lr_diff = 0
-    for p in range(len(a["mn"])):
-        ia, ib = a["a_row"][p], a["b_row"][p]        # rows of the count / raster-index arrays; [2F, 3F) = the previous step's left images
-        if ib is None:                               # pipe: frame 0's temporal partner lives in the previous submit's block
-            continue
-
-        def pairs(m):
-            n = int(m["mn"][p])
-            return {(int(m["kidx"][ia][q]), int(m["kidx"][ib][t])) for q, t in zip(m["mq"][p, :n].tolist(), m["mt"][p, :n].tolist())}
-        pa, pb = pairs(a), pairs(b)
-        d = len(pa ^ pb)
-        m_tot += len(pb); m_diff += d
-        if ib < 2 * F:
-            lr_tot += len(pb); lr_diff += d
-    return {"images": NI, "keypoints_exact_mode": kp_tot, "keypoints_in_one_mode_only": kp_diff, "images_with_any_keypoint_difference": int(img_diff),
-            "match_pairs": len(a["mn"]), "matches_exact_mode": m_tot, "matches_in_one_mode_only": m_diff,
-            "left_right_matches_exact_mode": lr_tot, "left_right_matches_in_one_mode_only": lr_diff,
-            "note": "symmetric differences over the last step's frames (current L, R and the previous step's L); seeded random-init weights compress the score distribution, so near-ties at the top-K cut are far "
-                    "more frequent than with a trained network (DESIGN.md section 2)"}
-
-
-def self_launch(n):
-    """`python bench.py --gpus N` from a bare shell: the same command line as N ranks on this node (torch.distributed.run, rendezvous on
-    127.0.0.1 and a free port).  The ranks' stdout/stderr pass through; rank 0 prints the JSON line."""
-    import socket
-    import subprocess
-    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
-    env.setdefault("OMP_NUM_THREADS", "8")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    # the ranks inherit this process's ORIGINAL stdout as their fd 1 (this process's own fd 1 already points at stderr, see claim_stdout)
-    return subprocess.call(cmd, env=env, stdout=_REAL_STDOUT if _REAL_STDOUT is not None else None)
-
-
-def collective_evidence(torch, dist, dev, backend, rank, world):
-    """What the N>1 record needs to prove N ranks on N devices: the backend and world size as the process group reports them, every
-    rank's device identity gathered with all_gather_object, and one all-reduce over the group on the device (sum of ranks)."""
-    p = torch.cuda.get_device_properties(dev)
-    mine = {"rank": rank, "pid": os.getpid(), "device_index": dev.index, "name": p.name,
-            "uuid": str(getattr(p, "uuid", "")), "pci_bus_id": getattr(p, "pci_bus_id", None), "pci_device_id": getattr(p, "pci_device_id", None),
-            "cus": p.multi_processor_count}
-    allr = [None] * world
-    dist.all_gather_object(allr, mine)
-    t = torch.tensor([float(rank)], device=dev)
-    dist.all_reduce(t)
-    ver = None
-    try:
-        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
-    except Exception:
-        pass
-    ids = {(r["uuid"], r["pci_bus_id"], r["device_index"]) for r in allr}
-    return {"backend": dist.get_backend(), "is_rccl": dist.get_backend() == "nccl", "rccl_version": ver, "world_size": dist.get_world_size(),
-            "allreduce_sum_of_ranks": float(t.item()), "expected_sum": float(world * (world - 1) // 2),
-            "distinct_devices": len(ids), "ranks": allr}
-
-
-def index_parity_evidence():
-    """The committed run of tools/mode_disagreement.py (profiles/r04_mode_disagreement.json): keypoint / match index differences of the Winograd and
-    fp16 hi/lo modes against the exact fp32 mode over 1056 images (992 synthetic + 64 derived from the real crops of the reference's sample image) at
-    N = 100 / 150 / 200 and thresholds 0.015 / 0.15.  Summarised here as the worst rate over the six configurations; the bench frames of THIS run are
-    compared live in `wino_vs_exact_on_bench_frames` / `f16x2_vs_exact_on_bench_frames`."""
-    name = next((n for n in ("r05_mode_disagreement.json", "r04_mode_disagreement.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
-    if name is None:
-        return None
-    j = json.load(open(os.path.join(ROOT, "profiles", name)))
-    out = {"source": "profiles/" + name + " (python tools/mode_disagreement.py on MI355X, same kernels; the FULL study is not collected inside this run -- its 128-image subset is: "
-                     "`index_parity_in_run`)",
-           "images": j["images"], "real_derived_images": j["real_derived_images"], "pairs": j["pairs"], "configs": "N in {100, 150, 200} x threshold in {0.015, 0.15}"}
-    for m in ("wino", "f16x2"):
-        rows = [c["%s_vs_f32_all" % m] for c in j["configs"]]
-        out[m + "_vs_f32"] = {"keypoints_compared": sum(r["keypoints"] for r in rows), "keypoints_in_one_mode_only": sum(r["keypoints_in_one_mode_only"] for r in rows),
-                              "worst_per_1e4_keypoints": max(r["per_1e4_keypoints"] for r in rows),
-                              "matches_compared": sum(r["matches"] for r in rows), "matches_in_one_mode_only": sum(r["matches_in_one_mode_only"] for r in rows),
-                              "worst_per_1e4_matches": max(r["per_1e4_matches"] for r in rows)}
-    return out
-
-
-def profiled_traffic(kernel_tag):
-    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes of this command (profiles/r05_wino_rocprofv3_summary.txt, else round 4's:
-    separate --pmc FETCH_SIZE and WRITE_SIZE passes, tools/profile.sh; KiB per dispatch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    gfx950's wide reads).  bench.py itself does not collect counters: null when the file is absent."""
-    name = next((n for n in ("r06_wino_rocprofv3_summary.txt", "r05_wino_rocprofv3_summary.txt", "r04_wino_rocprofv3_summary.txt") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
-    if name is None:
-        return None, None
-    path = os.path.join(ROOT, "profiles", name)
-    fetch = write = None
-    lines = open(path).read().split("\n")
-    sect = ""
-    for i, l in enumerate(lines):
-        if l.startswith("== "):
-            sect = l
-        if kernel_tag in l and i + 1 < len(lines):
-            nxt = lines[i + 1]
-            if "pmc_fetch" in sect and "FETCH_SIZE=" in nxt:
-                fetch = float(nxt.split("FETCH_SIZE=")[1].split()[0])
-            if "pmc_write" in sect and "WRITE_SIZE=" in nxt:
-                write = float(nxt.split("WRITE_SIZE=")[1].split()[0])
-    if fetch is None or write is None:
-        return None, None
-    return int((2.0 * fetch + write) * 1024), "profiles/" + name + ": 2 x FETCH_SIZE %.4g KiB + WRITE_SIZE %.4g KiB per dispatch (rocprofv3 --pmc passes of `python bench.py`, same build; not collected inside this run)" % (fetch, write)
-
-
-def live_traffic(kernel_tag):
-    """roofline.traffic measured by THIS run: two child passes of this script under `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE, then WRITE_SIZE --
-    separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; KiB per dispatch; FETCH_SIZE doubled for gfx950's wide reads), the headline step with ONE
-    submit in flight and nothing else (--single-mode), averaged over the dispatches of the dominant kernel.  None when rocprofv3 is not there or a pass fails
-    (the committed profile is then quoted, see profiled_traffic)."""
-    import csv, glob, shutil, subprocess, tempfile
-    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(rp) or os.environ.get("D2FE_BENCH_CHILD"):
-        return None
-    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
-        return None              # this run is itself being profiled: no nested profiler
-    vals, t0 = {}, time.time()
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="d2fe_pmc_", dir="/tmp")
-        try:
-            env = dict(os.environ, D2FE_BENCH_CHILD="1", TMPDIR="/tmp")
-            cmd = [rp, "--output-format", "csv", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
-                   "--steps", "3", "--warmup", "1", "--precision", "wino", "--single-mode", "--no-cpu-baseline", "--lanes", "1"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
-            fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not fs:
-                return None
-            acc = n = 0
-            for row in csv.DictReader(open(fs[0])):
-                if kernel_tag in row["Kernel_Name"] and row["Counter_Name"] == ctr:
-                    acc += float(row["Counter_Value"]); n += 1
-            if not n:
-                return None
-            vals[ctr] = (acc / n, n)
-        except Exception:
-            return None
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
-    fetch, write = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
-    return {"traffic": int((2.0 * fetch + write) * 1024),
-            "counters": {"FETCH_SIZE_KiB_per_dispatch": round(fetch, 1), "WRITE_SIZE_KiB_per_dispatch": round(write, 1), "dispatches_averaged": [vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]],
-                         "seconds": round(time.time() - t0, 1)},
-            "note": "measured by this run: two child passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --single-mode --lanes 1 --steps 3` (same build, same "
-                    "step, one submit in flight); traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB per dispatch of the dominant kernel (the doubling: gfx950's 128-byte reads, MI355X_MICROARCH.md)"}
-
-
-def conv1b_roofline(precision, avg_ms, launches, NI, fused):
-    peak = PEAK_TFLOPS[precision]
-    alg = CONV1B_FLOP_PER_IMG * NI
-    if precision == "wino":
-        # Winograd F(2x2,3x3): 16 multiply-adds per output and channel pair where the direct convolution has 36.  The launch is the
-        # conv1a-fused kernel (D2FE_FUSE1A default): per 8x16-pixel work item 1024 conv1b MFMAs + 60 conv1a MFMAs (v_mfma_f32_32x32x2_f32).
-        items = NI * (H // 8) * (W // 16)
-        executed = items * (1024 + (60 if fused is not False else 0)) * 4096.0
-        ach_e = executed / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        ach_a = alg / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic, tnote = profiled_traffic("conv_wino_kernel<64, true, true, 0, 1, true") if (fused is not False and NI == 64) else (None, None)
-        return {"kernel": "conv_wino_kernel<64,POOL,RELU,FUSE> (conv1a from the u8 frame fused into conv1b as Winograd F(2x2,3x3), + ReLU + 2x2 max-pool)",
-                "bound": "mfma", "achieved": round(ach_e, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach_e / peak, 4),
-                "frac_executed": round(ach_e / peak, 4), "frac_algorithmic": round(ach_a / peak, 4),
-                "achieved_algorithmic": round(ach_a, 2),
-                "traffic": traffic, "traffic_note": tnote or "HBM bytes per launch are in profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes); not collected inside this run",
-                "compulsory_bytes_per_launch": int(NI * (H * W + (H // 2) * (W // 2) * 64 * 4)),
-                "avg_launch_ms": round(avg_ms, 4), "launches": launches,
-                "algorithmic_flop_per_launch": alg, "executed_mfma_flop_per_launch": executed,
-                "note": "frac = frac_executed = MFMA FLOPs the kernel executes / HIP-event time / 157.3 TF (the matrix pipe's roofline fraction); "
-                        "frac_algorithmic = SURVEY section 8(d)'s direct-convolution FLOPs / time / peak, above 1 because Winograd executes 16/36 of them"}
-    ach = alg / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-    ex = 3.0 if precision == "f16x2" else 1.0
-    return {"kernel": "conv_%s_kernel<64,3,4,32,2,2,2,1,POOL,RELU,FUSE1A> (conv1a fused into conv1b)" % ("f32" if precision == "f32" else "f16x2"),
-            "bound": "mfma", "achieved": round(ach * ex, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach * ex / peak, 4),
-            "frac_executed": round(ach * ex / peak, 4), "frac_algorithmic": round(ach / peak, 4), "achieved_algorithmic": round(ach, 2),
-            "traffic": None, "traffic_note": "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): 22.2 MB per image, 19.7 MB of it the pooled output",
-            "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_flop_per_launch": alg,
-            "executed_mfma_flop_per_launch": alg * ex,
-            "note": "f16x2 executes 3 MFMA FLOPs (hi*hi + hi*lo + lo*hi) per algorithmic FLOP" if precision == "f16x2" else "one MFMA FLOP per algorithmic FLOP"}
-
-
-def run_quadcam(args, torch, api, weights, dev, local_rank, world, rank=0):
-    """BASELINE configs[2] on one GPU: quadcam FOURCORNER_FISHEYE, 4 raw 1280x800 frames -> FisheyeUndist (800x400, photometric
-    gain) -> SuperPoint (100 keypoints, threshold 0.15: config/quadcam/quadcam_single.yaml:83,117) + NetVLAD on every view ->
-    neighbour matching as D2FeatureTracker::matchLocalFeatures does it for quadcam (d2featuretracker.cpp:1144-1182: half-image filter on
-    both views, a-side x shifted by +-move_cols, matchKNN with the search radius, index remap) + temporal matchKNN per view."""
-    import torch.distributed as dist
-    from d2slam_amd import netvlad as nvm, quadcam, swarm
-    from d2slam_amd.synth import synth_image
-    RH, RW, UH, UW, CAPQ = 800, 1280, 400, 800, 100
-    Q = max(1, args.frames // 4)          # quad frames per step
-    NI = 4 * Q
-    prec = {"f32": api.PREC_F32, "f16x2": api.PREC_F16X2, "wino": api.PREC_F32_WINO}[args.precision]
-    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAPQ, input_width=UW, input_height=UH, max_batch=NI, precision=prec,
-                                           keypoint_threshold=0.15, device_id=local_rank))
-    fe.load_superpoint(synthetic_sp_for_threshold(weights))
-    fe.load_netvlad(nvm.synthetic_netvlad_weights())
-    main = torch.cuda.Stream(device=dev); torch.cuda.set_stream(main)
-    st = main.cuda_stream
-    # raw frames camera-major: [c0: q0..q(Q-1) | c1: ... ] so that one undistort launch per camera writes a contiguous slab
-    # every agent flies through the same scenes (seed 7000 + i) with its own sensor noise, so that cross-agent matches exist
-    def frame(i):
-        im = synth_image(RH, RW, 7000 + i)
-        if world > 1:
-            rng = np.random.RandomState(977 * rank + i)
-            im = np.clip(im.astype(np.int16) + rng.randint(-2, 3, im.shape), 0, 255).astype(np.uint8)
-        return im
-    raw = torch.from_numpy(np.stack([frame(i) for i in range(NI)])).to(dev)
-    maps = [tuple(torch.from_numpy(m).to(dev) for m in quadcam.synthetic_maps(c, RH, RW, UH, UW)) for c in range(4)]
-    chain = quadcam.QuadcamChain(fe, torch, dev, Q, UH, UW, CAPQ, undistort_fov=200.0, knn_ratio=0.8, search_local_max_dist=0.2)
-    qs = swarm.QuadSwarm(chain, torch, dev, world, rank, fe.netvlad_dim, NETVLAD_GATE, mode=os.environ.get("D2FE_QUAD_SWARM_MODE", "all2all"),
-                         exchange=args.exchange) if world > 1 else None
-
-    side = torch.cuda.Stream(device=dev) if world > 1 else None
-
-    def step():
-        chain.step(raw, RH, RW, maps, st)
-        if qs:
-            # configs[4]: one block per view, ONE all-gather, the quadcam NetVLAD gate, view x view cross-agent matchKNN -- on a stream of its own behind a
-            # snapshot of the step's outputs, beside the next step's convolutions (the main stream waits for the 1.7 MB snapshot, never for the collective)
-            qs.step_overlapped(main, side)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    fe.profile_enable(1)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-    prof = fe.profile_read(); fe.profile_enable(0)
-    c1b_ms, c1b_n = prof["conv1b"]
-    avg_ms = c1b_ms / max(c1b_n, 1)
-    flop = 2.0 * UH * UW * 64 * 576 * NI
-    peak = PEAK_TFLOPS[args.precision]
-    items = NI * (UH // 8) * (UW // 16)
-    executed = items * 1084 * 4096.0 if args.precision == "wino" else flop * (3.0 if args.precision == "f16x2" else 1.0)
-    ach = executed / (avg_ms * 1e-3) / 1e12 if avg_ms else 0.0
-    out = {"metric": "quad frames/sec undistort+SuperPoint+NetVLAD+match, 4x(1280x800->800x400)", "value": round(Q * world * args.steps / el, 2),
-           "unit": "quad_frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision != "f16x2" else "f16x2(hi+lo split)/f32-acc", "data": "synthetic",
-           "config": {"workload": ("configs[2]: quadcam FOURCORNER_FISHEYE 1280x800 x4 virtual cams, undistort + SuperPoint + NetVLAD + "
-                                   "neighbour matching (half-image filter, +-move_cols shift, radius gate, index remap) + temporal matchKNN, 1 MI355X") if world == 1 else
-                                  ("configs[4]: %d-agent quadcam swarm, one agent per GPU: the configs[2] chain per agent + one exchange block per view "
-                                   "(4 per quad frame), ONE all-gather, the quadcam NetVLAD gate (getMatchedPrevKeyframe, FOURCORNER_FISHEYE branch) on the "
-                                   "device and view x view cross-agent matchKNN against every remote agent (%s)" % (world, qs.mode)),
-                      "quad_frames_per_step_per_gpu": Q, "max_keypoints": CAPQ, "threshold": 0.15, "undistort_fov": 200.0, "search_radius_px": 0.2 * UW,
-                      "precision": args.precision},
-           "avg_keypoints_per_image": round(chain.cnt[:NI].float().mean().item(), 1),
-           "avg_matches_per_pair": round(chain.mn.float().mean().item(), 1),
-           "roofline": {"kernel": "conv1b (executed MFMA FLOPs)", "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "frac_executed": round(ach / peak, 4), "frac_algorithmic": round(flop / (avg_ms * 1e-3) / 1e12 / peak, 4) if avg_ms else 0,
-                        "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": c1b_n,
-                        "measured": "HIP events on the one stream the quadcam chain runs on (undistort, NetVLAD, SuperPoint, matching in stream order): the launch has the device to itself",
-                        "traffic_note": "not collected for this leg (the d435 headline's conv1b launch is the same kernel: `roofline.traffic`)"},
-           "cpu_baseline": None}
-    if qs:
-        dp = qs.dir_prev.cpu().numpy()
-        out["cross_agent"] = {"jobs_per_step_per_gpu": qs.njobs, "view_pairs_per_step_per_gpu": qs.NP, "mode": qs.mode,
-                              "avg_matches_per_view_pair": round(qs.mn.float().mean().item(), 2),
-                              "wire_precision": qs.exchange, "block_bytes": qs.block_bytes, "all_gather_bytes_received_per_step": qs.block_bytes * NI * (world - 1),
-                              "stream": "its own, behind a snapshot of the step's outputs (QuadSwarm.step_overlapped): the main stream never waits for the collective"}
-        out["netvlad_gate"] = {"jobs": qs.njobs, "passing_netvlad_gate": int(qs.n_pass.item()), "threshold": NETVLAD_GATE,
-                               "rotation_histogram_dir_prev": {str(k): int((dp == k).sum()) for k in (-1, 0, 1, 2, 3)},
-                               "rule": "remote view 2 vs local views 2,3,0,1 in order, first similarity >= threshold (d2featuretracker.cpp:212-233)"}
-    fe.close()
-    return out
-
-
-def run_latency(api, weights, nv_weights, device_id, precision, calls):
-    """Single-call latency through the boundary AS THE REFERENCE CALLS IT: one image per SuperPoint::infer / MobileNetVLADONNX::inference
-    call (loop_cam.cpp:609-616), one matchKNN per pair, host pointers in and out (the H2D / D2H copies and the synchronisation are inside).
-    Raw ctypes calls into the C ABI with preallocated buffers; p50 / p99 over `calls` calls after 20 warm-up calls."""
-    import ctypes as C
-    from d2slam_amd.synth import synth_descriptor_pair, synth_image, synth_stereo
-    prec = {"f32": api.PREC_F32, "f16x2": api.PREC_F16X2, "wino": api.PREC_F32_WINO}[precision]
-    lib = api.load_library()
-    P = lambda a: a.ctypes.data_as(C.c_void_p)
-
-    def stats(fn):
-        for _ in range(20):
-            fn()
-        t = np.empty(calls)
-        for i in range(calls):
-            t0 = time.perf_counter(); fn(); t[i] = time.perf_counter() - t0
-        t *= 1e3
-        return {"p50_ms": round(float(np.percentile(t, 50)), 4), "p99_ms": round(float(np.percentile(t, 99)), 4), "mean_ms": round(float(t.mean()), 4)}
-
-    out = {"calls": calls, "precision": precision, "api": "host-pointer C ABI (sync H2D + kernels + D2H per call), python ctypes with preallocated buffers",
-           "reference_call_sites": "loop_cam.cpp:609-616 (infer / inference, one image per call), d2featuretracker.cpp:1134-1138 (matchKNN)"}
-    fe = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAP, input_width=W, input_height=H, max_batch=2, precision=prec, device_id=device_id))
-    fe.load_superpoint(weights)
-    if nv_weights is not None:
-        fe.load_netvlad(nv_weights)
-    h = fe._h
-    l, r = synth_stereo(H, W, seed=3)
-    pair = np.ascontiguousarray(np.stack([l, r]))
-    kps = np.zeros((2, CAP, 2), np.float32); sc = np.zeros((2, CAP), np.float32); desc = np.zeros((2, CAP, 256), np.float32)
-    cnt = np.zeros(2, np.int32)
-    one = lambda: lib.d2fe_superpoint_extract(h, P(pair), W, H, W, P(kps), P(sc), P(desc), CAP, P(cnt))
-    two = lambda: lib.d2fe_superpoint_extract_batch(h, P(pair), 2, W, H, W, H * W, P(kps), P(sc), P(desc), CAP, P(cnt))
-    assert one() == 0 and two() == 0
-    out["d2fe_superpoint_extract_1_image"] = stats(one)
-    out["d2fe_superpoint_extract_batch_2_images"] = stats(two)
-    if nv_weights is not None:
-        g = np.zeros(fe.netvlad_dim, np.float32)
-        nvc = lambda: lib.d2fe_netvlad(h, P(l), W, H, W, P(g))
-        assert nvc() == 0
-        out["d2fe_netvlad_1_image"] = stats(nvc)
-    two()
-    na, nb = int(cnt[0]), int(cnt[1])
-    da, db = desc[0, :na].copy(), desc[1, :nb].copy()
-    q = np.zeros(CAP, np.int32); t = np.zeros(CAP, np.int32); d = np.zeros(CAP, np.float32); nm = C.c_int(0)
-    mk = lambda: lib.d2fe_match_knn(h, P(da), na, P(db), nb, 256, C.c_double(0.8), None, None, C.c_double(-1.0), P(q), P(t), P(d), CAP, C.byref(nm))
-    assert mk() == 0
-    out["d2fe_match_knn_%dx%dx256" % (na, nb)] = stats(mk)
-
-    def stereo():            # what trackLocalFrames costs per stereo frame without NetVLAD: 2 images + L<->R + L<->prevL
-        two(); mk(); mk()
-    out["stereo_frame_2_images_2_matches_host_to_host"] = stats(stereo)
-    if nv_weights is not None:
-        def stereo_nv():
-            two(); nvc(); mk(); mk()
-        out["stereo_frame_with_netvlad_host_to_host"] = stats(stereo_nv)
-        # the fused entry point: ONE upload, SuperPoint (L+R) and NetVLAD (L) side by side on two streams (loop_cam.cpp:609-616 makes the two calls
-        # back to back for the same image)
-        g1 = np.zeros((1, fe.netvlad_dim), np.float32)
-        all1 = lambda: lib.d2fe_extract_all(h, P(pair), W, H, W, P(kps), P(sc), P(desc), CAP, P(cnt), P(g1))
-        all2 = lambda: lib.d2fe_extract_all_batch(h, P(pair), 2, W, H, W, H * W, P(kps), P(sc), P(desc), CAP, P(cnt), 1, P(g1))
-        assert all1() == 0 and all2() == 0
-        out["d2fe_extract_all_1_image_superpoint_and_netvlad"] = stats(all1)
-        out["d2fe_extract_all_batch_stereo_pair_netvlad_left"] = stats(all2)
-
-        def stereo_all():
-            all2(); mk(); mk()
-        out["stereo_frame_with_netvlad_fused_host_to_host"] = stats(stereo_all)
-        # the same frame through the pipe with ONE frame in flight (submit + wait): one upload, both networks, ONE matcher launch over both pairs with the
-        # previous left frame's descriptors still on the device, ONE download -- the whole per-frame work of processStereoframe as a single round trip
-        pipe = api.StereoPipe(fe, lanes=1, frames=1, width=W, height=H, cap=CAP, netvlad=True, ratio=0.8)
-        l1, r1 = np.ascontiguousarray(l[None]), np.ascontiguousarray(r[None])
-        def through_pipe():
-            pipe.wait_raw(pipe.submit_ptr(l1.ctypes.data, r1.ctypes.data))
-        through_pipe()
-        out["stereo_frame_with_netvlad_through_the_pipe_one_in_flight"] = stats(through_pipe)
-        pipe.close()
-    fe.close()
-    # one quadcam frame (configs[2] geometry): 4 undistorted 800x400 views through extract_batch + netvlad_batch
-    UH, UW, CAPQ = 400, 800, 100
-    fq = api.FrontEnd(api.SuperPointConfig(max_keypoints=CAPQ, input_width=UW, input_height=UH, max_batch=4, precision=prec, keypoint_threshold=0.15,
-                                           device_id=device_id))
-    fq.load_superpoint(synthetic_sp_for_threshold(weights))
-    views = np.ascontiguousarray(np.stack([synth_image(UH, UW, 7100 + i) for i in range(4)]))
-    k4 = np.zeros((4, CAPQ, 2), np.float32); s4 = np.zeros((4, CAPQ), np.float32); d4 = np.zeros((4, CAPQ, 256), np.float32); c4 = np.zeros(4, np.int32)
-    quad = lambda: lib.d2fe_superpoint_extract_batch(fq._h, P(views), 4, UW, UH, UW, UH * UW, P(k4), P(s4), P(d4), CAPQ, P(c4))
-    assert quad() == 0
-    out["quadcam_frame_4_views_800x400_extract_batch"] = stats(quad)
-    if nv_weights is not None:
-        fq.load_netvlad(nv_weights)
-        g4 = np.zeros((4, fq.netvlad_dim), np.float32)
-        qnv = lambda: lib.d2fe_netvlad_batch(fq._h, P(views), 4, UW, UH, UW, UH * UW, P(g4))
-        assert qnv() == 0
-        out["quadcam_frame_4_views_netvlad_batch"] = stats(qnv)
-        qall = lambda: lib.d2fe_extract_all_batch(fq._h, P(views), 4, UW, UH, UW, UH * UW, P(k4), P(s4), P(d4), CAPQ, P(c4), 4, P(g4))
-        assert qall() == 0
-        out["quadcam_frame_4_views_extract_all_batch"] = stats(qall)
-    fq.close()
-    return out
-
-
-def synthetic_sp_for_threshold(weights):
-    """quadcam uses threshold 0.15: lower the dustbin bias so the random-init net still yields >100 candidates per view."""
-    w = dict(weights)
-    Wt, b = w["convPb"]
-    b = b.copy(); b[64] -= np.float32(3.5)
-    w["convPb"] = (Wt, b)
-    return w
-
-
+# ---- cpu_baseline (kind "port") and the in-run parity check: the ONLY places of the benchmark that touch oracle/ (the checker and the reported baseline, never the
+# thing measured) -- kept in this file, run as child processes (--cpu-baseline-only) beside the secondary GPU legs ------------------------------------------------------
 def _torch_superpoint(torch, F, x, w):
     """superpoint.ipynb:300-374 in plain PyTorch (oneDNN convolutions on the host): image [n,1,H,W] fp32 in [0,1] -> semi [n,H,W], raw desc [n,256,H/8,W/8]."""
     def cv(t, name, relu=True):
@@ -1408,9 +624,6 @@ def _torch_superpoint(torch, F, x, w):
     sm = sm.permute(0, 2, 3, 1).reshape(n, hc, wc, 8, 8).permute(0, 1, 3, 2, 4).reshape(n, hc * 8, wc * 8)
     desc = desc / torch.norm(desc, p=2, dim=1, keepdim=True)
     return sm, desc
-
-
-CPU_WARMUP = 5          # warm-up 5, >= 50 timed iterations, median + p95
 
 
 def run_cpu_baseline_half(which, weights, nv_weights, iterations):
