@@ -72,11 +72,20 @@ __device__ __forceinline__ f32x4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, int vo
   __builtin_memcpy(&o, &v, 16);
   return o;
 }
+// Cache policy of the STREAMED data (aux bit 1 = nt on gfx940+).  The ablation sweep (profiles/r06_wino_ring_ablation.txt) shows the U loads as the largest exposed cost
+// of the K loop (13 %), so non-temporal patch copies / output stores were tried to leave the L2 ways to U: measured SLOWER (same-box A/B of bench.py --single-mode, round 6: value 2327 -> 2098 with
+// both, 2309 -> 2032 with the loads alone, 2317 -> 2308 with the stores alone: the second 64-channel walk and the neighbouring items re-read the patches from L2).  Kept as compile-time A/B switches, default 0
+#ifndef D2FE_WINO_LOAD_AUX
+#define D2FE_WINO_LOAD_AUX 0
+#endif
+#ifndef D2FE_WINO_STORE_AUX
+#define D2FE_WINO_STORE_AUX 0
+#endif
 __device__ __forceinline__ void buf_store_f32(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, D2FE_WINO_STORE_AUX);
 }
 __device__ __forceinline__ void buf_load_lds16(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {   // LDS-DMA, 16 B per lane
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lvoid_t*)lds, 16, voff, soff, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lvoid_t*)lds, 16, voff, soff, 0, D2FE_WINO_LOAD_AUX);
 }
 
 }  // namespace
