@@ -327,6 +327,10 @@ def main():
     pk = dict(world=world, dist=dist, exchange=xmode, loopback=loopback, exchange_impl=args.exchange_impl, exchange_own_stream=not args.exchange_lane_streams)
     full_run = world == 1 and not dist_path and not args.single_mode          # the default `python bench.py`: every secondary leg
     primary = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, lanes, args.steps, args.warmup, local_rank, rank, netvlad=use_nv, **pk)
+    if rank == 0 and not (primary.get("stream_placement") or {}).get("classes_told_apart"):
+        # a pipe whose stream placement could not be MEASURED (device not quiet when it was created: two ranks on one GPU, another handle at work) used creation
+        # order, which may put both of a lane's streams on one hardware pipe -- say so next to the number (`config.stream_placement.classes_told_apart` = 0 in the line)
+        print("bench.py: WARNING: the timed pipe's stream placement was not measured (classes_told_apart = 0): streams in creation order", file=sys.stderr, flush=True)
     if world == 1 and not dist_path and lanes > 1 and not args.no_solo:
         # the step with ONE submit in flight: every kernel has the device to itself -- the dominant kernel's own roofline measurement (also the batch curve's F x 1 point)
         solo = run_pipe(torch, api, weights, nv_weights, args.precision, args.frames, 1, max(5, args.steps // 2) if args.single_mode else max(12, min(400, int(700 / args.frames))), 4,
