@@ -110,30 +110,85 @@ __global__ __launch_bounds__(256) void nv_pw_mfma_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = bv;
   }
-  for (int c0 = 0; c0 < Cin; c0 += PW_CK) {
-    const int cc = (Cin - c0) < PW_CK ? (Cin - c0) : PW_CK;
-    const int cc4 = cc / 4;
+  // Both operand streams run one step ahead of the MFMAs: the next chunk of the input span is fetched into registers while this chunk is multiplied (a
+  // launch of a dozen workgroups -- one image at 15 x 20 -- has nothing else to hide that latency behind), and the weight fragments of step c8 + 1 are
+  // in flight during step c8.  Summation order per output is unchanged: chunk by chunk, c8 by c8.
+  f32x4 pre[8];
+  auto fetch = [&](int c0) {
+    const int cc4 = ((Cin - c0) < PW_CK ? (Cin - c0) : PW_CK) / 4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + k * 256;
+      const int pp = cc4 == 16 ? (i >> 4) : i / cc4, q = cc4 == 16 ? (i & 15) : i % cc4;
+      pre[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < 128 * cc4 && pp < npix) pre[k] = *reinterpret_cast<const f32x4*>(in + (size_t)(p0 + pp) * Cin + c0 + q * 4);
+    }
+  };
+  auto stage = [&](int cc4) {
     __syncthreads();
-    for (int i = tid; i < 128 * cc4; i += 256) {
-      const int pp = i / cc4, q = i % cc4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pp < npix) v = *reinterpret_cast<const f32x4*>(in + (size_t)(p0 + pp) * Cin + c0 + q * 4);
-      float* d = xs + pp * (PW_CK + 1) + q * 4;
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + k * 256;
+      if (i < 128 * cc4) {
+        const int pp = cc4 == 16 ? (i >> 4) : i / cc4, q = cc4 == 16 ? (i & 15) : i % cc4;
+        float* d = xs + pp * (PW_CK + 1) + q * 4;
+        d[0] = pre[k][0]; d[1] = pre[k][1]; d[2] = pre[k][2]; d[3] = pre[k][3];
+      }
     }
     __syncthreads();
-    const float* ap = xs + (wave * 32 + (lane & 31)) * (PW_CK + 1) + (lane >> 5);
-    for (int c8 = 0; c8 < cc / 8; ++c8) {
-      f32x4 bw[NT];
+  };
+  const float* ap = xs + (wave * 32 + (lane & 31)) * (PW_CK + 1) + (lane >> 5);
+  fetch(0);
+  if constexpr (NT == 1) {
+    // one channel tile per workgroup is what the small launches get (launch_nv_pw): the weight fragments of the WHOLE next chunk are in flight as well
+    f32x4 wc[8], wn[8];
+    auto wfetch = [&](int c0, f32x4 (&w)[8]) {
+      const int n8 = ((Cin - c0) < PW_CK ? (Cin - c0) : PW_CK) / 8;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bw[n] = wpack[((size_t)(nt0 + n) * c8n + (c0 / 8 + c8)) * 64 + lane];
-      float av[4];
+      for (int c8 = 0; c8 < 8; ++c8)
+        if (c8 < n8) w[c8] = wpack[((size_t)nt0 * c8n + (c0 / 8 + c8)) * 64 + lane];
+    };
+    wfetch(0, wc);
+    for (int c0 = 0; c0 < Cin; c0 += PW_CK) {
+      const int cc = (Cin - c0) < PW_CK ? (Cin - c0) : PW_CK;
+      stage(cc / 4);
+      if (c0 + PW_CK < Cin) { fetch(c0 + PW_CK); wfetch(c0 + PW_CK, wn); }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) av[q] = ap[c8 * 8 + 2 * q];
+      for (int c8 = 0; c8 < 8; ++c8)
+        if (c8 < cc / 8) {
+          float av[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+          for (int q = 0; q < 4; ++q) av[q] = ap[c8 * 8 + 2 * q];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bw[n][q], acc[n], 0, 0, 0);
+          for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], wc[c8][q], acc[0], 0, 0, 0);
+        }
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) wc[c8] = wn[c8];
+    }
+  } else {
+    for (int c0 = 0; c0 < Cin; c0 += PW_CK) {
+      const int cc = (Cin - c0) < PW_CK ? (Cin - c0) : PW_CK;
+      const int n8 = cc / 8;
+      f32x4 bw[NT], bwn[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bw[n] = wpack[((size_t)(nt0 + n) * c8n + c0 / 8) * 64 + lane];
+      stage(cc / 4);
+      if (c0 + PW_CK < Cin) fetch(c0 + PW_CK);
+      for (int c8 = 0; c8 < n8; ++c8) {
+        if (c8 + 1 < n8) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bwn[n] = wpack[((size_t)(nt0 + n) * c8n + (c0 / 8 + c8 + 1)) * 64 + lane];
+        }
+        float av[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = ap[c8 * 8 + 2 * q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bw[n][q], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bw[n] = bwn[n];
+      }
     }
   }
   // C layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel of this wave's 32)
