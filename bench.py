@@ -451,7 +451,10 @@ def main():
     quad = None
     if rank == 0 and full_run:
         qa = argparse.Namespace(**vars(args)); qa.steps = 8; qa.warmup = 2
-        quad = run_quadcam(qa, torch, api, weights, dev, local_rank, world)
+        # best of two, as the width legs: eight steps of ~9 ms beside the CPU-baseline children have shown one outlier of -27 % (640 against 873-894 quad frames/s)
+        runs = [run_quadcam(qa, torch, api, weights, dev, local_rank, world) for _ in range(2)]
+        quad = max(runs, key=lambda q: q.get("value") or 0.0)
+        quad["runs"] = [q.get("value") for q in runs]
 
     if rank == 0 and full_run and not args.no_exchange_loopback:
         # LAST leg of the run: it creates (and destroys) a one-rank RCCL communicator, whose proxy threads and streams must not sit beside any other measurement

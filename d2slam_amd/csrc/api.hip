@@ -916,11 +916,23 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     nv_groups(tiles1, a.Chid / 16, pj.gmax, &groups, &cpg, h->nv_blocks_target,
               st.pblock ? nv_pblock_slots(a.Cin, a.Cout, h->ncu_dev, 1) * 85 / 100 : 0, next_single || sum_for_plain_consumer, h->nv_group_rule);
     a.cpg = cpg; a.out = pj.out; a.out_slab_stride = (long)n * a.Ho * a.Wo * a.Cout;
-    pj.slabs = groups; pj.slab_stride = a.out_slab_stride;
+    // Six or more groups per image (30 x 40 and 15 x 20 layers: what ONE image needs to reach 60-135 workgroups) are 2-3 rounds of short workgroups for a batch, each
+    // staging its input patch again and writing its own slab.  The summation order of such a layer is a two-level tree -- runs of `tree` groups, then the runs in order --
+    // and a batch lets one workgroup walk a whole run (NvBlockArgs::gmerge): same bits as one image's unmerged launch + tree-ordered slab sum, a third of the
+    // workgroups, patch loads and slabs.  `tree` depends on the layer alone, merging on the batch
+    int tree = 1, wgroups = groups;
+    const int half0 = nv_pblock_half_cout(a.Cout, 0);
+    if (st.pblock && !st.front && groups >= 6 && nv_pblock_can_merge(a.Cin, half0) &&
+        (!st.wp2 || nv_pblock_can_merge(a.Cin, a.Cout - half0))) {
+      tree = 3;
+      const long slots = nv_pblock_slots(a.Cin, a.Cout, h->ncu_dev, 1);
+      if (h->nv_merge && tiles * groups > slots && tiles * ((groups + tree - 1) / tree) * 2 >= (h->ncu_dev > 0 ? h->ncu_dev : 256)) { a.gmerge = tree; wgroups = (groups + tree - 1) / tree; }
+    }
+    pj.slabs = wgroups; pj.slab_stride = a.out_slab_stride;
     a.ncu = h->ncu; a.tpw = h->nv_front_tpw; a.nbuf = h->nv_nbuf;
-    if ((int)si == h->nv_stamp_step && h->nv_stamps && (tiles * groups <= 32768)) {
+    if ((int)si == h->nv_stamp_step && h->nv_stamps && (tiles * wgroups <= 32768)) {
       HIP_TRY(hipMemsetAsync(h->nv_stamps, 0, sizeof(unsigned long long) * 32 * 32768, s));
-      a.stamps = h->nv_stamps; h->nv_stamp_wgs = (int)(tiles * groups);
+      a.stamps = h->nv_stamps; h->nv_stamp_wgs = (int)(tiles * wgroups);
     }
     if (st.pblock && st.front) HIP_TRY(launch_nv_fpair(a, n, s));
     else if (st.pblock && st.wp2) {
@@ -935,7 +947,11 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     else if (st.xblock) HIP_TRY(launch_nv_xblock(a, n, groups, s));
     else HIP_TRY(launch_nv_block(a, st.expand, st.front ? 1 : 0, n, groups, s));
     // three or more partial slabs: sum them once instead of in every consumer workgroup (and in every residual read)
-    if ((h->nv_slabsum > 0 && groups >= h->nv_slabsum) || ((next_single || sum_for_plain_consumer) && groups > 1)) { HIP_TRY(launch_nv_slab_sum(pj.out, groups, pj.slab_stride, pj.slab_stride, s)); pj.slabs = 1; }
+    // (decided on `groups`, the layer's own count: a consumer sees one slab or several whatever the batch merged)
+    if ((h->nv_slabsum > 0 && groups >= h->nv_slabsum) || ((next_single || sum_for_plain_consumer) && groups > 1)) {
+      HIP_TRY(launch_nv_slab_sum(pj.out, wgroups, pj.slab_stride, pj.slab_stride, s, a.gmerge > 1 ? 1 : tree));
+      pj.slabs = 1;
+    }
     ch = a.Ho; cw = a.Wo;
   }
   const int np = ch * cw;
@@ -1019,6 +1035,7 @@ int d2fe_load_netvlad(d2fe_handle h, const d2fe_netvlad_weights* w) {
     { const int v = d2fe_dev_env("D2FE_NV_TAIL_BLOCKS", 0); if (v > 0) h->nv_tail_blocks = v; }
     h->nv_slabsum = d2fe_dev_env("D2FE_NV_SLABSUM", h->nv_slabsum);
     h->nv_group_rule = d2fe_dev_env("D2FE_NV_GROUP_RULE", 1) != 0;
+    h->nv_merge = d2fe_dev_env("D2FE_NV_MERGE", 1) != 0;
     h->nv_front_tpw = d2fe_dev_env("D2FE_NV_FRONT_TPW", 0); h->nv_nbuf = d2fe_dev_env("D2FE_NV_NBUF", 0);
     h->nv_stamp_step = d2fe_dev_env("D2FE_NV_STAMP_STEP", -1);
     if (h->nv_stamp_step >= 0 && !h->nv_stamps) HIP_TRY(hipMalloc(&h->nv_stamps, sizeof(unsigned long long) * 32 * 32768));
@@ -1285,7 +1302,7 @@ int clone_lane(d2fe_context* p, int max_batch, d2fe_context** out, hipStream_t s
     c->nv = p->nv;
     for (auto& l : c->nv) { l.out = nullptr; l.slabs = 1; l.slab_stride = 0; }
     c->nv_plan = p->nv_plan;
-    c->nv_feat_gmax = p->nv_feat_gmax; c->nv_blocks_target = p->nv_blocks_target; c->nv_tail_blocks = p->nv_tail_blocks; c->nv_slabsum = p->nv_slabsum; c->nv_group_rule = p->nv_group_rule;
+    c->nv_feat_gmax = p->nv_feat_gmax; c->nv_blocks_target = p->nv_blocks_target; c->nv_tail_blocks = p->nv_tail_blocks; c->nv_slabsum = p->nv_slabsum; c->nv_group_rule = p->nv_group_rule; c->nv_merge = p->nv_merge;
     c->nv_front_tpw = p->nv_front_tpw; c->nv_nbuf = p->nv_nbuf;
     c->nv_feat = p->nv_feat; c->nv_proj = p->nv_proj; c->nv_k = p->nv_k;
     c->nv_pre_w = p->nv_pre_w; c->nv_pre_b = p->nv_pre_b; c->nv_aw = p->nv_aw; c->nv_aw_pack = p->nv_aw_pack; c->nv_ab = p->nv_ab; c->nv_cen = p->nv_cen;

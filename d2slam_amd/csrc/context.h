@@ -126,6 +126,7 @@ struct d2fe_context {
   float *nv_pre_w = nullptr, *nv_pre_b = nullptr, *nv_aw = nullptr, *nv_aw_pack = nullptr, *nv_ab = nullptr, *nv_cen = nullptr;
   float *nv_feat_buf = nullptr, *nv_raw = nullptr, *nv_pca_out = nullptr, *nv_part = nullptr;
   bool nv_group_rule = true;       // nv_groups(): no split past two groups when the slab-sum launch costs more than the chunks it saves (D2FE_NV_GROUP_RULE=0, development library: off)
+  bool nv_merge = true;            // a batch lets one workgroup walk a run of hidden-channel groups (NvBlockArgs::gmerge; D2FE_NV_MERGE=0, development library: never) -- same bits either way
   float *nv_pca_comp = nullptr, *nv_pca_mean = nullptr; int nv_pca_m = 0;
   uint8_t* nv_s_img = nullptr; float* nv_s_out = nullptr;
   bool fuse1a = true;      // conv1a fused into conv1b's staging (D2FE_FUSE1A=0 keeps the stand-alone conv1a kernel)

@@ -131,6 +131,9 @@ struct NvBlockArgs {
   int th, tw;                      // nv_xblock_kernel: output tile (th x tw <= 128 pixels)
   unsigned inv_iw, inv_tw;         // ceil(2^20 / d) for d = patch width, tile width: n / d = (n * inv) >> 20 for n < 1024 (filled in by the launcher)
   int cpg;                         // chunks of 16 hidden channels per workgroup group
+  int gmerge;                      // nv_pblock_kernel: consecutive groups ONE workgroup walks (0 / 1: one).  The groups stay the unit of the fp32 summation order: a
+                                   // workgroup closes each group's partial sum and adds it to a running total, so slab j of the launch holds (s[j gm] + s[j gm + 1]) + ... --
+                                   // exactly what launch_nv_slab_sum(..., tree = gm) makes of the unmerged slabs (a batch merges, one image does not: same bits)
   const float* we;                    // expand weights + bias, one record per chunk (pack_nv_expand)
   const float* wp;                    // depthwise weights + bias + project weights, one record per chunk (pack_nv_dwproj)
   const float* bp;                    // project bias [Cout padded to the n-tiles]
@@ -173,7 +176,8 @@ hipError_t launch_nv_pblock(const NvBlockArgs& a, int n, int groups, hipStream_t
 bool nv_fpair_supported(int c0_cout, int c0_stride, int dw_stride, int cout);      // the first block (conv from u8 -> dw -> pw) in the same form
 hipError_t launch_nv_fpair(const NvBlockArgs& a, int n, hipStream_t s);
 long nv_pblock_slots(int cin, int cout, int ncu, int nbuf);     // resident workgroups of that block shape on the whole device
-hipError_t launch_nv_slab_sum(float* t, int slabs, long slab_stride, long count, hipStream_t s);   // slab 0 += slabs 1..
+hipError_t launch_nv_slab_sum(float* t, int slabs, long slab_stride, long count, hipStream_t s, int tree = 1);   // slab 0 = sum of the slabs, in slab order; tree > 1: runs of `tree` slabs are summed first
+bool nv_pblock_can_merge(int cin, int cv);   // the block shape exists with a running total (NvBlockArgs::gmerge > 1)
 void pack_nv_conv0(const float* w /*[cout][9]*/, const float* b, int cout, float* dst /*[384]*/);
 
 // ---- SURVEY 8(f) next rows (next.hip) ------------------------------------------------------------------------------------

@@ -882,19 +882,30 @@ hipError_t launch_nv_block(const NvBlockArgs& a, bool expand, int mode, int n, i
 // A block that split its hidden channels over g groups leaves g partial slabs; every consumer workgroup group would re-read all of them
 // (measured: the tail kernel's prologue alone moved 215 MB of L2 traffic for 21 MB of input at g = 5 producers x 10 consumer groups).
 // For g >= 3 the slabs are summed once, in place into slab 0, in slab order (deterministic), by this kernel.
-__global__ __launch_bounds__(256) void nv_slab_sum_kernel(float* __restrict__ t, int slabs, long slab_stride, long n4) {
+// `tree` > 1: runs of `tree` consecutive slabs are summed first, then the runs in order -- the order in which a launch of merged groups (NvBlockArgs::gmerge = tree) adds
+// the same partial sums, so that a batch (merged) and one image (not merged) give the same bits.
+__global__ __launch_bounds__(256) void nv_slab_sum_kernel(float* __restrict__ t, int slabs, long slab_stride, long n4, int tree) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   f32x4* p = reinterpret_cast<f32x4*>(t) + i;
   f32x4 v = *p;
-  for (int sl = 1; sl < slabs; ++sl) v += *reinterpret_cast<const f32x4*>(t + (size_t)sl * slab_stride + i * 4);
+  if (tree <= 1) {
+    for (int sl = 1; sl < slabs; ++sl) v += *reinterpret_cast<const f32x4*>(t + (size_t)sl * slab_stride + i * 4);
+  } else {
+    for (int s0 = 0; s0 < slabs; s0 += tree) {
+      const int s1 = s0 + tree < slabs ? s0 + tree : slabs;
+      f32x4 r = *reinterpret_cast<const f32x4*>(t + (size_t)s0 * slab_stride + i * 4);
+      for (int sl = s0 + 1; sl < s1; ++sl) r += *reinterpret_cast<const f32x4*>(t + (size_t)sl * slab_stride + i * 4);
+      v = s0 == 0 ? r : v + r;
+    }
+  }
   *p = v;
 }
-hipError_t launch_nv_slab_sum(float* t, int slabs, long slab_stride, long count, hipStream_t s) {
+hipError_t launch_nv_slab_sum(float* t, int slabs, long slab_stride, long count, hipStream_t s, int tree) {
   if (slabs < 2) return hipSuccess;
   if ((count & 3) || (slab_stride & 3)) return hipErrorInvalidValue;
   const long n4 = count >> 2;
-  hipLaunchKernelGGL(nv_slab_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, t, slabs, slab_stride, n4);
+  hipLaunchKernelGGL(nv_slab_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, t, slabs, slab_stride, n4, tree);
   return hipGetLastError();
 }
 

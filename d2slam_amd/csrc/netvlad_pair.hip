@@ -44,7 +44,7 @@ __host__ __device__ constexpr int nvp_row(int c) { return c * NVP_EROW + 4 * (c 
 
 // waves per SIMD the register allocation must leave room for (unified VGPR + AGPR file, 512 per lane): what the launches of this network need to be
 // resident in ONE round -- 640 workgroups of <2, 8> on 256 CUs need 3 per CU, 1280 of <1, 4> need 5; left alone the compiler settles for 2 and 4
-__host__ __device__ constexpr int nvp_min_waves(int nt, int nk) { return nt == 1 ? (nk <= 4 ? 5 : nk <= 8 ? 4 : 3) : nt == 2 ? (nk <= 8 ? 3 : 2) : (nt <= 5 && nk <= 12) ? 3 : 2; }
+__host__ __device__ constexpr int nvp_min_waves(int nt, int nk, bool merge = false) { return (merge && nt * 8 + nk * 3 > 72) ? 2 : nt == 1 ? (nk <= 4 ? 5 : nk <= 8 ? 4 : 3) : nt == 2 ? (nk <= 8 ? 3 : 2) : (nt <= 5 && nk <= 12) ? 3 : 2; }
 // Cin >= 72 (18 / 30 k-steps: 54 / 90 input registers per lane): no second register set for a producer's partial slabs -- the input must be ONE slab (run_netvlad sums
 // first; these layers' producers split into >= 3 groups and are summed anyway).  That, and the residual read in the epilogue from Cin 48 on, is what lets the 48-wide
 // blocks run three workgroups per CU instead of two (166 registers, no spills; the 72-wide ones spill at 168 and measured slower: two; tools/kernel_resources.py)
@@ -76,8 +76,13 @@ __device__ __forceinline__ void nvp_project(const float* wks, int lane, float d0
   }
 }
 
-template <int NT, int NK, int NBUF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_waves(NT, NK)))) void nv_pblock_kernel(NvBlockArgs a) {
+// MERGE: a workgroup walks a.gmerge consecutive hidden-channel groups (see NvBlockArgs::gmerge): at every group boundary the project accumulators are closed into a
+// running total `tot` and cleared.  `tot` starts as the residual (group 0's workgroup; zero elsewhere), so the first boundary makes (acc + bias) + residual -- the
+// value group 0 stores in the unmerged launch -- and every further boundary adds one more group's partial sum, in group order.
+// Not for Cin = 120 (240-250 registers without a running total); a variant that kept the total in the workgroup's own output slab (read back, add, store at every
+// boundary) measured 101 us against 80 for the 15 x 20 layers at 32 images: those launches are bound by their chunks, not by the workgroups' prologues.
+template <int NT, int NK, int NBUF, int MERGE = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_waves(NT, NK, MERGE == 1)))) void nv_pblock_kernel(NvBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WE_N = nvp_we_rec(NK), WD_N = nvp_wd_rec(NT), WER = WE_N / 256, WDR = WD_N / 256;
   constexpr int NK4 = NK / 4, NK2 = (NK % 4) / 2, KSF = nvp_ks_floats(NT);
@@ -95,7 +100,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
   const int oy0 = ty * th, ox0 = ((int)blockIdx.x - ty * tiles_x) * tw;
   const int iy0 = oy0 - a.pt, ix0 = ox0 - a.pl;
   const int nchunk = a.Chid >> 4;
-  const int ch0 = blockIdx.z * a.cpg, ch1 = min(nchunk, ch0 + a.cpg);
+  const int wspan = MERGE ? a.gmerge * a.cpg : a.cpg;          // chunks of this workgroup
+  const int ch0 = blockIdx.z * wspan, ch1 = min(nchunk, ch0 + wspan);
   const bool lead = blockIdx.z == 0;
   unsigned long long* stamp = a.stamps ? a.stamps + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 : nullptr;
   int stamp_i = 0;
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
 
   // ---- residual (hidden-channel group 0 only): C layout of the project accumulators, row = pair 16 wave + 4 lq + r, pixel 2 px + m2 ----------
   const float* rp = (a.res && lead) ? a.res + (size_t)n * a.Ho * a.Wo * Cout : nullptr;
-  constexpr bool RES_EARLY = NT <= 4 && NK < 12;
+  constexpr bool RES_EARLY = !MERGE && NT <= 4 && NK < 12;
   float resv[2][4][RES_EARLY ? NT : 1];
   int obase[4];                 // element offset of (pixel of pair r, m2 = 0, channel lp), or -1
   bool ok2[4];                  // the pair's odd pixel is inside the output too
@@ -122,6 +128,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
   float bvv[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) bvv[t] = a.bp[t * 16 + lp];           // padded to the n-tiles by the host
+  f32x4 tot[2][MERGE == 1 ? NT : 1];
+  if constexpr (MERGE == 1) {                 // the residual's slabs are summed first, in slab order (as the unmerged epilogue does)
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool okr = rp && obase[r] >= 0 && (m2 == 0 || ok2[r]) && t * 16 + lp < Cv;
+          tot[m2][t][r] = okr ? rp[(unsigned)(obase[r] + m2 * Cout + t * 16)] : 0.f;
+        }
+    for (int sl = 1; sl < (rp ? a.res_slabs : 0); ++sl)
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool okr = obase[r] >= 0 && (m2 == 0 || ok2[r]) && t * 16 + lp < Cv;
+            tot[m2][t][r] += okr ? (rp + (size_t)sl * a.res_slab_stride)[(unsigned)(obase[r] + m2 * Cout + t * 16)] : 0.f;
+          }
+  }
   float r1[2][4][RES_EARLY ? NT : 1];
   if (RES_EARLY && rp) {
 #pragma unroll
@@ -265,6 +293,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float lo_e = nvp_lo(a.act_e), hi_e = nvp_hi(a.act_e), lo_d = nvp_lo(a.act_d), hi_d = nvp_hi(a.act_d);
+  int gleft = a.cpg;                     // MERGE: chunks left in the current group
+  bool gfirst = true;
 
   for (int ch = ch0; ch < ch1; ++ch) {
     const int wb_i = (ch - ch0) & 1;
@@ -328,6 +358,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
       d[0] = nvp_clamp(d[0], lo_d, hi_d); d[1] = nvp_clamp(d[1], lo_d, hi_d);
       nvp_project<NT>(wd + 256 + ks * KSF, lane, d[0], d[1], acc);
     }
+    if constexpr (MERGE == 1) {
+      if (--gleft == 0 || ch + 1 == ch1) {               // the group's partial sum is complete (uniform branch)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float bv = (gfirst && lead) ? bvv[t] : 0.f;
+#pragma unroll
+          for (int m2 = 0; m2 < 2; ++m2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tot[m2][t][r] = (acc[m2][t][r] + bv) + tot[m2][t][r];
+            acc[m2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        gleft = a.cpg; gfirst = false;
+      }
+    }
     STAMP();
     if (ch + 1 < ch1) store_wd(wb_i ^ 1);              // everybody passed this chunk's barrier, so chunk ch - 1 is done with WD[wb_i ^ 1]
     if (ch + 2 < ch1) fetch_wd(ch + 2);
@@ -347,9 +392,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvp_min_wav
       for (int r = 0; r < 4; ++r) {
         if (obase[r] < 0 || (m2 == 1 && !ok2[r])) continue;
         const int o = obase[r] + m2 * Cout + t * 16;
+        if constexpr (MERGE == 1) { op[o] = nvp_clamp(tot[m2][t][r], lo_p, hi_p); continue; }
         float v = acc[m2][t][r] + bv;
         if constexpr (RES_EARLY) { if (rp) v += resv[m2][r][t]; }
-        else if (rp) { for (int sl = 0; sl < a.res_slabs; ++sl) v += rp[(size_t)sl * a.res_slab_stride + o]; }
+        else if (rp) { float rs = rp[o]; for (int sl = 1; sl < a.res_slabs; ++sl) rs += rp[(size_t)sl * a.res_slab_stride + o]; v += rs; }
         op[o] = nvp_clamp(v, lo_p, hi_p);
       }
   }
@@ -639,10 +685,10 @@ void pack_nv_dwproj_pair(const float* wd /*[chid][9]*/, const float* bd, const f
   }
 }
 
-template <int NT, int NK, int NBUF>
-static hipError_t launch_pblock_b(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
+template <int NT, int NK, int NBUF, int MERGE = 0>
+static hipError_t launch_pblock_b(const NvBlockArgs& a, int n, int groups, hipStream_t s) {      // groups: grid.z (workgroup groups of this launch)
   const size_t lds = sizeof(float) * (NBUF * (size_t)NVP_EBUF + 2 * nvp_we_rec(NK) + 2 * nvp_wd_rec(NT));
-  auto k = nv_pblock_kernel<NT, NK, NBUF>;
+  auto k = nv_pblock_kernel<NT, NK, NBUF, MERGE>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const long tiles = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th);
@@ -659,18 +705,27 @@ long nv_pblock_slots(int cin, int cout, int ncu, int nbuf) {
 // E double-buffered (one barrier per chunk) when every workgroup of the launch is resident at once anyway; one buffer (two barriers per chunk,
 // 16 KB less LDS: 5-6 workgroups per CU instead of 3-4) when the launch would otherwise run in rounds.  The dispatch is never perfectly even:
 // "fits" means 85 % of the slots.  D2FE_NV_NBUF=1|2 (NvBlockArgs::nbuf) forces.
-template <int NT, int NK>
+template <int NT, int NK, int MERGE = 0>
 static hipError_t launch_pblock_t(const NvBlockArgs& a, int n, int groups, hipStream_t s) {
   const int force = a.nbuf;            // D2FE_NV_NBUF, read when the network was loaded
   const long wgs = (long)((a.Wo + a.tw - 1) / a.tw) * ((a.Ho + a.th - 1) / a.th) * n * groups;
   const bool one = force ? force == 1 : wgs * 100 > nv_pblock_slots(a.Cin, a.Cout, a.ncu, 2) * 85;
-  return one ? launch_pblock_b<NT, NK, 1>(a, n, groups, s) : launch_pblock_b<NT, NK, 2>(a, n, groups, s);
+  return one ? launch_pblock_b<NT, NK, 1, MERGE>(a, n, groups, s) : launch_pblock_b<NT, NK, 2, MERGE>(a, n, groups, s);
 }
 // the (k-steps of the expand GEMM = Cin / 4, n-tiles of the project GEMM) pairs that exist as kernels: MobileNetV2 x 0.35 (rounds 3-5) and x 0.75 (round 6:
 // Cin 48 -> 48 / 72, 72 -> 72, 120 -> 120 and the two halves 128 + 112 of 120 -> 240) with their neighbours
 #define NVP_SHAPES(X) \
   X(2, 1) X(2, 2) X(2, 4) X(2, 8) X(4, 1) X(4, 2) X(4, 4) X(4, 8) X(6, 1) X(6, 2) X(6, 3) X(6, 4) X(6, 8) X(8, 1) X(8, 2) X(8, 4) X(8, 8) \
   X(12, 3) X(12, 4) X(12, 5) X(14, 1) X(14, 2) X(14, 4) X(14, 7) X(14, 8) X(18, 5) X(18, 8) X(30, 7) X(30, 8)
+// the shapes whose layers split into six or more groups per image (30 x 40 and 15 x 20 at alpha = 0.75): also as kernels that walk several groups per workgroup
+#define NVP_MERGE_SHAPES(X) X(12, 3, 1) X(18, 5, 1)
+bool nv_pblock_can_merge(int cin, int cv) {
+  const int nk = cin / 4, nt = nv_pblock_ntiles(cv);
+#define X(K, T, M) if (nk == K && nt == T) return true;
+  NVP_MERGE_SHAPES(X)
+#undef X
+  return false;
+}
 static bool nvp_shape_exists(int nk, int nt) {
 #define X(K, T) if (nk == K && nt == T) return true;
   NVP_SHAPES(X)
@@ -726,6 +781,13 @@ hipError_t launch_nv_pblock(const NvBlockArgs& a_in, int n, int groups, hipStrea
   if (a.co0 < 0 || a.co0 + a.Cv > a.Cout || a.Cv > 128) return hipErrorInvalidValue;
   const int nk = a.Cin / 4, nt = nv_pblock_ntiles(a.Cv);
   if (a.in_slabs > 1 && !nvp_multi_in(nk)) return hipErrorInvalidValue;
+  if (a.gmerge > 1) {                    // `groups` stays the number of groups of the summation order; the launch has ceil(groups / gmerge) workgroup groups
+    const int wg = (groups + a.gmerge - 1) / a.gmerge;
+#define X(K, T, M) if (nk == K && nt == T) return launch_pblock_t<T, K, M>(a, n, wg, s);
+    NVP_MERGE_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+  }
 #define X(K, T) if (nk == K && nt == T) return launch_pblock_t<T, K>(a, n, groups, s);
   NVP_SHAPES(X)
 #undef X

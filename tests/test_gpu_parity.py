@@ -1006,18 +1006,19 @@ def test_variant_a_batch_and_pca(api, orc, sp_weights):
     fe.close()
 
 
-def test_netvlad_does_not_depend_on_the_batch(api):
+@pytest.mark.parametrize("H,W,n", [(240, 320, 5), (480, 640, 20)])
+def test_netvlad_does_not_depend_on_the_batch(api, H, W, n):
     """The split of a block's hidden channels over workgroup groups fixes the fp32 summation order; it is decided per image, so an image's
-    descriptor is the same bits alone, in a batch of 5 and at any position of it (what lets the frames-in-flight pipe batch frames freely)."""
+    descriptor is the same bits alone, in a batch and at any position of it (what lets the frames-in-flight pipe batch frames freely).
+    480 x 640, 20 images: the 30 x 40 layers of the batch run with merged groups (NvBlockArgs::gmerge: one workgroup walks a run of three groups), one image's
+    launch does not -- the tree-ordered slab sum makes the same bits of it."""
     from d2slam_amd import netvlad as nvm
     from d2slam_amd.synth import synth_image
-    H, W = 240, 320
-    fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=5))
+    fe = api.FrontEnd(api.SuperPointConfig(input_width=W, input_height=H, max_batch=n))
     fe.load_netvlad(nvm.synthetic_netvlad_weights())
-    imgs = np.stack([synth_image(H, W, 40 + i) for i in range(5)])
-    g5 = fe.netvlad(imgs)
-    for i in (0, 2, 4):
-        assert np.array_equal(fe.netvlad(imgs[i:i + 1])[0], g5[i])
-    assert np.array_equal(fe.netvlad(imgs[1:4]), g5[1:4])
+    imgs = np.stack([synth_image(H, W, 40 + i) for i in range(n)])
+    gn = fe.netvlad(imgs)
+    for i in (0, 2, n - 1):
+        assert np.array_equal(fe.netvlad(imgs[i:i + 1])[0], gn[i])
+    assert np.array_equal(fe.netvlad(imgs[1:4]), gn[1:4])
     fe.close()
-

@@ -1,5 +1,5 @@
 """NetVLAD (A9) timing on the GPU: fused-block plan vs one launch per layer, HIP-event timed on the launch stream.
-usage: python tools/bench_netvlad.py [n_images ...]   (default 1 4 32)"""
+usage: python tools/bench_netvlad.py [n_images ...] [--mult=0.75] [--hw=480x640] [--fused-only]   (default 1 4 32)"""
 import os
 import sys
 import time
@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from d2slam_amd import api, netvlad as nvm
 from d2slam_amd.synth import synth_image
-H, W = 480, 640
+H, W = [int(v) for v in next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--hw=")), "480x640").split("x")]
 ns = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 4, 32]
 MULT = float(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--mult=")), os.environ.get("NV_MULT", "0.75")))
 GF = nvm.arch_flops(MULT, H, W)
