@@ -589,7 +589,7 @@ def main():
         if latency:
             out["latency"] = latency
         if quad:
-            out["quadcam"] = {k: quad[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "avg_keypoints_per_image", "avg_matches_per_pair", "roofline")}
+            out["quadcam"] = {k: quad[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "avg_keypoints_per_image", "avg_matches_per_pair", "roofline", "runs")}
         b = primary["breakdown"] or (device_resident or {}).get("breakdown")
         if b:
             out["stage_ms"] = b
