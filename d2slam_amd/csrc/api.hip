@@ -948,7 +948,8 @@ int run_netvlad(d2fe_context* h, const uint8_t* d_gray, int n, int W, int H, int
     else HIP_TRY(launch_nv_block(a, st.expand, st.front ? 1 : 0, n, groups, s));
     // three or more partial slabs: sum them once instead of in every consumer workgroup (and in every residual read)
     // (decided on `groups`, the layer's own count: a consumer sees one slab or several whatever the batch merged)
-    if ((h->nv_slabsum > 0 && groups >= h->nv_slabsum) || ((next_single || sum_for_plain_consumer) && groups > 1)) {
+    // (a tree-ordered layer is always summed here: a consumer adding the slabs itself would do so in slab order, i.e. differently for merged and unmerged launches)
+    if (tree > 1 || (h->nv_slabsum > 0 && groups >= h->nv_slabsum) || ((next_single || sum_for_plain_consumer) && groups > 1)) {
       HIP_TRY(launch_nv_slab_sum(pj.out, wgroups, pj.slab_stride, pj.slab_stride, s, a.gmerge > 1 ? 1 : tree));
       pj.slabs = 1;
     }
