@@ -44,7 +44,7 @@ __host__ __device__ constexpr int nvp_row(int c) { return c * NVP_EROW + 4 * (c 
 
 // waves per SIMD the register allocation must leave room for (unified VGPR + AGPR file, 512 per lane): what the launches of this network need to be
 // resident in ONE round -- 640 workgroups of <2, 8> on 256 CUs need 3 per CU, 1280 of <1, 4> need 5; left alone the compiler settles for 2 and 4
-__host__ __device__ constexpr int nvp_min_waves(int nt, int nk, bool merge = false) { return (merge && nt * 8 + nk * 3 > 72) ? 2 : nt == 1 ? (nk <= 4 ? 5 : nk <= 8 ? 4 : 3) : nt == 2 ? (nk <= 8 ? 3 : 2) : (nt <= 5 && nk <= 12) ? 3 : 2; }
+__host__ __device__ constexpr int nvp_min_waves(int nt, int nk, bool merge = false) { return (merge && nt * 8 + nk * 3 > 72) ? 2 : nt == 1 ? (nk <= 4 ? 5 : nk <= 8 ? 4 : 3) : nt == 2 ? (nk == 6 ? 4 : nk <= 8 ? 3 : 2) : (nt <= 5 && nk <= 12) ? 3 : 2; }
 // Cin >= 72 (18 / 30 k-steps: 54 / 90 input registers per lane): no second register set for a producer's partial slabs -- the input must be ONE slab (run_netvlad sums
 // first; these layers' producers split into >= 3 groups and are summed anyway).  That, and the residual read in the epilogue from Cin 48 on, is what lets the 48-wide
 // blocks run three workgroups per CU instead of two (166 registers, no spills; the 72-wide ones spill at 168 and measured slower: two; tools/kernel_resources.py)
