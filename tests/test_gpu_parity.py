@@ -1006,7 +1006,7 @@ def test_variant_a_batch_and_pca(api, orc, sp_weights):
     fe.close()
 
 
-@pytest.mark.parametrize("H,W,n", [(240, 320, 5), (480, 640, 20)])
+@pytest.mark.parametrize("H,W,n", [(240, 320, 5), (480, 640, 20), (400, 800, 33), (480, 752, 13)])
 def test_netvlad_does_not_depend_on_the_batch(api, H, W, n):
     """The split of a block's hidden channels over workgroup groups fixes the fp32 summation order; it is decided per image, so an image's
     descriptor is the same bits alone, in a batch and at any position of it (what lets the frames-in-flight pipe batch frames freely).
