@@ -363,6 +363,7 @@ static hipError_t launch_block_nt(const NvBlockArgs& a, int n, int groups, hipSt
   return hipErrorInvalidValue;
 }
 
+__host__ __device__ constexpr int nvx_min_waves(int s, int nt, int nj) { return (s == 2 && nt == 2 && nj == 2) ? 3 : 1; }
 // ---- expand -> depthwise -> project with the block INPUT in registers ------------------------------------------------------------------
 // What limits the LDS-resident form above on the low-resolution layers is occupancy: the input patch (Cin x 208 floats) plus two
 // E buffers leave room for two workgroups per CU, i.e. ~1.3 waves per SIMD on average, and every LDS round trip and barrier is
@@ -374,7 +375,7 @@ static hipError_t launch_block_nt(const NvBlockArgs& a, int n, int groups, hipSt
 // Tile shape is a run-time choice (th x tw <= 128 output pixels, row-major flat index -> m-tiles), so that 15x20 or 30x40 maps are
 // cut into 5x20 / 6x20 tiles without padding instead of 47 % / 78 % useful 8x16 tiles; the lane -> pixel maps are computed once.
 template <int S, int NT, int NJ>
-__global__ __launch_bounds__(256) void nv_xblock_kernel(NvBlockArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(nvx_min_waves(S, NT, NJ)))) void nv_xblock_kernel(NvBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int MT_IN = nvb_mt_in(S, 0), EP = nvb_ep(S, 0), NBUF = S == 1 ? 2 : 1;
   constexpr int MPW = MT_IN / 4, GI = 3;
